@@ -1,0 +1,549 @@
+"""
+ctypes binding of libfawkes_hip.so + the host-side mirror of the reference's prover interface.
+
+Reference interface mirrored here (file:line under /root/reference/fawkes-crypto/src/backend/bellman_groth16/):
+  Parameters            mod.rs:139-175     (bellman Parameters + circuit replay data)
+  Proof / Borsh         prover.rs:13-60
+  prove                 prover.rs:63-90    (returns (public inputs without ONE, proof))
+  G1Point / G2Point     group.rs:13-122    ((0,0) <=> infinity)
+  OsRng                 osrng.rs:12-18     (r, s source; `prove_with_rs` bypasses it)
+No oracle code is imported here, and nothing falls back to the CPU.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+FK_PROOF_BYTES = 256
+FK_MSM_RESULT_BYTES = 4 * 64 + 128
+FR_MODULUS = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+FQ_MODULUS = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+
+# every symbol include/fawkes_hip.h declares (tests check the .so exports all of them)
+EXPORTED_SYMBOLS = [
+    'fk_init', 'fk_free', 'fk_last_error', 'fk_set_window_bits',
+    'fk_dev_alloc', 'fk_dev_free', 'fk_upload', 'fk_download', 'fk_sync',
+    'fk_key_load', 'fk_key_synthetic', 'fk_key_host_vk', 'fk_key_free',
+    'fk_prove', 'fk_prove_dev', 'fk_prove_msms', 'fk_prove_msms_dev', 'fk_prove_assemble',
+    'fk_fr_mul_batch', 'fk_ntt', 'fk_ntt_dev', 'fk_quotient_h', 'fk_quotient_h_dev',
+    'fk_msm_g1', 'fk_msm_g2', 'fk_msm_g1_dev', 'fk_msm_g2_dev',
+    'fk_gen_points_g1_dev', 'fk_gen_points_g2_dev', 'fk_gen_scalars_dev',
+    'fk_synthesize', 'fk_stats_reset', 'fk_stats_get', 'fk_shard_range',
+]
+
+_ERR = {1: 'FK_ERR_BAD_ARG', 2: 'FK_ERR_DOMAIN_TOO_LARGE (bellman: PolynomialDegreeTooLarge)',
+        3: 'FK_ERR_UNEXPECTED_IDENTITY (bellman: UnexpectedIdentity)', 4: 'FK_ERR_HIP', 5: 'FK_ERR_OOM',
+        6: 'FK_ERR_KEY_MISMATCH'}
+
+
+class FkError(RuntimeError):
+    def __init__(self, code, msg=''):
+        self.code = code
+        super().__init__('%s: %s' % (_ERR.get(code, 'error %d' % code), msg))
+
+
+def lib_path():
+    return os.path.join(_HERE, 'libfawkes_hip.so')
+
+
+def build_library(jobs=3):
+    """hipcc --offload-arch=gfx950 build of csrc/ (cross-compiles without a GPU)."""
+    subprocess.check_call(['make', '-C', os.path.join(_HERE, 'csrc'), '-j%d' % jobs, '-s'])
+
+
+_LIB = None
+
+
+class KeyDesc(C.Structure):
+    _fields_ = [('m', C.c_uint64), ('num_input', C.c_uint32), ('num_aux', C.c_uint32),
+                ('alpha_g1', C.c_void_p), ('beta_g1', C.c_void_p), ('delta_g1', C.c_void_p),
+                ('beta_g2', C.c_void_p), ('delta_g2', C.c_void_p),
+                ('h', C.c_void_p), ('n_h', C.c_uint64), ('l', C.c_void_p), ('n_l', C.c_uint64),
+                ('a', C.c_void_p), ('n_a', C.c_uint64),
+                ('b_g1', C.c_void_p), ('b_g2', C.c_void_p), ('n_b', C.c_uint64),
+                ('shard_index', C.c_uint32), ('shard_count', C.c_uint32)]
+
+
+class Timings(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ('upload_ms', 'ntt_ms', 'msm_h_ms', 'msm_l_ms', 'msm_a_ms', 'msm_b1_ms',
+                                          'msm_b2_ms', 'assemble_ms', 'total_ms')]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class R1csStruct(C.Structure):
+    _fields_ = [('num_input', C.c_uint32), ('num_aux', C.c_uint32), ('num_gates', C.c_uint64),
+                ('a_ptr', C.c_void_p), ('a_col', C.c_void_p), ('a_val', C.c_void_p),
+                ('b_ptr', C.c_void_p), ('b_col', C.c_void_p), ('b_val', C.c_void_p),
+                ('c_ptr', C.c_void_p), ('c_col', C.c_void_p), ('c_val', C.c_void_p)]
+
+
+def load_library():
+    """Loads libfawkes_hip.so; raises if it has not been built (no fallback)."""
+    global _LIB
+    if _LIB is None:
+        p = lib_path()
+        if not os.path.exists(p):
+            raise FileNotFoundError('%s missing: run __graft_entry__.build() (hipcc, gfx950)' % p)
+        lib = C.CDLL(p)
+        lib.fk_last_error.restype = C.c_char_p
+        lib.fk_last_error.argtypes = [C.c_void_p]
+        lib.fk_free.argtypes = [C.c_void_p]
+        lib.fk_free.restype = None
+        lib.fk_key_free.argtypes = [C.c_void_p, C.c_void_p]
+        lib.fk_key_free.restype = None
+        _LIB = lib
+    return _LIB
+
+
+def _vp(arr):
+    if arr is None:
+        return None
+    return C.c_void_p(arr.ctypes.data)
+
+
+def _fr(arr, rows=None):
+    a = np.ascontiguousarray(arr, dtype=np.uint64)
+    if a.ndim == 1:
+        a = a.reshape(-1, 4)
+    assert a.ndim == 2 and a.shape[1] == 4
+    if rows is not None:
+        assert a.shape[0] == rows, (a.shape, rows)
+    return a
+
+
+def _u8(arr, n=None):
+    a = np.ascontiguousarray(arr, dtype=np.uint8).reshape(-1)
+    if n is not None:
+        assert a.shape[0] == n, (a.shape, n)
+    return a
+
+
+def int_to_limbs(x):
+    return np.frombuffer(int(x).to_bytes(32, 'little'), dtype=np.uint64).copy()
+
+
+def limbs_to_int(l):
+    return int.from_bytes(np.ascontiguousarray(l, dtype=np.uint64).tobytes(), 'little')
+
+
+class R1cs:
+    """CSR constraint matrices (what `WitnessCS` streams out of the brotli gate blob, cs.rs:184-223):
+    variable index = i for Input(i), num_input + j for Aux(j); coefficients Montgomery Fr."""
+
+    def __init__(self, num_input, num_aux, a, b, c):
+        self.num_input, self.num_aux = int(num_input), int(num_aux)
+        self.mats = []
+        for (ptr, col, val) in (a, b, c):
+            self.mats.append((np.ascontiguousarray(ptr, np.uint64), np.ascontiguousarray(col, np.uint32),
+                              np.ascontiguousarray(val, np.uint64).reshape(-1, 4)))
+        self.num_gates = len(self.mats[0][0]) - 1
+        s = R1csStruct()
+        s.num_input, s.num_aux, s.num_gates = self.num_input, self.num_aux, self.num_gates
+        for nm, (ptr, col, val) in zip('abc', self.mats):
+            setattr(s, nm + '_ptr', ptr.ctypes.data)
+            setattr(s, nm + '_col', col.ctypes.data)
+            setattr(s, nm + '_val', val.ctypes.data)
+        self.struct = s
+
+    @property
+    def n_rows(self):
+        return self.num_gates + self.num_input
+
+
+class G1Point:
+    """group.rs:13 -- affine (x, y) as canonical ints; (0, 0) is the point at infinity (group.rs:55)."""
+
+    def __init__(self, x, y):
+        self.x, self.y = int(x), int(y)
+
+    def is_zero(self):
+        return self.x == 0 and self.y == 0
+
+    def to_bytes(self):  # Borsh (group.rs:16-21)
+        return self.x.to_bytes(32, 'little') + self.y.to_bytes(32, 'little')
+
+    @classmethod
+    def from_bytes(cls, b):
+        return cls(int.from_bytes(b[:32], 'little'), int.from_bytes(b[32:64], 'little'))
+
+    def __eq__(self, o):
+        return (self.x, self.y) == (o.x, o.y)
+
+
+class G2Point:
+    """group.rs:85 -- ((x_re, x_im), (y_re, y_im))."""
+
+    def __init__(self, x, y):
+        self.x, self.y = (int(x[0]), int(x[1])), (int(y[0]), int(y[1]))
+
+    def is_zero(self):
+        return self.x == (0, 0) and self.y == (0, 0)
+
+    def to_bytes(self):  # Borsh (group.rs:33-39)
+        return b''.join(v.to_bytes(32, 'little') for v in (self.x[0], self.x[1], self.y[0], self.y[1]))
+
+    @classmethod
+    def from_bytes(cls, b):
+        v = [int.from_bytes(b[i * 32:(i + 1) * 32], 'little') for i in range(4)]
+        return cls((v[0], v[1]), (v[2], v[3]))
+
+    def __eq__(self, o):
+        return (self.x, self.y) == (o.x, o.y)
+
+
+class Proof:
+    """prover.rs:13-17; Borsh = a || b || c = 256 bytes (prover.rs:39-45)."""
+
+    def __init__(self, a, b, c):
+        self.a, self.b, self.c = a, b, c
+
+    def to_bytes(self):
+        return self.a.to_bytes() + self.b.to_bytes() + self.c.to_bytes()
+
+    @classmethod
+    def from_bytes(cls, b):
+        b = bytes(b)
+        assert len(b) == FK_PROOF_BYTES
+        return cls(G1Point.from_bytes(b[:64]), G2Point.from_bytes(b[64:192]), G1Point.from_bytes(b[192:]))
+
+    def __eq__(self, o):
+        return self.to_bytes() == o.to_bytes()
+
+
+class Parameters:
+    """Mirror of `Parameters<E>` (mod.rs:139): the bellman proving key arrays (raw Montgomery-LE points,
+    the layout group.rs:57-66 exchanges) plus the constraint system that `WitnessCS` replays.
+    `key_arrays`: dict with m, num_input, num_aux, alpha_g1, beta_g1, beta_g2, delta_g1, delta_g2 (uint8
+    arrays) and h, l, a, b_g1 (n x 64 uint8), b_g2 (n x 128)."""
+
+    def __init__(self, key_arrays, r1cs=None):
+        k = key_arrays
+        self.m, self.num_input, self.num_aux = int(k['m']), int(k['num_input']), int(k['num_aux'])
+        self.vk = {n: _u8(k[n], w) for n, w in (('alpha_g1', 64), ('beta_g1', 64), ('delta_g1', 64),
+                                                 ('beta_g2', 128), ('delta_g2', 128))}
+        self.h = np.ascontiguousarray(k['h'], np.uint8).reshape(-1, 64)
+        self.l = np.ascontiguousarray(k['l'], np.uint8).reshape(-1, 64)
+        self.a = np.ascontiguousarray(k['a'], np.uint8).reshape(-1, 64)
+        self.b_g1 = np.ascontiguousarray(k['b_g1'], np.uint8).reshape(-1, 64)
+        self.b_g2 = np.ascontiguousarray(k['b_g2'], np.uint8).reshape(-1, 128)
+        self.r1cs = r1cs
+        self._handles = {}
+
+    def desc(self, shard_index=0, shard_count=1):
+        d = KeyDesc()
+        d.m, d.num_input, d.num_aux = self.m, self.num_input, self.num_aux
+        for n in self.vk:
+            setattr(d, n, self.vk[n].ctypes.data)
+        d.h, d.n_h = self.h.ctypes.data, self.h.shape[0]
+        d.l, d.n_l = self.l.ctypes.data, self.l.shape[0]
+        d.a, d.n_a = self.a.ctypes.data, self.a.shape[0]
+        d.b_g1, d.b_g2, d.n_b = self.b_g1.ctypes.data, self.b_g2.ctypes.data, self.b_g1.shape[0]
+        d.shard_index, d.shard_count = shard_index, shard_count
+        return d
+
+
+class DeviceKey:
+    def __init__(self, ctx, handle, shard_index=0, shard_count=1):
+        self.ctx, self.handle = ctx, handle
+        self.shard_index, self.shard_count = shard_index, shard_count
+
+    def free(self):
+        if self.handle:
+            self.ctx.lib.fk_key_free(self.ctx.handle, self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class HostVk:
+    """Host-only key (vk points only) for fk_prove_assemble -- needs no GPU."""
+
+    def __init__(self, params):
+        self.lib = load_library()
+        h = C.c_void_p()
+        v = params.vk
+        rc = self.lib.fk_key_host_vk(_vp(v['alpha_g1']), _vp(v['beta_g1']), _vp(v['delta_g1']), _vp(v['beta_g2']),
+                                     _vp(v['delta_g2']), C.byref(h))
+        if rc != 0:
+            raise FkError(rc, 'fk_key_host_vk')
+        self.handle = h
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self.lib.fk_key_free(None, self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class Context:
+    """One GPU (one process per GPU for multi-GPU runs).  Raises FkError if no GPU is usable."""
+
+    def __init__(self, device_id=0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.fk_init(C.c_int(device_id), C.byref(h))
+        if rc != 0:
+            raise FkError(rc, 'fk_init(device %d) failed -- no usable MI355X/HIP device; there is no CPU fallback' % device_id)
+        self.handle = h
+        self.device_id = device_id
+
+    def close(self):
+        if getattr(self, 'handle', None):
+            self.lib.fk_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != 0:
+            msg = self.lib.fk_last_error(self.handle)
+            raise FkError(rc, msg.decode() if msg else '')
+
+    # ---- device memory
+    def dev_alloc(self, nbytes):
+        p = C.c_void_p()
+        self._ck(self.lib.fk_dev_alloc(self.handle, C.c_size_t(nbytes), C.byref(p)))
+        return p.value
+
+    def dev_free(self, dptr):
+        self._ck(self.lib.fk_dev_free(self.handle, C.c_void_p(dptr)))
+
+    def upload(self, dptr, arr):
+        arr = np.ascontiguousarray(arr)
+        self._ck(self.lib.fk_upload(self.handle, C.c_void_p(dptr), _vp(arr), C.c_size_t(arr.nbytes)))
+
+    def download(self, dptr, nbytes, dtype=np.uint8):
+        out = np.zeros(nbytes // np.dtype(dtype).itemsize, dtype)
+        self._ck(self.lib.fk_download(self.handle, _vp(out), C.c_void_p(dptr), C.c_size_t(nbytes)))
+        return out
+
+    def sync(self):
+        self._ck(self.lib.fk_sync(self.handle))
+
+    def set_window_bits(self, c):
+        self._ck(self.lib.fk_set_window_bits(self.handle, C.c_uint(c)))
+
+    # ---- keys
+    def load_key(self, params, shard_index=0, shard_count=1):
+        d = params.desc(shard_index, shard_count)
+        h = C.c_void_p()
+        self._ck(self.lib.fk_key_load(self.handle, C.byref(d), C.byref(h)))
+        return DeviceKey(self, h, shard_index, shard_count)
+
+    def synthetic_key(self, m, num_input, num_aux, n_a, n_b, seed=1, shard_index=0, shard_count=1):
+        h = C.c_void_p()
+        self._ck(self.lib.fk_key_synthetic(self.handle, C.c_uint64(m), C.c_uint32(num_input), C.c_uint32(num_aux),
+                                           C.c_uint64(n_a), C.c_uint64(n_b), C.c_uint64(seed), C.c_uint32(shard_index),
+                                           C.c_uint32(shard_count), C.byref(h)))
+        return DeviceKey(self, h, shard_index, shard_count)
+
+    # ---- building blocks (host arrays)
+    def fr_mul_batch(self, a, b):
+        a, b = _fr(a), _fr(b, None)
+        out = np.zeros_like(a)
+        self._ck(self.lib.fk_fr_mul_batch(self.handle, _vp(a), _vp(b), _vp(out), C.c_size_t(a.shape[0])))
+        return out
+
+    def ntt(self, data, inverse=False, coset=False):
+        d = _fr(data).copy()
+        log_n = int(d.shape[0]).bit_length() - 1
+        if (1 << log_n) != d.shape[0]:
+            raise FkError(1, 'ntt size must be a power of two')
+        self._ck(self.lib.fk_ntt(self.handle, _vp(d), C.c_uint32(log_n), C.c_int(int(inverse)), C.c_int(int(coset))))
+        return d
+
+    def ntt_dev(self, dptr, log_n, inverse=False, coset=False):
+        self._ck(self.lib.fk_ntt_dev(self.handle, C.c_void_p(dptr), C.c_uint32(log_n), C.c_int(int(inverse)), C.c_int(int(coset))))
+
+    def quotient_h(self, a, b, c):
+        a, b, c = _fr(a), _fr(b), _fr(c)
+        n = a.shape[0]
+        m = 1
+        while m < n:
+            m *= 2
+        h = np.zeros((max(m - 1, 0), 4), np.uint64)
+        hbuf = h if m > 1 else np.zeros((1, 4), np.uint64)
+        self._ck(self.lib.fk_quotient_h(self.handle, _vp(a), _vp(b), _vp(c), C.c_uint64(n), _vp(hbuf)))
+        return h
+
+    def quotient_h_dev(self, d_a, d_b, d_c, n, d_h):
+        self._ck(self.lib.fk_quotient_h_dev(self.handle, C.c_void_p(d_a), C.c_void_p(d_b), C.c_void_p(d_c), C.c_uint64(n), C.c_void_p(d_h)))
+
+    def msm_g1(self, bases, scalars):
+        bases = np.ascontiguousarray(bases, np.uint8).reshape(-1, 64)
+        scalars = _fr(scalars, bases.shape[0])
+        out = np.zeros(64, np.uint8)
+        self._ck(self.lib.fk_msm_g1(self.handle, _vp(bases), _vp(scalars), C.c_size_t(bases.shape[0]), _vp(out)))
+        return out
+
+    def msm_g2(self, bases, scalars):
+        bases = np.ascontiguousarray(bases, np.uint8).reshape(-1, 128)
+        scalars = _fr(scalars, bases.shape[0])
+        out = np.zeros(128, np.uint8)
+        self._ck(self.lib.fk_msm_g2(self.handle, _vp(bases), _vp(scalars), C.c_size_t(bases.shape[0]), _vp(out)))
+        return out
+
+    def msm_g1_dev(self, d_bases, d_scalars, n):
+        out = np.zeros(64, np.uint8)
+        self._ck(self.lib.fk_msm_g1_dev(self.handle, C.c_void_p(d_bases), C.c_void_p(d_scalars), C.c_size_t(n), _vp(out)))
+        return out
+
+    def msm_g2_dev(self, d_bases, d_scalars, n):
+        out = np.zeros(128, np.uint8)
+        self._ck(self.lib.fk_msm_g2_dev(self.handle, C.c_void_p(d_bases), C.c_void_p(d_scalars), C.c_size_t(n), _vp(out)))
+        return out
+
+    def gen_points_g1_dev(self, dptr, n, seed):
+        self._ck(self.lib.fk_gen_points_g1_dev(self.handle, C.c_void_p(dptr), C.c_size_t(n), C.c_uint64(seed)))
+
+    def gen_points_g2_dev(self, dptr, n, seed):
+        self._ck(self.lib.fk_gen_points_g2_dev(self.handle, C.c_void_p(dptr), C.c_size_t(n), C.c_uint64(seed)))
+
+    def gen_scalars_dev(self, dptr, n, seed, kind=0):
+        self._ck(self.lib.fk_gen_scalars_dev(self.handle, C.c_void_p(dptr), C.c_size_t(n), C.c_uint64(seed), C.c_int(kind)))
+
+    # ---- synthesis + proving
+    def synthesize(self, r1cs, z):
+        return synthesize(r1cs, z, ctx=self)
+
+    def prove_raw(self, key, a, b, c, z, a_aux, b_in, b_aux, r, s, want_timings=False):
+        """fk_prove: returns the 256-byte proof (numpy uint8)."""
+        a, b, c, z = _fr(a), _fr(b), _fr(c), _fr(z)
+        out = np.zeros(FK_PROOF_BYTES, np.uint8)
+        tm = Timings()
+        self._ck(self.lib.fk_prove(self.handle, key.handle, _vp(a), _vp(b), _vp(c), C.c_uint64(a.shape[0]), _vp(z),
+                                   C.c_void_p(_u8(a_aux).ctypes.data), _vp(_u8(b_in)), C.c_void_p(_u8(b_aux).ctypes.data),
+                                   _vp(_fr(r, 1)), _vp(_fr(s, 1)), _vp(out), C.byref(tm)))
+        return (out, tm.as_dict()) if want_timings else out
+
+    def prove_msms(self, key, a, b, c, z, a_aux, b_in, b_aux):
+        a, b, c, z = _fr(a), _fr(b), _fr(c), _fr(z)
+        out = np.zeros(FK_MSM_RESULT_BYTES, np.uint8)
+        self._ck(self.lib.fk_prove_msms(self.handle, key.handle, _vp(a), _vp(b), _vp(c), C.c_uint64(a.shape[0]), _vp(z),
+                                        C.c_void_p(_u8(a_aux).ctypes.data), _vp(_u8(b_in)), C.c_void_p(_u8(b_aux).ctypes.data),
+                                        _vp(out), None))
+        return out
+
+    def prove_msms_dev(self, key, d_a, d_b, d_c, n, d_z, d_a_aux, d_b_in, d_b_aux, want_timings=False):
+        out = np.zeros(FK_MSM_RESULT_BYTES, np.uint8)
+        tm = Timings()
+        self._ck(self.lib.fk_prove_msms_dev(self.handle, key.handle, C.c_void_p(d_a), C.c_void_p(d_b), C.c_void_p(d_c),
+                                            C.c_uint64(n), C.c_void_p(d_z), C.c_void_p(d_a_aux), C.c_void_p(d_b_in),
+                                            C.c_void_p(d_b_aux), _vp(out), C.byref(tm)))
+        return (out, tm.as_dict()) if want_timings else out
+
+    def prove_dev(self, key, d_a, d_b, d_c, n, d_z, d_a_aux, d_b_in, d_b_aux, r, s, want_timings=False):
+        out = np.zeros(FK_PROOF_BYTES, np.uint8)
+        tm = Timings()
+        self._ck(self.lib.fk_prove_dev(self.handle, key.handle, C.c_void_p(d_a), C.c_void_p(d_b), C.c_void_p(d_c),
+                                       C.c_uint64(n), C.c_void_p(d_z), C.c_void_p(d_a_aux), C.c_void_p(d_b_in),
+                                       C.c_void_p(d_b_aux), _vp(_fr(r, 1)), _vp(_fr(s, 1)), _vp(out), C.byref(tm)))
+        return (out, tm.as_dict()) if want_timings else out
+
+    def prove_assemble(self, key, parts, r, s):
+        return assemble(key.handle, parts, r, s, ctx=self)
+
+    def stats_reset(self):
+        self._ck(self.lib.fk_stats_reset(self.handle))
+
+    def stats(self):
+        acc_ms, ntt_ms = C.c_double(), C.c_double()
+        acc_n, acc_pts, ntt_n = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._ck(self.lib.fk_stats_get(self.handle, C.byref(acc_ms), C.byref(acc_n), C.byref(acc_pts), C.byref(ntt_ms), C.byref(ntt_n)))
+        return dict(accumulate_ms=acc_ms.value, accumulate_launches=acc_n.value, accumulate_points=acc_pts.value,
+                    ntt_ms=ntt_ms.value, ntt_launches=ntt_n.value)
+
+
+def synthesize(r1cs, z, ctx=None):
+    """ProvingAssignment::enforce/eval: a, b, c and the density maps (host code of the
+    product library; needs no GPU)."""
+    lib = load_library()
+    z = _fr(z, r1cs.num_input + r1cs.num_aux)
+    n = r1cs.n_rows
+    a = np.zeros((n, 4), np.uint64); b = np.zeros((n, 4), np.uint64); c = np.zeros((n, 4), np.uint64)
+    a_aux = np.zeros(max(r1cs.num_aux, 1), np.uint8)[:r1cs.num_aux]
+    b_in = np.zeros(r1cs.num_input, np.uint8)
+    b_aux = np.zeros(max(r1cs.num_aux, 1), np.uint8)[:r1cs.num_aux]
+    rc = lib.fk_synthesize(ctx.handle if ctx else None, C.byref(r1cs.struct), _vp(z), _vp(a), _vp(b), _vp(c),
+                           C.c_void_p(a_aux.ctypes.data), _vp(b_in), C.c_void_p(b_aux.ctypes.data))
+    if rc != 0:
+        msg = lib.fk_last_error(ctx.handle) if ctx else b''
+        raise FkError(rc, msg.decode() if msg else '')
+    return a, b, c, a_aux, b_in, b_aux
+
+
+def assemble(key_handle, parts, r, s, ctx=None):
+    """fk_prove_assemble: fold n_parts x 384 B partial MSM results into the 256-byte proof (host only)."""
+    lib = load_library()
+    parts = np.ascontiguousarray(parts, np.uint8).reshape(-1, FK_MSM_RESULT_BYTES)
+    out = np.zeros(FK_PROOF_BYTES, np.uint8)
+    rc = lib.fk_prove_assemble(ctx.handle if ctx else None, key_handle, _vp(parts), C.c_uint32(parts.shape[0]),
+                               _vp(_fr(r, 1)), _vp(_fr(s, 1)), _vp(out))
+    if rc != 0:
+        msg = lib.fk_last_error(ctx.handle) if ctx else b''
+        raise FkError(rc, msg.decode() if msg else '')
+    return out
+
+
+def shard_range(n, index, count):
+    lib = load_library()
+    lo, hi = C.c_uint64(), C.c_uint64()
+    lib.fk_shard_range(C.c_uint64(n), C.c_uint32(index), C.c_uint32(count), C.byref(lo), C.byref(hi))
+    return lo.value, hi.value
+
+
+# ------------------------------------------------------------------------------------------ r, s sampling
+def _osrng_next_u64(rand=os.urandom):
+    # fawkes OsRng::next_u32 = 4 getrandom bytes big-endian (osrng.rs:13-17); rand-0.4 composes
+    # next_u64 from two next_u32, high word first
+    hi = int.from_bytes(rand(4), 'big')
+    lo = int.from_bytes(rand(4), 'big')
+    return (hi << 32) | lo
+
+
+def sample_fr(rand=os.urandom):
+    """bellman `Fr::rand`: 4 x next_u64 limbs, top 2 bits cleared, rejected unless < r; the accepted
+    limbs are the MONTGOMERY representation.  Returns uint64[4]."""
+    while True:
+        limbs = [_osrng_next_u64(rand) for _ in range(4)]
+        limbs[3] &= (1 << 62) - 1
+        v = sum(l << (64 * i) for i, l in enumerate(limbs))
+        if v < FR_MODULUS:
+            return np.array(limbs, dtype=np.uint64)
+
+
+# ------------------------------------------------------------------------------------------ prove
+def prove_with_rs(ctx, params, key, z_input, z_aux, r, s, want_timings=False):
+    """Deterministic twin of `prove` (bellman's create_proof(circuit, params, r, s)).
+    z_input / z_aux: the `WitnessCS` value vectors (cs.rs:100-101), Montgomery limbs (n,4) uint64;
+    z_input[0] must be ONE (cs.rs:111).  Returns (public inputs without ONE, Proof)."""
+    if params.r1cs is None:
+        raise FkError(1, 'Parameters carries no constraint system')
+    z_input, z_aux = _fr(z_input, params.num_input), _fr(z_aux, params.num_aux) if params.num_aux else np.zeros((0, 4), np.uint64)
+    z = np.concatenate([z_input, z_aux], axis=0)
+    a, b, c, a_aux, b_in, b_aux = ctx.synthesize(params.r1cs, z)
+    res = ctx.prove_raw(key, a, b, c, z, a_aux, b_in, b_aux, r, s, want_timings=want_timings)
+    proof_bytes, tm = (res if want_timings else (res, None))
+    inputs = z_input[1:].copy()   # prover.rs:84-87
+    proof = Proof.from_bytes(proof_bytes.tobytes())
+    return (inputs, proof, tm) if want_timings else (inputs, proof)
+
+
+def prove(ctx, params, key, z_input, z_aux):
+    """Mirror of prover.rs:63-90 below the DSL: r, s are drawn from the OS entropy source exactly like
+    `create_random_proof` does through fawkes' OsRng (prover.rs:78-80)."""
+    return prove_with_rs(ctx, params, key, z_input, z_aux, sample_fr(), sample_fr())

@@ -1,0 +1,109 @@
+// Shared host-side plumbing of libfawkes_hip.so: context, error handling, grow-only device scratch.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <map>
+#include <string>
+#include <vector>
+#include "../../include/fawkes_hip.h"
+#include "curve.cuh"
+
+namespace fk {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    // grow-only; contents are NOT preserved across a growth
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        size_t want = bytes + (bytes >> 3) + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { e = hipMalloc(&p, bytes); want = bytes; }
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T *as() const { return (T *)p; }
+};
+
+struct NttDomain;
+
+struct EventPair { hipEvent_t a, b; uint64_t units; };
+
+}  // namespace fk
+
+struct fk_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    unsigned window_bits = 0;  // 0 = auto
+    std::map<uint32_t, fk::NttDomain *> domains;
+    // MSM scratch
+    fk::DevBuf digits, sorted, counts, totals, starts, buckets, winparts, overlist, tasktab, partials, misc;
+    // NTT / prover scratch
+    fk::DevBuf ntt_s1, ntt_s2, ntt_io, hbuf, sc_a, sc_b, scan_tmp, stage_a, stage_b, stage_c, stage_z, stage_d;
+    // stats
+    std::vector<fk::EventPair> ev_acc, ev_ntt;
+    std::vector<hipEvent_t> ev_pool;
+    bool stats_on = true;
+};
+
+struct fk_key {
+    uint64_t m = 0;
+    uint32_t num_input = 0, num_aux = 0;
+    uint64_t n_h = 0, n_l = 0, n_a = 0, n_b = 0;          // full (unsharded) counts
+    uint32_t shard_index = 0, shard_count = 1;
+    // [lo, hi) slices held by this context
+    uint64_t h_lo = 0, h_hi = 0, l_lo = 0, l_hi = 0, a_lo = 0, a_hi = 0, b_lo = 0, b_hi = 0;
+    fk::G1Affine *d_h = nullptr, *d_l = nullptr, *d_a = nullptr, *d_b1 = nullptr;
+    fk::G2Affine *d_b2 = nullptr;
+    fk::G1Affine alpha_g1, beta_g1, delta_g1;
+    fk::G2Affine beta_g2, delta_g2;
+};
+
+#define FK_SET_ERR(ctx, code, ...)                                   \
+    do {                                                             \
+        char _b[512]; snprintf(_b, sizeof _b, __VA_ARGS__);          \
+        (ctx)->err = _b;                                             \
+        return (code);                                               \
+    } while (0)
+
+#define FK_HIP(ctx, expr)                                                                         \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess) {                                                                   \
+            char _b[512];                                                                         \
+            snprintf(_b, sizeof _b, "%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            (ctx)->err = _b;                                                                      \
+            return (_e == hipErrorOutOfMemory) ? FK_ERR_OOM : FK_ERR_HIP;                         \
+        }                                                                                         \
+    } while (0)
+
+#define FK_TRY(expr) do { int _rc = (expr); if (_rc != FK_OK) return _rc; } while (0)
+
+namespace fk {
+
+static inline uint32_t ceil_log2_u64(uint64_t n) { uint32_t k = 0; while (((uint64_t)1 << k) < n) k++; return k; }
+
+// stats helpers (HIP events on the library stream)
+int stats_begin(fk_ctx *ctx, std::vector<EventPair> &v, uint64_t units);
+int stats_end(fk_ctx *ctx, std::vector<EventPair> &v);
+
+// ntt.hip
+int ntt_exec_simple(fk_ctx *ctx, Fr *d_data, uint32_t log_n, bool inverse, bool coset);
+int quotient_dev(fk_ctx *ctx, Fr *d_a, Fr *d_b, Fr *d_c, uint64_t n, Fr *d_h_out, uint64_t *m_out);
+void ntt_free_domains(fk_ctx *ctx);
+int fr_mul_batch_dev(fk_ctx *ctx, const Fr *a, const Fr *b, Fr *o, size_t n);
+
+// msm.hip
+int msm_g1_dev(fk_ctx *ctx, const G1Affine *d_bases, const Fr *d_scalars, size_t n, G1Xyzz *out);
+int msm_g2_dev(fk_ctx *ctx, const G2Affine *d_bases, const Fr *d_scalars, size_t n, G2Xyzz *out);
+int gen_points_g1(fk_ctx *ctx, G1Affine *d_out, size_t n, uint64_t seed);
+int gen_points_g2(fk_ctx *ctx, G2Affine *d_out, size_t n, uint64_t seed);
+int gen_scalars(fk_ctx *ctx, Fr *d_out, size_t n, uint64_t seed, int kind);
+// out[k] = z[j] for the k-th j with density[j] != 0 (device pointers); returns count via *n_out
+int compact_scalars(fk_ctx *ctx, const Fr *d_z, const uint8_t *d_density, size_t n, Fr *d_out, uint64_t *n_out);
+
+}  // namespace fk

@@ -1,0 +1,207 @@
+// BN254 prime fields for gfx950: 8 x u32 little-endian limbs, Montgomery form with R = 2^256.
+//
+// The limb/Montgomery convention is the one fawkes-crypto hands across the boundary: a `Num<Fr>` is
+// `#[repr(transparent)]` over 4 x u64 LE Montgomery limbs (ff-uint/src/num/mod.rs:21-23,
+// ff-uint/src/uint/mod.rs:21-26; R/R2/INV rules ff-uint_derive/src/lib.rs:237-253,354-366), and
+// bellman receives the same raw limbs (backend/bellman_groth16/mod.rs:105-120).  8 x u32 LE is the
+// same byte image, so witness buffers are read as-is.
+//
+// No MFMA here: this is 256-bit integer modular arithmetic.  The product is a CIOS Montgomery
+// multiplication built from 32x32->64 multiply-adds (v_mad_u64_u32 on CDNA4); every value that
+// leaves a function is fully reduced to [0, p) so equality tests are plain limb compares.
+#pragma once
+#include <stdint.h>
+#include "bn254_consts.h"
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FK_HD __host__ __device__ __forceinline__   // device pass: hot loops want the CIOS body inline
+#else
+#define FK_HD __host__ __device__ inline            // host pass: let the compiler decide (build time)
+#endif
+#else
+#define FK_HD inline
+#endif
+
+namespace fk {
+
+struct FqParams {
+    static constexpr FK_HD uint32_t p(int i) { constexpr uint32_t t[8] = FK_FQ_P; return t[i]; }
+    static constexpr FK_HD uint32_t one(int i) { constexpr uint32_t t[8] = FK_FQ_R; return t[i]; }
+    static constexpr FK_HD uint32_t r2(int i) { constexpr uint32_t t[8] = FK_FQ_R2; return t[i]; }
+    static constexpr uint32_t INV = FK_FQ_INV;
+};
+struct FrParams {
+    static constexpr FK_HD uint32_t p(int i) { constexpr uint32_t t[8] = FK_FR_P; return t[i]; }
+    static constexpr FK_HD uint32_t one(int i) { constexpr uint32_t t[8] = FK_FR_R; return t[i]; }
+    static constexpr FK_HD uint32_t r2(int i) { constexpr uint32_t t[8] = FK_FR_R2; return t[i]; }
+    static constexpr uint32_t INV = FK_FR_INV;
+};
+
+template <class P>
+struct alignas(16) Fp {
+    uint32_t v[8];
+
+    static FK_HD Fp zero() { Fp r; for (int i = 0; i < 8; i++) r.v[i] = 0; return r; }
+    static FK_HD Fp one() { Fp r; for (int i = 0; i < 8; i++) r.v[i] = P::one(i); return r; }
+    static FK_HD Fp r2() { Fp r; for (int i = 0; i < 8; i++) r.v[i] = P::r2(i); return r; }
+
+    FK_HD bool is_zero() const {
+        uint32_t o = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) o |= v[i];
+        return o == 0;
+    }
+    friend FK_HD bool operator==(const Fp &a, const Fp &b) {
+        uint32_t o = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) o |= a.v[i] ^ b.v[i];
+        return o == 0;
+    }
+    friend FK_HD bool operator!=(const Fp &a, const Fp &b) { return !(a == b); }
+
+    // r = a - p if a >= p (a < 2p)
+    static FK_HD Fp reduce_once(const Fp &a) {
+        Fp d; uint32_t br = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            uint64_t t = (uint64_t)a.v[i] - P::p(i) - br;
+            d.v[i] = (uint32_t)t; br = (uint32_t)(t >> 63);
+        }
+        Fp r;
+#pragma unroll
+        for (int i = 0; i < 8; i++) r.v[i] = br ? a.v[i] : d.v[i];
+        return r;
+    }
+
+    static FK_HD Fp add(const Fp &a, const Fp &b) {
+        Fp s; uint32_t c = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            uint64_t t = (uint64_t)a.v[i] + b.v[i] + c;
+            s.v[i] = (uint32_t)t; c = (uint32_t)(t >> 32);
+        }
+        // p < 2^254 so a + b < 2^255: no carry out of limb 7
+        return reduce_once(s);
+    }
+    static FK_HD Fp dbl(const Fp &a) { return add(a, a); }
+
+    static FK_HD Fp sub(const Fp &a, const Fp &b) {
+        Fp d; uint32_t br = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            uint64_t t = (uint64_t)a.v[i] - b.v[i] - br;
+            d.v[i] = (uint32_t)t; br = (uint32_t)(t >> 63);
+        }
+        uint32_t mask = 0u - br, c = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            uint64_t t = (uint64_t)d.v[i] + (P::p(i) & mask) + c;
+            d.v[i] = (uint32_t)t; c = (uint32_t)(t >> 32);
+        }
+        return d;
+    }
+    static FK_HD Fp neg(const Fp &a) { return sub(zero(), a); }
+
+    // CIOS Montgomery product a * b * 2^-256 mod p.
+    static FK_HD Fp mul(const Fp &a, const Fp &b) {
+        uint32_t t[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) t[i] = 0;
+        uint32_t t8 = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            uint64_t c = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                uint64_t x = (uint64_t)a.v[j] * b.v[i] + t[j] + c;
+                t[j] = (uint32_t)x; c = x >> 32;
+            }
+            uint64_t top = (uint64_t)t8 + c;          // fits 33 bits
+            uint32_t m = t[0] * P::INV;
+            uint64_t x = (uint64_t)m * P::p(0) + t[0];
+            c = x >> 32;
+#pragma unroll
+            for (int j = 1; j < 8; j++) {
+                x = (uint64_t)m * P::p(j) + t[j] + c;
+                t[j - 1] = (uint32_t)x; c = x >> 32;
+            }
+            top += c;
+            t[7] = (uint32_t)top; t8 = (uint32_t)(top >> 32);
+        }
+        // a, b < p < 2^254 keeps the running value < 2p, so t8 == 0 here
+        Fp r;
+#pragma unroll
+        for (int i = 0; i < 8; i++) r.v[i] = t[i];
+        return reduce_once(r);
+    }
+    static FK_HD Fp sqr(const Fp &a) { return mul(a, a); }
+
+    // Montgomery -> canonical integer (multiply by 1)
+    static FK_HD Fp from_mont(const Fp &a) {
+        Fp o = zero(); o.v[0] = 1;
+        return mul(a, o);
+    }
+    static FK_HD Fp to_mont(const Fp &a) { return mul(a, r2()); }
+
+    // a^e, e given as 8 x u32 canonical LE (host-side helper; also fine on device)
+    static FK_HD Fp pow(const Fp &a, const uint32_t e[8]) {
+        Fp acc = one(), base = a;
+        for (int i = 0; i < 256; i++) {
+            if ((e[i >> 5] >> (i & 31)) & 1) acc = mul(acc, base);
+            base = sqr(base);
+        }
+        return acc;
+    }
+    static FK_HD Fp pow_u64(const Fp &a, uint64_t e) {
+        Fp acc = one(), base = a;
+        while (e) { if (e & 1) acc = mul(acc, base); base = sqr(base); e >>= 1; }
+        return acc;
+    }
+    static FK_HD Fp inv(const Fp &a) {  // Fermat; callers never pass zero where it matters
+        uint32_t e[8]; uint32_t br = 2;
+        for (int i = 0; i < 8; i++) {
+            uint64_t t = (uint64_t)P::p(i) - br; e[i] = (uint32_t)t; br = (uint32_t)(t >> 63);
+        }
+        return pow(a, e);
+    }
+    static FK_HD Fp from_u64(uint64_t x) {
+        Fp o = zero(); o.v[0] = (uint32_t)x; o.v[1] = (uint32_t)(x >> 32);
+        return to_mont(o);
+    }
+};
+
+using Fq = Fp<FqParams>;
+using Fr = Fp<FrParams>;
+
+// Fq2 = Fq[u]/(u^2 + 1)   (pairing_ce bn256 tower)
+struct alignas(16) Fq2 {
+    Fq c0, c1;
+    static FK_HD Fq2 zero() { return Fq2{Fq::zero(), Fq::zero()}; }
+    static FK_HD Fq2 one() { return Fq2{Fq::one(), Fq::zero()}; }
+    FK_HD bool is_zero() const { return c0.is_zero() && c1.is_zero(); }
+    friend FK_HD bool operator==(const Fq2 &a, const Fq2 &b) { return a.c0 == b.c0 && a.c1 == b.c1; }
+    friend FK_HD bool operator!=(const Fq2 &a, const Fq2 &b) { return !(a == b); }
+    static FK_HD Fq2 add(const Fq2 &a, const Fq2 &b) { return Fq2{Fq::add(a.c0, b.c0), Fq::add(a.c1, b.c1)}; }
+    static FK_HD Fq2 sub(const Fq2 &a, const Fq2 &b) { return Fq2{Fq::sub(a.c0, b.c0), Fq::sub(a.c1, b.c1)}; }
+    static FK_HD Fq2 dbl(const Fq2 &a) { return Fq2{Fq::dbl(a.c0), Fq::dbl(a.c1)}; }
+    static FK_HD Fq2 neg(const Fq2 &a) { return Fq2{Fq::neg(a.c0), Fq::neg(a.c1)}; }
+    static FK_HD Fq2 mul(const Fq2 &a, const Fq2 &b) {  // Karatsuba, 3 base multiplications
+        Fq aa = Fq::mul(a.c0, b.c0);
+        Fq bb = Fq::mul(a.c1, b.c1);
+        Fq t = Fq::mul(Fq::add(a.c0, a.c1), Fq::add(b.c0, b.c1));
+        return Fq2{Fq::sub(aa, bb), Fq::sub(Fq::sub(t, aa), bb)};
+    }
+    static FK_HD Fq2 sqr(const Fq2 &a) {  // (c0+c1)(c0-c1), 2 c0 c1
+        Fq s = Fq::add(a.c0, a.c1), d = Fq::sub(a.c0, a.c1);
+        Fq m = Fq::mul(a.c0, a.c1);
+        return Fq2{Fq::mul(s, d), Fq::dbl(m)};
+    }
+    static FK_HD Fq2 inv(const Fq2 &a) {
+        Fq n = Fq::inv(Fq::add(Fq::sqr(a.c0), Fq::sqr(a.c1)));
+        return Fq2{Fq::mul(a.c0, n), Fq::neg(Fq::mul(a.c1, n))};
+    }
+};
+
+}  // namespace fk

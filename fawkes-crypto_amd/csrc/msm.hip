@@ -1,0 +1,551 @@
+// BN254 G1 / G2 Pippenger multi-scalar multiplication on gfx950.
+//
+// Replaces bellman_ce::multiexp::multiexp as called five times by bellman's prover (H, L, A, B1 in G1 and
+// B2 in G2; reached from
+// /root/reference/fawkes-crypto/src/backend/bellman_groth16/prover.rs:80).  Any correct MSM yields the
+// same group element, so the result is bit-identical to bellman's after `into_affine`.
+//
+// MI355X pipeline (all on one stream, no MFMA -- 256-bit modular integer work):
+//   1. msm_digits      scalars leave Montgomery form (bellman's `into_repr`) and are cut into W signed
+//                      c-bit digits (buckets 1..2^(c-1), sign bit) -- halves the bucket count.
+//   2. counting sort   per (window, chunk) histograms live in LDS (up to 2^15 counters = 128 KiB of the
+//                      160 KiB), a scan turns them into offsets, and a second LDS-cursor pass scatters
+//                      point indices so that every bucket's points are contiguous.  No global atomics,
+//                      so skewed witness scalars (many 0/1) cost nothing extra.
+//   3. msm_accumulate  one lane per bucket walks its run with XYZZ mixed additions (8M+2S), gathering
+//                      64-byte affine bases; buckets above `cap` entries hand the excess to
+//   4. msm_overflow    256-lane workgroups that reduce fixed 4096-entry segments with wavefront
+//                      shuffles, then one wave per oversized bucket folds the partials.
+//   5. msm_bucket_reduce  sum_b b*S_b per window: each lane runs the running-sum trick over L buckets,
+//                      adds its offset multiple by double-and-add, then wave64 shuffle + LDS reduction.
+//   6. host            W window sums are Horner-combined (c doublings each) -- microseconds.
+#include "common.hpp"
+#include <algorithm>
+
+namespace fk {
+
+static constexpr uint32_t SEG = 4096;          // overflow segment (entries) per workgroup
+static constexpr uint32_t SORT_THREADS = 1024;
+
+struct MsmPlan {
+    size_t n;
+    uint32_t c, W, B;        // window bits, windows, buckets per window (2^(c-1))
+    uint32_t nchunks;
+    size_t chunk;
+    uint32_t cap;            // max entries a bucket-lane handles itself
+    uint32_t L, T, nblk;     // bucket-reduce: buckets per lane, lanes per window, blocks per window
+};
+
+static MsmPlan make_plan(size_t n, unsigned forced_c) {
+    MsmPlan p{};
+    p.n = n;
+    uint32_t lg = 0; while (((size_t)1 << (lg + 1)) <= n) lg++;
+    uint32_t c = forced_c ? forced_c : (lg >= 18 ? 16 : (lg >= 6 ? lg - 2 : 4));
+    if (c < 2) c = 2;
+    if (c > 16) c = 16;
+    p.c = c;
+    p.W = (255 + c - 1) / c;
+    p.B = 1u << (c - 1);
+    size_t chunk = (n + 31) / 32;
+    if (chunk < 16384) chunk = 16384;
+    p.chunk = chunk;
+    p.nchunks = (uint32_t)((n + chunk - 1) / chunk);
+    size_t mean = n / p.B;
+    p.cap = (uint32_t)std::min<size_t>(2 * mean + 64, 1u << 30);
+    p.L = p.B >= 4096 ? p.B / 2048 : 1;
+    p.T = p.B / p.L;
+    p.nblk = (p.T + 255) / 256;
+    return p;
+}
+
+// ------------------------------------------------------------------------------------------ digits
+__global__ void msm_digits_kernel(const Fr *scalars, size_t n, uint32_t c, uint32_t W, uint32_t *digits) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr s = Fr::from_mont(scalars[i]);   // canonical integer, 254 bits
+    const uint32_t B = 1u << (c - 1), mask = (1u << c) - 1;
+    uint32_t carry = 0;
+    for (uint32_t w = 0; w < W; w++) {
+        const uint32_t o = w * c, limb = o >> 5, sh = o & 31;
+        uint32_t lo = limb < 8 ? s.v[limb] : 0, hi = limb + 1 < 8 ? s.v[limb + 1] : 0;
+        uint32_t raw = (uint32_t)((((uint64_t)hi << 32) | lo) >> sh) & mask;
+        raw += carry;
+        uint32_t d, neg;
+        if (raw > B) { d = (1u << c) - raw; neg = 1; carry = 1; } else { d = raw; neg = 0; carry = 0; }
+        digits[(size_t)w * n + i] = d | (neg << 31);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ counting sort
+__global__ __launch_bounds__(SORT_THREADS) void msm_hist_kernel(const uint32_t *digits, size_t n, size_t chunk,
+                                                                 uint32_t nchunks, uint32_t B, uint32_t *counts) {
+    extern __shared__ uint32_t hist[];
+    const uint32_t ch = blockIdx.x, w = blockIdx.y;
+    for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) hist[b] = 0;
+    __syncthreads();
+    const size_t lo = (size_t)ch * chunk, hi = lo + chunk < n ? lo + chunk : n;
+    const uint32_t *dg = digits + (size_t)w * n;
+    for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        uint32_t d = dg[i] & 0x7fffffffu;
+        if (d) atomicAdd(&hist[d - 1], 1u);
+    }
+    __syncthreads();
+    uint32_t *out = counts + ((size_t)w * nchunks + ch) * B;
+    for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) out[b] = hist[b];
+}
+
+// counts[w][ch][b] -> exclusive prefix over ch; totals[w][b] = sum over ch
+__global__ void msm_chunk_prefix_kernel(uint32_t *counts, uint32_t nchunks, uint32_t B, uint32_t W, uint32_t *totals) {
+    size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (size_t)W * B) return;
+    const uint32_t w = (uint32_t)(g / B), b = (uint32_t)(g % B);
+    uint32_t run = 0;
+    for (uint32_t ch = 0; ch < nchunks; ch++) {
+        uint32_t *p = counts + ((size_t)w * nchunks + ch) * B + b;
+        uint32_t v = *p; *p = run; run += v;
+    }
+    totals[g] = run;
+}
+
+struct OverEntry { uint32_t g, size; };
+
+// one block per window: starts[w][b] = exclusive scan of totals[w][.]; oversized buckets are listed
+__global__ __launch_bounds__(1024) void msm_window_scan_kernel(const uint32_t *totals, uint32_t B, uint32_t cap,
+                                                                uint32_t *starts, OverEntry *over, uint32_t *n_over,
+                                                                uint32_t over_cap) {
+    __shared__ uint32_t part[1024];
+    const uint32_t w = blockIdx.x, tid = threadIdx.x;
+    const uint32_t ipt = (B + 1023) / 1024;
+    const uint32_t lo = tid * ipt, hi = lo + ipt < B ? lo + ipt : B;
+    uint32_t sum = 0;
+    for (uint32_t b = lo; b < hi; b++) {
+        uint32_t v = totals[(size_t)w * B + b];
+        sum += v;
+        if (v > cap) {
+            uint32_t k = atomicAdd(n_over, 1u);
+            if (k < over_cap) { over[k].g = w * B + b; over[k].size = v; }
+        }
+    }
+    part[tid] = sum;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+        uint32_t v = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[tid] - sum;  // exclusive
+    for (uint32_t b = lo; b < hi; b++) {
+        starts[(size_t)w * B + b] = run;
+        run += totals[(size_t)w * B + b];
+    }
+}
+
+__global__ __launch_bounds__(SORT_THREADS) void msm_scatter_kernel(const uint32_t *digits, size_t n, size_t chunk,
+                                                                    uint32_t nchunks, uint32_t B, const uint32_t *counts,
+                                                                    const uint32_t *starts, uint32_t *sorted) {
+    extern __shared__ uint32_t cursor[];
+    const uint32_t ch = blockIdx.x, w = blockIdx.y;
+    const uint32_t *cnt = counts + ((size_t)w * nchunks + ch) * B;
+    const uint32_t *st = starts + (size_t)w * B;
+    for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) cursor[b] = st[b] + cnt[b];
+    __syncthreads();
+    const size_t lo = (size_t)ch * chunk, hi = lo + chunk < n ? lo + chunk : n;
+    const uint32_t *dg = digits + (size_t)w * n;
+    uint32_t *out = sorted + (size_t)w * n;
+    for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        uint32_t d = dg[i];
+        uint32_t bkt = d & 0x7fffffffu;
+        if (bkt) {
+            uint32_t pos = atomicAdd(&cursor[bkt - 1], 1u);
+            out[pos] = (uint32_t)i | (d & 0x80000000u);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ cold-path point ops
+// Only msm_accumulate_kernel is hot; everything else calls these out-of-line copies so that the
+// 14-multiplication group law is instantiated once per field instead of once per call site.
+template <class F> static __device__ __noinline__ void pt_add(Xyzz<F> &a, const Xyzz<F> &b) { a.add(b); }
+template <class F> static __device__ __noinline__ void pt_add_mixed(Xyzz<F> &a, const Affine<F> &b) { a.add_mixed(b); }
+template <class F> static __device__ __noinline__ void pt_dbl(Xyzz<F> &a) { a = Xyzz<F>::dbl(a); }
+template <class F> static __device__ __noinline__ void pt_to_affine(Affine<F> &o, const Xyzz<F> &a) { o = a.to_affine(); }
+
+// ------------------------------------------------------------------------------------------ wave / block reductions
+template <class T>
+static __device__ __forceinline__ T shfl_down_obj(const T &v, int off) {
+    static_assert(sizeof(T) % 4 == 0, "word sized");
+    T r;
+    const uint32_t *s = reinterpret_cast<const uint32_t *>(&v);
+    uint32_t *d = reinterpret_cast<uint32_t *>(&r);
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 4; i++) d[i] = (uint32_t)__shfl_down((int)s[i], off, 64);
+    return r;
+}
+
+// wave64 tree: after the call lane 0 holds the sum of all 64 lanes' points
+template <class F>
+static __device__ __forceinline__ void wave_reduce(Xyzz<F> &acc) {
+#pragma unroll 1
+    for (int off = 32; off >= 1; off >>= 1) {
+        Xyzz<F> o = shfl_down_obj(acc, off);
+        pt_add(acc, o);
+    }
+}
+
+// 256-thread block: result valid in thread 0.  `sh` holds 4 points.
+template <class F>
+static __device__ __forceinline__ void block_reduce_256(Xyzz<F> &acc, Xyzz<F> *sh) {
+    wave_reduce(acc);
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) sh[wv] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        acc = sh[0];
+        for (int k = 1; k < 4; k++) { Xyzz<F> o = sh[k]; pt_add(acc, o); }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ bucket accumulation
+template <class F>
+__global__ __launch_bounds__(256) void msm_accumulate_kernel(const Affine<F> *bases, const uint32_t *sorted, size_t n,
+                                                             const uint32_t *starts, const uint32_t *totals, uint32_t B,
+                                                             uint32_t W, uint32_t cap, Xyzz<F> *buckets) {
+    size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (size_t)W * B) return;
+    const uint32_t w = (uint32_t)(g / B);
+    const uint32_t *src = sorted + (size_t)w * n + starts[g];
+    uint32_t cnt = totals[g];
+    if (cnt > cap) cnt = cap;
+    Xyzz<F> acc = Xyzz<F>::inf();
+    for (uint32_t k = 0; k < cnt; k++) {
+        const uint32_t e = src[k];
+        Affine<F> p = bases[e & 0x7fffffffu];
+        acc.add_mixed(affine_neg_if(p, (e >> 31) != 0));
+    }
+    buckets[g] = acc;
+}
+
+struct Task { uint32_t g, seg; };
+
+// one workgroup per 4096-entry segment of an oversized bucket (entries beyond `cap`)
+template <class F>
+__global__ __launch_bounds__(256) void msm_overflow_kernel(const Affine<F> *bases, const uint32_t *sorted, size_t n,
+                                                           const uint32_t *starts, const uint32_t *totals, uint32_t B,
+                                                           uint32_t cap, const Task *tasks, Xyzz<F> *partials) {
+    __shared__ Xyzz<F> sh[4];
+    const Task t = tasks[blockIdx.x];
+    const uint32_t w = t.g / B;
+    const uint32_t *src = sorted + (size_t)w * n + starts[t.g];
+    const uint32_t size = totals[t.g];
+    const uint32_t lo = cap + t.seg * SEG;
+    const uint32_t hi = lo + SEG < size ? lo + SEG : size;
+    Xyzz<F> acc = Xyzz<F>::inf();
+    for (uint32_t k = lo + threadIdx.x; k < hi; k += 256) {
+        const uint32_t e = src[k];
+        Affine<F> p = affine_neg_if(bases[e & 0x7fffffffu], (e >> 31) != 0);
+        pt_add_mixed(acc, p);
+    }
+    block_reduce_256(acc, sh);
+    if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+}
+
+struct OverBucket { uint32_t g, task0, ntask; };
+
+// one wave per oversized bucket: fold its partials into buckets[g]
+template <class F>
+__global__ __launch_bounds__(64) void msm_overflow_fold_kernel(const OverBucket *ob, const Xyzz<F> *partials, Xyzz<F> *buckets) {
+    const OverBucket o = ob[blockIdx.x];
+    Xyzz<F> acc = Xyzz<F>::inf();
+    for (uint32_t k = threadIdx.x; k < o.ntask; k += 64) { Xyzz<F> q = partials[o.task0 + k]; pt_add(acc, q); }
+    wave_reduce(acc);
+    if (threadIdx.x == 0) { Xyzz<F> b = buckets[o.g]; pt_add(b, acc); buckets[o.g] = b; }
+}
+
+// ------------------------------------------------------------------------------------------ bucket reduction
+// window sum = sum_{slot s} (s+1) * bucket[s].  Lane t owns slots [tL, (t+1)L).
+template <class F>
+__global__ __launch_bounds__(256) void msm_bucket_reduce_kernel(const Xyzz<F> *buckets, uint32_t B, uint32_t L, uint32_t T,
+                                                                uint32_t nblk, Xyzz<F> *winparts) {
+    __shared__ Xyzz<F> sh[4];
+    const uint32_t w = blockIdx.y;
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    Xyzz<F> acc = Xyzz<F>::inf();
+    if (t < T) {
+        Xyzz<F> run = Xyzz<F>::inf();
+        const Xyzz<F> *bk = buckets + (size_t)w * B + (size_t)t * L;
+        for (uint32_t s = L; s-- > 0;) {
+            Xyzz<F> q = bk[s];
+            pt_add(run, q);
+            pt_add(acc, run);
+        }
+        // + (t*L) * run
+        const uint32_t k = t * L;
+        if (k) {
+            Xyzz<F> m = Xyzz<F>::inf();
+            for (int bit = 31 - __clz(k); bit >= 0; bit--) {
+                pt_dbl(m);
+                if ((k >> bit) & 1) pt_add(m, run);
+            }
+            pt_add(acc, m);
+        }
+    }
+    block_reduce_256(acc, sh);
+    if (threadIdx.x == 0) winparts[(size_t)w * nblk + blockIdx.x] = acc;
+}
+
+// ------------------------------------------------------------------------------------------ host driver
+template <class F>
+static int msm_run(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars, size_t n, Xyzz<F> *out) {
+    *out = Xyzz<F>::inf();
+    if (n == 0) return FK_OK;
+    if (n >= ((size_t)1 << 31)) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "msm: n too large");
+    const MsmPlan p = make_plan(n, ctx->window_bits);
+    hipStream_t st = ctx->stream;
+    const size_t WB = (size_t)p.W * p.B;
+    FK_HIP(ctx, ctx->digits.reserve((size_t)p.W * n * 4));
+    FK_HIP(ctx, ctx->sorted.reserve((size_t)p.W * n * 4));
+    FK_HIP(ctx, ctx->counts.reserve((size_t)p.W * p.nchunks * p.B * 4));
+    FK_HIP(ctx, ctx->totals.reserve(WB * 4));
+    FK_HIP(ctx, ctx->starts.reserve(WB * 4));
+    FK_HIP(ctx, ctx->buckets.reserve(WB * sizeof(Xyzz<F>)));
+    FK_HIP(ctx, ctx->winparts.reserve((size_t)p.W * p.nblk * sizeof(Xyzz<F>)));
+    const uint32_t over_cap = 1u << 16;
+    FK_HIP(ctx, ctx->overlist.reserve(over_cap * sizeof(OverEntry) + 16));
+    uint32_t *d_nover = (uint32_t *)((char *)ctx->overlist.p + over_cap * sizeof(OverEntry));
+    uint32_t *digits = ctx->digits.as<uint32_t>(), *sorted = ctx->sorted.as<uint32_t>();
+    uint32_t *counts = ctx->counts.as<uint32_t>(), *totals = ctx->totals.as<uint32_t>(), *starts = ctx->starts.as<uint32_t>();
+    Xyzz<F> *buckets = ctx->buckets.as<Xyzz<F>>(), *winparts = ctx->winparts.as<Xyzz<F>>();
+
+    hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, p.c, p.W, digits);
+    FK_HIP(ctx, hipGetLastError());
+    const size_t lds = (size_t)p.B * 4;
+    FK_HIP(ctx, hipFuncSetAttribute((const void *)msm_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    FK_HIP(ctx, hipFuncSetAttribute((const void *)msm_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(msm_hist_kernel, dim3(p.nchunks, p.W), dim3(SORT_THREADS), lds, st, digits, n, p.chunk, p.nchunks, p.B, counts);
+    FK_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(msm_chunk_prefix_kernel, dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, counts, p.nchunks, p.B, p.W, totals);
+    FK_HIP(ctx, hipGetLastError());
+    FK_HIP(ctx, hipMemsetAsync(d_nover, 0, 4, st));
+    hipLaunchKernelGGL(msm_window_scan_kernel, dim3(p.W), dim3(1024), 0, st, totals, p.B, p.cap, starts,
+                       ctx->overlist.as<OverEntry>(), d_nover, over_cap);
+    FK_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(msm_scatter_kernel, dim3(p.nchunks, p.W), dim3(SORT_THREADS), lds, st, digits, n, p.chunk, p.nchunks, p.B,
+                       counts, starts, sorted);
+    FK_HIP(ctx, hipGetLastError());
+
+    FK_TRY(stats_begin(ctx, ctx->ev_acc, (uint64_t)n));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_kernel<F>), dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, d_bases, sorted, n,
+                       starts, totals, p.B, p.W, p.cap, buckets);
+    FK_HIP(ctx, hipGetLastError());
+    FK_TRY(stats_end(ctx, ctx->ev_acc));
+
+    // oversized buckets (skewed scalars): host builds the segment table -- a few entries in practice
+    uint32_t n_over = 0;
+    FK_HIP(ctx, hipMemcpyAsync(&n_over, d_nover, 4, hipMemcpyDeviceToHost, st));
+    FK_HIP(ctx, hipStreamSynchronize(st));
+    if (n_over > over_cap) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "msm: %u oversized buckets exceed the table (pathological scalar distribution)", n_over);
+    if (n_over) {
+        std::vector<OverEntry> ov(n_over);
+        FK_HIP(ctx, hipMemcpy(ov.data(), ctx->overlist.p, n_over * sizeof(OverEntry), hipMemcpyDeviceToHost));
+        std::sort(ov.begin(), ov.end(), [](const OverEntry &a, const OverEntry &b) { return a.g < b.g; });
+        std::vector<Task> tasks;
+        std::vector<OverBucket> obs;
+        for (const OverEntry &e : ov) {
+            const uint32_t extra = e.size - p.cap;
+            const uint32_t nt = (extra + SEG - 1) / SEG;
+            obs.push_back(OverBucket{e.g, (uint32_t)tasks.size(), nt});
+            for (uint32_t s = 0; s < nt; s++) tasks.push_back(Task{e.g, s});
+        }
+        const size_t tb = tasks.size() * sizeof(Task), ob = obs.size() * sizeof(OverBucket);
+        const size_t tb_al = (tb + 15) & ~(size_t)15;
+        FK_HIP(ctx, ctx->tasktab.reserve(tb_al + ob));
+        FK_HIP(ctx, ctx->partials.reserve(tasks.size() * sizeof(Xyzz<F>)));
+        Task *d_tasks = ctx->tasktab.as<Task>();
+        OverBucket *d_obs = (OverBucket *)((char *)ctx->tasktab.p + tb_al);
+        FK_HIP(ctx, hipMemcpyAsync(d_tasks, tasks.data(), tb, hipMemcpyHostToDevice, st));
+        FK_HIP(ctx, hipMemcpyAsync(d_obs, obs.data(), ob, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_overflow_kernel<F>), dim3((unsigned)tasks.size()), dim3(256), 0, st, d_bases, sorted, n, starts,
+                           totals, p.B, p.cap, d_tasks, ctx->partials.as<Xyzz<F>>());
+        FK_HIP(ctx, hipGetLastError());
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_overflow_fold_kernel<F>), dim3((unsigned)obs.size()), dim3(64), 0, st, d_obs,
+                           ctx->partials.as<Xyzz<F>>(), buckets);
+        FK_HIP(ctx, hipGetLastError());
+        FK_HIP(ctx, hipStreamSynchronize(st));  // tasks/obs vectors must outlive the async copies
+    }
+
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_bucket_reduce_kernel<F>), dim3(p.nblk, p.W), dim3(256), 0, st, buckets, p.B, p.L, p.T, p.nblk, winparts);
+    FK_HIP(ctx, hipGetLastError());
+
+    std::vector<Xyzz<F>> wp((size_t)p.W * p.nblk);
+    FK_HIP(ctx, hipMemcpyAsync(wp.data(), winparts, wp.size() * sizeof(Xyzz<F>), hipMemcpyDeviceToHost, st));
+    FK_HIP(ctx, hipStreamSynchronize(st));
+    // Horner over windows, most significant first
+    Xyzz<F> acc = Xyzz<F>::inf();
+    for (uint32_t w = p.W; w-- > 0;) {
+        for (uint32_t k = 0; k < p.c; k++) acc = Xyzz<F>::dbl(acc);
+        for (uint32_t b = 0; b < p.nblk; b++) acc.add(wp[(size_t)w * p.nblk + b]);
+    }
+    *out = acc;
+    return FK_OK;
+}
+
+int msm_g1_dev(fk_ctx *ctx, const G1Affine *d_bases, const Fr *d_scalars, size_t n, G1Xyzz *out) {
+    return msm_run<Fq>(ctx, d_bases, d_scalars, n, out);
+}
+int msm_g2_dev(fk_ctx *ctx, const G2Affine *d_bases, const Fr *d_scalars, size_t n, G2Xyzz *out) {
+    return msm_run<Fq2>(ctx, d_bases, d_scalars, n, out);
+}
+
+// ------------------------------------------------------------------------------------------ generators (bench/test inputs)
+static __host__ __device__ inline uint64_t splitmix64(uint64_t &s) {
+    s += 0x9E3779B97F4A7C15ull;
+    uint64_t z = s;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// Every lane derives a 254-bit multiplier k_t, computes k_t * G by double-and-add and then walks
+// P, P + D, P + 2D, ... (D = step point) writing PER affine points -- valid, distinct-looking points.
+template <class F>
+__global__ __launch_bounds__(64) void gen_points_kernel(Affine<F> gen, Affine<F> step, Affine<F> *out, size_t n, uint32_t per, uint64_t seed) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t lo = t * per;
+    if (lo >= n) return;
+    uint64_t s = seed ^ (0xA0761D6478BD642Full * (t + 1));
+    uint32_t k[8];
+    for (int i = 0; i < 4; i++) { uint64_t v = splitmix64(s); k[2 * i] = (uint32_t)v; k[2 * i + 1] = (uint32_t)(v >> 32); }
+    k[7] &= 0x0fffffffu;  // < 2^252 < r
+    Xyzz<F> acc = Xyzz<F>::inf();
+    for (int i = 251; i >= 0; i--) {
+        pt_dbl(acc);
+        if ((k[i >> 5] >> (i & 31)) & 1) pt_add_mixed(acc, gen);
+    }
+    size_t hi = lo + per < n ? lo + per : n;
+    for (size_t i = lo; i < hi; i++) {
+        Affine<F> o;
+        pt_to_affine(o, acc);
+        out[i] = o;
+        pt_add_mixed(acc, step);
+    }
+}
+
+static G1Affine g1_generator() { G1Affine g; g.x = Fq::from_u64(1); g.y = Fq::from_u64(2); return g; }
+static Fq fq_words(const uint32_t (&w)[8]) { Fq t; for (int i = 0; i < 8; i++) t.v[i] = w[i]; return t; }
+static G2Affine g2_generator() {
+    const uint32_t x0[8] = FK_G2_GEN_X0, x1[8] = FK_G2_GEN_X1, y0[8] = FK_G2_GEN_Y0, y1[8] = FK_G2_GEN_Y1;
+    G2Affine g;
+    g.x.c0 = fq_words(x0); g.x.c1 = fq_words(x1);
+    g.y.c0 = fq_words(y0); g.y.c1 = fq_words(y1);
+    return g;
+}
+
+template <class F>
+static int gen_points(fk_ctx *ctx, const Affine<F> &gen, Affine<F> *d_out, size_t n, uint64_t seed) {
+    if (!n) return FK_OK;
+    // step point D = kd * G on the host
+    uint64_t s = seed * 0x9E3779B97F4A7C15ull + 12345;
+    uint32_t kd[8];
+    for (int i = 0; i < 4; i++) { uint64_t v = splitmix64(s); kd[2 * i] = (uint32_t)v; kd[2 * i + 1] = (uint32_t)(v >> 32); }
+    kd[7] &= 0x0fffffffu; kd[0] |= 1;
+    Affine<F> step = Xyzz<F>::mul_scalar(Xyzz<F>::from_affine(gen), kd).to_affine();
+    const uint32_t per = 16;
+    const size_t threads = (n + per - 1) / per;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(gen_points_kernel<F>), dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, ctx->stream, gen, step, d_out, n, per, seed);
+    FK_HIP(ctx, hipGetLastError());
+    return FK_OK;
+}
+int gen_points_g1(fk_ctx *ctx, G1Affine *d_out, size_t n, uint64_t seed) { return gen_points<Fq>(ctx, g1_generator(), d_out, n, seed); }
+int gen_points_g2(fk_ctx *ctx, G2Affine *d_out, size_t n, uint64_t seed) { return gen_points<Fq2>(ctx, g2_generator(), d_out, n, seed); }
+
+__global__ void gen_scalars_kernel(Fr *out, size_t n, uint64_t seed, int kind) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t s = seed ^ (0xE7037ED1A0B428DBull * (i + 1));
+    Fr v;
+    for (int k = 0; k < 4; k++) { uint64_t x = splitmix64(s); v.v[2 * k] = (uint32_t)x; v.v[2 * k + 1] = (uint32_t)(x >> 32); }
+    v.v[7] &= 0x0fffffffu;                 // canonical value < 2^252 < r
+    if (kind == 1) {
+        uint64_t sel = splitmix64(s);
+        if (sel & 1) { for (int k = 0; k < 8; k++) v.v[k] = 0; v.v[0] = (uint32_t)((sel >> 1) & 1); }
+    }
+    out[i] = Fr::to_mont(v);
+}
+int gen_scalars(fk_ctx *ctx, Fr *d_out, size_t n, uint64_t seed, int kind) {
+    if (!n) return FK_OK;
+    hipLaunchKernelGGL(gen_scalars_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_out, n, seed, kind);
+    FK_HIP(ctx, hipGetLastError());
+    return FK_OK;
+}
+
+// ------------------------------------------------------------------------------------------ density compaction
+static constexpr uint32_t CP_BLOCK = 2048;  // elements per block (256 threads x 8)
+
+__global__ __launch_bounds__(256) void compact_count_kernel(const uint8_t *dens, size_t n, uint32_t *blk) {
+    __shared__ uint32_t sh[256];
+    const size_t base = (size_t)blockIdx.x * CP_BLOCK + (size_t)threadIdx.x * 8;
+    uint32_t c = 0;
+    for (int k = 0; k < 8; k++) if (base + k < n && dens[base + k]) c++;
+    sh[threadIdx.x] = c;
+    __syncthreads();
+    for (uint32_t off = 128; off; off >>= 1) { if (threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off]; __syncthreads(); }
+    if (threadIdx.x == 0) blk[blockIdx.x] = sh[0];
+}
+// single block exclusive scan of up to 2^16 * 1024 ... entries (each thread strides a contiguous slice)
+__global__ __launch_bounds__(1024) void scan_small_kernel(uint32_t *v, uint32_t n, uint32_t *total) {
+    __shared__ uint32_t part[1024];
+    const uint32_t tid = threadIdx.x, ipt = (n + 1023) / 1024;
+    const uint32_t lo = tid * ipt, hi = lo + ipt < n ? lo + ipt : n;
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi && lo < n; i++) sum += v[i];
+    part[tid] = sum;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+        uint32_t x = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += x;
+        __syncthreads();
+    }
+    uint32_t run = part[tid] - sum;
+    for (uint32_t i = lo; i < hi && lo < n; i++) { uint32_t x = v[i]; v[i] = run; run += x; }
+    if (tid == 1023) *total = part[1023];
+}
+__global__ __launch_bounds__(256) void compact_scatter_kernel(const Fr *z, const uint8_t *dens, size_t n, const uint32_t *blk, Fr *out) {
+    __shared__ uint32_t sh[256];
+    const size_t base = (size_t)blockIdx.x * CP_BLOCK + (size_t)threadIdx.x * 8;
+    uint32_t c = 0;
+    for (int k = 0; k < 8; k++) if (base + k < n && dens[base + k]) c++;
+    sh[threadIdx.x] = c;
+    __syncthreads();
+    for (uint32_t off = 1; off < 256; off <<= 1) {
+        uint32_t x = threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += x;
+        __syncthreads();
+    }
+    size_t pos = (size_t)blk[blockIdx.x] + sh[threadIdx.x] - c;
+    for (int k = 0; k < 8; k++) if (base + k < n && dens[base + k]) out[pos++] = z[base + k];
+}
+
+int compact_scalars(fk_ctx *ctx, const Fr *d_z, const uint8_t *d_density, size_t n, Fr *d_out, uint64_t *n_out) {
+    *n_out = 0;
+    if (!n) return FK_OK;
+    const uint32_t nb = (uint32_t)((n + CP_BLOCK - 1) / CP_BLOCK);
+    FK_HIP(ctx, ctx->scan_tmp.reserve((size_t)nb * 4 + 16));
+    uint32_t *blk = ctx->scan_tmp.as<uint32_t>();
+    uint32_t *d_total = blk + nb;
+    hipLaunchKernelGGL(compact_count_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_density, n, blk);
+    FK_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, ctx->stream, blk, nb, d_total);
+    FK_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(compact_scatter_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_z, d_density, n, blk, d_out);
+    FK_HIP(ctx, hipGetLastError());
+    uint32_t total = 0;
+    FK_HIP(ctx, hipMemcpyAsync(&total, d_total, 4, hipMemcpyDeviceToHost, ctx->stream));
+    FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *n_out = total;
+    return FK_OK;
+}
+
+}  // namespace fk

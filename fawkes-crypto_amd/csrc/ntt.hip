@@ -1,0 +1,323 @@
+// BN254 Fr radix-2 NTT / iNTT over bellman's evaluation domain and the A*B-C quotient pipeline.
+//
+// Replaces bellman_ce::domain::EvaluationDomain::{ifft, coset_fft, mul_assign, sub_assign,
+// divide_by_z_on_coset, icoset_fft} as driven by bellman's prover (reached from
+// /root/reference/fawkes-crypto/src/backend/bellman_groth16/prover.rs:80).  Convention: natural order
+// in and out, out[k] = sum_j in[j] * omega^(jk), omega = ROOT_OF_UNITY^(2^(S-exp)), generator 7
+// (fawkes-crypto/src/engines/bn256/mod.rs:23-24).
+//
+// MI355X design: a Stockham autosort decomposition (no bit-reversal pass over HBM).  The transform of
+// size N = 2^k is cut into P = ceil(k/9) passes; pass i does radix-2^deg_i sub-transforms entirely in
+// LDS.  A workgroup owns a tile of R = 2^deg rows x C adjacent columns so that every HBM access is a
+// run of C*32 contiguous bytes (coalesced 16 B/lane loads), stages it in LDS as two 16-byte planes
+// (conflict-free ds_read_b128/ds_write_b128), runs deg butterfly stages (decimation in frequency,
+// bit-reversed inside the tile only), and writes the tile to its autosorted position.  Inter-pass
+// twiddles omega^(k*r*N/(pR)) come from a two-level table (2^L + 2^(k-L) entries, L2-resident).
+// The coset shift (g^i), the 1/m scaling, the 1/Z(g) factor and the pointwise a*b-c are fused into
+// the first/last pass of the neighbouring transform, so the whole quotient is 7 transforms =
+// 7*P passes, each reading and writing every element once (64 B/element/pass algorithmic traffic).
+#include "common.hpp"
+
+namespace fk {
+
+static constexpr uint32_t NTT_MAXDEG = 9;       // R <= 512
+static constexpr uint32_t NTT_TILE_LOG = 11;    // R*C <= 2048 elements = 64 KiB of LDS
+static constexpr uint32_t NTT_THREADS = 256;
+
+enum { PRE_NONE = 0, PRE_TABLE = 1, PRE_ABC = 2 };
+enum { POST_NONE = 0, POST_CONST = 1, POST_TABLE = 2 };
+
+struct ScaleTable {          // value(i) = lo[i & (2^L - 1)] * hi[i >> L]
+    Fr *lo = nullptr, *hi = nullptr;
+};
+
+struct NttDomain {
+    uint32_t log_n = 0, L = 0, maxdeg = 0;
+    std::vector<uint32_t> degs;
+    Fr omega, omega_inv, minv, zinv;
+    Fr *tw_lo[2] = {nullptr, nullptr}, *tw_hi[2] = {nullptr, nullptr};   // [0] forward, [1] inverse
+    Fr *pq[2] = {nullptr, nullptr};                                       // omega_Rmax^e, e < Rmax/2
+    ScaleTable t_g, t_ginv_minv, t_g_minv, t_ginv_minv_zinv;
+    std::vector<void *> allocs;
+};
+
+struct PassArgs {
+    const Fr *x, *xb, *xc;
+    Fr *y;
+    uint32_t log_n, deg, lgp, logC;
+    const Fr *tw_lo, *tw_hi;
+    uint32_t L;
+    const Fr *pq;
+    uint32_t pq_shift;
+    int pre_mode;
+    const Fr *pre_lo, *pre_hi;
+    int post_mode;
+    Fr post_const;
+    const Fr *post_lo, *post_hi;
+};
+
+static __device__ __forceinline__ void lds_put(uint4 *p0, uint4 *p1, uint32_t e, const Fr &v) {
+    p0[e] = make_uint4(v.v[0], v.v[1], v.v[2], v.v[3]);
+    p1[e] = make_uint4(v.v[4], v.v[5], v.v[6], v.v[7]);
+}
+static __device__ __forceinline__ Fr lds_get(const uint4 *p0, const uint4 *p1, uint32_t e) {
+    uint4 a = p0[e], b = p1[e];
+    Fr v; v.v[0] = a.x; v.v[1] = a.y; v.v[2] = a.z; v.v[3] = a.w; v.v[4] = b.x; v.v[5] = b.y; v.v[6] = b.z; v.v[7] = b.w;
+    return v;
+}
+
+__global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(PassArgs a) {
+    extern __shared__ uint4 lds[];
+    const uint32_t R = 1u << a.deg, C = 1u << a.logC, tile = R << a.logC;
+    uint4 *p0 = lds, *p1 = lds + tile;
+    const uint32_t tid = threadIdx.x;
+    const uint64_t t = (uint64_t)1 << (a.log_n - a.deg);        // stride between the R inputs
+    const uint64_t pmask = ((uint64_t)1 << a.lgp) - 1;
+    const uint64_t i_base = (uint64_t)blockIdx.x << a.logC;
+    const uint32_t Lmask = (1u << a.L) - 1;
+
+    // ---- load tile (rows r, columns c), fused pre-op and inter-pass twiddle
+    for (uint32_t e = tid; e < tile; e += NTT_THREADS) {
+        const uint32_t c = e & (C - 1), r = e >> a.logC;
+        const uint64_t i = i_base + c;
+        const uint64_t idx = i + (uint64_t)r * t;
+        Fr v = a.x[idx];
+        if (a.pre_mode == PRE_ABC) {
+            v = Fr::sub(Fr::mul(v, a.xb[idx]), a.xc[idx]);
+        } else if (a.pre_mode == PRE_TABLE) {
+            v = Fr::mul(v, Fr::mul(a.pre_lo[idx & Lmask], a.pre_hi[idx >> a.L]));
+        }
+        if (a.lgp) {
+            const uint64_t k = i & pmask;
+            const uint64_t ee = (k * r) << (a.log_n - a.lgp - a.deg);
+            if (ee) v = Fr::mul(v, Fr::mul(a.tw_lo[ee & Lmask], a.tw_hi[ee >> a.L]));
+        }
+        lds_put(p0, p1, e, v);
+    }
+    __syncthreads();
+
+    // ---- deg radix-2 DIF stages in LDS
+    const uint32_t nbf = tile >> 1;
+    for (uint32_t rnd = 0; rnd < a.deg; rnd++) {
+        const uint32_t bit = (R >> 1) >> rnd;
+        for (uint32_t bf = tid; bf < nbf; bf += NTT_THREADS) {
+            const uint32_t c = bf & (C - 1), ii = bf >> a.logC;
+            const uint32_t di = ii & (bit - 1);
+            const uint32_t i0 = ((ii - di) << 1) + di, i1 = i0 + bit;
+            const uint32_t e0 = (i0 << a.logC) + c, e1 = (i1 << a.logC) + c;
+            Fr u = lds_get(p0, p1, e0), w = lds_get(p0, p1, e1);
+            Fr s = Fr::add(u, w), d = Fr::sub(u, w);
+            if (di) d = Fr::mul(d, a.pq[(di << rnd) << a.pq_shift]);
+            lds_put(p0, p1, e0, s);
+            lds_put(p0, p1, e1, d);
+        }
+        __syncthreads();
+    }
+
+    // ---- store tile to its autosorted place, fused post-op
+    for (uint32_t e = tid; e < tile; e += NTT_THREADS) {
+        uint32_t c, rr;
+        if (a.lgp == 0) { rr = e & (R - 1); c = e >> a.deg; }      // first pass: runs of R outputs
+        else { c = e & (C - 1); rr = e >> a.logC; }                // later passes: runs of C outputs
+        const uint32_t q = a.deg ? (__brev(rr) >> (32 - a.deg)) : 0;
+        Fr v = lds_get(p0, p1, (q << a.logC) + c);
+        const uint64_t i = i_base + c;
+        const uint64_t k = i & pmask;
+        const uint64_t o = ((i - k) << a.deg) + k + ((uint64_t)rr << a.lgp);
+        if (a.post_mode == POST_CONST) v = Fr::mul(v, a.post_const);
+        else if (a.post_mode == POST_TABLE) v = Fr::mul(v, Fr::mul(a.post_lo[o & Lmask], a.post_hi[o >> a.L]));
+        a.y[o] = v;
+    }
+}
+
+__global__ void fr_mul_batch_kernel(const Fr *a, const Fr *b, Fr *o, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) o[i] = Fr::mul(a[i], b[i]);
+}
+
+int fr_mul_batch_dev(fk_ctx *ctx, const Fr *a, const Fr *b, Fr *o, size_t n) {
+    if (!n) return FK_OK;
+    hipLaunchKernelGGL(fr_mul_batch_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, a, b, o, n);
+    FK_HIP(ctx, hipGetLastError());
+    return FK_OK;
+}
+
+// ------------------------------------------------------------------------------------------ domain setup (host)
+static Fr host_const(const uint32_t (&w)[8]) { Fr r; for (int i = 0; i < 8; i++) r.v[i] = w[i]; return r; }
+
+static int upload_table(fk_ctx *ctx, NttDomain *d, const std::vector<Fr> &h, Fr **out) {
+    void *p = nullptr;
+    FK_HIP(ctx, hipMalloc(&p, h.size() * sizeof(Fr)));
+    d->allocs.push_back(p);
+    FK_HIP(ctx, hipMemcpy(p, h.data(), h.size() * sizeof(Fr), hipMemcpyHostToDevice));
+    *out = (Fr *)p;
+    return FK_OK;
+}
+
+// lo[i] = c * base^i (i < 2^L), hi[j] = base^(j 2^L) (j < 2^(k-L))
+static int make_scale_table(fk_ctx *ctx, NttDomain *d, const Fr &base, const Fr &c, ScaleTable *t) {
+    const uint32_t nlo = 1u << d->L, nhi = 1u << (d->log_n - d->L);
+    std::vector<Fr> lo(nlo), hi(nhi);
+    Fr cur = c, pw = Fr::one();
+    for (uint32_t i = 0; i < nlo; i++) { lo[i] = cur; cur = Fr::mul(cur, base); pw = Fr::mul(pw, base); }
+    // pw = base^(2^L)
+    cur = Fr::one();
+    for (uint32_t j = 0; j < nhi; j++) { hi[j] = cur; cur = Fr::mul(cur, pw); }
+    FK_TRY(upload_table(ctx, d, lo, &t->lo));
+    FK_TRY(upload_table(ctx, d, hi, &t->hi));
+    return FK_OK;
+}
+
+static int get_domain(fk_ctx *ctx, uint32_t log_n, NttDomain **out) {
+    auto it = ctx->domains.find(log_n);
+    if (it != ctx->domains.end()) { *out = it->second; return FK_OK; }
+    // bellman's EvaluationDomain::from_coeffs rejects exp >= S
+    if (log_n >= FK_FR_S) FK_SET_ERR(ctx, FK_ERR_DOMAIN_TOO_LARGE, "evaluation domain 2^%u too large (max 2^%d)", log_n, FK_FR_S - 1);
+    NttDomain *d = new NttDomain();
+    d->log_n = log_n;
+    d->L = (log_n + 1) / 2;
+    const uint32_t P = log_n ? (log_n + NTT_MAXDEG - 1) / NTT_MAXDEG : 1;
+    const uint32_t base = log_n / P, extra = log_n % P;
+    for (uint32_t i = 0; i < P; i++) d->degs.push_back(base + (i < extra ? 1 : 0));
+    d->maxdeg = d->degs[0];
+    const uint32_t root_w[8] = FK_FR_ROOT, gen_w[8] = FK_FR_GEN, geninv_w[8] = FK_FR_GEN_INV;
+    Fr om = host_const(root_w);
+    for (uint32_t i = log_n; i < FK_FR_S; i++) om = Fr::sqr(om);
+    d->omega = om;
+    d->omega_inv = Fr::inv(om);
+    d->minv = Fr::inv(Fr::from_u64((uint64_t)1 << log_n));
+    const Fr g = host_const(gen_w), ginv = host_const(geninv_w);
+    d->zinv = Fr::inv(Fr::sub(Fr::pow_u64(g, (uint64_t)1 << log_n), Fr::one()));
+    int rc = FK_OK;
+    for (int dir = 0; dir < 2 && rc == FK_OK; dir++) {
+        const Fr w = dir ? d->omega_inv : d->omega;
+        ScaleTable t;
+        rc = make_scale_table(ctx, d, w, Fr::one(), &t);
+        d->tw_lo[dir] = t.lo; d->tw_hi[dir] = t.hi;
+        if (rc != FK_OK) break;
+        // pq[e] = (w^(N/Rmax))^e
+        const uint32_t half = d->maxdeg ? (1u << (d->maxdeg - 1)) : 1;
+        Fr wr = w;
+        for (uint32_t i = d->maxdeg; i < log_n; i++) wr = Fr::sqr(wr);
+        std::vector<Fr> pq(half);
+        Fr cur = Fr::one();
+        for (uint32_t e = 0; e < half; e++) { pq[e] = cur; cur = Fr::mul(cur, wr); }
+        rc = upload_table(ctx, d, pq, &d->pq[dir]);
+    }
+    if (rc == FK_OK) rc = make_scale_table(ctx, d, g, Fr::one(), &d->t_g);
+    if (rc == FK_OK) rc = make_scale_table(ctx, d, ginv, d->minv, &d->t_ginv_minv);
+    if (rc == FK_OK) rc = make_scale_table(ctx, d, g, d->minv, &d->t_g_minv);
+    if (rc == FK_OK) rc = make_scale_table(ctx, d, ginv, Fr::mul(d->minv, d->zinv), &d->t_ginv_minv_zinv);
+    if (rc != FK_OK) { for (void *p : d->allocs) (void)hipFree(p); delete d; return rc; }
+    ctx->domains[log_n] = d;
+    *out = d;
+    return FK_OK;
+}
+
+void ntt_free_domains(fk_ctx *ctx) {
+    for (auto &kv : ctx->domains) { for (void *p : kv.second->allocs) (void)hipFree(p); delete kv.second; }
+    ctx->domains.clear();
+}
+
+struct NttOp {
+    bool inverse = false;
+    int pre_mode = PRE_NONE; const ScaleTable *pre = nullptr; const Fr *xb = nullptr, *xc = nullptr;
+    int post_mode = POST_NONE; Fr post_const; const ScaleTable *post = nullptr;
+};
+
+// Runs all passes: in -> ... -> final_dst, intermediates alternate between tmp1 and tmp2.
+// Requirements: tmp1 != tmp2, neither aliases in / xb / xc / final_dst; final_dst may alias `in` only
+// when there are >= 2 passes.
+static int ntt_exec(fk_ctx *ctx, NttDomain *d, const NttOp &op, const Fr *in, Fr *tmp1, Fr *tmp2, Fr *final_dst) {
+    const uint32_t P = (uint32_t)d->degs.size();
+    const int dir = op.inverse ? 1 : 0;
+    const Fr *src = in;
+    uint32_t lgp = 0;
+    for (uint32_t i = 0; i < P; i++) {
+        const uint32_t deg = d->degs[i];
+        Fr *dst;
+        if (i == P - 1) dst = final_dst;
+        else dst = (((P - 2 - i) & 1) == 0) ? tmp1 : tmp2;
+        PassArgs a{};
+        a.x = src; a.xb = op.xb; a.xc = op.xc; a.y = dst;
+        a.log_n = d->log_n; a.deg = deg; a.lgp = lgp;
+        uint32_t logC = 3;
+        if (logC > NTT_TILE_LOG - deg) logC = NTT_TILE_LOG - deg;
+        if (logC > d->log_n - deg) logC = d->log_n - deg;
+        a.logC = logC;
+        a.tw_lo = d->tw_lo[dir]; a.tw_hi = d->tw_hi[dir]; a.L = d->L;
+        a.pq = d->pq[dir]; a.pq_shift = d->maxdeg - deg;
+        a.pre_mode = (i == 0) ? op.pre_mode : PRE_NONE;
+        if (op.pre) { a.pre_lo = op.pre->lo; a.pre_hi = op.pre->hi; }
+        a.post_mode = (i == P - 1) ? op.post_mode : POST_NONE;
+        a.post_const = op.post_const;
+        if (op.post) { a.post_lo = op.post->lo; a.post_hi = op.post->hi; }
+        const uint64_t nblk = ((uint64_t)1 << (d->log_n - deg)) >> logC;
+        const size_t lds_bytes = (size_t)2 * sizeof(uint4) << (deg + logC);
+        FK_HIP(ctx, hipFuncSetAttribute((const void *)ntt_pass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        FK_TRY(stats_begin(ctx, ctx->ev_ntt, (uint64_t)1 << d->log_n));
+        hipLaunchKernelGGL(ntt_pass_kernel, dim3((unsigned)nblk), dim3(NTT_THREADS), lds_bytes, ctx->stream, a);
+        FK_HIP(ctx, hipGetLastError());
+        FK_TRY(stats_end(ctx, ctx->ev_ntt));
+        src = dst;
+        lgp += deg;
+    }
+    return FK_OK;
+}
+
+// In-place transform of a device array (fk_ntt / fk_ntt_dev).
+int ntt_exec_simple(fk_ctx *ctx, Fr *d_data, uint32_t log_n, bool inverse, bool coset) {
+    NttDomain *d = nullptr;
+    FK_TRY(get_domain(ctx, log_n, &d));
+    const size_t bytes = sizeof(Fr) << log_n;
+    FK_HIP(ctx, ctx->ntt_s1.reserve(bytes));
+    FK_HIP(ctx, ctx->ntt_s2.reserve(bytes));
+    NttOp op;
+    op.inverse = inverse;
+    if (!inverse && coset) { op.pre_mode = PRE_TABLE; op.pre = &d->t_g; }            // coset_fft
+    if (inverse && !coset) { op.post_mode = POST_CONST; op.post_const = d->minv; }   // ifft
+    if (inverse && coset) { op.post_mode = POST_TABLE; op.post = &d->t_ginv_minv; }  // icoset_fft
+    if (d->degs.size() >= 2) return ntt_exec(ctx, d, op, d_data, ctx->ntt_s1.as<Fr>(), ctx->ntt_s2.as<Fr>(), d_data);
+    FK_TRY(ntt_exec(ctx, d, op, d_data, ctx->ntt_s1.as<Fr>(), ctx->ntt_s2.as<Fr>(), ctx->ntt_s1.as<Fr>()));
+    FK_HIP(ctx, hipMemcpyAsync(d_data, ctx->ntt_s1.p, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return FK_OK;
+}
+
+// h = (A*B - C)/Z.  d_a, d_b, d_c: device arrays with CAPACITY m = next_pow2(n) elements, the first n
+// hold the row evaluations; they are used as scratch.  d_h_out: m elements, the first m-1 are h.
+int quotient_dev(fk_ctx *ctx, Fr *d_a, Fr *d_b, Fr *d_c, uint64_t n, Fr *d_h_out, uint64_t *m_out) {
+    if (n == 0) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "quotient: n == 0");
+    const uint32_t log_n = ceil_log2_u64(n);
+    NttDomain *d = nullptr;
+    FK_TRY(get_domain(ctx, log_n, &d));
+    const uint64_t m = (uint64_t)1 << log_n;
+    if (m_out) *m_out = m;
+    const size_t bytes = sizeof(Fr) << log_n;
+    FK_HIP(ctx, ctx->ntt_s1.reserve(bytes));
+    FK_HIP(ctx, ctx->ntt_s2.reserve(bytes));
+    Fr *s1 = ctx->ntt_s1.as<Fr>(), *s2 = ctx->ntt_s2.as<Fr>();
+    Fr *polys[3] = {d_a, d_b, d_c};
+    const bool multi = d->degs.size() >= 2;
+    for (int k = 0; k < 3; k++) {
+        Fr *x = polys[k];
+        if (m > n) FK_HIP(ctx, hipMemsetAsync(x + n, 0, (m - n) * sizeof(Fr), ctx->stream));
+        // ifft followed by the coset shift g^i (first half of coset_fft), fused: * g^i / m on the way out
+        NttOp inv; inv.inverse = true; inv.post_mode = POST_TABLE; inv.post = &d->t_g_minv;
+        NttOp fwd;  // the transform part of coset_fft
+        if (multi) {
+            FK_TRY(ntt_exec(ctx, d, inv, x, s1, s2, x));
+            FK_TRY(ntt_exec(ctx, d, fwd, x, s1, s2, x));
+        } else {
+            FK_TRY(ntt_exec(ctx, d, inv, x, s1, s2, s1));
+            FK_TRY(ntt_exec(ctx, d, fwd, s1, s2, s2, x));
+        }
+    }
+    // a*b - c on the coset (fused into the first pass), divide_by_z_on_coset and icoset_fft's g^-i / m
+    // (fused into the last pass)
+    NttOp fin; fin.inverse = true; fin.pre_mode = PRE_ABC; fin.xb = d_b; fin.xc = d_c;
+    fin.post_mode = POST_TABLE; fin.post = &d->t_ginv_minv_zinv;
+    FK_TRY(ntt_exec(ctx, d, fin, d_a, s1, s2, d_h_out));
+    return FK_OK;
+}
+
+}  // namespace fk

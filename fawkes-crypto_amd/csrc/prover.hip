@@ -1,0 +1,584 @@
+// C-ABI entry points of libfawkes_hip.so (declared in include/fawkes_hip.h) and the Groth16 prover
+// pipeline that replaces bellman's `create_proof` behind
+// /root/reference/fawkes-crypto/src/backend/bellman_groth16/prover.rs:80 (algorithm: SURVEY.md App. A.1-A.5).
+//
+// Device pipeline per proof (one HIP stream, key resident in HBM):
+//   quotient (7 fused NTTs, ntt.hip)  ->  h
+//   scalar vectors: h | z_aux | z_in ++ compact(z_aux, a_aux) | compact(z_in, b_in) ++ compact(z_aux, b_aux)
+//   five Pippenger MSMs (msm.hip) against the resident key slices
+//   host: XYZZ -> affine, proof assembly with r, s and the vk points (a handful of group operations)
+#include "common.hpp"
+#include <chrono>
+#include <string.h>
+
+using namespace fk;
+
+namespace fk {
+
+int stats_begin(fk_ctx *ctx, std::vector<EventPair> &v, uint64_t units) {
+    if (!ctx->stats_on) return FK_OK;
+    EventPair ep{};
+    ep.units = units;
+    for (hipEvent_t *e : {&ep.a, &ep.b}) {
+        if (!ctx->ev_pool.empty()) { *e = ctx->ev_pool.back(); ctx->ev_pool.pop_back(); }
+        else FK_HIP(ctx, hipEventCreate(e));
+    }
+    FK_HIP(ctx, hipEventRecord(ep.a, ctx->stream));
+    v.push_back(ep);
+    return FK_OK;
+}
+int stats_end(fk_ctx *ctx, std::vector<EventPair> &v) {
+    if (!ctx->stats_on) return FK_OK;
+    FK_HIP(ctx, hipEventRecord(v.back().b, ctx->stream));
+    return FK_OK;
+}
+
+static void g1_to_raw(uint8_t out[64], const G1Xyzz &p) { G1Affine a = p.to_affine(); memcpy(out, &a, 64); }
+static void g2_to_raw(uint8_t out[128], const G2Xyzz &p) { G2Affine a = p.to_affine(); memcpy(out, &a, 128); }
+static G1Affine g1_from_raw(const uint8_t *b) { G1Affine a; memcpy(&a, b, 64); return a; }
+static G2Affine g2_from_raw(const uint8_t *b) { G2Affine a; memcpy(&a, b, 128); return a; }
+
+static void slice(uint64_t n, uint32_t idx, uint32_t cnt, uint64_t *lo, uint64_t *hi) {
+    *lo = (uint64_t)((unsigned __int128)n * idx / cnt);
+    *hi = (uint64_t)((unsigned __int128)n * (idx + 1) / cnt);
+}
+
+static double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace fk
+
+static_assert(sizeof(G1Affine) == 64 && sizeof(G2Affine) == 128 && sizeof(Fr) == 32, "raw layouts");
+
+extern "C" {
+
+// ------------------------------------------------------------------------------------------ context
+int fk_init(int device_id, fk_ctx **out) {
+    if (!out) return FK_ERR_BAD_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return FK_ERR_HIP;   // no GPU: fail loudly, no CPU fallback
+    if (device_id < 0 || device_id >= ndev) return FK_ERR_BAD_ARG;
+    if (hipSetDevice(device_id) != hipSuccess) return FK_ERR_HIP;
+    fk_ctx *ctx = new fk_ctx();
+    ctx->device = device_id;
+    if (hipStreamCreate(&ctx->stream) != hipSuccess) { delete ctx; return FK_ERR_HIP; }
+    *out = ctx;
+    return FK_OK;
+}
+
+void fk_free(fk_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    ntt_free_domains(ctx);
+    for (DevBuf *b : {&ctx->digits, &ctx->sorted, &ctx->counts, &ctx->totals, &ctx->starts, &ctx->buckets, &ctx->winparts,
+                      &ctx->overlist, &ctx->tasktab, &ctx->partials, &ctx->misc, &ctx->ntt_s1, &ctx->ntt_s2, &ctx->ntt_io,
+                      &ctx->hbuf, &ctx->sc_a, &ctx->sc_b, &ctx->scan_tmp, &ctx->stage_a, &ctx->stage_b, &ctx->stage_c,
+                      &ctx->stage_z, &ctx->stage_d})
+        b->release();
+    for (auto &v : {&ctx->ev_acc, &ctx->ev_ntt}) for (auto &ep : *v) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
+    for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *fk_last_error(const fk_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int fk_set_window_bits(fk_ctx *ctx, unsigned c) {
+    if (!ctx) return FK_ERR_BAD_ARG;
+    if (c != 0 && (c < 2 || c > 16)) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "window bits must be 0 or 2..16");
+    ctx->window_bits = c;
+    return FK_OK;
+}
+
+// ------------------------------------------------------------------------------------------ device buffers
+int fk_dev_alloc(fk_ctx *ctx, size_t bytes, void **dptr) {
+    if (!ctx || !dptr) return FK_ERR_BAD_ARG;
+    FK_HIP(ctx, hipSetDevice(ctx->device));
+    FK_HIP(ctx, hipMalloc(dptr, bytes ? bytes : 16));
+    return FK_OK;
+}
+int fk_dev_free(fk_ctx *ctx, void *dptr) {
+    if (!ctx) return FK_ERR_BAD_ARG;
+    if (dptr) FK_HIP(ctx, hipFree(dptr));
+    return FK_OK;
+}
+int fk_upload(fk_ctx *ctx, void *dptr, const void *host, size_t bytes) {
+    if (!ctx) return FK_ERR_BAD_ARG;
+    if (bytes) FK_HIP(ctx, hipMemcpyAsync(dptr, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FK_OK;
+}
+int fk_download(fk_ctx *ctx, void *host, const void *dptr, size_t bytes) {
+    if (!ctx) return FK_ERR_BAD_ARG;
+    if (bytes) FK_HIP(ctx, hipMemcpyAsync(host, dptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FK_OK;
+}
+int fk_sync(fk_ctx *ctx) {
+    if (!ctx) return FK_ERR_BAD_ARG;
+    FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FK_OK;
+}
+
+// ------------------------------------------------------------------------------------------ key
+static int key_alloc_slices(fk_ctx *ctx, fk_key *k) {
+    slice(k->n_h, k->shard_index, k->shard_count, &k->h_lo, &k->h_hi);
+    slice(k->n_l, k->shard_index, k->shard_count, &k->l_lo, &k->l_hi);
+    slice(k->n_a, k->shard_index, k->shard_count, &k->a_lo, &k->a_hi);
+    slice(k->n_b, k->shard_index, k->shard_count, &k->b_lo, &k->b_hi);
+    FK_HIP(ctx, hipMalloc((void **)&k->d_h, (k->h_hi - k->h_lo) * 64 + 64));
+    FK_HIP(ctx, hipMalloc((void **)&k->d_l, (k->l_hi - k->l_lo) * 64 + 64));
+    FK_HIP(ctx, hipMalloc((void **)&k->d_a, (k->a_hi - k->a_lo) * 64 + 64));
+    FK_HIP(ctx, hipMalloc((void **)&k->d_b1, (k->b_hi - k->b_lo) * 64 + 64));
+    FK_HIP(ctx, hipMalloc((void **)&k->d_b2, (k->b_hi - k->b_lo) * 128 + 128));
+    return FK_OK;
+}
+
+void fk_key_free(fk_ctx *ctx, fk_key *k) {
+    if (!k) return;
+    if (ctx) (void)hipSetDevice(ctx->device);
+    for (void *p : {(void *)k->d_h, (void *)k->d_l, (void *)k->d_a, (void *)k->d_b1, (void *)k->d_b2}) if (p) (void)hipFree(p);
+    delete k;
+}
+
+static int key_check_shape(fk_ctx *ctx, uint64_t m, uint32_t num_input, uint64_t n_h, uint64_t n_l, uint32_t num_aux,
+                           uint32_t shard_index, uint32_t shard_count) {
+    if (m == 0 || (m & (m - 1))) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "key: m must be a power of two");
+    if (m > ((uint64_t)1 << (FK_FR_S - 1))) FK_SET_ERR(ctx, FK_ERR_DOMAIN_TOO_LARGE, "key: m exceeds 2^%d", FK_FR_S - 1);
+    if (num_input == 0) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "key: num_input must include the constant ONE");
+    if (n_h != m - 1) FK_SET_ERR(ctx, FK_ERR_KEY_MISMATCH, "key: h must hold m-1 points");
+    if (n_l != num_aux) FK_SET_ERR(ctx, FK_ERR_KEY_MISMATCH, "key: l must hold num_aux points");
+    if (shard_count == 0 || shard_index >= shard_count) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "key: bad shard %u/%u", shard_index, shard_count);
+    return FK_OK;
+}
+
+int fk_key_load(fk_ctx *ctx, const fk_key_desc *d, fk_key **out) {
+    if (!ctx || !d || !out) return FK_ERR_BAD_ARG;
+    *out = nullptr;
+    FK_HIP(ctx, hipSetDevice(ctx->device));
+    FK_TRY(key_check_shape(ctx, d->m, d->num_input, d->n_h, d->n_l, d->num_aux, d->shard_index, d->shard_count));
+    if (!d->alpha_g1 || !d->beta_g1 || !d->delta_g1 || !d->beta_g2 || !d->delta_g2) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "key: missing vk points");
+    if ((d->n_h && !d->h) || (d->n_l && !d->l) || (d->n_a && !d->a) || (d->n_b && (!d->b_g1 || !d->b_g2)))
+        FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "key: missing key array");
+    fk_key *k = new fk_key();
+    k->m = d->m; k->num_input = d->num_input; k->num_aux = d->num_aux;
+    k->n_h = d->n_h; k->n_l = d->n_l; k->n_a = d->n_a; k->n_b = d->n_b;
+    k->shard_index = d->shard_index; k->shard_count = d->shard_count;
+    k->alpha_g1 = g1_from_raw(d->alpha_g1); k->beta_g1 = g1_from_raw(d->beta_g1); k->delta_g1 = g1_from_raw(d->delta_g1);
+    k->beta_g2 = g2_from_raw(d->beta_g2); k->delta_g2 = g2_from_raw(d->delta_g2);
+    int rc = key_alloc_slices(ctx, k);
+    auto up = [&](void *dst, const uint8_t *src, uint64_t lo, uint64_t hi, size_t w) -> int {
+        if (hi > lo) FK_HIP(ctx, hipMemcpy(dst, src + lo * w, (hi - lo) * w, hipMemcpyHostToDevice));
+        return FK_OK;
+    };
+    if (rc == FK_OK) rc = up(k->d_h, d->h, k->h_lo, k->h_hi, 64);
+    if (rc == FK_OK) rc = up(k->d_l, d->l, k->l_lo, k->l_hi, 64);
+    if (rc == FK_OK) rc = up(k->d_a, d->a, k->a_lo, k->a_hi, 64);
+    if (rc == FK_OK) rc = up(k->d_b1, d->b_g1, k->b_lo, k->b_hi, 64);
+    if (rc == FK_OK) rc = up(k->d_b2, d->b_g2, k->b_lo, k->b_hi, 128);
+    if (rc != FK_OK) { fk_key_free(ctx, k); return rc; }
+    *out = k;
+    return FK_OK;
+}
+
+int fk_key_host_vk(const uint8_t *alpha_g1, const uint8_t *beta_g1, const uint8_t *delta_g1, const uint8_t *beta_g2,
+                   const uint8_t *delta_g2, fk_key **out) {
+    if (!alpha_g1 || !beta_g1 || !delta_g1 || !beta_g2 || !delta_g2 || !out) return FK_ERR_BAD_ARG;
+    fk_key *k = new fk_key();
+    k->alpha_g1 = g1_from_raw(alpha_g1); k->beta_g1 = g1_from_raw(beta_g1); k->delta_g1 = g1_from_raw(delta_g1);
+    k->beta_g2 = g2_from_raw(beta_g2); k->delta_g2 = g2_from_raw(delta_g2);
+    *out = k;
+    return FK_OK;
+}
+
+int fk_key_synthetic(fk_ctx *ctx, uint64_t m, uint32_t num_input, uint32_t num_aux, uint64_t n_a, uint64_t n_b,
+                     uint64_t seed, uint32_t shard_index, uint32_t shard_count, fk_key **out) {
+    if (!ctx || !out) return FK_ERR_BAD_ARG;
+    *out = nullptr;
+    FK_HIP(ctx, hipSetDevice(ctx->device));
+    FK_TRY(key_check_shape(ctx, m, num_input, m - 1, num_aux, num_aux, shard_index, shard_count));
+    fk_key *k = new fk_key();
+    k->m = m; k->num_input = num_input; k->num_aux = num_aux;
+    k->n_h = m - 1; k->n_l = num_aux; k->n_a = n_a; k->n_b = n_b;
+    k->shard_index = shard_index; k->shard_count = shard_count;
+    int rc = key_alloc_slices(ctx, k);
+    const uint64_t sd = seed * 1000003ull + shard_index * 7919ull;
+    if (rc == FK_OK) rc = gen_points_g1(ctx, k->d_h, k->h_hi - k->h_lo, sd + 1);
+    if (rc == FK_OK) rc = gen_points_g1(ctx, k->d_l, k->l_hi - k->l_lo, sd + 2);
+    if (rc == FK_OK) rc = gen_points_g1(ctx, k->d_a, k->a_hi - k->a_lo, sd + 3);
+    if (rc == FK_OK) rc = gen_points_g1(ctx, k->d_b1, k->b_hi - k->b_lo, sd + 4);
+    if (rc == FK_OK) rc = gen_points_g2(ctx, k->d_b2, k->b_hi - k->b_lo, sd + 5);
+    // vk points: five of the generated points (same on every shard: taken from a seed-only tiny run)
+    if (rc == FK_OK) {
+        FK_HIP(ctx, ctx->misc.reserve(8 * 128));
+        G1Affine *t1 = ctx->misc.as<G1Affine>();
+        rc = gen_points_g1(ctx, t1, 3, seed + 99);
+        G1Affine h1[3];
+        if (rc == FK_OK) { if (hipMemcpy(h1, t1, sizeof h1, hipMemcpyDeviceToHost) != hipSuccess) rc = FK_ERR_HIP; }
+        G2Affine *t2 = ctx->misc.as<G2Affine>();
+        if (rc == FK_OK) rc = gen_points_g2(ctx, t2, 2, seed + 98);
+        G2Affine h2[2];
+        if (rc == FK_OK) { if (hipMemcpy(h2, t2, sizeof h2, hipMemcpyDeviceToHost) != hipSuccess) rc = FK_ERR_HIP; }
+        k->alpha_g1 = h1[0]; k->beta_g1 = h1[1]; k->delta_g1 = h1[2]; k->beta_g2 = h2[0]; k->delta_g2 = h2[1];
+    }
+    if (rc == FK_OK) { if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = FK_ERR_HIP; }
+    if (rc != FK_OK) { fk_key_free(ctx, k); return rc; }
+    *out = k;
+    return FK_OK;
+}
+
+// ------------------------------------------------------------------------------------------ prover
+static int prove_msms_dev(fk_ctx *ctx, const fk_key *key, Fr *d_a, Fr *d_b, Fr *d_c, uint64_t n, const Fr *d_z,
+                          const uint8_t *d_a_aux, const uint8_t *d_b_in, const uint8_t *d_b_aux, uint8_t out[FK_MSM_RESULT_BYTES],
+                          fk_timings *tm) {
+    if (!key || !d_a || !d_b || !d_c || !d_z || !out) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "prove: null argument");
+    if (n == 0 || n > key->m || (key->m > 1 && n <= key->m / 2)) FK_SET_ERR(ctx, FK_ERR_KEY_MISMATCH, "prove: %llu rows do not match key domain %llu",
+                                                      (unsigned long long)n, (unsigned long long)key->m);
+    FK_HIP(ctx, hipSetDevice(ctx->device));
+    const uint32_t v_in = key->num_input, v_aux = key->num_aux;
+    const double t0 = now_ms();
+    FK_HIP(ctx, ctx->hbuf.reserve(key->m * sizeof(Fr)));
+    Fr *d_h = ctx->hbuf.as<Fr>();
+    uint64_t m = 0;
+    FK_TRY(quotient_dev(ctx, d_a, d_b, d_c, n, d_h, &m));
+    FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const double t1 = now_ms();
+    G1Xyzz H, L, A, B1; G2Xyzz B2;
+    FK_TRY(msm_g1_dev(ctx, key->d_h, d_h + key->h_lo, key->h_hi - key->h_lo, &H));
+    const double t2 = now_ms();
+    FK_TRY(msm_g1_dev(ctx, key->d_l, d_z + v_in + key->l_lo, key->l_hi - key->l_lo, &L));
+    const double t3 = now_ms();
+    // A query: all inputs, then the aux variables that occur in some A-side LC
+    FK_HIP(ctx, ctx->sc_a.reserve(((size_t)v_in + v_aux) * sizeof(Fr)));
+    Fr *sa = ctx->sc_a.as<Fr>();
+    FK_HIP(ctx, hipMemcpyAsync(sa, d_z, (size_t)v_in * sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream));
+    uint64_t n_a_aux = 0;
+    FK_TRY(compact_scalars(ctx, d_z + v_in, d_a_aux, v_aux, sa + v_in, &n_a_aux));
+    if (v_in + n_a_aux != key->n_a) FK_SET_ERR(ctx, FK_ERR_KEY_MISMATCH, "prove: a query needs %llu points, key holds %llu",
+                                               (unsigned long long)(v_in + n_a_aux), (unsigned long long)key->n_a);
+    FK_TRY(msm_g1_dev(ctx, key->d_a, sa + key->a_lo, key->a_hi - key->a_lo, &A));
+    const double t4 = now_ms();
+    // B query: inputs and aux variables that occur in some B-side LC
+    FK_HIP(ctx, ctx->sc_b.reserve(((size_t)v_in + v_aux) * sizeof(Fr)));
+    Fr *sb = ctx->sc_b.as<Fr>();
+    uint64_t n_b_in = 0, n_b_aux = 0;
+    FK_TRY(compact_scalars(ctx, d_z, d_b_in, v_in, sb, &n_b_in));
+    FK_TRY(compact_scalars(ctx, d_z + v_in, d_b_aux, v_aux, sb + n_b_in, &n_b_aux));
+    if (n_b_in + n_b_aux != key->n_b) FK_SET_ERR(ctx, FK_ERR_KEY_MISMATCH, "prove: b query needs %llu points, key holds %llu",
+                                                 (unsigned long long)(n_b_in + n_b_aux), (unsigned long long)key->n_b);
+    FK_TRY(msm_g1_dev(ctx, key->d_b1, sb + key->b_lo, key->b_hi - key->b_lo, &B1));
+    const double t5 = now_ms();
+    FK_TRY(msm_g2_dev(ctx, key->d_b2, sb + key->b_lo, key->b_hi - key->b_lo, &B2));
+    const double t6 = now_ms();
+    g1_to_raw(out, H); g1_to_raw(out + 64, L); g1_to_raw(out + 128, A); g1_to_raw(out + 192, B1); g2_to_raw(out + 256, B2);
+    if (tm) {
+        tm->ntt_ms = t1 - t0; tm->msm_h_ms = t2 - t1; tm->msm_l_ms = t3 - t2; tm->msm_a_ms = t4 - t3;
+        tm->msm_b1_ms = t5 - t4; tm->msm_b2_ms = t6 - t5; tm->total_ms = now_ms() - t0;
+    }
+    return FK_OK;
+}
+
+int fk_prove_msms_dev(fk_ctx *ctx, const fk_key *key, void *d_a, void *d_b, void *d_c, uint64_t n, const void *d_z,
+                      const void *d_a_aux, const void *d_b_in, const void *d_b_aux, uint8_t out[FK_MSM_RESULT_BYTES], fk_timings *tm) {
+    if (!ctx) return FK_ERR_BAD_ARG;
+    if (tm) memset(tm, 0, sizeof *tm);
+    return prove_msms_dev(ctx, key, (Fr *)d_a, (Fr *)d_b, (Fr *)d_c, n, (const Fr *)d_z, (const uint8_t *)d_a_aux,
+                          (const uint8_t *)d_b_in, (const uint8_t *)d_b_aux, out, tm);
+}
+
+// A = alpha + A_q + r*delta1 ; B = beta2 + B2 + s*delta2 ;
+// C = H + L + s*A_q + r*B1 + s*alpha + r*beta1 + (r s)*delta1   
+int fk_prove_assemble(fk_ctx *ctx, const fk_key *key, const uint8_t *parts, uint32_t n_parts, const uint64_t r_[4],
+                      const uint64_t s_[4], uint8_t out[FK_PROOF_BYTES]) {
+    fk_ctx local;                  // host-only routine: usable without a GPU context
+    if (!ctx) ctx = &local;
+    if (!key || !parts || !n_parts || !r_ || !s_ || !out) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "assemble: null argument");
+    if (key->delta_g1.is_inf() || key->delta_g2.is_inf()) FK_SET_ERR(ctx, FK_ERR_UNEXPECTED_IDENTITY, "delta is the identity");
+    G1Xyzz H = G1Xyzz::inf(), L = G1Xyzz::inf(), A = G1Xyzz::inf(), B1 = G1Xyzz::inf();
+    G2Xyzz B2 = G2Xyzz::inf();
+    for (uint32_t i = 0; i < n_parts; i++) {
+        const uint8_t *p = parts + (size_t)i * FK_MSM_RESULT_BYTES;
+        H.add_mixed(g1_from_raw(p)); L.add_mixed(g1_from_raw(p + 64)); A.add_mixed(g1_from_raw(p + 128));
+        B1.add_mixed(g1_from_raw(p + 192)); B2.add_mixed(g2_from_raw(p + 256));
+    }
+    Fr rm, sm; memcpy(&rm, r_, 32); memcpy(&sm, s_, 32);
+    const Fr rc = Fr::from_mont(rm), sc = Fr::from_mont(sm), rsc = Fr::from_mont(Fr::mul(rm, sm));
+    const G1Xyzz d1 = G1Xyzz::from_affine(key->delta_g1), a1 = G1Xyzz::from_affine(key->alpha_g1), b1 = G1Xyzz::from_affine(key->beta_g1);
+    const G2Xyzz d2 = G2Xyzz::from_affine(key->delta_g2);
+    G1Xyzz gA = G1Xyzz::mul_scalar(d1, rc.v); gA.add_mixed(key->alpha_g1); gA.add(A);
+    G2Xyzz gB = G2Xyzz::mul_scalar(d2, sc.v); gB.add_mixed(key->beta_g2); gB.add(B2);
+    G1Xyzz gC = G1Xyzz::mul_scalar(d1, rsc.v);
+    gC.add(G1Xyzz::mul_scalar(a1, sc.v));
+    gC.add(G1Xyzz::mul_scalar(b1, rc.v));
+    gC.add(G1Xyzz::mul_scalar(A, sc.v));
+    gC.add(G1Xyzz::mul_scalar(B1, rc.v));
+    gC.add(H); gC.add(L);
+    const G1Affine pa = gA.to_affine(), pc = gC.to_affine();
+    const G2Affine pb = gB.to_affine();
+    // fawkes Borsh: canonical LE coordinates, infinity = zeros (Fq::from_mont(0) == 0)
+    const Fq words[8] = {Fq::from_mont(pa.x), Fq::from_mont(pa.y), Fq::from_mont(pb.x.c0), Fq::from_mont(pb.x.c1),
+                         Fq::from_mont(pb.y.c0), Fq::from_mont(pb.y.c1), Fq::from_mont(pc.x), Fq::from_mont(pc.y)};
+    memcpy(out, words, 256);
+    return FK_OK;
+}
+
+int fk_prove_dev(fk_ctx *ctx, const fk_key *key, void *d_a, void *d_b, void *d_c, uint64_t n, const void *d_z,
+                 const void *d_a_aux, const void *d_b_in, const void *d_b_aux, const uint64_t r[4], const uint64_t s[4],
+                 uint8_t out[FK_PROOF_BYTES], fk_timings *tm) {
+    if (!ctx) return FK_ERR_BAD_ARG;
+    if (key && key->shard_count != 1) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "fk_prove needs an unsharded key (use fk_prove_msms + fk_prove_assemble)");
+    uint8_t msms[FK_MSM_RESULT_BYTES];
+    FK_TRY(fk_prove_msms_dev(ctx, key, d_a, d_b, d_c, n, d_z, d_a_aux, d_b_in, d_b_aux, msms, tm));
+    const double t0 = now_ms();
+    FK_TRY(fk_prove_assemble(ctx, key, msms, 1, r, s, out));
+    if (tm) { tm->assemble_ms = now_ms() - t0; tm->total_ms += tm->assemble_ms; }
+    return FK_OK;
+}
+
+static int stage_inputs(fk_ctx *ctx, const fk_key *key, const uint64_t *a, const uint64_t *b, const uint64_t *c, uint64_t n,
+                        const uint64_t *z, const uint8_t *a_aux, const uint8_t *b_in, const uint8_t *b_aux) {
+    if (!key || !a || !b || !c || !z || !a_aux || !b_in || !b_aux) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "prove: null argument");
+    if (n == 0 || n > key->m) FK_SET_ERR(ctx, FK_ERR_KEY_MISMATCH, "prove: %llu rows do not fit key domain %llu", (unsigned long long)n, (unsigned long long)key->m);
+    FK_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t mb = key->m * sizeof(Fr), nb = n * sizeof(Fr);
+    const size_t nv = (size_t)key->num_input + key->num_aux;
+    FK_HIP(ctx, ctx->stage_a.reserve(mb)); FK_HIP(ctx, ctx->stage_b.reserve(mb)); FK_HIP(ctx, ctx->stage_c.reserve(mb));
+    FK_HIP(ctx, ctx->stage_z.reserve(nv * sizeof(Fr)));
+    FK_HIP(ctx, ctx->stage_d.reserve(nv + (size_t)key->num_aux + 64));
+    FK_HIP(ctx, hipMemcpyAsync(ctx->stage_a.p, a, nb, hipMemcpyHostToDevice, ctx->stream));
+    FK_HIP(ctx, hipMemcpyAsync(ctx->stage_b.p, b, nb, hipMemcpyHostToDevice, ctx->stream));
+    FK_HIP(ctx, hipMemcpyAsync(ctx->stage_c.p, c, nb, hipMemcpyHostToDevice, ctx->stream));
+    FK_HIP(ctx, hipMemcpyAsync(ctx->stage_z.p, z, nv * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+    uint8_t *dd = ctx->stage_d.as<uint8_t>();
+    if (key->num_aux) FK_HIP(ctx, hipMemcpyAsync(dd, a_aux, key->num_aux, hipMemcpyHostToDevice, ctx->stream));
+    FK_HIP(ctx, hipMemcpyAsync(dd + key->num_aux, b_in, key->num_input, hipMemcpyHostToDevice, ctx->stream));
+    if (key->num_aux) FK_HIP(ctx, hipMemcpyAsync(dd + key->num_aux + key->num_input, b_aux, key->num_aux, hipMemcpyHostToDevice, ctx->stream));
+    FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FK_OK;
+}
+
+int fk_prove_msms(fk_ctx *ctx, const fk_key *key, const uint64_t *a, const uint64_t *b, const uint64_t *c, uint64_t n,
+                  const uint64_t *z, const uint8_t *a_aux, const uint8_t *b_in, const uint8_t *b_aux,
+                  uint8_t out[FK_MSM_RESULT_BYTES], fk_timings *tm) {
+    if (!ctx) return FK_ERR_BAD_ARG;
+    const double t0 = now_ms();
+    FK_TRY(stage_inputs(ctx, key, a, b, c, n, z, a_aux, b_in, b_aux));
+    const double up = now_ms() - t0;
+    uint8_t *dd = ctx->stage_d.as<uint8_t>();
+    FK_TRY(fk_prove_msms_dev(ctx, key, ctx->stage_a.p, ctx->stage_b.p, ctx->stage_c.p, n, ctx->stage_z.p, dd, dd + key->num_aux,
+                             dd + key->num_aux + key->num_input, out, tm));
+    if (tm) { tm->upload_ms = up; tm->total_ms += up; }
+    return FK_OK;
+}
+
+int fk_prove(fk_ctx *ctx, const fk_key *key, const uint64_t *a, const uint64_t *b, const uint64_t *c, uint64_t n,
+             const uint64_t *z, const uint8_t *a_aux, const uint8_t *b_in, const uint8_t *b_aux, const uint64_t r[4],
+             const uint64_t s[4], uint8_t out[FK_PROOF_BYTES], fk_timings *tm) {
+    if (!ctx) return FK_ERR_BAD_ARG;
+    if (key && key->shard_count != 1) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "fk_prove needs an unsharded key (use fk_prove_msms + fk_prove_assemble)");
+    if (!r || !s || !out) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "prove: null argument");
+    uint8_t msms[FK_MSM_RESULT_BYTES];
+    FK_TRY(fk_prove_msms(ctx, key, a, b, c, n, z, a_aux, b_in, b_aux, msms, tm));
+    const double t0 = now_ms();
+    FK_TRY(fk_prove_assemble(ctx, key, msms, 1, r, s, out));
+    if (tm) { tm->assemble_ms = now_ms() - t0; tm->total_ms += tm->assemble_ms; }
+    return FK_OK;
+}
+
+// ------------------------------------------------------------------------------------------ building blocks
+int fk_fr_mul_batch(fk_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n) {
+    if (!ctx) return FK_ERR_BAD_ARG;
+    if (n && (!a || !b || !out)) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "null argument");
+    if (!n) return FK_OK;
+    FK_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = n * sizeof(Fr);
+    FK_HIP(ctx, ctx->stage_a.reserve(bytes)); FK_HIP(ctx, ctx->stage_b.reserve(bytes));
+    FK_HIP(ctx, hipMemcpyAsync(ctx->stage_a.p, a, bytes, hipMemcpyHostToDevice, ctx->stream));
+    FK_HIP(ctx, hipMemcpyAsync(ctx->stage_b.p, b, bytes, hipMemcpyHostToDevice, ctx->stream));
+    FK_TRY(fr_mul_batch_dev(ctx, ctx->stage_a.as<Fr>(), ctx->stage_b.as<Fr>(), ctx->stage_a.as<Fr>(), n));
+    FK_HIP(ctx, hipMemcpyAsync(out, ctx->stage_a.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FK_OK;
+}
+
+int fk_ntt_dev(fk_ctx *ctx, void *d_data, uint32_t log_n, int inverse, int coset) {
+    if (!ctx) return FK_ERR_BAD_ARG;
+    if (!d_data) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "null argument");
+    FK_HIP(ctx, hipSetDevice(ctx->device));
+    return ntt_exec_simple(ctx, (Fr *)d_data, log_n, inverse != 0, coset != 0);
+}
+
+int fk_ntt(fk_ctx *ctx, uint64_t *data, uint32_t log_n, int inverse, int coset) {
+    if (!ctx) return FK_ERR_BAD_ARG;
+    if (!data) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "null argument");
+    if (log_n >= FK_FR_S) FK_SET_ERR(ctx, FK_ERR_DOMAIN_TOO_LARGE, "evaluation domain 2^%u too large (max 2^%d)", log_n, FK_FR_S - 1);
+    FK_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = sizeof(Fr) << log_n;
+    FK_HIP(ctx, ctx->ntt_io.reserve(bytes));
+    FK_HIP(ctx, hipMemcpyAsync(ctx->ntt_io.p, data, bytes, hipMemcpyHostToDevice, ctx->stream));
+    FK_TRY(ntt_exec_simple(ctx, ctx->ntt_io.as<Fr>(), log_n, inverse != 0, coset != 0));
+    FK_HIP(ctx, hipMemcpyAsync(data, ctx->ntt_io.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FK_OK;
+}
+
+int fk_quotient_h_dev(fk_ctx *ctx, void *d_a, void *d_b, void *d_c, uint64_t n, void *d_h_out) {
+    if (!ctx) return FK_ERR_BAD_ARG;
+    if (!d_a || !d_b || !d_c || !d_h_out) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "null argument");
+    FK_HIP(ctx, hipSetDevice(ctx->device));
+    return quotient_dev(ctx, (Fr *)d_a, (Fr *)d_b, (Fr *)d_c, n, (Fr *)d_h_out, nullptr);
+}
+
+int fk_quotient_h(fk_ctx *ctx, const uint64_t *a, const uint64_t *b, const uint64_t *c, uint64_t n, uint64_t *h_out) {
+    if (!ctx) return FK_ERR_BAD_ARG;
+    if (!a || !b || !c || !h_out || !n) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "null argument");
+    const uint32_t log_n = ceil_log2_u64(n);
+    if (log_n >= FK_FR_S) FK_SET_ERR(ctx, FK_ERR_DOMAIN_TOO_LARGE, "evaluation domain 2^%u too large (max 2^%d)", log_n, FK_FR_S - 1);
+    FK_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t mb = sizeof(Fr) << log_n, nb = n * sizeof(Fr);
+    FK_HIP(ctx, ctx->stage_a.reserve(mb)); FK_HIP(ctx, ctx->stage_b.reserve(mb)); FK_HIP(ctx, ctx->stage_c.reserve(mb));
+    FK_HIP(ctx, ctx->hbuf.reserve(mb));
+    FK_HIP(ctx, hipMemcpyAsync(ctx->stage_a.p, a, nb, hipMemcpyHostToDevice, ctx->stream));
+    FK_HIP(ctx, hipMemcpyAsync(ctx->stage_b.p, b, nb, hipMemcpyHostToDevice, ctx->stream));
+    FK_HIP(ctx, hipMemcpyAsync(ctx->stage_c.p, c, nb, hipMemcpyHostToDevice, ctx->stream));
+    FK_TRY(quotient_dev(ctx, ctx->stage_a.as<Fr>(), ctx->stage_b.as<Fr>(), ctx->stage_c.as<Fr>(), n, ctx->hbuf.as<Fr>(), nullptr));
+    FK_HIP(ctx, hipMemcpyAsync(h_out, ctx->hbuf.p, mb - sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+    FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FK_OK;
+}
+
+int fk_msm_g1_dev(fk_ctx *ctx, const void *d_bases, const void *d_scalars, size_t n, uint8_t out[FK_G1_BYTES]) {
+    if (!ctx) return FK_ERR_BAD_ARG;
+    if (!out || (n && (!d_bases || !d_scalars))) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "null argument");
+    FK_HIP(ctx, hipSetDevice(ctx->device));
+    G1Xyzz r;
+    FK_TRY(msm_g1_dev(ctx, (const G1Affine *)d_bases, (const Fr *)d_scalars, n, &r));
+    g1_to_raw(out, r);
+    return FK_OK;
+}
+int fk_msm_g2_dev(fk_ctx *ctx, const void *d_bases, const void *d_scalars, size_t n, uint8_t out[FK_G2_BYTES]) {
+    if (!ctx) return FK_ERR_BAD_ARG;
+    if (!out || (n && (!d_bases || !d_scalars))) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "null argument");
+    FK_HIP(ctx, hipSetDevice(ctx->device));
+    G2Xyzz r;
+    FK_TRY(msm_g2_dev(ctx, (const G2Affine *)d_bases, (const Fr *)d_scalars, n, &r));
+    g2_to_raw(out, r);
+    return FK_OK;
+}
+
+static int msm_host(fk_ctx *ctx, const uint8_t *bases, const uint64_t *scalars, size_t n, size_t w, uint8_t *out) {
+    if (!out || (n && (!bases || !scalars))) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "null argument");
+    FK_HIP(ctx, hipSetDevice(ctx->device));
+    FK_HIP(ctx, ctx->stage_a.reserve(n * w + 16)); FK_HIP(ctx, ctx->stage_z.reserve(n * sizeof(Fr) + 16));
+    if (n) {
+        FK_HIP(ctx, hipMemcpyAsync(ctx->stage_a.p, bases, n * w, hipMemcpyHostToDevice, ctx->stream));
+        FK_HIP(ctx, hipMemcpyAsync(ctx->stage_z.p, scalars, n * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+    }
+    return w == 64 ? fk_msm_g1_dev(ctx, ctx->stage_a.p, ctx->stage_z.p, n, out) : fk_msm_g2_dev(ctx, ctx->stage_a.p, ctx->stage_z.p, n, out);
+}
+int fk_msm_g1(fk_ctx *ctx, const uint8_t *bases, const uint64_t *scalars, size_t n, uint8_t out[FK_G1_BYTES]) {
+    if (!ctx) return FK_ERR_BAD_ARG;
+    return msm_host(ctx, bases, scalars, n, 64, out);
+}
+int fk_msm_g2(fk_ctx *ctx, const uint8_t *bases, const uint64_t *scalars, size_t n, uint8_t out[FK_G2_BYTES]) {
+    if (!ctx) return FK_ERR_BAD_ARG;
+    return msm_host(ctx, bases, scalars, n, 128, out);
+}
+
+int fk_gen_points_g1_dev(fk_ctx *ctx, void *d_out, size_t n, uint64_t seed) {
+    if (!ctx) return FK_ERR_BAD_ARG;
+    FK_HIP(ctx, hipSetDevice(ctx->device));
+    FK_TRY(gen_points_g1(ctx, (G1Affine *)d_out, n, seed));
+    FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FK_OK;
+}
+int fk_gen_points_g2_dev(fk_ctx *ctx, void *d_out, size_t n, uint64_t seed) {
+    if (!ctx) return FK_ERR_BAD_ARG;
+    FK_HIP(ctx, hipSetDevice(ctx->device));
+    FK_TRY(gen_points_g2(ctx, (G2Affine *)d_out, n, seed));
+    FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FK_OK;
+}
+int fk_gen_scalars_dev(fk_ctx *ctx, void *d_out, size_t n, uint64_t seed, int kind) {
+    if (!ctx) return FK_ERR_BAD_ARG;
+    FK_HIP(ctx, hipSetDevice(ctx->device));
+    FK_TRY(gen_scalars(ctx, (Fr *)d_out, n, seed, kind));
+    FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FK_OK;
+}
+
+// ------------------------------------------------------------------------------------------ synthesis (host)
+static inline void eval_lc(Fr *out, const uint64_t *ptr, const uint32_t *col, const uint64_t *val, uint64_t row, const Fr *z,
+                           uint32_t num_input, uint8_t *din, uint8_t *daux) {
+    Fr acc = Fr::zero();
+    const Fr one = Fr::one();
+    for (uint64_t k = ptr[row]; k < ptr[row + 1]; k++) {
+        const uint32_t v = col[k];
+        if (v < num_input) { if (din) din[v] = 1; } else { if (daux) daux[v - num_input] = 1; }
+        Fr cf; memcpy(&cf, val + 4 * k, 32);
+        Fr t = z[v];
+        if (cf != one) t = Fr::mul(t, cf);
+        acc = Fr::add(acc, t);
+    }
+    *out = acc;
+}
+
+int fk_synthesize(fk_ctx *ctx, const fk_r1cs *cs, const uint64_t *z_, uint64_t *a, uint64_t *b, uint64_t *c,
+                  uint8_t *a_aux, uint8_t *b_in, uint8_t *b_aux) {
+    fk_ctx local;                  // host-only routine: usable without a GPU context
+    if (!ctx) ctx = &local;
+    if (!cs || !z_ || !a || !b || !c || !a_aux || !b_in || !b_aux) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "null argument");
+    const Fr *z = (const Fr *)z_;
+    const uint64_t nv = (uint64_t)cs->num_input + cs->num_aux;
+    for (const uint64_t *ptr : {cs->a_ptr, cs->b_ptr, cs->c_ptr}) if (!ptr) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "null row pointer");
+    const struct { const uint64_t *ptr; const uint32_t *col; } mats[3] = {{cs->a_ptr, cs->a_col}, {cs->b_ptr, cs->b_col}, {cs->c_ptr, cs->c_col}};
+    for (const auto &mt : mats)
+        for (uint64_t k = mt.ptr[0]; k < mt.ptr[cs->num_gates]; k++)
+            if (mt.col[k] >= nv) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "r1cs: variable index %u out of range", mt.col[k]);
+    memset(a_aux, 0, cs->num_aux); memset(b_in, 0, cs->num_input); memset(b_aux, 0, cs->num_aux);
+    for (uint64_t g = 0; g < cs->num_gates; g++) {
+        eval_lc((Fr *)(a + 4 * g), cs->a_ptr, cs->a_col, cs->a_val, g, z, cs->num_input, nullptr, a_aux);
+        eval_lc((Fr *)(b + 4 * g), cs->b_ptr, cs->b_col, cs->b_val, g, z, cs->num_input, b_in, b_aux);
+        eval_lc((Fr *)(c + 4 * g), cs->c_ptr, cs->c_col, cs->c_val, g, z, cs->num_input, nullptr, nullptr);
+    }
+    for (uint32_t i = 0; i < cs->num_input; i++) {   // bellman appends `input_i * 0 = 0` (App. A.1)
+        const uint64_t row = cs->num_gates + i;
+        memcpy(a + 4 * row, &z[i], 32); memset(b + 4 * row, 0, 32); memset(c + 4 * row, 0, 32);
+    }
+    return FK_OK;
+}
+
+void fk_shard_range(uint64_t n, uint32_t index, uint32_t count, uint64_t *lo, uint64_t *hi) {
+    if (!count || !lo || !hi) return;
+    slice(n, index, count, lo, hi);
+}
+
+// ------------------------------------------------------------------------------------------ stats
+int fk_stats_reset(fk_ctx *ctx) {
+    if (!ctx) return FK_ERR_BAD_ARG;
+    FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto *v : {&ctx->ev_acc, &ctx->ev_ntt}) {
+        for (auto &ep : *v) { ctx->ev_pool.push_back(ep.a); ctx->ev_pool.push_back(ep.b); }
+        v->clear();
+    }
+    return FK_OK;
+}
+int fk_stats_get(fk_ctx *ctx, double *acc_ms, uint64_t *acc_launches, uint64_t *acc_points, double *ntt_ms, uint64_t *ntt_launches) {
+    if (!ctx) return FK_ERR_BAD_ARG;
+    FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    double t = 0; uint64_t pts = 0;
+    for (auto &ep : ctx->ev_acc) { float ms = 0; FK_HIP(ctx, hipEventElapsedTime(&ms, ep.a, ep.b)); t += ms; pts += ep.units; }
+    if (acc_ms) *acc_ms = t;
+    if (acc_launches) *acc_launches = ctx->ev_acc.size();
+    if (acc_points) *acc_points = pts;
+    t = 0;
+    for (auto &ep : ctx->ev_ntt) { float ms = 0; FK_HIP(ctx, hipEventElapsedTime(&ms, ep.a, ep.b)); t += ms; }
+    if (ntt_ms) *ntt_ms = t;
+    if (ntt_launches) *ntt_launches = ctx->ev_ntt.size();
+    return FK_OK;
+}
+
+}  // extern "C"

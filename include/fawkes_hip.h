@@ -1,0 +1,185 @@
+/*
+ * fawkes_hip.h -- C ABI of libfawkes_hip.so, the MI355X (gfx950) Groth16 proving backend that
+ * replaces, for fawkes-crypto, the single call
+ *
+ *     bellman::groth16::create_random_proof(bcs, &params.0, rng)
+ *         /root/reference/fawkes-crypto/src/backend/bellman_groth16/prover.rs:80
+ *
+ * i.e. everything below `prover::prove` (prover.rs:63-90): the Fr NTT/iNTT quotient, the G1/G2
+ * Pippenger multi-scalar multiplications and the proof assembly.  The reference has no FFI for
+ * this path (it is a generic Rust call into the crate `fawkes-crypto-bellman_ce`); this header is
+ * what a Rust `extern "C"` block in a shim crate binds -- see INTEGRATION.md.
+ *
+ * Data conventions (all little-endian, no padding, no torch types):
+ *   Fr / Fq element  32 B = 4 x u64 limbs, MONTGOMERY form, R = 2^256 -- the in-memory image of
+ *                    `Num<Fr>` (ff-uint/src/num/mod.rs:21-23; backend/bellman_groth16/mod.rs:105-137).
+ *   G1 affine        64 B = x || y, Montgomery LE; the all-zero buffer is the point at infinity --
+ *                    `into_raw_uncompressed_le` as used at group.rs:57-66,74-77 (zero: group.rs:55,71).
+ *   G2 affine        128 B = x.c0 || x.c1 || y.c0 || y.c1 (group.rs:97-103,114-119).
+ *   proof            256 B = fawkes' Borsh `Proof`: a(G1) b(G2) c(G1), every coordinate the CANONICAL
+ *                    (non-Montgomery) LE integer (prover.rs:39-45, group.rs:16-21,33-39,
+ *                    ff-uint_derive/src/lib.rs:687-693); infinity = zeros.
+ *   density maps     one byte per variable, 0/1 -- bellman's DensityTracker bits for a_aux, b_input,
+ *                    b_aux (set when the variable is visited in an A- resp. B-side LC).
+ *
+ * Every function returns FK_OK (0) or an error code and never aborts; fk_last_error() gives text.
+ * A context is bound to one GPU and is not thread-safe (one call at a time per context); multi-GPU
+ * operation is one process + one context per GPU (see fk_prove_msms / fk_prove_assemble).
+ */
+#ifndef FAWKES_HIP_H
+#define FAWKES_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fk_ctx fk_ctx;
+typedef struct fk_key fk_key;
+
+enum {
+    FK_OK = 0,
+    FK_ERR_BAD_ARG = 1,
+    FK_ERR_DOMAIN_TOO_LARGE = 2,     /* bellman SynthesisError::PolynomialDegreeTooLarge (m > 2^27) */
+    FK_ERR_UNEXPECTED_IDENTITY = 3,  /* bellman SynthesisError::UnexpectedIdentity (delta is identity) */
+    FK_ERR_HIP = 4,
+    FK_ERR_OOM = 5,
+    FK_ERR_KEY_MISMATCH = 6          /* key arrays do not match m / densities (bellman: get_* errors) */
+};
+
+#define FK_PROOF_BYTES 256
+#define FK_G1_BYTES 64
+#define FK_G2_BYTES 128
+/* the five MSM results of one prover pass: H, L, A, B1 (G1) and B2 (G2), raw affine LE */
+#define FK_MSM_RESULT_BYTES (4 * FK_G1_BYTES + FK_G2_BYTES)
+
+/* ---------------------------------------------------------------- context */
+int fk_init(int device_id, fk_ctx **out);
+void fk_free(fk_ctx *ctx);
+const char *fk_last_error(const fk_ctx *ctx);
+/* 0 = library default.  Pippenger window bits (4..16) used by subsequent MSMs; for tests/tuning. */
+int fk_set_window_bits(fk_ctx *ctx, unsigned c);
+
+/* ---------------------------------------------------------------- device buffers (for resident inputs) */
+int fk_dev_alloc(fk_ctx *ctx, size_t bytes, void **dptr);
+int fk_dev_free(fk_ctx *ctx, void *dptr);
+int fk_upload(fk_ctx *ctx, void *dptr, const void *host, size_t bytes);
+int fk_download(fk_ctx *ctx, void *host, const void *dptr, size_t bytes);
+int fk_sync(fk_ctx *ctx);
+
+/* ---------------------------------------------------------------- proving key
+ * Replaces the `params.0` argument of prover.rs:80, i.e. bellman's `Parameters` { vk, h, l, a, b_g1,
+ * b_g2 } (mod.rs:139).  Uploaded once, stays resident in HBM.  With shard_count > 1 only the
+ * [shard_index/shard_count) contiguous slice of each of h, l, a, b_g1, b_g2 is kept (MSM sharding by
+ * points across GPUs); the host pointers always describe the FULL arrays. */
+typedef struct {
+    uint64_t m;              /* evaluation-domain size, power of two, = next_pow2(#gates + num_input) */
+    uint32_t num_input;      /* including the constant ONE (cs.rs:111) */
+    uint32_t num_aux;
+    const uint8_t *alpha_g1, *beta_g1, *delta_g1;   /* 64 B each  */
+    const uint8_t *beta_g2, *delta_g2;              /* 128 B each */
+    const uint8_t *h;   uint64_t n_h;               /* m - 1 points */
+    const uint8_t *l;   uint64_t n_l;               /* num_aux points */
+    const uint8_t *a;   uint64_t n_a;               /* num_input + popcount(a_aux) points */
+    const uint8_t *b_g1; const uint8_t *b_g2; uint64_t n_b;  /* popcount(b_input)+popcount(b_aux) */
+    uint32_t shard_index, shard_count;              /* 0,1 for a single GPU */
+} fk_key_desc;
+
+int fk_key_load(fk_ctx *ctx, const fk_key_desc *desc, fk_key **out);
+/* Synthetic key of the same shape (valid curve points, no trapdoor): benchmarking only.  vk points are
+ * synthetic too, so proofs made with it do not verify. */
+int fk_key_synthetic(fk_ctx *ctx, uint64_t m, uint32_t num_input, uint32_t num_aux, uint64_t n_a,
+                     uint64_t n_b, uint64_t seed, uint32_t shard_index, uint32_t shard_count, fk_key **out);
+/* Host-only key holding just the vk points fk_prove_assemble needs (no device memory, no GPU).
+ * Free with fk_key_free(NULL, key). */
+int fk_key_host_vk(const uint8_t *alpha_g1, const uint8_t *beta_g1, const uint8_t *delta_g1,
+                   const uint8_t *beta_g2, const uint8_t *delta_g2, fk_key **out);
+void fk_key_free(fk_ctx *ctx, fk_key *key);
+
+/* ---------------------------------------------------------------- the prover
+ * Inputs are exactly what bellman's ProvingAssignment holds after `synthesize`:
+ *   a, b, c    n x 32 B   row evaluations <A_i,z>, <B_i,z>, <C_i,z>, n = #gates + num_input rows
+ *   z          (num_input + num_aux) x 32 B   assignment, inputs first (z[0] = ONE)
+ *   a_aux_density[num_aux], b_input_density[num_input], b_aux_density[num_aux]
+ *   r, s       32 B each  -- the blinding scalars create_random_proof draws from OsRng (prover.rs:78;
+ *              sampled limbs are used as the Montgomery representation, App. A.6).  Passing them in
+ *              is what makes the proof reproducible: bellman's `create_proof(circuit, params, r, s)`.
+ * `*_dev` variants take device pointers for a, b, c, z and the density maps (inputs resident in HBM).
+ * a, b, c are consumed as scratch by the _dev variant. */
+typedef struct {
+    double upload_ms, ntt_ms, msm_h_ms, msm_l_ms, msm_a_ms, msm_b1_ms, msm_b2_ms, assemble_ms, total_ms;
+} fk_timings;
+
+int fk_prove(fk_ctx *ctx, const fk_key *key, const uint64_t *a, const uint64_t *b, const uint64_t *c,
+             uint64_t n, const uint64_t *z, const uint8_t *a_aux_density, const uint8_t *b_input_density,
+             const uint8_t *b_aux_density, const uint64_t r[4], const uint64_t s[4],
+             uint8_t out_proof[FK_PROOF_BYTES], fk_timings *timings);
+int fk_prove_dev(fk_ctx *ctx, const fk_key *key, void *d_a, void *d_b, void *d_c, uint64_t n,
+                 const void *d_z, const void *d_a_aux_density, const void *d_b_input_density,
+                 const void *d_b_aux_density, const uint64_t r[4], const uint64_t s[4],
+                 uint8_t out_proof[FK_PROOF_BYTES], fk_timings *timings);
+
+/* Multi-GPU split of the same computation: each rank runs the quotient and its shard of the five
+ * MSMs (fk_prove_msms*), the FK_MSM_RESULT_BYTES partial results are exchanged by the caller
+ * (all-gather over RCCL), and any rank folds them into the proof (fk_prove_assemble). */
+int fk_prove_msms(fk_ctx *ctx, const fk_key *key, const uint64_t *a, const uint64_t *b, const uint64_t *c,
+                  uint64_t n, const uint64_t *z, const uint8_t *a_aux_density, const uint8_t *b_input_density,
+                  const uint8_t *b_aux_density, uint8_t out_msms[FK_MSM_RESULT_BYTES], fk_timings *timings);
+int fk_prove_msms_dev(fk_ctx *ctx, const fk_key *key, void *d_a, void *d_b, void *d_c, uint64_t n,
+                      const void *d_z, const void *d_a_aux_density, const void *d_b_input_density,
+                      const void *d_b_aux_density, uint8_t out_msms[FK_MSM_RESULT_BYTES], fk_timings *timings);
+/* ctx may be NULL here (pure host arithmetic). */
+int fk_prove_assemble(fk_ctx *ctx, const fk_key *key, const uint8_t *msm_parts, uint32_t n_parts,
+                      const uint64_t r[4], const uint64_t s[4], uint8_t out_proof[FK_PROOF_BYTES]);
+/* the [lo, hi) slice of an n-element key array that shard `index` of `count` holds */
+void fk_shard_range(uint64_t n, uint32_t index, uint32_t count, uint64_t *lo, uint64_t *hi);
+
+/* ---------------------------------------------------------------- building blocks (tests / benches)
+ * bellman_ce::domain::EvaluationDomain pieces. */
+int fk_fr_mul_batch(fk_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n);
+/* in-place natural-order NTT of 2^log_n elements; inverse: omega^-1 and 1/n; coset: bellman's
+ * coset_fft / icoset_fft (multiplicative generator 7). */
+int fk_ntt(fk_ctx *ctx, uint64_t *data, uint32_t log_n, int inverse, int coset);
+int fk_ntt_dev(fk_ctx *ctx, void *d_data, uint32_t log_n, int inverse, int coset);
+/* h = (A*B - C)/Z coefficients: out has m-1 elements, m = next_pow2(n). */
+int fk_quotient_h(fk_ctx *ctx, const uint64_t *a, const uint64_t *b, const uint64_t *c, uint64_t n,
+                  uint64_t *h_out);
+int fk_quotient_h_dev(fk_ctx *ctx, void *d_a, void *d_b, void *d_c, uint64_t n, void *d_h_out /* m x 32 B */);
+/* bellman_ce::multiexp (App. A.3): sum_i scalars[i] * bases[i]; scalars Montgomery Fr; out raw affine. */
+int fk_msm_g1(fk_ctx *ctx, const uint8_t *bases, const uint64_t *scalars, size_t n, uint8_t out[FK_G1_BYTES]);
+int fk_msm_g2(fk_ctx *ctx, const uint8_t *bases, const uint64_t *scalars, size_t n, uint8_t out[FK_G2_BYTES]);
+int fk_msm_g1_dev(fk_ctx *ctx, const void *d_bases, const void *d_scalars, size_t n, uint8_t out[FK_G1_BYTES]);
+int fk_msm_g2_dev(fk_ctx *ctx, const void *d_bases, const void *d_scalars, size_t n, uint8_t out[FK_G2_BYTES]);
+/* n valid pseudo-random curve points written to device memory (bench/test input generator) */
+int fk_gen_points_g1_dev(fk_ctx *ctx, void *d_out, size_t n, uint64_t seed);
+int fk_gen_points_g2_dev(fk_ctx *ctx, void *d_out, size_t n, uint64_t seed);
+/* n pseudo-random Montgomery Fr elements; kind 0 = uniform, 1 = witness-like (half in {0,1}) */
+int fk_gen_scalars_dev(fk_ctx *ctx, void *d_out, size_t n, uint64_t seed, int kind);
+
+/* ---------------------------------------------------------------- synthesis (host side of the boundary)
+ * ProvingAssignment::enforce/eval restated (App. A.1): evaluates a CSR R1CS on the assignment and
+ * produces a, b, c and the density maps, i.e. what backend/bellman_groth16/mod.rs:92-99 feeds bellman.
+ * Variables: Input(i) -> i, Aux(j) -> num_input + j (circuit/r1cs/cs.rs:255-268).  ctx may be NULL. */
+typedef struct {
+    uint32_t num_input, num_aux;
+    uint64_t num_gates;
+    const uint64_t *a_ptr; const uint32_t *a_col; const uint64_t *a_val;   /* ptr[num_gates+1], col/val[nnz] */
+    const uint64_t *b_ptr; const uint32_t *b_col; const uint64_t *b_val;
+    const uint64_t *c_ptr; const uint32_t *c_col; const uint64_t *c_val;
+} fk_r1cs;
+
+int fk_synthesize(fk_ctx *ctx, const fk_r1cs *cs, const uint64_t *z, uint64_t *a, uint64_t *b, uint64_t *c,
+                  uint8_t *a_aux_density, uint8_t *b_input_density, uint8_t *b_aux_density);
+
+/* last-call kernel timing of the dominant MSM kernel (bucket accumulation), measured with HIP events
+ * on the library's stream: milliseconds and number of launches since the last reset. */
+int fk_stats_reset(fk_ctx *ctx);
+int fk_stats_get(fk_ctx *ctx, double *accumulate_ms, uint64_t *accumulate_launches, uint64_t *accumulate_points,
+                 double *ntt_ms, uint64_t *ntt_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FAWKES_HIP_H */

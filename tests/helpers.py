@@ -1,0 +1,83 @@
+"""Shared test helpers.  The oracle (oracle/) is used here only as the checker."""
+import json
+import os
+
+import numpy as np
+
+import bn254_ref as ref
+import c_oracle as co
+import fixtures as fx
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+R, Q = ref.R, ref.Q
+
+
+def golden(name):
+    with open(os.path.join(GOLDEN, name)) as f:
+        return json.load(f)
+
+
+def rand_fr_mont(rng, n, kind='uniform'):
+    """n Montgomery Fr elements as (n,4) uint64 from a numpy Generator.  kind: uniform | witness."""
+    raw = rng.integers(0, 1 << 63, size=(n, 5), dtype=np.uint64)
+    vals = []
+    for row in raw:
+        v = 0
+        for x in row:
+            v = (v << 63) | int(x)
+        vals.append(v % R)
+    if kind == 'witness':
+        sel = rng.integers(0, 4, size=n)
+        for i in range(n):
+            if sel[i] == 0:
+                vals[i] = 0
+            elif sel[i] == 1:
+                vals[i] = 1
+    return co.limbs_arr([ref.to_mont(v, R) for v in vals]) if n else np.zeros((0, 4), np.uint64)
+
+
+def mont_ints(arr, p=R):
+    """(n,4) Montgomery limbs -> canonical python ints"""
+    return [ref.from_mont(x, p) for x in co.ints(arr)]
+
+
+def g1_bases(n, seed=1):
+    """n distinct G1 points k*G as (n,64) raw LE (C oracle, fast)."""
+    g = np.frombuffer(ref.g1_raw_le(ref.G1_GEN), np.uint8)
+    return co.g1_series(g, fx.mont_fr(0x1234567 + seed * 7919), n)
+
+
+def g2_bases(n, seed=1):
+    g = np.frombuffer(ref.g2_raw_le(ref.G2_GEN), np.uint8)
+    return co.g2_series(g, fx.mont_fr(0x7654321 + seed * 104729), n)
+
+
+def params_from_oracle_key(key, r1cs=None):
+    """c_oracle.Key -> fawkes_crypto_amd.Parameters"""
+    import fawkes_crypto_amd as fk
+    arrays = dict(m=key.m, num_input=key.num_input, num_aux=key.num_aux,
+                  alpha_g1=key.alpha_g1, beta_g1=key.beta_g1, beta_g2=key.beta_g2,
+                  delta_g1=key.delta_g1, delta_g2=key.delta_g2,
+                  h=np.array(key.h), l=np.array(key.l), a=np.array(key.a), b_g1=np.array(key.b_g1), b_g2=np.array(key.b_g2))
+    return fk.Parameters(arrays, r1cs)
+
+
+def r1cs_product(csr):
+    """c_oracle.R1csC -> fawkes_crypto_amd.R1cs (same CSR arrays)"""
+    import fawkes_crypto_amd as fk
+    return fk.R1cs(csr.num_input, csr.num_aux, (csr.A.ptr, csr.A.col, csr.A.val), (csr.B.ptr, csr.B.col, csr.B.val),
+                   (csr.C.ptr, csr.C.col, csr.C.val))
+
+
+def golden_instance():
+    """The toy Groth16 instance of tests/golden/proof_golden.json as oracle objects."""
+    g = golden('proof_golden.json')
+    rows = [tuple([(int(cf, 16), (kind, idx)) for cf, kind, idx in lc] for lc in row) for row in g['rows']]
+    cs = ref.R1CS(g['num_input'], g['num_aux'], rows)
+    z_in = [int(x, 16) for x in g['z_in']]
+    z_aux = [int(x, 16) for x in g['z_aux']]
+    tw = {k: int(v, 16) for k, v in g['toxic'].items()}
+    return g, cs, z_in, z_aux, tw, int(g['r'], 16), int(g['s'], 16)
+
+
+TOXIC = dict(tau=0x1f2e3d4c5b6a79880123456789abcdef0fedcba987654321, alpha=0xa11ce, beta=0xb0b, gamma=0xc0ffee, delta=0xdec0de)

@@ -1,0 +1,128 @@
+"""CPU tests of the product's boundary and host logic (no GPU compute): the C-ABI library loads and
+exports every symbol include/fawkes_hip.h declares, fails loudly without a device, and its host-only
+routines (synthesis, proof assembly, sharding arithmetic, r/s sampling, Proof/Borsh) agree with the oracle."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import bn254_ref as ref
+import fixtures as fx
+from helpers import R, golden, golden_instance, params_from_oracle_key, r1cs_product, TOXIC
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_header_symbols():
+    import fawkes_crypto_amd as fk
+    lib = fk.load_library()
+    hdr = open(os.path.join(ROOT, 'include', 'fawkes_hip.h')).read()
+    declared = sorted(set(re.findall(r'\b(fk_[a-z0-9_]+)\s*\(', hdr)))
+    assert len(declared) >= 30
+    for sym in declared:
+        assert hasattr(lib, sym), 'libfawkes_hip.so does not export %s' % sym
+    assert sorted(fk.EXPORTED_SYMBOLS) == declared
+
+
+def test_no_gpu_fails_loudly():
+    """There is no CPU fallback: without a HIP device the context cannot be created."""
+    import torch
+    import fawkes_crypto_amd as fk
+    if torch.cuda.device_count() > 0:
+        pytest.skip('a GPU is visible')
+    with pytest.raises(fk.FkError):
+        fk.Context(0)
+
+
+def test_proof_borsh_roundtrip_and_points():
+    import fawkes_crypto_amd as fk
+    g = golden('proof_golden.json')
+    raw = bytes.fromhex(g['proof'])
+    p = fk.Proof.from_bytes(raw)
+    assert p.to_bytes() == raw
+    A, B, C = ref.proof_from_borsh(raw)
+    assert (p.a.x, p.a.y) == A and (p.b.x, p.b.y) == B and (p.c.x, p.c.y) == C
+    assert fk.G1Point(0, 0).is_zero() and fk.G1Point.from_bytes(bytes(64)).is_zero()
+    assert fk.G2Point.from_bytes(bytes(128)).is_zero()
+
+
+def test_sample_fr_rule():
+    """bellman Fr::rand as driven by fawkes' OsRng (osrng.rs:13-17)."""
+    from fawkes_crypto_amd import api
+    stream = bytes(range(1, 33)) + bytes([0xff] * 32) + bytes([7] * 32)
+    pos = [0]
+
+    def rand(n):
+        out = stream[pos[0]:pos[0] + n]
+        pos[0] += n
+        return out
+    limbs = api.sample_fr(rand)
+    # first 32 bytes: u32 big-endian words, two per limb (high word first)
+    want0 = (int.from_bytes(stream[0:4], 'big') << 32) | int.from_bytes(stream[4:8], 'big')
+    assert int(limbs[0]) == want0
+    assert api.limbs_to_int(limbs) < api.FR_MODULUS and int(limbs[3]) < (1 << 62)
+    # all-ones candidate is rejected (>= r after masking), next accepted
+    pos[0] = 32
+    limbs = api.sample_fr(rand)
+    assert all(int(x) == 0x0707070707070707 for x in limbs[:3])
+
+
+def test_shard_range_partition():
+    from fawkes_crypto_amd import api
+    for n in (0, 1, 7, 8, 1000, (1 << 25) - 1):
+        for cnt in (1, 2, 3, 8):
+            prev = 0
+            for i in range(cnt):
+                lo, hi = api.shard_range(n, i, cnt)
+                assert lo == prev and hi >= lo
+                prev = hi
+            assert prev == n
+
+
+def test_synthesize_matches_oracle(oracle):
+    """fk_synthesize (product host code) == the oracle's ProvingAssignment restatement."""
+    from fawkes_crypto_amd import api
+    for seed, gates, nin, naux in ((1, 40, 3, 44), (2, 200, 1, 150), (3, 5, 2, 30)):
+        cs, z_in, z_aux = ref.random_r1cs(seed, gates, nin, naux)
+        csr = fx.r1cs_to_csr(cs)
+        z = fx.witness_mont(z_in, z_aux)
+        want = oracle.synthesize(csr, z)
+        got = api.synthesize(r1cs_product(csr), z)
+        for w, g_ in zip(want, got):
+            assert np.array_equal(w, g_)
+    with pytest.raises(api.FkError):
+        bad = r1cs_product(csr)
+        bad.mats[0][1][0] = 10 ** 6
+        api.synthesize(bad, z)
+
+
+def test_assemble_matches_oracle(oracle):
+    """fk_prove_assemble (product host code) fed with the oracle's five MSM results reproduces the
+    oracle's / golden proof bytes, also when the results arrive as several partial shards."""
+    from fawkes_crypto_amd import api
+    g, cs, z_in, z_aux, tw, r, s = golden_instance()
+    csr = fx.r1cs_to_csr(cs)
+    key = oracle.setup(csr, **tw)
+    z = fx.witness_mont(z_in, z_aux)
+    a, b, c, aa, bi, ba = oracle.synthesize(csr, z)
+    proof, msms = oracle.prove(key, a, b, c, z, aa, bi, ba, fx.mont_fr(r), fx.mont_fr(s), want_msm=True)
+    assert proof.tobytes().hex() == g['proof']
+    params = params_from_oracle_key(key)
+    # a key handle without a GPU is not available; build one through the host-only path: fk_key_load
+    # needs a device, so the handle-free assemble is exercised through a minimal host key struct instead
+    pytest.importorskip('ctypes')
+    host_key = api.HostVk(params)
+    out = api.assemble(host_key.handle, msms, fx.mont_fr(r), fx.mont_fr(s))
+    assert out.tobytes().hex() == g['proof']
+    # split H into two partial sums P1 + P2 = H: shard 0 carries P1, shard 1 carries the rest
+    part0 = msms.copy()
+    part1 = np.zeros_like(msms)
+    k = fx.mont_fr(5)
+    gen = np.frombuffer(ref.g1_raw_le(ref.G1_GEN), np.uint8)
+    five_g = oracle.g1_mul(gen, k)
+    minus_five_g = np.frombuffer(ref.g1_raw_le(ref.G1.neg(ref.g1_from_raw_le(five_g.tobytes()))), np.uint8)
+    part0[:64] = oracle.g1_add(msms[:64], five_g)
+    part1[:64] = minus_five_g
+    out2 = api.assemble(host_key.handle, np.stack([part0, part1]), fx.mont_fr(r), fx.mont_fr(s))
+    assert out2.tobytes().hex() == g['proof']

@@ -1,0 +1,158 @@
+"""GPU parity of the full prover path behind prover.rs:63-90: proof bytes bit-identical to the oracle
+for fixed (r, s), pairing check, error behaviour, sharded == unsharded."""
+import numpy as np
+import pytest
+
+import bn254_ref as ref
+import fixtures as fx
+from helpers import R, golden_instance, params_from_oracle_key, r1cs_product, TOXIC
+
+pytestmark = pytest.mark.gpu
+
+
+def _instance(oracle, seed, gates, nin, naux, toxic=TOXIC):
+    cs, z_in, z_aux = ref.random_r1cs(seed, gates, nin, naux)
+    csr = fx.r1cs_to_csr(cs)
+    key = oracle.setup(csr, **toxic)
+    return cs, csr, key, z_in, z_aux
+
+
+def test_golden_proof_bit_exact(ctx, oracle):
+    import fawkes_crypto_amd as fk
+    g, cs, z_in, z_aux, tw, r, s = golden_instance()
+    csr = fx.r1cs_to_csr(cs)
+    key = oracle.setup(csr, **tw)
+    params = params_from_oracle_key(key, r1cs_product(csr))
+    dk = ctx.load_key(params)
+    z = fx.witness_mont(z_in, z_aux)
+    inputs, proof = fk.prove_with_rs(ctx, params, dk, z[:cs.num_input], z[cs.num_input:], fx.mont_fr(r), fx.mont_fr(s))
+    assert proof.to_bytes().hex() == g['proof']
+    assert np.array_equal(inputs, z[1:cs.num_input])       # prover.rs:84-87: inputs without the leading ONE
+    # h coefficients too
+    a, b, c, *_ = ctx.synthesize(params.r1cs, z)
+    from helpers import mont_ints
+    assert mont_ints(ctx.quotient_h(a, b, c)) == [int(x, 16) for x in g['h']]
+
+
+@pytest.mark.parametrize('shape', [(5, 7, 1, 9), (6, 100, 4, 97), (7, 1000, 2, 1100)])
+def test_prove_vs_oracle_small(ctx, oracle, shape):
+    import fawkes_crypto_amd as fk
+    seed, gates, nin, naux = shape
+    cs, csr, key, z_in, z_aux = _instance(oracle, seed, gates, nin, naux)
+    params = params_from_oracle_key(key, r1cs_product(csr))
+    dk = ctx.load_key(params)
+    z = fx.witness_mont(z_in, z_aux)
+    r, s = fx.mont_fr(0x1234567 * seed), fx.mont_fr(0x7654321 + seed)
+    a, b, c, aa, bi, ba = oracle.synthesize(csr, z)
+    want, want_msm = oracle.prove(key, a, b, c, z, aa, bi, ba, r, s, want_msm=True)
+    got_msm = ctx.prove_msms(dk, a, b, c, z, aa, bi, ba)
+    assert got_msm.tobytes() == want_msm.tobytes()
+    _, proof = fk.prove_with_rs(ctx, params, dk, z[:nin], z[nin:], r, s)
+    assert proof.to_bytes() == want.tobytes()
+    assert ref.verify(fx.key_to_py(key), z_in[1:], ref.proof_from_borsh(proof.to_bytes()))
+
+
+def test_config1_shape_bit_exact_and_verifies(ctx, oracle):
+    """BASELINE configs[0]: poseidon-merkle depth-32 shape (7362 gates + 2 input rows = 7364 rows, m = 2^13,
+    2 inputs, 7394 aux), synthetic satisfiable R1CS.  HIP proof == oracle proof, and the pairing holds."""
+    import fawkes_crypto_amd as fk
+    cs, csr, key, z_in, z_aux = _instance(oracle, 11, 7362, 2, 7394)
+    assert key.m == 1 << 13
+    params = params_from_oracle_key(key, r1cs_product(csr))
+    dk = ctx.load_key(params)
+    z = fx.witness_mont(z_in, z_aux)
+    r, s = fx.mont_fr(0xabcdef0123456789), fx.mont_fr(0x9876543210fedcba)
+    a, b, c, aa, bi, ba = oracle.synthesize(csr, z)
+    want = oracle.prove(key, a, b, c, z, aa, bi, ba, r, s)
+    inputs, proof, tm = fk.prove_with_rs(ctx, params, dk, z[:2], z[2:], r, s, want_timings=True)
+    assert proof.to_bytes() == want.tobytes()
+    assert ref.verify(fx.key_to_py(key), z_in[1:], ref.proof_from_borsh(proof.to_bytes()))
+    assert tm['total_ms'] > 0
+    # random r, s through the OsRng-style sampler: different bytes, still a valid proof
+    _, p2 = fk.prove(ctx, params, dk, z[:2], z[2:])
+    assert p2.to_bytes() != proof.to_bytes()
+    assert ref.verify(fx.key_to_py(key), z_in[1:], ref.proof_from_borsh(p2.to_bytes()))
+
+
+def test_sharded_equals_unsharded(ctx, oracle):
+    """MSM sharding by points: 3 shards run one after another on this GPU, partials folded by
+    fk_prove_assemble, must reproduce the single-GPU proof bytes."""
+    cs, csr, key, z_in, z_aux = _instance(oracle, 21, 500, 3, 520)
+    params = params_from_oracle_key(key, r1cs_product(csr))
+    z = fx.witness_mont(z_in, z_aux)
+    r, s = fx.mont_fr(77), fx.mont_fr(88)
+    a, b, c, aa, bi, ba = ctx.synthesize(params.r1cs, z)
+    dk = ctx.load_key(params)
+    want = ctx.prove_raw(dk, a, b, c, z, aa, bi, ba, r, s)
+    parts = []
+    for i in range(3):
+        sk = ctx.load_key(params, shard_index=i, shard_count=3)
+        parts.append(ctx.prove_msms(sk, a, b, c, z, aa, bi, ba))
+        sk.free()
+    got = ctx.prove_assemble(dk, np.stack(parts), r, s)
+    assert got.tobytes() == want.tobytes()
+    assert want.tobytes() == oracle.prove(key, a, b, c, z, aa, bi, ba, r, s).tobytes()
+
+
+def test_error_behaviour(ctx, oracle):
+    """C ABI returns codes where bellman returns SynthesisError."""
+    import fawkes_crypto_amd as fk
+    cs, csr, key, z_in, z_aux = _instance(oracle, 31, 20, 2, 25)
+    params = params_from_oracle_key(key, r1cs_product(csr))
+    dk = ctx.load_key(params)
+    z = fx.witness_mont(z_in, z_aux)
+    a, b, c, aa, bi, ba = ctx.synthesize(params.r1cs, z)
+    r, s = fx.mont_fr(1), fx.mont_fr(2)
+    # density map that selects a different number of points than the key holds
+    bad = ba.copy(); bad[:] = 1 - bad
+    with pytest.raises(fk.FkError) as e:
+        ctx.prove_raw(dk, a, b, c, z, aa, bi, bad, r, s)
+    assert e.value.code == 6
+    # wrong row count for the key's domain
+    with pytest.raises(fk.FkError) as e:
+        ctx.prove_raw(dk, a[:5], b[:5], c[:5], z, aa, bi, ba, r, s)
+    assert e.value.code == 6
+    # delta = identity -> UnexpectedIdentity
+    arrays = dict(m=key.m, num_input=key.num_input, num_aux=key.num_aux, alpha_g1=key.alpha_g1, beta_g1=key.beta_g1,
+                  beta_g2=key.beta_g2, delta_g1=np.zeros(64, np.uint8), delta_g2=key.delta_g2,
+                  h=np.array(key.h), l=np.array(key.l), a=np.array(key.a), b_g1=np.array(key.b_g1), b_g2=np.array(key.b_g2))
+    dk0 = ctx.load_key(fk.Parameters(arrays))
+    with pytest.raises(fk.FkError) as e:
+        ctx.prove_raw(dk0, a, b, c, z, aa, bi, ba, r, s)
+    assert e.value.code == 3
+    # malformed key shapes
+    arrays['h'] = arrays['h'][:-1]
+    with pytest.raises(fk.FkError) as e:
+        ctx.load_key(fk.Parameters(arrays))
+    assert e.value.code == 6
+
+
+def test_synthetic_key_full_pipeline_2_16(ctx):
+    """Device-resident pipeline with a synthetic key at 2^16: runs, is deterministic, and differs when
+    the witness changes (smoke for the bench path)."""
+    m = 1 << 16
+    v_in, v_aux = 4, m - 4
+    n = m
+    rng = np.random.default_rng(3)
+    dens_a = (rng.integers(0, 10, v_aux) < 6).astype(np.uint8)
+    dens_bi = np.ones(v_in, np.uint8)
+    dens_ba = (rng.integers(0, 10, v_aux) < 6).astype(np.uint8)
+    n_a = v_in + int(dens_a.sum()); n_b = int(dens_bi.sum()) + int(dens_ba.sum())
+    key = ctx.synthetic_key(m, v_in, v_aux, n_a, n_b, seed=5)
+    bufs = {k: ctx.dev_alloc(m * 32) for k in 'abc'}
+    d_z = ctx.dev_alloc((v_in + v_aux) * 32)
+    d_da, d_dbi, d_dba = ctx.dev_alloc(v_aux), ctx.dev_alloc(v_in), ctx.dev_alloc(v_aux)
+    try:
+        ctx.upload(d_da, dens_a); ctx.upload(d_dbi, dens_bi); ctx.upload(d_dba, dens_ba)
+        ctx.gen_scalars_dev(d_z, v_in + v_aux, 9, 1)
+        outs = []
+        for seed in (1, 1, 2):
+            for i, k in enumerate('abc'):
+                ctx.gen_scalars_dev(bufs[k], n, seed * 10 + i, 0)
+            outs.append(ctx.prove_dev(key, bufs['a'], bufs['b'], bufs['c'], n, d_z, d_da, d_dbi, d_dba,
+                                      fx.mont_fr(3), fx.mont_fr(4)).tobytes())
+        assert outs[0] == outs[1] and outs[0] != outs[2] and outs[0] != bytes(256)
+    finally:
+        for p in list(bufs.values()) + [d_z, d_da, d_dbi, d_dba]:
+            ctx.dev_free(p)
+        key.free()
