@@ -48,6 +48,7 @@ struct fk_ctx {
     std::vector<fk::EventPair> ev_acc, ev_ntt;
     std::vector<hipEvent_t> ev_pool;
     bool stats_on = true;
+    bool debug = false;   // FK_DEBUG=1: synchronise and log after every launch
 };
 
 struct fk_key {
@@ -78,6 +79,16 @@ struct fk_key {
             snprintf(_b, sizeof _b, "%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
             (ctx)->err = _b;                                                                      \
             return (_e == hipErrorOutOfMemory) ? FK_ERR_OOM : FK_ERR_HIP;                         \
+        }                                                                                         \
+    } while (0)
+
+// debug aid: FK_DEBUG=1 makes every stage synchronise and report (stderr)
+#define FK_DBG(ctx, name)                                                                         \
+    do {                                                                                          \
+        if ((ctx)->debug) {                                                                       \
+            fprintf(stderr, "[fk] launch %s ...", name); fflush(stderr);                          \
+            hipError_t _e = hipStreamSynchronize((ctx)->stream);                                  \
+            fprintf(stderr, " %s\n", hipGetErrorString(_e)); fflush(stderr);                      \
         }                                                                                         \
     } while (0)
 

@@ -39,7 +39,18 @@ struct FrParams {
     static constexpr uint32_t INV = FK_FR_INV;
 };
 
+// INL = true : the CIOS body is inlined at every use (hot kernels).
+// INL = false: on the device the product is an out-of-line call with by-value register arguments --
+//              same layout, same results, ~20x less code per point formula (cold kernels: reductions,
+//              generators).  The two instantiations are layout-identical and may be reinterpret_cast.
+template <class P, bool INL = true>
+struct Fp;
+#if defined(__HIP_DEVICE_COMPILE__)
 template <class P>
+__device__ __noinline__ Fp<P, false> mont_mul_call(Fp<P, false> a, Fp<P, false> b);
+#endif
+
+template <class P, bool INL>
 struct alignas(16) Fp {
     uint32_t v[8];
 
@@ -104,8 +115,17 @@ struct alignas(16) Fp {
     }
     static FK_HD Fp neg(const Fp &a) { return sub(zero(), a); }
 
-    // CIOS Montgomery product a * b * 2^-256 mod p.
     static FK_HD Fp mul(const Fp &a, const Fp &b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (!INL) return mont_mul_call<P>(a, b);
+        else return mul_body(a, b);
+#else
+        return mul_body(a, b);
+#endif
+    }
+
+    // CIOS Montgomery product a * b * 2^-256 mod p.
+    static FK_HD Fp mul_body(const Fp &a, const Fp &b) {
         uint32_t t[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) t[i] = 0;
@@ -172,11 +192,21 @@ struct alignas(16) Fp {
     }
 };
 
-using Fq = Fp<FqParams>;
-using Fr = Fp<FrParams>;
+#if defined(__HIP_DEVICE_COMPILE__)
+template <class P>
+__device__ __noinline__ Fp<P, false> mont_mul_call(Fp<P, false> a, Fp<P, false> b) {
+    return Fp<P, false>::mul_body(a, b);
+}
+#endif
+
+using Fq = Fp<FqParams, true>;
+using FqC = Fp<FqParams, false>;    // "cold": out-of-line multiply
+using Fr = Fp<FrParams, true>;
 
 // Fq2 = Fq[u]/(u^2 + 1)   (pairing_ce bn256 tower)
-struct alignas(16) Fq2 {
+template <class Fq>
+struct alignas(16) Fq2T {
+    using Fq2 = Fq2T;
     Fq c0, c1;
     static FK_HD Fq2 zero() { return Fq2{Fq::zero(), Fq::zero()}; }
     static FK_HD Fq2 one() { return Fq2{Fq::one(), Fq::zero()}; }
@@ -203,5 +233,13 @@ struct alignas(16) Fq2 {
         return Fq2{Fq::mul(a.c0, n), Fq::neg(Fq::mul(a.c1, n))};
     }
 };
+
+using Fq2 = Fq2T<Fq>;
+using Fq2C = Fq2T<FqC>;
+
+// cold twin of a coordinate field (same layout, out-of-line multiply)
+template <class F> struct ColdOf;
+template <> struct ColdOf<Fq> { using type = FqC; };
+template <> struct ColdOf<Fq2> { using type = Fq2C; };
 
 }  // namespace fk

@@ -21,6 +21,7 @@
 //   6. host            W window sums are Horner-combined (c doublings each) -- microseconds.
 #include "common.hpp"
 #include <algorithm>
+#include <string.h>
 
 namespace fk {
 
@@ -163,14 +164,6 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_scatter_kernel(const uint32_
     }
 }
 
-// ------------------------------------------------------------------------------------------ cold-path point ops
-// Only msm_accumulate_kernel is hot; everything else calls these out-of-line copies so that the
-// 14-multiplication group law is instantiated once per field instead of once per call site.
-template <class F> static __device__ __noinline__ void pt_add(Xyzz<F> &a, const Xyzz<F> &b) { a.add(b); }
-template <class F> static __device__ __noinline__ void pt_add_mixed(Xyzz<F> &a, const Affine<F> &b) { a.add_mixed(b); }
-template <class F> static __device__ __noinline__ void pt_dbl(Xyzz<F> &a) { a = Xyzz<F>::dbl(a); }
-template <class F> static __device__ __noinline__ void pt_to_affine(Affine<F> &o, const Xyzz<F> &a) { o = a.to_affine(); }
-
 // ------------------------------------------------------------------------------------------ wave / block reductions
 template <class T>
 static __device__ __forceinline__ T shfl_down_obj(const T &v, int off) {
@@ -189,7 +182,7 @@ static __device__ __forceinline__ void wave_reduce(Xyzz<F> &acc) {
 #pragma unroll 1
     for (int off = 32; off >= 1; off >>= 1) {
         Xyzz<F> o = shfl_down_obj(acc, off);
-        pt_add(acc, o);
+        acc.add(o);
     }
 }
 
@@ -202,7 +195,7 @@ static __device__ __forceinline__ void block_reduce_256(Xyzz<F> &acc, Xyzz<F> *s
     __syncthreads();
     if (threadIdx.x == 0) {
         acc = sh[0];
-        for (int k = 1; k < 4; k++) { Xyzz<F> o = sh[k]; pt_add(acc, o); }
+        for (int k = 1; k < 4; k++) { Xyzz<F> o = sh[k]; acc.add(o); }
     }
 }
 
@@ -243,8 +236,7 @@ __global__ __launch_bounds__(256) void msm_overflow_kernel(const Affine<F> *base
     Xyzz<F> acc = Xyzz<F>::inf();
     for (uint32_t k = lo + threadIdx.x; k < hi; k += 256) {
         const uint32_t e = src[k];
-        Affine<F> p = affine_neg_if(bases[e & 0x7fffffffu], (e >> 31) != 0);
-        pt_add_mixed(acc, p);
+        acc.add_mixed(affine_neg_if(bases[e & 0x7fffffffu], (e >> 31) != 0));
     }
     block_reduce_256(acc, sh);
     if (threadIdx.x == 0) partials[blockIdx.x] = acc;
@@ -257,9 +249,9 @@ template <class F>
 __global__ __launch_bounds__(64) void msm_overflow_fold_kernel(const OverBucket *ob, const Xyzz<F> *partials, Xyzz<F> *buckets) {
     const OverBucket o = ob[blockIdx.x];
     Xyzz<F> acc = Xyzz<F>::inf();
-    for (uint32_t k = threadIdx.x; k < o.ntask; k += 64) { Xyzz<F> q = partials[o.task0 + k]; pt_add(acc, q); }
+    for (uint32_t k = threadIdx.x; k < o.ntask; k += 64) acc.add(partials[o.task0 + k]);
     wave_reduce(acc);
-    if (threadIdx.x == 0) { Xyzz<F> b = buckets[o.g]; pt_add(b, acc); buckets[o.g] = b; }
+    if (threadIdx.x == 0) { Xyzz<F> b = buckets[o.g]; b.add(acc); buckets[o.g] = b; }
 }
 
 // ------------------------------------------------------------------------------------------ bucket reduction
@@ -275,19 +267,18 @@ __global__ __launch_bounds__(256) void msm_bucket_reduce_kernel(const Xyzz<F> *b
         Xyzz<F> run = Xyzz<F>::inf();
         const Xyzz<F> *bk = buckets + (size_t)w * B + (size_t)t * L;
         for (uint32_t s = L; s-- > 0;) {
-            Xyzz<F> q = bk[s];
-            pt_add(run, q);
-            pt_add(acc, run);
+            run.add(bk[s]);
+            acc.add(run);
         }
         // + (t*L) * run
         const uint32_t k = t * L;
         if (k) {
             Xyzz<F> m = Xyzz<F>::inf();
             for (int bit = 31 - __clz(k); bit >= 0; bit--) {
-                pt_dbl(m);
-                if ((k >> bit) & 1) pt_add(m, run);
+                m = Xyzz<F>::dbl(m);
+                if ((k >> bit) & 1) m.add(run);
             }
-            pt_add(acc, m);
+            acc.add(m);
         }
     }
     block_reduce_256(acc, sh);
@@ -297,6 +288,7 @@ __global__ __launch_bounds__(256) void msm_bucket_reduce_kernel(const Xyzz<F> *b
 // ------------------------------------------------------------------------------------------ host driver
 template <class F>
 static int msm_run(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars, size_t n, Xyzz<F> *out) {
+    using FC = typename ColdOf<F>::type;   // layout-identical field with an out-of-line multiply
     *out = Xyzz<F>::inf();
     if (n == 0) return FK_OK;
     if (n >= ((size_t)1 << 31)) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "msm: n too large");
@@ -319,25 +311,31 @@ static int msm_run(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars, s
 
     hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, p.c, p.W, digits);
     FK_HIP(ctx, hipGetLastError());
+    FK_DBG(ctx, "msm_digits");
     const size_t lds = (size_t)p.B * 4;
     FK_HIP(ctx, hipFuncSetAttribute((const void *)msm_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     FK_HIP(ctx, hipFuncSetAttribute((const void *)msm_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(msm_hist_kernel, dim3(p.nchunks, p.W), dim3(SORT_THREADS), lds, st, digits, n, p.chunk, p.nchunks, p.B, counts);
     FK_HIP(ctx, hipGetLastError());
+    FK_DBG(ctx, "msm_hist");
     hipLaunchKernelGGL(msm_chunk_prefix_kernel, dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, counts, p.nchunks, p.B, p.W, totals);
     FK_HIP(ctx, hipGetLastError());
+    FK_DBG(ctx, "msm_chunk_prefix");
     FK_HIP(ctx, hipMemsetAsync(d_nover, 0, 4, st));
     hipLaunchKernelGGL(msm_window_scan_kernel, dim3(p.W), dim3(1024), 0, st, totals, p.B, p.cap, starts,
                        ctx->overlist.as<OverEntry>(), d_nover, over_cap);
     FK_HIP(ctx, hipGetLastError());
+    FK_DBG(ctx, "msm_window_scan");
     hipLaunchKernelGGL(msm_scatter_kernel, dim3(p.nchunks, p.W), dim3(SORT_THREADS), lds, st, digits, n, p.chunk, p.nchunks, p.B,
                        counts, starts, sorted);
     FK_HIP(ctx, hipGetLastError());
+    FK_DBG(ctx, "msm_scatter");
 
     FK_TRY(stats_begin(ctx, ctx->ev_acc, (uint64_t)n));
     hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_kernel<F>), dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, d_bases, sorted, n,
                        starts, totals, p.B, p.W, p.cap, buckets);
     FK_HIP(ctx, hipGetLastError());
+    FK_DBG(ctx, "msm_accumulate");
     FK_TRY(stats_end(ctx, ctx->ev_acc));
 
     // oversized buckets (skewed scalars): host builds the segment table -- a few entries in practice
@@ -365,17 +363,22 @@ static int msm_run(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars, s
         OverBucket *d_obs = (OverBucket *)((char *)ctx->tasktab.p + tb_al);
         FK_HIP(ctx, hipMemcpyAsync(d_tasks, tasks.data(), tb, hipMemcpyHostToDevice, st));
         FK_HIP(ctx, hipMemcpyAsync(d_obs, obs.data(), ob, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_overflow_kernel<F>), dim3((unsigned)tasks.size()), dim3(256), 0, st, d_bases, sorted, n, starts,
-                           totals, p.B, p.cap, d_tasks, ctx->partials.as<Xyzz<F>>());
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_overflow_kernel<FC>), dim3((unsigned)tasks.size()), dim3(256), 0, st,
+                           reinterpret_cast<const Affine<FC> *>(d_bases), sorted, n, starts,
+                           totals, p.B, p.cap, d_tasks, ctx->partials.as<Xyzz<FC>>());
         FK_HIP(ctx, hipGetLastError());
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_overflow_fold_kernel<F>), dim3((unsigned)obs.size()), dim3(64), 0, st, d_obs,
-                           ctx->partials.as<Xyzz<F>>(), buckets);
+    FK_DBG(ctx, "msm_overflow");
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_overflow_fold_kernel<FC>), dim3((unsigned)obs.size()), dim3(64), 0, st, d_obs,
+                           ctx->partials.as<Xyzz<FC>>(), reinterpret_cast<Xyzz<FC> *>(buckets));
         FK_HIP(ctx, hipGetLastError());
+    FK_DBG(ctx, "msm_overflow_fold");
         FK_HIP(ctx, hipStreamSynchronize(st));  // tasks/obs vectors must outlive the async copies
     }
 
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_bucket_reduce_kernel<F>), dim3(p.nblk, p.W), dim3(256), 0, st, buckets, p.B, p.L, p.T, p.nblk, winparts);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_bucket_reduce_kernel<FC>), dim3(p.nblk, p.W), dim3(256), 0, st,
+                       reinterpret_cast<const Xyzz<FC> *>(buckets), p.B, p.L, p.T, p.nblk, reinterpret_cast<Xyzz<FC> *>(winparts));
     FK_HIP(ctx, hipGetLastError());
+    FK_DBG(ctx, "msm_bucket_reduce");
 
     std::vector<Xyzz<F>> wp((size_t)p.W * p.nblk);
     FK_HIP(ctx, hipMemcpyAsync(wp.data(), winparts, wp.size() * sizeof(Xyzz<F>), hipMemcpyDeviceToHost, st));
@@ -387,6 +390,7 @@ static int msm_run(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars, s
         for (uint32_t b = 0; b < p.nblk; b++) acc.add(wp[(size_t)w * p.nblk + b]);
     }
     *out = acc;
+    if (ctx->debug) { fprintf(stderr, "[fk] msm host horner done\n"); fflush(stderr); }
     return FK_OK;
 }
 
@@ -419,15 +423,13 @@ __global__ __launch_bounds__(64) void gen_points_kernel(Affine<F> gen, Affine<F>
     k[7] &= 0x0fffffffu;  // < 2^252 < r
     Xyzz<F> acc = Xyzz<F>::inf();
     for (int i = 251; i >= 0; i--) {
-        pt_dbl(acc);
-        if ((k[i >> 5] >> (i & 31)) & 1) pt_add_mixed(acc, gen);
+        acc = Xyzz<F>::dbl(acc);
+        if ((k[i >> 5] >> (i & 31)) & 1) acc.add_mixed(gen);
     }
     size_t hi = lo + per < n ? lo + per : n;
     for (size_t i = lo; i < hi; i++) {
-        Affine<F> o;
-        pt_to_affine(o, acc);
-        out[i] = o;
-        pt_add_mixed(acc, step);
+        out[i] = acc.to_affine();
+        acc.add_mixed(step);
     }
 }
 
@@ -452,7 +454,12 @@ static int gen_points(fk_ctx *ctx, const Affine<F> &gen, Affine<F> *d_out, size_
     Affine<F> step = Xyzz<F>::mul_scalar(Xyzz<F>::from_affine(gen), kd).to_affine();
     const uint32_t per = 16;
     const size_t threads = (n + per - 1) / per;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(gen_points_kernel<F>), dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, ctx->stream, gen, step, d_out, n, per, seed);
+    using FC = typename ColdOf<F>::type;
+    Affine<FC> genc, stepc;
+    static_assert(sizeof(genc) == sizeof(gen), "layout");
+    memcpy(&genc, &gen, sizeof gen); memcpy(&stepc, &step, sizeof step);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(gen_points_kernel<FC>), dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, ctx->stream, genc, stepc,
+                       reinterpret_cast<Affine<FC> *>(d_out), n, per, seed);
     FK_HIP(ctx, hipGetLastError());
     return FK_OK;
 }

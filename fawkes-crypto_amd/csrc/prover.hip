@@ -10,6 +10,7 @@
 #include "common.hpp"
 #include <chrono>
 #include <string.h>
+#include <stdlib.h>
 
 using namespace fk;
 
@@ -63,6 +64,7 @@ int fk_init(int device_id, fk_ctx **out) {
     if (hipSetDevice(device_id) != hipSuccess) return FK_ERR_HIP;
     fk_ctx *ctx = new fk_ctx();
     ctx->device = device_id;
+    { const char *d = getenv("FK_DEBUG"); ctx->debug = d && d[0] && d[0] != '0'; }
     if (hipStreamCreate(&ctx->stream) != hipSuccess) { delete ctx; return FK_ERR_HIP; }
     *out = ctx;
     return FK_OK;
