@@ -24,7 +24,7 @@ FQ_MODULUS = 2188824287183927522224640574525727508869631115729782366268903789464
 # every symbol include/fawkes_hip.h declares (tests check the .so exports all of them)
 EXPORTED_SYMBOLS = [
     'fk_init', 'fk_free', 'fk_last_error', 'fk_set_window_bits',
-    'fk_dev_alloc', 'fk_dev_free', 'fk_upload', 'fk_download', 'fk_sync',
+    'fk_dev_alloc', 'fk_dev_free', 'fk_upload', 'fk_download', 'fk_dev_copy', 'fk_sync',
     'fk_key_load', 'fk_key_synthetic', 'fk_key_host_vk', 'fk_key_free',
     'fk_prove', 'fk_prove_dev', 'fk_prove_msms', 'fk_prove_msms_dev', 'fk_prove_assemble',
     'fk_fr_mul_batch', 'fk_ntt', 'fk_ntt_dev', 'fk_quotient_h', 'fk_quotient_h_dev',
@@ -461,11 +461,16 @@ class Context:
         self._ck(self.lib.fk_stats_reset(self.handle))
 
     def stats(self):
-        acc_ms, ntt_ms = C.c_double(), C.c_double()
-        acc_n, acc_pts, ntt_n = C.c_uint64(), C.c_uint64(), C.c_uint64()
-        self._ck(self.lib.fk_stats_get(self.handle, C.byref(acc_ms), C.byref(acc_n), C.byref(acc_pts), C.byref(ntt_ms), C.byref(ntt_n)))
-        return dict(accumulate_ms=acc_ms.value, accumulate_launches=acc_n.value, accumulate_points=acc_pts.value,
-                    ntt_ms=ntt_ms.value, ntt_launches=ntt_n.value)
+        """HIP-event kernel times since stats_reset(): G1/G2 bucket accumulation and NTT passes."""
+        out = {}
+        for which, name in ((0, 'acc_g1'), (1, 'acc_g2'), (2, 'ntt')):
+            ms, n, u = C.c_double(), C.c_uint64(), C.c_uint64()
+            self._ck(self.lib.fk_stats_get(self.handle, C.c_int(which), C.byref(ms), C.byref(n), C.byref(u)))
+            out[name] = dict(ms=ms.value, launches=n.value, units=u.value)
+        return out
+
+    def dev_copy(self, dst, src, nbytes):
+        self._ck(self.lib.fk_dev_copy(self.handle, C.c_void_p(dst), C.c_void_p(src), C.c_size_t(nbytes)))
 
 
 def synthesize(r1cs, z, ctx=None):

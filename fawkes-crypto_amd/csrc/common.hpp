@@ -45,7 +45,7 @@ struct fk_ctx {
     // NTT / prover scratch
     fk::DevBuf ntt_s1, ntt_s2, ntt_io, hbuf, sc_a, sc_b, scan_tmp, stage_a, stage_b, stage_c, stage_z, stage_d;
     // stats
-    std::vector<fk::EventPair> ev_acc, ev_ntt;
+    std::vector<fk::EventPair> ev_acc, ev_acc2, ev_ntt;   // G1 accumulate, G2 accumulate, NTT passes
     std::vector<hipEvent_t> ev_pool;
     bool stats_on = true;
     bool debug = false;   // FK_DEBUG=1: synchronise and log after every launch

@@ -331,12 +331,13 @@ static int msm_run(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars, s
     FK_HIP(ctx, hipGetLastError());
     FK_DBG(ctx, "msm_scatter");
 
-    FK_TRY(stats_begin(ctx, ctx->ev_acc, (uint64_t)n));
+    std::vector<EventPair> &evv = (sizeof(F) == sizeof(Fq)) ? ctx->ev_acc : ctx->ev_acc2;
+    FK_TRY(stats_begin(ctx, evv, (uint64_t)n));
     hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_kernel<F>), dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, d_bases, sorted, n,
                        starts, totals, p.B, p.W, p.cap, buckets);
     FK_HIP(ctx, hipGetLastError());
     FK_DBG(ctx, "msm_accumulate");
-    FK_TRY(stats_end(ctx, ctx->ev_acc));
+    FK_TRY(stats_end(ctx, evv));
 
     // oversized buckets (skewed scalars): host builds the segment table -- a few entries in practice
     uint32_t n_over = 0;

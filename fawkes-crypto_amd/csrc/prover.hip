@@ -80,7 +80,7 @@ void fk_free(fk_ctx *ctx) {
                       &ctx->hbuf, &ctx->sc_a, &ctx->sc_b, &ctx->scan_tmp, &ctx->stage_a, &ctx->stage_b, &ctx->stage_c,
                       &ctx->stage_z, &ctx->stage_d})
         b->release();
-    for (auto &v : {&ctx->ev_acc, &ctx->ev_ntt}) for (auto &ep : *v) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
+    for (auto &v : {&ctx->ev_acc, &ctx->ev_acc2, &ctx->ev_ntt}) for (auto &ep : *v) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -117,6 +117,11 @@ int fk_download(fk_ctx *ctx, void *host, const void *dptr, size_t bytes) {
     if (!ctx) return FK_ERR_BAD_ARG;
     if (bytes) FK_HIP(ctx, hipMemcpyAsync(host, dptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
     FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FK_OK;
+}
+int fk_dev_copy(fk_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (!ctx) return FK_ERR_BAD_ARG;
+    if (bytes) FK_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     return FK_OK;
 }
 int fk_sync(fk_ctx *ctx) {
@@ -562,24 +567,22 @@ void fk_shard_range(uint64_t n, uint32_t index, uint32_t count, uint64_t *lo, ui
 int fk_stats_reset(fk_ctx *ctx) {
     if (!ctx) return FK_ERR_BAD_ARG;
     FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (auto *v : {&ctx->ev_acc, &ctx->ev_ntt}) {
+    for (auto *v : {&ctx->ev_acc, &ctx->ev_acc2, &ctx->ev_ntt}) {
         for (auto &ep : *v) { ctx->ev_pool.push_back(ep.a); ctx->ev_pool.push_back(ep.b); }
         v->clear();
     }
     return FK_OK;
 }
-int fk_stats_get(fk_ctx *ctx, double *acc_ms, uint64_t *acc_launches, uint64_t *acc_points, double *ntt_ms, uint64_t *ntt_launches) {
+int fk_stats_get(fk_ctx *ctx, int which, double *ms, uint64_t *launches, uint64_t *units) {
     if (!ctx) return FK_ERR_BAD_ARG;
+    if (which < 0 || which > 2) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "stats: which must be 0 (G1 accumulate), 1 (G2 accumulate) or 2 (NTT pass)");
     FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    double t = 0; uint64_t pts = 0;
-    for (auto &ep : ctx->ev_acc) { float ms = 0; FK_HIP(ctx, hipEventElapsedTime(&ms, ep.a, ep.b)); t += ms; pts += ep.units; }
-    if (acc_ms) *acc_ms = t;
-    if (acc_launches) *acc_launches = ctx->ev_acc.size();
-    if (acc_points) *acc_points = pts;
-    t = 0;
-    for (auto &ep : ctx->ev_ntt) { float ms = 0; FK_HIP(ctx, hipEventElapsedTime(&ms, ep.a, ep.b)); t += ms; }
-    if (ntt_ms) *ntt_ms = t;
-    if (ntt_launches) *ntt_launches = ctx->ev_ntt.size();
+    std::vector<EventPair> &v = which == 0 ? ctx->ev_acc : (which == 1 ? ctx->ev_acc2 : ctx->ev_ntt);
+    double t = 0; uint64_t u = 0;
+    for (auto &ep : v) { float x = 0; FK_HIP(ctx, hipEventElapsedTime(&x, ep.a, ep.b)); t += x; u += ep.units; }
+    if (ms) *ms = t;
+    if (launches) *launches = v.size();
+    if (units) *units = u;
     return FK_OK;
 }
 

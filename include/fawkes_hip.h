@@ -67,6 +67,8 @@ int fk_dev_alloc(fk_ctx *ctx, size_t bytes, void **dptr);
 int fk_dev_free(fk_ctx *ctx, void *dptr);
 int fk_upload(fk_ctx *ctx, void *dptr, const void *host, size_t bytes);
 int fk_download(fk_ctx *ctx, void *host, const void *dptr, size_t bytes);
+/* asynchronous device-to-device copy on the library stream */
+int fk_dev_copy(fk_ctx *ctx, void *dst, const void *src, size_t bytes);
 int fk_sync(fk_ctx *ctx);
 
 /* ---------------------------------------------------------------- proving key
@@ -173,11 +175,11 @@ typedef struct {
 int fk_synthesize(fk_ctx *ctx, const fk_r1cs *cs, const uint64_t *z, uint64_t *a, uint64_t *b, uint64_t *c,
                   uint8_t *a_aux_density, uint8_t *b_input_density, uint8_t *b_aux_density);
 
-/* last-call kernel timing of the dominant MSM kernel (bucket accumulation), measured with HIP events
- * on the library's stream: milliseconds and number of launches since the last reset. */
+/* Kernel timing measured with HIP events on the library's stream since the last reset, summed over
+ * launches.  which: 0 = msm_accumulate_kernel<Fq> (G1 bucket accumulation; units = points per launch),
+ * 1 = msm_accumulate_kernel<Fq2> (G2), 2 = ntt_pass_kernel (units = elements per pass). */
 int fk_stats_reset(fk_ctx *ctx);
-int fk_stats_get(fk_ctx *ctx, double *accumulate_ms, uint64_t *accumulate_launches, uint64_t *accumulate_points,
-                 double *ntt_ms, uint64_t *ntt_launches);
+int fk_stats_get(fk_ctx *ctx, int which, double *ms, uint64_t *launches, uint64_t *units);
 
 #ifdef __cplusplus
 }

@@ -235,6 +235,33 @@ class Key:
             pass
 
 
+class ArrayKey:
+    """An orc_key whose arrays are numpy-owned (e.g. a synthetic key downloaded from the GPU)."""
+
+    def __init__(self, m, num_input, num_aux, vk, h, l, a, b_g1, b_g2, ic=None):
+        self._keep = []
+
+        def arr(x, w):
+            x = np.ascontiguousarray(x, np.uint8).reshape(-1, w)
+            self._keep.append(x)
+            return x
+        k = OrcKey()
+        k.m, k.num_input, k.num_aux = m, num_input, num_aux
+        self.h, self.l, self.a = arr(h, 64), arr(l, 64), arr(a, 64)
+        self.b_g1, self.b_g2 = arr(b_g1, 64), arr(b_g2, 128)
+        self.ic = arr(ic if ic is not None else np.zeros((num_input, 64), np.uint8), 64)
+        k.n_h, k.n_l, k.n_a, k.n_b = self.h.shape[0], self.l.shape[0], self.a.shape[0], self.b_g1.shape[0]
+        for nm, w in (('alpha_g1', 64), ('beta_g1', 64), ('beta_g2', 128), ('gamma_g2', 128), ('delta_g1', 64), ('delta_g2', 128)):
+            v = np.ascontiguousarray(vk.get(nm, np.zeros(w, np.uint8)), np.uint8).reshape(-1)
+            C.memmove(getattr(k, nm), v.ctypes.data, w)
+            setattr(self, nm, v.copy())
+        for nm in ('ic', 'h', 'l', 'a', 'b_g1', 'b_g2'):
+            setattr(k, nm, getattr(self, nm).ctypes.data)
+        self.struct = k
+        self.ptr = C.pointer(k)
+        self.m, self.num_input, self.num_aux = m, num_input, num_aux
+
+
 def setup(cs, tau, alpha, beta, gamma, delta, g1=None, g2=None):
     """Toxic waste as python ints (canonical)."""
     import bn254_ref as ref

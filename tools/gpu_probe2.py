@@ -45,6 +45,6 @@ for lg in (16, 20, 22):
         dt = (time.time() - t) / reps
         st = ctx.stats()
         log('msm_g1 2^%d kind=%d: %.2f ms  (%.1f M scalar-muls/s; accumulate kernel %.2f ms/launch)' % (
-            lg, kind, dt * 1e3, n / dt / 1e6, st['accumulate_ms'] / max(st['accumulate_launches'], 1)))
+            lg, kind, dt * 1e3, n / dt / 1e6, st['acc_g1']['ms'] / max(st['acc_g1']['launches'], 1)))
     ctx.dev_free(db); ctx.dev_free(ds)
 log('done')
