@@ -91,7 +91,7 @@ def main():
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--log2n', type=int, default=25, help='log2 of the constraint count (rows handed to the prover)')
-    ap.add_argument('--cpu-log2n', type=int, default=15, help='size of the CPU-baseline sample instance')
+    ap.add_argument('--cpu-log2n', type=int, default=18, help='size of the CPU-baseline sample instance')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
