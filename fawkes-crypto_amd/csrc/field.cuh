@@ -6,9 +6,11 @@
 // bellman receives the same raw limbs (backend/bellman_groth16/mod.rs:105-120).  8 x u32 LE is the
 // same byte image, so witness buffers are read as-is.
 //
-// No MFMA here: this is 256-bit integer modular arithmetic.  The product is a CIOS Montgomery
-// multiplication built from 32x32->64 multiply-adds (v_mad_u64_u32 on CDNA4); every value that
-// leaves a function is fully reduced to [0, p) so equality tests are plain limb compares.
+// No MFMA here: this is 256-bit integer modular arithmetic.  On the device the product is a
+// product-scanning Montgomery multiplication (mont_mul_gfx950.inc, generated): 128 v_mad_u64_u32, each
+// followed by one v_addc that folds the carry-out into a 96-bit column accumulator.  The host pass (and
+// the reference for the device code) is the plain CIOS loop `mul_body`.  Every value that leaves a
+// function is fully reduced to [0, p) so equality tests are plain limb compares.
 #pragma once
 #include <stdint.h>
 #include "bn254_consts.h"
@@ -118,11 +120,15 @@ struct alignas(16) Fp {
     static FK_HD Fp mul(const Fp &a, const Fp &b) {
 #if defined(__HIP_DEVICE_COMPILE__)
         if constexpr (!INL) return mont_mul_call<P>(a, b);
-        else return mul_body(a, b);
+        else return mul_body_asm(a, b);
 #else
         return mul_body(a, b);
 #endif
     }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#include "mont_mul_gfx950.inc"
+#endif
 
     // CIOS Montgomery product a * b * 2^-256 mod p.
     static FK_HD Fp mul_body(const Fp &a, const Fp &b) {
@@ -195,7 +201,7 @@ struct alignas(16) Fp {
 #if defined(__HIP_DEVICE_COMPILE__)
 template <class P>
 __device__ __noinline__ Fp<P, false> mont_mul_call(Fp<P, false> a, Fp<P, false> b) {
-    return Fp<P, false>::mul_body(a, b);
+    return Fp<P, false>::mul_body_asm(a, b);
 }
 #endif
 
