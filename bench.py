@@ -182,6 +182,16 @@ def main():
         acc = stats['acc_g1']
         # dominant kernel: msm_accumulate_kernel<Fq>; achieved = algorithmic bytes / its HIP-event time
         achieved = (acc['units'] * G1_BYTES_PER_SCALAR_MUL) / (acc['ms'] * 1e-3) / 1e9 if acc['ms'] > 0 else 0.0
+        # HBM traffic of the dominant kernel from the committed PMC pass (profiles/), if it was taken at this size
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic_bench_2p25.json')))
+            if pmc['log2n'] == args.log2n and world == 1 and acc['ms'] > 0:
+                dk = pmc['dominant_kernel']
+                per_proof = dk['fetch_bytes_per_proof_raw'] + dk['write_bytes_per_proof']
+                traffic = per_proof / (acc['ms'] / args.steps * 1e-3) / 1e9      # GB/s at this run's kernel time
+        except Exception:
+            traffic = None
         out = {
             'metric': 'Groth16 proofs/sec (BN254, 2^%d constraints)' % args.log2n,
             'value': args.steps / elapsed,
@@ -203,7 +213,9 @@ def main():
             'roofline': {
                 'bound': 'hbm', 'kernel': 'msm_accumulate_kernel<Fq> (G1 bucket accumulation)',
                 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                'traffic': None,
+                'traffic': traffic,
+                'traffic_source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/r01_pmc_traffic_bench_2p25.json '
+                                  '(raw FETCH_SIZE: gather width uncalibrated, see file)' if traffic else None,
                 'launches': acc['launches'], 'avg_launch_ms': acc['ms'] / max(acc['launches'], 1),
                 'algorithmic_bytes_per_scalar_mul': G1_BYTES_PER_SCALAR_MUL,
                 'note': 'MSM is 256-bit modular integer work: VALU-bound, not HBM-bound; see DESIGN.md',
