@@ -12,9 +12,10 @@ evaluations, the assignment z, density maps, proving key) are resident in HBM be
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-N > 1: one process per GPU; every rank holds 1/N of each key array (MSM sharded by points), computes
-its partial sums, ONE all-gather (RCCL over xGMI) of 384 bytes per rank exchanges them and the proof is
-folded locally -- strong scaling of a single proof (the quotient is replicated; see fawkes-crypto_amd/parallel.py).
+N > 1: one process per GPU; every rank holds a slice of each key array (MSM sharded by points).  Rank 0
+computes the quotient while the others start on the witness MSMs, h slices go point-to-point over xGMI,
+ONE all-gather (RCCL) of 384 bytes per rank exchanges the partial sums and the proof is folded locally --
+strong scaling of a single proof (fawkes-crypto_amd/parallel.py: prove_balanced).
 
 The CPU oracle (oracle/) appears here only as the timed `cpu_baseline` and as a live parity check of
 that same sample; it is never the thing measured as `value`.
@@ -93,6 +94,7 @@ def main():
     ap.add_argument('--log2n', type=int, default=25, help='log2 of the constraint count (rows handed to the prover)')
     ap.add_argument('--cpu-log2n', type=int, default=18, help='size of the CPU-baseline sample instance')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--backend', default='nccl', help="torch.distributed backend ('nccl' = RCCL; 'gloo' only for single-GPU dry runs of the N>1 code path with FK_BENCH_SAME_DEVICE=1)")
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -106,12 +108,18 @@ def main():
     import torch
     import fawkes_crypto_amd as fk
     from fawkes_crypto_amd import parallel
+    if os.environ.get('FK_BENCH_SAME_DEVICE') == '1':
+        local_rank = 0                      # dry run: all ranks share GPU 0 (needs --backend gloo)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
+    comm_dev = dev if args.backend == 'nccl' else None
     ctx = fk.Context(local_rank)
 
     # ---------------------------------------------------------------- workload (SURVEY section 8d, config 4 shape)
@@ -127,7 +135,13 @@ def main():
     n_a = v_in + int(dens_a.sum()); n_b = int(dens_bi.sum()) + int(dens_ba.sum())
     d_dens_a, d_dens_bi, d_dens_ba = dens_a.to(dev), dens_bi.to(dev), dens_ba.to(dev)
 
-    key = ctx.synthetic_key(m, v_in, v_aux, n_a, n_b, seed=2026, shard_index=rank, shard_count=world)
+    # multi-GPU: h sharded equally, witness arrays by the work-balanced fractions (rank 0 also runs the quotient)
+    fracs = parallel.plan_z_fractions(world, m, v_aux, n_a, n_b)
+    key = ctx.synthetic_key(m, v_in, v_aux, n_a, n_b, seed=2026, shard_index=rank, shard_count=world,
+                            z_frac=fracs[rank] if world > 1 else (0.0, 0.0))
+    h_ranges = [fk.api.shard_range(m - 1, g, world) for g in range(world)]
+    h_full_buf = torch.empty(m * 32, dtype=torch.uint8, device=dev) if (world > 1 and rank == 0) else None
+    recv_buf = torch.empty(max(h_ranges[rank][1] - h_ranges[rank][0], 1) * 32, dtype=torch.uint8, device=dev) if (world > 1 and rank > 0) else None
     # pristine inputs + working copies (the prover consumes a, b, c as scratch)
     nbytes = m * 32
     pristine = [torch.empty(nbytes, dtype=torch.uint8, device=dev) for _ in range(3)]
@@ -141,14 +155,15 @@ def main():
     r, s = fx.mont_fr(0xA11CE), fx.mont_fr(0xB0B)
 
     def step():
-        for w_, p_ in zip(work, pristine):
-            ctx.dev_copy(w_.data_ptr(), p_.data_ptr(), nbytes)
+        if world == 1 or rank == 0:       # only the rank that runs the quotient consumes a, b, c
+            for w_, p_ in zip(work, pristine):
+                ctx.dev_copy(w_.data_ptr(), p_.data_ptr(), nbytes)
         if world == 1:
             return ctx.prove_dev(key, work[0].data_ptr(), work[1].data_ptr(), work[2].data_ptr(), n, d_z.data_ptr(),
                                  d_dens_a.data_ptr(), d_dens_bi.data_ptr(), d_dens_ba.data_ptr(), r, s)
-        return parallel.prove_sharded_dev(ctx, key, work[0].data_ptr(), work[1].data_ptr(), work[2].data_ptr(), n,
-                                          d_z.data_ptr(), d_dens_a.data_ptr(), d_dens_bi.data_ptr(), d_dens_ba.data_ptr(),
-                                          r, s, device=dev)
+        return parallel.prove_balanced_dev(ctx, key, rank, world, work[0].data_ptr(), work[1].data_ptr(), work[2].data_ptr(), n,
+                                           d_z.data_ptr(), d_dens_a.data_ptr(), d_dens_bi.data_ptr(), d_dens_ba.data_ptr(),
+                                           r, s, h_ranges, h_full_buf, recv_buf, device=comm_dev)
 
     def barrier():
         if world > 1:
@@ -172,7 +187,7 @@ def main():
         raise AssertionError('bench: proofs differ between steps (non-deterministic result)')
     if world > 1:
         import torch.distributed as dist
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == 'nccl' else 'cpu')
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
@@ -208,7 +223,7 @@ def main():
                        'log2_constraints': args.log2n, 'num_input': v_in, 'num_aux': v_aux,
                        'density_a_aux': dens_frac, 'density_b_aux': dens_frac,
                        'scalar_distribution': 'a,b,c uniform; assignment witness-like (50% in {0,1})',
-                       'parallelism': 'msm-shard%d' % world},
+                       'parallelism': 'msm-shard%d%s' % (world, '+balanced-quotient' if world > 1 else '')},
             'msm_scalar_muls_per_sec': msm_units / sec_per_step,
             'roofline': {
                 'bound': 'hbm', 'kernel': 'msm_accumulate_kernel<Fq> (G1 bucket accumulation)',

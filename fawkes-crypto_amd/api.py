@@ -25,8 +25,9 @@ FQ_MODULUS = 2188824287183927522224640574525727508869631115729782366268903789464
 EXPORTED_SYMBOLS = [
     'fk_init', 'fk_free', 'fk_last_error', 'fk_set_window_bits',
     'fk_dev_alloc', 'fk_dev_free', 'fk_upload', 'fk_download', 'fk_dev_copy', 'fk_sync',
-    'fk_key_load', 'fk_key_synthetic', 'fk_key_host_vk', 'fk_key_free',
-    'fk_prove', 'fk_prove_dev', 'fk_prove_msms', 'fk_prove_msms_dev', 'fk_prove_assemble',
+    'fk_key_load', 'fk_key_synthetic', 'fk_key_shard_info', 'fk_key_host_vk', 'fk_key_free',
+    'fk_prove', 'fk_prove_dev', 'fk_prove_msms', 'fk_prove_msms_dev', 'fk_prove_msms_z_dev', 'fk_prove_msm_h_dev',
+    'fk_prove_assemble',
     'fk_fr_mul_batch', 'fk_ntt', 'fk_ntt_dev', 'fk_quotient_h', 'fk_quotient_h_dev',
     'fk_msm_g1', 'fk_msm_g2', 'fk_msm_g1_dev', 'fk_msm_g2_dev',
     'fk_gen_points_g1_dev', 'fk_gen_points_g2_dev', 'fk_gen_scalars_dev',
@@ -63,7 +64,8 @@ class KeyDesc(C.Structure):
                 ('h', C.c_void_p), ('n_h', C.c_uint64), ('l', C.c_void_p), ('n_l', C.c_uint64),
                 ('a', C.c_void_p), ('n_a', C.c_uint64),
                 ('b_g1', C.c_void_p), ('b_g2', C.c_void_p), ('n_b', C.c_uint64),
-                ('shard_index', C.c_uint32), ('shard_count', C.c_uint32)]
+                ('shard_index', C.c_uint32), ('shard_count', C.c_uint32),
+                ('z_frac_lo', C.c_double), ('z_frac_hi', C.c_double)]
 
 
 class Timings(C.Structure):
@@ -233,8 +235,9 @@ class Parameters:
         self.r1cs = r1cs
         self._handles = {}
 
-    def desc(self, shard_index=0, shard_count=1):
+    def desc(self, shard_index=0, shard_count=1, z_frac=(0.0, 0.0)):
         d = KeyDesc()
+        d.z_frac_lo, d.z_frac_hi = float(z_frac[0]), float(z_frac[1])
         d.m, d.num_input, d.num_aux = self.m, self.num_input, self.num_aux
         for n in self.vk:
             setattr(d, n, self.vk[n].ctypes.data)
@@ -255,6 +258,15 @@ class DeviceKey:
         if self.handle:
             self.ctx.lib.fk_key_free(self.ctx.handle, self.handle)
             self.handle = None
+
+    def shard_info(self):
+        """dict of the [lo, hi) slices this key holds: h, l, a, b"""
+        out = (C.c_uint64 * 8)()
+        rc = self.ctx.lib.fk_key_shard_info(self.handle, out)
+        if rc != 0:
+            raise FkError(rc, 'fk_key_shard_info')
+        v = list(out)
+        return dict(h=(v[0], v[1]), l=(v[2], v[3]), a=(v[4], v[5]), b=(v[6], v[7]))
 
     def __del__(self):
         try:
@@ -338,17 +350,17 @@ class Context:
         self._ck(self.lib.fk_set_window_bits(self.handle, C.c_uint(c)))
 
     # ---- keys
-    def load_key(self, params, shard_index=0, shard_count=1):
-        d = params.desc(shard_index, shard_count)
+    def load_key(self, params, shard_index=0, shard_count=1, z_frac=(0.0, 0.0)):
+        d = params.desc(shard_index, shard_count, z_frac)
         h = C.c_void_p()
         self._ck(self.lib.fk_key_load(self.handle, C.byref(d), C.byref(h)))
         return DeviceKey(self, h, shard_index, shard_count)
 
-    def synthetic_key(self, m, num_input, num_aux, n_a, n_b, seed=1, shard_index=0, shard_count=1):
+    def synthetic_key(self, m, num_input, num_aux, n_a, n_b, seed=1, shard_index=0, shard_count=1, z_frac=(0.0, 0.0)):
         h = C.c_void_p()
         self._ck(self.lib.fk_key_synthetic(self.handle, C.c_uint64(m), C.c_uint32(num_input), C.c_uint32(num_aux),
                                            C.c_uint64(n_a), C.c_uint64(n_b), C.c_uint64(seed), C.c_uint32(shard_index),
-                                           C.c_uint32(shard_count), C.byref(h)))
+                                           C.c_uint32(shard_count), C.c_double(z_frac[0]), C.c_double(z_frac[1]), C.byref(h)))
         return DeviceKey(self, h, shard_index, shard_count)
 
     # ---- building blocks (host arrays)
@@ -445,6 +457,18 @@ class Context:
                                             C.c_uint64(n), C.c_void_p(d_z), C.c_void_p(d_a_aux), C.c_void_p(d_b_in),
                                             C.c_void_p(d_b_aux), _vp(out), C.byref(tm)))
         return (out, tm.as_dict()) if want_timings else out
+
+    def prove_msms_z_dev(self, key, d_z, d_a_aux, d_b_in, d_b_aux):
+        """witness MSMs L, A, B1, B2 of this key's slices -> 384-byte record with H = identity"""
+        out = np.zeros(FK_MSM_RESULT_BYTES, np.uint8)
+        self._ck(self.lib.fk_prove_msms_z_dev(self.handle, key.handle, C.c_void_p(d_z), C.c_void_p(d_a_aux), C.c_void_p(d_b_in),
+                                              C.c_void_p(d_b_aux), _vp(out), None))
+        return out
+
+    def prove_msm_h_dev(self, key, d_h_slice):
+        out = np.zeros(64, np.uint8)
+        self._ck(self.lib.fk_prove_msm_h_dev(self.handle, key.handle, C.c_void_p(d_h_slice), _vp(out)))
+        return out
 
     def prove_dev(self, key, d_a, d_b, d_c, n, d_z, d_a_aux, d_b_in, d_b_aux, r, s, want_timings=False):
         out = np.zeros(FK_PROOF_BYTES, np.uint8)

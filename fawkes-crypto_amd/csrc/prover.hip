@@ -131,11 +131,26 @@ int fk_sync(fk_ctx *ctx) {
 }
 
 // ------------------------------------------------------------------------------------------ key
-static int key_alloc_slices(fk_ctx *ctx, fk_key *k) {
+static void frac_slice(uint64_t n, double lo, double hi, uint64_t *olo, uint64_t *ohi) {
+    uint64_t a = (uint64_t)((long double)n * lo + 0.5L), b = (uint64_t)((long double)n * hi + 0.5L);
+    if (hi >= 1.0) b = n;
+    if (a > n) a = n;
+    if (b > n) b = n;
+    if (b < a) b = a;
+    *olo = a; *ohi = b;
+}
+
+static int key_alloc_slices(fk_ctx *ctx, fk_key *k, double zlo, double zhi) {
     slice(k->n_h, k->shard_index, k->shard_count, &k->h_lo, &k->h_hi);
-    slice(k->n_l, k->shard_index, k->shard_count, &k->l_lo, &k->l_hi);
-    slice(k->n_a, k->shard_index, k->shard_count, &k->a_lo, &k->a_hi);
-    slice(k->n_b, k->shard_index, k->shard_count, &k->b_lo, &k->b_hi);
+    if (zlo == 0.0 && zhi == 0.0) {
+        slice(k->n_l, k->shard_index, k->shard_count, &k->l_lo, &k->l_hi);
+        slice(k->n_a, k->shard_index, k->shard_count, &k->a_lo, &k->a_hi);
+        slice(k->n_b, k->shard_index, k->shard_count, &k->b_lo, &k->b_hi);
+    } else {
+        frac_slice(k->n_l, zlo, zhi, &k->l_lo, &k->l_hi);
+        frac_slice(k->n_a, zlo, zhi, &k->a_lo, &k->a_hi);
+        frac_slice(k->n_b, zlo, zhi, &k->b_lo, &k->b_hi);
+    }
     FK_HIP(ctx, hipMalloc((void **)&k->d_h, (k->h_hi - k->h_lo) * 64 + 64));
     FK_HIP(ctx, hipMalloc((void **)&k->d_l, (k->l_hi - k->l_lo) * 64 + 64));
     FK_HIP(ctx, hipMalloc((void **)&k->d_a, (k->a_hi - k->a_lo) * 64 + 64));
@@ -161,6 +176,10 @@ static int key_check_shape(fk_ctx *ctx, uint64_t m, uint32_t num_input, uint64_t
     if (shard_count == 0 || shard_index >= shard_count) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "key: bad shard %u/%u", shard_index, shard_count);
     return FK_OK;
 }
+static int key_check_frac(fk_ctx *ctx, double lo, double hi) {
+    if (!(lo >= 0.0 && hi <= 1.0 && lo <= hi)) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "key: bad z fraction range [%g, %g)", lo, hi);
+    return FK_OK;
+}
 
 int fk_key_load(fk_ctx *ctx, const fk_key_desc *d, fk_key **out) {
     if (!ctx || !d || !out) return FK_ERR_BAD_ARG;
@@ -176,7 +195,8 @@ int fk_key_load(fk_ctx *ctx, const fk_key_desc *d, fk_key **out) {
     k->shard_index = d->shard_index; k->shard_count = d->shard_count;
     k->alpha_g1 = g1_from_raw(d->alpha_g1); k->beta_g1 = g1_from_raw(d->beta_g1); k->delta_g1 = g1_from_raw(d->delta_g1);
     k->beta_g2 = g2_from_raw(d->beta_g2); k->delta_g2 = g2_from_raw(d->delta_g2);
-    int rc = key_alloc_slices(ctx, k);
+    FK_TRY(key_check_frac(ctx, d->z_frac_lo, d->z_frac_hi));
+    int rc = key_alloc_slices(ctx, k, d->z_frac_lo, d->z_frac_hi);
     auto up = [&](void *dst, const uint8_t *src, uint64_t lo, uint64_t hi, size_t w) -> int {
         if (hi > lo) FK_HIP(ctx, hipMemcpy(dst, src + lo * w, (hi - lo) * w, hipMemcpyHostToDevice));
         return FK_OK;
@@ -201,8 +221,15 @@ int fk_key_host_vk(const uint8_t *alpha_g1, const uint8_t *beta_g1, const uint8_
     return FK_OK;
 }
 
+int fk_key_shard_info(const fk_key *k, uint64_t out[8]) {
+    if (!k || !out) return FK_ERR_BAD_ARG;
+    const uint64_t v[8] = {k->h_lo, k->h_hi, k->l_lo, k->l_hi, k->a_lo, k->a_hi, k->b_lo, k->b_hi};
+    memcpy(out, v, sizeof v);
+    return FK_OK;
+}
+
 int fk_key_synthetic(fk_ctx *ctx, uint64_t m, uint32_t num_input, uint32_t num_aux, uint64_t n_a, uint64_t n_b,
-                     uint64_t seed, uint32_t shard_index, uint32_t shard_count, fk_key **out) {
+                     uint64_t seed, uint32_t shard_index, uint32_t shard_count, double z_frac_lo, double z_frac_hi, fk_key **out) {
     if (!ctx || !out) return FK_ERR_BAD_ARG;
     *out = nullptr;
     FK_HIP(ctx, hipSetDevice(ctx->device));
@@ -211,7 +238,8 @@ int fk_key_synthetic(fk_ctx *ctx, uint64_t m, uint32_t num_input, uint32_t num_a
     k->m = m; k->num_input = num_input; k->num_aux = num_aux;
     k->n_h = m - 1; k->n_l = num_aux; k->n_a = n_a; k->n_b = n_b;
     k->shard_index = shard_index; k->shard_count = shard_count;
-    int rc = key_alloc_slices(ctx, k);
+    int rc = key_check_frac(ctx, z_frac_lo, z_frac_hi);
+    if (rc == FK_OK) rc = key_alloc_slices(ctx, k, z_frac_lo, z_frac_hi);
     const uint64_t sd = seed * 1000003ull + shard_index * 7919ull;
     if (rc == FK_OK) rc = gen_points_g1(ctx, k->d_h, k->h_hi - k->h_lo, sd + 1);
     if (rc == FK_OK) rc = gen_points_g1(ctx, k->d_l, k->l_hi - k->l_lo, sd + 2);
@@ -238,23 +266,13 @@ int fk_key_synthetic(fk_ctx *ctx, uint64_t m, uint32_t num_input, uint32_t num_a
 }
 
 // ------------------------------------------------------------------------------------------ prover
-static int prove_msms_dev(fk_ctx *ctx, const fk_key *key, Fr *d_a, Fr *d_b, Fr *d_c, uint64_t n, const Fr *d_z,
-                          const uint8_t *d_a_aux, const uint8_t *d_b_in, const uint8_t *d_b_aux, uint8_t out[FK_MSM_RESULT_BYTES],
-                          fk_timings *tm) {
-    if (!key || !d_a || !d_b || !d_c || !d_z || !out) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "prove: null argument");
-    if (n == 0 || n > key->m || (key->m > 1 && n <= key->m / 2)) FK_SET_ERR(ctx, FK_ERR_KEY_MISMATCH, "prove: %llu rows do not match key domain %llu",
-                                                      (unsigned long long)n, (unsigned long long)key->m);
+// L, A, B1, B2 over this key's slices (they depend on the assignment only, not on the quotient)
+static int prove_msms_z(fk_ctx *ctx, const fk_key *key, const Fr *d_z, const uint8_t *d_a_aux, const uint8_t *d_b_in,
+                        const uint8_t *d_b_aux, uint8_t out[FK_MSM_RESULT_BYTES], fk_timings *tm) {
+    if (!key || !d_z || !out) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "prove: null argument");
     FK_HIP(ctx, hipSetDevice(ctx->device));
     const uint32_t v_in = key->num_input, v_aux = key->num_aux;
-    const double t0 = now_ms();
-    FK_HIP(ctx, ctx->hbuf.reserve(key->m * sizeof(Fr)));
-    Fr *d_h = ctx->hbuf.as<Fr>();
-    uint64_t m = 0;
-    FK_TRY(quotient_dev(ctx, d_a, d_b, d_c, n, d_h, &m));
-    FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    const double t1 = now_ms();
-    G1Xyzz H, L, A, B1; G2Xyzz B2;
-    FK_TRY(msm_g1_dev(ctx, key->d_h, d_h + key->h_lo, key->h_hi - key->h_lo, &H));
+    G1Xyzz L, A, B1; G2Xyzz B2;
     const double t2 = now_ms();
     FK_TRY(msm_g1_dev(ctx, key->d_l, d_z + v_in + key->l_lo, key->l_hi - key->l_lo, &L));
     const double t3 = now_ms();
@@ -280,11 +298,49 @@ static int prove_msms_dev(fk_ctx *ctx, const fk_key *key, Fr *d_a, Fr *d_b, Fr *
     const double t5 = now_ms();
     FK_TRY(msm_g2_dev(ctx, key->d_b2, sb + key->b_lo, key->b_hi - key->b_lo, &B2));
     const double t6 = now_ms();
-    g1_to_raw(out, H); g1_to_raw(out + 64, L); g1_to_raw(out + 128, A); g1_to_raw(out + 192, B1); g2_to_raw(out + 256, B2);
-    if (tm) {
-        tm->ntt_ms = t1 - t0; tm->msm_h_ms = t2 - t1; tm->msm_l_ms = t3 - t2; tm->msm_a_ms = t4 - t3;
-        tm->msm_b1_ms = t5 - t4; tm->msm_b2_ms = t6 - t5; tm->total_ms = now_ms() - t0;
-    }
+    memset(out, 0, FK_G1_BYTES);   // H slot: identity
+    g1_to_raw(out + 64, L); g1_to_raw(out + 128, A); g1_to_raw(out + 192, B1); g2_to_raw(out + 256, B2);
+    if (tm) { tm->msm_l_ms = t3 - t2; tm->msm_a_ms = t4 - t3; tm->msm_b1_ms = t5 - t4; tm->msm_b2_ms = t6 - t5; }
+    return FK_OK;
+}
+
+static int prove_msms_dev(fk_ctx *ctx, const fk_key *key, Fr *d_a, Fr *d_b, Fr *d_c, uint64_t n, const Fr *d_z,
+                          const uint8_t *d_a_aux, const uint8_t *d_b_in, const uint8_t *d_b_aux, uint8_t out[FK_MSM_RESULT_BYTES],
+                          fk_timings *tm) {
+    if (!key || !d_a || !d_b || !d_c || !d_z || !out) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "prove: null argument");
+    if (n == 0 || n > key->m || (key->m > 1 && n <= key->m / 2)) FK_SET_ERR(ctx, FK_ERR_KEY_MISMATCH, "prove: %llu rows do not match key domain %llu",
+                                                      (unsigned long long)n, (unsigned long long)key->m);
+    FK_HIP(ctx, hipSetDevice(ctx->device));
+    const double t0 = now_ms();
+    FK_HIP(ctx, ctx->hbuf.reserve(key->m * sizeof(Fr)));
+    Fr *d_h = ctx->hbuf.as<Fr>();
+    uint64_t m = 0;
+    FK_TRY(quotient_dev(ctx, d_a, d_b, d_c, n, d_h, &m));
+    FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const double t1 = now_ms();
+    G1Xyzz H;
+    FK_TRY(msm_g1_dev(ctx, key->d_h, d_h + key->h_lo, key->h_hi - key->h_lo, &H));
+    const double t2 = now_ms();
+    FK_TRY(prove_msms_z(ctx, key, d_z, d_a_aux, d_b_in, d_b_aux, out, tm));
+    g1_to_raw(out, H);
+    if (tm) { tm->ntt_ms = t1 - t0; tm->msm_h_ms = t2 - t1; tm->total_ms = now_ms() - t0; }
+    return FK_OK;
+}
+
+int fk_prove_msms_z_dev(fk_ctx *ctx, const fk_key *key, const void *d_z, const void *d_a_aux, const void *d_b_in,
+                        const void *d_b_aux, uint8_t out[FK_MSM_RESULT_BYTES], fk_timings *tm) {
+    if (!ctx) return FK_ERR_BAD_ARG;
+    if (tm) memset(tm, 0, sizeof *tm);
+    return prove_msms_z(ctx, key, (const Fr *)d_z, (const uint8_t *)d_a_aux, (const uint8_t *)d_b_in, (const uint8_t *)d_b_aux, out, tm);
+}
+
+int fk_prove_msm_h_dev(fk_ctx *ctx, const fk_key *key, const void *d_h_slice, uint8_t out[FK_G1_BYTES]) {
+    if (!ctx) return FK_ERR_BAD_ARG;
+    if (!key || !out || (!d_h_slice && key->h_hi > key->h_lo)) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "prove: null argument");
+    FK_HIP(ctx, hipSetDevice(ctx->device));
+    G1Xyzz H;
+    FK_TRY(msm_g1_dev(ctx, key->d_h, (const Fr *)d_h_slice, key->h_hi - key->h_lo, &H));
+    g1_to_raw(out, H);
     return FK_OK;
 }
 

@@ -3,18 +3,47 @@ Multi-GPU proving: one process per GPU, `torch.distributed` (backend "nccl" = RC
 ROCm; "gloo" in the CPU tests).
 
 What shards: each of the five MSMs is a sum over independent (scalar, base)
-units, so rank g keeps only the [g/N, (g+1)/N) slice of every key array in its HBM (fk_key_load with
-shard_index/shard_count) and computes the partial sums of its slice.  The quotient (7 NTTs, ~10 % of
-the work) is computed redundantly on every rank so that no polynomial data crosses xGMI.
+units, so rank g keeps only a slice of every key array in its HBM (fk_key_load with shard_index /
+shard_count / z_frac) and computes the partial sums of its slice.
 
-The exchange step: north_star's "all-reduce of partial bucket sums".  RCCL has no elliptic-curve
-reduction operator, so the reduction is realised as ONE all-gather of the 384-byte partial results
-(4 x 64 B G1 + 128 B G2 per rank) followed by a local fold of N points per MSM (fk_prove_assemble).
-The payload is N x 384 B -- latency-bound, a single collective per proof.
+Schedule (work-balanced, `prove_balanced`):
+  * the witness MSMs L, A, B1, B2 depend only on the assignment z, not on the quotient, so ranks
+    1..N-1 start on them immediately while rank 0 computes the quotient h (7 NTTs);
+  * rank 0 then sends every peer ITS slice of h point-to-point (one xGMI link per peer, in parallel:
+    m*32/N bytes each -- 128 MiB at 2^25 / 8 GPUs), and everybody runs the H MSM of its slice;
+  * rank 0 holds a smaller share of the witness points (`plan_z_fractions`) so that all ranks finish
+    the first phase at about the same time;
+  * the exchange step -- north_star's "all-reduce of partial bucket sums": RCCL has no elliptic-curve
+    reduction operator, so the reduction is ONE all-gather of the 384-byte partial results (4 x 64 B G1 +
+    128 B G2 per rank) and a local fold of N points per MSM (fk_prove_assemble).  Latency-bound.
+
+`prove_sharded*` is the simpler variant (every rank runs the quotient itself; no h traffic).
 """
 import numpy as np
 
 from . import api
+
+# relative costs used by plan_z_fractions, measured on MI355X at 2^25 (profiles/r01_*):
+COST_G2_POINT = 3.2          # one G2 scalar-mul ~ 3.2 G1 scalar-muls
+COST_WITNESS_SCALAR = 0.62   # witness-like scalars (25 % zero, 25 % one) vs dense 254-bit scalars
+COST_NTT_PER_ROW = 0.85      # quotient (7 NTTs) per row, in units of one dense G1 scalar-mul
+
+
+def plan_z_fractions(world, m, num_aux, n_a, n_b):
+    """[lo, hi) fractions of the l / a / b arrays per rank.  Rank 0 also computes the quotient, so it gets
+    the share f0 that equalises  t_quotient + f0 * Z  with  (1 - f0) * Z / (world - 1)."""
+    if world == 1:
+        return [(0.0, 1.0)]
+    z_cost = COST_WITNESS_SCALAR * (num_aux + n_a + n_b + COST_G2_POINT * n_b)
+    ntt_cost = COST_NTT_PER_ROW * m
+    f0 = (z_cost / (world - 1) - ntt_cost) / (z_cost + z_cost / (world - 1)) if z_cost > 0 else 0.0
+    f0 = min(max(f0, 0.0), 1.0 / world)
+    rest = (1.0 - f0) / (world - 1)
+    out = [(0.0, f0)]
+    for g in range(1, world):
+        lo = f0 + (g - 1) * rest
+        out.append((lo, 1.0 if g == world - 1 else lo + rest))
+    return out
 
 
 def all_gather_parts(local_part, group=None, device=None):
@@ -30,16 +59,98 @@ def all_gather_parts(local_part, group=None, device=None):
     return np.stack([o.cpu().numpy() for o in out], axis=0)
 
 
+def distribute_h(h_full, h_ranges, rank, recv_buf, group=None):
+    """Rank 0 sends h[lo_g:hi_g] (32-byte elements) to rank g; every rank returns the tensor that holds ITS
+    slice.  h_full: uint8 tensor of m*32 bytes on rank 0 (None elsewhere); recv_buf: uint8 tensor with room for
+    this rank's slice (ranks > 0).  Point-to-point so that each peer's slice rides its own xGMI link."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    # gloo cannot move device tensors point-to-point: stage through the host (test configurations only)
+    stage = dist.get_backend(group) == 'gloo'
+    if rank == 0:
+        ops, keep = [], []
+        for g in range(1, world):
+            lo, hi = h_ranges[g]
+            if hi > lo:
+                t = h_full[lo * 32:hi * 32]
+                if stage and t.is_cuda:
+                    t = t.cpu()
+                keep.append(t)
+                ops.append(dist.P2POp(dist.isend, t, g, group))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        lo, hi = h_ranges[0]
+        return h_full[lo * 32:hi * 32]
+    lo, hi = h_ranges[rank]
+    mine = recv_buf[:(hi - lo) * 32]
+    if hi > lo:
+        t = mine.cpu() if (stage and mine.is_cuda) else mine
+        for w in dist.batch_isend_irecv([dist.P2POp(dist.irecv, t, 0, group)]):
+            w.wait()
+        if t is not mine:
+            mine.copy_(t)
+    return mine
+
+
+def prove_balanced(rank, world, quotient_fn, z_fn, h_fn, assemble_fn, h_ranges, recv_buf, group=None, device=None, sync_fn=None):
+    """Backend-agnostic orchestration of the balanced schedule (the GPU backend is `prove_balanced_dev`; the
+    gloo test injects CPU stand-ins).
+      quotient_fn() -> uint8 tensor with the full h (rank 0 only)
+      z_fn()        -> uint8[384] numpy record of this rank's L, A, B1, B2 partials (H slot zero)
+      h_fn(tensor)  -> uint8[64] numpy: H over this rank's h slice
+      assemble_fn(parts uint8[world, 384]) -> proof bytes
+    """
+    if rank == 0:
+        h_full = quotient_fn()
+        if sync_fn:
+            sync_fn()
+        mine = distribute_h(h_full, h_ranges, 0, None, group)
+        part = z_fn()
+    else:
+        part = z_fn()
+        if sync_fn:
+            sync_fn()
+        mine = distribute_h(None, h_ranges, rank, recv_buf, group)
+    if sync_fn:
+        sync_fn()
+    part = np.array(part, dtype=np.uint8, copy=True)
+    part[:64] = h_fn(mine)
+    parts = all_gather_parts(part, group=group, device=device)
+    return assemble_fn(parts)
+
+
+def prove_balanced_dev(ctx, key, rank, world, d_a, d_b, d_c, n, d_z, d_a_aux, d_b_in, d_b_aux, r, s, h_ranges, h_full_buf, recv_buf,
+                       group=None, device=None):
+    """GPU backend of `prove_balanced`.  h_full_buf: uint8 torch tensor of m*32 bytes on rank 0 (the quotient is
+    written there); recv_buf: uint8 torch tensor for this rank's h slice (ranks > 0)."""
+    import torch
+
+    def quotient_fn():
+        ctx.quotient_h_dev(d_a, d_b, d_c, n, h_full_buf.data_ptr())
+        return h_full_buf
+
+    def sync_fn():
+        ctx.sync()
+        torch.cuda.synchronize()
+
+    return prove_balanced(
+        rank, world, quotient_fn,
+        lambda: ctx.prove_msms_z_dev(key, d_z, d_a_aux, d_b_in, d_b_aux),
+        lambda t: ctx.prove_msm_h_dev(key, t.data_ptr() if t.numel() else 0),
+        lambda parts: ctx.prove_assemble(key, parts, r, s),
+        h_ranges, recv_buf, group=group, device=device, sync_fn=sync_fn)
+
+
 def prove_sharded(ctx, key, a, b, c, z, a_aux, b_in, b_aux, r, s, group=None, device=None):
-    """Host-buffer variant: every rank passes the same witness-derived inputs, holds its key shard, and
-    every rank returns the same 256-byte proof."""
+    """Simple variant, host buffers: every rank runs the quotient itself and its equal key shard."""
     part = ctx.prove_msms(key, a, b, c, z, a_aux, b_in, b_aux)
     parts = all_gather_parts(part, group=group, device=device)
     return ctx.prove_assemble(key, parts, r, s)
 
 
 def prove_sharded_dev(ctx, key, d_a, d_b, d_c, n, d_z, d_a_aux, d_b_in, d_b_aux, r, s, group=None, device=None):
-    """Device-resident variant used by bench.py."""
+    """Simple variant, device-resident inputs."""
     part = ctx.prove_msms_dev(key, d_a, d_b, d_c, n, d_z, d_a_aux, d_b_in, d_b_aux)
     parts = all_gather_parts(part, group=group, device=device)
     return ctx.prove_assemble(key, parts, r, s)

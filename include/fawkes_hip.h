@@ -86,14 +86,21 @@ typedef struct {
     const uint8_t *l;   uint64_t n_l;               /* num_aux points */
     const uint8_t *a;   uint64_t n_a;               /* num_input + popcount(a_aux) points */
     const uint8_t *b_g1; const uint8_t *b_g2; uint64_t n_b;  /* popcount(b_input)+popcount(b_aux) */
-    uint32_t shard_index, shard_count;              /* 0,1 for a single GPU */
+    uint32_t shard_index, shard_count;              /* 0,1 for a single GPU: slice of h */
+    /* slice of l, a, b_g1, b_g2 as fractions of each array: [z_frac_lo, z_frac_hi).  Both 0 = the same
+     * equal split as h.  Unequal fractions let the rank that computes the quotient take fewer witness
+     * points (work-balanced multi-GPU schedule, fawkes-crypto_amd/parallel.py). */
+    double z_frac_lo, z_frac_hi;
 } fk_key_desc;
 
 int fk_key_load(fk_ctx *ctx, const fk_key_desc *desc, fk_key **out);
 /* Synthetic key of the same shape (valid curve points, no trapdoor): benchmarking only.  vk points are
  * synthetic too, so proofs made with it do not verify. */
 int fk_key_synthetic(fk_ctx *ctx, uint64_t m, uint32_t num_input, uint32_t num_aux, uint64_t n_a,
-                     uint64_t n_b, uint64_t seed, uint32_t shard_index, uint32_t shard_count, fk_key **out);
+                     uint64_t n_b, uint64_t seed, uint32_t shard_index, uint32_t shard_count,
+                     double z_frac_lo, double z_frac_hi, fk_key **out);
+/* out[8] = h_lo, h_hi, l_lo, l_hi, a_lo, a_hi, b_lo, b_hi: the slices this key holds */
+int fk_key_shard_info(const fk_key *key, uint64_t out[8]);
 /* Host-only key holding just the vk points fk_prove_assemble needs (no device memory, no GPU).
  * Free with fk_key_free(NULL, key). */
 int fk_key_host_vk(const uint8_t *alpha_g1, const uint8_t *beta_g1, const uint8_t *delta_g1,
@@ -132,6 +139,15 @@ int fk_prove_msms(fk_ctx *ctx, const fk_key *key, const uint64_t *a, const uint6
 int fk_prove_msms_dev(fk_ctx *ctx, const fk_key *key, void *d_a, void *d_b, void *d_c, uint64_t n,
                       const void *d_z, const void *d_a_aux_density, const void *d_b_input_density,
                       const void *d_b_aux_density, uint8_t out_msms[FK_MSM_RESULT_BYTES], fk_timings *timings);
+/* The two halves of fk_prove_msms_dev, for schedules where one rank computes the quotient and ships h:
+ *   fk_prove_msms_z_dev  the witness MSMs L, A, B1, B2 of this key's slices; writes a full
+ *                        FK_MSM_RESULT_BYTES record whose H entry is the identity (zeros);
+ *   fk_prove_msm_h_dev   H over this key's h slice; d_h_slice points at the (h_hi - h_lo) scalars
+ *                        h[h_lo .. h_hi) (Montgomery), result raw affine. */
+int fk_prove_msms_z_dev(fk_ctx *ctx, const fk_key *key, const void *d_z, const void *d_a_aux_density,
+                        const void *d_b_input_density, const void *d_b_aux_density,
+                        uint8_t out_msms[FK_MSM_RESULT_BYTES], fk_timings *timings);
+int fk_prove_msm_h_dev(fk_ctx *ctx, const fk_key *key, const void *d_h_slice, uint8_t out[FK_G1_BYTES]);
 /* ctx may be NULL here (pure host arithmetic). */
 int fk_prove_assemble(fk_ctx *ctx, const fk_key *key, const uint8_t *msm_parts, uint32_t n_parts,
                       const uint64_t r[4], const uint64_t s[4], uint8_t out_proof[FK_PROOF_BYTES]);

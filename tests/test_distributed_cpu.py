@@ -58,12 +58,48 @@ def _worker(rank, world, port, q):
         assert np.array_equal(parts[rank], part)
         vk = api.HostVk(params_from_oracle_key(key))
         got = api.assemble(vk.handle, parts, r, s)
-        q.put((rank, got.tobytes() == want.tobytes(), got.tobytes().hex()))
+        ok = got.tobytes() == want.tobytes()
+
+        # ---- the work-balanced schedule (parallel.prove_balanced) with CPU stand-ins for the GPU MSMs:
+        # rank 0 computes h and ships slices point-to-point, witness arrays are split by plan_z_fractions
+        import torch
+        fracs = parallel.plan_z_fractions(world, key.m, cs.num_aux, len(key.a), len(key.b_g1))
+        h_ranges = [api.shard_range(key.m - 1, g, world) for g in range(world)]
+
+        def frac_range(n_, lo_, hi_):
+            a_ = int(n_ * lo_ + 0.5); b_ = n_ if hi_ >= 1.0 else int(n_ * hi_ + 0.5)
+            return a_, max(a_, b_)
+
+        def z_fn():
+            rec = np.zeros(api.FK_MSM_RESULT_BYTES, np.uint8)
+            for off, bases, scalars, fn in ((64, key.l, z[nin:], co.msm_g1), (128, key.a, sa, co.msm_g1),
+                                            (192, key.b_g1, sb, co.msm_g1), (256, key.b_g2, sb, co.msm_g2)):
+                lo_, hi_ = frac_range(len(bases), *fracs[rank])
+                if hi_ > lo_:
+                    res = fn(np.array(bases[lo_:hi_]), scalars[lo_:hi_])
+                    rec[off:off + len(res)] = res
+            return rec
+
+        def h_fn(t):
+            lo_, hi_ = h_ranges[rank]
+            sl = np.frombuffer(t.numpy().tobytes(), np.uint64).reshape(-1, 4)
+            assert sl.shape[0] == hi_ - lo_
+            return co.msm_g1(np.array(key.h[lo_:hi_]), sl) if hi_ > lo_ else np.zeros(64, np.uint8)
+
+        def quotient_fn():
+            full = np.zeros((key.m, 4), np.uint64); full[:key.m - 1] = h
+            return torch.from_numpy(full.view(np.uint8).reshape(-1).copy())
+
+        recv = torch.zeros(max(h_ranges[rank][1] - h_ranges[rank][0], 1) * 32, dtype=torch.uint8)
+        got2 = parallel.prove_balanced(rank, world, quotient_fn, z_fn, h_fn, lambda parts_: api.assemble(vk.handle, parts_, r, s),
+                                       h_ranges, recv)
+        ok = ok and got2.tobytes() == want.tobytes()
+        q.put((rank, ok, got.tobytes().hex()))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world', [2])
+@pytest.mark.parametrize('world', [2, 3])
 def test_sharded_prove_gloo(world):
     import torch.multiprocessing as mp
     ctx = mp.get_context('spawn')

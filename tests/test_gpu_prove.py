@@ -94,6 +94,47 @@ def test_sharded_equals_unsharded(ctx, oracle):
     assert want.tobytes() == oracle.prove(key, a, b, c, z, aa, bi, ba, r, s).tobytes()
 
 
+def test_balanced_schedule_pieces(ctx, oracle):
+    """The work-balanced multi-GPU split, ranks simulated one after another on this GPU: weighted witness
+    shards (fk_prove_msms_z_dev), h slices shipped to fk_prove_msm_h_dev, folded by fk_prove_assemble --
+    must reproduce the single-GPU proof bytes."""
+    from fawkes_crypto_amd import api, parallel
+    cs, csr, key, z_in, z_aux = _instance(oracle, 23, 700, 2, 760)
+    params = params_from_oracle_key(key, r1cs_product(csr))
+    z = fx.witness_mont(z_in, z_aux)
+    r, s = fx.mont_fr(1234), fx.mont_fr(5678)
+    a, b, c, aa, bi, ba = ctx.synthesize(params.r1cs, z)
+    dk = ctx.load_key(params)
+    want = ctx.prove_raw(dk, a, b, c, z, aa, bi, ba, r, s)
+    world = 3
+    fracs = parallel.plan_z_fractions(world, params.m, params.num_aux, params.a.shape[0], params.b_g1.shape[0])
+    assert fracs[0][0] == 0.0 and fracs[-1][1] == 1.0 and all(abs(fracs[i][1] - fracs[i + 1][0]) < 1e-12 for i in range(world - 1))
+    m = params.m
+    d = {k: ctx.dev_alloc(m * 32) for k in 'abch'}
+    d_z = ctx.dev_alloc(z.nbytes)
+    d_aa, d_bi, d_ba = ctx.dev_alloc(max(len(aa), 1)), ctx.dev_alloc(len(bi)), ctx.dev_alloc(max(len(ba), 1))
+    try:
+        for k, v in (('a', a), ('b', b), ('c', c)):
+            ctx.upload(d[k], v)
+        ctx.upload(d_z, z); ctx.upload(d_aa, aa); ctx.upload(d_bi, bi); ctx.upload(d_ba, ba)
+        ctx.quotient_h_dev(d['a'], d['b'], d['c'], a.shape[0], d['h'])          # "rank 0"
+        parts = []
+        for g in range(world):
+            sk = ctx.load_key(params, shard_index=g, shard_count=world, z_frac=fracs[g])
+            info = sk.shard_info()
+            assert info['h'] == api.shard_range(m - 1, g, world)
+            part = ctx.prove_msms_z_dev(sk, d_z, d_aa, d_bi, d_ba)
+            assert part[:64].tobytes() == bytes(64)
+            part[:64] = ctx.prove_msm_h_dev(sk, d['h'] + info['h'][0] * 32)
+            parts.append(part)
+            sk.free()
+        got = ctx.prove_assemble(dk, np.stack(parts), r, s)
+        assert got.tobytes() == want.tobytes()
+    finally:
+        for p_ in list(d.values()) + [d_z, d_aa, d_bi, d_ba]:
+            ctx.dev_free(p_)
+
+
 def test_error_behaviour(ctx, oracle):
     """C ABI returns codes where bellman returns SynthesisError."""
     import fawkes_crypto_amd as fk
