@@ -32,6 +32,7 @@ EXPORTED_SYMBOLS = [
     'fk_msm_g1', 'fk_msm_g2', 'fk_msm_g1_dev', 'fk_msm_g2_dev',
     'fk_gen_points_g1_dev', 'fk_gen_points_g2_dev', 'fk_gen_scalars_dev',
     'fk_synthesize', 'fk_stats_reset', 'fk_stats_get', 'fk_shard_range',
+    'fk_r1cs_load', 'fk_r1cs_free', 'fk_r1cs_info', 'fk_r1cs_eval_dev', 'fk_prove_r1cs', 'fk_prove_r1cs_dev',
 ]
 
 _ERR = {1: 'FK_ERR_BAD_ARG', 2: 'FK_ERR_DOMAIN_TOO_LARGE (bellman: PolynomialDegreeTooLarge)',
@@ -275,6 +276,32 @@ class DeviceKey:
             pass
 
 
+class DeviceR1cs:
+    """Constraint system resident in HBM (fk_r1cs_load): CSR + coefficient dictionary + density maps."""
+
+    def __init__(self, ctx, handle):
+        self.ctx, self.handle = ctx, handle
+
+    def info(self):
+        out = (C.c_uint64 * 8)()
+        rc = self.ctx.lib.fk_r1cs_info(self.handle, out)
+        if rc != 0:
+            raise FkError(rc, 'fk_r1cs_info')
+        v = list(out)
+        return dict(rows=v[0], nnz=(v[1], v[2], v[3]), distinct_coefficients=v[4], n_a=v[5], n_b=v[6])
+
+    def free(self):
+        if self.handle:
+            self.ctx.lib.fk_r1cs_free(self.ctx.handle, self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class HostVk:
     """Host-only key (vk points only) for fk_prove_assemble -- needs no GPU."""
 
@@ -478,6 +505,29 @@ class Context:
                                        C.c_void_p(d_b_aux), _vp(_fr(r, 1)), _vp(_fr(s, 1)), _vp(out), C.byref(tm)))
         return (out, tm.as_dict()) if want_timings else out
 
+    # ---- device-resident constraint system: only the witness crosses the boundary
+    def load_r1cs(self, r1cs):
+        h = C.c_void_p()
+        self._ck(self.lib.fk_r1cs_load(self.handle, C.byref(r1cs.struct), C.byref(h)))
+        return DeviceR1cs(self, h)
+
+    def r1cs_eval_dev(self, dr, d_z, d_a, d_b, d_c):
+        self._ck(self.lib.fk_r1cs_eval_dev(self.handle, dr.handle, C.c_void_p(d_z), C.c_void_p(d_a), C.c_void_p(d_b), C.c_void_p(d_c)))
+
+    def prove_witness(self, key, dr, z, r, s, want_timings=False):
+        """fk_prove_r1cs: z (host, (num_input+num_aux, 4) uint64 Montgomery) -> 256-byte proof."""
+        z = _fr(z)
+        out = np.zeros(FK_PROOF_BYTES, np.uint8)
+        tm = Timings()
+        self._ck(self.lib.fk_prove_r1cs(self.handle, key.handle, dr.handle, _vp(z), _vp(_fr(r, 1)), _vp(_fr(s, 1)), _vp(out), C.byref(tm)))
+        return (out, tm.as_dict()) if want_timings else out
+
+    def prove_witness_dev(self, key, dr, d_z, r, s, want_timings=False):
+        out = np.zeros(FK_PROOF_BYTES, np.uint8)
+        tm = Timings()
+        self._ck(self.lib.fk_prove_r1cs_dev(self.handle, key.handle, dr.handle, C.c_void_p(d_z), _vp(_fr(r, 1)), _vp(_fr(s, 1)), _vp(out), C.byref(tm)))
+        return (out, tm.as_dict()) if want_timings else out
+
     def prove_assemble(self, key, parts, r, s):
         return assemble(key.handle, parts, r, s, ctx=self)
 
@@ -556,7 +606,7 @@ def sample_fr(rand=os.urandom):
 
 
 # ------------------------------------------------------------------------------------------ prove
-def prove_with_rs(ctx, params, key, z_input, z_aux, r, s, want_timings=False):
+def prove_with_rs(ctx, params, key, z_input, z_aux, r, s, want_timings=False, device_r1cs=None):
     """Deterministic twin of `prove` (bellman's create_proof(circuit, params, r, s)).
     z_input / z_aux: the `WitnessCS` value vectors (cs.rs:100-101), Montgomery limbs (n,4) uint64;
     z_input[0] must be ONE (cs.rs:111).  Returns (public inputs without ONE, Proof)."""
@@ -564,15 +614,18 @@ def prove_with_rs(ctx, params, key, z_input, z_aux, r, s, want_timings=False):
         raise FkError(1, 'Parameters carries no constraint system')
     z_input, z_aux = _fr(z_input, params.num_input), _fr(z_aux, params.num_aux) if params.num_aux else np.zeros((0, 4), np.uint64)
     z = np.concatenate([z_input, z_aux], axis=0)
-    a, b, c, a_aux, b_in, b_aux = ctx.synthesize(params.r1cs, z)
-    res = ctx.prove_raw(key, a, b, c, z, a_aux, b_in, b_aux, r, s, want_timings=want_timings)
+    if device_r1cs is not None:     # constraint system resident in HBM: only z crosses the boundary
+        res = ctx.prove_witness(key, device_r1cs, z, r, s, want_timings=want_timings)
+    else:                           # host synthesis (bellman's ProvingAssignment restated in the library)
+        a, b, c, a_aux, b_in, b_aux = ctx.synthesize(params.r1cs, z)
+        res = ctx.prove_raw(key, a, b, c, z, a_aux, b_in, b_aux, r, s, want_timings=want_timings)
     proof_bytes, tm = (res if want_timings else (res, None))
     inputs = z_input[1:].copy()   # prover.rs:84-87
     proof = Proof.from_bytes(proof_bytes.tobytes())
     return (inputs, proof, tm) if want_timings else (inputs, proof)
 
 
-def prove(ctx, params, key, z_input, z_aux):
+def prove(ctx, params, key, z_input, z_aux, device_r1cs=None):
     """Mirror of prover.rs:63-90 below the DSL: r, s are drawn from the OS entropy source exactly like
     `create_random_proof` does through fawkes' OsRng (prover.rs:78-80)."""
-    return prove_with_rs(ctx, params, key, z_input, z_aux, sample_fr(), sample_fr())
+    return prove_with_rs(ctx, params, key, z_input, z_aux, sample_fr(), sample_fr(), device_r1cs=device_r1cs)

@@ -14,8 +14,8 @@
 //                      so skewed witness scalars (many 0/1) cost nothing extra.
 //   3. msm_accumulate  one lane per bucket walks its run with XYZZ mixed additions (8M+2S), gathering
 //                      64-byte affine bases; buckets above `cap` entries hand the excess to
-//   4. msm_overflow    256-lane workgroups that reduce fixed 16384-entry segments with wavefront
-//                      shuffles, then one wave per oversized bucket folds the partials.
+//   4. msm_overflow    one wave per fixed 4096-entry segment, reduced with wavefront shuffles; then one
+//                      wave per oversized bucket folds the partials.
 //   5. msm_bucket_reduce  sum_b b*S_b per window: each lane runs the running-sum trick over L buckets,
 //                      adds its offset multiple by double-and-add, then wave64 shuffle + LDS reduction.
 //   6. host            W window sums are Horner-combined (c doublings each) -- microseconds.
@@ -25,7 +25,7 @@
 
 namespace fk {
 
-static constexpr uint32_t SEG = 16384;         // overflow segment (entries) per workgroup: 64 per lane
+static constexpr uint32_t SEG = 4096;          // overflow segment (entries) per wave: 64 per lane
 static constexpr uint32_t SORT_THREADS = 1024;
 
 struct MsmPlan {
@@ -221,13 +221,14 @@ __global__ __launch_bounds__(256) void msm_accumulate_kernel(const Affine<F> *ba
 
 struct Task { uint32_t g, seg; };
 
-// one workgroup per SEG-entry segment of an oversized bucket (entries beyond `cap`).  The per-lane walk
-// uses the inlined multiply (F); the cross-lane reduction runs on the layout-identical cold twin (FC).
+// one WAVE per SEG-entry segment of an oversized bucket (entries beyond `cap`): many small workgroups keep
+// several waves per SIMD in flight (the multiply is a serial chain, one wave alone cannot fill the VALU).
+// The per-lane walk uses the inlined multiply (F); the wave64 shuffle reduction runs on the
+// layout-identical cold twin (FC).
 template <class F, class FC>
-__global__ __launch_bounds__(256) void msm_overflow_kernel(const Affine<F> *bases, const uint32_t *sorted, size_t n,
-                                                           const uint32_t *starts, const uint32_t *totals, uint32_t B,
-                                                           uint32_t cap, const Task *tasks, Xyzz<FC> *partials) {
-    __shared__ Xyzz<FC> sh[4];
+__global__ __launch_bounds__(64) void msm_overflow_kernel(const Affine<F> *bases, const uint32_t *sorted, size_t n,
+                                                          const uint32_t *starts, const uint32_t *totals, uint32_t B,
+                                                          uint32_t cap, const Task *tasks, Xyzz<FC> *partials) {
     const Task t = tasks[blockIdx.x];
     const uint32_t w = t.g / B;
     const uint32_t *src = sorted + (size_t)w * n + starts[t.g];
@@ -235,14 +236,14 @@ __global__ __launch_bounds__(256) void msm_overflow_kernel(const Affine<F> *base
     const uint32_t lo = cap + t.seg * SEG;
     const uint32_t hi = lo + SEG < size ? lo + SEG : size;
     Xyzz<F> acc = Xyzz<F>::inf();
-    for (uint32_t k = lo + threadIdx.x; k < hi; k += 256) {
+    for (uint32_t k = lo + threadIdx.x; k < hi; k += 64) {
         const uint32_t e = src[k];
         acc.add_mixed(affine_neg_if(bases[e & 0x7fffffffu], (e >> 31) != 0));
     }
     static_assert(sizeof(Xyzz<F>) == sizeof(Xyzz<FC>), "layout");
     Xyzz<FC> accc;
     __builtin_memcpy(&accc, &acc, sizeof acc);
-    block_reduce_256(accc, sh);
+    wave_reduce(accc);
     if (threadIdx.x == 0) partials[blockIdx.x] = accc;
 }
 
@@ -368,7 +369,7 @@ static int msm_run(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars, s
         OverBucket *d_obs = (OverBucket *)((char *)ctx->tasktab.p + tb_al);
         FK_HIP(ctx, hipMemcpyAsync(d_tasks, tasks.data(), tb, hipMemcpyHostToDevice, st));
         FK_HIP(ctx, hipMemcpyAsync(d_obs, obs.data(), ob, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_overflow_kernel<F, FC>), dim3((unsigned)tasks.size()), dim3(256), 0, st,
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_overflow_kernel<F, FC>), dim3((unsigned)tasks.size()), dim3(64), 0, st,
                            d_bases, sorted, n, starts,
                            totals, p.B, p.cap, d_tasks, ctx->partials.as<Xyzz<FC>>());
         FK_HIP(ctx, hipGetLastError());

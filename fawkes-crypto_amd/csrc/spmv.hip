@@ -1,0 +1,195 @@
+// Device-resident R1CS and the sparse evaluation  a = A z, b = B z, c = C z  (SURVEY.md section 8f, row 1).
+//
+// Replaces, for the prover, what bellman's ProvingAssignment does gate by gate on the CPU while
+// fawkes streams the constraint system out of its brotli blob
+// (/root/reference/fawkes-crypto/src/backend/bellman_groth16/mod.rs:92-99,
+//  /root/reference/fawkes-crypto/src/circuit/r1cs/cs.rs:184-223; evaluation semantics SURVEY App. A.1):
+// a_i = <A_i, z>, b_i = <B_i, z>, c_i = <C_i, z>, plus one `input_i * 0 = 0` row per input, and the
+// three density maps, which are structural (a variable is marked when it is *visited*) and are therefore
+// computed once at load time.
+//
+// Layout in HBM: CSR per matrix -- row_ptr u64[num_gates+1], col u32[nnz] (Input(i) -> i,
+// Aux(j) -> num_input + j) and a coefficient DICTIONARY: fawkes LCs carry few distinct constants
+// (1, -1, small integers, Poseidon MDS entries), so each term stores a u32 index into a table of unique
+// 32-byte Montgomery values instead of the value itself: 8 B per term instead of 36 B, and the table
+// stays in L2.  Index 0 is reserved for ONE (multiply skipped, exactly as bellman's eval does).
+// Kernel: one lane per (matrix, row); HBM-bound gather of z (32 B per term).
+#include "common.hpp"
+#include <string.h>
+#include <unordered_map>
+#include <string>
+
+struct fk_r1cs_dev {
+    uint32_t num_input = 0, num_aux = 0;
+    uint64_t num_gates = 0;
+    uint64_t *ptr[3] = {nullptr, nullptr, nullptr};
+    uint32_t *col[3] = {nullptr, nullptr, nullptr};
+    uint32_t *cidx[3] = {nullptr, nullptr, nullptr};
+    fk::Fr *table = nullptr;
+    uint64_t n_table = 0, nnz[3] = {0, 0, 0};
+    uint8_t *d_a_aux = nullptr, *d_b_in = nullptr, *d_b_aux = nullptr;
+    uint64_t n_a_aux = 0, n_b_in = 0, n_b_aux = 0;   // popcounts
+};
+
+namespace fk {
+
+struct SpmvArgs {
+    const uint64_t *ptr[3];
+    const uint32_t *col[3];
+    const uint32_t *cidx[3];
+    Fr *out[3];
+};
+
+__global__ __launch_bounds__(256) void spmv_kernel(SpmvArgs a, const Fr *table, const Fr *z, uint64_t num_gates, uint32_t num_input) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t mtx = blockIdx.y;
+    const uint64_t rows = num_gates + num_input;
+    if (t >= rows) return;
+    const uint64_t *ptr = a.ptr[mtx]; const uint32_t *col = a.col[mtx]; const uint32_t *cidx = a.cidx[mtx];
+    Fr acc = Fr::zero();
+    if (t < num_gates) {
+        for (uint64_t k = ptr[t], e = ptr[t + 1]; k < e; k++) {
+            Fr v = z[col[k]];
+            const uint32_t ci = cidx[k];
+            if (ci) v = Fr::mul(v, table[ci]);
+            acc = Fr::add(acc, v);
+        }
+    } else if (mtx == 0) {
+        acc = z[t - num_gates];        // bellman's extra rows: input_i * 0 = 0
+    }
+    a.out[mtx][t] = acc;
+}
+
+}  // namespace fk
+
+using namespace fk;
+
+extern "C" {
+
+void fk_r1cs_free(fk_ctx *ctx, fk_r1cs_dev *r) {
+    if (!r) return;
+    if (ctx) (void)hipSetDevice(ctx->device);
+    for (int k = 0; k < 3; k++) { if (r->ptr[k]) (void)hipFree(r->ptr[k]); if (r->col[k]) (void)hipFree(r->col[k]); if (r->cidx[k]) (void)hipFree(r->cidx[k]); }
+    for (void *p : {(void *)r->table, (void *)r->d_a_aux, (void *)r->d_b_in, (void *)r->d_b_aux}) if (p) (void)hipFree(p);
+    delete r;
+}
+
+int fk_r1cs_load(fk_ctx *ctx, const fk_r1cs *cs, fk_r1cs_dev **out) {
+    if (!ctx || !cs || !out) return FK_ERR_BAD_ARG;
+    *out = nullptr;
+    FK_HIP(ctx, hipSetDevice(ctx->device));
+    const uint64_t *ptrs[3] = {cs->a_ptr, cs->b_ptr, cs->c_ptr};
+    const uint32_t *cols[3] = {cs->a_col, cs->b_col, cs->c_col};
+    const uint64_t *vals[3] = {cs->a_val, cs->b_val, cs->c_val};
+    const uint64_t nv = (uint64_t)cs->num_input + cs->num_aux;
+    if (cs->num_input == 0) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "r1cs: num_input must include the constant ONE");
+    for (int k = 0; k < 3; k++) {
+        if (!ptrs[k]) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "r1cs: null row pointer");
+        if (ptrs[k][0] != 0) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "r1cs: row_ptr[0] must be 0");
+        for (uint64_t g = 0; g < cs->num_gates; g++) if (ptrs[k][g + 1] < ptrs[k][g]) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "r1cs: row_ptr not monotone");
+        const uint64_t nnz = ptrs[k][cs->num_gates];
+        if (nnz && (!cols[k] || !vals[k])) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "r1cs: null column/value array");
+        for (uint64_t i = 0; i < nnz; i++) if (cols[k][i] >= nv) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "r1cs: variable index %u out of range", cols[k][i]);
+    }
+    fk_r1cs_dev *r = new fk_r1cs_dev();
+    r->num_input = cs->num_input; r->num_aux = cs->num_aux; r->num_gates = cs->num_gates;
+    // coefficient dictionary; slot 0 = ONE
+    std::unordered_map<std::string, uint32_t> dict;
+    std::vector<Fr> table;
+    const Fr one = Fr::one();
+    table.push_back(one);
+    dict.emplace(std::string((const char *)&one, 32), 0u);
+    std::vector<uint8_t> a_aux(cs->num_aux ? cs->num_aux : 1, 0), b_in(cs->num_input, 0), b_aux(cs->num_aux ? cs->num_aux : 1, 0);
+    int rc = FK_OK;
+    auto fail = [&](int code) { fk_r1cs_free(ctx, r); return code; };
+    for (int k = 0; k < 3 && rc == FK_OK; k++) {
+        const uint64_t nnz = ptrs[k][cs->num_gates];
+        r->nnz[k] = nnz;
+        std::vector<uint32_t> cidx(nnz ? nnz : 1);
+        for (uint64_t i = 0; i < nnz; i++) {
+            std::string key((const char *)(vals[k] + 4 * i), 32);
+            auto it = dict.find(key);
+            if (it == dict.end()) {
+                if (table.size() >= 0xffffffffull) { ctx->err = "r1cs: too many distinct coefficients"; return fail(FK_ERR_BAD_ARG); }
+                Fr v; memcpy(&v, vals[k] + 4 * i, 32);
+                it = dict.emplace(key, (uint32_t)table.size()).first;
+                table.push_back(v);
+            }
+            cidx[i] = it->second;
+            const uint32_t v = cols[k][i];
+            if (k == 0) { if (v >= cs->num_input) a_aux[v - cs->num_input] = 1; }
+            else if (k == 1) { if (v < cs->num_input) b_in[v] = 1; else b_aux[v - cs->num_input] = 1; }
+        }
+        if (hipMalloc((void **)&r->ptr[k], (cs->num_gates + 1) * 8) != hipSuccess || hipMalloc((void **)&r->col[k], (nnz + 1) * 4) != hipSuccess ||
+            hipMalloc((void **)&r->cidx[k], (nnz + 1) * 4) != hipSuccess) { ctx->err = "r1cs: device allocation failed"; return fail(FK_ERR_OOM); }
+        if (hipMemcpy(r->ptr[k], ptrs[k], (cs->num_gates + 1) * 8, hipMemcpyHostToDevice) != hipSuccess) rc = FK_ERR_HIP;
+        if (nnz && hipMemcpy(r->col[k], cols[k], nnz * 4, hipMemcpyHostToDevice) != hipSuccess) rc = FK_ERR_HIP;
+        if (nnz && hipMemcpy(r->cidx[k], cidx.data(), nnz * 4, hipMemcpyHostToDevice) != hipSuccess) rc = FK_ERR_HIP;
+    }
+    if (rc != FK_OK) { ctx->err = "r1cs: upload failed"; return fail(rc); }
+    r->n_table = table.size();
+    if (hipMalloc((void **)&r->table, table.size() * sizeof(Fr)) != hipSuccess || hipMalloc((void **)&r->d_a_aux, a_aux.size()) != hipSuccess ||
+        hipMalloc((void **)&r->d_b_in, b_in.size()) != hipSuccess || hipMalloc((void **)&r->d_b_aux, b_aux.size()) != hipSuccess) {
+        ctx->err = "r1cs: device allocation failed"; return fail(FK_ERR_OOM);
+    }
+    if (hipMemcpy(r->table, table.data(), table.size() * sizeof(Fr), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(r->d_a_aux, a_aux.data(), a_aux.size(), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(r->d_b_in, b_in.data(), b_in.size(), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(r->d_b_aux, b_aux.data(), b_aux.size(), hipMemcpyHostToDevice) != hipSuccess) { ctx->err = "r1cs: upload failed"; return fail(FK_ERR_HIP); }
+    for (uint32_t j = 0; j < cs->num_aux; j++) { r->n_a_aux += a_aux[j]; r->n_b_aux += b_aux[j]; }
+    for (uint32_t i = 0; i < cs->num_input; i++) r->n_b_in += b_in[i];
+    *out = r;
+    return FK_OK;
+}
+
+int fk_r1cs_info(const fk_r1cs_dev *r, uint64_t out[8]) {
+    if (!r || !out) return FK_ERR_BAD_ARG;
+    const uint64_t v[8] = {r->num_gates + r->num_input, r->nnz[0], r->nnz[1], r->nnz[2], r->n_table,
+                           (uint64_t)r->num_input + r->n_a_aux, r->n_b_in + r->n_b_aux, 0};
+    memcpy(out, v, sizeof v);
+    return FK_OK;
+}
+
+// a, b, c: device arrays with room for next_pow2(rows) elements each (fk_prove_dev's contract); rows written.
+int fk_r1cs_eval_dev(fk_ctx *ctx, const fk_r1cs_dev *r, const void *d_z, void *d_a, void *d_b, void *d_c) {
+    if (!ctx) return FK_ERR_BAD_ARG;
+    if (!r || !d_z || !d_a || !d_b || !d_c) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "r1cs eval: null argument");
+    FK_HIP(ctx, hipSetDevice(ctx->device));
+    SpmvArgs a;
+    for (int k = 0; k < 3; k++) { a.ptr[k] = r->ptr[k]; a.col[k] = r->col[k]; a.cidx[k] = r->cidx[k]; }
+    a.out[0] = (Fr *)d_a; a.out[1] = (Fr *)d_b; a.out[2] = (Fr *)d_c;
+    const uint64_t rows = r->num_gates + r->num_input;
+    hipLaunchKernelGGL(spmv_kernel, dim3((unsigned)((rows + 255) / 256), 3), dim3(256), 0, ctx->stream, a, r->table, (const Fr *)d_z, r->num_gates, r->num_input);
+    FK_HIP(ctx, hipGetLastError());
+    FK_DBG(ctx, "spmv");
+    return FK_OK;
+}
+
+// witness in -> proof out: SpMV, quotient, MSMs, assembly.  z: device pointer (num_input + num_aux elements).
+int fk_prove_r1cs_dev(fk_ctx *ctx, const fk_key *key, const fk_r1cs_dev *r, const void *d_z, const uint64_t rr[4], const uint64_t ss[4],
+                      uint8_t out_proof[FK_PROOF_BYTES], fk_timings *tm) {
+    if (!ctx) return FK_ERR_BAD_ARG;
+    if (!key || !r || !d_z) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "prove: null argument");
+    if (r->num_input != key->num_input || r->num_aux != key->num_aux) FK_SET_ERR(ctx, FK_ERR_KEY_MISMATCH, "prove: constraint system and key disagree on the variable counts");
+    const uint64_t rows = r->num_gates + r->num_input;
+    if (rows > key->m || (key->m > 1 && rows <= key->m / 2)) FK_SET_ERR(ctx, FK_ERR_KEY_MISMATCH, "prove: %llu rows do not match key domain %llu",
+                                                                     (unsigned long long)rows, (unsigned long long)key->m);
+    FK_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t mb = key->m * sizeof(Fr);
+    FK_HIP(ctx, ctx->stage_a.reserve(mb)); FK_HIP(ctx, ctx->stage_b.reserve(mb)); FK_HIP(ctx, ctx->stage_c.reserve(mb));
+    FK_TRY(fk_r1cs_eval_dev(ctx, r, d_z, ctx->stage_a.p, ctx->stage_b.p, ctx->stage_c.p));
+    return fk_prove_dev(ctx, key, ctx->stage_a.p, ctx->stage_b.p, ctx->stage_c.p, rows, d_z, r->d_a_aux, r->d_b_in, r->d_b_aux, rr, ss, out_proof, tm);
+}
+
+int fk_prove_r1cs(fk_ctx *ctx, const fk_key *key, const fk_r1cs_dev *r, const uint64_t *z, const uint64_t rr[4], const uint64_t ss[4],
+                  uint8_t out_proof[FK_PROOF_BYTES], fk_timings *tm) {
+    if (!ctx) return FK_ERR_BAD_ARG;
+    if (!key || !r || !z) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "prove: null argument");
+    FK_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t zb = ((size_t)r->num_input + r->num_aux) * sizeof(Fr);
+    FK_HIP(ctx, ctx->stage_z.reserve(zb));
+    FK_HIP(ctx, hipMemcpyAsync(ctx->stage_z.p, z, zb, hipMemcpyHostToDevice, ctx->stream));
+    return fk_prove_r1cs_dev(ctx, key, r, ctx->stage_z.p, rr, ss, out_proof, tm);
+}
+
+}  // extern "C"

@@ -191,6 +191,24 @@ typedef struct {
 int fk_synthesize(fk_ctx *ctx, const fk_r1cs *cs, const uint64_t *z, uint64_t *a, uint64_t *b, uint64_t *c,
                   uint8_t *a_aux_density, uint8_t *b_input_density, uint8_t *b_aux_density);
 
+/* ---------------------------------------------------------------- device-resident constraint system
+ * (SURVEY section 8f row 1).  fk_r1cs_load uploads the CSR matrices once (coefficients dictionary-encoded)
+ * and derives the structural density maps; afterwards only the witness vector crosses the boundary:
+ * fk_prove_r1cs = SpMV (a = Az, b = Bz, c = Cz + the per-input rows) -> quotient -> MSMs -> assembly,
+ * i.e. the whole of `create_proof` behind prover.rs:80 including bellman's `synthesize` evaluation
+ * (mod.rs:92-99).  z: num_input + num_aux Montgomery elements, inputs first, z[0] = ONE. */
+typedef struct fk_r1cs_dev fk_r1cs_dev;
+int fk_r1cs_load(fk_ctx *ctx, const fk_r1cs *cs, fk_r1cs_dev **out);
+void fk_r1cs_free(fk_ctx *ctx, fk_r1cs_dev *r1cs);
+/* out[8] = rows, nnz(A), nnz(B), nnz(C), distinct coefficients, points the a query needs, points the b query needs, 0 */
+int fk_r1cs_info(const fk_r1cs_dev *r1cs, uint64_t out[8]);
+/* a, b, c <- A z, B z, C z on the device (arrays sized for next_pow2(rows) elements, `rows` written) */
+int fk_r1cs_eval_dev(fk_ctx *ctx, const fk_r1cs_dev *r1cs, const void *d_z, void *d_a, void *d_b, void *d_c);
+int fk_prove_r1cs(fk_ctx *ctx, const fk_key *key, const fk_r1cs_dev *r1cs, const uint64_t *z,
+                  const uint64_t r[4], const uint64_t s[4], uint8_t out_proof[FK_PROOF_BYTES], fk_timings *timings);
+int fk_prove_r1cs_dev(fk_ctx *ctx, const fk_key *key, const fk_r1cs_dev *r1cs, const void *d_z,
+                      const uint64_t r[4], const uint64_t s[4], uint8_t out_proof[FK_PROOF_BYTES], fk_timings *timings);
+
 /* Kernel timing measured with HIP events on the library's stream since the last reset, summed over
  * launches.  which: 0 = msm_accumulate_kernel<Fq> (G1 bucket accumulation; units = points per launch),
  * 1 = msm_accumulate_kernel<Fq2> (G2), 2 = ntt_pass_kernel (units = elements per pass). */

@@ -1,0 +1,76 @@
+"""GPU parity of the device-resident constraint system: SpMV a = Az, b = Bz, c = Cz and
+the witness-in / proof-out entry point against the oracle's ProvingAssignment restatement.  Bit-exact."""
+import numpy as np
+import pytest
+
+import bn254_ref as ref
+import fixtures as fx
+from helpers import params_from_oracle_key, r1cs_product, TOXIC
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('shape', [(1, 1, 1, 3), (2, 40, 3, 44), (3, 500, 2, 480), (4, 3000, 5, 3100)])
+def test_spmv_vs_oracle(ctx, oracle, shape):
+    seed, gates, nin, naux = shape
+    cs, z_in, z_aux = ref.random_r1cs(seed, gates, nin, naux)
+    csr = fx.r1cs_to_csr(cs)
+    z = fx.witness_mont(z_in, z_aux)
+    want = oracle.synthesize(csr, z)
+    dr = ctx.load_r1cs(r1cs_product(csr))
+    info = dr.info()
+    rows = gates + nin
+    assert info['rows'] == rows
+    assert info['n_a'] == nin + int(want[3].sum()) and info['n_b'] == int(want[4].sum()) + int(want[5].sum())
+    m = 1
+    while m < rows:
+        m *= 2
+    d = [ctx.dev_alloc(m * 32) for _ in range(3)]
+    d_z = ctx.dev_alloc(z.nbytes)
+    try:
+        ctx.upload(d_z, z)
+        ctx.r1cs_eval_dev(dr, d_z, *d)
+        for k in range(3):
+            got = ctx.download(d[k], rows * 32, np.uint64).reshape(-1, 4)
+            assert np.array_equal(got, want[k]), 'matrix %d' % k
+    finally:
+        for p in d + [d_z]:
+            ctx.dev_free(p)
+        dr.free()
+
+
+def test_prove_witness_bit_exact(ctx, oracle):
+    """witness vector in -> 256-byte proof out, everything else resident in HBM"""
+    import fawkes_crypto_amd as fk
+    cs, z_in, z_aux = ref.random_r1cs(77, 900, 3, 950)
+    csr = fx.r1cs_to_csr(cs)
+    key = oracle.setup(csr, **TOXIC)
+    params = params_from_oracle_key(key, r1cs_product(csr))
+    dk = ctx.load_key(params)
+    dr = ctx.load_r1cs(params.r1cs)
+    z = fx.witness_mont(z_in, z_aux)
+    r, s = fx.mont_fr(0x13579), fx.mont_fr(0x2468a)
+    a, b, c, aa, bi, ba = oracle.synthesize(csr, z)
+    want = oracle.prove(key, a, b, c, z, aa, bi, ba, r, s)
+    got = ctx.prove_witness(dk, dr, z, r, s)
+    assert got.tobytes() == want.tobytes()
+    # the host mirror of prove() can use it too
+    _, proof = fk.prove_with_rs(ctx, params, dk, z[:3], z[3:], r, s, device_r1cs=dr)
+    assert proof.to_bytes() == want.tobytes()
+    assert ref.verify(fx.key_to_py(key), z_in[1:], ref.proof_from_borsh(proof.to_bytes()))
+    # a constraint system that does not belong to the key is rejected
+    cs2, _, _ = ref.random_r1cs(78, 900, 3, 951)
+    dr2 = ctx.load_r1cs(r1cs_product(fx.r1cs_to_csr(cs2)))
+    with pytest.raises(fk.FkError) as e:
+        ctx.prove_witness(dk, dr2, np.zeros((954, 4), np.uint64), r, s)
+    assert e.value.code == 6
+
+
+def test_r1cs_load_rejects_bad_input(ctx):
+    import fawkes_crypto_amd as fk
+    one = fx.mont_fr(1)
+    ptr = np.array([0, 1], np.uint64)
+    good = (ptr, np.array([1], np.uint32), one.reshape(1, 4))
+    bad = (ptr, np.array([9], np.uint32), one.reshape(1, 4))
+    with pytest.raises(fk.FkError):
+        ctx.load_r1cs(fk.R1cs(1, 1, bad, good, good))
