@@ -39,8 +39,10 @@ struct fk_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     unsigned window_bits = 0;  // 0 = auto
+    unsigned ntt_threads = 512;  // workgroup size cap of the NTT pass kernel (FK_NTT_THREADS overrides)
     std::map<uint32_t, fk::NttDomain *> domains;
     // MSM scratch
+    const void *last_sort_scalars = nullptr; size_t last_sort_n = 0; unsigned last_sort_c = 0;   // what `sorted` currently holds
     fk::DevBuf digits, sorted, counts, totals, starts, buckets, winparts, overlist, tasktab, partials, misc;
     // NTT / prover scratch
     fk::DevBuf ntt_s1, ntt_s2, ntt_io, hbuf, sc_a, sc_b, scan_tmp, stage_a, stage_b, stage_c, stage_z, stage_d;
@@ -110,7 +112,9 @@ int fr_mul_batch_dev(fk_ctx *ctx, const Fr *a, const Fr *b, Fr *o, size_t n);
 
 // msm.hip
 int msm_g1_dev(fk_ctx *ctx, const G1Affine *d_bases, const Fr *d_scalars, size_t n, G1Xyzz *out);
-int msm_g2_dev(fk_ctx *ctx, const G2Affine *d_bases, const Fr *d_scalars, size_t n, G2Xyzz *out);
+// reuse_sort: the scalars are the ones of the immediately preceding MSM call on this context (same pointer
+// and n), so its digits / bucket sort are still valid and are not recomputed (B1 and B2 share scalars)
+int msm_g2_dev(fk_ctx *ctx, const G2Affine *d_bases, const Fr *d_scalars, size_t n, G2Xyzz *out, bool reuse_sort = false);
 int gen_points_g1(fk_ctx *ctx, G1Affine *d_out, size_t n, uint64_t seed);
 int gen_points_g2(fk_ctx *ctx, G2Affine *d_out, size_t n, uint64_t seed);
 int gen_scalars(fk_ctx *ctx, Fr *d_out, size_t n, uint64_t seed, int kind);

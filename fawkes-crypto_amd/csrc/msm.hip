@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256) void msm_bucket_reduce_kernel(const Xyzz<F> *b
 
 // ------------------------------------------------------------------------------------------ host driver
 template <class F>
-static int msm_run(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars, size_t n, Xyzz<F> *out) {
+static int msm_run(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars, size_t n, Xyzz<F> *out, bool reuse_sort = false) {
     using FC = typename ColdOf<F>::type;   // layout-identical field with an out-of-line multiply
     *out = Xyzz<F>::inf();
     if (n == 0) return FK_OK;
@@ -314,28 +314,32 @@ static int msm_run(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars, s
     uint32_t *counts = ctx->counts.as<uint32_t>(), *totals = ctx->totals.as<uint32_t>(), *starts = ctx->starts.as<uint32_t>();
     Xyzz<F> *buckets = ctx->buckets.as<Xyzz<F>>(), *winparts = ctx->winparts.as<Xyzz<F>>();
 
-    hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, p.c, p.W, digits);
-    FK_HIP(ctx, hipGetLastError());
-    FK_DBG(ctx, "msm_digits");
-    const size_t lds = (size_t)p.B * 4;
-    FK_HIP(ctx, hipFuncSetAttribute((const void *)msm_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    FK_HIP(ctx, hipFuncSetAttribute((const void *)msm_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(msm_hist_kernel, dim3(p.nchunks, p.W), dim3(SORT_THREADS), lds, st, digits, n, p.chunk, p.nchunks, p.B, counts);
-    FK_HIP(ctx, hipGetLastError());
-    FK_DBG(ctx, "msm_hist");
-    hipLaunchKernelGGL(msm_chunk_prefix_kernel, dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, counts, p.nchunks, p.B, p.W, totals);
-    FK_HIP(ctx, hipGetLastError());
-    FK_DBG(ctx, "msm_chunk_prefix");
-    FK_HIP(ctx, hipMemsetAsync(d_nover, 0, 4, st));
-    hipLaunchKernelGGL(msm_window_scan_kernel, dim3(p.W), dim3(1024), 0, st, totals, p.B, p.cap, starts,
-                       ctx->overlist.as<OverEntry>(), d_nover, over_cap);
-    FK_HIP(ctx, hipGetLastError());
-    FK_DBG(ctx, "msm_window_scan");
-    hipLaunchKernelGGL(msm_scatter_kernel, dim3(p.nchunks, p.W), dim3(SORT_THREADS), lds, st, digits, n, p.chunk, p.nchunks, p.B,
-                       counts, starts, sorted);
-    FK_HIP(ctx, hipGetLastError());
-    FK_DBG(ctx, "msm_scatter");
-
+    const bool have_sort = reuse_sort && ctx->last_sort_scalars == (const void *)d_scalars && ctx->last_sort_n == n && ctx->last_sort_c == p.c;
+    if (!have_sort) {
+        ctx->last_sort_scalars = nullptr;
+        hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, p.c, p.W, digits);
+        FK_HIP(ctx, hipGetLastError());
+        FK_DBG(ctx, "msm_digits");
+        const size_t lds = (size_t)p.B * 4;
+        FK_HIP(ctx, hipFuncSetAttribute((const void *)msm_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        FK_HIP(ctx, hipFuncSetAttribute((const void *)msm_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(msm_hist_kernel, dim3(p.nchunks, p.W), dim3(SORT_THREADS), lds, st, digits, n, p.chunk, p.nchunks, p.B, counts);
+        FK_HIP(ctx, hipGetLastError());
+        FK_DBG(ctx, "msm_hist");
+        hipLaunchKernelGGL(msm_chunk_prefix_kernel, dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, counts, p.nchunks, p.B, p.W, totals);
+        FK_HIP(ctx, hipGetLastError());
+        FK_DBG(ctx, "msm_chunk_prefix");
+        FK_HIP(ctx, hipMemsetAsync(d_nover, 0, 4, st));
+        hipLaunchKernelGGL(msm_window_scan_kernel, dim3(p.W), dim3(1024), 0, st, totals, p.B, p.cap, starts,
+                           ctx->overlist.as<OverEntry>(), d_nover, over_cap);
+        FK_HIP(ctx, hipGetLastError());
+        FK_DBG(ctx, "msm_window_scan");
+        hipLaunchKernelGGL(msm_scatter_kernel, dim3(p.nchunks, p.W), dim3(SORT_THREADS), lds, st, digits, n, p.chunk, p.nchunks, p.B,
+                           counts, starts, sorted);
+        FK_HIP(ctx, hipGetLastError());
+        FK_DBG(ctx, "msm_scatter");
+        ctx->last_sort_scalars = (const void *)d_scalars; ctx->last_sort_n = n; ctx->last_sort_c = p.c;
+    }
     std::vector<EventPair> &evv = (sizeof(F) == sizeof(Fq)) ? ctx->ev_acc : ctx->ev_acc2;
     FK_TRY(stats_begin(ctx, evv, (uint64_t)n));
     hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_kernel<F>), dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, d_bases, sorted, n,
@@ -403,8 +407,8 @@ static int msm_run(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars, s
 int msm_g1_dev(fk_ctx *ctx, const G1Affine *d_bases, const Fr *d_scalars, size_t n, G1Xyzz *out) {
     return msm_run<Fq>(ctx, d_bases, d_scalars, n, out);
 }
-int msm_g2_dev(fk_ctx *ctx, const G2Affine *d_bases, const Fr *d_scalars, size_t n, G2Xyzz *out) {
-    return msm_run<Fq2>(ctx, d_bases, d_scalars, n, out);
+int msm_g2_dev(fk_ctx *ctx, const G2Affine *d_bases, const Fr *d_scalars, size_t n, G2Xyzz *out, bool reuse_sort) {
+    return msm_run<Fq2>(ctx, d_bases, d_scalars, n, out, reuse_sort);
 }
 
 // ------------------------------------------------------------------------------------------ generators (bench/test inputs)

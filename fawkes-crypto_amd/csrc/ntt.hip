@@ -22,7 +22,7 @@ namespace fk {
 
 static constexpr uint32_t NTT_MAXDEG = 9;       // R <= 512
 static constexpr uint32_t NTT_TILE_LOG = 11;    // R*C <= 2048 elements = 64 KiB of LDS
-static constexpr uint32_t NTT_THREADS = 256;
+static constexpr uint32_t NTT_MAX_THREADS = 1024;
 
 enum { PRE_NONE = 0, PRE_TABLE = 1, PRE_ABC = 2 };
 enum { POST_NONE = 0, POST_CONST = 1, POST_TABLE = 2 };
@@ -66,7 +66,8 @@ static __device__ __forceinline__ Fr lds_get(const uint4 *p0, const uint4 *p1, u
     return v;
 }
 
-__global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(PassArgs a) {
+__global__ __launch_bounds__(NTT_MAX_THREADS) void ntt_pass_kernel(PassArgs a) {
+    const uint32_t NTT_THREADS = blockDim.x;
     extern __shared__ uint4 lds[];
     const uint32_t R = 1u << a.deg, C = 1u << a.logC, tile = R << a.logC;
     uint4 *p0 = lds, *p1 = lds + tile;
@@ -256,7 +257,11 @@ static int ntt_exec(fk_ctx *ctx, NttDomain *d, const NttOp &op, const Fr *in, Fr
         const size_t lds_bytes = (size_t)2 * sizeof(uint4) << (deg + logC);
         FK_HIP(ctx, hipFuncSetAttribute((const void *)ntt_pass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         FK_TRY(stats_begin(ctx, ctx->ev_ntt, (uint64_t)1 << d->log_n));
-        hipLaunchKernelGGL(ntt_pass_kernel, dim3((unsigned)nblk), dim3(NTT_THREADS), lds_bytes, ctx->stream, a);
+        // one lane per butterfly where the tile allows it: more waves per CU to hide LDS / multiply latency
+        uint32_t threads = 1u << (deg + logC > 0 ? deg + logC - 1 : 0);
+        if (threads < 64) threads = 64;
+        if (threads > ctx->ntt_threads) threads = ctx->ntt_threads;
+        hipLaunchKernelGGL(ntt_pass_kernel, dim3((unsigned)nblk), dim3(threads), lds_bytes, ctx->stream, a);
         FK_HIP(ctx, hipGetLastError());
         FK_TRY(stats_end(ctx, ctx->ev_ntt));
         src = dst;

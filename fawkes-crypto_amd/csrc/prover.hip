@@ -65,6 +65,7 @@ int fk_init(int device_id, fk_ctx **out) {
     fk_ctx *ctx = new fk_ctx();
     ctx->device = device_id;
     { const char *d = getenv("FK_DEBUG"); ctx->debug = d && d[0] && d[0] != '0'; }
+    { const char *t = getenv("FK_NTT_THREADS"); if (t) { int v = atoi(t); if (v == 64 || v == 128 || v == 256 || v == 512 || v == 1024) ctx->ntt_threads = (unsigned)v; } }
     if (hipStreamCreate(&ctx->stream) != hipSuccess) { delete ctx; return FK_ERR_HIP; }
     *out = ctx;
     return FK_OK;
@@ -296,7 +297,7 @@ static int prove_msms_z(fk_ctx *ctx, const fk_key *key, const Fr *d_z, const uin
                                                  (unsigned long long)(n_b_in + n_b_aux), (unsigned long long)key->n_b);
     FK_TRY(msm_g1_dev(ctx, key->d_b1, sb + key->b_lo, key->b_hi - key->b_lo, &B1));
     const double t5 = now_ms();
-    FK_TRY(msm_g2_dev(ctx, key->d_b2, sb + key->b_lo, key->b_hi - key->b_lo, &B2));
+    FK_TRY(msm_g2_dev(ctx, key->d_b2, sb + key->b_lo, key->b_hi - key->b_lo, &B2, /*reuse_sort=*/true));   // same scalars as B1
     const double t6 = now_ms();
     memset(out, 0, FK_G1_BYTES);   // H slot: identity
     g1_to_raw(out + 64, L); g1_to_raw(out + 128, A); g1_to_raw(out + 192, B1); g2_to_raw(out + 256, B2);
