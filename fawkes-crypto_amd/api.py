@@ -32,6 +32,7 @@ EXPORTED_SYMBOLS = [
     'fk_msm_g1', 'fk_msm_g2', 'fk_msm_g1_dev', 'fk_msm_g2_dev',
     'fk_gen_points_g1_dev', 'fk_gen_points_g2_dev', 'fk_gen_scalars_dev',
     'fk_synthesize', 'fk_stats_reset', 'fk_stats_get', 'fk_shard_range',
+    'fk_setup', 'fk_key_download',
     'fk_r1cs_load', 'fk_r1cs_free', 'fk_r1cs_info', 'fk_r1cs_eval_dev', 'fk_prove_r1cs', 'fk_prove_r1cs_dev',
 ]
 
@@ -259,6 +260,17 @@ class DeviceKey:
         if self.handle:
             self.ctx.lib.fk_key_free(self.ctx.handle, self.handle)
             self.handle = None
+
+    def download(self, name):
+        """this key's slice of one array as numpy: 'h' | 'l' | 'a' | 'b_g1' (n,64) or 'b_g2' (n,128)"""
+        which = ['h', 'l', 'a', 'b_g1', 'b_g2'].index(name)
+        info = self.shard_info()
+        lo, hi = info[{'h': 'h', 'l': 'l', 'a': 'a', 'b_g1': 'b', 'b_g2': 'b'}[name]]
+        w = 128 if name == 'b_g2' else 64
+        out = np.zeros((max(hi - lo, 0), w), np.uint8)
+        buf = out if out.size else np.zeros((1, w), np.uint8)
+        self.ctx._ck(self.ctx.lib.fk_key_download(self.ctx.handle, self.handle, C.c_int(which), C.c_void_p(buf.ctypes.data), C.c_size_t(buf.nbytes)))
+        return out
 
     def shard_info(self):
         """dict of the [lo, hi) slices this key holds: h, l, a, b"""
@@ -504,6 +516,19 @@ class Context:
                                        C.c_uint64(n), C.c_void_p(d_z), C.c_void_p(d_a_aux), C.c_void_p(d_b_in),
                                        C.c_void_p(d_b_aux), _vp(_fr(r, 1)), _vp(_fr(s, 1)), _vp(out), C.byref(tm)))
         return (out, tm.as_dict()) if want_timings else out
+
+    def setup(self, r1cs, tau, alpha, beta, gamma, delta):
+        """fk_setup: GPU key generation with explicit toxic waste (Montgomery limbs).  Returns (DeviceKey, vk dict)
+        with vk = alpha_g1, beta_g1, beta_g2, gamma_g2, delta_g1, delta_g2 (raw LE uint8 arrays) and ic (num_input, 64)."""
+        h = C.c_void_p()
+        vk = np.zeros(6 * 128, np.uint8)
+        ic = np.zeros((r1cs.num_input, 64), np.uint8)
+        self._ck(self.lib.fk_setup(self.handle, C.byref(r1cs.struct), _vp(_fr(tau, 1)), _vp(_fr(alpha, 1)), _vp(_fr(beta, 1)),
+                                   _vp(_fr(gamma, 1)), _vp(_fr(delta, 1)), C.byref(h), _vp(vk), _vp(ic)))
+        names = (('alpha_g1', 64), ('beta_g1', 64), ('beta_g2', 128), ('gamma_g2', 128), ('delta_g1', 64), ('delta_g2', 128))
+        out = {n: vk[i * 128:i * 128 + w].copy() for i, (n, w) in enumerate(names)}
+        out['ic'] = ic
+        return DeviceKey(self, h), out
 
     # ---- device-resident constraint system: only the witness crosses the boundary
     def load_r1cs(self, r1cs):

@@ -1,0 +1,339 @@
+// Groth16 key generation on the GPU.
+//
+// Restates bellman_ce::groth16::generator::generate_parameters, which fawkes reaches
+// from /root/reference/fawkes-crypto/src/backend/bellman_groth16/setup.rs:20, for explicit toxic waste
+// (tau, alpha, beta, gamma, delta).  It exists so that VALID proving keys can be produced at the sizes the
+// benchmark configurations name (2^20 and up), where a CPU setup takes minutes to hours: with a valid key a
+// GPU proof can be checked against the Groth16 pairing equation at full size.
+//
+//   powers of tau            two-level table expansion (one multiply per element)
+//   h[i] = g1^(tau^i (tau^m - 1)/delta)
+//   Lagrange L_j(tau)        iNTT of the power vector (the shared NTT kernels)
+//   A_k, B_k, C_k            transposed sparse product over a CSC copy of the R1CS (one lane per variable)
+//   a, b_g1, b_g2, ic, l     fixed-base scalar multiplication: 32 windows x 8 bits, table in L2, XYZZ mixed adds
+//   a, b_g1, b_g2            compacted to the non-identity points (inputs first, then aux) -- the layout the
+//                            prover's density-filtered queries index into
+#include "common.hpp"
+#include <string.h>
+#include <unordered_map>
+#include <string>
+
+namespace fk {
+
+__global__ void expand_powers_kernel(const Fr *lo, const Fr *hi, uint32_t L, size_t n, Fr *out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = Fr::mul(lo[i & ((1u << L) - 1)], hi[i >> L]);
+}
+__global__ void scale_kernel(const Fr *in, Fr c, size_t n, Fr *out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = Fr::mul(in[i], c);
+}
+
+// out[v] = sum over the column's entries  table[cidx] * lag[row]   (+ lag[num_gates + v] for inputs in matrix 0)
+struct CscArgs { const uint64_t *ptr[3]; const uint32_t *row[3]; const uint32_t *cidx[3]; Fr *out[3]; };
+__global__ __launch_bounds__(256) void csc_eval_kernel(CscArgs a, const Fr *table, const Fr *lag, uint64_t num_gates, uint32_t num_input, uint64_t nv) {
+    const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t mtx = blockIdx.y;
+    if (v >= nv) return;
+    Fr acc = Fr::zero();
+    for (uint64_t k = a.ptr[mtx][v], e = a.ptr[mtx][v + 1]; k < e; k++) {
+        Fr t = lag[a.row[mtx][k]];
+        const uint32_t ci = a.cidx[mtx][k];
+        if (ci) t = Fr::mul(t, table[ci]);
+        acc = Fr::add(acc, t);
+    }
+    if (mtx == 0 && v < num_input) acc = Fr::add(acc, lag[num_gates + v]);
+    a.out[mtx][v] = acc;
+}
+
+// e[v] = (beta A_v + alpha B_v + C_v) * (v < num_input ? 1/gamma : 1/delta); flags: A_v != 0, B_v != 0
+__global__ void combine_kernel(const Fr *A, const Fr *B, const Fr *C, Fr beta, Fr alpha, Fr ginv, Fr dinv, uint32_t num_input, uint64_t nv,
+                               Fr *e, uint8_t *fa, uint8_t *fb) {
+    const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nv) return;
+    Fr x = Fr::add(Fr::add(Fr::mul(A[v], beta), Fr::mul(B[v], alpha)), C[v]);
+    e[v] = Fr::mul(x, v < num_input ? ginv : dinv);
+    fa[v] = A[v].is_zero() ? 0 : 1;
+    fb[v] = B[v].is_zero() ? 0 : 1;
+}
+
+// table[w * 255 + (d - 1)] = d * 2^(8w) * G, affine.  out[i] = scalar[i] * G.
+template <class F>
+__global__ __launch_bounds__(128) void fixed_base_kernel(const Affine<F> *table, const Fr *scalars, size_t n, Affine<F> *out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Fr k = Fr::from_mont(scalars[i]);
+    Xyzz<F> acc = Xyzz<F>::inf();
+    for (int w = 0; w < 32; w++) {
+        const uint32_t d = (k.v[w >> 2] >> ((w & 3) * 8)) & 0xff;
+        if (d) acc.add_mixed(table[w * 255 + d - 1]);
+    }
+    out[i] = acc.to_affine();
+}
+
+// ---- stream compaction of fixed-size elements by a byte flag (order preserving)
+static constexpr uint32_t CE_BLOCK = 2048;
+__global__ __launch_bounds__(256) void ce_count_kernel(const uint8_t *flag, size_t n, uint32_t *blk) {
+    __shared__ uint32_t sh[256];
+    const size_t base = (size_t)blockIdx.x * CE_BLOCK + (size_t)threadIdx.x * 8;
+    uint32_t c = 0;
+    for (int k = 0; k < 8; k++) if (base + k < n && flag[base + k]) c++;
+    sh[threadIdx.x] = c;
+    __syncthreads();
+    for (uint32_t off = 128; off; off >>= 1) { if (threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off]; __syncthreads(); }
+    if (threadIdx.x == 0) blk[blockIdx.x] = sh[0];
+}
+__global__ __launch_bounds__(1024) void ce_scan_kernel(uint32_t *v, uint32_t n, uint32_t *total) {
+    __shared__ uint32_t part[1024];
+    const uint32_t tid = threadIdx.x, ipt = (n + 1023) / 1024;
+    const uint32_t lo = tid * ipt, hi = lo + ipt < n ? lo + ipt : n;
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi && lo < n; i++) sum += v[i];
+    part[tid] = sum;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+        uint32_t x = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += x;
+        __syncthreads();
+    }
+    uint32_t run = part[tid] - sum;
+    for (uint32_t i = lo; i < hi && lo < n; i++) { uint32_t x = v[i]; v[i] = run; run += x; }
+    if (tid == 1023) *total = part[1023];
+}
+template <class T>
+__global__ __launch_bounds__(256) void ce_scatter_kernel(const T *in, const uint8_t *flag, size_t n, const uint32_t *blk, T *out) {
+    __shared__ uint32_t sh[256];
+    const size_t base = (size_t)blockIdx.x * CE_BLOCK + (size_t)threadIdx.x * 8;
+    uint32_t c = 0;
+    for (int k = 0; k < 8; k++) if (base + k < n && flag[base + k]) c++;
+    sh[threadIdx.x] = c;
+    __syncthreads();
+    for (uint32_t off = 1; off < 256; off <<= 1) {
+        uint32_t x = threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += x;
+        __syncthreads();
+    }
+    size_t pos = (size_t)blk[blockIdx.x] + sh[threadIdx.x] - c;
+    for (int k = 0; k < 8; k++) if (base + k < n && flag[base + k]) out[pos++] = in[base + k];
+}
+
+template <class T>
+static int compact_elems(fk_ctx *ctx, const T *d_in, const uint8_t *d_flag, size_t n, T *d_out, uint64_t *n_out) {
+    *n_out = 0;
+    if (!n) return FK_OK;
+    const uint32_t nb = (uint32_t)((n + CE_BLOCK - 1) / CE_BLOCK);
+    FK_HIP(ctx, ctx->scan_tmp.reserve((size_t)nb * 4 + 16));
+    uint32_t *blk = ctx->scan_tmp.as<uint32_t>(), *d_total = blk + nb;
+    hipLaunchKernelGGL(ce_count_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_flag, n, blk);
+    hipLaunchKernelGGL(ce_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, blk, nb, d_total);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(ce_scatter_kernel<T>), dim3(nb), dim3(256), 0, ctx->stream, d_in, d_flag, n, blk, d_out);
+    FK_HIP(ctx, hipGetLastError());
+    uint32_t total = 0;
+    FK_HIP(ctx, hipMemcpyAsync(&total, d_total, 4, hipMemcpyDeviceToHost, ctx->stream));
+    FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *n_out = total;
+    return FK_OK;
+}
+
+// host: fixed-base table d * 2^(8w) * G for w < 32, d in 1..255, affine via one batched inversion
+template <class F>
+static std::vector<Affine<F>> host_fb_table(const Affine<F> &g) {
+    std::vector<Xyzz<F>> pts(32 * 255);
+    Xyzz<F> base = Xyzz<F>::from_affine(g);
+    for (int w = 0; w < 32; w++) {
+        Xyzz<F> cur = base;
+        for (int d = 1; d <= 255; d++) { pts[w * 255 + d - 1] = cur; cur.add(base); }
+        base = cur;  // 256 * previous base
+    }
+    // batched XYZZ -> affine: invert prod(zz * zzz)
+    const size_t n = pts.size();
+    std::vector<F> pre(n);
+    F run = F::one();
+    for (size_t i = 0; i < n; i++) { pre[i] = run; run = F::mul(run, F::mul(pts[i].zz, pts[i].zzz)); }
+    F inv = F::inv(run);
+    std::vector<Affine<F>> out(n);
+    for (size_t i = n; i-- > 0;) {
+        const F t = F::mul(inv, pre[i]);                       // 1 / (zz_i zzz_i)
+        inv = F::mul(inv, F::mul(pts[i].zz, pts[i].zzz));
+        out[i] = Affine<F>{F::mul(pts[i].x, F::mul(t, pts[i].zzz)), F::mul(pts[i].y, F::mul(t, pts[i].zz))};
+    }
+    return out;
+}
+
+template <class F>
+static Affine<F> host_mul(const Affine<F> &p, const Fr &k_mont) {
+    const Fr k = Fr::from_mont(k_mont);
+    return Xyzz<F>::mul_scalar(Xyzz<F>::from_affine(p), k.v).to_affine();
+}
+
+static Fr fr_load(const uint64_t *p) { Fr r; memcpy(&r, p, 32); return r; }
+
+}  // namespace fk
+
+using namespace fk;
+
+struct DevFree { std::vector<void *> v; ~DevFree() { for (void *p : v) if (p) (void)hipFree(p); } };
+
+extern "C" {
+
+int fk_setup(fk_ctx *ctx, const fk_r1cs *cs, const uint64_t tau_[4], const uint64_t alpha_[4], const uint64_t beta_[4],
+             const uint64_t gamma_[4], const uint64_t delta_[4], fk_key **out_key, uint8_t vk_out[6 * 128], uint8_t *ic_out) {
+    if (!ctx) return FK_ERR_BAD_ARG;
+    if (!cs || !tau_ || !alpha_ || !beta_ || !gamma_ || !delta_ || !out_key || !vk_out || !ic_out) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "setup: null argument");
+    *out_key = nullptr;
+    FK_HIP(ctx, hipSetDevice(ctx->device));
+    const Fr tau = fr_load(tau_), alpha = fr_load(alpha_), beta = fr_load(beta_), gamma = fr_load(gamma_), delta = fr_load(delta_);
+    if (gamma.is_zero() || delta.is_zero()) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "setup: gamma and delta must be non-zero");
+    if (cs->num_input == 0) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "setup: num_input must include the constant ONE");
+    const uint64_t rows = cs->num_gates + cs->num_input;
+    const uint32_t log_m = ceil_log2_u64(rows);
+    if (log_m >= FK_FR_S) FK_SET_ERR(ctx, FK_ERR_DOMAIN_TOO_LARGE, "setup: evaluation domain 2^%u too large (max 2^%d)", log_m, FK_FR_S - 1);
+    const uint64_t m = (uint64_t)1 << log_m;
+    const uint64_t nv = (uint64_t)cs->num_input + cs->num_aux;
+    const uint64_t *ptrs[3] = {cs->a_ptr, cs->b_ptr, cs->c_ptr};
+    const uint32_t *cols[3] = {cs->a_col, cs->b_col, cs->c_col};
+    const uint64_t *vals[3] = {cs->a_val, cs->b_val, cs->c_val};
+    for (int k = 0; k < 3; k++) {
+        if (!ptrs[k]) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "setup: null row pointer");
+        const uint64_t nnz = ptrs[k][cs->num_gates];
+        for (uint64_t i = 0; i < nnz; i++) if (cols[k][i] >= nv) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "setup: variable index %u out of range", cols[k][i]);
+    }
+    DevFree tmp;
+    auto dalloc = [&](size_t bytes) -> void * { void *p = nullptr; if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return nullptr; tmp.v.push_back(p); return p; };
+    hipStream_t st = ctx->stream;
+
+    // ---- CSC copies with dictionary-coded coefficients (slot 0 = ONE)
+    std::unordered_map<std::string, uint32_t> dict;
+    std::vector<Fr> table; const Fr one = Fr::one();
+    table.push_back(one); dict.emplace(std::string((const char *)&one, 32), 0u);
+    CscArgs ca;
+    Fr *d_abc[3];
+    for (int k = 0; k < 3; k++) {
+        const uint64_t nnz = ptrs[k][cs->num_gates];
+        std::vector<uint64_t> cptr(nv + 1, 0);
+        for (uint64_t i = 0; i < nnz; i++) cptr[cols[k][i] + 1]++;
+        for (uint64_t v = 0; v < nv; v++) cptr[v + 1] += cptr[v];
+        std::vector<uint32_t> crow(nnz ? nnz : 1), cidx(nnz ? nnz : 1);
+        std::vector<uint64_t> cur(cptr.begin(), cptr.end() - 1);
+        for (uint64_t g = 0; g < cs->num_gates; g++)
+            for (uint64_t i = ptrs[k][g]; i < ptrs[k][g + 1]; i++) {
+                std::string key((const char *)(vals[k] + 4 * i), 32);
+                auto it = dict.find(key);
+                if (it == dict.end()) { Fr v; memcpy(&v, vals[k] + 4 * i, 32); it = dict.emplace(key, (uint32_t)table.size()).first; table.push_back(v); }
+                const uint64_t pos = cur[cols[k][i]]++;
+                crow[pos] = (uint32_t)g; cidx[pos] = it->second;
+            }
+        uint64_t *dp = (uint64_t *)dalloc((nv + 1) * 8); uint32_t *dr = (uint32_t *)dalloc((nnz + 1) * 4), *di = (uint32_t *)dalloc((nnz + 1) * 4);
+        d_abc[k] = (Fr *)dalloc(nv * sizeof(Fr));
+        if (!dp || !dr || !di || !d_abc[k]) FK_SET_ERR(ctx, FK_ERR_OOM, "setup: device allocation failed");
+        FK_HIP(ctx, hipMemcpy(dp, cptr.data(), (nv + 1) * 8, hipMemcpyHostToDevice));
+        if (nnz) { FK_HIP(ctx, hipMemcpy(dr, crow.data(), nnz * 4, hipMemcpyHostToDevice)); FK_HIP(ctx, hipMemcpy(di, cidx.data(), nnz * 4, hipMemcpyHostToDevice)); }
+        ca.ptr[k] = dp; ca.row[k] = dr; ca.cidx[k] = di; ca.out[k] = d_abc[k];
+    }
+    Fr *d_table = (Fr *)dalloc(table.size() * sizeof(Fr));
+    if (!d_table) FK_SET_ERR(ctx, FK_ERR_OOM, "setup: device allocation failed");
+    FK_HIP(ctx, hipMemcpy(d_table, table.data(), table.size() * sizeof(Fr), hipMemcpyHostToDevice));
+
+    // ---- powers of tau (two-level expansion), h scalars, Lagrange coefficients
+    const uint32_t L = (log_m + 1) / 2;
+    std::vector<Fr> lo((size_t)1 << L), hi((size_t)1 << (log_m - L));
+    { Fr cur = Fr::one(), pw = Fr::one();
+      for (size_t i = 0; i < lo.size(); i++) { lo[i] = cur; cur = Fr::mul(cur, tau); pw = Fr::mul(pw, tau); }
+      cur = Fr::one();
+      for (size_t j = 0; j < hi.size(); j++) { hi[j] = cur; cur = Fr::mul(cur, pw); } }
+    Fr *d_lo = (Fr *)dalloc(lo.size() * sizeof(Fr)), *d_hi = (Fr *)dalloc(hi.size() * sizeof(Fr));
+    Fr *d_pt = (Fr *)dalloc(m * sizeof(Fr)), *d_hs = (Fr *)dalloc(m * sizeof(Fr));
+    if (!d_lo || !d_hi || !d_pt || !d_hs) FK_SET_ERR(ctx, FK_ERR_OOM, "setup: device allocation failed");
+    FK_HIP(ctx, hipMemcpy(d_lo, lo.data(), lo.size() * sizeof(Fr), hipMemcpyHostToDevice));
+    FK_HIP(ctx, hipMemcpy(d_hi, hi.data(), hi.size() * sizeof(Fr), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(expand_powers_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, d_lo, d_hi, L, (size_t)m, d_pt);
+    const Fr delta_inv = Fr::inv(delta), gamma_inv = Fr::inv(gamma);
+    const Fr coeff = Fr::mul(Fr::sub(Fr::pow_u64(tau, m), Fr::one()), delta_inv);
+    hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, d_pt, coeff, (size_t)m, d_hs);
+    FK_HIP(ctx, hipGetLastError());
+    FK_TRY(ntt_exec_simple(ctx, d_pt, log_m, /*inverse=*/true, /*coset=*/false));      // d_pt := L_j(tau)
+
+    // ---- A_k, B_k, C_k and the combined exponent
+    hipLaunchKernelGGL(csc_eval_kernel, dim3((unsigned)((nv + 255) / 256), 3), dim3(256), 0, st, ca, d_table, d_pt, cs->num_gates, cs->num_input, nv);
+    Fr *d_e = (Fr *)dalloc(nv * sizeof(Fr));
+    uint8_t *d_fa = (uint8_t *)dalloc(nv), *d_fb = (uint8_t *)dalloc(nv);
+    if (!d_e || !d_fa || !d_fb) FK_SET_ERR(ctx, FK_ERR_OOM, "setup: device allocation failed");
+    hipLaunchKernelGGL(combine_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, st, d_abc[0], d_abc[1], d_abc[2], beta, alpha, gamma_inv, delta_inv,
+                       cs->num_input, nv, d_e, d_fa, d_fb);
+    FK_HIP(ctx, hipGetLastError());
+
+    // ---- fixed-base tables (host) and the scalar multiplications
+    G1Affine g1; g1.x = Fq::from_u64(1); g1.y = Fq::from_u64(2);
+    G2Affine g2; { const uint32_t x0[8] = FK_G2_GEN_X0, x1[8] = FK_G2_GEN_X1, y0[8] = FK_G2_GEN_Y0, y1[8] = FK_G2_GEN_Y1;
+                   for (int i = 0; i < 8; i++) { g2.x.c0.v[i] = x0[i]; g2.x.c1.v[i] = x1[i]; g2.y.c0.v[i] = y0[i]; g2.y.c1.v[i] = y1[i]; } }
+    const std::vector<G1Affine> t1 = host_fb_table<Fq>(g1);
+    const std::vector<G2Affine> t2 = host_fb_table<Fq2>(g2);
+    G1Affine *d_t1 = (G1Affine *)dalloc(t1.size() * sizeof(G1Affine)); G2Affine *d_t2 = (G2Affine *)dalloc(t2.size() * sizeof(G2Affine));
+    if (!d_t1 || !d_t2) FK_SET_ERR(ctx, FK_ERR_OOM, "setup: device allocation failed");
+    FK_HIP(ctx, hipMemcpy(d_t1, t1.data(), t1.size() * sizeof(G1Affine), hipMemcpyHostToDevice));
+    FK_HIP(ctx, hipMemcpy(d_t2, t2.data(), t2.size() * sizeof(G2Affine), hipMemcpyHostToDevice));
+
+    fk_key *k = new fk_key();
+    k->m = m; k->num_input = cs->num_input; k->num_aux = cs->num_aux; k->shard_index = 0; k->shard_count = 1;
+    k->n_h = m - 1; k->n_l = cs->num_aux;
+    auto fail = [&](int code, const char *msg) { ctx->err = msg; fk_key_free(ctx, k); return code; };
+    G1Affine *d_a_all = (G1Affine *)dalloc(nv * sizeof(G1Affine)), *d_b1_all = (G1Affine *)dalloc(nv * sizeof(G1Affine)), *d_el = (G1Affine *)dalloc(nv * sizeof(G1Affine));
+    G2Affine *d_b2_all = (G2Affine *)dalloc(nv * sizeof(G2Affine));
+    if (!d_a_all || !d_b1_all || !d_el || !d_b2_all) return fail(FK_ERR_OOM, "setup: device allocation failed");
+    if (hipMalloc((void **)&k->d_h, m * sizeof(G1Affine)) != hipSuccess || hipMalloc((void **)&k->d_l, (cs->num_aux + 1) * sizeof(G1Affine)) != hipSuccess ||
+        hipMalloc((void **)&k->d_a, (nv + 1) * sizeof(G1Affine)) != hipSuccess || hipMalloc((void **)&k->d_b1, (nv + 1) * sizeof(G1Affine)) != hipSuccess ||
+        hipMalloc((void **)&k->d_b2, (nv + 1) * sizeof(G2Affine)) != hipSuccess) return fail(FK_ERR_OOM, "setup: device allocation failed");
+    const unsigned fb_threads = 128;
+    auto fb1 = [&](const Fr *sc, size_t n, G1Affine *o) { if (n) hipLaunchKernelGGL(HIP_KERNEL_NAME(fixed_base_kernel<Fq>), dim3((unsigned)((n + fb_threads - 1) / fb_threads)), dim3(fb_threads), 0, st, d_t1, sc, n, o); };
+    fb1(d_hs, m - 1, k->d_h);
+    fb1(d_abc[0], nv, d_a_all);
+    fb1(d_abc[1], nv, d_b1_all);
+    fb1(d_e, nv, d_el);
+    if (nv) hipLaunchKernelGGL(HIP_KERNEL_NAME(fixed_base_kernel<Fq2>), dim3((unsigned)((nv + fb_threads - 1) / fb_threads)), dim3(fb_threads), 0, st, d_t2, d_abc[1], (size_t)nv, d_b2_all);
+    if (hipGetLastError() != hipSuccess) return fail(FK_ERR_HIP, "setup: kernel launch failed");
+    // l = exponent points of the aux variables; ic = those of the inputs
+    if (hipMemcpyAsync(k->d_l, d_el + cs->num_input, (size_t)cs->num_aux * sizeof(G1Affine), hipMemcpyDeviceToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(ic_out, d_el, (size_t)cs->num_input * sizeof(G1Affine), hipMemcpyDeviceToHost, st) != hipSuccess) return fail(FK_ERR_HIP, "setup: copy failed");
+    // a, b_g1, b_g2: drop identity points, keep order
+    uint64_t n_a = 0, n_b1 = 0, n_b2 = 0;
+    int rc = compact_elems<G1Affine>(ctx, d_a_all, d_fa, nv, k->d_a, &n_a);
+    if (rc == FK_OK) rc = compact_elems<G1Affine>(ctx, d_b1_all, d_fb, nv, k->d_b1, &n_b1);
+    if (rc == FK_OK) rc = compact_elems<G2Affine>(ctx, d_b2_all, d_fb, nv, k->d_b2, &n_b2);
+    if (rc != FK_OK) { fk_key_free(ctx, k); return rc; }
+    k->n_a = n_a; k->n_b = n_b1;
+    k->h_lo = 0; k->h_hi = k->n_h; k->l_lo = 0; k->l_hi = k->n_l; k->a_lo = 0; k->a_hi = n_a; k->b_lo = 0; k->b_hi = n_b1;
+    // vk
+    k->alpha_g1 = host_mul<Fq>(g1, alpha); k->beta_g1 = host_mul<Fq>(g1, beta); k->delta_g1 = host_mul<Fq>(g1, delta);
+    k->beta_g2 = host_mul<Fq2>(g2, beta); k->delta_g2 = host_mul<Fq2>(g2, delta);
+    const G2Affine gamma_g2 = host_mul<Fq2>(g2, gamma);
+    memset(vk_out, 0, 6 * 128);
+    memcpy(vk_out + 0 * 128, &k->alpha_g1, 64); memcpy(vk_out + 1 * 128, &k->beta_g1, 64); memcpy(vk_out + 2 * 128, &k->beta_g2, 128);
+    memcpy(vk_out + 3 * 128, &gamma_g2, 128); memcpy(vk_out + 4 * 128, &k->delta_g1, 64); memcpy(vk_out + 5 * 128, &k->delta_g2, 128);
+    if (hipStreamSynchronize(st) != hipSuccess) return fail(FK_ERR_HIP, "setup: synchronize failed");
+    *out_key = k;
+    return FK_OK;
+}
+
+// which: 0 = h, 1 = l, 2 = a, 3 = b_g1, 4 = b_g2.  Copies this key's slice of the array to the host.
+int fk_key_download(fk_ctx *ctx, const fk_key *key, int which, void *host, size_t host_bytes) {
+    if (!ctx) return FK_ERR_BAD_ARG;
+    if (!key || !host) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "key download: null argument");
+    FK_HIP(ctx, hipSetDevice(ctx->device));
+    const void *src = nullptr; size_t bytes = 0;
+    switch (which) {
+        case 0: src = key->d_h; bytes = (key->h_hi - key->h_lo) * 64; break;
+        case 1: src = key->d_l; bytes = (key->l_hi - key->l_lo) * 64; break;
+        case 2: src = key->d_a; bytes = (key->a_hi - key->a_lo) * 64; break;
+        case 3: src = key->d_b1; bytes = (key->b_hi - key->b_lo) * 64; break;
+        case 4: src = key->d_b2; bytes = (key->b_hi - key->b_lo) * 128; break;
+        default: FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "key download: which must be 0..4");
+    }
+    if (host_bytes < bytes) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "key download: buffer too small (%zu < %zu)", host_bytes, bytes);
+    if (bytes) FK_HIP(ctx, hipMemcpy(host, src, bytes, hipMemcpyDeviceToHost));
+    return FK_OK;
+}
+
+}  // extern "C"

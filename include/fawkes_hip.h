@@ -209,6 +209,17 @@ int fk_prove_r1cs(fk_ctx *ctx, const fk_key *key, const fk_r1cs_dev *r1cs, const
 int fk_prove_r1cs_dev(fk_ctx *ctx, const fk_key *key, const fk_r1cs_dev *r1cs, const void *d_z,
                       const uint64_t r[4], const uint64_t s[4], uint8_t out_proof[FK_PROOF_BYTES], fk_timings *timings);
 
+/* ---------------------------------------------------------------- key generation on the GPU
+ * (SURVEY section 8f row 4): bellman's generate_parameters (reached from setup.rs:20) for EXPLICIT toxic
+ * waste tau, alpha, beta, gamma, delta (Montgomery Fr) and the standard BN254 generators.  Produces a
+ * resident, unsharded proving key.  vk_out: six 128-byte slots alpha_g1, beta_g1, beta_g2, gamma_g2, delta_g1,
+ * delta_g2 (G1 points use the first 64 bytes); ic_out: num_input x 64 bytes.  For tests and benchmarks:
+ * a real deployment runs an MPC ceremony, never a setup with known toxic waste. */
+int fk_setup(fk_ctx *ctx, const fk_r1cs *cs, const uint64_t tau[4], const uint64_t alpha[4], const uint64_t beta[4],
+             const uint64_t gamma[4], const uint64_t delta[4], fk_key **out_key, uint8_t vk_out[6 * 128], uint8_t *ic_out);
+/* copies this key's slice of one array to the host; which: 0 = h, 1 = l, 2 = a, 3 = b_g1, 4 = b_g2 */
+int fk_key_download(fk_ctx *ctx, const fk_key *key, int which, void *host, size_t host_bytes);
+
 /* Kernel timing measured with HIP events on the library's stream since the last reset, summed over
  * launches.  which: 0 = msm_accumulate_kernel<Fq> (G1 bucket accumulation; units = points per launch),
  * 1 = msm_accumulate_kernel<Fq2> (G2), 2 = ntt_pass_kernel (units = elements per pass). */

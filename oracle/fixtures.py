@@ -44,3 +44,43 @@ def key_to_py(key):
 
 def mont_fr(x):
     return co.limbs(ref.to_mont(x % ref.R, ref.R))
+
+
+def fast_r1cs(seed, num_gates, num_input, num_aux):
+    """Large satisfiable R1CS built directly in CSR/Montgomery form (for 2^16..2^20-gate tests):
+    gate k is  (z[i] + ka * z[j]) * (kb * z[l]) = prod * ONE  with the witness chosen first, so rows are
+    independent.  A draws from aux variables, B from inputs and aux, C is a multiple of Input(0) = ONE.
+    Returns (c_oracle.R1csC, z Montgomery (nv,4) uint64, z_in ints, z_aux ints)."""
+    import random
+    R = ref.R
+    rnd = random.Random(seed)
+    nv = num_input + num_aux
+    z_in = [1] + [rnd.randrange(R) for _ in range(num_input - 1)]
+    z_aux = [rnd.randrange(R) if rnd.random() < 0.5 else rnd.randrange(2) for _ in range(num_aux)]
+    zs = z_in + z_aux
+    MONT = ref.MONT_R % R
+    one_m = MONT
+    a_col, a_val, b_col, b_val, c_col, c_val, lens = [], [], [], [], [], [], []
+    for _ in range(num_gates):
+        i = num_input + rnd.randrange(num_aux)
+        j = num_input + rnd.randrange(num_aux)
+        l = rnd.randrange(nv)
+        ka = rnd.randrange(1, R)
+        kb = rnd.randrange(1, R) if rnd.random() < 0.5 else 1
+        av = (zs[i] + ka * zs[j]) % R if j != i else (zs[i] * (1 + ka)) % R
+        prod = av * (kb * zs[l] % R) % R
+        if j != i:
+            a_col += [i, j]; a_val += [one_m, ka * MONT % R]; lens.append(2)
+        else:
+            a_col += [i]; a_val += [(1 + ka) % R * MONT % R]; lens.append(1)
+        b_col.append(l); b_val.append(kb * MONT % R)
+        c_col.append(0); c_val.append(prod * MONT % R)
+    a_ptr = np.zeros(num_gates + 1, np.uint64)
+    a_ptr[1:] = np.cumsum(np.array(lens, np.uint64))
+    seq = np.arange(num_gates + 1, dtype=np.uint64)
+    A = co.Csr(a_ptr, np.array(a_col, np.uint32), co.limbs_arr(a_val))
+    B = co.Csr(seq, np.array(b_col, np.uint32), co.limbs_arr(b_val))
+    Cm = co.Csr(seq, np.array(c_col, np.uint32), co.limbs_arr(c_val))
+    cs = co.R1csC(num_input, num_aux, A, B, Cm)
+    z = co.limbs_arr([x * MONT % R for x in zs])
+    return cs, z, z_in, z_aux
