@@ -2,23 +2,26 @@
 """
 bench.py -- Groth16 proofs/sec on MI355X through the C ABI (include/fawkes_hip.h).
 
-One "step" = one complete Groth16 proof for a synthetic 2^LOG2-constraint BN254 R1CS (default 2^25, the
-size BASELINE.json's metric is quoted on): the 7-NTT quotient, the four G1 MSMs (H, L, A, B1), the G2
-MSM (B2) and the proof assembly -- exactly the work behind `create_random_proof`
-(/root/reference/fawkes-crypto/src/backend/bellman_groth16/prover.rs:80).  Inputs (a, b, c row
-evaluations, the assignment z, density maps, proving key) are resident in HBM before the timed region.
+One "step" = one complete Groth16 proof for a satisfiable rollup-shaped BN254 R1CS of 2^LOG2 rows (default
+2^25, the size BASELINE.json's metric is quoted on), starting from the WITNESS VECTOR: device SpMV
+(a = Az, b = Bz, c = Cz), the 7-NTT quotient, the four G1 MSMs (H, L, A, B1), the G2 MSM (B2) and the
+proof assembly -- the work behind `create_random_proof`
+(/root/reference/fawkes-crypto/src/backend/bellman_groth16/prover.rs:80), including bellman's `synthesize`
+evaluation (mod.rs:92-99).  The witness, the constraint system and the proving key are resident in HBM before
+the timed region.  The key is a VALID key (fk_setup, fixed toxic waste), so the proof produced in the timed
+region is checked afterwards with the Groth16 pairing equation.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
 N > 1: one process per GPU; every rank holds a slice of each key array (MSM sharded by points).  Rank 0
-computes the quotient while the others start on the witness MSMs, h slices go point-to-point over xGMI,
-ONE all-gather (RCCL) of 384 bytes per rank exchanges the partial sums and the proof is folded locally --
-strong scaling of a single proof (fawkes-crypto_amd/parallel.py: prove_balanced).
+evaluates the constraint system and computes the quotient while the others start on the witness MSMs, h slices
+go point-to-point over xGMI, ONE all-gather (RCCL) of 384 bytes per rank exchanges the partial sums and the
+proof is folded locally -- strong scaling of a single proof (fawkes-crypto_amd/parallel.py: prove_balanced).
 
-The CPU oracle (oracle/) appears here only as the timed `cpu_baseline` and as a live parity check of
-that same sample; it is never the thing measured as `value`.
+The CPU oracle (oracle/) appears here only in the `cpu_baseline` leg: the timed CPU baseline, a live parity
+check of that same sample, and the pairing check of the benchmarked proof; it is never the thing measured.
 """
 import argparse
 import json
@@ -35,55 +38,96 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 achievable
 G1_BYTES_PER_SCALAR_MUL = 96     # 64 B affine base + 32 B scalar
-G2_BYTES_PER_SCALAR_MUL = 160
+FR_MODULUS = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+MONT_R = (1 << 256) % FR_MODULUS
+TOXIC = dict(tau=0x1f2e3d4c5b6a79880123456789abcdef0fedcba987654321, alpha=0xa11ce, beta=0xb0b, gamma=0xc0ffee, delta=0xdec0de)
 
 
-def cpu_baseline(ctx, log2_sample):
-    """Times the C oracle (bellman's algorithm restated, single thread = the reference's configured
-    worker) on a bounded sample: the FULL prover on a 2^log2_sample instance with the same
-    shape ratios and scalar distribution, with key points generated on the GPU and downloaded.  The same
-    instance is proved on the GPU and the 256 proof bytes must match (live parity check)."""
+def mont(x):
+    return np.frombuffer(((x % FR_MODULUS) * MONT_R % FR_MODULUS).to_bytes(32, 'little'), dtype=np.uint64).copy()
+
+
+def build_workload(ctx, fk, log2n, seed=2026):
+    """Satisfiable rollup-shaped R1CS with m = 2^log2n rows (gates + inputs = m exactly) and its witness.
+    40 % boolean constraints b*(b-1)=0 (bit decompositions dominate fawkes circuits, circuit/bitify.rs),
+    10 % linear gates, 50 % product gates over random field elements.  Coefficients are 1 and -1 only.
+    Witness: 20 % zeros, 20 % ones, 60 % dense 254-bit values.  Returns (R1cs, z (nv,4) uint64 Montgomery)."""
+    m = 1 << log2n
+    v_in = 2
+    G = m - v_in
+    nb = int(0.4 * G); nf = max(int(0.1 * G), 1); npr = G - nb - nf
+    v_aux = G
+    rng = np.random.default_rng(seed)
+    one, minus_one = mont(1), mont(-1)
+    # witness
+    z = np.zeros((v_in + v_aux, 4), np.uint64)
+    z[0] = one
+    z[1] = mont(0x5eed5eed5eed)
+    bits = rng.integers(0, 2, nb, dtype=np.uint8)
+    z[v_in:v_in + nb][bits == 1] = one
+    free = rng.integers(0, 1 << 63, size=(nf, 4), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=(nf, 4), dtype=np.uint64)
+    free[:, 3] &= np.uint64((1 << 60) - 1)            # Montgomery images < 2^252 < r
+    z[v_in + nb:v_in + nb + nf] = free
+    i_k = rng.integers(0, nf, npr, dtype=np.int64)
+    l_k = rng.integers(0, nf, npr, dtype=np.int64)
+    CH = 1 << 22
+    for lo in range(0, npr, CH):
+        hi = min(lo + CH, npr)
+        z[v_in + nb + nf + lo:v_in + nb + nf + hi] = ctx.fr_mul_batch(free[i_k[lo:hi]], free[l_k[lo:hi]])
+    # matrices (variable index: Input(i) -> i, Aux(j) -> v_in + j)
+    a_col = np.concatenate([v_in + np.arange(nb, dtype=np.uint32), (v_in + nb + np.arange(nf)).astype(np.uint32),
+                            (v_in + nb + i_k).astype(np.uint32)])
+    a_ptr = np.arange(G + 1, dtype=np.uint64)
+    b_len = np.concatenate([np.full(nb, 2, np.uint64), np.ones(nf + npr, np.uint64)])
+    b_ptr = np.zeros(G + 1, np.uint64); b_ptr[1:] = np.cumsum(b_len)
+    b_col = np.zeros(int(b_ptr[-1]), np.uint32)
+    b_val = np.tile(one, (int(b_ptr[-1]), 1))
+    b_col[0:2 * nb:2] = v_in + np.arange(nb, dtype=np.uint32)       # b
+    b_col[1:2 * nb:2] = 0                                            # - ONE
+    b_val[1:2 * nb:2] = minus_one
+    b_col[2 * nb:2 * nb + nf] = 0                                    # linear gates: * ONE
+    b_col[2 * nb + nf:] = (v_in + nb + l_k).astype(np.uint32)
+    c_len = np.concatenate([np.zeros(nb, np.uint64), np.ones(nf + npr, np.uint64)])
+    c_ptr = np.zeros(G + 1, np.uint64); c_ptr[1:] = np.cumsum(c_len)
+    c_col = np.concatenate([(v_in + nb + np.arange(nf)).astype(np.uint32), (v_in + nb + nf + np.arange(npr)).astype(np.uint32)])
+    r1cs = fk.R1cs(v_in, v_aux, (a_ptr, a_col, None), (b_ptr, b_col, b_val), (c_ptr, c_col, None))
+    return r1cs, z
+
+
+def cpu_baseline_leg(ctx, fk, log2_sample, full):
+    """(1) times the C oracle (bellman's algorithm restated, single thread = the reference's configured worker,
+    SURVEY fact 3) proving a 2^log2_sample instance of the same workload family; (2) the GPU proof of that same
+    sample must match byte for byte; (3) the benchmarked full-size proof must satisfy the pairing equation."""
+    import bn254_ref as ref
     import c_oracle as co
-    import fixtures as fx
-    import fawkes_crypto_amd as fk
-    m = 1 << log2_sample
-    v_in, v_aux = 2, m - 2
-    rng = np.random.default_rng(12345)
-    dens_a = (rng.random(v_aux) < 0.6).astype(np.uint8)
-    dens_bi = np.ones(v_in, np.uint8)
-    dens_ba = (rng.random(v_aux) < 0.6).astype(np.uint8)
-    n_a = v_in + int(dens_a.sum())
-    n_b = int(dens_bi.sum()) + int(dens_ba.sum())
-
-    def gen_g1(n, seed):
-        d = ctx.dev_alloc(max(n, 1) * 64); ctx.gen_points_g1_dev(d, n, seed)
-        out = ctx.download(d, n * 64).reshape(-1, 64); ctx.dev_free(d); return out
-
-    def gen_g2(n, seed):
-        d = ctx.dev_alloc(max(n, 1) * 128); ctx.gen_points_g2_dev(d, n, seed)
-        out = ctx.download(d, n * 128).reshape(-1, 128); ctx.dev_free(d); return out
-
-    def gen_fr(n, seed, kind):
-        d = ctx.dev_alloc(n * 32); ctx.gen_scalars_dev(d, n, seed, kind)
-        out = ctx.download(d, n * 32, np.uint64).reshape(-1, 4); ctx.dev_free(d); return out
-    vk1, vk2 = gen_g1(3, 901), gen_g2(2, 902)
-    arrays = dict(m=m, num_input=v_in, num_aux=v_aux, alpha_g1=vk1[0], beta_g1=vk1[1], delta_g1=vk1[2],
-                  beta_g2=vk2[0], delta_g2=vk2[1], h=gen_g1(m - 1, 1), l=gen_g1(v_aux, 2), a=gen_g1(n_a, 3),
-                  b_g1=gen_g1(n_b, 4), b_g2=gen_g2(n_b, 5))
-    a, b, c = gen_fr(m, 21, 0), gen_fr(m, 22, 0), gen_fr(m, 23, 0)
-    z = gen_fr(v_in + v_aux, 24, 1)
-    r, s = fx.mont_fr(0x1234567), fx.mont_fr(0x89abcdef)
-    okey = co.ArrayKey(m, v_in, v_aux, dict(alpha_g1=vk1[0], beta_g1=vk1[1], delta_g1=vk1[2], beta_g2=vk2[0], delta_g2=vk2[1]),
-                       arrays['h'], arrays['l'], arrays['a'], arrays['b_g1'], arrays['b_g2'])
+    r1cs, z = build_workload(ctx, fk, log2_sample, seed=77)
+    tox = {k: mont(v) for k, v in TOXIC.items()}
+    dk, vk = ctx.setup(r1cs, **tox)
+    okey = co.ArrayKey(1 << log2_sample, r1cs.num_input, r1cs.num_aux, vk, dk.download('h'), dk.download('l'), dk.download('a'),
+                       dk.download('b_g1'), dk.download('b_g2'), ic=vk['ic'])
+    a, b, c, aa, bi, ba = fk.api.synthesize(r1cs, z)
+    r, s = mont(0x1234567), mont(0x89abcdef)
     t0 = time.time()
-    want = co.prove(okey, a, b, c, z, dens_a, dens_bi, dens_ba, r, s)
+    want = co.prove(okey, a, b, c, z, aa, bi, ba, r, s)
     cpu_s = time.time() - t0
-    dk = ctx.load_key(fk.Parameters(arrays))
-    got = ctx.prove_raw(dk, a, b, c, z, dens_a, dens_bi, dens_ba, r, s)
-    dk.free()
+    dr = ctx.load_r1cs(r1cs)
+    got = ctx.prove_witness(dk, dr, z, r, s)
+    dr.free(); dk.free()
     if got.tobytes() != want.tobytes():
         raise AssertionError('bench parity check failed: HIP proof != oracle proof on the CPU-baseline sample')
-    return cpu_s, m
+    verified = None
+    if full is not None:
+        vk_full, z_in1, proof = full
+        g1 = lambda b_: ref.g1_from_raw_le(bytes(b_))
+        g2 = lambda b_: ref.g2_from_raw_le(bytes(b_))
+        pk = dict(alpha_g1=g1(vk_full['alpha_g1']), beta_g2=g2(vk_full['beta_g2']), gamma_g2=g2(vk_full['gamma_g2']),
+                  delta_g2=g2(vk_full['delta_g2']), ic=[g1(x.tobytes()) for x in vk_full['ic']])
+        Rinv = pow(MONT_R, -1, FR_MODULUS)
+        pub = [int.from_bytes(z_in1.tobytes(), 'little') * Rinv % FR_MODULUS]
+        verified = bool(ref.verify(pk, pub, ref.proof_from_borsh(proof)))
+        if not verified:
+            raise AssertionError('bench: the benchmarked proof does not satisfy the Groth16 pairing equation')
+    return cpu_s, 1 << log2_sample, verified
 
 
 def main():
@@ -91,7 +135,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--log2n', type=int, default=25, help='log2 of the constraint count (rows handed to the prover)')
+    ap.add_argument('--log2n', type=int, default=25, help='log2 of the row count handed to the prover')
     ap.add_argument('--cpu-log2n', type=int, default=18, help='size of the CPU-baseline sample instance')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend ('nccl' = RCCL; 'gloo' only for single-GPU dry runs of the N>1 code path with FK_BENCH_SAME_DEVICE=1)")
@@ -122,48 +166,41 @@ def main():
     comm_dev = dev if args.backend == 'nccl' else None
     ctx = fk.Context(local_rank)
 
-    # ---------------------------------------------------------------- workload (SURVEY section 8d, config 4 shape)
+    # ---------------------------------------------------------------- workload: constraint system, witness, valid key
+    t_prep = time.time()
     m = 1 << args.log2n
-    v_in = 2
-    v_aux = m - v_in
-    n = m                                   # rows = #gates + num_input = m exactly
-    dens_frac = 0.6                         # share of aux variables occurring in A- resp. B-side LCs (assumption)
-    g = torch.Generator(device='cpu'); g.manual_seed(7)
-    dens_a = (torch.rand(v_aux, generator=g) < dens_frac).to(torch.uint8)
-    dens_ba = (torch.rand(v_aux, generator=g) < dens_frac).to(torch.uint8)
-    dens_bi = torch.ones(v_in, dtype=torch.uint8)
-    n_a = v_in + int(dens_a.sum()); n_b = int(dens_bi.sum()) + int(dens_ba.sum())
-    d_dens_a, d_dens_bi, d_dens_ba = dens_a.to(dev), dens_bi.to(dev), dens_ba.to(dev)
-
-    # multi-GPU: h sharded equally, witness arrays by the work-balanced fractions (rank 0 also runs the quotient)
+    r1cs, z = build_workload(ctx, fk, args.log2n)
+    v_in, v_aux, n = r1cs.num_input, r1cs.num_aux, r1cs.n_rows
+    assert n == m
+    dr = ctx.load_r1cs(r1cs)
+    info = dr.info()
+    n_a, n_b = info['n_a'], info['n_b']
     fracs = parallel.plan_z_fractions(world, m, v_aux, n_a, n_b)
-    key = ctx.synthetic_key(m, v_in, v_aux, n_a, n_b, seed=2026, shard_index=rank, shard_count=world,
-                            z_frac=fracs[rank] if world > 1 else (0.0, 0.0))
-    h_ranges = [fk.api.shard_range(m - 1, g, world) for g in range(world)]
-    h_full_buf = torch.empty(m * 32, dtype=torch.uint8, device=dev) if (world > 1 and rank == 0) else None
-    recv_buf = torch.empty(max(h_ranges[rank][1] - h_ranges[rank][0], 1) * 32, dtype=torch.uint8, device=dev) if (world > 1 and rank > 0) else None
-    # pristine inputs + working copies (the prover consumes a, b, c as scratch)
-    nbytes = m * 32
-    pristine = [torch.empty(nbytes, dtype=torch.uint8, device=dev) for _ in range(3)]
-    work = [torch.empty(nbytes, dtype=torch.uint8, device=dev) for _ in range(3)]
+    tox = {k: mont(v) for k, v in TOXIC.items()}
+    key, vk = ctx.setup(r1cs, shard_index=rank, shard_count=world, z_frac=fracs[rank] if world > 1 else (0.0, 0.0), **tox)
     d_z = torch.empty((v_in + v_aux) * 32, dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
-    for i, t in enumerate(pristine):
-        ctx.gen_scalars_dev(t.data_ptr(), m, 100 + i, 0)          # uniform row evaluations
-    ctx.gen_scalars_dev(d_z.data_ptr(), v_in + v_aux, 200, 1)     # witness-like assignment (half in {0,1})
-    import fixtures as fx
-    r, s = fx.mont_fr(0xA11CE), fx.mont_fr(0xB0B)
+    ctx.upload(d_z.data_ptr(), z)
+    z_in1 = z[1].copy()
+    zeros = int((~z.any(axis=1)).sum()); ones = int((z == mont(1)).all(axis=1).sum())
+    del z
+    r, s = mont(0xA11CE), mont(0xB0B)
+    d_dens = dr.density_ptrs()
+    if world > 1:
+        h_ranges = [fk.api.shard_range(m - 1, g, world) for g in range(world)]
+        h_full_buf = torch.empty(m * 32, dtype=torch.uint8, device=dev) if rank == 0 else None
+        recv_buf = torch.empty(max(h_ranges[rank][1] - h_ranges[rank][0], 1) * 32, dtype=torch.uint8, device=dev) if rank > 0 else None
+        work = [torch.empty(m * 32, dtype=torch.uint8, device=dev) for _ in range(3)] if rank == 0 else [None] * 3
+    prep_s = time.time() - t_prep
 
     def step():
-        if world == 1 or rank == 0:       # only the rank that runs the quotient consumes a, b, c
-            for w_, p_ in zip(work, pristine):
-                ctx.dev_copy(w_.data_ptr(), p_.data_ptr(), nbytes)
         if world == 1:
-            return ctx.prove_dev(key, work[0].data_ptr(), work[1].data_ptr(), work[2].data_ptr(), n, d_z.data_ptr(),
-                                 d_dens_a.data_ptr(), d_dens_bi.data_ptr(), d_dens_ba.data_ptr(), r, s)
-        return parallel.prove_balanced_dev(ctx, key, rank, world, work[0].data_ptr(), work[1].data_ptr(), work[2].data_ptr(), n,
-                                           d_z.data_ptr(), d_dens_a.data_ptr(), d_dens_bi.data_ptr(), d_dens_ba.data_ptr(),
-                                           r, s, h_ranges, h_full_buf, recv_buf, device=comm_dev)
+            return ctx.prove_witness_dev(key, dr, d_z.data_ptr(), r, s)
+        wp = [w_.data_ptr() if w_ is not None else 0 for w_ in work]
+        return parallel.prove_balanced_dev(
+            ctx, key, rank, world, wp[0], wp[1], wp[2], n, d_z.data_ptr(), d_dens[0], d_dens[1], d_dens[2], r, s,
+            h_ranges, h_full_buf, recv_buf, device=comm_dev,
+            eval_fn=(lambda: ctx.r1cs_eval_dev(dr, d_z.data_ptr(), wp[0], wp[1], wp[2])) if rank == 0 else None)
 
     def barrier():
         if world > 1:
@@ -197,14 +234,13 @@ def main():
         acc = stats['acc_g1']
         # dominant kernel: msm_accumulate_kernel<Fq>; achieved = algorithmic bytes / its HIP-event time
         achieved = (acc['units'] * G1_BYTES_PER_SCALAR_MUL) / (acc['ms'] * 1e-3) / 1e9 if acc['ms'] > 0 else 0.0
-        # HBM traffic of the dominant kernel from the committed PMC pass (profiles/), if it was taken at this size
         traffic = None
-        try:
+        try:   # HBM traffic of the dominant kernel from the committed PMC pass (profiles/), if taken at this size
             pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic_bench_2p25.json')))
             if pmc['log2n'] == args.log2n and world == 1 and acc['ms'] > 0:
-                dk = pmc['dominant_kernel']
-                per_proof = dk['fetch_bytes_per_proof_raw'] + dk['write_bytes_per_proof']
-                traffic = per_proof / (acc['ms'] / args.steps * 1e-3) / 1e9      # GB/s at this run's kernel time
+                dkk = pmc['dominant_kernel']
+                per_pt = (dkk['fetch_bytes_per_proof_raw'] + dkk['write_bytes_per_proof']) / dkk['points_per_proof']
+                traffic = per_pt * (acc['units'] / args.steps) / (acc['ms'] / args.steps * 1e-3) / 1e9
         except Exception:
             traffic = None
         out = {
@@ -218,19 +254,21 @@ def main():
             'vs_baseline': None,
             'dtype': 'u32',
             'data': 'synthetic',
-            'config': {'workload': 'synthetic rollup-shape R1CS, 2^%d rows (BASELINE configs[3] shape): 7-NTT quotient + '
-                                   'G1 MSMs H/L/A/B1 + G2 MSM B2 + assembly, inputs and key resident in HBM' % args.log2n,
+            'config': {'workload': 'satisfiable rollup-shape R1CS, 2^%d rows (BASELINE configs[3] shape), valid key: witness -> '
+                                   'device SpMV + 7-NTT quotient + G1 MSMs H/L/A/B1 + G2 MSM B2 + assembly; witness, constraint system '
+                                   'and key resident in HBM' % args.log2n,
                        'log2_constraints': args.log2n, 'num_input': v_in, 'num_aux': v_aux,
-                       'density_a_aux': dens_frac, 'density_b_aux': dens_frac,
-                       'scalar_distribution': 'a,b,c uniform; assignment witness-like (50% in {0,1})',
+                       'gates': '40% boolean b*(b-1)=0, 10% linear, 50% products', 'nnz': list(info['nnz']),
+                       'a_query_points': n_a, 'b_query_points': n_b,
+                       'witness': '%.0f%% zeros, %.0f%% ones, rest dense 254-bit' % (100.0 * zeros / (v_in + v_aux), 100.0 * ones / (v_in + v_aux)),
                        'parallelism': 'msm-shard%d%s' % (world, '+balanced-quotient' if world > 1 else '')},
             'msm_scalar_muls_per_sec': msm_units / sec_per_step,
             'roofline': {
                 'bound': 'hbm', 'kernel': 'msm_accumulate_kernel<Fq> (G1 bucket accumulation)',
                 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                 'traffic': traffic,
-                'traffic_source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/r01_pmc_traffic_bench_2p25.json '
-                                  '(raw FETCH_SIZE: gather width uncalibrated, see file)' if traffic else None,
+                'traffic_source': ('rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/r01_pmc_traffic_bench_2p25.json '
+                                   '(bytes per point from that pass x this run\'s points; raw FETCH_SIZE, gather width uncalibrated)') if traffic else None,
                 'launches': acc['launches'], 'avg_launch_ms': acc['ms'] / max(acc['launches'], 1),
                 'algorithmic_bytes_per_scalar_mul': G1_BYTES_PER_SCALAR_MUL,
                 'note': 'MSM is 256-bit modular integer work: VALU-bound, not HBM-bound; see DESIGN.md',
@@ -241,19 +279,22 @@ def main():
                 'ntt_passes': stats['ntt']['ms'] / args.steps,
                 'ntt_algorithmic_GBps': (stats['ntt']['units'] * 64) / (stats['ntt']['ms'] * 1e-3) / 1e9 if stats['ntt']['ms'] > 0 else 0.0,
             },
+            'prep_seconds': prep_s,
         }
         if world == 1 and not args.no_cpu_baseline:
-            cpu_s, cpu_m = cpu_baseline(ctx, args.cpu_log2n)
+            cpu_s, cpu_m, verified = cpu_baseline_leg(ctx, fk, args.cpu_log2n, (vk, z_in1, proofs[-1]))
             scale = m / cpu_m
+            out['proof_verified_by_pairing_check'] = verified
             out['cpu_baseline'] = {
                 'value': 1.0 / (cpu_s * scale), 'unit': 'proofs/s', 'cores': 1, 'kind': 'port',
-                'sample': 'oracle/groth16_oracle.c (bellman algorithm restated, 1 thread) proving a 2^%d-row instance of '
-                          'the same shape in %.2f s; scaled linearly by %d to 2^%d rows (optimistic for the CPU: NTT is '
-                          'n log n); the GPU proof of the same sample matched byte for byte' % (args.cpu_log2n, cpu_s, scale, args.log2n),
+                'sample': 'oracle/groth16_oracle.c (bellman algorithm restated, 1 thread) proving a 2^%d-row instance of the same '
+                          'workload family in %.2f s; scaled linearly by %d to 2^%d rows (optimistic for the CPU: NTT is n log n); '
+                          'the GPU proof of the same sample matched byte for byte' % (args.cpu_log2n, cpu_s, scale, args.log2n),
                 'sample_seconds': cpu_s,
             }
         print(json.dumps(out), flush=True)
 
+    dr.free()
     key.free()
     if world > 1:
         import torch.distributed as dist

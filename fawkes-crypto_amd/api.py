@@ -33,7 +33,7 @@ EXPORTED_SYMBOLS = [
     'fk_gen_points_g1_dev', 'fk_gen_points_g2_dev', 'fk_gen_scalars_dev',
     'fk_synthesize', 'fk_stats_reset', 'fk_stats_get', 'fk_shard_range',
     'fk_setup', 'fk_key_download',
-    'fk_r1cs_load', 'fk_r1cs_free', 'fk_r1cs_info', 'fk_r1cs_eval_dev', 'fk_prove_r1cs', 'fk_prove_r1cs_dev',
+    'fk_r1cs_load', 'fk_r1cs_free', 'fk_r1cs_info', 'fk_r1cs_density_ptrs', 'fk_r1cs_eval_dev', 'fk_prove_r1cs', 'fk_prove_r1cs_dev',
 ]
 
 _ERR = {1: 'FK_ERR_BAD_ARG', 2: 'FK_ERR_DOMAIN_TOO_LARGE (bellman: PolynomialDegreeTooLarge)',
@@ -141,16 +141,16 @@ class R1cs:
     def __init__(self, num_input, num_aux, a, b, c):
         self.num_input, self.num_aux = int(num_input), int(num_aux)
         self.mats = []
-        for (ptr, col, val) in (a, b, c):
+        for (ptr, col, val) in (a, b, c):       # val None: every coefficient of that matrix is ONE
             self.mats.append((np.ascontiguousarray(ptr, np.uint64), np.ascontiguousarray(col, np.uint32),
-                              np.ascontiguousarray(val, np.uint64).reshape(-1, 4)))
+                              None if val is None else np.ascontiguousarray(val, np.uint64).reshape(-1, 4)))
         self.num_gates = len(self.mats[0][0]) - 1
         s = R1csStruct()
         s.num_input, s.num_aux, s.num_gates = self.num_input, self.num_aux, self.num_gates
         for nm, (ptr, col, val) in zip('abc', self.mats):
             setattr(s, nm + '_ptr', ptr.ctypes.data)
             setattr(s, nm + '_col', col.ctypes.data)
-            setattr(s, nm + '_val', val.ctypes.data)
+            setattr(s, nm + '_val', val.ctypes.data if val is not None else None)
         self.struct = s
 
     @property
@@ -301,6 +301,14 @@ class DeviceR1cs:
             raise FkError(rc, 'fk_r1cs_info')
         v = list(out)
         return dict(rows=v[0], nnz=(v[1], v[2], v[3]), distinct_coefficients=v[4], n_a=v[5], n_b=v[6])
+
+    def density_ptrs(self):
+        """device pointers (a_aux, b_input, b_aux) of the structural density maps"""
+        out = (C.c_void_p * 3)()
+        rc = self.ctx.lib.fk_r1cs_density_ptrs(self.handle, out)
+        if rc != 0:
+            raise FkError(rc, 'fk_r1cs_density_ptrs')
+        return tuple(int(x or 0) for x in out)
 
     def free(self):
         if self.handle:
@@ -517,18 +525,19 @@ class Context:
                                        C.c_void_p(d_b_aux), _vp(_fr(r, 1)), _vp(_fr(s, 1)), _vp(out), C.byref(tm)))
         return (out, tm.as_dict()) if want_timings else out
 
-    def setup(self, r1cs, tau, alpha, beta, gamma, delta):
+    def setup(self, r1cs, tau, alpha, beta, gamma, delta, shard_index=0, shard_count=1, z_frac=(0.0, 0.0)):
         """fk_setup: GPU key generation with explicit toxic waste (Montgomery limbs).  Returns (DeviceKey, vk dict)
         with vk = alpha_g1, beta_g1, beta_g2, gamma_g2, delta_g1, delta_g2 (raw LE uint8 arrays) and ic (num_input, 64)."""
         h = C.c_void_p()
         vk = np.zeros(6 * 128, np.uint8)
         ic = np.zeros((r1cs.num_input, 64), np.uint8)
         self._ck(self.lib.fk_setup(self.handle, C.byref(r1cs.struct), _vp(_fr(tau, 1)), _vp(_fr(alpha, 1)), _vp(_fr(beta, 1)),
-                                   _vp(_fr(gamma, 1)), _vp(_fr(delta, 1)), C.byref(h), _vp(vk), _vp(ic)))
+                                   _vp(_fr(gamma, 1)), _vp(_fr(delta, 1)), C.c_uint32(shard_index), C.c_uint32(shard_count),
+                                   C.c_double(z_frac[0]), C.c_double(z_frac[1]), C.byref(h), _vp(vk), _vp(ic)))
         names = (('alpha_g1', 64), ('beta_g1', 64), ('beta_g2', 128), ('gamma_g2', 128), ('delta_g1', 64), ('delta_g2', 128))
         out = {n: vk[i * 128:i * 128 + w].copy() for i, (n, w) in enumerate(names)}
         out['ic'] = ic
-        return DeviceKey(self, h), out
+        return DeviceKey(self, h, shard_index, shard_count), out
 
     # ---- device-resident constraint system: only the witness crosses the boundary
     def load_r1cs(self, r1cs):

@@ -582,9 +582,11 @@ static inline void eval_lc(Fr *out, const uint64_t *ptr, const uint32_t *col, co
     for (uint64_t k = ptr[row]; k < ptr[row + 1]; k++) {
         const uint32_t v = col[k];
         if (v < num_input) { if (din) din[v] = 1; } else { if (daux) daux[v - num_input] = 1; }
-        Fr cf; memcpy(&cf, val + 4 * k, 32);
         Fr t = z[v];
-        if (cf != one) t = Fr::mul(t, cf);
+        if (val) {                              // NULL: every coefficient of this matrix is ONE
+            Fr cf; memcpy(&cf, val + 4 * k, 32);
+            if (cf != one) t = Fr::mul(t, cf);
+        }
         acc = Fr::add(acc, t);
     }
     *out = acc;

@@ -180,10 +180,13 @@ struct DevFree { std::vector<void *> v; ~DevFree() { for (void *p : v) if (p) (v
 extern "C" {
 
 int fk_setup(fk_ctx *ctx, const fk_r1cs *cs, const uint64_t tau_[4], const uint64_t alpha_[4], const uint64_t beta_[4],
-             const uint64_t gamma_[4], const uint64_t delta_[4], fk_key **out_key, uint8_t vk_out[6 * 128], uint8_t *ic_out) {
+             const uint64_t gamma_[4], const uint64_t delta_[4], uint32_t shard_index, uint32_t shard_count, double z_frac_lo, double z_frac_hi,
+             fk_key **out_key, uint8_t vk_out[6 * 128], uint8_t *ic_out) {
     if (!ctx) return FK_ERR_BAD_ARG;
     if (!cs || !tau_ || !alpha_ || !beta_ || !gamma_ || !delta_ || !out_key || !vk_out || !ic_out) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "setup: null argument");
     *out_key = nullptr;
+    if (shard_count == 0 || shard_index >= shard_count) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "setup: bad shard %u/%u", shard_index, shard_count);
+    if (!(z_frac_lo >= 0.0 && z_frac_hi <= 1.0 && z_frac_lo <= z_frac_hi)) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "setup: bad z fraction range");
     FK_HIP(ctx, hipSetDevice(ctx->device));
     const Fr tau = fr_load(tau_), alpha = fr_load(alpha_), beta = fr_load(beta_), gamma = fr_load(gamma_), delta = fr_load(delta_);
     if (gamma.is_zero() || delta.is_zero()) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "setup: gamma and delta must be non-zero");
@@ -211,6 +214,7 @@ int fk_setup(fk_ctx *ctx, const fk_r1cs *cs, const uint64_t tau_[4], const uint6
     table.push_back(one); dict.emplace(std::string((const char *)&one, 32), 0u);
     CscArgs ca;
     Fr *d_abc[3];
+    Fr last = one; uint32_t last_idx = 0;
     for (int k = 0; k < 3; k++) {
         const uint64_t nnz = ptrs[k][cs->num_gates];
         std::vector<uint64_t> cptr(nv + 1, 0);
@@ -220,11 +224,18 @@ int fk_setup(fk_ctx *ctx, const fk_r1cs *cs, const uint64_t tau_[4], const uint6
         std::vector<uint64_t> cur(cptr.begin(), cptr.end() - 1);
         for (uint64_t g = 0; g < cs->num_gates; g++)
             for (uint64_t i = ptrs[k][g]; i < ptrs[k][g + 1]; i++) {
-                std::string key((const char *)(vals[k] + 4 * i), 32);
-                auto it = dict.find(key);
-                if (it == dict.end()) { Fr v; memcpy(&v, vals[k] + 4 * i, 32); it = dict.emplace(key, (uint32_t)table.size()).first; table.push_back(v); }
+                uint32_t ci = 0;
+                if (vals[k] && memcmp(vals[k] + 4 * i, &one, 32) != 0) {       // NULL vals / ONE -> slot 0
+                    if (memcmp(vals[k] + 4 * i, &last, 32) == 0) ci = last_idx;
+                    else {
+                        std::string key((const char *)(vals[k] + 4 * i), 32);
+                        auto it = dict.find(key);
+                        if (it == dict.end()) { Fr v; memcpy(&v, vals[k] + 4 * i, 32); it = dict.emplace(key, (uint32_t)table.size()).first; table.push_back(v); }
+                        ci = it->second; memcpy(&last, vals[k] + 4 * i, 32); last_idx = ci;
+                    }
+                }
                 const uint64_t pos = cur[cols[k][i]]++;
-                crow[pos] = (uint32_t)g; cidx[pos] = it->second;
+                crow[pos] = (uint32_t)g; cidx[pos] = ci;
             }
         uint64_t *dp = (uint64_t *)dalloc((nv + 1) * 8); uint32_t *dr = (uint32_t *)dalloc((nnz + 1) * 4), *di = (uint32_t *)dalloc((nnz + 1) * 4);
         d_abc[k] = (Fr *)dalloc(nv * sizeof(Fr));
@@ -313,6 +324,29 @@ int fk_setup(fk_ctx *ctx, const fk_r1cs *cs, const uint64_t tau_[4], const uint6
     memcpy(vk_out + 0 * 128, &k->alpha_g1, 64); memcpy(vk_out + 1 * 128, &k->beta_g1, 64); memcpy(vk_out + 2 * 128, &k->beta_g2, 128);
     memcpy(vk_out + 3 * 128, &gamma_g2, 128); memcpy(vk_out + 4 * 128, &k->delta_g1, 64); memcpy(vk_out + 5 * 128, &k->delta_g2, 128);
     if (hipStreamSynchronize(st) != hipSuccess) return fail(FK_ERR_HIP, "setup: synchronize failed");
+    // multi-GPU: keep only this rank's slices (every rank derives the same key deterministically)
+    if (shard_count > 1 || z_frac_lo != 0.0 || z_frac_hi != 0.0) {
+        k->shard_index = shard_index; k->shard_count = shard_count;
+        auto sl = [](uint64_t n, uint32_t i, uint32_t c, uint64_t *lo, uint64_t *hi) { *lo = (uint64_t)((unsigned __int128)n * i / c); *hi = (uint64_t)((unsigned __int128)n * (i + 1) / c); };
+        auto fr = [](uint64_t n, double lo, double hi, uint64_t *olo, uint64_t *ohi) {
+            uint64_t a = (uint64_t)((long double)n * lo + 0.5L), b = hi >= 1.0 ? n : (uint64_t)((long double)n * hi + 0.5L);
+            if (a > n) a = n; if (b > n) b = n; if (b < a) b = a; *olo = a; *ohi = b; };
+        sl(k->n_h, shard_index, shard_count, &k->h_lo, &k->h_hi);
+        if (z_frac_lo == 0.0 && z_frac_hi == 0.0) { sl(k->n_l, shard_index, shard_count, &k->l_lo, &k->l_hi); sl(k->n_a, shard_index, shard_count, &k->a_lo, &k->a_hi); sl(k->n_b, shard_index, shard_count, &k->b_lo, &k->b_hi); }
+        else { fr(k->n_l, z_frac_lo, z_frac_hi, &k->l_lo, &k->l_hi); fr(k->n_a, z_frac_lo, z_frac_hi, &k->a_lo, &k->a_hi); fr(k->n_b, z_frac_lo, z_frac_hi, &k->b_lo, &k->b_hi); }
+        auto shrink = [&](void **p, uint64_t lo, uint64_t hi, size_t w) -> int {
+            void *q = nullptr;
+            if (hipMalloc(&q, (hi - lo) * w + w) != hipSuccess) return FK_ERR_OOM;
+            if (hi > lo && hipMemcpy(q, (char *)*p + lo * w, (hi - lo) * w, hipMemcpyDeviceToDevice) != hipSuccess) { (void)hipFree(q); return FK_ERR_HIP; }
+            (void)hipFree(*p); *p = q; return FK_OK;
+        };
+        int rc2 = shrink((void **)&k->d_h, k->h_lo, k->h_hi, 64);
+        if (rc2 == FK_OK) rc2 = shrink((void **)&k->d_l, k->l_lo, k->l_hi, 64);
+        if (rc2 == FK_OK) rc2 = shrink((void **)&k->d_a, k->a_lo, k->a_hi, 64);
+        if (rc2 == FK_OK) rc2 = shrink((void **)&k->d_b1, k->b_lo, k->b_hi, 64);
+        if (rc2 == FK_OK) rc2 = shrink((void **)&k->d_b2, k->b_lo, k->b_hi, 128);
+        if (rc2 != FK_OK) return fail(rc2, "setup: resharding failed");
+    }
     *out_key = k;
     return FK_OK;
 }

@@ -88,7 +88,7 @@ int fk_r1cs_load(fk_ctx *ctx, const fk_r1cs *cs, fk_r1cs_dev **out) {
         if (ptrs[k][0] != 0) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "r1cs: row_ptr[0] must be 0");
         for (uint64_t g = 0; g < cs->num_gates; g++) if (ptrs[k][g + 1] < ptrs[k][g]) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "r1cs: row_ptr not monotone");
         const uint64_t nnz = ptrs[k][cs->num_gates];
-        if (nnz && (!cols[k] || !vals[k])) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "r1cs: null column/value array");
+        if (nnz && !cols[k]) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "r1cs: null column array");   // vals[k] == NULL: all coefficients ONE
         for (uint64_t i = 0; i < nnz; i++) if (cols[k][i] >= nv) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "r1cs: variable index %u out of range", cols[k][i]);
     }
     fk_r1cs_dev *r = new fk_r1cs_dev();
@@ -106,16 +106,24 @@ int fk_r1cs_load(fk_ctx *ctx, const fk_r1cs *cs, fk_r1cs_dev **out) {
         const uint64_t nnz = ptrs[k][cs->num_gates];
         r->nnz[k] = nnz;
         std::vector<uint32_t> cidx(nnz ? nnz : 1);
+        Fr last = one; uint32_t last_idx = 0;        // one-entry cache in front of the hash map
         for (uint64_t i = 0; i < nnz; i++) {
-            std::string key((const char *)(vals[k] + 4 * i), 32);
-            auto it = dict.find(key);
-            if (it == dict.end()) {
-                if (table.size() >= 0xffffffffull) { ctx->err = "r1cs: too many distinct coefficients"; return fail(FK_ERR_BAD_ARG); }
-                Fr v; memcpy(&v, vals[k] + 4 * i, 32);
-                it = dict.emplace(key, (uint32_t)table.size()).first;
-                table.push_back(v);
+            uint32_t ci = 0;
+            if (vals[k] && memcmp(vals[k] + 4 * i, &one, 32) != 0) {
+                if (memcmp(vals[k] + 4 * i, &last, 32) == 0) ci = last_idx;
+                else {
+                    std::string key((const char *)(vals[k] + 4 * i), 32);
+                    auto it = dict.find(key);
+                    if (it == dict.end()) {
+                        if (table.size() >= 0xffffffffull) { ctx->err = "r1cs: too many distinct coefficients"; return fail(FK_ERR_BAD_ARG); }
+                        Fr v; memcpy(&v, vals[k] + 4 * i, 32);
+                        it = dict.emplace(key, (uint32_t)table.size()).first;
+                        table.push_back(v);
+                    }
+                    ci = it->second; memcpy(&last, vals[k] + 4 * i, 32); last_idx = ci;
+                }
             }
-            cidx[i] = it->second;
+            cidx[i] = ci;
             const uint32_t v = cols[k][i];
             if (k == 0) { if (v >= cs->num_input) a_aux[v - cs->num_input] = 1; }
             else if (k == 1) { if (v < cs->num_input) b_in[v] = 1; else b_aux[v - cs->num_input] = 1; }
@@ -139,6 +147,12 @@ int fk_r1cs_load(fk_ctx *ctx, const fk_r1cs *cs, fk_r1cs_dev **out) {
     for (uint32_t j = 0; j < cs->num_aux; j++) { r->n_a_aux += a_aux[j]; r->n_b_aux += b_aux[j]; }
     for (uint32_t i = 0; i < cs->num_input; i++) r->n_b_in += b_in[i];
     *out = r;
+    return FK_OK;
+}
+
+int fk_r1cs_density_ptrs(const fk_r1cs_dev *r, const void *out[3]) {
+    if (!r || !out) return FK_ERR_BAD_ARG;
+    out[0] = r->d_a_aux; out[1] = r->d_b_in; out[2] = r->d_b_aux;
     return FK_OK;
 }
 

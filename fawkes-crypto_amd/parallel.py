@@ -121,12 +121,15 @@ def prove_balanced(rank, world, quotient_fn, z_fn, h_fn, assemble_fn, h_ranges, 
 
 
 def prove_balanced_dev(ctx, key, rank, world, d_a, d_b, d_c, n, d_z, d_a_aux, d_b_in, d_b_aux, r, s, h_ranges, h_full_buf, recv_buf,
-                       group=None, device=None):
+                       group=None, device=None, eval_fn=None):
     """GPU backend of `prove_balanced`.  h_full_buf: uint8 torch tensor of m*32 bytes on rank 0 (the quotient is
-    written there); recv_buf: uint8 torch tensor for this rank's h slice (ranks > 0)."""
+    written there); recv_buf: uint8 torch tensor for this rank's h slice (ranks > 0).  eval_fn (rank 0): produces
+    a, b, c in d_a, d_b, d_c first (e.g. the device SpMV of a resident constraint system)."""
     import torch
 
     def quotient_fn():
+        if eval_fn is not None:
+            eval_fn()
         ctx.quotient_h_dev(d_a, d_b, d_c, n, h_full_buf.data_ptr())
         return h_full_buf
 

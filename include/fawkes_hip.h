@@ -183,7 +183,7 @@ int fk_gen_scalars_dev(fk_ctx *ctx, void *d_out, size_t n, uint64_t seed, int ki
 typedef struct {
     uint32_t num_input, num_aux;
     uint64_t num_gates;
-    const uint64_t *a_ptr; const uint32_t *a_col; const uint64_t *a_val;   /* ptr[num_gates+1], col/val[nnz] */
+    const uint64_t *a_ptr; const uint32_t *a_col; const uint64_t *a_val;   /* ptr[num_gates+1], col/val[nnz]; val == NULL: all ONE */
     const uint64_t *b_ptr; const uint32_t *b_col; const uint64_t *b_val;
     const uint64_t *c_ptr; const uint32_t *c_col; const uint64_t *c_val;
 } fk_r1cs;
@@ -202,6 +202,8 @@ int fk_r1cs_load(fk_ctx *ctx, const fk_r1cs *cs, fk_r1cs_dev **out);
 void fk_r1cs_free(fk_ctx *ctx, fk_r1cs_dev *r1cs);
 /* out[8] = rows, nnz(A), nnz(B), nnz(C), distinct coefficients, points the a query needs, points the b query needs, 0 */
 int fk_r1cs_info(const fk_r1cs_dev *r1cs, uint64_t out[8]);
+/* device pointers of the structural density maps: a_aux[num_aux], b_input[num_input], b_aux[num_aux] */
+int fk_r1cs_density_ptrs(const fk_r1cs_dev *r1cs, const void *out[3]);
 /* a, b, c <- A z, B z, C z on the device (arrays sized for next_pow2(rows) elements, `rows` written) */
 int fk_r1cs_eval_dev(fk_ctx *ctx, const fk_r1cs_dev *r1cs, const void *d_z, void *d_a, void *d_b, void *d_c);
 int fk_prove_r1cs(fk_ctx *ctx, const fk_key *key, const fk_r1cs_dev *r1cs, const uint64_t *z,
@@ -212,11 +214,12 @@ int fk_prove_r1cs_dev(fk_ctx *ctx, const fk_key *key, const fk_r1cs_dev *r1cs, c
 /* ---------------------------------------------------------------- key generation on the GPU
  * (SURVEY section 8f row 4): bellman's generate_parameters (reached from setup.rs:20) for EXPLICIT toxic
  * waste tau, alpha, beta, gamma, delta (Montgomery Fr) and the standard BN254 generators.  Produces a
- * resident, unsharded proving key.  vk_out: six 128-byte slots alpha_g1, beta_g1, beta_g2, gamma_g2, delta_g1,
+ * resident proving key (the full key is derived, then only the requested shard is kept; 0,1,0,0 = whole key).  vk_out: six 128-byte slots alpha_g1, beta_g1, beta_g2, gamma_g2, delta_g1,
  * delta_g2 (G1 points use the first 64 bytes); ic_out: num_input x 64 bytes.  For tests and benchmarks:
  * a real deployment runs an MPC ceremony, never a setup with known toxic waste. */
 int fk_setup(fk_ctx *ctx, const fk_r1cs *cs, const uint64_t tau[4], const uint64_t alpha[4], const uint64_t beta[4],
-             const uint64_t gamma[4], const uint64_t delta[4], fk_key **out_key, uint8_t vk_out[6 * 128], uint8_t *ic_out);
+             const uint64_t gamma[4], const uint64_t delta[4], uint32_t shard_index, uint32_t shard_count,
+             double z_frac_lo, double z_frac_hi, fk_key **out_key, uint8_t vk_out[6 * 128], uint8_t *ic_out);
 /* copies this key's slice of one array to the host; which: 0 = h, 1 = l, 2 = a, 3 = b_g1, 4 = b_g2 */
 int fk_key_download(fk_ctx *ctx, const fk_key *key, int which, void *host, size_t host_bytes);
 
