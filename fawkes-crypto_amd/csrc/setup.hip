@@ -31,13 +31,17 @@ __global__ void scale_kernel(const Fr *in, Fr c, size_t n, Fr *out) {
 }
 
 // out[v] = sum over the column's entries  table[cidx] * lag[row]   (+ lag[num_gates + v] for inputs in matrix 0)
+static constexpr uint64_t CSC_HEAVY = 4096;      // columns with more entries go through csc_heavy_kernel
+static constexpr uint64_t CSC_SEG = 16384;       // entries per workgroup there
 struct CscArgs { const uint64_t *ptr[3]; const uint32_t *row[3]; const uint32_t *cidx[3]; Fr *out[3]; };
 __global__ __launch_bounds__(256) void csc_eval_kernel(CscArgs a, const Fr *table, const Fr *lag, uint64_t num_gates, uint32_t num_input, uint64_t nv) {
     const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t mtx = blockIdx.y;
     if (v >= nv) return;
     Fr acc = Fr::zero();
-    for (uint64_t k = a.ptr[mtx][v], e = a.ptr[mtx][v + 1]; k < e; k++) {
+    uint64_t k0 = a.ptr[mtx][v], k1 = a.ptr[mtx][v + 1];
+    if (k1 - k0 > CSC_HEAVY) k1 = k0;            // heavy column (e.g. the constant ONE): summed by csc_heavy_kernel
+    for (uint64_t k = k0, e = k1; k < e; k++) {
         Fr t = lag[a.row[mtx][k]];
         const uint32_t ci = a.cidx[mtx][k];
         if (ci) t = Fr::mul(t, table[ci]);
@@ -45,6 +49,27 @@ __global__ __launch_bounds__(256) void csc_eval_kernel(CscArgs a, const Fr *tabl
     }
     if (mtx == 0 && v < num_input) acc = Fr::add(acc, lag[num_gates + v]);
     a.out[mtx][v] = acc;
+}
+
+// one workgroup per CSC_SEG-entry segment of a heavy column: partial[seg] = sum table[cidx] * lag[row]
+struct HeavySeg { uint32_t mtx; uint32_t pad; uint64_t lo, hi; };
+__global__ __launch_bounds__(256) void csc_heavy_kernel(CscArgs a, const Fr *table, const Fr *lag, const HeavySeg *segs, Fr *partial) {
+    __shared__ Fr sh[256];
+    const HeavySeg sg = segs[blockIdx.x];
+    Fr acc = Fr::zero();
+    for (uint64_t k = sg.lo + threadIdx.x; k < sg.hi; k += 256) {
+        Fr t = lag[a.row[sg.mtx][k]];
+        const uint32_t ci = a.cidx[sg.mtx][k];
+        if (ci) t = Fr::mul(t, table[ci]);
+        acc = Fr::add(acc, t);
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (uint32_t off = 128; off; off >>= 1) {
+        if (threadIdx.x < off) sh[threadIdx.x] = Fr::add(sh[threadIdx.x], sh[threadIdx.x + off]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
 }
 
 // e[v] = (beta A_v + alpha B_v + C_v) * (v < num_input ? 1/gamma : 1/delta); flags: A_v != 0, B_v != 0
@@ -215,6 +240,7 @@ int fk_setup(fk_ctx *ctx, const fk_r1cs *cs, const uint64_t tau_[4], const uint6
     CscArgs ca;
     Fr *d_abc[3];
     Fr last = one; uint32_t last_idx = 0;
+    std::vector<HeavySeg> heavy_segs; std::vector<uint64_t> heavy_var;
     for (int k = 0; k < 3; k++) {
         const uint64_t nnz = ptrs[k][cs->num_gates];
         std::vector<uint64_t> cptr(nv + 1, 0);
@@ -243,6 +269,13 @@ int fk_setup(fk_ctx *ctx, const fk_r1cs *cs, const uint64_t tau_[4], const uint6
         FK_HIP(ctx, hipMemcpy(dp, cptr.data(), (nv + 1) * 8, hipMemcpyHostToDevice));
         if (nnz) { FK_HIP(ctx, hipMemcpy(dr, crow.data(), nnz * 4, hipMemcpyHostToDevice)); FK_HIP(ctx, hipMemcpy(di, cidx.data(), nnz * 4, hipMemcpyHostToDevice)); }
         ca.ptr[k] = dp; ca.row[k] = dr; ca.cidx[k] = di; ca.out[k] = d_abc[k];
+        for (uint64_t v = 0; v < nv; v++)
+            if (cptr[v + 1] - cptr[v] > CSC_HEAVY) {
+                for (uint64_t lo_ = cptr[v]; lo_ < cptr[v + 1]; lo_ += CSC_SEG) {
+                    heavy_segs.push_back(HeavySeg{(uint32_t)k, 0, lo_, lo_ + CSC_SEG < cptr[v + 1] ? lo_ + CSC_SEG : cptr[v + 1]});
+                    heavy_var.push_back(v);
+                }
+            }
     }
     Fr *d_table = (Fr *)dalloc(table.size() * sizeof(Fr));
     if (!d_table) FK_SET_ERR(ctx, FK_ERR_OOM, "setup: device allocation failed");
@@ -269,6 +302,26 @@ int fk_setup(fk_ctx *ctx, const fk_r1cs *cs, const uint64_t tau_[4], const uint6
 
     // ---- A_k, B_k, C_k and the combined exponent
     hipLaunchKernelGGL(csc_eval_kernel, dim3((unsigned)((nv + 255) / 256), 3), dim3(256), 0, st, ca, d_table, d_pt, cs->num_gates, cs->num_input, nv);
+    if (!heavy_segs.empty()) {      // heavy columns: segment partial sums on the device, folded on the host (a handful of values)
+        HeavySeg *d_segs = (HeavySeg *)dalloc(heavy_segs.size() * sizeof(HeavySeg));
+        Fr *d_part = (Fr *)dalloc(heavy_segs.size() * sizeof(Fr));
+        if (!d_segs || !d_part) FK_SET_ERR(ctx, FK_ERR_OOM, "setup: device allocation failed");
+        FK_HIP(ctx, hipMemcpyAsync(d_segs, heavy_segs.data(), heavy_segs.size() * sizeof(HeavySeg), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(csc_heavy_kernel, dim3((unsigned)heavy_segs.size()), dim3(256), 0, st, ca, d_table, d_pt, d_segs, d_part);
+        FK_HIP(ctx, hipGetLastError());
+        std::vector<Fr> part(heavy_segs.size());
+        FK_HIP(ctx, hipMemcpyAsync(part.data(), d_part, part.size() * sizeof(Fr), hipMemcpyDeviceToHost, st));
+        FK_HIP(ctx, hipStreamSynchronize(st));
+        for (size_t i = 0; i < heavy_segs.size();) {
+            const uint32_t mtx = heavy_segs[i].mtx; const uint64_t v = heavy_var[i];
+            Fr sum = Fr::zero();
+            for (; i < heavy_segs.size() && heavy_segs[i].mtx == mtx && heavy_var[i] == v; i++) sum = Fr::add(sum, part[i]);
+            Fr cur;                                      // csc_eval_kernel left the light part (input row term) there
+            FK_HIP(ctx, hipMemcpy(&cur, d_abc[mtx] + v, sizeof(Fr), hipMemcpyDeviceToHost));
+            cur = Fr::add(cur, sum);
+            FK_HIP(ctx, hipMemcpy(d_abc[mtx] + v, &cur, sizeof(Fr), hipMemcpyHostToDevice));
+        }
+    }
     Fr *d_e = (Fr *)dalloc(nv * sizeof(Fr));
     uint8_t *d_fa = (uint8_t *)dalloc(nv), *d_fb = (uint8_t *)dalloc(nv);
     if (!d_e || !d_fa || !d_fb) FK_SET_ERR(ctx, FK_ERR_OOM, "setup: device allocation failed");

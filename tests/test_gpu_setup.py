@@ -36,6 +36,26 @@ def test_setup_vs_oracle(ctx, oracle, shape):
     assert ctx.prove_raw(dk, a, b, c, z, aa, bi, ba, r, s).tobytes() == oracle.prove(want, a, b, c, z, aa, bi, ba, r, s).tobytes()
 
 
+def test_setup_heavy_column_vs_oracle(ctx, oracle):
+    """The constant ONE occurs in thousands of B-side LCs (boolean constraints b*(b-1)=0): the transposed sparse
+    product takes the segmented heavy-column path; result must still equal the oracle's key."""
+    import c_oracle as co
+    nin, nbits = 2, 9000
+    one, minus_one = fx.mont_fr(1), fx.mont_fr(-1)
+    seq = np.arange(nbits + 1, dtype=np.uint64)
+    a = co.Csr(seq, (nin + np.arange(nbits)).astype(np.uint32), np.tile(one, (nbits, 1)))
+    b_col = np.zeros(2 * nbits, np.uint32); b_col[0::2] = nin + np.arange(nbits); b_col[1::2] = 0
+    b_val = np.tile(one, (2 * nbits, 1)); b_val[1::2] = minus_one
+    b = co.Csr(2 * seq, b_col, b_val)
+    c = co.Csr(np.zeros(nbits + 1, np.uint64), np.zeros(0, np.uint32), np.zeros((0, 4), np.uint64))
+    csr = co.R1csC(nin, nbits, a, b, c)
+    want = oracle.setup(csr, **TOXIC)
+    dk, vk = ctx.setup(r1cs_product(csr), **_toxic_mont())
+    for name in ('h', 'l', 'a', 'b_g1', 'b_g2'):
+        assert dk.download(name).tobytes() == np.array(getattr(want, name)).tobytes(), name
+    assert vk['ic'].tobytes() == np.array(want.ic).tobytes()
+
+
 def _vk_to_py(vk, nin):
     g1 = lambda b: ref.g1_from_raw_le(bytes(b))
     g2 = lambda b: ref.g2_from_raw_le(bytes(b))
