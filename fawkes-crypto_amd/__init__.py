@@ -15,3 +15,4 @@ from .api import (  # noqa: F401
     FK_MSM_RESULT_BYTES, FK_PROOF_BYTES, EXPORTED_SYMBOLS, build_library,
 )
 from . import parallel  # noqa: F401
+from . import params_io  # noqa: F401

@@ -32,7 +32,7 @@ EXPORTED_SYMBOLS = [
     'fk_msm_g1', 'fk_msm_g2', 'fk_msm_g1_dev', 'fk_msm_g2_dev',
     'fk_gen_points_g1_dev', 'fk_gen_points_g2_dev', 'fk_gen_scalars_dev',
     'fk_synthesize', 'fk_stats_reset', 'fk_stats_get', 'fk_shard_range',
-    'fk_setup', 'fk_key_download',
+    'fk_setup', 'fk_key_download', 'fk_key_load_bellman', 'fk_key_vk', 'fk_key_counts',
     'fk_r1cs_load', 'fk_r1cs_free', 'fk_r1cs_info', 'fk_r1cs_density_ptrs', 'fk_r1cs_eval_dev', 'fk_prove_r1cs', 'fk_prove_r1cs_dev',
 ]
 
@@ -271,6 +271,23 @@ class DeviceKey:
         buf = out if out.size else np.zeros((1, w), np.uint8)
         self.ctx._ck(self.ctx.lib.fk_key_download(self.ctx.handle, self.handle, C.c_int(which), C.c_void_p(buf.ctypes.data), C.c_size_t(buf.nbytes)))
         return out
+
+    def counts(self):
+        out = (C.c_uint64 * 8)()
+        rc = self.ctx.lib.fk_key_counts(self.handle, out)
+        if rc != 0:
+            raise FkError(rc, 'fk_key_counts')
+        v = list(out)
+        return dict(m=v[0], num_input=v[1], num_aux=v[2], n_h=v[3], n_l=v[4], n_a=v[5], n_b=v[6], shard_count=v[7])
+
+    def vk(self):
+        """prover-side vk points as raw Montgomery LE uint8 arrays"""
+        buf = np.zeros(3 * 64 + 2 * 128, np.uint8)
+        rc = self.ctx.lib.fk_key_vk(self.handle, C.c_void_p(buf.ctypes.data))
+        if rc != 0:
+            raise FkError(rc, 'fk_key_vk')
+        return dict(alpha_g1=buf[0:64].copy(), beta_g1=buf[64:128].copy(), delta_g1=buf[128:192].copy(),
+                    beta_g2=buf[192:320].copy(), delta_g2=buf[320:448].copy())
 
     def shard_info(self):
         """dict of the [lo, hi) slices this key holds: h, l, a, b"""
@@ -524,6 +541,19 @@ class Context:
                                        C.c_uint64(n), C.c_void_p(d_z), C.c_void_p(d_a_aux), C.c_void_p(d_b_in),
                                        C.c_void_p(d_b_aux), _vp(_fr(r, 1)), _vp(_fr(s, 1)), _vp(out), C.byref(tm)))
         return (out, tm.as_dict()) if want_timings else out
+
+    def load_key_bellman(self, data, shard_index=0, shard_count=1, z_frac=(0.0, 0.0)):
+        """fk_key_load_bellman: `data` = bytes of bellman's Parameters::write.  Returns (DeviceKey, gamma_g2, ic)."""
+        buf = np.frombuffer(bytes(data), np.uint8)
+        h = C.c_void_p()
+        gamma = np.zeros(128, np.uint8)
+        n_ic = C.c_uint32()
+        cap = 1 << 16
+        ic = np.zeros((cap, 64), np.uint8)
+        self._ck(self.lib.fk_key_load_bellman(self.handle, _vp(buf), C.c_size_t(buf.size), C.c_uint32(shard_index), C.c_uint32(shard_count),
+                                              C.c_double(z_frac[0]), C.c_double(z_frac[1]), C.byref(h), _vp(gamma), _vp(ic), C.c_uint32(cap),
+                                              C.byref(n_ic)))
+        return DeviceKey(self, h, shard_index, shard_count), gamma, ic[:min(n_ic.value, cap)].copy()
 
     def setup(self, r1cs, tau, alpha, beta, gamma, delta, shard_index=0, shard_count=1, z_frac=(0.0, 0.0)):
         """fk_setup: GPU key generation with explicit toxic waste (Montgomery limbs).  Returns (DeviceKey, vk dict)

@@ -1,0 +1,180 @@
+// Loading a bellman-serialised proving key straight into the device layout.
+//
+// fawkes' `Parameters::write` (/root/reference/fawkes-crypto/src/backend/bellman_groth16/mod.rs:150-157) emits
+// its own header (num_gates, brotli gate blob, const_tracker bit vector -- parsed on the host side, see
+// fawkes-crypto_amd/params_io.py) followed by bellman's `Parameters::write`.  That second part lives in the
+// un-vendored crate fawkes-crypto-bellman_ce 0.3.5 / pairing_ce 0.18.1, so its layout is restated from the
+// upstream sources and could NOT be checked against a file written by the reference:
+//   vk:  alpha_g1, beta_g1 (G1), beta_g2, gamma_g2 (G2), delta_g1 (G1), delta_g2 (G2), u32 BE count, ic[] (G1)
+//   then h, l, a, b_g1 (G1) and b_g2 (G2), each: u32 BE count + points
+//   G1 uncompressed = x || y, 32-byte BIG-endian canonical integers; G2 uncompressed = x.c1 || x.c0 || y.c1 || y.c0;
+//   point at infinity = first byte 0x40, rest zero.
+// The device kernel turns every 32-byte big-endian coordinate into the Montgomery little-endian limbs the
+// kernels use (byte reversal + one Montgomery multiplication by R^2) and reorders G2 to c0 || c1.
+#include "common.hpp"
+#include <string.h>
+
+namespace fk {
+
+static __device__ __forceinline__ Fq be32_to_mont(const uint8_t *p) {
+    Fq v;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint8_t *q = p + 28 - 4 * i;
+        v.v[i] = ((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | (uint32_t)q[3];
+    }
+    return Fq::to_mont(v);
+}
+
+// in: n points of 64 bytes (BE x || y); out: Affine<Fq> raw Montgomery LE, infinity -> zeros
+__global__ void convert_g1_kernel(const uint8_t *in, size_t n, G1Affine *out, uint32_t *bad) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t *p = in + 64 * i;
+    if (p[0] & 0x40) { out[i] = G1Affine::inf(); return; }
+    if (p[0] & 0x80) atomicAdd(bad, 1u);          // compression flag in an uncompressed encoding
+    out[i] = G1Affine{be32_to_mont(p), be32_to_mont(p + 32)};
+}
+__global__ void convert_g2_kernel(const uint8_t *in, size_t n, G2Affine *out, uint32_t *bad) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t *p = in + 128 * i;
+    if (p[0] & 0x40) { out[i] = G2Affine::inf(); return; }
+    if (p[0] & 0x80) atomicAdd(bad, 1u);
+    G2Affine a;
+    a.x.c1 = be32_to_mont(p); a.x.c0 = be32_to_mont(p + 32);
+    a.y.c1 = be32_to_mont(p + 64); a.y.c0 = be32_to_mont(p + 96);
+    out[i] = a;
+}
+
+struct Cursor {
+    const uint8_t *p; size_t left;
+    bool take(size_t n, const uint8_t **out) { if (left < n) return false; *out = p; p += n; left -= n; return true; }
+    bool u32be(uint32_t *v) { const uint8_t *q; if (!take(4, &q)) return false; *v = ((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | q[3]; return true; }
+};
+
+}  // namespace fk
+
+using namespace fk;
+
+extern "C" {
+
+// buf/len: bellman `Parameters::write` bytes.  ic_out (may be NULL): receives up to ic_cap raw 64-byte points;
+// *n_ic gets the count; gamma_g2_out (may be NULL): 128 bytes raw.  shard arguments as in fk_key_desc.
+int fk_key_load_bellman(fk_ctx *ctx, const uint8_t *buf, size_t len, uint32_t shard_index, uint32_t shard_count, double z_frac_lo,
+                        double z_frac_hi, fk_key **out, uint8_t *gamma_g2_out, uint8_t *ic_out, uint32_t ic_cap, uint32_t *n_ic) {
+    if (!ctx) return FK_ERR_BAD_ARG;
+    if (!buf || !out) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "key file: null argument");
+    *out = nullptr;
+    FK_HIP(ctx, hipSetDevice(ctx->device));
+    Cursor c{buf, len};
+    const uint8_t *vkp[6];
+    const size_t vkw[6] = {64, 64, 128, 128, 64, 128};    // alpha_g1, beta_g1, beta_g2, gamma_g2, delta_g1, delta_g2
+    for (int i = 0; i < 6; i++) if (!c.take(vkw[i], &vkp[i])) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "key file: truncated verifying key");
+    uint32_t cnt[6]; const uint8_t *arr[6];
+    const size_t w[6] = {64, 64, 64, 64, 64, 128};        // ic, h, l, a, b_g1, b_g2
+    static const char *nm[6] = {"ic", "h", "l", "a", "b_g1", "b_g2"};
+    for (int i = 0; i < 6; i++) {
+        if (!c.u32be(&cnt[i]) || !c.take((size_t)cnt[i] * w[i], &arr[i])) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "key file: truncated %s array", nm[i]);
+    }
+    if (cnt[0] == 0) FK_SET_ERR(ctx, FK_ERR_KEY_MISMATCH, "key file: empty ic (no constant ONE input)");
+    if (cnt[4] != cnt[5]) FK_SET_ERR(ctx, FK_ERR_KEY_MISMATCH, "key file: b_g1 and b_g2 differ in length");
+    const uint64_t m = (uint64_t)cnt[1] + 1;
+    if (m & (m - 1)) FK_SET_ERR(ctx, FK_ERR_KEY_MISMATCH, "key file: h holds %u points, not 2^k - 1", cnt[1]);
+    if (m > ((uint64_t)1 << (FK_FR_S - 1))) FK_SET_ERR(ctx, FK_ERR_DOMAIN_TOO_LARGE, "key file: domain exceeds 2^%d", FK_FR_S - 1);
+    if (shard_count == 0 || shard_index >= shard_count) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "key file: bad shard %u/%u", shard_index, shard_count);
+    if (!(z_frac_lo >= 0.0 && z_frac_hi <= 1.0 && z_frac_lo <= z_frac_hi)) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "key file: bad z fraction range");
+
+    fk_key *k = new fk_key();
+    k->m = m; k->num_input = cnt[0]; k->num_aux = cnt[2];
+    k->n_h = cnt[1]; k->n_l = cnt[2]; k->n_a = cnt[3]; k->n_b = cnt[4];
+    k->shard_index = shard_index; k->shard_count = shard_count;
+    auto sl = [](uint64_t n, uint32_t i, uint32_t cc, uint64_t *lo, uint64_t *hi) { *lo = (uint64_t)((unsigned __int128)n * i / cc); *hi = (uint64_t)((unsigned __int128)n * (i + 1) / cc); };
+    auto fr = [](uint64_t n, double lo, double hi, uint64_t *olo, uint64_t *ohi) {
+        uint64_t a = (uint64_t)((long double)n * lo + 0.5L), b = hi >= 1.0 ? n : (uint64_t)((long double)n * hi + 0.5L);
+        if (a > n) a = n; if (b > n) b = n; if (b < a) b = a; *olo = a; *ohi = b; };
+    sl(k->n_h, shard_index, shard_count, &k->h_lo, &k->h_hi);
+    if (z_frac_lo == 0.0 && z_frac_hi == 0.0) { sl(k->n_l, shard_index, shard_count, &k->l_lo, &k->l_hi); sl(k->n_a, shard_index, shard_count, &k->a_lo, &k->a_hi); sl(k->n_b, shard_index, shard_count, &k->b_lo, &k->b_hi); }
+    else { fr(k->n_l, z_frac_lo, z_frac_hi, &k->l_lo, &k->l_hi); fr(k->n_a, z_frac_lo, z_frac_hi, &k->a_lo, &k->a_hi); fr(k->n_b, z_frac_lo, z_frac_hi, &k->b_lo, &k->b_hi); }
+    auto fail = [&](int code, const char *msg) { ctx->err = msg; fk_key_free(ctx, k); return code; };
+
+    uint32_t *d_bad = nullptr;
+    if (hipMalloc((void **)&d_bad, 4) != hipSuccess) return fail(FK_ERR_OOM, "key file: device allocation failed");
+    (void)hipMemset(d_bad, 0, 4);
+    // staged conversion: raw big-endian bytes go up in chunks, converted points are written in place
+    const size_t CH = (size_t)1 << 22;   // points per chunk
+    auto conv = [&](const uint8_t *src, uint64_t lo, uint64_t hi, size_t width, void **dst) -> int {
+        const uint64_t n = hi - lo;
+        if (hipMalloc(dst, (n + 1) * width) != hipSuccess) return FK_ERR_OOM;
+        for (uint64_t off = 0; off < n; off += CH) {
+            const size_t cn = (size_t)((n - off) < CH ? (n - off) : CH);
+            if (ctx->misc.reserve(cn * width) != hipSuccess) return FK_ERR_OOM;
+            if (hipMemcpyAsync(ctx->misc.p, src + (lo + off) * width, cn * width, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return FK_ERR_HIP;
+            if (width == 64) hipLaunchKernelGGL(convert_g1_kernel, dim3((unsigned)((cn + 255) / 256)), dim3(256), 0, ctx->stream, ctx->misc.as<uint8_t>(), cn, (G1Affine *)*dst + off, d_bad);
+            else hipLaunchKernelGGL(convert_g2_kernel, dim3((unsigned)((cn + 255) / 256)), dim3(256), 0, ctx->stream, ctx->misc.as<uint8_t>(), cn, (G2Affine *)*dst + off, d_bad);
+            if (hipStreamSynchronize(ctx->stream) != hipSuccess) return FK_ERR_HIP;   // misc is reused by the next chunk
+        }
+        return FK_OK;
+    };
+    int rc = conv(arr[1], k->h_lo, k->h_hi, 64, (void **)&k->d_h);
+    if (rc == FK_OK) rc = conv(arr[2], k->l_lo, k->l_hi, 64, (void **)&k->d_l);
+    if (rc == FK_OK) rc = conv(arr[3], k->a_lo, k->a_hi, 64, (void **)&k->d_a);
+    if (rc == FK_OK) rc = conv(arr[4], k->b_lo, k->b_hi, 64, (void **)&k->d_b1);
+    if (rc == FK_OK) rc = conv(arr[5], k->b_lo, k->b_hi, 128, (void **)&k->d_b2);
+    // vk + ic through the same kernels
+    G1Affine vk1[3]; G2Affine vk2[3];
+    std::vector<G1Affine> ic(cnt[0]);
+    if (rc == FK_OK) {
+        void *d_tmp = nullptr;
+        std::vector<uint8_t> g1buf(3 * 64 + (size_t)cnt[0] * 64), g2buf(3 * 128);
+        memcpy(g1buf.data(), vkp[0], 64); memcpy(g1buf.data() + 64, vkp[1], 64); memcpy(g1buf.data() + 128, vkp[4], 64);
+        memcpy(g1buf.data() + 192, arr[0], (size_t)cnt[0] * 64);
+        memcpy(g2buf.data(), vkp[2], 128); memcpy(g2buf.data() + 128, vkp[3], 128); memcpy(g2buf.data() + 256, vkp[5], 128);
+        const size_t n1 = 3 + cnt[0];
+        if (hipMalloc(&d_tmp, g1buf.size() + n1 * 64 + g2buf.size() + 3 * 128) != hipSuccess) rc = FK_ERR_OOM;
+        else {
+            uint8_t *d_in1 = (uint8_t *)d_tmp; G1Affine *d_o1 = (G1Affine *)(d_in1 + g1buf.size());
+            uint8_t *d_in2 = (uint8_t *)(d_o1 + n1); G2Affine *d_o2 = (G2Affine *)(d_in2 + g2buf.size());
+            std::vector<G1Affine> o1(n1);
+            if (hipMemcpy(d_in1, g1buf.data(), g1buf.size(), hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d_in2, g2buf.data(), g2buf.size(), hipMemcpyHostToDevice) != hipSuccess) rc = FK_ERR_HIP;
+            else {
+                hipLaunchKernelGGL(convert_g1_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, ctx->stream, d_in1, n1, d_o1, d_bad);
+                hipLaunchKernelGGL(convert_g2_kernel, dim3(1), dim3(256), 0, ctx->stream, d_in2, (size_t)3, d_o2, d_bad);
+                if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipMemcpy(o1.data(), d_o1, n1 * 64, hipMemcpyDeviceToHost) != hipSuccess ||
+                    hipMemcpy(vk2, d_o2, 3 * 128, hipMemcpyDeviceToHost) != hipSuccess) rc = FK_ERR_HIP;
+                else { vk1[0] = o1[0]; vk1[1] = o1[1]; vk1[2] = o1[2]; for (uint32_t i = 0; i < cnt[0]; i++) ic[i] = o1[3 + i]; }
+            }
+            (void)hipFree(d_tmp);
+        }
+    }
+    uint32_t bad = 0;
+    if (rc == FK_OK && hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost) != hipSuccess) rc = FK_ERR_HIP;
+    (void)hipFree(d_bad);
+    if (rc != FK_OK) return fail(rc, "key file: conversion failed");
+    if (bad) return fail(FK_ERR_BAD_ARG, "key file: compressed-point flag found in an uncompressed key");
+    k->alpha_g1 = vk1[0]; k->beta_g1 = vk1[1]; k->delta_g1 = vk1[2];
+    k->beta_g2 = vk2[0]; k->delta_g2 = vk2[2];
+    if (gamma_g2_out) memcpy(gamma_g2_out, &vk2[1], 128);
+    if (n_ic) *n_ic = cnt[0];
+    if (ic_out) memcpy(ic_out, ic.data(), (size_t)(cnt[0] < ic_cap ? cnt[0] : ic_cap) * 64);
+    *out = k;
+    return FK_OK;
+}
+
+// vk points of a key as raw Montgomery LE: alpha_g1, beta_g1, delta_g1 (64 B each) then beta_g2, delta_g2 (128 B each)
+int fk_key_vk(const fk_key *key, uint8_t out[3 * 64 + 2 * 128]) {
+    if (!key || !out) return FK_ERR_BAD_ARG;
+    memcpy(out, &key->alpha_g1, 64); memcpy(out + 64, &key->beta_g1, 64); memcpy(out + 128, &key->delta_g1, 64);
+    memcpy(out + 192, &key->beta_g2, 128); memcpy(out + 320, &key->delta_g2, 128);
+    return FK_OK;
+}
+
+// m, num_input, num_aux, n_h, n_l, n_a, n_b, shard_count
+int fk_key_counts(const fk_key *key, uint64_t out[8]) {
+    if (!key || !out) return FK_ERR_BAD_ARG;
+    const uint64_t v[8] = {key->m, key->num_input, key->num_aux, key->n_h, key->n_l, key->n_a, key->n_b, key->shard_count};
+    memcpy(out, v, sizeof v);
+    return FK_OK;
+}
+
+}  // extern "C"

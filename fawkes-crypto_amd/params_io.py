@@ -1,0 +1,207 @@
+"""
+Reading / writing the reference's on-disk `Parameters`.
+
+File layout (fawkes header: /root/reference/fawkes-crypto/src/backend/bellman_groth16/mod.rs:150-175):
+    u32 LE   num_gates                      (Borsh u32, mod.rs:152)
+    u32 LE   blob length, blob bytes        (Borsh Vec<u8>, mod.rs:153): brotli(concat of Borsh gates), setup.rs:26-32
+    u32 LE   const_tracker bit length       (mod.rs:151,154)
+    u32 LE   byte length, bytes             (Borsh Vec<u8> of BitVec::to_bytes(), mod.rs:155; bit i = byte i/8, MSB first)
+    ...      bellman Parameters::write      (mod.rs:156)  -> fk_key_load_bellman (csrc/keyfile.hip), SURVEY Appendix B.2
+Gate stream inside the blob (circuit/r1cs/cs.rs:193-223): per gate three parts, each
+    u32 LE count, then count x ( 32 B canonical LE Fr | u8 tag 0 = Input / 1 = Aux (lc.rs:144-149) | u32 LE index ).
+
+The brotli codec is a third-party dependency that is not in this image: pass `decompress=` / `compress=` callables
+(e.g. `brotli.decompress`) when reading / writing real files; without them the blob is kept as opaque bytes
+and only raw (uncompressed) gate streams written by this module can be decoded.  The bellman part and the bit-vector
+packing are restated from the un-vendored crates and could not be checked against a file written by the reference.
+"""
+import struct
+
+import numpy as np
+
+from . import api
+
+FQ = api.FQ_MODULUS
+FR = api.FR_MODULUS
+_R = 1 << 256
+RAW_MAGIC = b'FKRAWGATES\x00'     # marks a gate blob stored uncompressed by this module (never produced by fawkes)
+
+
+# ------------------------------------------------------------------------------------------ bit vector
+def bits_to_bytes(bits):
+    """bit-vec 0.6 `BitVec::to_bytes`: first bit = high-order bit of byte 0"""
+    out = bytearray((len(bits) + 7) // 8)
+    for i, b in enumerate(bits):
+        if b:
+            out[i >> 3] |= 0x80 >> (i & 7)
+    return bytes(out)
+
+
+def bytes_to_bits(data, nbits):
+    if nbits > len(data) * 8:
+        raise ValueError('inconsistent bitvec length')          # mod.rs:165-167
+    return [bool(data[i >> 3] & (0x80 >> (i & 7))) for i in range(nbits)]
+
+
+# ------------------------------------------------------------------------------------------ gate stream
+def encode_gate_stream(r1cs):
+    """api.R1cs -> bytes in the reference's Borsh gate format (cs.rs:193-213), uncompressed."""
+    out = bytearray()
+    rinv = pow(_R, -1, FR)
+    for g in range(r1cs.num_gates):
+        for ptr, col, val in r1cs.mats:
+            lo, hi = int(ptr[g]), int(ptr[g + 1])
+            out += struct.pack('<I', hi - lo)
+            for k in range(lo, hi):
+                coeff = 1 if val is None else api.limbs_to_int(val[k]) * rinv % FR
+                v = int(col[k])
+                out += coeff.to_bytes(32, 'little')
+                if v < r1cs.num_input:
+                    out += b'\x00' + struct.pack('<I', v)
+                else:
+                    out += b'\x01' + struct.pack('<I', v - r1cs.num_input)
+    return bytes(out)
+
+
+def decode_gate_stream(data, num_gates, num_input, num_aux):
+    """bytes (decompressed blob) -> api.R1cs.  Mirrors GateStreamedIterator (cs.rs:215-223)."""
+    pos = 0
+    mats = [([0], [], []) for _ in range(3)]
+    for _ in range(num_gates):
+        for ptr, col, val in mats:
+            if pos + 4 > len(data):
+                raise ValueError('gate stream truncated')
+            (cnt,) = struct.unpack_from('<I', data, pos)
+            pos += 4
+            if pos + cnt * 37 > len(data):
+                raise ValueError('gate stream truncated')
+            for _k in range(cnt):
+                coeff = int.from_bytes(data[pos:pos + 32], 'little')
+                tag = data[pos + 32]
+                (idx,) = struct.unpack_from('<I', data, pos + 33)
+                pos += 37
+                if tag == 0:
+                    if idx >= num_input:
+                        raise ValueError('input index out of range')
+                    v = idx
+                elif tag == 1:
+                    if idx >= num_aux:
+                        raise ValueError('aux index out of range')
+                    v = num_input + idx
+                else:
+                    raise ValueError('enum elements overflow')        # cs.rs:209
+                if coeff >= FR:
+                    raise ValueError('non-canonical field element')
+                col.append(v)
+                val.append(coeff * _R % FR)
+            ptr.append(len(col))
+    conv = []
+    for ptr, col, val in mats:
+        v = np.frombuffer(b''.join(x.to_bytes(32, 'little') for x in val), np.uint64).reshape(-1, 4).copy() if val else np.zeros((0, 4), np.uint64)
+        conv.append((np.array(ptr, np.uint64), np.array(col, np.uint32), v))
+    return api.R1cs(num_input, num_aux, *conv)
+
+
+# ------------------------------------------------------------------------------------------ bellman part (small keys, tests)
+def _fq_be(x_mont_le):
+    """32 raw Montgomery LE bytes -> 32 canonical big-endian bytes"""
+    return (int.from_bytes(bytes(x_mont_le), 'little') * pow(_R, -1, FQ) % FQ).to_bytes(32, 'big')
+
+
+def g1_uncompressed(raw):
+    raw = bytes(raw)
+    if raw == bytes(64):
+        return b'\x40' + bytes(63)
+    return _fq_be(raw[:32]) + _fq_be(raw[32:])
+
+
+def g2_uncompressed(raw):
+    raw = bytes(raw)
+    if raw == bytes(128):
+        return b'\x40' + bytes(127)
+    x0, x1, y0, y1 = (raw[i * 32:(i + 1) * 32] for i in range(4))
+    return _fq_be(x1) + _fq_be(x0) + _fq_be(y1) + _fq_be(y0)       # c1 before c0
+
+
+def encode_bellman_parameters(k):
+    """k: dict of raw Montgomery-LE arrays (alpha_g1, beta_g1, beta_g2, gamma_g2, delta_g1, delta_g2, ic, h, l, a, b_g1,
+    b_g2) -> bellman `Parameters::write` bytes.  Python big-int conversion: for tests / small keys."""
+    out = bytearray()
+    out += g1_uncompressed(k['alpha_g1']) + g1_uncompressed(k['beta_g1']) + g2_uncompressed(k['beta_g2'])
+    out += g2_uncompressed(k['gamma_g2']) + g1_uncompressed(k['delta_g1']) + g2_uncompressed(k['delta_g2'])
+    for name, enc in (('ic', g1_uncompressed), ('h', g1_uncompressed), ('l', g1_uncompressed), ('a', g1_uncompressed),
+                      ('b_g1', g1_uncompressed), ('b_g2', g2_uncompressed)):
+        arr = np.asarray(k[name], np.uint8)
+        arr = arr.reshape(-1, 128 if name == 'b_g2' else 64)
+        out += struct.pack('>I', arr.shape[0])
+        for row in arr:
+            out += enc(row)
+    return bytes(out)
+
+
+# ------------------------------------------------------------------------------------------ the fawkes wrapper
+def write_parameters(num_gates, gates_blob, const_tracker_bits, bellman_bytes):
+    """mod.rs:150-157"""
+    bv = bits_to_bytes(const_tracker_bits)
+    return (struct.pack('<I', num_gates) + struct.pack('<I', len(gates_blob)) + bytes(gates_blob) +
+            struct.pack('<I', len(const_tracker_bits)) + struct.pack('<I', len(bv)) + bv + bytes(bellman_bytes))
+
+
+def read_parameters(data):
+    """mod.rs:159-175.  Returns dict(num_gates, gates_blob, const_tracker (list of bool), bellman (bytes))."""
+    data = bytes(data)
+    pos = 0
+
+    def u32():
+        nonlocal pos
+        if pos + 4 > len(data):
+            raise ValueError('Parameters file truncated')
+        (v,) = struct.unpack_from('<I', data, pos)
+        pos += 4
+        return v
+
+    def blob():
+        nonlocal pos
+        n = u32()
+        if pos + n > len(data):
+            raise ValueError('Parameters file truncated')
+        b = data[pos:pos + n]
+        pos += n
+        return b
+    num_gates = u32()
+    gates_blob = blob()
+    nbits = u32()
+    bv = blob()
+    return dict(num_gates=num_gates, gates_blob=gates_blob, const_tracker=bytes_to_bits(bv, nbits), bellman=data[pos:])
+
+
+def load_parameters(ctx, data, decompress=None, shard_index=0, shard_count=1, z_frac=(0.0, 0.0)):
+    """File bytes -> (DeviceKey resident in HBM, api.R1cs or None, header dict incl. gamma_g2 / ic for a verifier).
+    The constraint system is decoded when the blob can be decompressed (`decompress=brotli.decompress`) or was
+    written raw by `store_parameters`."""
+    hdr = read_parameters(data)
+    key, gamma_g2, ic = ctx.load_key_bellman(hdr['bellman'], shard_index, shard_count, z_frac)
+    c = key.counts()
+    blob = hdr['gates_blob']
+    stream = None
+    if blob.startswith(RAW_MAGIC):
+        stream = blob[len(RAW_MAGIC):]
+    elif decompress is not None:
+        stream = decompress(blob)
+    else:
+        try:
+            import brotli                      # not in this image; used when present
+            stream = brotli.decompress(blob)
+        except ImportError:
+            stream = None
+    r1cs = decode_gate_stream(stream, hdr['num_gates'], c['num_input'], c['num_aux']) if stream is not None else None
+    hdr.update(gamma_g2=gamma_g2, ic=ic)
+    return key, r1cs, hdr
+
+
+def store_parameters(key_arrays, r1cs, const_tracker_bits=(), compress=None):
+    """Inverse of load_parameters for small keys.  compress=brotli.compress reproduces the reference's blob format
+    (quality 9, lgwin 22: setup.rs:26); without it the gate stream is stored raw behind RAW_MAGIC."""
+    stream = encode_gate_stream(r1cs)
+    blob = compress(stream) if compress is not None else RAW_MAGIC + stream
+    return write_parameters(r1cs.num_gates, blob, list(const_tracker_bits), encode_bellman_parameters(key_arrays))

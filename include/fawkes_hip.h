@@ -223,6 +223,21 @@ int fk_setup(fk_ctx *ctx, const fk_r1cs *cs, const uint64_t tau[4], const uint64
 /* copies this key's slice of one array to the host; which: 0 = h, 1 = l, 2 = a, 3 = b_g1, 4 = b_g2 */
 int fk_key_download(fk_ctx *ctx, const fk_key *key, int which, void *host, size_t host_bytes);
 
+/* ---------------------------------------------------------------- bellman key files
+ * Loads the bellman part of a fawkes `Parameters` file (what `self.0.write(writer)` emits at mod.rs:156, i.e.
+ * bellman_ce's Parameters::write: big-endian uncompressed points, SURVEY Appendix B.2 -- layout restated from
+ * the upstream crate, NOT verifiable against the reference here) into the resident device layout; the
+ * big-endian -> Montgomery conversion runs on the GPU.  gamma_g2_out (128 B, may be NULL) and ic_out (ic_cap x 64 B,
+ * may be NULL) receive the verifier-only parts as raw Montgomery LE.  The fawkes header in front of it
+ * (num_gates, gate blob, const_tracker) is parsed by the host layer (fawkes-crypto_amd/params_io.py). */
+int fk_key_load_bellman(fk_ctx *ctx, const uint8_t *buf, size_t len, uint32_t shard_index, uint32_t shard_count,
+                        double z_frac_lo, double z_frac_hi, fk_key **out, uint8_t *gamma_g2_out, uint8_t *ic_out,
+                        uint32_t ic_cap, uint32_t *n_ic);
+/* alpha_g1, beta_g1, delta_g1 (64 B each) then beta_g2, delta_g2 (128 B each), raw Montgomery LE */
+int fk_key_vk(const fk_key *key, uint8_t out[3 * 64 + 2 * 128]);
+/* out[8] = m, num_input, num_aux, n_h, n_l, n_a, n_b, shard_count */
+int fk_key_counts(const fk_key *key, uint64_t out[8]);
+
 /* Kernel timing measured with HIP events on the library's stream since the last reset, summed over
  * launches.  which: 0 = msm_accumulate_kernel<Fq> (G1 bucket accumulation; units = points per launch),
  * 1 = msm_accumulate_kernel<Fq2> (G2), 2 = ntt_pass_kernel (units = elements per pass). */
