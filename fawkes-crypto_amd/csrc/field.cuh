@@ -130,6 +130,15 @@ struct alignas(16) Fp {
 #include "mont_mul_gfx950.inc"
 #endif
 
+    // r1 = a*b, r2 = c*d.  On the device (inlined flavour) the two products run as two interleaved accumulator
+    // chains in one instruction stream -- twice the ILP per wave, same instruction count.
+    static FK_HD void mul2(const Fp &a, const Fp &b, const Fp &c, const Fp &d, Fp &r1, Fp &r2) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (INL) { mul2_body_asm(a, b, c, d, r1, r2); return; }
+#endif
+        r1 = mul(a, b); r2 = mul(c, d);
+    }
+
     // CIOS Montgomery product a * b * 2^-256 mod p.
     static FK_HD Fp mul_body(const Fp &a, const Fp &b) {
         uint32_t t[8];

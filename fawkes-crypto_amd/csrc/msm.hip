@@ -342,8 +342,14 @@ static int msm_run(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars, s
     }
     std::vector<EventPair> &evv = (sizeof(F) == sizeof(Fq)) ? ctx->ev_acc : ctx->ev_acc2;
     FK_TRY(stats_begin(ctx, evv, (uint64_t)n));
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_kernel<F>), dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, d_bases, sorted, n,
-                       starts, totals, p.B, p.W, p.cap, buckets);
+    // acc_cold: run the bucket walk on the out-of-line-multiply twin (a ~10x smaller loop body; instruction-cache relief)
+    const bool acc_cold = (sizeof(F) == sizeof(Fq)) ? ctx->acc_cold_g1 : ctx->acc_cold_g2;
+    if (acc_cold)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_kernel<FC>), dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st,
+                           reinterpret_cast<const Affine<FC> *>(d_bases), sorted, n, starts, totals, p.B, p.W, p.cap, reinterpret_cast<Xyzz<FC> *>(buckets));
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_kernel<F>), dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, d_bases, sorted, n,
+                           starts, totals, p.B, p.W, p.cap, buckets);
     FK_HIP(ctx, hipGetLastError());
     FK_DBG(ctx, "msm_accumulate");
     FK_TRY(stats_end(ctx, evv));

@@ -2,62 +2,189 @@
 """Generates fawkes-crypto_amd/csrc/mont_mul_gfx950.inc: the device-side Montgomery product for 8 x u32
 limbs as a product-scanning (column-wise) schedule with a 96-bit accumulator (lo:64, hi:32).
 
-Every multiply-accumulate is  v_mad_u64_u32 lo, vcc, x, y, lo ; v_addc_co_u32 hi, vcc, 0, hi, vcc
-(the carry-out of the 64-bit add lands in VCC and is folded into `hi` by one v_addc).  Measured on
-MI355X (tools/mulbench): 117 G mul/s against 77 G mul/s for the compiler-scheduled CIOS loop, because
-v_mad_u64_u32 issues at the same rate as v_mul_lo_u32 (about half the rate of v_add_u32) and the CIOS
-form spends half of its VALU slots on v_mov / 64-bit adds.  All macs of one column half are emitted as
-ONE asm statement so hipcc's per-statement s_nop padding is paid ~32 times per product, not 136.
-Result (before the final conditional subtraction) is identical to CIOS: a*b*2^-256 mod p, < 2p.
+Every multiply-accumulate is   v_mad_u64_u32 lo, C, x, y, lo   +   v_addc_co_u32 hi, C, 0, hi, C
+(the carry-out of the 64-bit add lands in an SGPR pair C and is folded into `hi` by one v_addc).
+Measured on MI355X (tools/mulbench): ~126 G mul/s against 77 G mul/s for the compiler-scheduled CIOS loop,
+because v_mad_u64_u32 issues at the same rate as v_mul_lo_u32 (about half the rate of v_add_u32) and the CIOS
+form spends half of its VALU slots on v_mov / 64-bit adds.
+
+HAZARD RULE (gfx90a+/gfx950): a VALU instruction that reads an SGPR/VCC written by a previous VALU instruction
+needs 2 wait states in between (hipcc pads `s_nop 1` for it in its own code), and nothing inside an asm string is
+padded by hipcc.  The schedule is therefore software-pipelined: carries rotate through three SGPR pairs and each
+v_addc is emitted two instructions behind its v_mad (mad0 mad1 mad2 addc0 mad3 addc1 ...); columns with fewer
+than three macs are padded with s_nop.  mul2 (two independent products) interleaves two such chains, which
+satisfies the rule without padding and gives every wave two dependency chains.
+
+All macs of one column half are ONE asm statement.  Result (before the final conditional subtraction) is
+identical to CIOS: a*b*2^-256 mod p, < 2p.
 """
 import os
 
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'fawkes-crypto_amd', 'csrc', 'mont_mul_gfx950.inc')
 
 
-def stmt(pairs, kinds):
-    """pairs: list of (x_expr, y_expr); kinds: 'vv' or 'vs' (y is a constant -> SGPR, placed in src0)."""
-    lines = []
-    ops = []
-    idx = 2
-    for (x, y), kind in zip(pairs, kinds):
-        if kind == 'vv':
-            lines.append('v_mad_u64_u32 %%0, vcc, %%%d, %%%d, %%0' % (idx, idx + 1))
-            ops.append('"v"(%s), "v"(%s)' % (x, y))
-        else:
-            lines.append('v_mad_u64_u32 %%0, vcc, %%%d, %%%d, %%0' % (idx + 1, idx))
-            ops.append('"v"(%s), "s"(%s)' % (x, y))
-        lines.append('v_addc_co_u32 %1, vcc, 0, %1, vcc')
+def mad_line(acc, carry, kind, xi, yi):
+    # 'vs': y is an SGPR constant -> src0
+    if kind == 'vs':
+        return 'v_mad_u64_u32 %%%d, %%%d, %%%d, %%%d, %%%d' % (acc, carry, yi, xi, acc)
+    return 'v_mad_u64_u32 %%%d, %%%d, %%%d, %%%d, %%%d' % (acc, carry, xi, yi, acc)
+
+
+def addc_line(hi, carry):
+    return 'v_addc_co_u32 %%%d, %%%d, 0, %%%d, %%%d' % (hi, carry, hi, carry)
+
+
+def stmt1(pairs, kind):
+    """single chain; operands: %0 lo, %1 hi, %2..%4 carries, then x,y pairs"""
+    n = len(pairs)
+    seq = []                      # ('mad', i) / ('addc', i) / ('nop',)
+    for i in range(n):
+        seq.append(('mad', i))
+        if i >= 2:
+            seq.append(('addc', i - 2))
+    for i in range(max(0, n - 2), n):      # drain: >= 2 instructions between mad i and addc i
+        pos_mad = max(k for k, s in enumerate(seq) if s == ('mad', i))
+        gap = len(seq) - pos_mad - 1
+        while gap < 2:
+            seq.append(('nop',))
+            gap += 1
+        seq.append(('addc', i))
+    idx = 5
+    opidx, ops, lines = {}, [], []
+    for i, (x, y) in enumerate(pairs):
+        opidx[i] = (idx, idx + 1)
+        ops.append('"v"(%s), "%s"(%s)' % (x, 's' if kind == 'vs' else 'v', y))
         idx += 2
+    for s in seq:
+        if s[0] == 'mad':
+            xi, yi = opidx[s[1]]
+            lines.append(mad_line(0, 2 + s[1] % 3, kind, xi, yi))
+        elif s[0] == 'addc':
+            lines.append(addc_line(1, 2 + s[1] % 3))
+        else:
+            lines.append('s_nop 0')
     body = '\\n\\t'.join(lines)
-    return '        asm("%s" : "+v"(lo), "+v"(hi) : %s : "vcc");' % (body, ', '.join(ops))
+    return '        asm("%s" : "+v"(lo), "+v"(hi), "=&s"(c0), "=&s"(c1), "=&s"(c2) : %s);' % (body, ', '.join(ops))
 
 
-def main():
-    o = []
-    o.append('// GENERATED by tools/gen_mont_mul.py -- do not edit.')
-    o.append('// Product-scanning Montgomery multiplication, 8 x u32 limbs, gfx950 inline asm (see the generator).')
-    o.append('    static __device__ __forceinline__ Fp mul_body_asm(const Fp &a, const Fp &b) {')
-    o.append('        uint64_t lo = 0; uint32_t hi = 0;')
-    o.append('        uint32_t m0, m1, m2, m3, m4, m5, m6, m7;')
-    o.append('        Fp r;')
+def stmt2(pairs_a, pairs_b, kind):
+    """two chains; operands: %0 lo, %1 hi, %2 lo2, %3 hi2, %4,%5 carries of A, %6,%7 carries of B, then operands"""
+    n = len(pairs_a)
+    lines, ops = [], []
+    idx = 8
+    opidx = {}
+    for i in range(n):
+        (xa, ya), (xb, yb) = pairs_a[i], pairs_b[i]
+        if kind == 'vs':       # the constant is shared by both chains
+            opidx[i] = (idx, idx + 2, idx + 1, idx + 2)
+            ops.append('"v"(%s), "v"(%s), "s"(%s)' % (xa, xb, ya))
+            idx += 3
+        else:
+            opidx[i] = (idx, idx + 1, idx + 2, idx + 3)
+            ops.append('"v"(%s), "v"(%s), "v"(%s), "v"(%s)' % (xa, ya, xb, yb))
+            idx += 4
+    for i in range(n):
+        xa, ya, xb, yb = opidx[i]
+        lines.append(mad_line(0, 4 + i % 2, kind, xa, ya))
+        lines.append(mad_line(2, 6 + i % 2, kind, xb, yb))
+        if i >= 1:
+            lines.append(addc_line(1, 4 + (i - 1) % 2))
+            lines.append(addc_line(3, 6 + (i - 1) % 2))
+    if n == 1:
+        lines.append('s_nop 0')
+    lines.append(addc_line(1, 4 + (n - 1) % 2))
+    lines.append(addc_line(3, 6 + (n - 1) % 2))
+    body = '\\n\\t'.join(lines)
+    return ('        asm("%s" : "+v"(lo), "+v"(hi), "+v"(lo2), "+v"(hi2), "=&s"(a0), "=&s"(a1), "=&s"(b0), "=&s"(b1) : %s);'
+            % (body, ', '.join(ops)))
+
+
+def columns():
     for k in range(16):
         ab = [(i, k - i) for i in range(max(0, k - 7), min(k, 7) + 1)]
         mp = [(i, k - i) for i in range(max(0, k - 7), min(k - 1, 7) + 1) if k - i >= 1]
+        yield k, ab, mp
+
+
+def gen_mul(o):
+    o.append('    static __device__ __forceinline__ Fp mul_body_asm(const Fp &a, const Fp &b) {')
+    o.append('        uint64_t lo = 0; uint32_t hi = 0; uint64_t c0, c1, c2;')
+    o.append('        uint32_t m0, m1, m2, m3, m4, m5, m6, m7;')
+    o.append('        Fp r;')
+    for k, ab, mp in columns():
         o.append('        // column %d' % k)
         if mp:
-            o.append(stmt([('m%d' % i, 'P::p(%d)' % j) for i, j in mp], ['vs'] * len(mp)))
-        o.append(stmt([('a.v[%d]' % i, 'b.v[%d]' % j) for i, j in ab], ['vv'] * len(ab)))
+            o.append(stmt1([('m%d' % i, 'P::p(%d)' % j) for i, j in mp], 'vs'))
+        o.append(stmt1([('a.v[%d]' % i, 'b.v[%d]' % j) for i, j in ab], 'vv'))
         if k < 8:
             o.append('        m%d = (uint32_t)lo * P::INV;' % k)
-            o.append(stmt([('m%d' % k, 'P::p(0)')], ['vs']))
+            o.append(stmt1([('m%d' % k, 'P::p(0)')], 'vs'))
         else:
             o.append('        r.v[%d] = (uint32_t)lo;' % (k - 8))
         o.append('        lo = (lo >> 32) | ((uint64_t)hi << 32); hi = 0;')
     o.append('        return reduce_once(r);')
     o.append('    }')
-    open(OUT, 'w').write('\n'.join(o) + '\n')
-    print('wrote', os.path.normpath(OUT))
+
+
+def gen_mul2(o):
+    o.append('// Two independent products at once (r1 = a*b, r2 = c*d): the two column accumulators are interleaved')
+    o.append('// instruction by instruction so every wave carries two dependency chains.')
+    o.append('    static __device__ __forceinline__ void mul2_body_asm(const Fp &a, const Fp &b, const Fp &c, const Fp &d, Fp &r1, Fp &r2) {')
+    o.append('        uint64_t lo = 0, lo2 = 0; uint32_t hi = 0, hi2 = 0; uint64_t a0, a1, b0, b1;')
+    o.append('        uint32_t m0, m1, m2, m3, m4, m5, m6, m7, n0, n1, n2, n3, n4, n5, n6, n7;')
+    o.append('        Fp x, y;')
+    for k, ab, mp in columns():
+        o.append('        // column %d' % k)
+        if mp:   # 8 + 3n operands <= 29 for n <= 7
+            o.append(stmt2([('m%d' % i, 'P::p(%d)' % j) for i, j in mp], [('n%d' % i, 'P::p(%d)' % j) for i, j in mp], 'vs'))
+        for lo_ in range(0, len(ab), 5):     # 8 + 4n <= 28 operands
+            chunk = ab[lo_:lo_ + 5]
+            o.append(stmt2([('a.v[%d]' % i, 'b.v[%d]' % j) for i, j in chunk], [('c.v[%d]' % i, 'd.v[%d]' % j) for i, j in chunk], 'vv'))
+        if k < 8:
+            o.append('        m%d = (uint32_t)lo * P::INV; n%d = (uint32_t)lo2 * P::INV;' % (k, k))
+            o.append(stmt2([('m%d' % k, 'P::p(0)')], [('n%d' % k, 'P::p(0)')], 'vs'))
+        else:
+            o.append('        x.v[%d] = (uint32_t)lo; y.v[%d] = (uint32_t)lo2;' % (k - 8, k - 8))
+        o.append('        lo = (lo >> 32) | ((uint64_t)hi << 32); hi = 0; lo2 = (lo2 >> 32) | ((uint64_t)hi2 << 32); hi2 = 0;')
+    o.append('        r1 = reduce_once(x); r2 = reduce_once(y);')
+    o.append('    }')
+
+
+def check(text):
+    """Static check of the hazard rule on the generated text: inside every asm string, a v_addc that reads carry
+    operand %k must sit >= 2 instructions after the last instruction that wrote %k."""
+    import re
+    bad = n = 0
+    for m in re.finditer(r'asm\("(.*?)" :', text):
+        ins = m.group(1).split('\\n\\t')
+        lastw = {}
+        for i, l in enumerate(ins):
+            t = l.replace(',', ' ').split()
+            if not t:
+                continue
+            if t[0] == 'v_mad_u64_u32':
+                lastw[t[2]] = i
+            elif t[0] == 'v_addc_co_u32':
+                c = t[5]
+                if c in lastw and i - lastw[c] - 1 < 2:
+                    bad += 1
+                lastw[t[2]] = i
+                n += 1
+    return n, bad
+
+
+def main():
+    o = ['// GENERATED by tools/gen_mont_mul.py -- do not edit.',
+         '// Product-scanning Montgomery multiplication, 8 x u32 limbs, gfx950 inline asm (see the generator for the',
+         '// schedule and the SGPR-carry hazard rule it obeys).']
+    gen_mul(o)
+    gen_mul2(o)
+    text = '\n'.join(o) + '\n'
+    n, bad = check(text)
+    if bad:
+        raise SystemExit('hazard rule violated in %d of %d v_addc' % (bad, n))
+    open(OUT, 'w').write(text)
+    print('wrote %s (%d v_addc checked against the SGPR-carry hazard rule, 0 violations)' % (os.path.normpath(OUT), n))
 
 
 if __name__ == '__main__':
