@@ -66,22 +66,25 @@ struct alignas(16) Xyzz {
     FK_HD void add_mixed(const Affine<F> &q) {
         if (q.is_inf()) return;
         if (is_inf()) { x = q.x; y = q.y; zz = F::one(); zzz = F::one(); return; }
-        F u2 = F::mul(q.x, zz);
-        F s2 = F::mul(q.y, zzz);
+        // the ten multiplications form five independent pairs -> five dual-chain products (F::mul2)
+        F u2, s2;
+        F::mul2(q.x, zz, q.y, zzz, u2, s2);
         F p = F::sub(u2, x);
         F r = F::sub(s2, y);
         if (p.is_zero()) {
             if (r.is_zero()) *this = dbl_affine(q); else *this = inf();
             return;
         }
-        F pp = F::sqr(p);
-        F ppp = F::mul(p, pp);
-        F q_ = F::mul(x, pp);
-        F x3 = F::sub(F::sub(F::sqr(r), ppp), F::dbl(q_));
-        y = F::sub(F::mul(r, F::sub(q_, x3)), F::mul(y, ppp));
+        F pp, rr;
+        F::mul2(p, p, r, r, pp, rr);
+        F ppp, q_;
+        F::mul2(p, pp, x, pp, ppp, q_);
+        F x3 = F::sub(F::sub(rr, ppp), F::dbl(q_));
+        F t, yppp;
+        F::mul2(r, F::sub(q_, x3), y, ppp, t, yppp);
+        y = F::sub(t, yppp);
         x = x3;
-        zz = F::mul(zz, pp);
-        zzz = F::mul(zzz, ppp);
+        F::mul2(zz, pp, zzz, ppp, zz, zzz);
     }
 
     // acc += q (XYZZ), add-2008-s with the exceptional cases handled

@@ -238,6 +238,15 @@ struct alignas(16) Fq2T {
         Fq t = Fq::mul(Fq::add(a.c0, a.c1), Fq::add(b.c0, b.c1));
         return Fq2{Fq::sub(aa, bb), Fq::sub(Fq::sub(t, aa), bb)};
     }
+    // r1 = a*b, r2 = c*d: the six base-field products of two Karatsuba multiplications run as three dual chains
+    static FK_HD void mul2(const Fq2 &a, const Fq2 &b, const Fq2 &c, const Fq2 &d, Fq2 &r1, Fq2 &r2) {
+        Fq aa, bb, cc, dd, t1, t2;
+        Fq::mul2(a.c0, b.c0, a.c1, b.c1, aa, bb);
+        Fq::mul2(c.c0, d.c0, c.c1, d.c1, cc, dd);
+        Fq::mul2(Fq::add(a.c0, a.c1), Fq::add(b.c0, b.c1), Fq::add(c.c0, c.c1), Fq::add(d.c0, d.c1), t1, t2);
+        r1 = Fq2{Fq::sub(aa, bb), Fq::sub(Fq::sub(t1, aa), bb)};
+        r2 = Fq2{Fq::sub(cc, dd), Fq::sub(Fq::sub(t2, cc), dd)};
+    }
     static FK_HD Fq2 sqr(const Fq2 &a) {  // (c0+c1)(c0-c1), 2 c0 c1
         Fq s = Fq::add(a.c0, a.c1), d = Fq::sub(a.c0, a.c1);
         Fq m = Fq::mul(a.c0, a.c1);
