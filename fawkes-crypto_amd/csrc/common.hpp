@@ -44,7 +44,7 @@ struct fk_ctx {
     std::map<uint32_t, fk::NttDomain *> domains;
     // MSM scratch
     const void *last_sort_scalars = nullptr; size_t last_sort_n = 0; unsigned last_sort_c = 0;   // what `sorted` currently holds
-    fk::DevBuf digits, sorted, counts, totals, starts, buckets, winparts, overlist, tasktab, partials, misc;
+    fk::DevBuf digits, sorted, counts, totals, starts, buckets, winparts, overlist, tasktab, partials, misc, perm;
     // NTT / prover scratch
     fk::DevBuf ntt_s1, ntt_s2, ntt_io, hbuf, sc_a, sc_b, scan_tmp, stage_a, stage_b, stage_c, stage_z, stage_d;
     // stats

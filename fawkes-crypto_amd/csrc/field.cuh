@@ -233,19 +233,17 @@ struct alignas(16) Fq2T {
     static FK_HD Fq2 dbl(const Fq2 &a) { return Fq2{Fq::dbl(a.c0), Fq::dbl(a.c1)}; }
     static FK_HD Fq2 neg(const Fq2 &a) { return Fq2{Fq::neg(a.c0), Fq::neg(a.c1)}; }
     static FK_HD Fq2 mul(const Fq2 &a, const Fq2 &b) {  // Karatsuba, 3 base multiplications
-        Fq aa = Fq::mul(a.c0, b.c0);
-        Fq bb = Fq::mul(a.c1, b.c1);
+        Fq aa, bb;
+        Fq::mul2(a.c0, b.c0, a.c1, b.c1, aa, bb);
         Fq t = Fq::mul(Fq::add(a.c0, a.c1), Fq::add(b.c0, b.c1));
         return Fq2{Fq::sub(aa, bb), Fq::sub(Fq::sub(t, aa), bb)};
     }
-    // r1 = a*b, r2 = c*d: the six base-field products of two Karatsuba multiplications run as three dual chains
+    // r1 = a*b, r2 = c*d.  Register pressure decides here (XYZZ<Fq2> is 64 registers of state): the two products
+    // run one after the other; inside each, a0*b0 and a1*b1 form one dual chain (see mul).
     static FK_HD void mul2(const Fq2 &a, const Fq2 &b, const Fq2 &c, const Fq2 &d, Fq2 &r1, Fq2 &r2) {
-        Fq aa, bb, cc, dd, t1, t2;
-        Fq::mul2(a.c0, b.c0, a.c1, b.c1, aa, bb);
-        Fq::mul2(c.c0, d.c0, c.c1, d.c1, cc, dd);
-        Fq::mul2(Fq::add(a.c0, a.c1), Fq::add(b.c0, b.c1), Fq::add(c.c0, c.c1), Fq::add(d.c0, d.c1), t1, t2);
-        r1 = Fq2{Fq::sub(aa, bb), Fq::sub(Fq::sub(t1, aa), bb)};
-        r2 = Fq2{Fq::sub(cc, dd), Fq::sub(Fq::sub(t2, cc), dd)};
+        const Fq2 t = mul(a, b);
+        r2 = mul(c, d);
+        r1 = t;
     }
     static FK_HD Fq2 sqr(const Fq2 &a) {  // (c0+c1)(c0-c1), 2 c0 c1
         Fq s = Fq::add(a.c0, a.c1), d = Fq::sub(a.c0, a.c1);

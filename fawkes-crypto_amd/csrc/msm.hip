@@ -164,6 +164,42 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_scatter_kernel(const uint32_
     }
 }
 
+// ------------------------------------------------------------------------------------------ bucket -> lane assignment
+// A wave runs as long as its longest bucket, so lanes are handed buckets of (nearly) equal length: buckets are
+// binned by min(size, cap) into 1024 classes, largest first (counting sort on the class), and lane t of the
+// accumulate kernel takes bucket perm[t].  VALUUtilization of the accumulate kernels was 80-86 % without this.
+static constexpr uint32_t SIZE_BINS = 1024;
+static __device__ __forceinline__ uint32_t size_class(uint32_t size, uint32_t cap) {
+    const uint32_t s = size < cap ? size : cap;
+    return (SIZE_BINS - 1) - (uint32_t)(((uint64_t)s * (SIZE_BINS - 1)) / (cap ? cap : 1));      // descending
+}
+__global__ __launch_bounds__(256) void msm_size_hist_kernel(const uint32_t *totals, size_t WB, uint32_t cap, uint32_t *bins) {
+    __shared__ uint32_t sh[SIZE_BINS];
+    for (uint32_t i = threadIdx.x; i < SIZE_BINS; i += 256) sh[i] = 0;
+    __syncthreads();
+    for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < WB; g += (size_t)gridDim.x * 256) atomicAdd(&sh[size_class(totals[g], cap)], 1u);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < SIZE_BINS; i += 256) if (sh[i]) atomicAdd(&bins[i], sh[i]);
+}
+__global__ __launch_bounds__(SIZE_BINS) void msm_size_scan_kernel(uint32_t *bins) {      // exclusive scan in place
+    __shared__ uint32_t sh[SIZE_BINS];
+    const uint32_t t = threadIdx.x, v = bins[t];
+    sh[t] = v;
+    __syncthreads();
+    for (uint32_t off = 1; off < SIZE_BINS; off <<= 1) {
+        uint32_t x = t >= off ? sh[t - off] : 0;
+        __syncthreads();
+        sh[t] += x;
+        __syncthreads();
+    }
+    bins[t] = sh[t] - v;
+}
+__global__ __launch_bounds__(256) void msm_size_scatter_kernel(const uint32_t *totals, size_t WB, uint32_t cap, uint32_t *cursor, uint32_t *perm) {
+    const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= WB) return;
+    perm[atomicAdd(&cursor[size_class(totals[g], cap)], 1u)] = (uint32_t)g;
+}
+
 // ------------------------------------------------------------------------------------------ wave / block reductions
 template <class T>
 static __device__ __forceinline__ T shfl_down_obj(const T &v, int off) {
@@ -200,12 +236,15 @@ static __device__ __forceinline__ void block_reduce_256(Xyzz<F> &acc, Xyzz<F> *s
 }
 
 // ------------------------------------------------------------------------------------------ bucket accumulation
-template <class F>
-__global__ __launch_bounds__(256) void msm_accumulate_kernel(const Affine<F> *bases, const uint32_t *sorted, size_t n,
+// MINW = minimum waves per SIMD the register allocator must leave room for (G1: 4 -> <= 128 registers;
+// G2: 2 -> <= 256 VGPR+AGPR; unconstrained the G2 body takes 256 VGPRs + 177 AGPRs = 1 wave per SIMD)
+template <class F, int MINW>
+__global__ __launch_bounds__(256, MINW) void msm_accumulate_kernel(const Affine<F> *bases, const uint32_t *sorted, size_t n,
                                                              const uint32_t *starts, const uint32_t *totals, uint32_t B,
-                                                             uint32_t W, uint32_t cap, Xyzz<F> *buckets) {
-    size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= (size_t)W * B) return;
+                                                             uint32_t W, uint32_t cap, const uint32_t *perm, Xyzz<F> *buckets) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)W * B) return;
+    const size_t g = perm[t];                 // buckets of similar length share a wave
     const uint32_t w = (uint32_t)(g / B);
     const uint32_t *src = sorted + (size_t)w * n + starts[g];
     uint32_t cnt = totals[g];
@@ -313,6 +352,8 @@ static int msm_run(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars, s
     uint32_t *digits = ctx->digits.as<uint32_t>(), *sorted = ctx->sorted.as<uint32_t>();
     uint32_t *counts = ctx->counts.as<uint32_t>(), *totals = ctx->totals.as<uint32_t>(), *starts = ctx->starts.as<uint32_t>();
     Xyzz<F> *buckets = ctx->buckets.as<Xyzz<F>>(), *winparts = ctx->winparts.as<Xyzz<F>>();
+    FK_HIP(ctx, ctx->perm.reserve(WB * 4 + SIZE_BINS * 4));
+    uint32_t *perm = ctx->perm.as<uint32_t>(), *size_bins = perm + WB;
 
     const bool have_sort = reuse_sort && ctx->last_sort_scalars == (const void *)d_scalars && ctx->last_sort_n == n && ctx->last_sort_c == p.c;
     if (!have_sort) {
@@ -338,6 +379,13 @@ static int msm_run(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars, s
                            counts, starts, sorted);
         FK_HIP(ctx, hipGetLastError());
         FK_DBG(ctx, "msm_scatter");
+        // size-ordered bucket -> lane assignment
+        FK_HIP(ctx, hipMemsetAsync(size_bins, 0, SIZE_BINS * 4, st));
+        hipLaunchKernelGGL(msm_size_hist_kernel, dim3((unsigned)std::min<size_t>((WB + 255) / 256, 1024)), dim3(256), 0, st, totals, WB, p.cap, size_bins);
+        hipLaunchKernelGGL(msm_size_scan_kernel, dim3(1), dim3(SIZE_BINS), 0, st, size_bins);
+        hipLaunchKernelGGL(msm_size_scatter_kernel, dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, totals, WB, p.cap, size_bins, perm);
+        FK_HIP(ctx, hipGetLastError());
+        FK_DBG(ctx, "msm_size_order");
         ctx->last_sort_scalars = (const void *)d_scalars; ctx->last_sort_n = n; ctx->last_sort_c = p.c;
     }
     std::vector<EventPair> &evv = (sizeof(F) == sizeof(Fq)) ? ctx->ev_acc : ctx->ev_acc2;
@@ -345,11 +393,11 @@ static int msm_run(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars, s
     // acc_cold: run the bucket walk on the out-of-line-multiply twin (a ~10x smaller loop body; instruction-cache relief)
     const bool acc_cold = (sizeof(F) == sizeof(Fq)) ? ctx->acc_cold_g1 : ctx->acc_cold_g2;
     if (acc_cold)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_kernel<FC>), dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st,
-                           reinterpret_cast<const Affine<FC> *>(d_bases), sorted, n, starts, totals, p.B, p.W, p.cap, reinterpret_cast<Xyzz<FC> *>(buckets));
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_kernel<FC, (sizeof(F) == sizeof(Fq) ? 4 : 2)>), dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st,
+                           reinterpret_cast<const Affine<FC> *>(d_bases), sorted, n, starts, totals, p.B, p.W, p.cap, perm, reinterpret_cast<Xyzz<FC> *>(buckets));
     else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_kernel<F>), dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, d_bases, sorted, n,
-                           starts, totals, p.B, p.W, p.cap, buckets);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_kernel<F, (sizeof(F) == sizeof(Fq) ? 4 : 2)>), dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, d_bases, sorted, n,
+                           starts, totals, p.B, p.W, p.cap, perm, buckets);
     FK_HIP(ctx, hipGetLastError());
     FK_DBG(ctx, "msm_accumulate");
     FK_TRY(stats_end(ctx, evv));

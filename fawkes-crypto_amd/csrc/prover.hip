@@ -78,7 +78,7 @@ void fk_free(fk_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     ntt_free_domains(ctx);
     for (DevBuf *b : {&ctx->digits, &ctx->sorted, &ctx->counts, &ctx->totals, &ctx->starts, &ctx->buckets, &ctx->winparts,
-                      &ctx->overlist, &ctx->tasktab, &ctx->partials, &ctx->misc, &ctx->ntt_s1, &ctx->ntt_s2, &ctx->ntt_io,
+                      &ctx->overlist, &ctx->tasktab, &ctx->partials, &ctx->misc, &ctx->perm, &ctx->ntt_s1, &ctx->ntt_s2, &ctx->ntt_io,
                       &ctx->hbuf, &ctx->sc_a, &ctx->sc_b, &ctx->scan_tmp, &ctx->stage_a, &ctx->stage_b, &ctx->stage_c,
                       &ctx->stage_z, &ctx->stage_d})
         b->release();
