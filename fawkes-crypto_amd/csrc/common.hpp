@@ -39,7 +39,6 @@ struct fk_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     unsigned window_bits = 0;  // 0 = auto
-    bool acc_cold_g1 = false, acc_cold_g2 = false;   // FK_ACC_COLD_G1 / FK_ACC_COLD_G2: tuning switches
     unsigned ntt_threads = 512;  // workgroup size cap of the NTT pass kernel (FK_NTT_THREADS overrides)
     std::map<uint32_t, fk::NttDomain *> domains;
     // MSM scratch

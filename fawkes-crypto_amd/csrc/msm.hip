@@ -236,8 +236,10 @@ static __device__ __forceinline__ void block_reduce_256(Xyzz<F> &acc, Xyzz<F> *s
 }
 
 // ------------------------------------------------------------------------------------------ bucket accumulation
-// MINW = minimum waves per SIMD the register allocator must leave room for (G1: 4 -> <= 128 registers;
-// G2: 2 -> <= 256 VGPR+AGPR; unconstrained the G2 body takes 256 VGPRs + 177 AGPRs = 1 wave per SIMD)
+// MINW = minimum waves per SIMD the register allocator must leave room for.  G1: 4 (<= 128 registers, no spills).
+// G2: the inlined Fq2 mixed addition wants 256 VGPRs + ~180 AGPRs; forcing 2 waves spills ~260 registers to
+// scratch and is slower (41 ms vs 33 ms at 2^25) -- also with the accumulator staged in LDS (160 spills) or with the
+// out-of-line multiply (+14 %) -- so G2 runs at MINW = 1.
 template <class F, int MINW>
 __global__ __launch_bounds__(256, MINW) void msm_accumulate_kernel(const Affine<F> *bases, const uint32_t *sorted, size_t n,
                                                              const uint32_t *starts, const uint32_t *totals, uint32_t B,
@@ -390,14 +392,8 @@ static int msm_run(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars, s
     }
     std::vector<EventPair> &evv = (sizeof(F) == sizeof(Fq)) ? ctx->ev_acc : ctx->ev_acc2;
     FK_TRY(stats_begin(ctx, evv, (uint64_t)n));
-    // acc_cold: run the bucket walk on the out-of-line-multiply twin (a ~10x smaller loop body; instruction-cache relief)
-    const bool acc_cold = (sizeof(F) == sizeof(Fq)) ? ctx->acc_cold_g1 : ctx->acc_cold_g2;
-    if (acc_cold)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_kernel<FC, (sizeof(F) == sizeof(Fq) ? 4 : 2)>), dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st,
-                           reinterpret_cast<const Affine<FC> *>(d_bases), sorted, n, starts, totals, p.B, p.W, p.cap, perm, reinterpret_cast<Xyzz<FC> *>(buckets));
-    else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_kernel<F, (sizeof(F) == sizeof(Fq) ? 4 : 2)>), dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, d_bases, sorted, n,
-                           starts, totals, p.B, p.W, p.cap, perm, buckets);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_kernel<F, (sizeof(F) == sizeof(Fq) ? 4 : 1)>), dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, d_bases, sorted, n,
+                       starts, totals, p.B, p.W, p.cap, perm, buckets);
     FK_HIP(ctx, hipGetLastError());
     FK_DBG(ctx, "msm_accumulate");
     FK_TRY(stats_end(ctx, evv));

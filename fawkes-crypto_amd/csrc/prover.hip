@@ -65,7 +65,6 @@ int fk_init(int device_id, fk_ctx **out) {
     fk_ctx *ctx = new fk_ctx();
     ctx->device = device_id;
     { const char *d = getenv("FK_DEBUG"); ctx->debug = d && d[0] && d[0] != '0'; }
-    { const char *a = getenv("FK_ACC_COLD_G1"); if (a) ctx->acc_cold_g1 = a[0] == '1'; a = getenv("FK_ACC_COLD_G2"); if (a) ctx->acc_cold_g2 = a[0] == '1'; }
     { const char *t = getenv("FK_NTT_THREADS"); if (t) { int v = atoi(t); if (v == 64 || v == 128 || v == 256 || v == 512 || v == 1024) ctx->ntt_threads = (unsigned)v; } }
     if (hipStreamCreate(&ctx->stream) != hipSuccess) { delete ctx; return FK_ERR_HIP; }
     *out = ctx;
