@@ -35,27 +35,38 @@ struct MsmPlan {
     size_t chunk;
     uint32_t cap;            // max entries a bucket-lane handles itself
     uint32_t L, T, nblk;     // bucket-reduce: buckets per lane, lanes per window, blocks per window
+    bool two_pass;           // c > 16: two-pass radix sort (high bits, then low bits inside each segment)
+    uint32_t LB, nhi, nlo;   // low bits of the bucket index, number of high / low bins
 };
+static constexpr uint32_t S2_TILE = 16384;     // entries per second-pass workgroup
 
-static MsmPlan make_plan(size_t n, unsigned forced_c) {
+static MsmPlan make_plan(size_t n, unsigned forced_c, bool force_two_pass, unsigned chunks_2p = 256) {
     MsmPlan p{};
     p.n = n;
     uint32_t lg = 0; while (((size_t)1 << (lg + 1)) <= n) lg++;
-    uint32_t c = forced_c ? forced_c : (lg >= 18 ? 16 : (lg >= 6 ? lg - 2 : 4));
+    // large MSMs: bucket loads of ~64 are enough now that lanes are size-ordered, so c grows with n (fewer digits
+    // per scalar: 13 at c = 20 instead of 16); c > 16 needs the two-pass sort (the LDS histogram holds 2^15 counters)
+    uint32_t c = forced_c ? forced_c : (lg >= 22 ? lg - 5 : (lg >= 18 ? 16 : (lg >= 6 ? lg - 2 : 4)));
     if (c < 2) c = 2;
-    if (c > 16) c = 16;
+    if (c > 22) c = 22;
     p.c = c;
     p.W = (255 + c - 1) / c;
     p.B = 1u << (c - 1);
-    size_t chunk = (n + 31) / 32;
+    const bool two_pass_ = force_two_pass || c > 16;
+    // one-pass sort: 128 KiB of LDS counters per workgroup -> few big chunks; two-pass: a few KiB -> many small ones
+    size_t chunk = two_pass_ ? (n + chunks_2p - 1) / chunks_2p : (n + 31) / 32;
     if (chunk < 16384) chunk = 16384;
     p.chunk = chunk;
     p.nchunks = (uint32_t)((n + chunk - 1) / chunk);
     size_t mean = n / p.B;
     p.cap = (uint32_t)std::min<size_t>(2 * mean + 64, 1u << 30);
-    p.L = p.B >= 4096 ? p.B / 2048 : 1;
+    p.L = p.B >= 4096 ? (p.B >= (1u << 18) ? 64 : p.B / 2048) : 1;     // <= 64 buckets per lane
     p.T = p.B / p.L;
     p.nblk = (p.T + 255) / 256;
+    p.two_pass = force_two_pass || c > 16;
+    p.LB = (c - 1) < 10 ? (c - 1) : 10;
+    p.nlo = 1u << p.LB;
+    p.nhi = p.B >> p.LB;
     return p;
 }
 
@@ -164,6 +175,150 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_scatter_kernel(const uint32_
     }
 }
 
+// ------------------------------------------------------------------------------------------ two-pass radix sort (c > 16)
+// Pass 1 partitions each window's entries by the high bits of the bucket index (<= 2^11 bins, LDS counters and
+// cursors), pass 2 sorts every high-bin segment by the low bits (<= 2^10 bins) in tiles of S2_TILE entries.  Both
+// passes write through a few hundred open lines per workgroup, so stores combine in L2 instead of the one-pass
+// scatter's 4-byte writes over 2^15 open lines (5.8x write amplification measured).
+__global__ __launch_bounds__(SORT_THREADS) void s2_hist1_kernel(const uint32_t *digits, size_t n, size_t chunk, uint32_t nchunks,
+                                                                 uint32_t LB, uint32_t nhi, uint32_t *cnt1) {
+    extern __shared__ uint32_t hist[];
+    const uint32_t ch = blockIdx.x, w = blockIdx.y;
+    for (uint32_t b = threadIdx.x; b < nhi; b += blockDim.x) hist[b] = 0;
+    __syncthreads();
+    const size_t lo = (size_t)ch * chunk, hi = lo + chunk < n ? lo + chunk : n;
+    const uint32_t *dg = digits + (size_t)w * n;
+    for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const uint32_t d = dg[i] & 0x7fffffffu;
+        if (d) atomicAdd(&hist[(d - 1) >> LB], 1u);
+    }
+    __syncthreads();
+    uint32_t *out = cnt1 + ((size_t)w * nchunks + ch) * nhi;
+    for (uint32_t b = threadIdx.x; b < nhi; b += blockDim.x) out[b] = hist[b];
+}
+
+// one block per window: cnt1 -> exclusive prefix over chunks; seg_size / seg_start (relative to the window) per high bin
+__global__ __launch_bounds__(1024) void s2_prefix1_kernel(uint32_t *cnt1, uint32_t nchunks, uint32_t nhi, uint32_t *seg_size, uint32_t *seg_start,
+                                                           uint32_t *seg_tiles) {
+    extern __shared__ uint32_t ssz[];
+    const uint32_t w = blockIdx.x;
+    for (uint32_t h = threadIdx.x; h < nhi; h += blockDim.x) {
+        uint32_t run = 0;
+        for (uint32_t ch = 0; ch < nchunks; ch++) {
+            uint32_t *p = cnt1 + ((size_t)w * nchunks + ch) * nhi + h;
+            const uint32_t v = *p; *p = run; run += v;
+        }
+        ssz[h] = run;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (uint32_t h = 0; h < nhi; h++) {
+            const uint32_t v = ssz[h];
+            seg_size[(size_t)w * nhi + h] = v; seg_start[(size_t)w * nhi + h] = run; seg_tiles[(size_t)w * nhi + h] = (v + S2_TILE - 1) / S2_TILE;
+            run += v;
+        }
+    }
+}
+
+// exclusive prefix of the per-segment tile counts (one lane; <= 22 * 2^11 values); tile_start[nseg] = total
+__global__ void s2_tile_prefix_kernel(const uint32_t *seg_tiles, uint32_t nseg, uint32_t *tile_start) {
+    if (threadIdx.x || blockIdx.x) return;
+    uint32_t run = 0;
+    for (uint32_t s = 0; s < nseg; s++) { tile_start[s] = run; run += seg_tiles[s]; }
+    tile_start[nseg] = run;
+}
+
+__global__ __launch_bounds__(SORT_THREADS) void s2_scatter1_kernel(const uint32_t *digits, size_t n, size_t chunk, uint32_t nchunks, uint32_t LB,
+                                                                    uint32_t nhi, const uint32_t *cnt1, const uint32_t *seg_start, uint32_t *tmp_idx,
+                                                                    uint16_t *tmp_lo) {
+    extern __shared__ uint32_t cursor[];
+    const uint32_t ch = blockIdx.x, w = blockIdx.y;
+    const uint32_t *cnt = cnt1 + ((size_t)w * nchunks + ch) * nhi;
+    for (uint32_t b = threadIdx.x; b < nhi; b += blockDim.x) cursor[b] = seg_start[(size_t)w * nhi + b] + cnt[b];
+    __syncthreads();
+    const size_t lo = (size_t)ch * chunk, hi = lo + chunk < n ? lo + chunk : n;
+    const uint32_t *dg = digits + (size_t)w * n;
+    const uint32_t lomask = (1u << LB) - 1;
+    for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const uint32_t d = dg[i], bkt = d & 0x7fffffffu;
+        if (bkt) {
+            const uint32_t pos = atomicAdd(&cursor[(bkt - 1) >> LB], 1u);
+            tmp_idx[(size_t)w * n + pos] = (uint32_t)i | (d & 0x80000000u);
+            tmp_lo[(size_t)w * n + pos] = (uint16_t)((bkt - 1) & lomask);
+        }
+    }
+}
+
+// which segment does tile `t` belong to (tile_start is non-decreasing; empty segments own no tile)
+static __device__ __forceinline__ uint32_t s2_find_segment(const uint32_t *tile_start, uint32_t nseg, uint32_t t) {
+    uint32_t lo = 0, hi = nseg;          // invariant: tile_start[lo] <= t < tile_start[hi]
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (tile_start[mid] <= t) lo = mid; else hi = mid; }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void s2_hist2_kernel(const uint16_t *tmp_lo, size_t n, uint32_t nhi, uint32_t nlo, const uint32_t *tile_start,
+                                                        uint32_t nseg, const uint32_t *seg_start, const uint32_t *seg_size, uint32_t *cnt2) {
+    extern __shared__ uint32_t hist[];
+    const uint32_t tile = blockIdx.x;
+    const uint32_t sgm = s2_find_segment(tile_start, nseg, tile), w = sgm / nhi, t = tile - tile_start[sgm];
+    for (uint32_t b = threadIdx.x; b < nlo; b += 256) hist[b] = 0;
+    __syncthreads();
+    const uint32_t size = seg_size[sgm], lo = t * S2_TILE, hi = lo + S2_TILE < size ? lo + S2_TILE : size;
+    const uint16_t *src = tmp_lo + (size_t)w * n + seg_start[sgm];
+    for (uint32_t k = lo + threadIdx.x; k < hi; k += 256) atomicAdd(&hist[src[k]], 1u);
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nlo; b += 256) cnt2[(size_t)tile * nlo + b] = hist[b];
+}
+
+// one block per high-bin segment, one lane per low bin: prefix over the segment's tiles, bucket totals and starts
+__global__ __launch_bounds__(1024) void s2_prefix2_kernel(uint32_t *cnt2, uint32_t nhi, uint32_t nlo, uint32_t B, const uint32_t *tile_start,
+                                                           const uint32_t *seg_start, uint32_t cap, uint32_t *totals, uint32_t *starts,
+                                                           OverEntry *over, uint32_t *n_over, uint32_t over_cap) {
+    __shared__ uint32_t part[1024];
+    const uint32_t sgm = blockIdx.x, w = sgm / nhi, h = sgm % nhi, b = threadIdx.x;
+    uint32_t run = 0;
+    if (b < nlo) {
+        for (uint32_t t = tile_start[sgm]; t < tile_start[sgm + 1]; t++) {
+            uint32_t *p = cnt2 + (size_t)t * nlo + b;
+            const uint32_t v = *p; *p = run; run += v;
+        }
+    }
+    part[b] = run;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+        const uint32_t v = b >= off ? part[b - off] : 0;
+        __syncthreads();
+        part[b] += v;
+        __syncthreads();
+    }
+    if (b < nlo) {
+        const size_t g = (size_t)w * B + (size_t)h * nlo + b;
+        totals[g] = run;
+        starts[g] = seg_start[sgm] + part[b] - run;
+        if (run > cap) {
+            const uint32_t k = atomicAdd(n_over, 1u);
+            if (k < over_cap) { over[k].g = (uint32_t)g; over[k].size = run; }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void s2_scatter2_kernel(const uint32_t *tmp_idx, const uint16_t *tmp_lo, size_t n, uint32_t nhi, uint32_t nlo, uint32_t B,
+                                                           const uint32_t *tile_start, uint32_t nseg, const uint32_t *seg_start, const uint32_t *seg_size,
+                                                           const uint32_t *cnt2, const uint32_t *starts, uint32_t *sorted) {
+    extern __shared__ uint32_t cursor[];
+    const uint32_t tile = blockIdx.x;
+    const uint32_t sgm = s2_find_segment(tile_start, nseg, tile), w = sgm / nhi, h = sgm % nhi, t = tile - tile_start[sgm];
+    for (uint32_t b = threadIdx.x; b < nlo; b += 256) cursor[b] = starts[(size_t)w * B + (size_t)h * nlo + b] + cnt2[(size_t)tile * nlo + b];
+    __syncthreads();
+    const uint32_t size = seg_size[sgm], lo = t * S2_TILE, hi = lo + S2_TILE < size ? lo + S2_TILE : size;
+    const size_t base = (size_t)w * n + seg_start[sgm];
+    for (uint32_t k = lo + threadIdx.x; k < hi; k += 256) {
+        const uint32_t pos = atomicAdd(&cursor[tmp_lo[base + k]], 1u);
+        sorted[(size_t)w * n + pos] = tmp_idx[base + k];
+    }
+}
+
 // ------------------------------------------------------------------------------------------ bucket -> lane assignment
 // A wave runs as long as its longest bucket, so lanes are handed buckets of (nearly) equal length: buckets are
 // binned by min(size, cap) into 1024 classes, largest first (counting sort on the class), and lane t of the
@@ -194,10 +349,20 @@ __global__ __launch_bounds__(SIZE_BINS) void msm_size_scan_kernel(uint32_t *bins
     }
     bins[t] = sh[t] - v;
 }
-__global__ __launch_bounds__(256) void msm_size_scatter_kernel(const uint32_t *totals, size_t WB, uint32_t cap, uint32_t *cursor, uint32_t *perm) {
-    const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (g >= WB) return;
-    perm[atomicAdd(&cursor[size_class(totals[g], cap)], 1u)] = (uint32_t)g;
+// ranks inside the workgroup come from LDS counters; one global atomic per (workgroup, non-empty class) reserves the
+// range -- with millions of similar-sized buckets a per-bucket global atomic serialises on a few dozen hot cursors
+__global__ __launch_bounds__(1024) void msm_size_scatter_kernel(const uint32_t *totals, size_t WB, uint32_t cap, uint32_t *cursor, uint32_t *perm) {
+    __shared__ uint32_t cnt[SIZE_BINS];
+    __shared__ uint32_t base[SIZE_BINS];
+    const size_t g = (size_t)blockIdx.x * 1024 + threadIdx.x;
+    cnt[threadIdx.x] = 0;                       // SIZE_BINS == blockDim.x == 1024
+    __syncthreads();
+    uint32_t cls = 0, rank = 0;
+    if (g < WB) { cls = size_class(totals[g], cap); rank = atomicAdd(&cnt[cls], 1u); }
+    __syncthreads();
+    if (cnt[threadIdx.x]) base[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], cnt[threadIdx.x]);
+    __syncthreads();
+    if (g < WB) perm[base[cls] + rank] = (uint32_t)g;
 }
 
 // ------------------------------------------------------------------------------------------ wave / block reductions
@@ -338,12 +503,12 @@ static int msm_run(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars, s
     *out = Xyzz<F>::inf();
     if (n == 0) return FK_OK;
     if (n >= ((size_t)1 << 31)) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "msm: n too large");
-    const MsmPlan p = make_plan(n, ctx->window_bits);
+    const MsmPlan p = make_plan(n, ctx->window_bits, ctx->force_sort2, ctx->sort2_chunks);
     hipStream_t st = ctx->stream;
     const size_t WB = (size_t)p.W * p.B;
     FK_HIP(ctx, ctx->digits.reserve((size_t)p.W * n * 4));
     FK_HIP(ctx, ctx->sorted.reserve((size_t)p.W * n * 4));
-    FK_HIP(ctx, ctx->counts.reserve((size_t)p.W * p.nchunks * p.B * 4));
+    if (!p.two_pass) FK_HIP(ctx, ctx->counts.reserve((size_t)p.W * p.nchunks * p.B * 4));
     FK_HIP(ctx, ctx->totals.reserve(WB * 4));
     FK_HIP(ctx, ctx->starts.reserve(WB * 4));
     FK_HIP(ctx, ctx->buckets.reserve(WB * sizeof(Xyzz<F>)));
@@ -363,29 +528,66 @@ static int msm_run(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars, s
         hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, p.c, p.W, digits);
         FK_HIP(ctx, hipGetLastError());
         FK_DBG(ctx, "msm_digits");
-        const size_t lds = (size_t)p.B * 4;
-        FK_HIP(ctx, hipFuncSetAttribute((const void *)msm_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        FK_HIP(ctx, hipFuncSetAttribute((const void *)msm_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(msm_hist_kernel, dim3(p.nchunks, p.W), dim3(SORT_THREADS), lds, st, digits, n, p.chunk, p.nchunks, p.B, counts);
-        FK_HIP(ctx, hipGetLastError());
-        FK_DBG(ctx, "msm_hist");
-        hipLaunchKernelGGL(msm_chunk_prefix_kernel, dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, counts, p.nchunks, p.B, p.W, totals);
-        FK_HIP(ctx, hipGetLastError());
-        FK_DBG(ctx, "msm_chunk_prefix");
         FK_HIP(ctx, hipMemsetAsync(d_nover, 0, 4, st));
-        hipLaunchKernelGGL(msm_window_scan_kernel, dim3(p.W), dim3(1024), 0, st, totals, p.B, p.cap, starts,
-                           ctx->overlist.as<OverEntry>(), d_nover, over_cap);
-        FK_HIP(ctx, hipGetLastError());
-        FK_DBG(ctx, "msm_window_scan");
-        hipLaunchKernelGGL(msm_scatter_kernel, dim3(p.nchunks, p.W), dim3(SORT_THREADS), lds, st, digits, n, p.chunk, p.nchunks, p.B,
-                           counts, starts, sorted);
-        FK_HIP(ctx, hipGetLastError());
-        FK_DBG(ctx, "msm_scatter");
+        if (!p.two_pass) {
+            const size_t lds = (size_t)p.B * 4;
+            FK_HIP(ctx, hipFuncSetAttribute((const void *)msm_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            FK_HIP(ctx, hipFuncSetAttribute((const void *)msm_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(msm_hist_kernel, dim3(p.nchunks, p.W), dim3(SORT_THREADS), lds, st, digits, n, p.chunk, p.nchunks, p.B, counts);
+            FK_HIP(ctx, hipGetLastError());
+            FK_DBG(ctx, "msm_hist");
+            hipLaunchKernelGGL(msm_chunk_prefix_kernel, dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, counts, p.nchunks, p.B, p.W, totals);
+            FK_HIP(ctx, hipGetLastError());
+            FK_DBG(ctx, "msm_chunk_prefix");
+            hipLaunchKernelGGL(msm_window_scan_kernel, dim3(p.W), dim3(1024), 0, st, totals, p.B, p.cap, starts,
+                               ctx->overlist.as<OverEntry>(), d_nover, over_cap);
+            FK_HIP(ctx, hipGetLastError());
+            FK_DBG(ctx, "msm_window_scan");
+            hipLaunchKernelGGL(msm_scatter_kernel, dim3(p.nchunks, p.W), dim3(SORT_THREADS), lds, st, digits, n, p.chunk, p.nchunks, p.B,
+                               counts, starts, sorted);
+            FK_HIP(ctx, hipGetLastError());
+            FK_DBG(ctx, "msm_scatter");
+
+        } else {
+            const uint32_t nseg = p.W * p.nhi;
+            const size_t max_tiles = (size_t)p.W * ((n + S2_TILE - 1) / S2_TILE) + nseg + 1;
+            FK_HIP(ctx, ctx->s2_cnt1.reserve((size_t)p.W * p.nchunks * p.nhi * 4));
+            FK_HIP(ctx, ctx->s2_seg.reserve(((size_t)nseg * 4 + 2) * 4));
+            FK_HIP(ctx, ctx->s2_cnt2.reserve(max_tiles * p.nlo * 4));
+            FK_HIP(ctx, ctx->s2_tmp_idx.reserve((size_t)p.W * n * 4));
+            FK_HIP(ctx, ctx->s2_tmp_lo.reserve((size_t)p.W * n * 2));
+            uint32_t *cnt1 = ctx->s2_cnt1.as<uint32_t>();
+            uint32_t *seg_size = ctx->s2_seg.as<uint32_t>(), *seg_start = seg_size + nseg, *seg_tiles = seg_start + nseg, *tile_start = seg_tiles + nseg;
+            uint32_t *cnt2 = ctx->s2_cnt2.as<uint32_t>(), *tmp_idx = ctx->s2_tmp_idx.as<uint32_t>();
+            uint16_t *tmp_lo = ctx->s2_tmp_lo.as<uint16_t>();
+            hipLaunchKernelGGL(s2_hist1_kernel, dim3(p.nchunks, p.W), dim3(SORT_THREADS), p.nhi * 4, st, digits, n, p.chunk, p.nchunks, p.LB, p.nhi, cnt1);
+            hipLaunchKernelGGL(s2_prefix1_kernel, dim3(p.W), dim3(1024), p.nhi * 4, st, cnt1, p.nchunks, p.nhi, seg_size, seg_start, seg_tiles);
+            hipLaunchKernelGGL(s2_tile_prefix_kernel, dim3(1), dim3(64), 0, st, seg_tiles, nseg, tile_start);
+            hipLaunchKernelGGL(s2_scatter1_kernel, dim3(p.nchunks, p.W), dim3(SORT_THREADS), p.nhi * 4, st, digits, n, p.chunk, p.nchunks, p.LB, p.nhi, cnt1,
+                               seg_start, tmp_idx, tmp_lo);
+            FK_HIP(ctx, hipGetLastError());
+            uint32_t n_tiles = 0;
+            FK_HIP(ctx, hipMemcpyAsync(&n_tiles, tile_start + nseg, 4, hipMemcpyDeviceToHost, st));
+            FK_HIP(ctx, hipStreamSynchronize(st));
+            FK_DBG(ctx, "msm_sort_pass1");
+            if (n_tiles > max_tiles) FK_SET_ERR(ctx, FK_ERR_HIP, "msm: tile count %u exceeds the bound %zu", n_tiles, max_tiles);
+            if (n_tiles) {
+                hipLaunchKernelGGL(s2_hist2_kernel, dim3(n_tiles), dim3(256), p.nlo * 4, st, tmp_lo, n, p.nhi, p.nlo, tile_start, nseg, seg_start, seg_size, cnt2);
+            }
+            hipLaunchKernelGGL(s2_prefix2_kernel, dim3(nseg), dim3(1024), 0, st, cnt2, p.nhi, p.nlo, p.B, tile_start, seg_start, p.cap, totals, starts,
+                               ctx->overlist.as<OverEntry>(), d_nover, over_cap);
+            if (n_tiles) {
+                hipLaunchKernelGGL(s2_scatter2_kernel, dim3(n_tiles), dim3(256), p.nlo * 4, st, tmp_idx, tmp_lo, n, p.nhi, p.nlo, p.B, tile_start, nseg, seg_start,
+                                   seg_size, cnt2, starts, sorted);
+            }
+            FK_HIP(ctx, hipGetLastError());
+            FK_DBG(ctx, "msm_sort_pass2");
+        }
         // size-ordered bucket -> lane assignment
         FK_HIP(ctx, hipMemsetAsync(size_bins, 0, SIZE_BINS * 4, st));
         hipLaunchKernelGGL(msm_size_hist_kernel, dim3((unsigned)std::min<size_t>((WB + 255) / 256, 1024)), dim3(256), 0, st, totals, WB, p.cap, size_bins);
         hipLaunchKernelGGL(msm_size_scan_kernel, dim3(1), dim3(SIZE_BINS), 0, st, size_bins);
-        hipLaunchKernelGGL(msm_size_scatter_kernel, dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, totals, WB, p.cap, size_bins, perm);
+        hipLaunchKernelGGL(msm_size_scatter_kernel, dim3((unsigned)((WB + 1023) / 1024)), dim3(1024), 0, st, totals, WB, p.cap, size_bins, perm);
         FK_HIP(ctx, hipGetLastError());
         FK_DBG(ctx, "msm_size_order");
         ctx->last_sort_scalars = (const void *)d_scalars; ctx->last_sort_n = n; ctx->last_sort_c = p.c;

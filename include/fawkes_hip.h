@@ -59,7 +59,7 @@ enum {
 int fk_init(int device_id, fk_ctx **out);
 void fk_free(fk_ctx *ctx);
 const char *fk_last_error(const fk_ctx *ctx);
-/* 0 = library default.  Pippenger window bits (4..16) used by subsequent MSMs; for tests/tuning. */
+/* 0 = library default.  Pippenger window bits (2..22) used by subsequent MSMs; for tests/tuning. */
 int fk_set_window_bits(fk_ctx *ctx, unsigned c);
 
 /* ---------------------------------------------------------------- device buffers (for resident inputs) */

@@ -85,7 +85,7 @@ def test_msm_oversized_bucket_path(ctx, oracle):
     assert ctx.msm_g2(g2b, s2).tobytes() == oracle.msm_g2(g2b, s2).tobytes()
 
 
-@pytest.mark.parametrize('c', [2, 5, 8, 13, 16])
+@pytest.mark.parametrize('c', [2, 5, 8, 13, 16, 17, 19, 21])
 def test_msm_window_bits(ctx, oracle, c):
     n = 1500
     rng = np.random.default_rng(c)
@@ -94,6 +94,30 @@ def test_msm_window_bits(ctx, oracle, c):
     ctx.set_window_bits(c)
     try:
         assert ctx.msm_g1(bases, sc).tobytes() == want
+    finally:
+        ctx.set_window_bits(0)
+
+
+def test_msm_two_pass_sort_paths(ctx, oracle):
+    """c > 16 goes through the two-pass radix sort (high bits, then low bits per segment): ragged sizes, skewed
+    scalars that overflow one bucket, G1 and G2, several window sizes; FK_SORT2-style forcing is covered by c = 17."""
+    rng = np.random.default_rng(1717)
+    for n, c in ((1, 17), (77, 18), (5000, 17), (40000, 20), (40000, 22)):
+        bases, sc = g1_bases(n, seed=n + c), rand_fr_mont(rng, n, 'witness')
+        if n >= 5000:
+            sc[: n // 3] = fx.mont_fr(1)            # one oversized bucket
+            sc[n // 3: n // 2] = sc[n // 3]         # and another one in every window
+        want = oracle.msm_g1(bases, sc).tobytes()
+        ctx.set_window_bits(c)
+        try:
+            assert ctx.msm_g1(bases, sc).tobytes() == want, (n, c)
+        finally:
+            ctx.set_window_bits(0)
+    g2b, s2 = g2_bases(3000, seed=8), rand_fr_mont(rng, 3000, 'witness')
+    want = oracle.msm_g2(g2b, s2).tobytes()
+    ctx.set_window_bits(18)
+    try:
+        assert ctx.msm_g2(g2b, s2).tobytes() == want
     finally:
         ctx.set_window_bits(0)
 
