@@ -33,17 +33,21 @@ struct MsmPlan {
     uint32_t c, W, B;        // window bits, windows, buckets per window (2^(c-1))
     uint32_t nchunks;
     size_t chunk;
-    uint32_t cap;            // max entries a bucket-lane handles itself
+    uint32_t cap, cap_top;   // max entries a bucket-lane handles itself (all windows but the last / the last, shorter one)
     uint32_t L, T, nblk;     // bucket-reduce: buckets per lane, lanes per window, blocks per window
     bool two_pass;           // c > 16: two-pass radix sort (high bits, then low bits inside each segment)
     uint32_t LB, nhi, nlo;   // low bits of the bucket index, number of high / low bins
 };
 static constexpr uint32_t S2_TILE = 16384;     // entries per second-pass workgroup
 
+// Windows are sized from n.  Sizing them from the number of non-trivial scalars (0 and 1 never reach the ordinary
+// buckets) was measured slower on the witness MSMs: fewer windows win even at bucket loads of ~6 once lanes are
+// size-ordered (G2 accumulate 22.6 ms at c = 20 vs 26.2 ms at c = 16 for 16.7M scalars of which 3.3M are dense).
 static MsmPlan make_plan(size_t n, unsigned forced_c, bool force_two_pass, unsigned chunks_2p = 256) {
     MsmPlan p{};
     p.n = n;
-    uint32_t lg = 0; while (((size_t)1 << (lg + 1)) <= n) lg++;
+    const size_t nd = n ? n : 1;
+    uint32_t lg = 0; while (((size_t)1 << (lg + 1)) <= nd) lg++;
     // large MSMs: bucket loads of ~64 are enough now that lanes are size-ordered, so c grows with n (fewer digits
     // per scalar: 13 at c = 20 instead of 16); c > 16 needs the two-pass sort (the LDS histogram holds 2^15 counters)
     uint32_t c = forced_c ? forced_c : (lg >= 22 ? lg - 5 : (lg >= 18 ? 16 : (lg >= 6 ? lg - 2 : 4)));
@@ -58,8 +62,12 @@ static MsmPlan make_plan(size_t n, unsigned forced_c, bool force_two_pass, unsig
     if (chunk < 16384) chunk = 16384;
     p.chunk = chunk;
     p.nchunks = (uint32_t)((n + chunk - 1) / chunk);
-    size_t mean = n / p.B;
+    size_t mean = nd / p.B;
     p.cap = (uint32_t)std::min<size_t>(2 * mean + 64, 1u << 30);
+    // The short top window (254 - (W-1)c bits) concentrates its entries on few buckets.  Those go through the
+    // oversized-bucket path (64 lanes per 4096-entry segment): handing them to single lanes via a larger cap was
+    // measured slower (and catastrophic when the top window has only a handful of buckets), so the cap is uniform.
+    p.cap_top = p.cap;
     p.L = p.B >= 4096 ? (p.B >= (1u << 18) ? 64 : p.B / 2048) : 1;     // <= 64 buckets per lane
     p.T = p.B / p.L;
     p.nblk = (p.T + 255) / 256;
@@ -122,11 +130,12 @@ __global__ void msm_chunk_prefix_kernel(uint32_t *counts, uint32_t nchunks, uint
 struct OverEntry { uint32_t g, size; };
 
 // one block per window: starts[w][b] = exclusive scan of totals[w][.]; oversized buckets are listed
-__global__ __launch_bounds__(1024) void msm_window_scan_kernel(const uint32_t *totals, uint32_t B, uint32_t cap,
+__global__ __launch_bounds__(1024) void msm_window_scan_kernel(const uint32_t *totals, uint32_t B, uint32_t cap_all, uint32_t cap_top,
                                                                 uint32_t *starts, OverEntry *over, uint32_t *n_over,
                                                                 uint32_t over_cap) {
     __shared__ uint32_t part[1024];
     const uint32_t w = blockIdx.x, tid = threadIdx.x;
+    const uint32_t cap = (w == gridDim.x - 1) ? cap_top : cap_all;
     const uint32_t ipt = (B + 1023) / 1024;
     const uint32_t lo = tid * ipt, hi = lo + ipt < B ? lo + ipt : B;
     uint32_t sum = 0;
@@ -273,10 +282,11 @@ __global__ __launch_bounds__(256) void s2_hist2_kernel(const uint16_t *tmp_lo, s
 
 // one block per high-bin segment, one lane per low bin: prefix over the segment's tiles, bucket totals and starts
 __global__ __launch_bounds__(1024) void s2_prefix2_kernel(uint32_t *cnt2, uint32_t nhi, uint32_t nlo, uint32_t B, const uint32_t *tile_start,
-                                                           const uint32_t *seg_start, uint32_t cap, uint32_t *totals, uint32_t *starts,
+                                                           const uint32_t *seg_start, uint32_t cap_all, uint32_t cap_top, uint32_t W, uint32_t *totals, uint32_t *starts,
                                                            OverEntry *over, uint32_t *n_over, uint32_t over_cap) {
     __shared__ uint32_t part[1024];
     const uint32_t sgm = blockIdx.x, w = sgm / nhi, h = sgm % nhi, b = threadIdx.x;
+    const uint32_t cap = (w == W - 1) ? cap_top : cap_all;
     uint32_t run = 0;
     if (b < nlo) {
         for (uint32_t t = tile_start[sgm]; t < tile_start[sgm + 1]; t++) {
@@ -324,11 +334,14 @@ __global__ __launch_bounds__(256) void s2_scatter2_kernel(const uint32_t *tmp_id
 // binned by min(size, cap) into 1024 classes, largest first (counting sort on the class), and lane t of the
 // accumulate kernel takes bucket perm[t].  VALUUtilization of the accumulate kernels was 80-86 % without this.
 static constexpr uint32_t SIZE_BINS = 1024;
+// monotone, largest first: sizes below 768 get one class each (classes 256..1023), larger ones share 256 coarse classes
 static __device__ __forceinline__ uint32_t size_class(uint32_t size, uint32_t cap) {
     const uint32_t s = size < cap ? size : cap;
-    return (SIZE_BINS - 1) - (uint32_t)(((uint64_t)s * (SIZE_BINS - 1)) / (cap ? cap : 1));      // descending
+    if (s < 768) return (SIZE_BINS - 1) - s;
+    const uint32_t span = cap > 768 ? cap - 768 : 1;
+    return 255u - (uint32_t)(((uint64_t)(s - 768) * 255u) / span);
 }
-__global__ __launch_bounds__(256) void msm_size_hist_kernel(const uint32_t *totals, size_t WB, uint32_t cap, uint32_t *bins) {
+__global__ __launch_bounds__(256) void msm_size_hist_kernel(const uint32_t *totals, size_t WB, uint32_t cap, uint32_t *bins) {   // cap = the larger (top-window) cap
     __shared__ uint32_t sh[SIZE_BINS];
     for (uint32_t i = threadIdx.x; i < SIZE_BINS; i += 256) sh[i] = 0;
     __syncthreads();
@@ -408,11 +421,12 @@ static __device__ __forceinline__ void block_reduce_256(Xyzz<F> &acc, Xyzz<F> *s
 template <class F, int MINW>
 __global__ __launch_bounds__(256, MINW) void msm_accumulate_kernel(const Affine<F> *bases, const uint32_t *sorted, size_t n,
                                                              const uint32_t *starts, const uint32_t *totals, uint32_t B,
-                                                             uint32_t W, uint32_t cap, const uint32_t *perm, Xyzz<F> *buckets) {
+                                                             uint32_t W, uint32_t cap_all, uint32_t cap_top, const uint32_t *perm, Xyzz<F> *buckets) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (size_t)W * B) return;
     const size_t g = perm[t];                 // buckets of similar length share a wave
     const uint32_t w = (uint32_t)(g / B);
+    const uint32_t cap = (w == W - 1) ? cap_top : cap_all;
     const uint32_t *src = sorted + (size_t)w * n + starts[g];
     uint32_t cnt = totals[g];
     if (cnt > cap) cnt = cap;
@@ -434,9 +448,10 @@ struct Task { uint32_t g, seg; };
 template <class F, class FC>
 __global__ __launch_bounds__(64) void msm_overflow_kernel(const Affine<F> *bases, const uint32_t *sorted, size_t n,
                                                           const uint32_t *starts, const uint32_t *totals, uint32_t B,
-                                                          uint32_t cap, const Task *tasks, Xyzz<FC> *partials) {
+                                                          uint32_t W, uint32_t cap_all, uint32_t cap_top, const Task *tasks, Xyzz<FC> *partials) {
     const Task t = tasks[blockIdx.x];
     const uint32_t w = t.g / B;
+    const uint32_t cap = (w == W - 1) ? cap_top : cap_all;
     const uint32_t *src = sorted + (size_t)w * n + starts[t.g];
     const uint32_t size = totals[t.g];
     const uint32_t lo = cap + t.seg * SEG;
@@ -539,7 +554,7 @@ static int msm_run(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars, s
             hipLaunchKernelGGL(msm_chunk_prefix_kernel, dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, counts, p.nchunks, p.B, p.W, totals);
             FK_HIP(ctx, hipGetLastError());
             FK_DBG(ctx, "msm_chunk_prefix");
-            hipLaunchKernelGGL(msm_window_scan_kernel, dim3(p.W), dim3(1024), 0, st, totals, p.B, p.cap, starts,
+            hipLaunchKernelGGL(msm_window_scan_kernel, dim3(p.W), dim3(1024), 0, st, totals, p.B, p.cap, p.cap_top, starts,
                                ctx->overlist.as<OverEntry>(), d_nover, over_cap);
             FK_HIP(ctx, hipGetLastError());
             FK_DBG(ctx, "msm_window_scan");
@@ -574,7 +589,7 @@ static int msm_run(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars, s
             if (n_tiles) {
                 hipLaunchKernelGGL(s2_hist2_kernel, dim3(n_tiles), dim3(256), p.nlo * 4, st, tmp_lo, n, p.nhi, p.nlo, tile_start, nseg, seg_start, seg_size, cnt2);
             }
-            hipLaunchKernelGGL(s2_prefix2_kernel, dim3(nseg), dim3(1024), 0, st, cnt2, p.nhi, p.nlo, p.B, tile_start, seg_start, p.cap, totals, starts,
+            hipLaunchKernelGGL(s2_prefix2_kernel, dim3(nseg), dim3(1024), 0, st, cnt2, p.nhi, p.nlo, p.B, tile_start, seg_start, p.cap, p.cap_top, p.W, totals, starts,
                                ctx->overlist.as<OverEntry>(), d_nover, over_cap);
             if (n_tiles) {
                 hipLaunchKernelGGL(s2_scatter2_kernel, dim3(n_tiles), dim3(256), p.nlo * 4, st, tmp_idx, tmp_lo, n, p.nhi, p.nlo, p.B, tile_start, nseg, seg_start,
@@ -585,9 +600,9 @@ static int msm_run(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars, s
         }
         // size-ordered bucket -> lane assignment
         FK_HIP(ctx, hipMemsetAsync(size_bins, 0, SIZE_BINS * 4, st));
-        hipLaunchKernelGGL(msm_size_hist_kernel, dim3((unsigned)std::min<size_t>((WB + 255) / 256, 1024)), dim3(256), 0, st, totals, WB, p.cap, size_bins);
+        hipLaunchKernelGGL(msm_size_hist_kernel, dim3((unsigned)std::min<size_t>((WB + 255) / 256, 1024)), dim3(256), 0, st, totals, WB, p.cap_top, size_bins);
         hipLaunchKernelGGL(msm_size_scan_kernel, dim3(1), dim3(SIZE_BINS), 0, st, size_bins);
-        hipLaunchKernelGGL(msm_size_scatter_kernel, dim3((unsigned)((WB + 1023) / 1024)), dim3(1024), 0, st, totals, WB, p.cap, size_bins, perm);
+        hipLaunchKernelGGL(msm_size_scatter_kernel, dim3((unsigned)((WB + 1023) / 1024)), dim3(1024), 0, st, totals, WB, p.cap_top, size_bins, perm);
         FK_HIP(ctx, hipGetLastError());
         FK_DBG(ctx, "msm_size_order");
         ctx->last_sort_scalars = (const void *)d_scalars; ctx->last_sort_n = n; ctx->last_sort_c = p.c;
@@ -595,7 +610,7 @@ static int msm_run(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars, s
     std::vector<EventPair> &evv = (sizeof(F) == sizeof(Fq)) ? ctx->ev_acc : ctx->ev_acc2;
     FK_TRY(stats_begin(ctx, evv, (uint64_t)n));
     hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_kernel<F, (sizeof(F) == sizeof(Fq) ? 4 : 1)>), dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, d_bases, sorted, n,
-                       starts, totals, p.B, p.W, p.cap, perm, buckets);
+                       starts, totals, p.B, p.W, p.cap, p.cap_top, perm, buckets);
     FK_HIP(ctx, hipGetLastError());
     FK_DBG(ctx, "msm_accumulate");
     FK_TRY(stats_end(ctx, evv));
@@ -612,7 +627,8 @@ static int msm_run(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars, s
         std::vector<Task> tasks;
         std::vector<OverBucket> obs;
         for (const OverEntry &e : ov) {
-            const uint32_t extra = e.size - p.cap;
+            const uint32_t cap_w = (e.g / p.B == p.W - 1) ? p.cap_top : p.cap;
+            const uint32_t extra = e.size - cap_w;
             const uint32_t nt = (extra + SEG - 1) / SEG;
             obs.push_back(OverBucket{e.g, (uint32_t)tasks.size(), nt});
             for (uint32_t s = 0; s < nt; s++) tasks.push_back(Task{e.g, s});
@@ -627,7 +643,7 @@ static int msm_run(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars, s
         FK_HIP(ctx, hipMemcpyAsync(d_obs, obs.data(), ob, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_overflow_kernel<F, FC>), dim3((unsigned)tasks.size()), dim3(64), 0, st,
                            d_bases, sorted, n, starts,
-                           totals, p.B, p.cap, d_tasks, ctx->partials.as<Xyzz<FC>>());
+                           totals, p.B, p.W, p.cap, p.cap_top, d_tasks, ctx->partials.as<Xyzz<FC>>());
         FK_HIP(ctx, hipGetLastError());
     FK_DBG(ctx, "msm_overflow");
         hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_overflow_fold_kernel<FC>), dim3((unsigned)obs.size()), dim3(64), 0, st, d_obs,
