@@ -39,13 +39,11 @@ struct fk_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     unsigned window_bits = 0;  // 0 = auto
-    unsigned sort2_chunks = 256; // first-pass chunks per window of the two-pass sort (FK_SORT2_CHUNKS)
-    bool force_sort2 = false;    // FK_SORT2=1: use the two-pass bucket sort for every window size (testing)
     unsigned ntt_threads = 512;  // workgroup size cap of the NTT pass kernel (FK_NTT_THREADS overrides)
     std::map<uint32_t, fk::NttDomain *> domains;
     // MSM scratch
     const void *last_sort_scalars = nullptr; size_t last_sort_n = 0; unsigned last_sort_c = 0;   // what `sorted` currently holds
-    fk::DevBuf digits, sorted, counts, totals, starts, buckets, winparts, overlist, tasktab, partials, misc, perm, s2_cnt1, s2_seg, s2_cnt2, s2_tmp_idx, s2_tmp_lo;
+    fk::DevBuf digits, sorted, totals, starts, buckets, winparts, overlist, tasktab, partials, misc, perm, s2_cnt1, s2_seg, s2_cnt2, s2_tmp_idx, s2_tmp_lo;
     // NTT / prover scratch
     fk::DevBuf ntt_s1, ntt_s2, ntt_io, hbuf, sc_a, sc_b, scan_tmp, stage_a, stage_b, stage_c, stage_z, stage_d;
     // stats

@@ -8,10 +8,10 @@
 // MI355X pipeline (all on one stream, no MFMA -- 256-bit modular integer work):
 //   1. msm_digits      scalars leave Montgomery form (bellman's `into_repr`) and are cut into W signed
 //                      c-bit digits (buckets 1..2^(c-1), sign bit) -- halves the bucket count.
-//   2. counting sort   per (window, chunk) histograms live in LDS (up to 2^15 counters = 128 KiB of the
-//                      160 KiB), a scan turns them into offsets, and a second LDS-cursor pass scatters
-//                      point indices so that every bucket's points are contiguous.  No global atomics,
-//                      so skewed witness scalars (many 0/1) cost nothing extra.
+//   2. bucket sort     two-pass radix sort on the bucket index (high bits, then the low 10 bits inside each
+//                      segment): LDS histograms and cursors, every tile ranked and staged in LDS and written as
+//                      contiguous runs.  No global atomics, so skewed witness scalars (many 0/1) cost nothing extra.
+//   2b. size order     buckets are counting-sorted by length so the 64 lanes of a wave run equally long.
 //   3. msm_accumulate  one lane per bucket walks its run with XYZZ mixed additions (8M+2S), gathering
 //                      64-byte affine bases; buckets above `cap` entries hand the excess to
 //   4. msm_overflow    one wave per fixed 4096-entry segment, reduced with wavefront shuffles; then one
@@ -35,30 +35,28 @@ struct MsmPlan {
     size_t chunk;
     uint32_t cap, cap_top;   // max entries a bucket-lane handles itself (all windows but the last / the last, shorter one)
     uint32_t L, T, nblk;     // bucket-reduce: buckets per lane, lanes per window, blocks per window
-    bool two_pass;           // c > 16: two-pass radix sort (high bits, then low bits inside each segment)
     uint32_t LB, nhi, nlo;   // low bits of the bucket index, number of high / low bins
 };
-static constexpr uint32_t S2_TILE = 16384;     // entries per second-pass workgroup
+static constexpr uint32_t S2_TILE = 16384;     // entries per staged sort tile
+static constexpr uint32_t S2_EPT = S2_TILE / 1024;      // entries per lane (1024-lane workgroups)
 
 // Windows are sized from n.  Sizing them from the number of non-trivial scalars (0 and 1 never reach the ordinary
 // buckets) was measured slower on the witness MSMs: fewer windows win even at bucket loads of ~6 once lanes are
 // size-ordered (G2 accumulate 22.6 ms at c = 20 vs 26.2 ms at c = 16 for 16.7M scalars of which 3.3M are dense).
-static MsmPlan make_plan(size_t n, unsigned forced_c, bool force_two_pass, unsigned chunks_2p = 256) {
+static MsmPlan make_plan(size_t n, unsigned forced_c) {
     MsmPlan p{};
     p.n = n;
     const size_t nd = n ? n : 1;
     uint32_t lg = 0; while (((size_t)1 << (lg + 1)) <= nd) lg++;
     // large MSMs: bucket loads of ~64 are enough now that lanes are size-ordered, so c grows with n (fewer digits
-    // per scalar: 13 at c = 20 instead of 16); c > 16 needs the two-pass sort (the LDS histogram holds 2^15 counters)
+    // per scalar: 13 at c = 20 instead of 16)
     uint32_t c = forced_c ? forced_c : (lg >= 22 ? lg - 5 : (lg >= 18 ? 16 : (lg >= 6 ? lg - 2 : 4)));
     if (c < 2) c = 2;
     if (c > 22) c = 22;
     p.c = c;
     p.W = (255 + c - 1) / c;
     p.B = 1u << (c - 1);
-    const bool two_pass_ = force_two_pass || c > 16;
-    // one-pass sort: 128 KiB of LDS counters per workgroup -> few big chunks; two-pass: a few KiB -> many small ones
-    size_t chunk = two_pass_ ? (n + chunks_2p - 1) / chunks_2p : (n + 31) / 32;
+    size_t chunk = (n + 255) / 256;          // first-pass chunks per window
     if (chunk < 16384) chunk = 16384;
     p.chunk = chunk;
     p.nchunks = (uint32_t)((n + chunk - 1) / chunk);
@@ -71,7 +69,6 @@ static MsmPlan make_plan(size_t n, unsigned forced_c, bool force_two_pass, unsig
     p.L = p.B >= 4096 ? (p.B >= (1u << 18) ? 64 : p.B / 2048) : 1;     // <= 64 buckets per lane
     p.T = p.B / p.L;
     p.nblk = (p.T + 255) / 256;
-    p.two_pass = force_two_pass || c > 16;
     p.LB = (c - 1) < 10 ? (c - 1) : 10;
     p.nlo = 1u << p.LB;
     p.nhi = p.B >> p.LB;
@@ -96,95 +93,10 @@ __global__ void msm_digits_kernel(const Fr *scalars, size_t n, uint32_t c, uint3
     }
 }
 
-// ------------------------------------------------------------------------------------------ counting sort
-__global__ __launch_bounds__(SORT_THREADS) void msm_hist_kernel(const uint32_t *digits, size_t n, size_t chunk,
-                                                                 uint32_t nchunks, uint32_t B, uint32_t *counts) {
-    extern __shared__ uint32_t hist[];
-    const uint32_t ch = blockIdx.x, w = blockIdx.y;
-    for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) hist[b] = 0;
-    __syncthreads();
-    const size_t lo = (size_t)ch * chunk, hi = lo + chunk < n ? lo + chunk : n;
-    const uint32_t *dg = digits + (size_t)w * n;
-    for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        uint32_t d = dg[i] & 0x7fffffffu;
-        if (d) atomicAdd(&hist[d - 1], 1u);
-    }
-    __syncthreads();
-    uint32_t *out = counts + ((size_t)w * nchunks + ch) * B;
-    for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) out[b] = hist[b];
-}
-
-// counts[w][ch][b] -> exclusive prefix over ch; totals[w][b] = sum over ch
-__global__ void msm_chunk_prefix_kernel(uint32_t *counts, uint32_t nchunks, uint32_t B, uint32_t W, uint32_t *totals) {
-    size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= (size_t)W * B) return;
-    const uint32_t w = (uint32_t)(g / B), b = (uint32_t)(g % B);
-    uint32_t run = 0;
-    for (uint32_t ch = 0; ch < nchunks; ch++) {
-        uint32_t *p = counts + ((size_t)w * nchunks + ch) * B + b;
-        uint32_t v = *p; *p = run; run += v;
-    }
-    totals[g] = run;
-}
-
+// ------------------------------------------------------------------------------------------ bucket sort
 struct OverEntry { uint32_t g, size; };
 
-// one block per window: starts[w][b] = exclusive scan of totals[w][.]; oversized buckets are listed
-__global__ __launch_bounds__(1024) void msm_window_scan_kernel(const uint32_t *totals, uint32_t B, uint32_t cap_all, uint32_t cap_top,
-                                                                uint32_t *starts, OverEntry *over, uint32_t *n_over,
-                                                                uint32_t over_cap) {
-    __shared__ uint32_t part[1024];
-    const uint32_t w = blockIdx.x, tid = threadIdx.x;
-    const uint32_t cap = (w == gridDim.x - 1) ? cap_top : cap_all;
-    const uint32_t ipt = (B + 1023) / 1024;
-    const uint32_t lo = tid * ipt, hi = lo + ipt < B ? lo + ipt : B;
-    uint32_t sum = 0;
-    for (uint32_t b = lo; b < hi; b++) {
-        uint32_t v = totals[(size_t)w * B + b];
-        sum += v;
-        if (v > cap) {
-            uint32_t k = atomicAdd(n_over, 1u);
-            if (k < over_cap) { over[k].g = w * B + b; over[k].size = v; }
-        }
-    }
-    part[tid] = sum;
-    __syncthreads();
-    for (uint32_t off = 1; off < 1024; off <<= 1) {
-        uint32_t v = tid >= off ? part[tid - off] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    uint32_t run = part[tid] - sum;  // exclusive
-    for (uint32_t b = lo; b < hi; b++) {
-        starts[(size_t)w * B + b] = run;
-        run += totals[(size_t)w * B + b];
-    }
-}
-
-__global__ __launch_bounds__(SORT_THREADS) void msm_scatter_kernel(const uint32_t *digits, size_t n, size_t chunk,
-                                                                    uint32_t nchunks, uint32_t B, const uint32_t *counts,
-                                                                    const uint32_t *starts, uint32_t *sorted) {
-    extern __shared__ uint32_t cursor[];
-    const uint32_t ch = blockIdx.x, w = blockIdx.y;
-    const uint32_t *cnt = counts + ((size_t)w * nchunks + ch) * B;
-    const uint32_t *st = starts + (size_t)w * B;
-    for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) cursor[b] = st[b] + cnt[b];
-    __syncthreads();
-    const size_t lo = (size_t)ch * chunk, hi = lo + chunk < n ? lo + chunk : n;
-    const uint32_t *dg = digits + (size_t)w * n;
-    uint32_t *out = sorted + (size_t)w * n;
-    for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        uint32_t d = dg[i];
-        uint32_t bkt = d & 0x7fffffffu;
-        if (bkt) {
-            uint32_t pos = atomicAdd(&cursor[bkt - 1], 1u);
-            out[pos] = (uint32_t)i | (d & 0x80000000u);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------ two-pass radix sort (c > 16)
+// ------------------------------------------------------------------------------------------ two-pass radix sort
 // Pass 1 partitions each window's entries by the high bits of the bucket index (<= 2^11 bins, LDS counters and
 // cursors), pass 2 sorts every high-bin segment by the low bits (<= 2^10 bins) in tiles of S2_TILE entries.  Both
 // passes write through a few hundred open lines per workgroup, so stores combine in L2 instead of the one-pass
@@ -238,24 +150,75 @@ __global__ void s2_tile_prefix_kernel(const uint32_t *seg_tiles, uint32_t nseg, 
     tile_start[nseg] = run;
 }
 
-__global__ __launch_bounds__(SORT_THREADS) void s2_scatter1_kernel(const uint32_t *digits, size_t n, size_t chunk, uint32_t nchunks, uint32_t LB,
-                                                                    uint32_t nhi, const uint32_t *cnt1, const uint32_t *seg_start, uint32_t *tmp_idx,
-                                                                    uint16_t *tmp_lo) {
-    extern __shared__ uint32_t cursor[];
-    const uint32_t ch = blockIdx.x, w = blockIdx.y;
+// First-pass scatter, LDS-staged like the second one: the chunk is walked in sub-tiles of S2_TILE entries; each sub-tile
+// is ranked per high bin, laid out in bin order in LDS and written as contiguous runs (idx: 4 B, low bits: 2 B per
+// entry) behind the workgroup's per-bin cursors.
+static constexpr uint32_t S2_MAX_HI = 2048;             // c <= 22  ->  at most 2^11 high bins
+__global__ __launch_bounds__(1024) void s2_scatter1_kernel(const uint32_t *digits, size_t n, size_t chunk, uint32_t nchunks, uint32_t LB,
+                                                            uint32_t nhi, const uint32_t *cnt1, const uint32_t *seg_start, uint32_t *tmp_idx,
+                                                            uint16_t *tmp_lo) {
+    __shared__ uint32_t cursor[S2_MAX_HI];      // next free slot of the bin (window-relative)
+    __shared__ uint32_t lcnt[S2_MAX_HI];        // entries of the sub-tile in the bin
+    __shared__ uint32_t lexc[S2_MAX_HI];        // exclusive offsets inside the sub-tile
+    __shared__ uint32_t part[1024];
+    __shared__ uint32_t stage_idx[S2_TILE];
+    __shared__ uint16_t stage_lo[S2_TILE];
+    const uint32_t ch = blockIdx.x, w = blockIdx.y, tid = threadIdx.x;
     const uint32_t *cnt = cnt1 + ((size_t)w * nchunks + ch) * nhi;
-    for (uint32_t b = threadIdx.x; b < nhi; b += blockDim.x) cursor[b] = seg_start[(size_t)w * nhi + b] + cnt[b];
-    __syncthreads();
-    const size_t lo = (size_t)ch * chunk, hi = lo + chunk < n ? lo + chunk : n;
+    for (uint32_t b = tid; b < S2_MAX_HI; b += 1024) cursor[b] = b < nhi ? seg_start[(size_t)w * nhi + b] + cnt[b] : 0;
+    const size_t c_lo = (size_t)ch * chunk, c_hi = c_lo + chunk < n ? c_lo + chunk : n;
     const uint32_t *dg = digits + (size_t)w * n;
     const uint32_t lomask = (1u << LB) - 1;
-    for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        const uint32_t d = dg[i], bkt = d & 0x7fffffffu;
-        if (bkt) {
-            const uint32_t pos = atomicAdd(&cursor[(bkt - 1) >> LB], 1u);
-            tmp_idx[(size_t)w * n + pos] = (uint32_t)i | (d & 0x80000000u);
-            tmp_lo[(size_t)w * n + pos] = (uint16_t)((bkt - 1) & lomask);
+    uint32_t *oidx = tmp_idx + (size_t)w * n;
+    uint16_t *olo = tmp_lo + (size_t)w * n;
+    for (size_t sub = c_lo; sub < c_hi; sub += S2_TILE) {
+        const uint32_t cntt = (uint32_t)(c_hi - sub < S2_TILE ? c_hi - sub : S2_TILE);
+        lcnt[tid] = 0; lcnt[tid + 1024] = 0;
+        __syncthreads();
+        uint32_t e_idx[S2_EPT], e_bin[S2_EPT], e_lo[S2_EPT], e_rank[S2_EPT];
+#pragma unroll
+        for (uint32_t j = 0; j < S2_EPT; j++) {
+            const uint32_t k = tid + j * 1024;
+            e_bin[j] = 0xffffffffu;
+            if (k < cntt) {
+                const uint32_t d = dg[sub + k], bkt = d & 0x7fffffffu;
+                if (bkt) {
+                    e_idx[j] = (uint32_t)(sub + k) | (d & 0x80000000u);
+                    e_bin[j] = (bkt - 1) >> LB; e_lo[j] = (bkt - 1) & lomask;
+                    e_rank[j] = atomicAdd(&lcnt[e_bin[j]], 1u);
+                }
+            }
         }
+        __syncthreads();
+        // exclusive scan over the (<= 2048) bins: two bins per lane
+        const uint32_t c0 = lcnt[2 * tid], c1 = lcnt[2 * tid + 1];
+        part[tid] = c0 + c1;
+        __syncthreads();
+        for (uint32_t off = 1; off < 1024; off <<= 1) {
+            const uint32_t v = tid >= off ? part[tid - off] : 0;
+            __syncthreads();
+            part[tid] += v;
+            __syncthreads();
+        }
+        const uint32_t ex = part[tid] - (c0 + c1);
+        lexc[2 * tid] = ex; lexc[2 * tid + 1] = ex + c0;
+        const uint32_t total = part[1023];
+        __syncthreads();
+#pragma unroll
+        for (uint32_t j = 0; j < S2_EPT; j++) {
+            if (e_bin[j] != 0xffffffffu) { const uint32_t q = lexc[e_bin[j]] + e_rank[j]; stage_idx[q] = e_idx[j]; stage_lo[q] = (uint16_t)e_lo[j]; }
+        }
+        __syncthreads();
+        for (uint32_t q = tid; q < total; q += 1024) {
+            uint32_t lo_ = 0, hi_ = S2_MAX_HI;          // last bin with lexc[bin] <= q (empty bins share the next bin's offset)
+            while (hi_ - lo_ > 1) { const uint32_t mid = (lo_ + hi_) >> 1; if (lexc[mid] <= q) lo_ = mid; else hi_ = mid; }
+            const uint32_t dst = cursor[lo_] + (q - lexc[lo_]);
+            oidx[dst] = stage_idx[q];
+            olo[dst] = stage_lo[q];
+        }
+        __syncthreads();
+        cursor[tid] += lcnt[tid]; cursor[tid + 1024] += lcnt[tid + 1024];
+        __syncthreads();
     }
 }
 
@@ -313,19 +276,53 @@ __global__ __launch_bounds__(1024) void s2_prefix2_kernel(uint32_t *cnt2, uint32
     }
 }
 
-__global__ __launch_bounds__(256) void s2_scatter2_kernel(const uint32_t *tmp_idx, const uint16_t *tmp_lo, size_t n, uint32_t nhi, uint32_t nlo, uint32_t B,
-                                                           const uint32_t *tile_start, uint32_t nseg, const uint32_t *seg_start, const uint32_t *seg_size,
-                                                           const uint32_t *cnt2, const uint32_t *starts, uint32_t *sorted) {
-    extern __shared__ uint32_t cursor[];
-    const uint32_t tile = blockIdx.x;
+// Second-pass scatter with LDS staging: entries of the tile are ranked per low bin (LDS counters), placed in bin order in
+// an LDS staging buffer and then written out so that consecutive lanes store consecutive addresses of one bucket run
+// (64-byte runs on average) instead of one 4-byte store per lane to an arbitrary line.
+__global__ __launch_bounds__(1024) void s2_scatter2_kernel(const uint32_t *tmp_idx, const uint16_t *tmp_lo, size_t n, uint32_t nhi, uint32_t nlo, uint32_t B,
+                                                            const uint32_t *tile_start, uint32_t nseg, const uint32_t *seg_start, const uint32_t *seg_size,
+                                                            const uint32_t *cnt2, const uint32_t *starts, uint32_t *sorted) {
+    __shared__ uint32_t lcnt[1024];          // per-bin count, then exclusive offset inside the tile
+    __shared__ uint32_t gbase[1024];         // global position (window-relative) of this tile's first entry of the bin
+    __shared__ uint32_t stage_idx[S2_TILE];
+    __shared__ uint16_t stage_lo[S2_TILE];
+    const uint32_t tile = blockIdx.x, tid = threadIdx.x;
     const uint32_t sgm = s2_find_segment(tile_start, nseg, tile), w = sgm / nhi, h = sgm % nhi, t = tile - tile_start[sgm];
-    for (uint32_t b = threadIdx.x; b < nlo; b += 256) cursor[b] = starts[(size_t)w * B + (size_t)h * nlo + b] + cnt2[(size_t)tile * nlo + b];
+    lcnt[tid] = 0;
+    gbase[tid] = tid < nlo ? starts[(size_t)w * B + (size_t)h * nlo + tid] + cnt2[(size_t)tile * nlo + tid] : 0;
     __syncthreads();
-    const uint32_t size = seg_size[sgm], lo = t * S2_TILE, hi = lo + S2_TILE < size ? lo + S2_TILE : size;
-    const size_t base = (size_t)w * n + seg_start[sgm];
-    for (uint32_t k = lo + threadIdx.x; k < hi; k += 256) {
-        const uint32_t pos = atomicAdd(&cursor[tmp_lo[base + k]], 1u);
-        sorted[(size_t)w * n + pos] = tmp_idx[base + k];
+    const uint32_t size = seg_size[sgm], lo = t * S2_TILE, cnt = (lo + S2_TILE < size ? lo + S2_TILE : size) - lo;
+    const size_t base = (size_t)w * n + seg_start[sgm] + lo;
+    uint32_t e_idx[S2_EPT], e_lo[S2_EPT], e_rank[S2_EPT];
+#pragma unroll
+    for (uint32_t j = 0; j < S2_EPT; j++) {
+        const uint32_t k = tid + j * 1024;
+        if (k < cnt) { e_idx[j] = tmp_idx[base + k]; e_lo[j] = tmp_lo[base + k]; e_rank[j] = atomicAdd(&lcnt[e_lo[j]], 1u); }
+    }
+    __syncthreads();
+    // exclusive scan of the 1024 bin counts
+    const uint32_t mine = lcnt[tid];
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+        const uint32_t v = tid >= off ? lcnt[tid - off] : 0;
+        __syncthreads();
+        lcnt[tid] += v;
+        __syncthreads();
+    }
+    const uint32_t excl = lcnt[tid] - mine;
+    __syncthreads();
+    lcnt[tid] = excl;
+    __syncthreads();
+#pragma unroll
+    for (uint32_t j = 0; j < S2_EPT; j++) {
+        const uint32_t k = tid + j * 1024;
+        if (k < cnt) { const uint32_t q = lcnt[e_lo[j]] + e_rank[j]; stage_idx[q] = e_idx[j]; stage_lo[q] = (uint16_t)e_lo[j]; }
+    }
+    __syncthreads();
+    uint32_t *out = sorted + (size_t)w * n;
+    for (uint32_t q = tid; q < cnt; q += 1024) {
+        const uint32_t b = stage_lo[q];
+        out[gbase[b] + (q - lcnt[b])] = stage_idx[q];
     }
 }
 
@@ -518,12 +515,11 @@ static int msm_run(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars, s
     *out = Xyzz<F>::inf();
     if (n == 0) return FK_OK;
     if (n >= ((size_t)1 << 31)) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "msm: n too large");
-    const MsmPlan p = make_plan(n, ctx->window_bits, ctx->force_sort2, ctx->sort2_chunks);
+    const MsmPlan p = make_plan(n, ctx->window_bits);
     hipStream_t st = ctx->stream;
     const size_t WB = (size_t)p.W * p.B;
     FK_HIP(ctx, ctx->digits.reserve((size_t)p.W * n * 4));
     FK_HIP(ctx, ctx->sorted.reserve((size_t)p.W * n * 4));
-    if (!p.two_pass) FK_HIP(ctx, ctx->counts.reserve((size_t)p.W * p.nchunks * p.B * 4));
     FK_HIP(ctx, ctx->totals.reserve(WB * 4));
     FK_HIP(ctx, ctx->starts.reserve(WB * 4));
     FK_HIP(ctx, ctx->buckets.reserve(WB * sizeof(Xyzz<F>)));
@@ -532,7 +528,7 @@ static int msm_run(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars, s
     FK_HIP(ctx, ctx->overlist.reserve(over_cap * sizeof(OverEntry) + 16));
     uint32_t *d_nover = (uint32_t *)((char *)ctx->overlist.p + over_cap * sizeof(OverEntry));
     uint32_t *digits = ctx->digits.as<uint32_t>(), *sorted = ctx->sorted.as<uint32_t>();
-    uint32_t *counts = ctx->counts.as<uint32_t>(), *totals = ctx->totals.as<uint32_t>(), *starts = ctx->starts.as<uint32_t>();
+    uint32_t *totals = ctx->totals.as<uint32_t>(), *starts = ctx->starts.as<uint32_t>();
     Xyzz<F> *buckets = ctx->buckets.as<Xyzz<F>>(), *winparts = ctx->winparts.as<Xyzz<F>>();
     FK_HIP(ctx, ctx->perm.reserve(WB * 4 + SIZE_BINS * 4));
     uint32_t *perm = ctx->perm.as<uint32_t>(), *size_bins = perm + WB;
@@ -544,26 +540,7 @@ static int msm_run(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars, s
         FK_HIP(ctx, hipGetLastError());
         FK_DBG(ctx, "msm_digits");
         FK_HIP(ctx, hipMemsetAsync(d_nover, 0, 4, st));
-        if (!p.two_pass) {
-            const size_t lds = (size_t)p.B * 4;
-            FK_HIP(ctx, hipFuncSetAttribute((const void *)msm_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            FK_HIP(ctx, hipFuncSetAttribute((const void *)msm_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(msm_hist_kernel, dim3(p.nchunks, p.W), dim3(SORT_THREADS), lds, st, digits, n, p.chunk, p.nchunks, p.B, counts);
-            FK_HIP(ctx, hipGetLastError());
-            FK_DBG(ctx, "msm_hist");
-            hipLaunchKernelGGL(msm_chunk_prefix_kernel, dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, counts, p.nchunks, p.B, p.W, totals);
-            FK_HIP(ctx, hipGetLastError());
-            FK_DBG(ctx, "msm_chunk_prefix");
-            hipLaunchKernelGGL(msm_window_scan_kernel, dim3(p.W), dim3(1024), 0, st, totals, p.B, p.cap, p.cap_top, starts,
-                               ctx->overlist.as<OverEntry>(), d_nover, over_cap);
-            FK_HIP(ctx, hipGetLastError());
-            FK_DBG(ctx, "msm_window_scan");
-            hipLaunchKernelGGL(msm_scatter_kernel, dim3(p.nchunks, p.W), dim3(SORT_THREADS), lds, st, digits, n, p.chunk, p.nchunks, p.B,
-                               counts, starts, sorted);
-            FK_HIP(ctx, hipGetLastError());
-            FK_DBG(ctx, "msm_scatter");
-
-        } else {
+        {
             const uint32_t nseg = p.W * p.nhi;
             const size_t max_tiles = (size_t)p.W * ((n + S2_TILE - 1) / S2_TILE) + nseg + 1;
             FK_HIP(ctx, ctx->s2_cnt1.reserve((size_t)p.W * p.nchunks * p.nhi * 4));
@@ -578,7 +555,7 @@ static int msm_run(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars, s
             hipLaunchKernelGGL(s2_hist1_kernel, dim3(p.nchunks, p.W), dim3(SORT_THREADS), p.nhi * 4, st, digits, n, p.chunk, p.nchunks, p.LB, p.nhi, cnt1);
             hipLaunchKernelGGL(s2_prefix1_kernel, dim3(p.W), dim3(1024), p.nhi * 4, st, cnt1, p.nchunks, p.nhi, seg_size, seg_start, seg_tiles);
             hipLaunchKernelGGL(s2_tile_prefix_kernel, dim3(1), dim3(64), 0, st, seg_tiles, nseg, tile_start);
-            hipLaunchKernelGGL(s2_scatter1_kernel, dim3(p.nchunks, p.W), dim3(SORT_THREADS), p.nhi * 4, st, digits, n, p.chunk, p.nchunks, p.LB, p.nhi, cnt1,
+            hipLaunchKernelGGL(s2_scatter1_kernel, dim3(p.nchunks, p.W), dim3(1024), 0, st, digits, n, p.chunk, p.nchunks, p.LB, p.nhi, cnt1,
                                seg_start, tmp_idx, tmp_lo);
             FK_HIP(ctx, hipGetLastError());
             uint32_t n_tiles = 0;
@@ -592,7 +569,7 @@ static int msm_run(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars, s
             hipLaunchKernelGGL(s2_prefix2_kernel, dim3(nseg), dim3(1024), 0, st, cnt2, p.nhi, p.nlo, p.B, tile_start, seg_start, p.cap, p.cap_top, p.W, totals, starts,
                                ctx->overlist.as<OverEntry>(), d_nover, over_cap);
             if (n_tiles) {
-                hipLaunchKernelGGL(s2_scatter2_kernel, dim3(n_tiles), dim3(256), p.nlo * 4, st, tmp_idx, tmp_lo, n, p.nhi, p.nlo, p.B, tile_start, nseg, seg_start,
+                hipLaunchKernelGGL(s2_scatter2_kernel, dim3(n_tiles), dim3(1024), 0, st, tmp_idx, tmp_lo, n, p.nhi, p.nlo, p.B, tile_start, nseg, seg_start,
                                    seg_size, cnt2, starts, sorted);
             }
             FK_HIP(ctx, hipGetLastError());

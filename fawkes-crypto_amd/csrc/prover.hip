@@ -65,7 +65,6 @@ int fk_init(int device_id, fk_ctx **out) {
     fk_ctx *ctx = new fk_ctx();
     ctx->device = device_id;
     { const char *d = getenv("FK_DEBUG"); ctx->debug = d && d[0] && d[0] != '0'; }
-    { const char *a = getenv("FK_SORT2"); if (a) ctx->force_sort2 = a[0] == '1'; a = getenv("FK_SORT2_CHUNKS"); if (a && atoi(a) >= 1 && atoi(a) <= 4096) ctx->sort2_chunks = (unsigned)atoi(a); }
     { const char *t = getenv("FK_NTT_THREADS"); if (t) { int v = atoi(t); if (v == 64 || v == 128 || v == 256 || v == 512 || v == 1024) ctx->ntt_threads = (unsigned)v; } }
     if (hipStreamCreate(&ctx->stream) != hipSuccess) { delete ctx; return FK_ERR_HIP; }
     *out = ctx;
@@ -77,7 +76,7 @@ void fk_free(fk_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     ntt_free_domains(ctx);
-    for (DevBuf *b : {&ctx->digits, &ctx->sorted, &ctx->counts, &ctx->totals, &ctx->starts, &ctx->buckets, &ctx->winparts,
+    for (DevBuf *b : {&ctx->digits, &ctx->sorted, &ctx->totals, &ctx->starts, &ctx->buckets, &ctx->winparts,
                       &ctx->overlist, &ctx->tasktab, &ctx->partials, &ctx->misc, &ctx->perm, &ctx->s2_cnt1, &ctx->s2_seg, &ctx->s2_cnt2,
                       &ctx->s2_tmp_idx, &ctx->s2_tmp_lo, &ctx->ntt_s1, &ctx->ntt_s2, &ctx->ntt_io,
                       &ctx->hbuf, &ctx->sc_a, &ctx->sc_b, &ctx->scan_tmp, &ctx->stage_a, &ctx->stage_b, &ctx->stage_c,
