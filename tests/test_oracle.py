@@ -27,6 +27,15 @@ def test_ff_uint_kats(oracle):
         assert g(oracle.fe_pow(oracle.FX, f(a), int(e))) == int(want)
     for a, want in k['neg']:
         assert g(oracle.fe_neg(oracle.FX, f(a))) == int(want)
+    # legendre symbol = a^((p-1)/2) and the sqrt KATs (ff-uint_tests.rs:102-141) through the same pow / mul code
+    for a, want in k['legendre']:
+        l = g(oracle.fe_pow(oracle.FX, f(a), (p - 1) // 2))
+        assert (0 if l == 0 else (1 if l == 1 else -1)) == want and l in (0, 1, p - 1)
+    for a, root in k['sqrt']:
+        if root is None:
+            assert g(oracle.fe_pow(oracle.FX, f(a), (p - 1) // 2)) == p - 1          # non-residue: no root
+        else:
+            assert g(oracle.fe_mul(oracle.FX, f(root), f(root))) == int(a)
 
 
 def test_bn254_constants(oracle):
