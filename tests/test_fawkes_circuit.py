@@ -1,0 +1,126 @@
+"""CPU tests of the restated circuit DSL (oracle/fawkes_circuit.py): BASELINE configs[0], the reference's own
+Groth16 test circuit (tests/bellman_groth16.rs:19-48, poseidon merkle proof of depth 32).  Pins: published known
+answers of keccak-256 / ChaCha20, the gate counts in the reference's README.md:46-52, satisfiability, and the
+Groth16 pairing equation on a proof produced by the C oracle for this constraint system."""
+import hashlib
+import random
+
+import numpy as np
+
+import bn254_ref as ref
+import fawkes_circuit as fc
+import fixtures as fx
+from helpers import golden, TOXIC
+
+
+def test_keccak256_known_answers():
+    assert fc.keccak256(b'').hex() == 'c5d2460186f7233c927e7db2dcc703c0e500b653ca82273b7bfad8045d85a470'
+    assert fc.keccak256(b'abc').hex() == '4e03657aea45a94fc7d47ba826c8d667c0d1e6e33a64a036ec44f58fa12d6c45'
+    # the sponge core against hashlib's SHA3 (same permutation, different domain byte): swap the padding byte
+    msg = bytes(range(200)) * 3
+    a = bytearray(msg) + b'\x06'
+    while len(a) % 136:
+        a.append(0)
+    a[-1] |= 0x80
+    st = [[0] * 5 for _ in range(5)]
+    for off in range(0, len(a), 136):
+        for i in range(17):
+            st[i % 5][i // 5] ^= int.from_bytes(a[off + 8 * i:off + 8 * i + 8], 'little')
+        st = fc._keccak_f(st)
+    assert b''.join(st[i % 5][i // 5].to_bytes(8, 'little') for i in range(4)) == hashlib.sha3_256(msg).digest()
+
+
+def test_chacha20_known_answers():
+    """zero key, zero nonce keystream (the djb / RFC 7539 A.1 vectors rand_chacha's own tests use)"""
+    ks = b''.join(w.to_bytes(4, 'little') for blk in (0, 1) for w in fc.chacha20_block([0] * 8, blk))
+    assert ks[:32].hex() == '76b8e0ada0f13d90405d6ae55386bd28bdd219b8a08ded1aa836efcc8b770dc7'
+    assert ks[64:96].hex() == '9f07e7be5551387a98ba977c732d080dcb0f29a048e3656912c6533e32ee7aed'
+
+
+def test_seedbox_sampling_is_montgomery_rejection():
+    sb = fc.SeedboxChaCha20(b'x')
+    sb2 = fc.SeedboxChaCha20(b'x')
+    v = sb.gen_fr()
+    limbs = [sb2.next_u64() for _ in range(4)]
+    limbs[3] &= (1 << 62) - 1
+    mont = sum(l << (64 * i) for i, l in enumerate(limbs))
+    if mont < ref.R:                       # first draw accepted: value * 2^256 == sampled limbs
+        assert ref.to_mont(v, ref.R) == mont
+    assert 0 <= v < ref.R
+
+
+def test_poseidon_gate_counts_match_reference_readme():
+    """README.md:46-52: poseidon hash (4, 8, 54) = 255 constraints; poseidon merkle proof 32 = 7328"""
+    rnd = random.Random(1)
+    p4 = fc.PoseidonParams(4, 8, 54)
+    cs = fc.CS()
+    ins = [cs.alloc(rnd.randrange(ref.R)) for _ in range(3)]
+    h = fc.c_poseidon(ins, p4)
+    assert len(cs.gates) == 255 and cs.satisfied()
+    assert h.value == fc.poseidon([i.value for i in ins], p4)
+
+    p3 = fc.PoseidonParams(3, 8, 53)
+    cs = fc.CS()
+    leaf = cs.alloc(rnd.randrange(ref.R))
+    sib = [cs.alloc(rnd.randrange(ref.R)) for _ in range(32)]
+    bits = [rnd.randrange(2) for _ in range(32)]
+    path = [cs.alloc(b) for b in bits]       # unchecked bits: the README count excludes the 32 assert_bit gates
+    root = fc.c_poseidon_merkle_proof_root(leaf, sib, path, p3)
+    assert len(cs.gates) == 7328 and cs.satisfied()
+    assert root.value == fc.poseidon_merkle_proof_root(leaf.value, [s.value for s in sib], bits, p3)
+
+
+def _instance(seed=20261003):
+    rnd = random.Random(seed)
+    leaf = rnd.randrange(ref.R)
+    sib = [rnd.randrange(ref.R) for _ in range(32)]
+    path = [rnd.randrange(2) for _ in range(32)]
+    return leaf, sib, path
+
+
+def test_config0_shape_and_witness():
+    """7328 + 32 assert_bit + inputize + assert_eq = 7362 gates, 7394 aux, 2 inputs, m = 2^13"""
+    cs, root = fc.poseidon_merkle_circuit(*_instance())
+    assert (len(cs.gates), cs.num_aux, cs.num_input) == (7362, 7394, 2)
+    assert ref.next_pow2(len(cs.gates) + cs.num_input) == 1 << 13
+    assert cs.z_in == [1, root] and cs.z_aux[0] == root
+    assert cs.satisfied()
+    # two as_const probes per product (num.rs:249), one per switch (num.rs:162)
+    assert len(cs.const_tracker) == 32 * (2 * (61 * 3 + 8 * 6) + 1 + 2)
+    cs.z_aux[40] ^= 1                          # flip a path bit: the root no longer matches
+    assert not cs.satisfied()
+    # a path bit that is not boolean violates its assert_bit gate only
+    cs2, _ = fc.poseidon_merkle_circuit(*_instance())
+    g = cs2.gates[1 + 5]                       # gate 0 is inputize, then the 32 assert_bit gates
+    assert g[0] == [(1, ('a', 34 + 5))] and g[1] == [(ref.R - 1, ('i', 0)), (1, ('a', 34 + 5))] and g[2] == [(0, ('i', 0))]
+
+
+def test_merkle_switch_orders_children():
+    p = fc.PoseidonParams(3, 8, 53)
+    a, b = 5, 7
+    assert fc.poseidon_merkle_proof_root(a, [b], [0], p) == fc.poseidon([a, b], p)
+    assert fc.poseidon_merkle_proof_root(a, [b], [1], p) == fc.poseidon([b, a], p)
+    assert fc.poseidon([a, b], p) != fc.poseidon([b, a], p)
+
+
+def test_config0_oracle_proof_verifies_and_matches_golden(oracle):
+    """prove(params, root, (leaf, proof), circuit) then verify(vk, proof, inputs): tests/bellman_groth16.rs:43-46"""
+    g = golden('poseidon_merkle_golden.json')
+    leaf, sib, path = _instance(g['seed'])
+    cs, root = fc.poseidon_merkle_circuit(leaf, sib, path)
+    assert '%064x' % root == g['root']
+    r1 = cs.r1cs()
+    from fawkes_crypto_amd import params_io
+    csr = fx.r1cs_to_csr(r1)
+    from helpers import r1cs_product
+    stream = params_io.encode_gate_stream(r1cs_product(csr))
+    assert hashlib.sha256(stream).hexdigest() == g['gate_stream_sha256']
+    key = oracle.setup(csr, **TOXIC)
+    z = fx.witness_mont(cs.z_in, cs.z_aux)
+    a, b, c, aa, bi, ba = oracle.synthesize(csr, z)
+    assert int(aa.sum()) == g['a_aux_density'] and int(ba.sum()) == g['b_aux_density'] and int(bi.sum()) == 1
+    proof = oracle.prove(key, a, b, c, z, aa, bi, ba, fx.mont_fr(int(g['r'], 16)), fx.mont_fr(int(g['s'], 16)))
+    assert proof.tobytes().hex() == g['proof']
+    pk = fx.key_to_py(key)
+    assert ref.verify(pk, [root], ref.proof_from_borsh(proof.tobytes()))
+    assert not ref.verify(pk, [(root + 1) % ref.R], ref.proof_from_borsh(proof.tobytes()))
