@@ -15,10 +15,11 @@ region is checked afterwards with the Groth16 pairing equation.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-N > 1: one process per GPU; every rank holds a slice of each key array (MSM sharded by points).  Rank 0
-evaluates the constraint system and computes the quotient while the others start on the witness MSMs, h slices
-go point-to-point over xGMI, ONE all-gather (RCCL) of 384 bytes per rank exchanges the partial sums and the
-proof is folded locally -- strong scaling of a single proof (fawkes-crypto_amd/parallel.py: prove_balanced).
+N > 1: one process per GPU, strong scaling of a single proof: every rank holds 1/N of each key array (MSM sharded
+by points) and computes 1/N of the quotient -- the seven transforms are cut across the ranks with one all-to-all
+(RCCL over xGMI) each -- then ONE all-gather of 384 bytes per rank exchanges the partial MSM sums and the proof is
+folded locally (fawkes-crypto_amd/parallel.py: prove_distributed_dev).  FK_DIST_QUOTIENT=0 or a rank count that
+is not a power of two selects the older schedule (rank 0 computes the quotient and ships h slices point to point).
 
 The CPU oracle (oracle/) appears here only in the `cpu_baseline` leg: the timed CPU baseline, a live parity
 check of that same sample, and the pairing check of the benchmarked proof; it is never the thing measured.
@@ -115,19 +116,22 @@ def cpu_baseline_leg(ctx, fk, log2_sample, full):
     dr.free(); dk.free()
     if got.tobytes() != want.tobytes():
         raise AssertionError('bench parity check failed: HIP proof != oracle proof on the CPU-baseline sample')
-    verified = None
-    if full is not None:
-        vk_full, z_in1, proof = full
-        g1 = lambda b_: ref.g1_from_raw_le(bytes(b_))
-        g2 = lambda b_: ref.g2_from_raw_le(bytes(b_))
-        pk = dict(alpha_g1=g1(vk_full['alpha_g1']), beta_g2=g2(vk_full['beta_g2']), gamma_g2=g2(vk_full['gamma_g2']),
-                  delta_g2=g2(vk_full['delta_g2']), ic=[g1(x.tobytes()) for x in vk_full['ic']])
-        Rinv = pow(MONT_R, -1, FR_MODULUS)
-        pub = [int.from_bytes(z_in1.tobytes(), 'little') * Rinv % FR_MODULUS]
-        verified = bool(ref.verify(pk, pub, ref.proof_from_borsh(proof)))
-        if not verified:
-            raise AssertionError('bench: the benchmarked proof does not satisfy the Groth16 pairing equation')
+    verified = pairing_check(*full) if full is not None else None
     return cpu_s, 1 << log2_sample, verified
+
+
+def pairing_check(vk_full, z_in1, proof):
+    """the benchmarked proof must satisfy the Groth16 pairing equation (checker: oracle/bn254_ref.py verifier)"""
+    import bn254_ref as ref
+    g1 = lambda b_: ref.g1_from_raw_le(bytes(b_))
+    g2 = lambda b_: ref.g2_from_raw_le(bytes(b_))
+    pk = dict(alpha_g1=g1(vk_full['alpha_g1']), beta_g2=g2(vk_full['beta_g2']), gamma_g2=g2(vk_full['gamma_g2']),
+              delta_g2=g2(vk_full['delta_g2']), ic=[g1(x.tobytes()) for x in vk_full['ic']])
+    Rinv = pow(MONT_R, -1, FR_MODULUS)
+    pub = [int.from_bytes(z_in1.tobytes(), 'little') * Rinv % FR_MODULUS]
+    if not ref.verify(pk, pub, ref.proof_from_borsh(proof)):
+        raise AssertionError('bench: the benchmarked proof does not satisfy the Groth16 pairing equation')
+    return True
 
 
 def main():
@@ -175,9 +179,12 @@ def main():
     dr = ctx.load_r1cs(r1cs)
     info = dr.info()
     n_a, n_b = info['n_a'], info['n_b']
+    # N > 1, N a power of two: quotient and MSMs cut 1/N each (parallel.prove_distributed_dev); otherwise (or with
+    # FK_DIST_QUOTIENT=0) rank 0 computes the quotient and ships h slices (parallel.prove_balanced_dev)
+    dist_q = world > 1 and (world & (world - 1)) == 0 and world <= 8 and os.environ.get('FK_DIST_QUOTIENT', '1') != '0'
     fracs = parallel.plan_z_fractions(world, m, v_aux, n_a, n_b)
     tox = {k: mont(v) for k, v in TOXIC.items()}
-    key, vk = ctx.setup(r1cs, shard_index=rank, shard_count=world, z_frac=fracs[rank] if world > 1 else (0.0, 0.0), **tox)
+    key, vk = ctx.setup(r1cs, shard_index=rank, shard_count=world, z_frac=fracs[rank] if (world > 1 and not dist_q) else (0.0, 0.0), **tox)
     d_z = torch.empty((v_in + v_aux) * 32, dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
     ctx.upload(d_z.data_ptr(), z)
@@ -186,8 +193,13 @@ def main():
     del z
     r, s = mont(0xA11CE), mont(0xB0B)
     d_dens = dr.density_ptrs()
-    if world > 1:
-        h_ranges = [fk.api.shard_range(m - 1, g, world) for g in range(world)]
+    if dist_q:
+        work = [torch.empty(m * 32, dtype=torch.uint8, device=dev) for _ in range(3)]
+        send = [torch.empty(m // world * 32, dtype=torch.uint8, device=dev) for _ in range(3)]
+        recv = [torch.empty(m // world * 32, dtype=torch.uint8, device=dev) for _ in range(3)]
+        a2a = parallel.torch_all_to_all(ctx)
+    elif world > 1:
+        h_ranges = [fk.api.h_shard_range(m - 1, g, world) for g in range(world)]
         h_full_buf = torch.empty(m * 32, dtype=torch.uint8, device=dev) if rank == 0 else None
         recv_buf = torch.empty(max(h_ranges[rank][1] - h_ranges[rank][0], 1) * 32, dtype=torch.uint8, device=dev) if rank > 0 else None
         work = [torch.empty(m * 32, dtype=torch.uint8, device=dev) for _ in range(3)] if rank == 0 else [None] * 3
@@ -197,6 +209,10 @@ def main():
         if world == 1:
             return ctx.prove_witness_dev(key, dr, d_z.data_ptr(), r, s)
         wp = [w_.data_ptr() if w_ is not None else 0 for w_ in work]
+        if dist_q:
+            return parallel.prove_distributed_dev(
+                ctx, key, rank, world, wp, n, args.log2n, d_z.data_ptr(), d_dens[0], d_dens[1], d_dens[2], r, s, send, recv,
+                device=comm_dev, a2a=a2a, eval_fn=lambda: ctx.r1cs_eval_dev(dr, d_z.data_ptr(), wp[0], wp[1], wp[2]))
         return parallel.prove_balanced_dev(
             ctx, key, rank, world, wp[0], wp[1], wp[2], n, d_z.data_ptr(), d_dens[0], d_dens[1], d_dens[2], r, s,
             h_ranges, h_full_buf, recv_buf, device=comm_dev,
@@ -261,7 +277,8 @@ def main():
                        'gates': '40% boolean b*(b-1)=0, 10% linear, 50% products', 'nnz': list(info['nnz']),
                        'a_query_points': n_a, 'b_query_points': n_b,
                        'witness': '%.0f%% zeros, %.0f%% ones, rest dense 254-bit' % (100.0 * zeros / (v_in + v_aux), 100.0 * ones / (v_in + v_aux)),
-                       'parallelism': 'msm-shard%d%s' % (world, '+balanced-quotient' if world > 1 else '')},
+                       'parallelism': 'msm-shard%d%s' % (world, '' if world == 1 else
+                                                         '+distributed-quotient (8 all-to-all per proof)' if dist_q else '+balanced-quotient')},
             'msm_scalar_muls_per_sec': msm_units / sec_per_step,
             'roofline': {
                 'bound': 'hbm', 'kernel': 'msm_accumulate_kernel<Fq> (G1 bucket accumulation)',
@@ -281,6 +298,8 @@ def main():
             },
             'prep_seconds': prep_s,
         }
+        if world > 1 and not args.no_cpu_baseline:
+            out['proof_verified_by_pairing_check'] = pairing_check(vk, z_in1, proofs[-1])
         if world == 1 and not args.no_cpu_baseline:
             cpu_s, cpu_m, verified = cpu_baseline_leg(ctx, fk, args.cpu_log2n, (vk, z_in1, proofs[-1]))
             scale = m / cpu_m

@@ -31,7 +31,8 @@ EXPORTED_SYMBOLS = [
     'fk_fr_mul_batch', 'fk_ntt', 'fk_ntt_dev', 'fk_quotient_h', 'fk_quotient_h_dev',
     'fk_msm_g1', 'fk_msm_g2', 'fk_msm_g1_dev', 'fk_msm_g2_dev',
     'fk_gen_points_g1_dev', 'fk_gen_points_g2_dev', 'fk_gen_scalars_dev',
-    'fk_synthesize', 'fk_stats_reset', 'fk_stats_get', 'fk_shard_range',
+    'fk_synthesize', 'fk_stats_reset', 'fk_stats_get', 'fk_shard_range', 'fk_h_shard_range',
+    'fk_dq_gather_dev', 'fk_dq_local_dev', 'fk_dq_cross_dev',
     'fk_setup', 'fk_key_download', 'fk_key_load_bellman', 'fk_key_vk', 'fk_key_counts',
     'fk_r1cs_load', 'fk_r1cs_free', 'fk_r1cs_info', 'fk_r1cs_density_ptrs', 'fk_r1cs_eval_dev', 'fk_prove_r1cs', 'fk_prove_r1cs_dev',
 ]
@@ -459,6 +460,19 @@ class Context:
     def quotient_h_dev(self, d_a, d_b, d_c, n, d_h):
         self._ck(self.lib.fk_quotient_h_dev(self.handle, C.c_void_p(d_a), C.c_void_p(d_b), C.c_void_p(d_c), C.c_uint64(n), C.c_void_p(d_h)))
 
+    # distributed quotient building blocks (include/fawkes_hip.h: fk_dq_*); world = 2^log_w ranks
+    def dq_gather_dev(self, d_full, n, log_m, rank, log_w, d_local):
+        self._ck(self.lib.fk_dq_gather_dev(self.handle, C.c_void_p(d_full), C.c_uint64(n), C.c_uint32(log_m), C.c_uint32(rank),
+                                           C.c_uint32(log_w), C.c_void_p(d_local)))
+
+    def dq_local_dev(self, d_x, log_m, rank, log_w, stage, d_xb=0, d_xc=0):
+        self._ck(self.lib.fk_dq_local_dev(self.handle, C.c_void_p(d_x), C.c_void_p(d_xb), C.c_void_p(d_xc), C.c_uint32(log_m),
+                                          C.c_uint32(rank), C.c_uint32(log_w), C.c_int(stage)))
+
+    def dq_cross_dev(self, d_buf, log_m, rank, log_w, mode):
+        self._ck(self.lib.fk_dq_cross_dev(self.handle, C.c_void_p(d_buf), C.c_uint32(log_m), C.c_uint32(rank), C.c_uint32(log_w),
+                                          C.c_int(mode)))
+
     def msm_g1(self, bases, scalars):
         bases = np.ascontiguousarray(bases, np.uint8).reshape(-1, 64)
         scalars = _fr(scalars, bases.shape[0])
@@ -646,6 +660,14 @@ def shard_range(n, index, count):
     lib = load_library()
     lo, hi = C.c_uint64(), C.c_uint64()
     lib.fk_shard_range(C.c_uint64(n), C.c_uint32(index), C.c_uint32(count), C.byref(lo), C.byref(hi))
+    return lo.value, hi.value
+
+
+def h_shard_range(n_h, index, count):
+    """[lo, hi) of the h bases shard `index` holds: blocks of the evaluation domain (fk_h_shard_range)"""
+    lib = load_library()
+    lo, hi = C.c_uint64(), C.c_uint64()
+    lib.fk_h_shard_range(C.c_uint64(n_h), C.c_uint32(index), C.c_uint32(count), C.byref(lo), C.byref(hi))
     return lo.value, hi.value
 
 

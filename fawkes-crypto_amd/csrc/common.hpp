@@ -100,6 +100,17 @@ namespace fk {
 
 static inline uint32_t ceil_log2_u64(uint64_t n) { uint32_t k = 0; while (((uint64_t)1 << k) < n) k++; return k; }
 
+// The h bases are sharded in blocks of the evaluation domain (m = n_h + 1 slots, the last one clipped): shard g holds
+// h[g*m/W, (g+1)*m/W) -- exactly the block of quotient coefficients the distributed quotient (ntt.hip, fk_dq_*)
+// leaves on rank g, so no element has to move before the H multi-scalar multiplication.
+static inline void h_slice(uint64_t n_h, uint32_t idx, uint32_t cnt, uint64_t *lo, uint64_t *hi) {
+    const uint64_t m = n_h + 1;
+    uint64_t a = (uint64_t)((unsigned __int128)m * idx / cnt), b = (uint64_t)((unsigned __int128)m * (idx + 1) / cnt);
+    if (a > n_h) a = n_h;
+    if (b > n_h) b = n_h;
+    *lo = a; *hi = b;
+}
+
 // stats helpers (HIP events on the library stream)
 int stats_begin(fk_ctx *ctx, std::vector<EventPair> &v, uint64_t units);
 int stats_end(fk_ctx *ctx, std::vector<EventPair> &v);
@@ -109,6 +120,9 @@ int ntt_exec_simple(fk_ctx *ctx, Fr *d_data, uint32_t log_n, bool inverse, bool 
 int quotient_dev(fk_ctx *ctx, Fr *d_a, Fr *d_b, Fr *d_c, uint64_t n, Fr *d_h_out, uint64_t *m_out);
 void ntt_free_domains(fk_ctx *ctx);
 int fr_mul_batch_dev(fk_ctx *ctx, const Fr *a, const Fr *b, Fr *o, size_t n);
+int dq_gather(fk_ctx *ctx, const Fr *d_full, uint64_t n, uint32_t log_m, uint32_t rank, uint32_t log_w, Fr *d_local);
+int dq_local(fk_ctx *ctx, Fr *d_x, const Fr *d_xb, const Fr *d_xc, uint32_t log_m, uint32_t rank, uint32_t log_w, int stage);
+int dq_cross(fk_ctx *ctx, Fr *d_buf, uint32_t log_m, uint32_t rank, uint32_t log_w, int mode);
 
 // msm.hip
 int msm_g1_dev(fk_ctx *ctx, const G1Affine *d_bases, const Fr *d_scalars, size_t n, G1Xyzz *out);

@@ -38,6 +38,7 @@ struct NttDomain {
     Fr *tw_lo[2] = {nullptr, nullptr}, *tw_hi[2] = {nullptr, nullptr};   // [0] forward, [1] inverse
     Fr *pq[2] = {nullptr, nullptr};                                       // omega_Rmax^e, e < Rmax/2
     ScaleTable t_g, t_ginv_minv, t_g_minv, t_ginv_minv_zinv;
+    std::map<uint64_t, ScaleTable> dist_post;   // distributed quotient: (omega_m^-rank)^k tables, key = log_w << 32 | rank
     std::vector<void *> allocs;
 };
 
@@ -322,6 +323,171 @@ int quotient_dev(fk_ctx *ctx, Fr *d_a, Fr *d_b, Fr *d_c, uint64_t n, Fr *d_h_out
     NttOp fin; fin.inverse = true; fin.pre_mode = PRE_ABC; fin.xb = d_b; fin.xc = d_c;
     fin.post_mode = POST_TABLE; fin.post = &d->t_ginv_minv_zinv;
     FK_TRY(ntt_exec(ctx, d, fin, d_a, s1, s2, d_h_out));
+    return FK_OK;
+}
+
+// ------------------------------------------------------------------------------------------ distributed quotient
+// One process per GPU, W = 2^w ranks, m = W * L.  The transform of size m is cut ONCE, between ranks, so that every
+// transform costs one all-to-all of the caller (RCCL over xGMI) and L-point transforms that never leave a GPU:
+//
+//   variant 1 (cyclic in -> block-cyclic out), j = j1 + W j2, k = k2 + L k1, rank = j1:
+//       X[k2 + L k1] = sum_j1 w_W^(j1 k1) * [ w_m^(j1 k2) * sum_j2 x[j1 + W j2] w_L^(j2 k2) ]
+//       local L-point transform + twiddle (fk_dq_local_dev) | all-to-all | W-point transform across the received
+//       chunks (fk_dq_cross_dev).  Rank p ends up with k2 in [p L/W, (p+1) L/W) for every k1.
+//   variant 2 (block-cyclic in -> cyclic out), j = j2 + L j1, k = k1 + W k2:
+//       X[k1 + W k2] = sum_j2 w_L^(j2 k2) * w_m^(j2 k1) * sum_j1 x[j2 + L j1] w_W^(j1 k1)
+//       W-point transform across chunks + twiddle (fk_dq_cross_dev) | all-to-all | local L-point transform.
+//
+// The quotient chains them: ifft (v1) . coset_fft (v2) . a*b-c . icoset_fft (v1); the W-point halves of the first two
+// meet in ONE kernel (inverse W-point, * g^i / m, forward W-point, twiddle).  A last all-to-all turns the
+// block-cyclic coefficients into contiguous blocks -- the h-base sharding of the key (h_slice in common.hpp).
+// All scale factors of the single-GPU pipeline (g^i, 1/m, 1/Z(g)) are applied once, in the cross kernels, from the
+// m-domain's two-level tables.
+
+__global__ void dq_gather_kernel(const Fr *full, uint64_t n, uint32_t log_w, uint32_t rank, uint64_t L, Fr *local) {
+    const uint64_t j2 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j2 >= L) return;
+    const uint64_t idx = rank + (j2 << log_w);
+    local[j2] = idx < n ? full[idx] : Fr::zero();
+}
+
+struct CrossArgs {
+    Fr *buf;
+    uint32_t log_m, log_w, rank;
+    int mode;                              // 0: ifft tail + coset shift + coset_fft head, 1: icoset_fft tail
+    Fr w_fwd[4], w_inv[4];                 // w_W^e and w_W^-e, e < W/2
+    const Fr *sc_lo, *sc_hi, *tw_lo, *tw_hi;
+    uint32_t Lbits;
+};
+
+// W-point decimation-in-frequency transform held in registers, natural order in and out
+template <int LOGW>
+static __device__ __forceinline__ void small_dft(Fr (&v)[1 << LOGW], const Fr *wt) {
+    constexpr int W = 1 << LOGW;
+#pragma unroll
+    for (int s = 0; s < LOGW; s++) {
+        const int half = W >> (s + 1);
+#pragma unroll
+        for (int blk = 0; blk < W; blk += 2 * half) {
+#pragma unroll
+            for (int j = 0; j < half; j++) {
+                Fr u = v[blk + j], t = v[blk + j + half];
+                v[blk + j] = Fr::add(u, t);
+                Fr d = Fr::sub(u, t);
+                v[blk + j + half] = j ? Fr::mul(d, wt[j << s]) : d;
+            }
+        }
+    }
+    Fr o[W];
+#pragma unroll
+    for (int i = 0; i < W; i++) {
+        int r = 0;
+#pragma unroll
+        for (int b = 0; b < LOGW; b++) r |= ((i >> b) & 1) << (LOGW - 1 - b);
+        o[r] = v[i];
+    }
+#pragma unroll
+    for (int i = 0; i < W; i++) v[i] = o[i];
+}
+
+template <int LOGW>
+__global__ __launch_bounds__(256) void dq_cross_kernel(CrossArgs a) {
+    constexpr int W = 1 << LOGW;
+    const uint64_t Lc = (uint64_t)1 << (a.log_m - 2 * a.log_w), L = (uint64_t)1 << (a.log_m - a.log_w);
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= Lc) return;
+    const uint32_t mask = (1u << a.Lbits) - 1;
+    Fr v[W];
+#pragma unroll
+    for (int j = 0; j < W; j++) v[j] = a.buf[(uint64_t)j * Lc + t];
+    small_dft<LOGW>(v, a.w_inv);
+    const uint64_t k2 = (uint64_t)a.rank * Lc + t;
+#pragma unroll
+    for (int k1 = 0; k1 < W; k1++) {
+        const uint64_t i = k2 + (uint64_t)k1 * L;                  // coefficient index
+        v[k1] = Fr::mul(v[k1], Fr::mul(a.sc_lo[i & mask], a.sc_hi[i >> a.Lbits]));
+    }
+    if (a.mode == 0) {
+        small_dft<LOGW>(v, a.w_fwd);
+#pragma unroll
+        for (int k1 = 1; k1 < W; k1++) {
+            const uint64_t e = k2 * (uint64_t)k1;                   // < m
+            if (e) v[k1] = Fr::mul(v[k1], Fr::mul(a.tw_lo[e & mask], a.tw_hi[e >> a.Lbits]));
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < W; j++) a.buf[(uint64_t)j * Lc + t] = v[j];
+}
+
+static int dq_check(fk_ctx *ctx, uint32_t log_m, uint32_t rank, uint32_t log_w) {
+    if (log_w > 3) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "distributed quotient: at most 8 ranks (log_w = %u)", log_w);
+    if (rank >> log_w) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "distributed quotient: rank %u of %u", rank, 1u << log_w);
+    if (log_m < 2 * log_w) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "distributed quotient: domain 2^%u too small for %u ranks", log_m, 1u << log_w);
+    return FK_OK;
+}
+
+int dq_gather(fk_ctx *ctx, const Fr *d_full, uint64_t n, uint32_t log_m, uint32_t rank, uint32_t log_w, Fr *d_local) {
+    FK_TRY(dq_check(ctx, log_m, rank, log_w));
+    if (n > ((uint64_t)1 << log_m)) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "distributed quotient: n exceeds the domain");
+    const uint64_t L = (uint64_t)1 << (log_m - log_w);
+    hipLaunchKernelGGL(dq_gather_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, ctx->stream, d_full, n, log_w, rank, L, d_local);
+    FK_HIP(ctx, hipGetLastError());
+    return FK_OK;
+}
+
+// stage 0: inverse L-point transform + twiddle (ifft, first half)      stage 1: forward L-point transform
+// stage 2: x := x * xb - xc, then as stage 0 (icoset_fft, first half)  (coset_fft, second half)
+int dq_local(fk_ctx *ctx, Fr *d_x, const Fr *d_xb, const Fr *d_xc, uint32_t log_m, uint32_t rank, uint32_t log_w, int stage) {
+    FK_TRY(dq_check(ctx, log_m, rank, log_w));
+    if (stage < 0 || stage > 2 || (stage == 2 && (!d_xb || !d_xc))) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "distributed quotient: bad stage");
+    NttDomain *dl = nullptr, *dm = nullptr;
+    FK_TRY(get_domain(ctx, log_m - log_w, &dl));
+    FK_TRY(get_domain(ctx, log_m, &dm));
+    const size_t bytes = sizeof(Fr) << (log_m - log_w);
+    FK_HIP(ctx, ctx->ntt_s1.reserve(bytes));
+    FK_HIP(ctx, ctx->ntt_s2.reserve(bytes));
+    NttOp op;
+    op.inverse = stage != 1;
+    if (stage == 2) { op.pre_mode = PRE_ABC; op.xb = d_xb; op.xc = d_xc; }
+    if (stage != 1 && rank != 0) {
+        const uint64_t key = ((uint64_t)log_w << 32) | rank;
+        auto it = dl->dist_post.find(key);
+        if (it == dl->dist_post.end()) {
+            ScaleTable t;
+            FK_TRY(make_scale_table(ctx, dl, Fr::pow_u64(dm->omega_inv, rank), Fr::one(), &t));
+            it = dl->dist_post.emplace(key, t).first;
+        }
+        op.post_mode = POST_TABLE; op.post = &it->second;
+    }
+    Fr *s1 = ctx->ntt_s1.as<Fr>(), *s2 = ctx->ntt_s2.as<Fr>();
+    if (dl->degs.size() >= 2) return ntt_exec(ctx, dl, op, d_x, s1, s2, d_x);
+    FK_TRY(ntt_exec(ctx, dl, op, d_x, s1, s2, s1));
+    FK_HIP(ctx, hipMemcpyAsync(d_x, s1, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return FK_OK;
+}
+
+int dq_cross(fk_ctx *ctx, Fr *d_buf, uint32_t log_m, uint32_t rank, uint32_t log_w, int mode) {
+    FK_TRY(dq_check(ctx, log_m, rank, log_w));
+    if (mode < 0 || mode > 1) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "distributed quotient: bad mode");
+    NttDomain *dm = nullptr;
+    FK_TRY(get_domain(ctx, log_m, &dm));
+    CrossArgs a{};
+    a.buf = d_buf; a.log_m = log_m; a.log_w = log_w; a.rank = rank; a.mode = mode;
+    const uint64_t L = (uint64_t)1 << (log_m - log_w);
+    const Fr ww = Fr::pow_u64(dm->omega, L), wwi = Fr::pow_u64(dm->omega_inv, L);     // w_W, w_W^-1
+    Fr cf = Fr::one(), ci = Fr::one();
+    for (int e = 0; e < 4; e++) { a.w_fwd[e] = cf; a.w_inv[e] = ci; cf = Fr::mul(cf, ww); ci = Fr::mul(ci, wwi); }
+    const ScaleTable &sc = mode == 0 ? dm->t_g_minv : dm->t_ginv_minv_zinv;
+    a.sc_lo = sc.lo; a.sc_hi = sc.hi; a.tw_lo = dm->tw_lo[0]; a.tw_hi = dm->tw_hi[0]; a.Lbits = dm->L;
+    const uint64_t Lc = (uint64_t)1 << (log_m - 2 * log_w);
+    const dim3 grid((unsigned)((Lc + 255) / 256)), block(256);
+    switch (log_w) {
+        case 0: hipLaunchKernelGGL(dq_cross_kernel<0>, grid, block, 0, ctx->stream, a); break;
+        case 1: hipLaunchKernelGGL(dq_cross_kernel<1>, grid, block, 0, ctx->stream, a); break;
+        case 2: hipLaunchKernelGGL(dq_cross_kernel<2>, grid, block, 0, ctx->stream, a); break;
+        default: hipLaunchKernelGGL(dq_cross_kernel<3>, grid, block, 0, ctx->stream, a); break;
+    }
+    FK_HIP(ctx, hipGetLastError());
     return FK_OK;
 }
 

@@ -143,7 +143,7 @@ static void frac_slice(uint64_t n, double lo, double hi, uint64_t *olo, uint64_t
 }
 
 static int key_alloc_slices(fk_ctx *ctx, fk_key *k, double zlo, double zhi) {
-    slice(k->n_h, k->shard_index, k->shard_count, &k->h_lo, &k->h_hi);
+    h_slice(k->n_h, k->shard_index, k->shard_count, &k->h_lo, &k->h_hi);
     if (zlo == 0.0 && zhi == 0.0) {
         slice(k->n_l, k->shard_index, k->shard_count, &k->l_lo, &k->l_hi);
         slice(k->n_a, k->shard_index, k->shard_count, &k->a_lo, &k->a_hi);
@@ -497,6 +497,29 @@ int fk_quotient_h_dev(fk_ctx *ctx, void *d_a, void *d_b, void *d_c, uint64_t n, 
     return quotient_dev(ctx, (Fr *)d_a, (Fr *)d_b, (Fr *)d_c, n, (Fr *)d_h_out, nullptr);
 }
 
+int fk_dq_gather_dev(fk_ctx *ctx, const void *d_full, uint64_t n, uint32_t log_m, uint32_t rank, uint32_t log_w, void *d_local) {
+    if (!ctx) return FK_ERR_BAD_ARG;
+    if (!d_full || !d_local) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "null argument");
+    FK_HIP(ctx, hipSetDevice(ctx->device));
+    return dq_gather(ctx, (const Fr *)d_full, n, log_m, rank, log_w, (Fr *)d_local);
+}
+
+int fk_dq_local_dev(fk_ctx *ctx, void *d_x, const void *d_xb, const void *d_xc, uint32_t log_m, uint32_t rank, uint32_t log_w, int stage) {
+    if (!ctx) return FK_ERR_BAD_ARG;
+    if (!d_x) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "null argument");
+    if (log_m >= FK_FR_S) FK_SET_ERR(ctx, FK_ERR_DOMAIN_TOO_LARGE, "evaluation domain 2^%u too large (max 2^%d)", log_m, FK_FR_S - 1);
+    FK_HIP(ctx, hipSetDevice(ctx->device));
+    return dq_local(ctx, (Fr *)d_x, (const Fr *)d_xb, (const Fr *)d_xc, log_m, rank, log_w, stage);
+}
+
+int fk_dq_cross_dev(fk_ctx *ctx, void *d_buf, uint32_t log_m, uint32_t rank, uint32_t log_w, int mode) {
+    if (!ctx) return FK_ERR_BAD_ARG;
+    if (!d_buf) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "null argument");
+    if (log_m >= FK_FR_S) FK_SET_ERR(ctx, FK_ERR_DOMAIN_TOO_LARGE, "evaluation domain 2^%u too large (max 2^%d)", log_m, FK_FR_S - 1);
+    FK_HIP(ctx, hipSetDevice(ctx->device));
+    return dq_cross(ctx, (Fr *)d_buf, log_m, rank, log_w, mode);
+}
+
 int fk_quotient_h(fk_ctx *ctx, const uint64_t *a, const uint64_t *b, const uint64_t *c, uint64_t n, uint64_t *h_out) {
     if (!ctx) return FK_ERR_BAD_ARG;
     if (!a || !b || !c || !h_out || !n) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "null argument");
@@ -621,6 +644,11 @@ int fk_synthesize(fk_ctx *ctx, const fk_r1cs *cs, const uint64_t *z_, uint64_t *
 void fk_shard_range(uint64_t n, uint32_t index, uint32_t count, uint64_t *lo, uint64_t *hi) {
     if (!count || !lo || !hi) return;
     slice(n, index, count, lo, hi);
+}
+
+void fk_h_shard_range(uint64_t n_h, uint32_t index, uint32_t count, uint64_t *lo, uint64_t *hi) {
+    if (!count || !lo || !hi) return;
+    h_slice(n_h, index, count, lo, hi);
 }
 
 // ------------------------------------------------------------------------------------------ stats

@@ -384,7 +384,7 @@ int fk_setup(fk_ctx *ctx, const fk_r1cs *cs, const uint64_t tau_[4], const uint6
         auto fr = [](uint64_t n, double lo, double hi, uint64_t *olo, uint64_t *ohi) {
             uint64_t a = (uint64_t)((long double)n * lo + 0.5L), b = hi >= 1.0 ? n : (uint64_t)((long double)n * hi + 0.5L);
             if (a > n) a = n; if (b > n) b = n; if (b < a) b = a; *olo = a; *ohi = b; };
-        sl(k->n_h, shard_index, shard_count, &k->h_lo, &k->h_hi);
+        h_slice(k->n_h, shard_index, shard_count, &k->h_lo, &k->h_hi);
         if (z_frac_lo == 0.0 && z_frac_hi == 0.0) { sl(k->n_l, shard_index, shard_count, &k->l_lo, &k->l_hi); sl(k->n_a, shard_index, shard_count, &k->a_lo, &k->a_hi); sl(k->n_b, shard_index, shard_count, &k->b_lo, &k->b_hi); }
         else { fr(k->n_l, z_frac_lo, z_frac_hi, &k->l_lo, &k->l_hi); fr(k->n_a, z_frac_lo, z_frac_hi, &k->a_lo, &k->a_hi); fr(k->n_b, z_frac_lo, z_frac_hi, &k->b_lo, &k->b_hi); }
         auto shrink = [&](void **p, uint64_t lo, uint64_t hi, size_t w) -> int {

@@ -18,6 +18,12 @@ Schedule (work-balanced, `prove_balanced`):
     128 B G2 per rank) and a local fold of N points per MSM (fk_prove_assemble).  Latency-bound.
 
 `prove_sharded*` is the simpler variant (every rank runs the quotient itself; no h traffic).
+
+Distributed quotient (`quotient_distributed`, `prove_distributed_dev`; world a power of two <= 8): the seven transforms
+themselves are cut across the ranks -- L = m/W-point transforms stay inside one GPU, one all-to-all per transform
+(8 in total, m*32/W bytes per rank each: 128 MiB at 2^25 / 8 GPUs) moves the data between the two halves of every
+transform, and rank g ends up with exactly the block of h coefficients whose bases its key shard holds.  Every rank
+does 1/W of the quotient and 1/W of all five MSMs; this is the default for `bench.py --gpus N`.
 """
 import numpy as np
 
@@ -155,5 +161,77 @@ def prove_sharded(ctx, key, a, b, c, z, a_aux, b_in, b_aux, r, s, group=None, de
 def prove_sharded_dev(ctx, key, d_a, d_b, d_c, n, d_z, d_a_aux, d_b_in, d_b_aux, r, s, group=None, device=None):
     """Simple variant, device-resident inputs."""
     part = ctx.prove_msms_dev(key, d_a, d_b, d_c, n, d_z, d_a_aux, d_b_in, d_b_aux)
+    parts = all_gather_parts(part, group=group, device=device)
+    return ctx.prove_assemble(key, parts, r, s)
+
+
+# ------------------------------------------------------------------------------------------ distributed quotient
+def log2_world(world):
+    lw = world.bit_length() - 1
+    if world < 1 or (1 << lw) != world or lw > 3:
+        raise ValueError('the distributed quotient needs 1, 2, 4 or 8 ranks, got %d' % world)
+    return lw
+
+
+def torch_all_to_all(ctx, group=None):
+    """all-to-all of lists of equally sized uint8 device tensors over torch.distributed (nccl = RCCL over xGMI).
+    The library computes on its own HIP stream, the collective runs on torch's: both sides are fenced.
+    Under gloo (CPU tests, single-device dry runs) the tensors are staged through the host."""
+    import torch
+    import torch.distributed as dist
+    stage = dist.get_backend(group) == 'gloo'
+
+    def a2a(dst, src):
+        ctx.sync()
+        if stage:
+            for d, s_ in zip(dst, src):
+                hs = s_.cpu()
+                hd = torch.empty_like(hs)
+                dist.all_to_all_single(hd, hs, group=group)
+                d.copy_(hd)
+        else:
+            works = [dist.all_to_all_single(d, s_, group=group, async_op=True) for d, s_ in zip(dst, src)]
+            for w in works:
+                w.wait()
+        if dst[0].is_cuda:
+            torch.cuda.synchronize()
+    return a2a
+
+
+def quotient_distributed(ctx, rank, world, d_full, n, log_m, send, recv, a2a):
+    """h = (A*B - C)/Z over `world` ranks.  d_full: device pointers of the three row-evaluation vectors a, b, c (n valid
+    rows; every rank holds them -- the SpMV is ~1 % of a proof).  send, recv: 3 + 3 buffers of (m/world)*32 bytes with
+    .data_ptr() (torch uint8 device tensors); a2a(dst_list, src_list): the exchange.  Returns the buffer that holds
+    this rank's block h[rank*m/world, (rank+1)*m/world) (Montgomery, 32 B per coefficient)."""
+    lw = log2_world(world)
+    p = lambda t: t.data_ptr()
+    for k in range(3):                                   # ifft, first half
+        ctx.dq_gather_dev(d_full[k], n, log_m, rank, lw, p(send[k]))
+        ctx.dq_local_dev(p(send[k]), log_m, rank, lw, 0)
+    a2a(recv, send)
+    for k in range(3):                                   # ifft second half, coset shift, coset_fft first half
+        ctx.dq_cross_dev(p(recv[k]), log_m, rank, lw, 0)
+    a2a(send, recv)
+    for k in range(1, 3):                                # coset_fft, second half
+        ctx.dq_local_dev(p(send[k]), log_m, rank, lw, 1)
+    ctx.dq_local_dev(p(send[0]), log_m, rank, lw, 1)
+    ctx.dq_local_dev(p(send[0]), log_m, rank, lw, 2, p(send[1]), p(send[2]))     # a*b - c, icoset_fft first half
+    a2a(recv[:1], send[:1])
+    ctx.dq_cross_dev(p(recv[0]), log_m, rank, lw, 1)     # icoset_fft second half, / Z(g)
+    a2a(send[:1], recv[:1])                              # block-cyclic -> blocks (the key's h sharding)
+    return send[0]
+
+
+def prove_distributed_dev(ctx, key, rank, world, d_full, n, log_m, d_z, d_a_aux, d_b_in, d_b_aux, r, s, send, recv,
+                          group=None, device=None, eval_fn=None, a2a=None):
+    """One proof over `world` GPUs with the quotient AND the five MSMs cut 1/world each.  key: this rank's equal shard
+    (shard_index = rank, shard_count = world, no z fractions).  eval_fn(): fills d_full (device SpMV)."""
+    if eval_fn is not None:
+        eval_fn()
+    if a2a is None:
+        a2a = torch_all_to_all(ctx, group)
+    h_blk = quotient_distributed(ctx, rank, world, d_full, n, log_m, send, recv, a2a)
+    part = np.array(ctx.prove_msms_z_dev(key, d_z, d_a_aux, d_b_in, d_b_aux), dtype=np.uint8, copy=True)
+    part[:64] = ctx.prove_msm_h_dev(key, h_blk.data_ptr())
     parts = all_gather_parts(part, group=group, device=device)
     return ctx.prove_assemble(key, parts, r, s)

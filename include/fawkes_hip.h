@@ -151,8 +151,30 @@ int fk_prove_msm_h_dev(fk_ctx *ctx, const fk_key *key, const void *d_h_slice, ui
 /* ctx may be NULL here (pure host arithmetic). */
 int fk_prove_assemble(fk_ctx *ctx, const fk_key *key, const uint8_t *msm_parts, uint32_t n_parts,
                       const uint64_t r[4], const uint64_t s[4], uint8_t out_proof[FK_PROOF_BYTES]);
-/* the [lo, hi) slice of an n-element key array that shard `index` of `count` holds */
+/* the [lo, hi) slice of an n-element key array (l, a, b_g1, b_g2) that shard `index` of `count` holds */
 void fk_shard_range(uint64_t n, uint32_t index, uint32_t count, uint64_t *lo, uint64_t *hi);
+/* the same for the h array (n_h = m - 1 bases): blocks of the evaluation domain, [index*m/count, (index+1)*m/count)
+ * clipped to n_h -- the block of quotient coefficients the distributed quotient below leaves on that rank. */
+void fk_h_shard_range(uint64_t n_h, uint32_t index, uint32_t count, uint64_t *lo, uint64_t *hi);
+
+/* Distributed quotient: bellman's EvaluationDomain pipeline (domain.rs ifft / coset_fft / mul_assign / sub_assign /
+ * divide_by_z_on_coset / icoset_fft) over W = 2^log_w GPUs, one process each ("NTT butterfly stages
+ * shard across the GPUs").  The m-point transform is cut once between ranks; the library provides the rank-local
+ * pieces, the caller moves the data with ONE all-to-all per transform (torch.distributed all_to_all_single = RCCL
+ * over xGMI) -- see fawkes-crypto_amd/parallel.py:quotient_distributed for the order.  All buffers are device
+ * memory of L = m / W elements (32 B each); chunk p of a buffer is elements [p*L/W, (p+1)*L/W).
+ *   fk_dq_gather_dev  local[j] = full[rank + W*j] (zero beyond n): the cyclic slice of a row-evaluation vector
+ *   fk_dq_local_dev   stage 0: inverse L-point transform, then * omega_m^(-rank*k)         (ifft, first half)
+ *                     stage 1: forward L-point transform                                    (coset_fft, second half)
+ *                     stage 2: x := x*xb - xc, then as stage 0                              (icoset_fft, first half)
+ *   fk_dq_cross_dev   after an all-to-all (chunk j received from rank j): W-point transforms across the chunks;
+ *                     mode 0: ifft second half, * g^i / m, coset_fft first half (result goes into the next all-to-all)
+ *                     mode 1: icoset_fft second half, * g^-i / (m Z(g)): quotient coefficients, block-cyclic;
+ *                             one more all-to-all leaves rank q with the block h[q*L, (q+1)*L).
+ * log_w <= 3, log_m >= 2*log_w.  With log_w = 0 the same calls compute the single-GPU quotient. */
+int fk_dq_gather_dev(fk_ctx *ctx, const void *d_full, uint64_t n, uint32_t log_m, uint32_t rank, uint32_t log_w, void *d_local);
+int fk_dq_local_dev(fk_ctx *ctx, void *d_x, const void *d_xb, const void *d_xc, uint32_t log_m, uint32_t rank, uint32_t log_w, int stage);
+int fk_dq_cross_dev(fk_ctx *ctx, void *d_buf, uint32_t log_m, uint32_t rank, uint32_t log_w, int mode);
 
 /* ---------------------------------------------------------------- building blocks (tests / benches)
  * bellman_ce::domain::EvaluationDomain pieces. */

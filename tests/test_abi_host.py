@@ -78,6 +78,16 @@ def test_shard_range_partition():
                 assert lo == prev and hi >= lo
                 prev = hi
             assert prev == n
+    # h bases: blocks of the evaluation domain m = n_h + 1, the last block one short
+    for log_m in (3, 10, 25):
+        m = 1 << log_m
+        for cnt in (1, 2, 3, 4, 8):
+            prev = 0
+            for i in range(cnt):
+                lo, hi = api.h_shard_range(m - 1, i, cnt)
+                assert lo == prev == m * i // cnt and hi >= lo
+                prev = hi
+            assert prev == m - 1
 
 
 def test_synthesize_matches_oracle(oracle):

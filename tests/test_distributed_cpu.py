@@ -50,7 +50,7 @@ def _worker(rank, world, port, q):
         part = np.zeros(api.FK_MSM_RESULT_BYTES, np.uint8)
         for off, bases, scalars, fn in ((0, key.h, h, co.msm_g1), (64, key.l, z[nin:], co.msm_g1), (128, key.a, sa, co.msm_g1),
                                         (192, key.b_g1, sb, co.msm_g1), (256, key.b_g2, sb, co.msm_g2)):
-            lo, hi = api.shard_range(len(bases), rank, world)
+            lo, hi = (api.h_shard_range if off == 0 else api.shard_range)(len(bases), rank, world)
             res = fn(np.array(bases[lo:hi]), scalars[lo:hi]) if hi > lo else np.zeros(128 if off == 256 else 64, np.uint8)
             part[off:off + len(res)] = res
         parts = parallel.all_gather_parts(part)
@@ -64,7 +64,7 @@ def _worker(rank, world, port, q):
         # rank 0 computes h and ships slices point-to-point, witness arrays are split by plan_z_fractions
         import torch
         fracs = parallel.plan_z_fractions(world, key.m, cs.num_aux, len(key.a), len(key.b_g1))
-        h_ranges = [api.shard_range(key.m - 1, g, world) for g in range(world)]
+        h_ranges = [api.h_shard_range(key.m - 1, g, world) for g in range(world)]
 
         def frac_range(n_, lo_, hi_):
             a_ = int(n_ * lo_ + 0.5); b_ = n_ if hi_ >= 1.0 else int(n_ * hi_ + 0.5)
@@ -114,3 +114,125 @@ def test_sharded_prove_gloo(world):
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in results), results
     assert len({hx for _, _, hx in results}) == 1      # every rank assembled the same proof
+
+
+# ------------------------------------------------------------------------------------------ distributed quotient
+class _CpuDq:
+    """CPU stand-in (python big ints, direct O(L^2) transforms) for the three rank-local device calls of the distributed
+    quotient, so that parallel.quotient_distributed + parallel.torch_all_to_all run over real gloo ranks here.
+    Buffers are uint8 torch tensors holding Montgomery limbs, looked up by data_ptr()."""
+
+    def __init__(self, ref, co, bufs):
+        self.ref, self.co = ref, co
+        self.bufs = {t.data_ptr(): t for t in bufs}
+
+    def sync(self):
+        pass
+
+    def _get(self, ptr):
+        R = self.ref.R
+        arr = np.frombuffer(self.bufs[ptr].numpy().tobytes(), np.uint64).reshape(-1, 4)
+        return [self.ref.from_mont(x, R) for x in self.co.ints(arr)]
+
+    def _put(self, ptr, vals):
+        import torch
+        R = self.ref.R
+        raw = self.co.limbs_arr([self.ref.to_mont(v % R, R) for v in vals]).tobytes()
+        self.bufs[ptr].copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
+
+    def dq_gather_dev(self, d_full, n, log_m, rank, log_w, d_local):
+        full = self._get(d_full)
+        L = 1 << (log_m - log_w)
+        self._put(d_local, [full[rank + (j << log_w)] if rank + (j << log_w) < n else 0 for j in range(L)])
+
+    def dq_local_dev(self, d_x, log_m, rank, log_w, stage, d_xb=0, d_xc=0):
+        R = self.ref.R
+        x = self._get(d_x)
+        L = len(x)
+        if stage == 2:
+            xb, xc = self._get(d_xb), self._get(d_xc)
+            x = [(u * v - w) % R for u, v, w in zip(x, xb, xc)]
+        wm = self.ref.omega_for(1 << log_m)
+        wl = pow(wm, 1 << log_w, R)
+        if stage != 1:
+            wl, wm = pow(wl, -1, R), pow(wm, -1, R)
+        out = [sum(x[j] * pow(wl, j * k, R) for j in range(L)) % R for k in range(L)]
+        if stage != 1:
+            out = [o * pow(wm, rank * k, R) % R for k, o in enumerate(out)]
+        self._put(d_x, out)
+
+    def dq_cross_dev(self, d_buf, log_m, rank, log_w, mode):
+        R = self.ref.R
+        W, m = 1 << log_w, 1 << log_m
+        L, Lc = m >> log_w, m >> (2 * log_w)
+        buf = self._get(d_buf)
+        wm = self.ref.omega_for(m)
+        ww = pow(wm, L, R)
+        g = 7
+        zinv = pow(pow(g, m, R) - 1, -1, R)
+        minv = pow(m, -1, R)
+        out = list(buf)
+        for t in range(Lc):
+            k2 = rank * Lc + t
+            v = [buf[j * Lc + t] for j in range(W)]
+            u = [sum(v[j] * pow(ww, -j * k1, R) for j in range(W)) % R for k1 in range(W)]
+            for k1 in range(W):
+                i = k2 + k1 * L
+                u[k1] = u[k1] * (pow(g, i, R) * minv if mode == 0 else pow(g, -i, R) * minv * zinv) % R
+            if mode == 0:
+                u = [sum(u[j] * pow(ww, j * k1, R) for j in range(W)) * pow(wm, k2 * k1, R) % R for k1 in range(W)]
+            for k1 in range(W):
+                out[k1 * Lc + t] = u[k1]
+        self._put(d_buf, out)
+
+
+def _dq_worker(rank, world, port, q):
+    for p in (ROOT, os.path.join(ROOT, 'oracle'), os.path.join(ROOT, 'tests')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    import bn254_ref as ref
+    import c_oracle as co
+    from fawkes_crypto_amd import parallel
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        log_m, n = 7, 121
+        m, L = 1 << log_m, (1 << log_m) // world
+        rng = ref.Lcg(77)
+        a, b, c = ([rng.below(ref.R) for _ in range(n)] for _ in range(3))
+        want = ref.quotient_h(a, b, c, m)                 # m - 1 coefficients, python oracle
+        full = []
+        for v in (a, b, c):
+            raw = co.limbs_arr([ref.to_mont(x, ref.R) for x in v] + [0] * (m - n)).tobytes()
+            full.append(torch.frombuffer(bytearray(raw), dtype=torch.uint8).clone())
+        send = [torch.zeros(L * 32, dtype=torch.uint8) for _ in range(3)]
+        recv = [torch.zeros(L * 32, dtype=torch.uint8) for _ in range(3)]
+        cpu = _CpuDq(ref, co, full + send + recv)
+        blk = parallel.quotient_distributed(cpu, rank, world, [t.data_ptr() for t in full], n, log_m, send, recv,
+                                            parallel.torch_all_to_all(cpu))
+        got = cpu._get(blk.data_ptr())
+        hi = min((rank + 1) * L, m - 1)
+        q.put((rank, got[:hi - rank * L] == want[rank * L:hi]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 4])
+def test_distributed_quotient_gloo(world):
+    """the exchange order of parallel.quotient_distributed over real torch.distributed ranks (gloo all_to_all_single):
+    every rank must end with its contiguous block of the python oracle's quotient coefficients"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dq_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in results), results

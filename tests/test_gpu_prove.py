@@ -122,7 +122,7 @@ def test_balanced_schedule_pieces(ctx, oracle):
         for g in range(world):
             sk = ctx.load_key(params, shard_index=g, shard_count=world, z_frac=fracs[g])
             info = sk.shard_info()
-            assert info['h'] == api.shard_range(m - 1, g, world)
+            assert info['h'] == api.h_shard_range(m - 1, g, world)
             part = ctx.prove_msms_z_dev(sk, d_z, d_aa, d_bi, d_ba)
             assert part[:64].tobytes() == bytes(64)
             part[:64] = ctx.prove_msm_h_dev(sk, d['h'] + info['h'][0] * 32)
