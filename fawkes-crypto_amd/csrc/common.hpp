@@ -32,6 +32,19 @@ struct NttDomain;
 
 struct EventPair { hipEvent_t a, b; uint64_t units; };
 
+// One multi-scalar multiplication whose bucket reduction has been queued on the second stream (msm.hip): the
+// reduction is a short, latency-bound kernel, so it runs underneath the sort / accumulation of the NEXT
+// multiplication instead of leaving the chip idle.
+struct MsmTail {
+    bool active = false;
+    uint32_t c = 0, W = 0, nblk = 0;
+    hipEvent_t done = nullptr;      // reduction finished and its window sums are in h_wp
+    void *h_wp = nullptr;           // pinned host copy of the window partial sums
+    size_t h_cap = 0;
+    DevBuf d_wp;
+};
+static constexpr int MSM_TAILS = 8;
+
 }  // namespace fk
 
 struct fk_ctx {
@@ -44,6 +57,13 @@ struct fk_ctx {
     // MSM scratch
     const void *last_sort_scalars = nullptr; size_t last_sort_n = 0; unsigned last_sort_c = 0;   // what `sorted` currently holds
     fk::DevBuf digits, sorted, totals, starts, buckets, winparts, overlist, tasktab, partials, misc, perm, s2_cnt1, s2_seg, s2_cnt2, s2_tmp_idx, s2_tmp_lo;
+    // deferred bucket reduction: second stream, two bucket arrays used in turn, one record per outstanding MSM
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_front = nullptr;
+    fk::MsmTail tails[fk::MSM_TAILS];
+    fk::DevBuf buckets2[2];
+    int bucket_tail[2] = {-1, -1};     // the tail that last read each bucket array
+    int bucket_next = 0;
     // NTT / prover scratch
     fk::DevBuf ntt_s1, ntt_s2, ntt_io, hbuf, sc_a, sc_b, scan_tmp, stage_a, stage_b, stage_c, stage_z, stage_d;
     // stats
@@ -126,6 +146,15 @@ int dq_cross(fk_ctx *ctx, Fr *d_buf, uint32_t log_m, uint32_t rank, uint32_t log
 
 // msm.hip
 int msm_g1_dev(fk_ctx *ctx, const G1Affine *d_bases, const Fr *d_scalars, size_t n, G1Xyzz *out);
+// split form: *_begin queues everything up to the bucket reduction (which goes to the second stream) and returns a
+// tail handle (-1 for an empty sum); *_end waits for it and folds the window sums on the host.  Several
+// multiplications may be outstanding; msm_abandon drops them all (error paths).
+int msm_g1_begin(fk_ctx *ctx, const G1Affine *d_bases, const Fr *d_scalars, size_t n, int *tail);
+int msm_g1_end(fk_ctx *ctx, int tail, G1Xyzz *out);
+int msm_g2_begin(fk_ctx *ctx, const G2Affine *d_bases, const Fr *d_scalars, size_t n, bool reuse_sort, int *tail);
+int msm_g2_end(fk_ctx *ctx, int tail, G2Xyzz *out);
+void msm_abandon(fk_ctx *ctx);
+void msm_release(fk_ctx *ctx);
 // reuse_sort: the scalars are the ones of the immediately preceding MSM call on this context (same pointer
 // and n), so its digits / bucket sort are still valid and are not recomputed (B1 and B2 share scalars)
 int msm_g2_dev(fk_ctx *ctx, const G2Affine *d_bases, const Fr *d_scalars, size_t n, G2Xyzz *out, bool reuse_sort = false);

@@ -510,11 +510,22 @@ __global__ __launch_bounds__(256) void msm_bucket_reduce_kernel(const Xyzz<F> *b
 
 // ------------------------------------------------------------------------------------------ host driver
 template <class F>
-static int msm_run(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars, size_t n, Xyzz<F> *out, bool reuse_sort = false) {
+static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars, size_t n, bool reuse_sort, int *tail_out) {
     using FC = typename ColdOf<F>::type;   // layout-identical field with an out-of-line multiply
-    *out = Xyzz<F>::inf();
+    *tail_out = -1;
     if (n == 0) return FK_OK;
     if (n >= ((size_t)1 << 31)) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "msm: n too large");
+    int ti = -1;
+    for (int i = 0; i < MSM_TAILS; i++) if (!ctx->tails[i].active) { ti = i; break; }
+    if (ti < 0) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "msm: too many outstanding multiplications");
+    MsmTail &tl = ctx->tails[ti];
+    if (!ctx->stream2) {
+        int lo = 0, hi = 0;
+        FK_HIP(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));      // hi = numerically lowest = highest priority
+        FK_HIP(ctx, hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, hi));
+        FK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_front, hipEventDisableTiming));
+    }
+    if (!tl.done) FK_HIP(ctx, hipEventCreateWithFlags(&tl.done, hipEventDisableTiming));
     const MsmPlan p = make_plan(n, ctx->window_bits);
     hipStream_t st = ctx->stream;
     const size_t WB = (size_t)p.W * p.B;
@@ -522,14 +533,29 @@ static int msm_run(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars, s
     FK_HIP(ctx, ctx->sorted.reserve((size_t)p.W * n * 4));
     FK_HIP(ctx, ctx->totals.reserve(WB * 4));
     FK_HIP(ctx, ctx->starts.reserve(WB * 4));
-    FK_HIP(ctx, ctx->buckets.reserve(WB * sizeof(Xyzz<F>)));
-    FK_HIP(ctx, ctx->winparts.reserve((size_t)p.W * p.nblk * sizeof(Xyzz<F>)));
+    // bucket arrays are used in turn so that the previous multiplication's reduction (second stream) can still
+    // read its buckets while this one accumulates
+    const int slot = ctx->bucket_next;
+    ctx->bucket_next ^= 1;
+    if (ctx->bucket_tail[slot] >= 0 && ctx->tails[ctx->bucket_tail[slot]].done)
+        FK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->tails[ctx->bucket_tail[slot]].done, 0));
+    if (WB * sizeof(Xyzz<F>) > ctx->buckets2[slot].cap) {            // growing frees the old array: nobody may still read it
+        FK_HIP(ctx, hipStreamSynchronize(ctx->stream2));
+        FK_HIP(ctx, ctx->buckets2[slot].reserve(WB * sizeof(Xyzz<F>)));
+    }
+    const size_t wp_bytes = (size_t)p.W * p.nblk * sizeof(Xyzz<F>);
+    FK_HIP(ctx, tl.d_wp.reserve(wp_bytes));
+    if (wp_bytes > tl.h_cap) {
+        if (tl.h_wp) { FK_HIP(ctx, hipHostFree(tl.h_wp)); tl.h_wp = nullptr; tl.h_cap = 0; }
+        FK_HIP(ctx, hipHostMalloc(&tl.h_wp, wp_bytes + (wp_bytes >> 2), hipHostMallocDefault));
+        tl.h_cap = wp_bytes + (wp_bytes >> 2);
+    }
     const uint32_t over_cap = 1u << 16;
     FK_HIP(ctx, ctx->overlist.reserve(over_cap * sizeof(OverEntry) + 16));
     uint32_t *d_nover = (uint32_t *)((char *)ctx->overlist.p + over_cap * sizeof(OverEntry));
     uint32_t *digits = ctx->digits.as<uint32_t>(), *sorted = ctx->sorted.as<uint32_t>();
     uint32_t *totals = ctx->totals.as<uint32_t>(), *starts = ctx->starts.as<uint32_t>();
-    Xyzz<F> *buckets = ctx->buckets.as<Xyzz<F>>(), *winparts = ctx->winparts.as<Xyzz<F>>();
+    Xyzz<F> *buckets = ctx->buckets2[slot].as<Xyzz<F>>(), *winparts = tl.d_wp.as<Xyzz<F>>();
     FK_HIP(ctx, ctx->perm.reserve(WB * 4 + SIZE_BINS * 4));
     uint32_t *perm = ctx->perm.as<uint32_t>(), *size_bins = perm + WB;
 
@@ -630,23 +656,82 @@ static int msm_run(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars, s
         FK_HIP(ctx, hipStreamSynchronize(st));  // tasks/obs vectors must outlive the async copies
     }
 
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_bucket_reduce_kernel<FC>), dim3(p.nblk, p.W), dim3(256), 0, st,
+    // ---- tail: bucket reduction + download of the window sums, on the second stream
+    hipStream_t s2 = ctx->stream2;
+    FK_HIP(ctx, hipEventRecord(ctx->ev_front, st));
+    FK_HIP(ctx, hipStreamWaitEvent(s2, ctx->ev_front, 0));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_bucket_reduce_kernel<FC>), dim3(p.nblk, p.W), dim3(256), 0, s2,
                        reinterpret_cast<const Xyzz<FC> *>(buckets), p.B, p.L, p.T, p.nblk, reinterpret_cast<Xyzz<FC> *>(winparts));
     FK_HIP(ctx, hipGetLastError());
-    FK_DBG(ctx, "msm_bucket_reduce");
+    FK_HIP(ctx, hipMemcpyAsync(tl.h_wp, winparts, wp_bytes, hipMemcpyDeviceToHost, s2));
+    FK_HIP(ctx, hipEventRecord(tl.done, s2));
+    if (ctx->debug) {
+        fprintf(stderr, "[fk] launch msm_bucket_reduce (stream 2) ..."); fflush(stderr);
+        hipError_t e_ = hipStreamSynchronize(s2);
+        fprintf(stderr, " %s\n", hipGetErrorString(e_)); fflush(stderr);
+    }
+    tl.active = true; tl.c = p.c; tl.W = p.W; tl.nblk = p.nblk;
+    ctx->bucket_tail[slot] = ti;
+    *tail_out = ti;
+    return FK_OK;
+}
 
-    std::vector<Xyzz<F>> wp((size_t)p.W * p.nblk);
-    FK_HIP(ctx, hipMemcpyAsync(wp.data(), winparts, wp.size() * sizeof(Xyzz<F>), hipMemcpyDeviceToHost, st));
-    FK_HIP(ctx, hipStreamSynchronize(st));
+template <class F>
+static int msm_end(fk_ctx *ctx, int tail, Xyzz<F> *out) {
+    *out = Xyzz<F>::inf();
+    if (tail < 0) return FK_OK;
+    if (tail >= MSM_TAILS || !ctx->tails[tail].active) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "msm: bad tail handle");
+    MsmTail &tl = ctx->tails[tail];
+    tl.active = false;
+    FK_HIP(ctx, hipEventSynchronize(tl.done));
+    const Xyzz<F> *wp = (const Xyzz<F> *)tl.h_wp;
     // Horner over windows, most significant first
     Xyzz<F> acc = Xyzz<F>::inf();
-    for (uint32_t w = p.W; w-- > 0;) {
-        for (uint32_t k = 0; k < p.c; k++) acc = Xyzz<F>::dbl(acc);
-        for (uint32_t b = 0; b < p.nblk; b++) acc.add(wp[(size_t)w * p.nblk + b]);
+    for (uint32_t w = tl.W; w-- > 0;) {
+        for (uint32_t k = 0; k < tl.c; k++) acc = Xyzz<F>::dbl(acc);
+        for (uint32_t b = 0; b < tl.nblk; b++) acc.add(wp[(size_t)w * tl.nblk + b]);
     }
     *out = acc;
     if (ctx->debug) { fprintf(stderr, "[fk] msm host horner done\n"); fflush(stderr); }
     return FK_OK;
+}
+
+void msm_abandon(fk_ctx *ctx) {
+    bool any = false;
+    for (int i = 0; i < MSM_TAILS; i++) { any = any || ctx->tails[i].active; ctx->tails[i].active = false; }
+    if (any && ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
+}
+
+void msm_release(fk_ctx *ctx) {
+    if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
+    for (int i = 0; i < MSM_TAILS; i++) {
+        MsmTail &tl = ctx->tails[i];
+        if (tl.done) (void)hipEventDestroy(tl.done);
+        if (tl.h_wp) (void)hipHostFree(tl.h_wp);
+        tl.d_wp.release();
+        tl = MsmTail();
+    }
+    ctx->buckets2[0].release(); ctx->buckets2[1].release();
+    if (ctx->ev_front) (void)hipEventDestroy(ctx->ev_front);
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+    ctx->ev_front = nullptr; ctx->stream2 = nullptr;
+}
+
+int msm_g1_begin(fk_ctx *ctx, const G1Affine *d_bases, const Fr *d_scalars, size_t n, int *tail) {
+    return msm_begin<Fq>(ctx, d_bases, d_scalars, n, false, tail);
+}
+int msm_g1_end(fk_ctx *ctx, int tail, G1Xyzz *out) { return msm_end<Fq>(ctx, tail, out); }
+int msm_g2_begin(fk_ctx *ctx, const G2Affine *d_bases, const Fr *d_scalars, size_t n, bool reuse_sort, int *tail) {
+    return msm_begin<Fq2>(ctx, d_bases, d_scalars, n, reuse_sort, tail);
+}
+int msm_g2_end(fk_ctx *ctx, int tail, G2Xyzz *out) { return msm_end<Fq2>(ctx, tail, out); }
+
+template <class F>
+static int msm_run(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars, size_t n, Xyzz<F> *out, bool reuse_sort = false) {
+    int tail = -1;
+    *out = Xyzz<F>::inf();
+    FK_TRY(msm_begin<F>(ctx, d_bases, d_scalars, n, reuse_sort, &tail));
+    return msm_end<F>(ctx, tail, out);
 }
 
 int msm_g1_dev(fk_ctx *ctx, const G1Affine *d_bases, const Fr *d_scalars, size_t n, G1Xyzz *out) {

@@ -76,6 +76,7 @@ void fk_free(fk_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     ntt_free_domains(ctx);
+    msm_release(ctx);
     for (DevBuf *b : {&ctx->digits, &ctx->sorted, &ctx->totals, &ctx->starts, &ctx->buckets, &ctx->winparts,
                       &ctx->overlist, &ctx->tasktab, &ctx->partials, &ctx->misc, &ctx->perm, &ctx->s2_cnt1, &ctx->s2_seg, &ctx->s2_cnt2,
                       &ctx->s2_tmp_idx, &ctx->s2_tmp_lo, &ctx->ntt_s1, &ctx->ntt_s2, &ctx->ntt_io,
@@ -268,41 +269,55 @@ int fk_key_synthetic(fk_ctx *ctx, uint64_t m, uint32_t num_input, uint32_t num_a
 }
 
 // ------------------------------------------------------------------------------------------ prover
-// L, A, B1, B2 over this key's slices (they depend on the assignment only, not on the quotient)
+// L, A, B1, B2 over this key's slices (they depend on the assignment only, not on the quotient).  The bucket
+// reductions run on the second stream underneath the next multiplication (msm_*_begin / msm_*_end); B1 and B2 come
+// first so that the long G2 reduction is covered by L and A.  tail_h: an H multiplication the caller has already
+// begun (-1: none) -- it is finished here, H receives its sum.
 static int prove_msms_z(fk_ctx *ctx, const fk_key *key, const Fr *d_z, const uint8_t *d_a_aux, const uint8_t *d_b_in,
-                        const uint8_t *d_b_aux, uint8_t out[FK_MSM_RESULT_BYTES], fk_timings *tm) {
-    if (!key || !d_z || !out) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "prove: null argument");
+                        const uint8_t *d_b_aux, uint8_t out[FK_MSM_RESULT_BYTES], fk_timings *tm, int tail_h = -1, G1Xyzz *H = nullptr) {
+    if (!key || !d_z || !out) { msm_abandon(ctx); FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "prove: null argument"); }
     FK_HIP(ctx, hipSetDevice(ctx->device));
     const uint32_t v_in = key->num_input, v_aux = key->num_aux;
     G1Xyzz L, A, B1; G2Xyzz B2;
-    const double t2 = now_ms();
-    FK_TRY(msm_g1_dev(ctx, key->d_l, d_z + v_in + key->l_lo, key->l_hi - key->l_lo, &L));
-    const double t3 = now_ms();
-    // A query: all inputs, then the aux variables that occur in some A-side LC
-    FK_HIP(ctx, ctx->sc_a.reserve(((size_t)v_in + v_aux) * sizeof(Fr)));
-    Fr *sa = ctx->sc_a.as<Fr>();
-    FK_HIP(ctx, hipMemcpyAsync(sa, d_z, (size_t)v_in * sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream));
-    uint64_t n_a_aux = 0;
-    FK_TRY(compact_scalars(ctx, d_z + v_in, d_a_aux, v_aux, sa + v_in, &n_a_aux));
-    if (v_in + n_a_aux != key->n_a) FK_SET_ERR(ctx, FK_ERR_KEY_MISMATCH, "prove: a query needs %llu points, key holds %llu",
-                                               (unsigned long long)(v_in + n_a_aux), (unsigned long long)key->n_a);
-    FK_TRY(msm_g1_dev(ctx, key->d_a, sa + key->a_lo, key->a_hi - key->a_lo, &A));
-    const double t4 = now_ms();
-    // B query: inputs and aux variables that occur in some B-side LC
-    FK_HIP(ctx, ctx->sc_b.reserve(((size_t)v_in + v_aux) * sizeof(Fr)));
-    Fr *sb = ctx->sc_b.as<Fr>();
-    uint64_t n_b_in = 0, n_b_aux = 0;
-    FK_TRY(compact_scalars(ctx, d_z, d_b_in, v_in, sb, &n_b_in));
-    FK_TRY(compact_scalars(ctx, d_z + v_in, d_b_aux, v_aux, sb + n_b_in, &n_b_aux));
-    if (n_b_in + n_b_aux != key->n_b) FK_SET_ERR(ctx, FK_ERR_KEY_MISMATCH, "prove: b query needs %llu points, key holds %llu",
-                                                 (unsigned long long)(n_b_in + n_b_aux), (unsigned long long)key->n_b);
-    FK_TRY(msm_g1_dev(ctx, key->d_b1, sb + key->b_lo, key->b_hi - key->b_lo, &B1));
-    const double t5 = now_ms();
-    FK_TRY(msm_g2_dev(ctx, key->d_b2, sb + key->b_lo, key->b_hi - key->b_lo, &B2, /*reuse_sort=*/true));   // same scalars as B1
-    const double t6 = now_ms();
+    int t_l = -1, t_a = -1, t_b1 = -1, t_b2 = -1;
+    auto body = [&]() -> int {
+        const double t2 = now_ms();
+        // B query: inputs and aux variables that occur in some B-side LC
+        FK_HIP(ctx, ctx->sc_b.reserve(((size_t)v_in + v_aux) * sizeof(Fr)));
+        Fr *sb = ctx->sc_b.as<Fr>();
+        uint64_t n_b_in = 0, n_b_aux = 0;
+        FK_TRY(compact_scalars(ctx, d_z, d_b_in, v_in, sb, &n_b_in));
+        FK_TRY(compact_scalars(ctx, d_z + v_in, d_b_aux, v_aux, sb + n_b_in, &n_b_aux));
+        if (n_b_in + n_b_aux != key->n_b) FK_SET_ERR(ctx, FK_ERR_KEY_MISMATCH, "prove: b query needs %llu points, key holds %llu",
+                                                     (unsigned long long)(n_b_in + n_b_aux), (unsigned long long)key->n_b);
+        FK_TRY(msm_g1_begin(ctx, key->d_b1, sb + key->b_lo, key->b_hi - key->b_lo, &t_b1));
+        const double t3 = now_ms();
+        FK_TRY(msm_g2_begin(ctx, key->d_b2, sb + key->b_lo, key->b_hi - key->b_lo, /*reuse_sort=*/true, &t_b2));   // same scalars as B1
+        const double t4 = now_ms();
+        FK_TRY(msm_g1_begin(ctx, key->d_l, d_z + v_in + key->l_lo, key->l_hi - key->l_lo, &t_l));
+        const double t5 = now_ms();
+        // A query: all inputs, then the aux variables that occur in some A-side LC
+        FK_HIP(ctx, ctx->sc_a.reserve(((size_t)v_in + v_aux) * sizeof(Fr)));
+        Fr *sa = ctx->sc_a.as<Fr>();
+        FK_HIP(ctx, hipMemcpyAsync(sa, d_z, (size_t)v_in * sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream));
+        uint64_t n_a_aux = 0;
+        FK_TRY(compact_scalars(ctx, d_z + v_in, d_a_aux, v_aux, sa + v_in, &n_a_aux));
+        if (v_in + n_a_aux != key->n_a) FK_SET_ERR(ctx, FK_ERR_KEY_MISMATCH, "prove: a query needs %llu points, key holds %llu",
+                                                   (unsigned long long)(v_in + n_a_aux), (unsigned long long)key->n_a);
+        FK_TRY(msm_g1_begin(ctx, key->d_a, sa + key->a_lo, key->a_hi - key->a_lo, &t_a));
+        if (tail_h >= 0) FK_TRY(msm_g1_end(ctx, tail_h, H));
+        FK_TRY(msm_g1_end(ctx, t_b1, &B1));
+        FK_TRY(msm_g2_end(ctx, t_b2, &B2));
+        FK_TRY(msm_g1_end(ctx, t_l, &L));
+        FK_TRY(msm_g1_end(ctx, t_a, &A));
+        const double t6 = now_ms();
+        if (tm) { tm->msm_b1_ms = t3 - t2; tm->msm_b2_ms = t4 - t3; tm->msm_l_ms = t5 - t4; tm->msm_a_ms = t6 - t5; }
+        return FK_OK;
+    };
+    const int rc = body();
+    if (rc != FK_OK) { msm_abandon(ctx); return rc; }
     memset(out, 0, FK_G1_BYTES);   // H slot: identity
     g1_to_raw(out + 64, L); g1_to_raw(out + 128, A); g1_to_raw(out + 192, B1); g2_to_raw(out + 256, B2);
-    if (tm) { tm->msm_l_ms = t3 - t2; tm->msm_a_ms = t4 - t3; tm->msm_b1_ms = t5 - t4; tm->msm_b2_ms = t6 - t5; }
     return FK_OK;
 }
 
@@ -320,10 +335,11 @@ static int prove_msms_dev(fk_ctx *ctx, const fk_key *key, Fr *d_a, Fr *d_b, Fr *
     FK_TRY(quotient_dev(ctx, d_a, d_b, d_c, n, d_h, &m));
     FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const double t1 = now_ms();
-    G1Xyzz H;
-    FK_TRY(msm_g1_dev(ctx, key->d_h, d_h + key->h_lo, key->h_hi - key->h_lo, &H));
+    G1Xyzz H = G1Xyzz::inf();
+    int t_h = -1;
+    FK_TRY(msm_g1_begin(ctx, key->d_h, d_h + key->h_lo, key->h_hi - key->h_lo, &t_h));
     const double t2 = now_ms();
-    FK_TRY(prove_msms_z(ctx, key, d_z, d_a_aux, d_b_in, d_b_aux, out, tm));
+    FK_TRY(prove_msms_z(ctx, key, d_z, d_a_aux, d_b_in, d_b_aux, out, tm, t_h, &H));
     g1_to_raw(out, H);
     if (tm) { tm->ntt_ms = t1 - t0; tm->msm_h_ms = t2 - t1; tm->total_ms = now_ms() - t0; }
     return FK_OK;
