@@ -37,7 +37,7 @@ struct EventPair { hipEvent_t a, b; uint64_t units; };
 // multiplication instead of leaving the chip idle.
 struct MsmTail {
     bool active = false;
-    uint32_t c = 0, W = 0, nblk = 0;
+    uint32_t cb = 0, wide = 0, W = 0, nblk = 0;     // window widths (msm.hip: MsmPlan), windows, partial sums per window
     hipEvent_t done = nullptr;      // reduction finished and its window sums are in h_wp
     void *h_wp = nullptr;           // pinned host copy of the window partial sums
     size_t h_cap = 0;

@@ -25,12 +25,13 @@
 
 namespace fk {
 
-static constexpr uint32_t SEG = 4096;          // overflow segment (entries) per wave: 64 per lane
+static constexpr uint32_t SEG_MAX = 4096, SEG_MIN = 256;   // overflow segment (entries) per wave: 4..64 per lane, sized per call
 static constexpr uint32_t SORT_THREADS = 1024;
 
 struct MsmPlan {
     size_t n;
-    uint32_t c, W, B;        // window bits, windows, buckets per window (2^(c-1))
+    uint32_t c, W, B;        // widest window's bits, windows, buckets per window (2^(c-1))
+    uint32_t cb, wide;       // window widths: the first `wide` windows have cb + 1 bits, the others cb (sum = 255)
     uint32_t nchunks;
     size_t chunk;
     uint32_t cap, cap_top;   // max entries a bucket-lane handles itself (all windows but the last / the last, shorter one)
@@ -47,24 +48,39 @@ static MsmPlan make_plan(size_t n, unsigned forced_c) {
     MsmPlan p{};
     p.n = n;
     const size_t nd = n ? n : 1;
-    uint32_t lg = 0; while (((size_t)1 << (lg + 1)) <= nd) lg++;
+    uint32_t lg = 0; while (((size_t)1 << (lg + 1)) <= nd + nd / 2) lg++;     // log2 rounded (2^25 - 1 counts as 2^25)
     // large MSMs: bucket loads of ~64 are enough now that lanes are size-ordered, so c grows with n (fewer digits
     // per scalar: 13 at c = 20 instead of 16)
-    uint32_t c = forced_c ? forced_c : (lg >= 22 ? lg - 5 : (lg >= 18 ? 16 : (lg >= 6 ? lg - 2 : 4)));
+    static int t_small = -1, t_delta = -1, t_sig = -1;
+    if (t_small < 0) {   // tuning knobs (environment, read once)
+        const char *e;
+        t_small = (e = getenv("FK_MSM_C_SMALL")) ? atoi(e) : 17;
+        t_delta = (e = getenv("FK_MSM_C_DELTA")) ? atoi(e) : 5;
+        t_sig = (e = getenv("FK_MSM_CAP_SIGMA")) ? atoi(e) : 6;
+    }
+    uint32_t c = forced_c ? forced_c : (lg >= 22 ? lg - t_delta : (lg >= 18 ? (uint32_t)t_small : (lg >= 6 ? lg - 2 : 4)));
     if (c < 2) c = 2;
     if (c > 22) c = 22;
     p.c = c;
     p.W = (255 + c - 1) / c;
+    p.cb = 255 / p.W;
+    p.wide = 255 - p.cb * p.W;
+    if (p.wide == 0) { p.cb -= 1; p.wide = p.W; }     // all windows equally wide
+    c = p.cb + 1;                                      // the widest window actually used (e.g. a request of 21 gives 13 windows of <= 20 bits)
+    p.c = c;
     p.B = 1u << (c - 1);
     size_t chunk = (n + 255) / 256;          // first-pass chunks per window
     if (chunk < 16384) chunk = 16384;
     p.chunk = chunk;
     p.nchunks = (uint32_t)((n + chunk - 1) / chunk);
-    size_t mean = nd / p.B;
+    // cap = mean load of the NARROW windows (2^(cb-1) buckets in use) + 6 sigma (Poisson) + 8; longer buckets go through the
+    // oversized-bucket path (64 lanes per segment).  One lane walks its bucket serially (~11 us per G1 addition, ~31 us
+    // per G2 addition at the occupancy these kernels run at), so the cap is a floor on the accumulate kernel's duration:
+    // with the former 2*mean + 64 the G2 kernel at 2^22 took cap x 31 us = 6 ms for 3 ms of work.  The windows split the
+    // 255 bits evenly, so there is no short top window any more whose few buckets would all end up on that path.
+    size_t mean = nd >> (p.wide < p.W ? p.cb - 1 : p.cb);
     p.cap = (uint32_t)std::min<size_t>(2 * mean + 64, 1u << 30);
-    // The short top window (254 - (W-1)c bits) concentrates its entries on few buckets.  Those go through the
-    // oversized-bucket path (64 lanes per 4096-entry segment): handing them to single lanes via a larger cap was
-    // measured slower (and catastrophic when the top window has only a handful of buckets), so the cap is uniform.
+    if (t_sig > 0) { uint32_t sq = 1; while ((size_t)sq * sq < mean) sq++; p.cap = (uint32_t)std::min<size_t>(mean + (size_t)t_sig * sq + 8, 1u << 30); }
     p.cap_top = p.cap;
     p.L = p.B >= 4096 ? (p.B >= (1u << 18) ? 64 : p.B / 2048) : 1;     // <= 64 buckets per lane
     p.T = p.B / p.L;
@@ -76,19 +92,23 @@ static MsmPlan make_plan(size_t n, unsigned forced_c) {
 }
 
 // ------------------------------------------------------------------------------------------ digits
-__global__ void msm_digits_kernel(const Fr *scalars, size_t n, uint32_t c, uint32_t W, uint32_t *digits) {
+// Signed digits over W windows that split the 255 bits (254-bit scalar + recoding carry) as evenly as possible: the
+// first `wide` windows are cb + 1 bits, the rest cb bits.  A uniform width would leave a short top window (14 bits at
+// c = 20) whose few buckets each receive thousands of entries and all have to go through the oversized-bucket path.
+__global__ void msm_digits_kernel(const Fr *scalars, size_t n, uint32_t cb, uint32_t wide, uint32_t W, uint32_t *digits) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Fr s = Fr::from_mont(scalars[i]);   // canonical integer, 254 bits
-    const uint32_t B = 1u << (c - 1), mask = (1u << c) - 1;
     uint32_t carry = 0;
     for (uint32_t w = 0; w < W; w++) {
-        const uint32_t o = w * c, limb = o >> 5, sh = o & 31;
+        const uint32_t cw = cb + (w < wide ? 1 : 0);
+        const uint32_t o = w * cb + (w < wide ? w : wide), limb = o >> 5, sh = o & 31;
+        const uint32_t B = 1u << (cw - 1), mask = (1u << cw) - 1;
         uint32_t lo = limb < 8 ? s.v[limb] : 0, hi = limb + 1 < 8 ? s.v[limb + 1] : 0;
         uint32_t raw = (uint32_t)((((uint64_t)hi << 32) | lo) >> sh) & mask;
         raw += carry;
         uint32_t d, neg;
-        if (raw > B) { d = (1u << c) - raw; neg = 1; carry = 1; } else { d = raw; neg = 0; carry = 0; }
+        if (raw > B) { d = (1u << cw) - raw; neg = 1; carry = 1; } else { d = raw; neg = 0; carry = 0; }
         digits[(size_t)w * n + i] = d | (neg << 31);
     }
 }
@@ -445,7 +465,7 @@ struct Task { uint32_t g, seg; };
 template <class F, class FC>
 __global__ __launch_bounds__(64) void msm_overflow_kernel(const Affine<F> *bases, const uint32_t *sorted, size_t n,
                                                           const uint32_t *starts, const uint32_t *totals, uint32_t B,
-                                                          uint32_t W, uint32_t cap_all, uint32_t cap_top, const Task *tasks, Xyzz<FC> *partials) {
+                                                          uint32_t W, uint32_t cap_all, uint32_t cap_top, uint32_t SEG, const Task *tasks, Xyzz<FC> *partials) {
     const Task t = tasks[blockIdx.x];
     const uint32_t w = t.g / B;
     const uint32_t cap = (w == W - 1) ? cap_top : cap_all;
@@ -467,13 +487,14 @@ __global__ __launch_bounds__(64) void msm_overflow_kernel(const Affine<F> *bases
 
 struct OverBucket { uint32_t g, task0, ntask; };
 
-// one wave per oversized bucket: fold its partials into buckets[g]
+// one 256-lane workgroup per oversized bucket: fold its partials into buckets[g]
 template <class F>
-__global__ __launch_bounds__(64) void msm_overflow_fold_kernel(const OverBucket *ob, const Xyzz<F> *partials, Xyzz<F> *buckets) {
+__global__ __launch_bounds__(256) void msm_overflow_fold_kernel(const OverBucket *ob, const Xyzz<F> *partials, Xyzz<F> *buckets) {
+    __shared__ Xyzz<F> sh[4];
     const OverBucket o = ob[blockIdx.x];
     Xyzz<F> acc = Xyzz<F>::inf();
-    for (uint32_t k = threadIdx.x; k < o.ntask; k += 64) acc.add(partials[o.task0 + k]);
-    wave_reduce(acc);
+    for (uint32_t k = threadIdx.x; k < o.ntask; k += 256) acc.add(partials[o.task0 + k]);
+    block_reduce_256(acc, sh);
     if (threadIdx.x == 0) { Xyzz<F> b = buckets[o.g]; b.add(acc); buckets[o.g] = b; }
 }
 
@@ -562,7 +583,7 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
     const bool have_sort = reuse_sort && ctx->last_sort_scalars == (const void *)d_scalars && ctx->last_sort_n == n && ctx->last_sort_c == p.c;
     if (!have_sort) {
         ctx->last_sort_scalars = nullptr;
-        hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, p.c, p.W, digits);
+        hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, p.cb, p.wide, p.W, digits);
         FK_HIP(ctx, hipGetLastError());
         FK_DBG(ctx, "msm_digits");
         FK_HIP(ctx, hipMemsetAsync(d_nover, 0, 4, st));
@@ -622,6 +643,7 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
     uint32_t n_over = 0;
     FK_HIP(ctx, hipMemcpyAsync(&n_over, d_nover, 4, hipMemcpyDeviceToHost, st));
     FK_HIP(ctx, hipStreamSynchronize(st));
+    if (ctx->debug) { fprintf(stderr, "[fk] msm n=%zu c=%u (W=%u: %u x %u bits + %u x %u bits) cap=%u: %u oversized buckets\n", n, p.c, p.W, p.wide, p.cb + 1, p.W - p.wide, p.cb, p.cap, n_over); fflush(stderr); }
     if (n_over > over_cap) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "msm: %u oversized buckets exceed the table (pathological scalar distribution)", n_over);
     if (n_over) {
         std::vector<OverEntry> ov(n_over);
@@ -629,6 +651,11 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
         std::sort(ov.begin(), ov.end(), [](const OverEntry &a, const OverEntry &b) { return a.g < b.g; });
         std::vector<Task> tasks;
         std::vector<OverBucket> obs;
+        // segment length: about two waves per SIMD over all oversized entries, so that a lone giant bucket (all the
+        // scalars equal to 1 meet in one) is a few additions per lane instead of a 64-addition serial walk
+        uint64_t extra_total = 0;
+        for (const OverEntry &e : ov) extra_total += e.size - ((e.g / p.B == p.W - 1) ? p.cap_top : p.cap);
+        uint32_t SEG = (uint32_t)std::min<uint64_t>(SEG_MAX, std::max<uint64_t>(SEG_MIN, ((extra_total / 2048 + 63) / 64) * 64));
         for (const OverEntry &e : ov) {
             const uint32_t cap_w = (e.g / p.B == p.W - 1) ? p.cap_top : p.cap;
             const uint32_t extra = e.size - cap_w;
@@ -646,10 +673,10 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
         FK_HIP(ctx, hipMemcpyAsync(d_obs, obs.data(), ob, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_overflow_kernel<F, FC>), dim3((unsigned)tasks.size()), dim3(64), 0, st,
                            d_bases, sorted, n, starts,
-                           totals, p.B, p.W, p.cap, p.cap_top, d_tasks, ctx->partials.as<Xyzz<FC>>());
+                           totals, p.B, p.W, p.cap, p.cap_top, SEG, d_tasks, ctx->partials.as<Xyzz<FC>>());
         FK_HIP(ctx, hipGetLastError());
     FK_DBG(ctx, "msm_overflow");
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_overflow_fold_kernel<FC>), dim3((unsigned)obs.size()), dim3(64), 0, st, d_obs,
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_overflow_fold_kernel<FC>), dim3((unsigned)obs.size()), dim3(256), 0, st, d_obs,
                            ctx->partials.as<Xyzz<FC>>(), reinterpret_cast<Xyzz<FC> *>(buckets));
         FK_HIP(ctx, hipGetLastError());
     FK_DBG(ctx, "msm_overflow_fold");
@@ -670,7 +697,7 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
         hipError_t e_ = hipStreamSynchronize(s2);
         fprintf(stderr, " %s\n", hipGetErrorString(e_)); fflush(stderr);
     }
-    tl.active = true; tl.c = p.c; tl.W = p.W; tl.nblk = p.nblk;
+    tl.active = true; tl.cb = p.cb; tl.wide = p.wide; tl.W = p.W; tl.nblk = p.nblk;
     ctx->bucket_tail[slot] = ti;
     *tail_out = ti;
     return FK_OK;
@@ -688,7 +715,8 @@ static int msm_end(fk_ctx *ctx, int tail, Xyzz<F> *out) {
     // Horner over windows, most significant first
     Xyzz<F> acc = Xyzz<F>::inf();
     for (uint32_t w = tl.W; w-- > 0;) {
-        for (uint32_t k = 0; k < tl.c; k++) acc = Xyzz<F>::dbl(acc);
+        const uint32_t cw = tl.cb + (w < tl.wide ? 1 : 0);       // acc holds the windows above w, relative to w's top bit
+        for (uint32_t k = 0; k < cw; k++) acc = Xyzz<F>::dbl(acc);
         for (uint32_t b = 0; b < tl.nblk; b++) acc.add(wp[(size_t)w * tl.nblk + b]);
     }
     *out = acc;
@@ -812,7 +840,8 @@ __global__ void gen_scalars_kernel(Fr *out, size_t n, uint64_t seed, int kind) {
     uint64_t s = seed ^ (0xE7037ED1A0B428DBull * (i + 1));
     Fr v;
     for (int k = 0; k < 4; k++) { uint64_t x = splitmix64(s); v.v[2 * k] = (uint32_t)x; v.v[2 * k + 1] = (uint32_t)(x >> 32); }
-    v.v[7] &= 0x0fffffffu;                 // canonical value < 2^252 < r
+    v.v[7] &= 0x3fffffffu;                 // 254 random bits, then one conditional subtraction: (almost) uniform mod r,
+    v = Fr::reduce_once(v);                // so that the top window sees the load real scalars give it
     if (kind == 1) {
         uint64_t sel = splitmix64(s);
         if (sel & 1) { for (int k = 0; k < 8; k++) v.v[k] = 0; v.v[0] = (uint32_t)((sel >> 1) & 1); }
