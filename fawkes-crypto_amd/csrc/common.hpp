@@ -32,13 +32,25 @@ struct NttDomain;
 
 struct EventPair { hipEvent_t a, b; uint64_t units; };
 
-// One multi-scalar multiplication whose bucket reduction has been queued on the second stream (msm.hip): the
-// reduction is a short, latency-bound kernel, so it runs underneath the sort / accumulation of the NEXT
-// multiplication instead of leaving the chip idle.
+// Multi-scalar multiplications run on two independent "lanes" (stream + private scratch) used in turn, so that the
+// memory-bound digit sort of multiplication k+1 and the latency-bound overflow / bucket-reduction kernels of
+// multiplication k run underneath the VALU-bound bucket accumulation of the other lane (msm.hip).
+struct MsmLane {
+    hipStream_t st = nullptr;
+    hipEvent_t ev_in = nullptr;     // main stream -> lane: the scalars are ready
+    DevBuf digits, sorted, totals, starts, perm, overlist, tasktab, partials, s2_cnt1, s2_seg, s2_cnt2, s2_tmp_idx, s2_tmp_lo, buckets;
+    void *h_stage = nullptr;        // pinned host staging: counters read back, oversized-bucket list, task tables
+    size_t h_cap = 0;
+    const void *last_sort_scalars = nullptr; size_t last_sort_n = 0; unsigned last_sort_c = 0;   // what `sorted` currently holds
+    // ... and the oversized-bucket tables that belong to it (already in tasktab on the device)
+    uint32_t last_n_over = 0, last_seg = 0; size_t last_n_tasks = 0, last_n_obs = 0, last_tb_al = 0;
+};
+
+// One outstanding multiplication: everything is queued, `done` fires when its window sums are in h_wp.
 struct MsmTail {
     bool active = false;
     uint32_t cb = 0, wide = 0, W = 0, nblk = 0;     // window widths (msm.hip: MsmPlan), windows, partial sums per window
-    hipEvent_t done = nullptr;      // reduction finished and its window sums are in h_wp
+    hipEvent_t done = nullptr;
     void *h_wp = nullptr;           // pinned host copy of the window partial sums
     size_t h_cap = 0;
     DevBuf d_wp;
@@ -54,16 +66,11 @@ struct fk_ctx {
     unsigned window_bits = 0;  // 0 = auto
     unsigned ntt_threads = 512;  // workgroup size cap of the NTT pass kernel (FK_NTT_THREADS overrides)
     std::map<uint32_t, fk::NttDomain *> domains;
-    // MSM scratch
-    const void *last_sort_scalars = nullptr; size_t last_sort_n = 0; unsigned last_sort_c = 0;   // what `sorted` currently holds
-    fk::DevBuf digits, sorted, totals, starts, buckets, winparts, overlist, tasktab, partials, misc, perm, s2_cnt1, s2_seg, s2_cnt2, s2_tmp_idx, s2_tmp_lo;
-    // deferred bucket reduction: second stream, two bucket arrays used in turn, one record per outstanding MSM
-    hipStream_t stream2 = nullptr;
-    hipEvent_t ev_front = nullptr;
+    // MSM: two lanes used in turn, one record per outstanding multiplication
+    fk::MsmLane lanes[2];
+    int lane_next = 0, lane_prev = 0;
     fk::MsmTail tails[fk::MSM_TAILS];
-    fk::DevBuf buckets2[2];
-    int bucket_tail[2] = {-1, -1};     // the tail that last read each bucket array
-    int bucket_next = 0;
+    fk::DevBuf misc;
     // NTT / prover scratch
     fk::DevBuf ntt_s1, ntt_s2, ntt_io, hbuf, sc_a, sc_b, scan_tmp, stage_a, stage_b, stage_c, stage_z, stage_d;
     // stats
@@ -132,8 +139,8 @@ static inline void h_slice(uint64_t n_h, uint32_t idx, uint32_t cnt, uint64_t *l
 }
 
 // stats helpers (HIP events on the library stream)
-int stats_begin(fk_ctx *ctx, std::vector<EventPair> &v, uint64_t units);
-int stats_end(fk_ctx *ctx, std::vector<EventPair> &v);
+int stats_begin(fk_ctx *ctx, std::vector<EventPair> &v, uint64_t units, hipStream_t st = nullptr);   // nullptr: ctx->stream
+int stats_end(fk_ctx *ctx, std::vector<EventPair> &v, hipStream_t st = nullptr);
 
 // ntt.hip
 int ntt_exec_simple(fk_ctx *ctx, Fr *d_data, uint32_t log_n, bool inverse, bool coset);
@@ -146,15 +153,16 @@ int dq_cross(fk_ctx *ctx, Fr *d_buf, uint32_t log_m, uint32_t rank, uint32_t log
 
 // msm.hip
 int msm_g1_dev(fk_ctx *ctx, const G1Affine *d_bases, const Fr *d_scalars, size_t n, G1Xyzz *out);
-// split form: *_begin queues everything up to the bucket reduction (which goes to the second stream) and returns a
-// tail handle (-1 for an empty sum); *_end waits for it and folds the window sums on the host.  Several
-// multiplications may be outstanding; msm_abandon drops them all (error paths).
+// split form: *_begin queues the whole multiplication on one of the two lanes and returns a tail handle (-1 for an
+// empty sum); *_end waits for it and folds the window sums on the host.  Several multiplications may be outstanding;
+// msm_abandon drops them all (error paths); msm_sync waits for both lanes.
 int msm_g1_begin(fk_ctx *ctx, const G1Affine *d_bases, const Fr *d_scalars, size_t n, int *tail);
 int msm_g1_end(fk_ctx *ctx, int tail, G1Xyzz *out);
 int msm_g2_begin(fk_ctx *ctx, const G2Affine *d_bases, const Fr *d_scalars, size_t n, bool reuse_sort, int *tail);
 int msm_g2_end(fk_ctx *ctx, int tail, G2Xyzz *out);
 void msm_abandon(fk_ctx *ctx);
 void msm_release(fk_ctx *ctx);
+int msm_sync(fk_ctx *ctx);
 // reuse_sort: the scalars are the ones of the immediately preceding MSM call on this context (same pointer
 // and n), so its digits / bucket sort are still valid and are not recomputed (B1 and B2 share scalars)
 int msm_g2_dev(fk_ctx *ctx, const G2Affine *d_bases, const Fr *d_scalars, size_t n, G2Xyzz *out, bool reuse_sort = false);

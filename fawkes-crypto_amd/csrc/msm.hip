@@ -152,22 +152,42 @@ __global__ __launch_bounds__(1024) void s2_prefix1_kernel(uint32_t *cnt1, uint32
         ssz[h] = run;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t run = 0;
-        for (uint32_t h = 0; h < nhi; h++) {
-            const uint32_t v = ssz[h];
-            seg_size[(size_t)w * nhi + h] = v; seg_start[(size_t)w * nhi + h] = run; seg_tiles[(size_t)w * nhi + h] = (v + S2_TILE - 1) / S2_TILE;
-            run += v;
-        }
+    // exclusive scan of the nhi (<= 2048) segment sizes: two values per lane, Hillis-Steele over the lane sums
+    __shared__ uint32_t part[1024];
+    const uint32_t t = threadIdx.x;
+    const uint32_t v0 = 2 * t < nhi ? ssz[2 * t] : 0, v1 = 2 * t + 1 < nhi ? ssz[2 * t + 1] : 0;
+    part[t] = v0 + v1;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+        const uint32_t x = t >= off ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += x;
+        __syncthreads();
     }
+    const uint32_t base = part[t] - (v0 + v1);
+    if (2 * t < nhi) { const size_t g = (size_t)w * nhi + 2 * t; seg_size[g] = v0; seg_start[g] = base; seg_tiles[g] = (v0 + S2_TILE - 1) / S2_TILE; }
+    if (2 * t + 1 < nhi) { const size_t g = (size_t)w * nhi + 2 * t + 1; seg_size[g] = v1; seg_start[g] = base + v0; seg_tiles[g] = (v1 + S2_TILE - 1) / S2_TILE; }
 }
 
-// exclusive prefix of the per-segment tile counts (one lane; <= 22 * 2^11 values); tile_start[nseg] = total
-__global__ void s2_tile_prefix_kernel(const uint32_t *seg_tiles, uint32_t nseg, uint32_t *tile_start) {
-    if (threadIdx.x || blockIdx.x) return;
-    uint32_t run = 0;
-    for (uint32_t s = 0; s < nseg; s++) { tile_start[s] = run; run += seg_tiles[s]; }
-    tile_start[nseg] = run;
+// exclusive prefix of the per-segment tile counts (<= 22 * 2^11 values); tile_start[nseg] = total.  One 1024-lane
+// workgroup: each lane owns a run of consecutive segments, the lane sums are scanned in LDS.
+__global__ __launch_bounds__(1024) void s2_tile_prefix_kernel(const uint32_t *seg_tiles, uint32_t nseg, uint32_t *tile_start) {
+    __shared__ uint32_t part[1024];
+    const uint32_t t = threadIdx.x, per = (nseg + 1023) / 1024;
+    const uint32_t lo = t * per, hi = lo + per < nseg ? lo + per : nseg;
+    uint32_t sum = 0;
+    for (uint32_t s = lo; s < hi; s++) sum += seg_tiles[s];
+    part[t] = sum;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+        const uint32_t v = t >= off ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[t] - sum;
+    for (uint32_t s = lo; s < hi; s++) { tile_start[s] = run; run += seg_tiles[s]; }
+    if (t == 1023) tile_start[nseg] = part[1023];
 }
 
 // First-pass scatter, LDS-staged like the second one: the chunk is walked in sub-tiles of S2_TILE entries; each sub-tile
@@ -530,6 +550,35 @@ __global__ __launch_bounds__(256) void msm_bucket_reduce_kernel(const Xyzz<F> *b
 }
 
 // ------------------------------------------------------------------------------------------ host driver
+#define FK_DBG_ST(ctx, st, name)                                                                  \
+    do {                                                                                          \
+        if ((ctx)->debug) {                                                                       \
+            fprintf(stderr, "[fk] launch %s ...", name); fflush(stderr);                          \
+            hipError_t _e = hipStreamSynchronize(st);                                             \
+            fprintf(stderr, " %s\n", hipGetErrorString(_e)); fflush(stderr);                      \
+        }                                                                                         \
+    } while (0)
+
+static int lane_init(fk_ctx *ctx, MsmLane &ln) {
+    if (ln.st) return FK_OK;
+    FK_HIP(ctx, hipStreamCreateWithFlags(&ln.st, hipStreamNonBlocking));
+    FK_HIP(ctx, hipEventCreateWithFlags(&ln.ev_in, hipEventDisableTiming));
+    return FK_OK;
+}
+
+static int lane_stage(fk_ctx *ctx, MsmLane &ln, size_t bytes) {     // pinned staging, grow-only; callers own the ordering
+    if (bytes <= ln.h_cap) return FK_OK;
+    if (ln.h_stage) { FK_HIP(ctx, hipHostFree(ln.h_stage)); ln.h_stage = nullptr; ln.h_cap = 0; }
+    FK_HIP(ctx, hipHostMalloc(&ln.h_stage, bytes + (bytes >> 2) + 4096, hipHostMallocDefault));
+    ln.h_cap = bytes + (bytes >> 2) + 4096;
+    return FK_OK;
+}
+
+// Queues one multiplication on a lane: digits, two-pass bucket sort, size ordering (host reads back the tile count
+// in the middle and the oversized-bucket list at the end -- the only two points where the host waits), then
+// accumulation, oversized buckets, bucket reduction and the download of the window sums, all without further host
+// involvement.  While the host sits in the sort's read-backs of multiplication k+1, the GPU works on the
+// accumulation of multiplication k on the other lane.
 template <class F>
 static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars, size_t n, bool reuse_sort, int *tail_out) {
     using FC = typename ColdOf<F>::type;   // layout-identical field with an out-of-line multiply
@@ -540,165 +589,169 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
     for (int i = 0; i < MSM_TAILS; i++) if (!ctx->tails[i].active) { ti = i; break; }
     if (ti < 0) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "msm: too many outstanding multiplications");
     MsmTail &tl = ctx->tails[ti];
-    if (!ctx->stream2) {
-        int lo = 0, hi = 0;
-        FK_HIP(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));      // hi = numerically lowest = highest priority
-        FK_HIP(ctx, hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, hi));
-        FK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_front, hipEventDisableTiming));
-    }
     if (!tl.done) FK_HIP(ctx, hipEventCreateWithFlags(&tl.done, hipEventDisableTiming));
     const MsmPlan p = make_plan(n, ctx->window_bits);
-    hipStream_t st = ctx->stream;
+    // lane: the other one than last time, unless this call reuses the previous call's sort (B2 after B1)
+    MsmLane &prev = ctx->lanes[ctx->lane_prev];
+    const bool have_sort = reuse_sort && prev.st && prev.last_sort_scalars == (const void *)d_scalars && prev.last_sort_n == n && prev.last_sort_c == p.c;
+    const int li = have_sort ? ctx->lane_prev : ctx->lane_next;
+    MsmLane &ln = ctx->lanes[li];
+    FK_TRY(lane_init(ctx, ln));
+    ctx->lane_prev = li; ctx->lane_next = li ^ 1;
+    hipStream_t st = ln.st;
+    FK_HIP(ctx, hipEventRecord(ln.ev_in, ctx->stream));            // scalars / bases produced on the main stream
+    FK_HIP(ctx, hipStreamWaitEvent(st, ln.ev_in, 0));
     const size_t WB = (size_t)p.W * p.B;
-    FK_HIP(ctx, ctx->digits.reserve((size_t)p.W * n * 4));
-    FK_HIP(ctx, ctx->sorted.reserve((size_t)p.W * n * 4));
-    FK_HIP(ctx, ctx->totals.reserve(WB * 4));
-    FK_HIP(ctx, ctx->starts.reserve(WB * 4));
-    // bucket arrays are used in turn so that the previous multiplication's reduction (second stream) can still
-    // read its buckets while this one accumulates
-    const int slot = ctx->bucket_next;
-    ctx->bucket_next ^= 1;
-    if (ctx->bucket_tail[slot] >= 0 && ctx->tails[ctx->bucket_tail[slot]].done)
-        FK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->tails[ctx->bucket_tail[slot]].done, 0));
-    if (WB * sizeof(Xyzz<F>) > ctx->buckets2[slot].cap) {            // growing frees the old array: nobody may still read it
-        FK_HIP(ctx, hipStreamSynchronize(ctx->stream2));
-        FK_HIP(ctx, ctx->buckets2[slot].reserve(WB * sizeof(Xyzz<F>)));
-    }
     const size_t wp_bytes = (size_t)p.W * p.nblk * sizeof(Xyzz<F>);
+    const uint32_t over_cap = 1u << 16;
+    // Growing a buffer frees the old one: everything queued on this lane must be finished first.
+    const uint32_t nseg = p.W * p.nhi;
+    const size_t max_tiles = (size_t)p.W * ((n + S2_TILE - 1) / S2_TILE) + nseg + 1;
+    struct Need { DevBuf *b; size_t bytes; };
+    const Need needs[] = {
+        {&ln.digits, (size_t)p.W * n * 4}, {&ln.sorted, (size_t)p.W * n * 4}, {&ln.totals, WB * 4}, {&ln.starts, WB * 4},
+        {&ln.perm, WB * 4 + SIZE_BINS * 4}, {&ln.overlist, over_cap * sizeof(OverEntry) + 16}, {&ln.buckets, WB * sizeof(Xyzz<F>)},
+        {&ln.s2_cnt1, (size_t)p.W * p.nchunks * p.nhi * 4}, {&ln.s2_seg, ((size_t)nseg * 4 + 2) * 4}, {&ln.s2_cnt2, max_tiles * p.nlo * 4},
+        {&ln.s2_tmp_idx, (size_t)p.W * n * 4}, {&ln.s2_tmp_lo, (size_t)p.W * n * 2}};
+    bool grow = false;
+    for (const Need &nd : needs) grow = grow || nd.bytes > nd.b->cap;
+    if (grow) {
+        FK_HIP(ctx, hipStreamSynchronize(st));
+        for (const Need &nd : needs) FK_HIP(ctx, nd.b->reserve(nd.bytes));
+        if (!have_sort) ln.last_sort_scalars = nullptr;
+    }
     FK_HIP(ctx, tl.d_wp.reserve(wp_bytes));
     if (wp_bytes > tl.h_cap) {
         if (tl.h_wp) { FK_HIP(ctx, hipHostFree(tl.h_wp)); tl.h_wp = nullptr; tl.h_cap = 0; }
         FK_HIP(ctx, hipHostMalloc(&tl.h_wp, wp_bytes + (wp_bytes >> 2), hipHostMallocDefault));
         tl.h_cap = wp_bytes + (wp_bytes >> 2);
     }
-    const uint32_t over_cap = 1u << 16;
-    FK_HIP(ctx, ctx->overlist.reserve(over_cap * sizeof(OverEntry) + 16));
-    uint32_t *d_nover = (uint32_t *)((char *)ctx->overlist.p + over_cap * sizeof(OverEntry));
-    uint32_t *digits = ctx->digits.as<uint32_t>(), *sorted = ctx->sorted.as<uint32_t>();
-    uint32_t *totals = ctx->totals.as<uint32_t>(), *starts = ctx->starts.as<uint32_t>();
-    Xyzz<F> *buckets = ctx->buckets2[slot].as<Xyzz<F>>(), *winparts = tl.d_wp.as<Xyzz<F>>();
-    FK_HIP(ctx, ctx->perm.reserve(WB * 4 + SIZE_BINS * 4));
-    uint32_t *perm = ctx->perm.as<uint32_t>(), *size_bins = perm + WB;
+    uint32_t *d_nover = (uint32_t *)((char *)ln.overlist.p + over_cap * sizeof(OverEntry));
+    uint32_t *digits = ln.digits.as<uint32_t>(), *sorted = ln.sorted.as<uint32_t>();
+    uint32_t *totals = ln.totals.as<uint32_t>(), *starts = ln.starts.as<uint32_t>();
+    Xyzz<F> *buckets = ln.buckets.as<Xyzz<F>>(), *winparts = tl.d_wp.as<Xyzz<F>>();
+    uint32_t *perm = ln.perm.as<uint32_t>(), *size_bins = perm + WB;
+    FK_TRY(lane_stage(ctx, ln, 64 + (size_t)over_cap * sizeof(OverEntry)));
 
-    const bool have_sort = reuse_sort && ctx->last_sort_scalars == (const void *)d_scalars && ctx->last_sort_n == n && ctx->last_sort_c == p.c;
     if (!have_sort) {
-        ctx->last_sort_scalars = nullptr;
+        ln.last_sort_scalars = nullptr;
         hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, p.cb, p.wide, p.W, digits);
         FK_HIP(ctx, hipGetLastError());
-        FK_DBG(ctx, "msm_digits");
+        FK_DBG_ST(ctx, st, "msm_digits");
         FK_HIP(ctx, hipMemsetAsync(d_nover, 0, 4, st));
-        {
-            const uint32_t nseg = p.W * p.nhi;
-            const size_t max_tiles = (size_t)p.W * ((n + S2_TILE - 1) / S2_TILE) + nseg + 1;
-            FK_HIP(ctx, ctx->s2_cnt1.reserve((size_t)p.W * p.nchunks * p.nhi * 4));
-            FK_HIP(ctx, ctx->s2_seg.reserve(((size_t)nseg * 4 + 2) * 4));
-            FK_HIP(ctx, ctx->s2_cnt2.reserve(max_tiles * p.nlo * 4));
-            FK_HIP(ctx, ctx->s2_tmp_idx.reserve((size_t)p.W * n * 4));
-            FK_HIP(ctx, ctx->s2_tmp_lo.reserve((size_t)p.W * n * 2));
-            uint32_t *cnt1 = ctx->s2_cnt1.as<uint32_t>();
-            uint32_t *seg_size = ctx->s2_seg.as<uint32_t>(), *seg_start = seg_size + nseg, *seg_tiles = seg_start + nseg, *tile_start = seg_tiles + nseg;
-            uint32_t *cnt2 = ctx->s2_cnt2.as<uint32_t>(), *tmp_idx = ctx->s2_tmp_idx.as<uint32_t>();
-            uint16_t *tmp_lo = ctx->s2_tmp_lo.as<uint16_t>();
-            hipLaunchKernelGGL(s2_hist1_kernel, dim3(p.nchunks, p.W), dim3(SORT_THREADS), p.nhi * 4, st, digits, n, p.chunk, p.nchunks, p.LB, p.nhi, cnt1);
-            hipLaunchKernelGGL(s2_prefix1_kernel, dim3(p.W), dim3(1024), p.nhi * 4, st, cnt1, p.nchunks, p.nhi, seg_size, seg_start, seg_tiles);
-            hipLaunchKernelGGL(s2_tile_prefix_kernel, dim3(1), dim3(64), 0, st, seg_tiles, nseg, tile_start);
-            hipLaunchKernelGGL(s2_scatter1_kernel, dim3(p.nchunks, p.W), dim3(1024), 0, st, digits, n, p.chunk, p.nchunks, p.LB, p.nhi, cnt1,
-                               seg_start, tmp_idx, tmp_lo);
-            FK_HIP(ctx, hipGetLastError());
-            uint32_t n_tiles = 0;
-            FK_HIP(ctx, hipMemcpyAsync(&n_tiles, tile_start + nseg, 4, hipMemcpyDeviceToHost, st));
-            FK_HIP(ctx, hipStreamSynchronize(st));
-            FK_DBG(ctx, "msm_sort_pass1");
-            if (n_tiles > max_tiles) FK_SET_ERR(ctx, FK_ERR_HIP, "msm: tile count %u exceeds the bound %zu", n_tiles, max_tiles);
-            if (n_tiles) {
-                hipLaunchKernelGGL(s2_hist2_kernel, dim3(n_tiles), dim3(256), p.nlo * 4, st, tmp_lo, n, p.nhi, p.nlo, tile_start, nseg, seg_start, seg_size, cnt2);
-            }
-            hipLaunchKernelGGL(s2_prefix2_kernel, dim3(nseg), dim3(1024), 0, st, cnt2, p.nhi, p.nlo, p.B, tile_start, seg_start, p.cap, p.cap_top, p.W, totals, starts,
-                               ctx->overlist.as<OverEntry>(), d_nover, over_cap);
-            if (n_tiles) {
-                hipLaunchKernelGGL(s2_scatter2_kernel, dim3(n_tiles), dim3(1024), 0, st, tmp_idx, tmp_lo, n, p.nhi, p.nlo, p.B, tile_start, nseg, seg_start,
-                                   seg_size, cnt2, starts, sorted);
-            }
-            FK_HIP(ctx, hipGetLastError());
-            FK_DBG(ctx, "msm_sort_pass2");
+        uint32_t *cnt1 = ln.s2_cnt1.as<uint32_t>();
+        uint32_t *seg_size = ln.s2_seg.as<uint32_t>(), *seg_start = seg_size + nseg, *seg_tiles = seg_start + nseg, *tile_start = seg_tiles + nseg;
+        uint32_t *cnt2 = ln.s2_cnt2.as<uint32_t>(), *tmp_idx = ln.s2_tmp_idx.as<uint32_t>();
+        uint16_t *tmp_lo = ln.s2_tmp_lo.as<uint16_t>();
+        hipLaunchKernelGGL(s2_hist1_kernel, dim3(p.nchunks, p.W), dim3(SORT_THREADS), p.nhi * 4, st, digits, n, p.chunk, p.nchunks, p.LB, p.nhi, cnt1);
+        hipLaunchKernelGGL(s2_prefix1_kernel, dim3(p.W), dim3(1024), p.nhi * 4, st, cnt1, p.nchunks, p.nhi, seg_size, seg_start, seg_tiles);
+        hipLaunchKernelGGL(s2_tile_prefix_kernel, dim3(1), dim3(1024), 0, st, seg_tiles, nseg, tile_start);
+        hipLaunchKernelGGL(s2_scatter1_kernel, dim3(p.nchunks, p.W), dim3(1024), 0, st, digits, n, p.chunk, p.nchunks, p.LB, p.nhi, cnt1,
+                           seg_start, tmp_idx, tmp_lo);
+        FK_HIP(ctx, hipGetLastError());
+        uint32_t *h_cnt = (uint32_t *)ln.h_stage;
+        FK_HIP(ctx, hipMemcpyAsync(h_cnt, tile_start + nseg, 4, hipMemcpyDeviceToHost, st));
+        FK_HIP(ctx, hipStreamSynchronize(st));
+        const uint32_t n_tiles = h_cnt[0];
+        FK_DBG_ST(ctx, st, "msm_sort_pass1");
+        if (n_tiles > max_tiles) FK_SET_ERR(ctx, FK_ERR_HIP, "msm: tile count %u exceeds the bound %zu", n_tiles, max_tiles);
+        if (n_tiles) {
+            hipLaunchKernelGGL(s2_hist2_kernel, dim3(n_tiles), dim3(256), p.nlo * 4, st, tmp_lo, n, p.nhi, p.nlo, tile_start, nseg, seg_start, seg_size, cnt2);
         }
+        hipLaunchKernelGGL(s2_prefix2_kernel, dim3(nseg), dim3(1024), 0, st, cnt2, p.nhi, p.nlo, p.B, tile_start, seg_start, p.cap, p.cap_top, p.W, totals, starts,
+                           ln.overlist.as<OverEntry>(), d_nover, over_cap);
+        if (n_tiles) {
+            hipLaunchKernelGGL(s2_scatter2_kernel, dim3(n_tiles), dim3(1024), 0, st, tmp_idx, tmp_lo, n, p.nhi, p.nlo, p.B, tile_start, nseg, seg_start,
+                               seg_size, cnt2, starts, sorted);
+        }
+        FK_HIP(ctx, hipGetLastError());
+        FK_DBG_ST(ctx, st, "msm_sort_pass2");
         // size-ordered bucket -> lane assignment
         FK_HIP(ctx, hipMemsetAsync(size_bins, 0, SIZE_BINS * 4, st));
         hipLaunchKernelGGL(msm_size_hist_kernel, dim3((unsigned)std::min<size_t>((WB + 255) / 256, 1024)), dim3(256), 0, st, totals, WB, p.cap_top, size_bins);
         hipLaunchKernelGGL(msm_size_scan_kernel, dim3(1), dim3(SIZE_BINS), 0, st, size_bins);
         hipLaunchKernelGGL(msm_size_scatter_kernel, dim3((unsigned)((WB + 1023) / 1024)), dim3(1024), 0, st, totals, WB, p.cap_top, size_bins, perm);
         FK_HIP(ctx, hipGetLastError());
-        FK_DBG(ctx, "msm_size_order");
-        ctx->last_sort_scalars = (const void *)d_scalars; ctx->last_sort_n = n; ctx->last_sort_c = p.c;
+        FK_DBG_ST(ctx, st, "msm_size_order");
+        ln.last_sort_scalars = (const void *)d_scalars; ln.last_sort_n = n; ln.last_sort_c = p.c;
     }
+    // oversized buckets (skewed scalars): known once the sort is done -- the host builds the segment table now, so that
+    // nothing has to wait for the accumulation.  With a reused sort the tables of the previous call are still valid.
+    uint32_t n_over = ln.last_n_over, SEG = ln.last_seg;
+    size_t n_tasks = ln.last_n_tasks, n_obs = ln.last_n_obs, tb_al = ln.last_tb_al;
+    if (!have_sort) {
+        uint32_t *h_nover = (uint32_t *)ln.h_stage + 4;
+        OverEntry *h_over = (OverEntry *)((char *)ln.h_stage + 64);
+        FK_HIP(ctx, hipMemcpyAsync(h_nover, d_nover, 4, hipMemcpyDeviceToHost, st));
+        FK_HIP(ctx, hipStreamSynchronize(st));
+        n_over = *h_nover;
+        if (ctx->debug) { fprintf(stderr, "[fk] msm n=%zu c=%u (W=%u: %u x %u bits + %u x %u bits) cap=%u: %u oversized buckets\n", n, p.c, p.W, p.wide, p.cb + 1, p.W - p.wide, p.cb, p.cap, n_over); fflush(stderr); }
+        if (n_over > over_cap) { ln.last_sort_scalars = nullptr; FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "msm: %u oversized buckets exceed the table (pathological scalar distribution)", n_over); }
+        n_tasks = n_obs = tb_al = 0; SEG = SEG_MIN;
+        if (n_over) {
+            FK_HIP(ctx, hipMemcpyAsync(h_over, ln.overlist.p, n_over * sizeof(OverEntry), hipMemcpyDeviceToHost, st));
+            FK_HIP(ctx, hipStreamSynchronize(st));
+            std::vector<OverEntry> ov(h_over, h_over + n_over);
+            std::sort(ov.begin(), ov.end(), [](const OverEntry &a, const OverEntry &b) { return a.g < b.g; });
+            std::vector<Task> tasks;
+            std::vector<OverBucket> obs;
+            // segment length: about two waves per SIMD over all oversized entries, so that a lone giant bucket (all the
+            // scalars equal to 1 meet in one) is a few additions per lane instead of a 64-addition serial walk
+            uint64_t extra_total = 0;
+            for (const OverEntry &e : ov) extra_total += e.size - ((e.g / p.B == p.W - 1) ? p.cap_top : p.cap);
+            SEG = (uint32_t)std::min<uint64_t>(SEG_MAX, std::max<uint64_t>(SEG_MIN, ((extra_total / 2048 + 63) / 64) * 64));
+            for (const OverEntry &e : ov) {
+                const uint32_t cap_w = (e.g / p.B == p.W - 1) ? p.cap_top : p.cap;
+                const uint32_t extra = e.size - cap_w;
+                const uint32_t nt = (extra + SEG - 1) / SEG;
+                obs.push_back(OverBucket{e.g, (uint32_t)tasks.size(), nt});
+                for (uint32_t s = 0; s < nt; s++) tasks.push_back(Task{e.g, s});
+            }
+            n_tasks = tasks.size(); n_obs = obs.size();
+            const size_t tb = n_tasks * sizeof(Task), ob = n_obs * sizeof(OverBucket);
+            tb_al = (tb + 15) & ~(size_t)15;
+            // the lane is idle here (just synchronised), so its buffers and the pinned staging area can be regrown / reused
+            FK_HIP(ctx, ln.tasktab.reserve(tb_al + ob));
+            FK_TRY(lane_stage(ctx, ln, 64 + tb_al + ob));
+            memcpy((char *)ln.h_stage + 64, tasks.data(), tb);
+            memcpy((char *)ln.h_stage + 64 + tb_al, obs.data(), ob);
+            FK_HIP(ctx, hipMemcpyAsync(ln.tasktab.p, (char *)ln.h_stage + 64, tb_al + ob, hipMemcpyHostToDevice, st));
+        }
+        ln.last_n_over = n_over; ln.last_seg = SEG; ln.last_n_tasks = n_tasks; ln.last_n_obs = n_obs; ln.last_tb_al = tb_al;
+    }
+    Task *d_tasks = ln.tasktab.as<Task>();
+    OverBucket *d_obs = (OverBucket *)((char *)ln.tasktab.p + tb_al);
+    if (n_tasks * sizeof(Xyzz<F>) > ln.partials.cap) {      // growing frees the old array: the lane must be idle
+        FK_HIP(ctx, hipStreamSynchronize(st));
+        FK_HIP(ctx, ln.partials.reserve(n_tasks * sizeof(Xyzz<F>)));
+    }
+
+    // ---- from here on nothing waits for the host
     std::vector<EventPair> &evv = (sizeof(F) == sizeof(Fq)) ? ctx->ev_acc : ctx->ev_acc2;
-    FK_TRY(stats_begin(ctx, evv, (uint64_t)n));
+    FK_TRY(stats_begin(ctx, evv, (uint64_t)n, st));
     hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_kernel<F, (sizeof(F) == sizeof(Fq) ? 4 : 1)>), dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, d_bases, sorted, n,
                        starts, totals, p.B, p.W, p.cap, p.cap_top, perm, buckets);
     FK_HIP(ctx, hipGetLastError());
-    FK_DBG(ctx, "msm_accumulate");
-    FK_TRY(stats_end(ctx, evv));
-
-    // oversized buckets (skewed scalars): host builds the segment table -- a few entries in practice
-    uint32_t n_over = 0;
-    FK_HIP(ctx, hipMemcpyAsync(&n_over, d_nover, 4, hipMemcpyDeviceToHost, st));
-    FK_HIP(ctx, hipStreamSynchronize(st));
-    if (ctx->debug) { fprintf(stderr, "[fk] msm n=%zu c=%u (W=%u: %u x %u bits + %u x %u bits) cap=%u: %u oversized buckets\n", n, p.c, p.W, p.wide, p.cb + 1, p.W - p.wide, p.cb, p.cap, n_over); fflush(stderr); }
-    if (n_over > over_cap) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "msm: %u oversized buckets exceed the table (pathological scalar distribution)", n_over);
+    FK_TRY(stats_end(ctx, evv, st));
+    FK_DBG_ST(ctx, st, "msm_accumulate");
     if (n_over) {
-        std::vector<OverEntry> ov(n_over);
-        FK_HIP(ctx, hipMemcpy(ov.data(), ctx->overlist.p, n_over * sizeof(OverEntry), hipMemcpyDeviceToHost));
-        std::sort(ov.begin(), ov.end(), [](const OverEntry &a, const OverEntry &b) { return a.g < b.g; });
-        std::vector<Task> tasks;
-        std::vector<OverBucket> obs;
-        // segment length: about two waves per SIMD over all oversized entries, so that a lone giant bucket (all the
-        // scalars equal to 1 meet in one) is a few additions per lane instead of a 64-addition serial walk
-        uint64_t extra_total = 0;
-        for (const OverEntry &e : ov) extra_total += e.size - ((e.g / p.B == p.W - 1) ? p.cap_top : p.cap);
-        uint32_t SEG = (uint32_t)std::min<uint64_t>(SEG_MAX, std::max<uint64_t>(SEG_MIN, ((extra_total / 2048 + 63) / 64) * 64));
-        for (const OverEntry &e : ov) {
-            const uint32_t cap_w = (e.g / p.B == p.W - 1) ? p.cap_top : p.cap;
-            const uint32_t extra = e.size - cap_w;
-            const uint32_t nt = (extra + SEG - 1) / SEG;
-            obs.push_back(OverBucket{e.g, (uint32_t)tasks.size(), nt});
-            for (uint32_t s = 0; s < nt; s++) tasks.push_back(Task{e.g, s});
-        }
-        const size_t tb = tasks.size() * sizeof(Task), ob = obs.size() * sizeof(OverBucket);
-        const size_t tb_al = (tb + 15) & ~(size_t)15;
-        FK_HIP(ctx, ctx->tasktab.reserve(tb_al + ob));
-        FK_HIP(ctx, ctx->partials.reserve(tasks.size() * sizeof(Xyzz<F>)));
-        Task *d_tasks = ctx->tasktab.as<Task>();
-        OverBucket *d_obs = (OverBucket *)((char *)ctx->tasktab.p + tb_al);
-        FK_HIP(ctx, hipMemcpyAsync(d_tasks, tasks.data(), tb, hipMemcpyHostToDevice, st));
-        FK_HIP(ctx, hipMemcpyAsync(d_obs, obs.data(), ob, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_overflow_kernel<F, FC>), dim3((unsigned)tasks.size()), dim3(64), 0, st,
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_overflow_kernel<F, FC>), dim3((unsigned)n_tasks), dim3(64), 0, st,
                            d_bases, sorted, n, starts,
-                           totals, p.B, p.W, p.cap, p.cap_top, SEG, d_tasks, ctx->partials.as<Xyzz<FC>>());
+                           totals, p.B, p.W, p.cap, p.cap_top, SEG, d_tasks, ln.partials.as<Xyzz<FC>>());
         FK_HIP(ctx, hipGetLastError());
-    FK_DBG(ctx, "msm_overflow");
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_overflow_fold_kernel<FC>), dim3((unsigned)obs.size()), dim3(256), 0, st, d_obs,
-                           ctx->partials.as<Xyzz<FC>>(), reinterpret_cast<Xyzz<FC> *>(buckets));
+        FK_DBG_ST(ctx, st, "msm_overflow");
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_overflow_fold_kernel<FC>), dim3((unsigned)n_obs), dim3(256), 0, st, d_obs,
+                           ln.partials.as<Xyzz<FC>>(), reinterpret_cast<Xyzz<FC> *>(buckets));
         FK_HIP(ctx, hipGetLastError());
-    FK_DBG(ctx, "msm_overflow_fold");
-        FK_HIP(ctx, hipStreamSynchronize(st));  // tasks/obs vectors must outlive the async copies
+        FK_DBG_ST(ctx, st, "msm_overflow_fold");
     }
-
-    // ---- tail: bucket reduction + download of the window sums, on the second stream
-    hipStream_t s2 = ctx->stream2;
-    FK_HIP(ctx, hipEventRecord(ctx->ev_front, st));
-    FK_HIP(ctx, hipStreamWaitEvent(s2, ctx->ev_front, 0));
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_bucket_reduce_kernel<FC>), dim3(p.nblk, p.W), dim3(256), 0, s2,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_bucket_reduce_kernel<FC>), dim3(p.nblk, p.W), dim3(256), 0, st,
                        reinterpret_cast<const Xyzz<FC> *>(buckets), p.B, p.L, p.T, p.nblk, reinterpret_cast<Xyzz<FC> *>(winparts));
     FK_HIP(ctx, hipGetLastError());
-    FK_HIP(ctx, hipMemcpyAsync(tl.h_wp, winparts, wp_bytes, hipMemcpyDeviceToHost, s2));
-    FK_HIP(ctx, hipEventRecord(tl.done, s2));
-    if (ctx->debug) {
-        fprintf(stderr, "[fk] launch msm_bucket_reduce (stream 2) ..."); fflush(stderr);
-        hipError_t e_ = hipStreamSynchronize(s2);
-        fprintf(stderr, " %s\n", hipGetErrorString(e_)); fflush(stderr);
-    }
+    FK_HIP(ctx, hipMemcpyAsync(tl.h_wp, winparts, wp_bytes, hipMemcpyDeviceToHost, st));
+    FK_HIP(ctx, hipEventRecord(tl.done, st));
+    FK_DBG_ST(ctx, st, "msm_bucket_reduce");
     tl.active = true; tl.cb = p.cb; tl.wide = p.wide; tl.W = p.W; tl.nblk = p.nblk;
-    ctx->bucket_tail[slot] = ti;
     *tail_out = ti;
     return FK_OK;
 }
@@ -724,14 +777,27 @@ static int msm_end(fk_ctx *ctx, int tail, Xyzz<F> *out) {
     return FK_OK;
 }
 
+int msm_sync(fk_ctx *ctx) {
+    for (MsmLane &ln : ctx->lanes) if (ln.st) FK_HIP(ctx, hipStreamSynchronize(ln.st));
+    return FK_OK;
+}
+
 void msm_abandon(fk_ctx *ctx) {
-    bool any = false;
-    for (int i = 0; i < MSM_TAILS; i++) { any = any || ctx->tails[i].active; ctx->tails[i].active = false; }
-    if (any && ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
+    for (int i = 0; i < MSM_TAILS; i++) ctx->tails[i].active = false;
+    for (MsmLane &ln : ctx->lanes) { if (ln.st) (void)hipStreamSynchronize(ln.st); ln.last_sort_scalars = nullptr; }
 }
 
 void msm_release(fk_ctx *ctx) {
-    if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
+    for (MsmLane &ln : ctx->lanes) {
+        if (ln.st) (void)hipStreamSynchronize(ln.st);
+        for (DevBuf *b : {&ln.digits, &ln.sorted, &ln.totals, &ln.starts, &ln.perm, &ln.overlist, &ln.tasktab, &ln.partials, &ln.s2_cnt1, &ln.s2_seg,
+                          &ln.s2_cnt2, &ln.s2_tmp_idx, &ln.s2_tmp_lo, &ln.buckets})
+            b->release();
+        if (ln.h_stage) (void)hipHostFree(ln.h_stage);
+        if (ln.ev_in) (void)hipEventDestroy(ln.ev_in);
+        if (ln.st) (void)hipStreamDestroy(ln.st);
+        ln = MsmLane();
+    }
     for (int i = 0; i < MSM_TAILS; i++) {
         MsmTail &tl = ctx->tails[i];
         if (tl.done) (void)hipEventDestroy(tl.done);
@@ -739,10 +805,6 @@ void msm_release(fk_ctx *ctx) {
         tl.d_wp.release();
         tl = MsmTail();
     }
-    ctx->buckets2[0].release(); ctx->buckets2[1].release();
-    if (ctx->ev_front) (void)hipEventDestroy(ctx->ev_front);
-    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
-    ctx->ev_front = nullptr; ctx->stream2 = nullptr;
 }
 
 int msm_g1_begin(fk_ctx *ctx, const G1Affine *d_bases, const Fr *d_scalars, size_t n, int *tail) {

@@ -16,7 +16,7 @@ using namespace fk;
 
 namespace fk {
 
-int stats_begin(fk_ctx *ctx, std::vector<EventPair> &v, uint64_t units) {
+int stats_begin(fk_ctx *ctx, std::vector<EventPair> &v, uint64_t units, hipStream_t st) {
     if (!ctx->stats_on) return FK_OK;
     EventPair ep{};
     ep.units = units;
@@ -24,13 +24,13 @@ int stats_begin(fk_ctx *ctx, std::vector<EventPair> &v, uint64_t units) {
         if (!ctx->ev_pool.empty()) { *e = ctx->ev_pool.back(); ctx->ev_pool.pop_back(); }
         else FK_HIP(ctx, hipEventCreate(e));
     }
-    FK_HIP(ctx, hipEventRecord(ep.a, ctx->stream));
+    FK_HIP(ctx, hipEventRecord(ep.a, st ? st : ctx->stream));
     v.push_back(ep);
     return FK_OK;
 }
-int stats_end(fk_ctx *ctx, std::vector<EventPair> &v) {
+int stats_end(fk_ctx *ctx, std::vector<EventPair> &v, hipStream_t st) {
     if (!ctx->stats_on) return FK_OK;
-    FK_HIP(ctx, hipEventRecord(v.back().b, ctx->stream));
+    FK_HIP(ctx, hipEventRecord(v.back().b, st ? st : ctx->stream));
     return FK_OK;
 }
 
@@ -77,9 +77,7 @@ void fk_free(fk_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     ntt_free_domains(ctx);
     msm_release(ctx);
-    for (DevBuf *b : {&ctx->digits, &ctx->sorted, &ctx->totals, &ctx->starts, &ctx->buckets, &ctx->winparts,
-                      &ctx->overlist, &ctx->tasktab, &ctx->partials, &ctx->misc, &ctx->perm, &ctx->s2_cnt1, &ctx->s2_seg, &ctx->s2_cnt2,
-                      &ctx->s2_tmp_idx, &ctx->s2_tmp_lo, &ctx->ntt_s1, &ctx->ntt_s2, &ctx->ntt_io,
+    for (DevBuf *b : {&ctx->misc, &ctx->ntt_s1, &ctx->ntt_s2, &ctx->ntt_io,
                       &ctx->hbuf, &ctx->sc_a, &ctx->sc_b, &ctx->scan_tmp, &ctx->stage_a, &ctx->stage_b, &ctx->stage_c,
                       &ctx->stage_z, &ctx->stage_d})
         b->release();
@@ -130,7 +128,7 @@ int fk_dev_copy(fk_ctx *ctx, void *dst, const void *src, size_t bytes) {
 int fk_sync(fk_ctx *ctx) {
     if (!ctx) return FK_ERR_BAD_ARG;
     FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return FK_OK;
+    return msm_sync(ctx);
 }
 
 // ------------------------------------------------------------------------------------------ key
@@ -671,6 +669,7 @@ void fk_h_shard_range(uint64_t n_h, uint32_t index, uint32_t count, uint64_t *lo
 int fk_stats_reset(fk_ctx *ctx) {
     if (!ctx) return FK_ERR_BAD_ARG;
     FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    FK_TRY(msm_sync(ctx));
     for (auto *v : {&ctx->ev_acc, &ctx->ev_acc2, &ctx->ev_ntt}) {
         for (auto &ep : *v) { ctx->ev_pool.push_back(ep.a); ctx->ev_pool.push_back(ep.b); }
         v->clear();
@@ -681,6 +680,7 @@ int fk_stats_get(fk_ctx *ctx, int which, double *ms, uint64_t *launches, uint64_
     if (!ctx) return FK_ERR_BAD_ARG;
     if (which < 0 || which > 2) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "stats: which must be 0 (G1 accumulate), 1 (G2 accumulate) or 2 (NTT pass)");
     FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    FK_TRY(msm_sync(ctx));
     std::vector<EventPair> &v = which == 0 ? ctx->ev_acc : (which == 1 ? ctx->ev_acc2 : ctx->ev_ntt);
     double t = 0; uint64_t u = 0;
     for (auto &ep : v) { float x = 0; FK_HIP(ctx, hipEventElapsedTime(&x, ep.a, ep.b)); t += x; u += ep.units; }
