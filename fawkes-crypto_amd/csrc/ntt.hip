@@ -78,23 +78,37 @@ __global__ __launch_bounds__(NTT_MAX_THREADS) void ntt_pass_kernel(PassArgs a) {
     const uint64_t i_base = (uint64_t)blockIdx.x << a.logC;
     const uint32_t Lmask = (1u << a.L) - 1;
 
+    // Every lane handles two elements / butterflies per step (e and e + NTT_THREADS) so that the field products can
+    // be issued as dual chains (Fr::mul2: two interleaved accumulator chains per wave, the same instruction count).
+    // tile is a multiple of 2 * NTT_THREADS except for tiny transforms, where the second element is masked off.
+
     // ---- load tile (rows r, columns c), fused pre-op and inter-pass twiddle
-    for (uint32_t e = tid; e < tile; e += NTT_THREADS) {
-        const uint32_t c = e & (C - 1), r = e >> a.logC;
-        const uint64_t i = i_base + c;
-        const uint64_t idx = i + (uint64_t)r * t;
-        Fr v = a.x[idx];
+    const Fr one = Fr::one();
+    for (uint32_t e0 = tid; e0 < tile; e0 += 2 * NTT_THREADS) {
+        const uint32_t e1 = e0 + NTT_THREADS;
+        const bool has1 = e1 < tile;
+        const uint32_t ee1 = has1 ? e1 : e0;
+        const uint32_t c0 = e0 & (C - 1), r0 = e0 >> a.logC, c1 = ee1 & (C - 1), r1 = ee1 >> a.logC;
+        const uint64_t i0 = i_base + c0, i1 = i_base + c1;
+        const uint64_t idx0 = i0 + (uint64_t)r0 * t, idx1 = i1 + (uint64_t)r1 * t;
+        Fr v0 = a.x[idx0], v1 = a.x[idx1];
         if (a.pre_mode == PRE_ABC) {
-            v = Fr::sub(Fr::mul(v, a.xb[idx]), a.xc[idx]);
+            Fr p0, p1;
+            Fr::mul2(v0, a.xb[idx0], v1, a.xb[idx1], p0, p1);
+            v0 = Fr::sub(p0, a.xc[idx0]); v1 = Fr::sub(p1, a.xc[idx1]);
         } else if (a.pre_mode == PRE_TABLE) {
-            v = Fr::mul(v, Fr::mul(a.pre_lo[idx & Lmask], a.pre_hi[idx >> a.L]));
+            Fr s0, s1;
+            Fr::mul2(a.pre_lo[idx0 & Lmask], a.pre_hi[idx0 >> a.L], a.pre_lo[idx1 & Lmask], a.pre_hi[idx1 >> a.L], s0, s1);
+            Fr::mul2(v0, s0, v1, s1, v0, v1);
         }
         if (a.lgp) {
-            const uint64_t k = i & pmask;
-            const uint64_t ee = (k * r) << (a.log_n - a.lgp - a.deg);
-            if (ee) v = Fr::mul(v, Fr::mul(a.tw_lo[ee & Lmask], a.tw_hi[ee >> a.L]));
+            const uint64_t x0 = ((i0 & pmask) * r0) << (a.log_n - a.lgp - a.deg), x1 = ((i1 & pmask) * r1) << (a.log_n - a.lgp - a.deg);
+            Fr w0, w1;
+            Fr::mul2(a.tw_lo[x0 & Lmask], a.tw_hi[x0 >> a.L], a.tw_lo[x1 & Lmask], a.tw_hi[x1 >> a.L], w0, w1);
+            Fr::mul2(v0, w0, v1, w1, v0, v1);
         }
-        lds_put(p0, p1, e, v);
+        lds_put(p0, p1, e0, v0);
+        if (has1) lds_put(p0, p1, e1, v1);
     }
     __syncthreads();
 
@@ -102,34 +116,58 @@ __global__ __launch_bounds__(NTT_MAX_THREADS) void ntt_pass_kernel(PassArgs a) {
     const uint32_t nbf = tile >> 1;
     for (uint32_t rnd = 0; rnd < a.deg; rnd++) {
         const uint32_t bit = (R >> 1) >> rnd;
-        for (uint32_t bf = tid; bf < nbf; bf += NTT_THREADS) {
-            const uint32_t c = bf & (C - 1), ii = bf >> a.logC;
-            const uint32_t di = ii & (bit - 1);
-            const uint32_t i0 = ((ii - di) << 1) + di, i1 = i0 + bit;
-            const uint32_t e0 = (i0 << a.logC) + c, e1 = (i1 << a.logC) + c;
-            Fr u = lds_get(p0, p1, e0), w = lds_get(p0, p1, e1);
-            Fr s = Fr::add(u, w), d = Fr::sub(u, w);
-            if (di) d = Fr::mul(d, a.pq[(di << rnd) << a.pq_shift]);
-            lds_put(p0, p1, e0, s);
-            lds_put(p0, p1, e1, d);
+        if (bit == 1) {                       // last stage: every twiddle is 1
+            for (uint32_t bf = tid; bf < nbf; bf += NTT_THREADS) {
+                const uint32_t c = bf & (C - 1), ii = bf >> a.logC;
+                const uint32_t e0 = ((ii << 1) << a.logC) + c, e1 = e0 + C;
+                Fr u = lds_get(p0, p1, e0), w = lds_get(p0, p1, e1);
+                lds_put(p0, p1, e0, Fr::add(u, w));
+                lds_put(p0, p1, e1, Fr::sub(u, w));
+            }
+        } else {
+            for (uint32_t bfa = tid; bfa < nbf; bfa += 2 * NTT_THREADS) {
+                const uint32_t bfb_ = bfa + NTT_THREADS;
+                const bool hasb = bfb_ < nbf;
+                const uint32_t bfb = hasb ? bfb_ : bfa;
+                const uint32_t ca = bfa & (C - 1), ia = bfa >> a.logC, cb = bfb & (C - 1), ib = bfb >> a.logC;
+                const uint32_t da = ia & (bit - 1), db = ib & (bit - 1);
+                const uint32_t a0 = ((ia - da) << 1) + da, b0 = ((ib - db) << 1) + db;
+                const uint32_t ea0 = (a0 << a.logC) + ca, ea1 = ((a0 + bit) << a.logC) + ca;
+                const uint32_t eb0 = (b0 << a.logC) + cb, eb1 = ((b0 + bit) << a.logC) + cb;
+                Fr ua = lds_get(p0, p1, ea0), wa = lds_get(p0, p1, ea1), ub = lds_get(p0, p1, eb0), wb = lds_get(p0, p1, eb1);
+                Fr sa = Fr::add(ua, wa), dfa = Fr::sub(ua, wa), sb = Fr::add(ub, wb), dfb = Fr::sub(ub, wb);
+                Fr::mul2(dfa, a.pq[(da << rnd) << a.pq_shift], dfb, a.pq[(db << rnd) << a.pq_shift], dfa, dfb);   // pq[0] = 1
+                lds_put(p0, p1, ea0, sa);
+                lds_put(p0, p1, ea1, dfa);
+                if (hasb) { lds_put(p0, p1, eb0, sb); lds_put(p0, p1, eb1, dfb); }
+            }
         }
         __syncthreads();
     }
 
     // ---- store tile to its autosorted place, fused post-op
-    for (uint32_t e = tid; e < tile; e += NTT_THREADS) {
-        uint32_t c, rr;
-        if (a.lgp == 0) { rr = e & (R - 1); c = e >> a.deg; }      // first pass: runs of R outputs
-        else { c = e & (C - 1); rr = e >> a.logC; }                // later passes: runs of C outputs
-        const uint32_t q = a.deg ? (__brev(rr) >> (32 - a.deg)) : 0;
-        Fr v = lds_get(p0, p1, (q << a.logC) + c);
-        const uint64_t i = i_base + c;
-        const uint64_t k = i & pmask;
-        const uint64_t o = ((i - k) << a.deg) + k + ((uint64_t)rr << a.lgp);
-        if (a.post_mode == POST_CONST) v = Fr::mul(v, a.post_const);
-        else if (a.post_mode == POST_TABLE) v = Fr::mul(v, Fr::mul(a.post_lo[o & Lmask], a.post_hi[o >> a.L]));
-        a.y[o] = v;
+    for (uint32_t e0 = tid; e0 < tile; e0 += 2 * NTT_THREADS) {
+        const uint32_t e1_ = e0 + NTT_THREADS;
+        const bool has1 = e1_ < tile;
+        const uint32_t e1 = has1 ? e1_ : e0;
+        uint32_t c0, rr0, c1, rr1;
+        if (a.lgp == 0) { rr0 = e0 & (R - 1); c0 = e0 >> a.deg; rr1 = e1 & (R - 1); c1 = e1 >> a.deg; }      // first pass: runs of R outputs
+        else { c0 = e0 & (C - 1); rr0 = e0 >> a.logC; c1 = e1 & (C - 1); rr1 = e1 >> a.logC; }            // later passes: runs of C outputs
+        const uint32_t q0 = a.deg ? (__brev(rr0) >> (32 - a.deg)) : 0, q1 = a.deg ? (__brev(rr1) >> (32 - a.deg)) : 0;
+        Fr v0 = lds_get(p0, p1, (q0 << a.logC) + c0), v1 = lds_get(p0, p1, (q1 << a.logC) + c1);
+        const uint64_t i0 = i_base + c0, i1 = i_base + c1;
+        const uint64_t k0 = i0 & pmask, k1 = i1 & pmask;
+        const uint64_t o0 = ((i0 - k0) << a.deg) + k0 + ((uint64_t)rr0 << a.lgp), o1 = ((i1 - k1) << a.deg) + k1 + ((uint64_t)rr1 << a.lgp);
+        if (a.post_mode == POST_CONST) Fr::mul2(v0, a.post_const, v1, a.post_const, v0, v1);
+        else if (a.post_mode == POST_TABLE) {
+            Fr s0, s1;
+            Fr::mul2(a.post_lo[o0 & Lmask], a.post_hi[o0 >> a.L], a.post_lo[o1 & Lmask], a.post_hi[o1 >> a.L], s0, s1);
+            Fr::mul2(v0, s0, v1, s1, v0, v1);
+        }
+        a.y[o0] = v0;
+        if (has1) a.y[o1] = v1;
     }
+    (void)one;
 }
 
 __global__ void fr_mul_batch_kernel(const Fr *a, const Fr *b, Fr *o, size_t n) {
@@ -258,8 +296,8 @@ static int ntt_exec(fk_ctx *ctx, NttDomain *d, const NttOp &op, const Fr *in, Fr
         const size_t lds_bytes = (size_t)2 * sizeof(uint4) << (deg + logC);
         FK_HIP(ctx, hipFuncSetAttribute((const void *)ntt_pass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         FK_TRY(stats_begin(ctx, ctx->ev_ntt, (uint64_t)1 << d->log_n));
-        // one lane per butterfly where the tile allows it: more waves per CU to hide LDS / multiply latency
-        uint32_t threads = 1u << (deg + logC > 0 ? deg + logC - 1 : 0);
+        // one lane per two butterflies (the kernel issues the field products of a pair as dual chains)
+        uint32_t threads = 1u << (deg + logC > 1 ? deg + logC - 2 : 0);
         if (threads < 64) threads = 64;
         if (threads > ctx->ntt_threads) threads = ctx->ntt_threads;
         hipLaunchKernelGGL(ntt_pass_kernel, dim3((unsigned)nblk), dim3(threads), lds_bytes, ctx->stream, a);
