@@ -360,6 +360,20 @@ int fk_prove_msm_h_dev(fk_ctx *ctx, const fk_key *key, const void *d_h_slice, ui
     return FK_OK;
 }
 
+int fk_prove_msms_hz_dev(fk_ctx *ctx, const fk_key *key, const void *d_h_slice, const void *d_z, const void *d_a_aux, const void *d_b_in,
+                         const void *d_b_aux, uint8_t out[FK_MSM_RESULT_BYTES], fk_timings *tm) {
+    if (!ctx) return FK_ERR_BAD_ARG;
+    if (tm) memset(tm, 0, sizeof *tm);
+    if (!key || !out || (!d_h_slice && key->h_hi > key->h_lo)) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "prove: null argument");
+    FK_HIP(ctx, hipSetDevice(ctx->device));
+    G1Xyzz H = G1Xyzz::inf();
+    int t_h = -1;
+    FK_TRY(msm_g1_begin(ctx, key->d_h, (const Fr *)d_h_slice, key->h_hi - key->h_lo, &t_h));
+    FK_TRY(prove_msms_z(ctx, key, (const Fr *)d_z, (const uint8_t *)d_a_aux, (const uint8_t *)d_b_in, (const uint8_t *)d_b_aux, out, tm, t_h, &H));
+    g1_to_raw(out, H);
+    return FK_OK;
+}
+
 int fk_prove_msms_dev(fk_ctx *ctx, const fk_key *key, void *d_a, void *d_b, void *d_c, uint64_t n, const void *d_z,
                       const void *d_a_aux, const void *d_b_in, const void *d_b_aux, uint8_t out[FK_MSM_RESULT_BYTES], fk_timings *tm) {
     if (!ctx) return FK_ERR_BAD_ARG;

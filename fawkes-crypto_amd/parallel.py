@@ -231,7 +231,6 @@ def prove_distributed_dev(ctx, key, rank, world, d_full, n, log_m, d_z, d_a_aux,
     if a2a is None:
         a2a = torch_all_to_all(ctx, group)
     h_blk = quotient_distributed(ctx, rank, world, d_full, n, log_m, send, recv, a2a)
-    part = np.array(ctx.prove_msms_z_dev(key, d_z, d_a_aux, d_b_in, d_b_aux), dtype=np.uint8, copy=True)
-    part[:64] = ctx.prove_msm_h_dev(key, h_blk.data_ptr())
+    part = ctx.prove_msms_hz_dev(key, h_blk.data_ptr(), d_z, d_a_aux, d_b_in, d_b_aux)
     parts = all_gather_parts(part, group=group, device=device)
     return ctx.prove_assemble(key, parts, r, s)

@@ -148,6 +148,11 @@ int fk_prove_msms_z_dev(fk_ctx *ctx, const fk_key *key, const void *d_z, const v
                         const void *d_b_input_density, const void *d_b_aux_density,
                         uint8_t out_msms[FK_MSM_RESULT_BYTES], fk_timings *timings);
 int fk_prove_msm_h_dev(fk_ctx *ctx, const fk_key *key, const void *d_h_slice, uint8_t out[FK_G1_BYTES]);
+/* both at once (the five multiplications are pipelined against each other): the complete FK_MSM_RESULT_BYTES record of
+ * this key's slices, given this rank's block of quotient coefficients (distributed quotient, fk_dq_*). */
+int fk_prove_msms_hz_dev(fk_ctx *ctx, const fk_key *key, const void *d_h_slice, const void *d_z, const void *d_a_aux,
+                         const void *d_b_input_density, const void *d_b_aux_density, uint8_t out_msms[FK_MSM_RESULT_BYTES],
+                         fk_timings *timings);
 /* ctx may be NULL here (pure host arithmetic). */
 int fk_prove_assemble(fk_ctx *ctx, const fk_key *key, const uint8_t *msm_parts, uint32_t n_parts,
                       const uint64_t r[4], const uint64_t s[4], uint8_t out_proof[FK_PROOF_BYTES]);
