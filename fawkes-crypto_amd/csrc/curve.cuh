@@ -69,8 +69,8 @@ struct alignas(16) Xyzz {
         // the ten multiplications form five independent pairs -> five dual-chain products (F::mul2)
         F u2, s2;
         F::mul2(q.x, zz, q.y, zzz, u2, s2);
-        F p = F::sub(u2, x);
-        F r = F::sub(s2, y);
+        F p, r;
+        F::sub2(u2, x, s2, y, p, r);                 // independent differences: one dual-chain operation
         if (p.is_zero()) {
             if (r.is_zero()) *this = dbl_affine(q); else *this = inf();
             return;
@@ -79,7 +79,9 @@ struct alignas(16) Xyzz {
         F::mul2(p, p, r, r, pp, rr);
         F ppp, q_;
         F::mul2(p, pp, x, pp, ppp, q_);
-        F x3 = F::sub(F::sub(rr, ppp), F::dbl(q_));
+        F q2, t1;
+        F::addsub2(q_, q_, rr, ppp, q2, t1);         // q2 = 2 q, t1 = rr - ppp
+        F x3 = F::sub(t1, q2);
         F t, yppp;
         F::mul2(r, F::sub(q_, x3), y, ppp, t, yppp);
         y = F::sub(t, yppp);

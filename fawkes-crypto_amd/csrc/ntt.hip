@@ -95,7 +95,7 @@ __global__ __launch_bounds__(NTT_MAX_THREADS) void ntt_pass_kernel(PassArgs a) {
         if (a.pre_mode == PRE_ABC) {
             Fr p0, p1;
             Fr::mul2(v0, a.xb[idx0], v1, a.xb[idx1], p0, p1);
-            v0 = Fr::sub(p0, a.xc[idx0]); v1 = Fr::sub(p1, a.xc[idx1]);
+            Fr::sub2(p0, a.xc[idx0], p1, a.xc[idx1], v0, v1);
         } else if (a.pre_mode == PRE_TABLE) {
             Fr s0, s1;
             Fr::mul2(a.pre_lo[idx0 & Lmask], a.pre_hi[idx0 >> a.L], a.pre_lo[idx1 & Lmask], a.pre_hi[idx1 >> a.L], s0, s1);
@@ -112,35 +112,50 @@ __global__ __launch_bounds__(NTT_MAX_THREADS) void ntt_pass_kernel(PassArgs a) {
     }
     __syncthreads();
 
-    // ---- deg radix-2 DIF stages in LDS
-    const uint32_t nbf = tile >> 1;
-    for (uint32_t rnd = 0; rnd < a.deg; rnd++) {
-        const uint32_t bit = (R >> 1) >> rnd;
-        if (bit == 1) {                       // last stage: every twiddle is 1
-            for (uint32_t bf = tid; bf < nbf; bf += NTT_THREADS) {
-                const uint32_t c = bf & (C - 1), ii = bf >> a.logC;
-                const uint32_t e0 = ((ii << 1) << a.logC) + c, e1 = e0 + C;
-                Fr u = lds_get(p0, p1, e0), w = lds_get(p0, p1, e1);
-                lds_put(p0, p1, e0, Fr::add(u, w));
-                lds_put(p0, p1, e1, Fr::sub(u, w));
+    // ---- deg DIF stages in LDS, two at a time: a lane holds the four elements of a radix-4 group in registers, so a
+    // pair of stages costs one LDS round trip and one barrier (same four products as two radix-2 stages:
+    // T1, T2 for the first stage, T3 twice for the second -- issued as two dual chains)
+    const uint32_t ngrp = tile >> 2;
+    uint32_t rnd = 0;
+    for (; rnd + 1 < a.deg; rnd += 2) {
+        const uint32_t bit = (R >> 1) >> rnd, bq = bit >> 1;
+        for (uint32_t g = tid; g < ngrp; g += NTT_THREADS) {
+            const uint32_t c = g & (C - 1), ii = g >> a.logC;
+            const uint32_t d = ii & (bq - 1);
+            const uint32_t row = ((ii - d) << 2) + d;                 // bits `bit` and `bq` of the row are zero
+            const uint32_t e0 = (row << a.logC) + c, e1 = e0 + (bq << a.logC), e2 = e0 + (bit << a.logC), e3 = e2 + (bq << a.logC);
+            Fr x0 = lds_get(p0, p1, e0), x1 = lds_get(p0, p1, e1), x2 = lds_get(p0, p1, e2), x3 = lds_get(p0, p1, e3);
+            Fr s0, d0, s1, d1, y0, y1;
+            Fr::addsub2(x0, x2, x0, x2, s0, d0);
+            Fr::addsub2(x1, x3, x1, x3, s1, d1);
+            Fr::addsub2(s0, s1, s0, s1, y0, y1);
+            if (bq == 1) {                                            // d = 0: T1 = T3 = 1, T2 = the fourth root
+                d1 = Fr::mul(d1, a.pq[(1u << rnd) << a.pq_shift]);
+            } else {
+                Fr::mul2(d0, a.pq[(d << rnd) << a.pq_shift], d1, a.pq[((d + bq) << rnd) << a.pq_shift], d0, d1);
             }
-        } else {
-            for (uint32_t bfa = tid; bfa < nbf; bfa += 2 * NTT_THREADS) {
-                const uint32_t bfb_ = bfa + NTT_THREADS;
-                const bool hasb = bfb_ < nbf;
-                const uint32_t bfb = hasb ? bfb_ : bfa;
-                const uint32_t ca = bfa & (C - 1), ia = bfa >> a.logC, cb = bfb & (C - 1), ib = bfb >> a.logC;
-                const uint32_t da = ia & (bit - 1), db = ib & (bit - 1);
-                const uint32_t a0 = ((ia - da) << 1) + da, b0 = ((ib - db) << 1) + db;
-                const uint32_t ea0 = (a0 << a.logC) + ca, ea1 = ((a0 + bit) << a.logC) + ca;
-                const uint32_t eb0 = (b0 << a.logC) + cb, eb1 = ((b0 + bit) << a.logC) + cb;
-                Fr ua = lds_get(p0, p1, ea0), wa = lds_get(p0, p1, ea1), ub = lds_get(p0, p1, eb0), wb = lds_get(p0, p1, eb1);
-                Fr sa = Fr::add(ua, wa), dfa = Fr::sub(ua, wa), sb = Fr::add(ub, wb), dfb = Fr::sub(ub, wb);
-                Fr::mul2(dfa, a.pq[(da << rnd) << a.pq_shift], dfb, a.pq[(db << rnd) << a.pq_shift], dfa, dfb);   // pq[0] = 1
-                lds_put(p0, p1, ea0, sa);
-                lds_put(p0, p1, ea1, dfa);
-                if (hasb) { lds_put(p0, p1, eb0, sb); lds_put(p0, p1, eb1, dfb); }
+            Fr y2, y3;
+            Fr::addsub2(d0, d1, d0, d1, y2, y3);
+            if (bq != 1) {
+                const Fr t3 = a.pq[(d << (rnd + 1)) << a.pq_shift];
+                Fr::mul2(y1, t3, y3, t3, y1, y3);
             }
+            lds_put(p0, p1, e0, y0);
+            lds_put(p0, p1, e1, y1);
+            lds_put(p0, p1, e2, y2);
+            lds_put(p0, p1, e3, y3);
+        }
+        __syncthreads();
+    }
+    if (rnd < a.deg) {                        // odd degree: the last stage stands alone, and all its twiddles are 1
+        const uint32_t nbf = tile >> 1;
+        for (uint32_t bf = tid; bf < nbf; bf += NTT_THREADS) {
+            const uint32_t c = bf & (C - 1), ii = bf >> a.logC;
+            const uint32_t e0 = ((ii << 1) << a.logC) + c, e1 = e0 + C;
+            Fr u = lds_get(p0, p1, e0), w = lds_get(p0, p1, e1), sm, df;
+            Fr::addsub2(u, w, u, w, sm, df);
+            lds_put(p0, p1, e0, sm);
+            lds_put(p0, p1, e1, df);
         }
         __syncthreads();
     }
@@ -410,8 +425,8 @@ static __device__ __forceinline__ void small_dft(Fr (&v)[1 << LOGW], const Fr *w
 #pragma unroll
             for (int j = 0; j < half; j++) {
                 Fr u = v[blk + j], t = v[blk + j + half];
-                v[blk + j] = Fr::add(u, t);
-                Fr d = Fr::sub(u, t);
+                Fr d;
+                Fr::addsub2(u, t, u, t, v[blk + j], d);
                 v[blk + j + half] = j ? Fr::mul(d, wt[j << s]) : d;
             }
         }
