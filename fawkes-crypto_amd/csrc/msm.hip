@@ -729,7 +729,7 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
     // ---- from here on nothing waits for the host
     std::vector<EventPair> &evv = (sizeof(F) == sizeof(Fq)) ? ctx->ev_acc : ctx->ev_acc2;
     FK_TRY(stats_begin(ctx, evv, (uint64_t)n, st));
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_kernel<F, (sizeof(F) == sizeof(Fq) ? 4 : 1)>), dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, d_bases, sorted, n,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_kernel<F, (sizeof(F) == sizeof(Fq) ? 4 : 2)>), dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, d_bases, sorted, n,
                        starts, totals, p.B, p.W, p.cap, p.cap_top, perm, buckets);
     FK_HIP(ctx, hipGetLastError());
     FK_TRY(stats_end(ctx, evv, st));

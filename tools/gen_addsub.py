@@ -15,7 +15,8 @@ of it.  The dual form (two independent operations = four chains, one limb of eac
 with no padding: 4 instructions per limb pair.  The single form pads with one s_nop per limb.  `check()` replays the
 generated statements back to back (assuming NO padding between statements) and verifies the rule.
 
-Forms generated (members of Fp):  as1_A, as1_S (single add / sub);  as2_AA, as2_SS, as2_AS (r1 = a op1 b, r2 = c op2 d).
+Forms generated (members of Fp):  as1_A, as1_S (single add / sub);  as2_AA, as2_SS, as2_AS (r1 = a op1 b, r2 = c op2 d);
+red2 (two conditional subtractions of p: the tail of the dual Montgomery product).
 """
 import os
 import re
@@ -83,6 +84,27 @@ def gen_dual(o, op1, op2):
     o.append('    }')
 
 
+def gen_red2(o):
+    """two conditional subtractions of p at once (the tail of a dual Montgomery product: x, y < 2p)"""
+    o.append('    static __device__ __forceinline__ void red2(const Fp &x, const Fp &y, Fp &r1, Fp &r2) {')
+    o.append('        uint32_t t1[8], t2[8]; uint64_t w1, w2; Fp u, v;')
+    for k in range(8):
+        cs = ', '.join('"%s"(%s)' % ('=&s' if k == 0 else '+s', n) for n in ('w1', 'w2'))
+        body = '\\n\\t'.join([prim('S', k, '%0', '%2', '%4', '%6'), prim('S', k, '%1', '%3', '%5', '%6'), 's_nop 0'])
+        o.append('        asm("%s" : "=&v"(t1[%d]), "=&v"(t2[%d]), %s : "v"(x.v[%d]), "v"(y.v[%d]), "v"(P::p(%d)));' % (body, k, k, cs, k, k, k))
+    first = True
+    for src, t, res, w in (('x', 't1', 'u', 'w1'), ('y', 't2', 'v', 'w2')):
+        for half in range(2):
+            ks = range(4 * half, 4 * half + 4)
+            lines = (['s_nop 0'] if first else []) + ['v_cndmask_b32_e64 %%%d, %%%d, %%%d, %%12' % (i, 5 + 2 * i, 4 + 2 * i) for i in range(4)]
+            first = False
+            outs = ', '.join('"=&v"(%s.v[%d])' % (res, k) for k in ks)
+            ins = ', '.join('"v"(%s.v[%d]), "v"(%s[%d])' % (src, k, t, k) for k in ks)
+            o.append('        asm("%s" : %s : %s, "s"(%s));' % ('\\n\\t'.join(lines), outs, ins, w))
+    o.append('        r1 = u; r2 = v;')
+    o.append('    }')
+
+
 def check(text):
     """Replay each function's asm statements back to back; operands are resolved to their C names so that carries are
     tracked across statements.  Every read of an SGPR carry / mask must be >= 2 instructions after its last write."""
@@ -117,6 +139,7 @@ def main():
     gen_dual(o, 'A', 'A')
     gen_dual(o, 'S', 'S')
     gen_dual(o, 'A', 'S')
+    gen_red2(o)
     text = '\n'.join(o) + '\n'
     n, bad = check(text)
     if bad or n == 0:

@@ -30,12 +30,15 @@ def mad_line(acc, carry, kind, xi, yi):
     return 'v_mad_u64_u32 %%%d, %%%d, %%%d, %%%d, %%%d' % (acc, carry, xi, yi, acc)
 
 
-def addc_line(hi, carry):
+def addc_line(hi, carry, fresh=False):
+    # fresh: `hi` holds nothing yet (start of a column) -> hi = 0 + 0 + carry, so no zeroing move is needed
+    if fresh:
+        return 'v_addc_co_u32 %%%d, %%%d, 0, 0, %%%d' % (hi, carry, carry)
     return 'v_addc_co_u32 %%%d, %%%d, 0, %%%d, %%%d' % (hi, carry, hi, carry)
 
 
-def stmt1(pairs, kind):
-    """single chain; operands: %0 lo, %1 hi, %2..%4 carries, then x,y pairs"""
+def stmt1(pairs, kind, first=False):
+    """single chain; operands: %0 lo, %1 hi, %2..%4 carries, then x,y pairs.  first: first statement of a column"""
     n = len(pairs)
     seq = []                      # ('mad', i) / ('addc', i) / ('nop',)
     for i in range(n):
@@ -55,19 +58,21 @@ def stmt1(pairs, kind):
         opidx[i] = (idx, idx + 1)
         ops.append('"v"(%s), "%s"(%s)' % (x, 's' if kind == 'vs' else 'v', y))
         idx += 2
+    fresh = first
     for s in seq:
         if s[0] == 'mad':
             xi, yi = opidx[s[1]]
             lines.append(mad_line(0, 2 + s[1] % 3, kind, xi, yi))
         elif s[0] == 'addc':
-            lines.append(addc_line(1, 2 + s[1] % 3))
+            lines.append(addc_line(1, 2 + s[1] % 3, fresh))
+            fresh = False
         else:
             lines.append('s_nop 0')
     body = '\\n\\t'.join(lines)
-    return '        asm("%s" : "+v"(lo), "+v"(hi), "=&s"(c0), "=&s"(c1), "=&s"(c2) : %s);' % (body, ', '.join(ops))
+    return '        asm("%s" : "+v"(lo), "%s"(hi), "=&s"(c0), "=&s"(c1), "=&s"(c2) : %s);' % (body, '=&v' if first else '+v', ', '.join(ops))
 
 
-def stmt2(pairs_a, pairs_b, kind):
+def stmt2(pairs_a, pairs_b, kind, first=False):
     """two chains; operands: %0 lo, %1 hi, %2 lo2, %3 hi2, %4,%5 carries of A, %6,%7 carries of B, then operands"""
     n = len(pairs_a)
     lines, ops = [], []
@@ -88,15 +93,16 @@ def stmt2(pairs_a, pairs_b, kind):
         lines.append(mad_line(0, 4 + i % 2, kind, xa, ya))
         lines.append(mad_line(2, 6 + i % 2, kind, xb, yb))
         if i >= 1:
-            lines.append(addc_line(1, 4 + (i - 1) % 2))
-            lines.append(addc_line(3, 6 + (i - 1) % 2))
+            lines.append(addc_line(1, 4 + (i - 1) % 2, first and i == 1))
+            lines.append(addc_line(3, 6 + (i - 1) % 2, first and i == 1))
     if n == 1:
         lines.append('s_nop 0')
-    lines.append(addc_line(1, 4 + (n - 1) % 2))
-    lines.append(addc_line(3, 6 + (n - 1) % 2))
+    lines.append(addc_line(1, 4 + (n - 1) % 2, first and n == 1))
+    lines.append(addc_line(3, 6 + (n - 1) % 2, first and n == 1))
     body = '\\n\\t'.join(lines)
-    return ('        asm("%s" : "+v"(lo), "+v"(hi), "+v"(lo2), "+v"(hi2), "=&s"(a0), "=&s"(a1), "=&s"(b0), "=&s"(b1) : %s);'
-            % (body, ', '.join(ops)))
+    hc = '=&v' if first else '+v'
+    return ('        asm("%s" : "+v"(lo), "%s"(hi), "+v"(lo2), "%s"(hi2), "=&s"(a0), "=&s"(a1), "=&s"(b0), "=&s"(b1) : %s);'
+            % (body, hc, hc, ', '.join(ops)))
 
 
 def columns():
@@ -108,20 +114,22 @@ def columns():
 
 def gen_mul(o):
     o.append('    static __device__ __forceinline__ Fp mul_body_asm(const Fp &a, const Fp &b) {')
-    o.append('        uint64_t lo = 0; uint32_t hi = 0; uint64_t c0, c1, c2;')
+    o.append('        uint64_t lo = 0; uint32_t hi; uint64_t c0, c1, c2;')
     o.append('        uint32_t m0, m1, m2, m3, m4, m5, m6, m7;')
     o.append('        Fp r;')
     for k, ab, mp in columns():
         o.append('        // column %d' % k)
         if mp:
-            o.append(stmt1([('m%d' % i, 'P::p(%d)' % j) for i, j in mp], 'vs'))
-        o.append(stmt1([('a.v[%d]' % i, 'b.v[%d]' % j) for i, j in ab], 'vv'))
+            o.append(stmt1([('m%d' % i, 'P::p(%d)' % j) for i, j in mp], 'vs', first=True))
+        if ab:
+            o.append(stmt1([('a.v[%d]' % i, 'b.v[%d]' % j) for i, j in ab], 'vv', first=not mp))
         if k < 8:
             o.append('        m%d = (uint32_t)lo * P::INV;' % k)
             o.append(stmt1([('m%d' % k, 'P::p(0)')], 'vs'))
         else:
             o.append('        r.v[%d] = (uint32_t)lo;' % (k - 8))
-        o.append('        lo = (lo >> 32) | ((uint64_t)hi << 32); hi = 0;')
+        if mp or ab:      # `hi` is (re)written by the first v_addc of every column that has products
+            o.append('        lo = (lo >> 32) | ((uint64_t)hi << 32);')
     o.append('        return reduce_once(r);')
     o.append('    }')
 
@@ -130,23 +138,25 @@ def gen_mul2(o):
     o.append('// Two independent products at once (r1 = a*b, r2 = c*d): the two column accumulators are interleaved')
     o.append('// instruction by instruction so every wave carries two dependency chains.')
     o.append('    static __device__ __forceinline__ void mul2_body_asm(const Fp &a, const Fp &b, const Fp &c, const Fp &d, Fp &r1, Fp &r2) {')
-    o.append('        uint64_t lo = 0, lo2 = 0; uint32_t hi = 0, hi2 = 0; uint64_t a0, a1, b0, b1;')
+    o.append('        uint64_t lo = 0, lo2 = 0; uint32_t hi, hi2; uint64_t a0, a1, b0, b1;')
     o.append('        uint32_t m0, m1, m2, m3, m4, m5, m6, m7, n0, n1, n2, n3, n4, n5, n6, n7;')
     o.append('        Fp x, y;')
     for k, ab, mp in columns():
         o.append('        // column %d' % k)
         if mp:   # 8 + 3n operands <= 29 for n <= 7
-            o.append(stmt2([('m%d' % i, 'P::p(%d)' % j) for i, j in mp], [('n%d' % i, 'P::p(%d)' % j) for i, j in mp], 'vs'))
+            o.append(stmt2([('m%d' % i, 'P::p(%d)' % j) for i, j in mp], [('n%d' % i, 'P::p(%d)' % j) for i, j in mp], 'vs', first=True))
         for lo_ in range(0, len(ab), 5):     # 8 + 4n <= 28 operands
             chunk = ab[lo_:lo_ + 5]
-            o.append(stmt2([('a.v[%d]' % i, 'b.v[%d]' % j) for i, j in chunk], [('c.v[%d]' % i, 'd.v[%d]' % j) for i, j in chunk], 'vv'))
+            o.append(stmt2([('a.v[%d]' % i, 'b.v[%d]' % j) for i, j in chunk], [('c.v[%d]' % i, 'd.v[%d]' % j) for i, j in chunk], 'vv',
+                           first=(not mp and lo_ == 0)))
         if k < 8:
             o.append('        m%d = (uint32_t)lo * P::INV; n%d = (uint32_t)lo2 * P::INV;' % (k, k))
             o.append(stmt2([('m%d' % k, 'P::p(0)')], [('n%d' % k, 'P::p(0)')], 'vs'))
         else:
             o.append('        x.v[%d] = (uint32_t)lo; y.v[%d] = (uint32_t)lo2;' % (k - 8, k - 8))
-        o.append('        lo = (lo >> 32) | ((uint64_t)hi << 32); hi = 0; lo2 = (lo2 >> 32) | ((uint64_t)hi2 << 32); hi2 = 0;')
-    o.append('        r1 = reduce_once(x); r2 = reduce_once(y);')
+        if mp or ab:
+            o.append('        lo = (lo >> 32) | ((uint64_t)hi << 32); lo2 = (lo2 >> 32) | ((uint64_t)hi2 << 32);')
+    o.append('        red2(x, y, r1, r2);')
     o.append('    }')
 
 
