@@ -71,6 +71,11 @@ struct fk_ctx {
     int lane_next = 0, lane_prev = 0;
     fk::MsmTail tails[fk::MSM_TAILS];
     fk::DevBuf misc;
+    // witness multiplications (L, A, B1, B2) in flight: begun before / while the quotient runs on the main stream
+    hipStream_t aux = nullptr;          // scalar compaction for the A / B queries
+    hipEvent_t ev_aux = nullptr, ev_main = nullptr;
+    bool wit_active = false;
+    int wit_tail[4] = {-1, -1, -1, -1}; // B1, B2, L, A
     // NTT / prover scratch
     fk::DevBuf ntt_s1, ntt_s2, ntt_io, hbuf, sc_a, sc_b, scan_tmp, stage_a, stage_b, stage_c, stage_z, stage_d;
     // stats
@@ -156,9 +161,10 @@ int msm_g1_dev(fk_ctx *ctx, const G1Affine *d_bases, const Fr *d_scalars, size_t
 // split form: *_begin queues the whole multiplication on one of the two lanes and returns a tail handle (-1 for an
 // empty sum); *_end waits for it and folds the window sums on the host.  Several multiplications may be outstanding;
 // msm_abandon drops them all (error paths); msm_sync waits for both lanes.
-int msm_g1_begin(fk_ctx *ctx, const G1Affine *d_bases, const Fr *d_scalars, size_t n, int *tail);
+// ready: event after which bases / scalars are valid (nullptr: everything queued on ctx->stream so far)
+int msm_g1_begin(fk_ctx *ctx, const G1Affine *d_bases, const Fr *d_scalars, size_t n, int *tail, hipEvent_t ready = nullptr);
 int msm_g1_end(fk_ctx *ctx, int tail, G1Xyzz *out);
-int msm_g2_begin(fk_ctx *ctx, const G2Affine *d_bases, const Fr *d_scalars, size_t n, bool reuse_sort, int *tail);
+int msm_g2_begin(fk_ctx *ctx, const G2Affine *d_bases, const Fr *d_scalars, size_t n, bool reuse_sort, int *tail, hipEvent_t ready = nullptr);
 int msm_g2_end(fk_ctx *ctx, int tail, G2Xyzz *out);
 void msm_abandon(fk_ctx *ctx);
 void msm_release(fk_ctx *ctx);
@@ -170,6 +176,6 @@ int gen_points_g1(fk_ctx *ctx, G1Affine *d_out, size_t n, uint64_t seed);
 int gen_points_g2(fk_ctx *ctx, G2Affine *d_out, size_t n, uint64_t seed);
 int gen_scalars(fk_ctx *ctx, Fr *d_out, size_t n, uint64_t seed, int kind);
 // out[k] = z[j] for the k-th j with density[j] != 0 (device pointers); returns count via *n_out
-int compact_scalars(fk_ctx *ctx, const Fr *d_z, const uint8_t *d_density, size_t n, Fr *d_out, uint64_t *n_out);
+int compact_scalars(fk_ctx *ctx, const Fr *d_z, const uint8_t *d_density, size_t n, Fr *d_out, uint64_t *n_out, hipStream_t st = nullptr);
 
 }  // namespace fk

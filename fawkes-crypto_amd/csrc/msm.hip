@@ -580,7 +580,7 @@ static int lane_stage(fk_ctx *ctx, MsmLane &ln, size_t bytes) {     // pinned st
 // involvement.  While the host sits in the sort's read-backs of multiplication k+1, the GPU works on the
 // accumulation of multiplication k on the other lane.
 template <class F>
-static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars, size_t n, bool reuse_sort, int *tail_out) {
+static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars, size_t n, bool reuse_sort, int *tail_out, hipEvent_t ready) {
     using FC = typename ColdOf<F>::type;   // layout-identical field with an out-of-line multiply
     *tail_out = -1;
     if (n == 0) return FK_OK;
@@ -599,8 +599,12 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
     FK_TRY(lane_init(ctx, ln));
     ctx->lane_prev = li; ctx->lane_next = li ^ 1;
     hipStream_t st = ln.st;
-    FK_HIP(ctx, hipEventRecord(ln.ev_in, ctx->stream));            // scalars / bases produced on the main stream
-    FK_HIP(ctx, hipStreamWaitEvent(st, ln.ev_in, 0));
+    if (ready) {
+        FK_HIP(ctx, hipStreamWaitEvent(st, ready, 0));
+    } else {
+        FK_HIP(ctx, hipEventRecord(ln.ev_in, ctx->stream));        // scalars / bases produced on the main stream
+        FK_HIP(ctx, hipStreamWaitEvent(st, ln.ev_in, 0));
+    }
     const size_t WB = (size_t)p.W * p.B;
     const size_t wp_bytes = (size_t)p.W * p.nblk * sizeof(Xyzz<F>);
     const uint32_t over_cap = 1u << 16;
@@ -778,16 +782,22 @@ static int msm_end(fk_ctx *ctx, int tail, Xyzz<F> *out) {
 }
 
 int msm_sync(fk_ctx *ctx) {
+    if (ctx->aux) FK_HIP(ctx, hipStreamSynchronize(ctx->aux));
     for (MsmLane &ln : ctx->lanes) if (ln.st) FK_HIP(ctx, hipStreamSynchronize(ln.st));
     return FK_OK;
 }
 
 void msm_abandon(fk_ctx *ctx) {
+    ctx->wit_active = false;
+    if (ctx->aux) (void)hipStreamSynchronize(ctx->aux);
     for (int i = 0; i < MSM_TAILS; i++) ctx->tails[i].active = false;
     for (MsmLane &ln : ctx->lanes) { if (ln.st) (void)hipStreamSynchronize(ln.st); ln.last_sort_scalars = nullptr; }
 }
 
 void msm_release(fk_ctx *ctx) {
+    if (ctx->aux) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamDestroy(ctx->aux); ctx->aux = nullptr; }
+    if (ctx->ev_aux) { (void)hipEventDestroy(ctx->ev_aux); ctx->ev_aux = nullptr; }
+    if (ctx->ev_main) { (void)hipEventDestroy(ctx->ev_main); ctx->ev_main = nullptr; }
     for (MsmLane &ln : ctx->lanes) {
         if (ln.st) (void)hipStreamSynchronize(ln.st);
         for (DevBuf *b : {&ln.digits, &ln.sorted, &ln.totals, &ln.starts, &ln.perm, &ln.overlist, &ln.tasktab, &ln.partials, &ln.s2_cnt1, &ln.s2_seg,
@@ -807,12 +817,12 @@ void msm_release(fk_ctx *ctx) {
     }
 }
 
-int msm_g1_begin(fk_ctx *ctx, const G1Affine *d_bases, const Fr *d_scalars, size_t n, int *tail) {
-    return msm_begin<Fq>(ctx, d_bases, d_scalars, n, false, tail);
+int msm_g1_begin(fk_ctx *ctx, const G1Affine *d_bases, const Fr *d_scalars, size_t n, int *tail, hipEvent_t ready) {
+    return msm_begin<Fq>(ctx, d_bases, d_scalars, n, false, tail, ready);
 }
 int msm_g1_end(fk_ctx *ctx, int tail, G1Xyzz *out) { return msm_end<Fq>(ctx, tail, out); }
-int msm_g2_begin(fk_ctx *ctx, const G2Affine *d_bases, const Fr *d_scalars, size_t n, bool reuse_sort, int *tail) {
-    return msm_begin<Fq2>(ctx, d_bases, d_scalars, n, reuse_sort, tail);
+int msm_g2_begin(fk_ctx *ctx, const G2Affine *d_bases, const Fr *d_scalars, size_t n, bool reuse_sort, int *tail, hipEvent_t ready) {
+    return msm_begin<Fq2>(ctx, d_bases, d_scalars, n, reuse_sort, tail, ready);
 }
 int msm_g2_end(fk_ctx *ctx, int tail, G2Xyzz *out) { return msm_end<Fq2>(ctx, tail, out); }
 
@@ -820,7 +830,7 @@ template <class F>
 static int msm_run(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars, size_t n, Xyzz<F> *out, bool reuse_sort = false) {
     int tail = -1;
     *out = Xyzz<F>::inf();
-    FK_TRY(msm_begin<F>(ctx, d_bases, d_scalars, n, reuse_sort, &tail));
+    FK_TRY(msm_begin<F>(ctx, d_bases, d_scalars, n, reuse_sort, &tail, nullptr));
     return msm_end<F>(ctx, tail, out);
 }
 
@@ -966,22 +976,23 @@ __global__ __launch_bounds__(256) void compact_scatter_kernel(const Fr *z, const
     for (int k = 0; k < 8; k++) if (base + k < n && dens[base + k]) out[pos++] = z[base + k];
 }
 
-int compact_scalars(fk_ctx *ctx, const Fr *d_z, const uint8_t *d_density, size_t n, Fr *d_out, uint64_t *n_out) {
+int compact_scalars(fk_ctx *ctx, const Fr *d_z, const uint8_t *d_density, size_t n, Fr *d_out, uint64_t *n_out, hipStream_t st) {
     *n_out = 0;
     if (!n) return FK_OK;
+    if (!st) st = ctx->stream;
     const uint32_t nb = (uint32_t)((n + CP_BLOCK - 1) / CP_BLOCK);
     FK_HIP(ctx, ctx->scan_tmp.reserve((size_t)nb * 4 + 16));
     uint32_t *blk = ctx->scan_tmp.as<uint32_t>();
     uint32_t *d_total = blk + nb;
-    hipLaunchKernelGGL(compact_count_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_density, n, blk);
+    hipLaunchKernelGGL(compact_count_kernel, dim3(nb), dim3(256), 0, st, d_density, n, blk);
     FK_HIP(ctx, hipGetLastError());
-    hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, ctx->stream, blk, nb, d_total);
+    hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, st, blk, nb, d_total);
     FK_HIP(ctx, hipGetLastError());
-    hipLaunchKernelGGL(compact_scatter_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_z, d_density, n, blk, d_out);
+    hipLaunchKernelGGL(compact_scatter_kernel, dim3(nb), dim3(256), 0, st, d_z, d_density, n, blk, d_out);
     FK_HIP(ctx, hipGetLastError());
     uint32_t total = 0;
-    FK_HIP(ctx, hipMemcpyAsync(&total, d_total, 4, hipMemcpyDeviceToHost, ctx->stream));
-    FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    FK_HIP(ctx, hipMemcpyAsync(&total, d_total, 4, hipMemcpyDeviceToHost, st));
+    FK_HIP(ctx, hipStreamSynchronize(st));
     *n_out = total;
     return FK_OK;
 }

@@ -267,55 +267,80 @@ int fk_key_synthetic(fk_ctx *ctx, uint64_t m, uint32_t num_input, uint32_t num_a
 }
 
 // ------------------------------------------------------------------------------------------ prover
-// L, A, B1, B2 over this key's slices (they depend on the assignment only, not on the quotient).  The bucket
-// reductions run on the second stream underneath the next multiplication (msm_*_begin / msm_*_end); B1 and B2 come
-// first so that the long G2 reduction is covered by L and A.  tail_h: an H multiplication the caller has already
-// begun (-1: none) -- it is finished here, H receives its sum.
-static int prove_msms_z(fk_ctx *ctx, const fk_key *key, const Fr *d_z, const uint8_t *d_a_aux, const uint8_t *d_b_in,
-                        const uint8_t *d_b_aux, uint8_t out[FK_MSM_RESULT_BYTES], fk_timings *tm, int tail_h = -1, G1Xyzz *H = nullptr) {
-    if (!key || !d_z || !out) { msm_abandon(ctx); FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "prove: null argument"); }
+// L, A, B1, B2 over this key's slices depend on the assignment only, not on the quotient: `witness_begin` queues them on
+// the MSM lanes (scalar compaction on an auxiliary stream) WITHOUT touching the main stream, so a quotient that is
+// running there -- or its all-to-all phases on several GPUs -- overlaps with their memory-bound sorts and their
+// latency-bound tails.  B1 and B2 come first so that the long G2 tail is covered by L and A.  `witness_end` collects
+// them (and an H multiplication the caller has begun, if any) into the FK_MSM_RESULT_BYTES record.
+static int witness_begin(fk_ctx *ctx, const fk_key *key, const Fr *d_z, const uint8_t *d_a_aux, const uint8_t *d_b_in,
+                         const uint8_t *d_b_aux, hipEvent_t z_ready) {
+    if (!key || !d_z) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "prove: null argument");
+    if (ctx->wit_active) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "prove: witness multiplications already in flight");
     FK_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->aux) {
+        FK_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
+        FK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_aux, hipEventDisableTiming));
+    }
     const uint32_t v_in = key->num_input, v_aux = key->num_aux;
-    G1Xyzz L, A, B1; G2Xyzz B2;
-    int t_l = -1, t_a = -1, t_b1 = -1, t_b2 = -1;
+    for (int i = 0; i < 4; i++) ctx->wit_tail[i] = -1;
     auto body = [&]() -> int {
-        const double t2 = now_ms();
-        // B query: inputs and aux variables that occur in some B-side LC
+        hipStream_t ax = ctx->aux;
+        if (z_ready) FK_HIP(ctx, hipStreamWaitEvent(ax, z_ready, 0));
+        // B query: inputs and aux variables that occur in some B-side LC;  A query: all inputs, then the aux variables
+        // that occur in some A-side LC
         FK_HIP(ctx, ctx->sc_b.reserve(((size_t)v_in + v_aux) * sizeof(Fr)));
-        Fr *sb = ctx->sc_b.as<Fr>();
-        uint64_t n_b_in = 0, n_b_aux = 0;
-        FK_TRY(compact_scalars(ctx, d_z, d_b_in, v_in, sb, &n_b_in));
-        FK_TRY(compact_scalars(ctx, d_z + v_in, d_b_aux, v_aux, sb + n_b_in, &n_b_aux));
+        FK_HIP(ctx, ctx->sc_a.reserve(((size_t)v_in + v_aux) * sizeof(Fr)));
+        Fr *sb = ctx->sc_b.as<Fr>(), *sa = ctx->sc_a.as<Fr>();
+        uint64_t n_b_in = 0, n_b_aux = 0, n_a_aux = 0;
+        FK_TRY(compact_scalars(ctx, d_z, d_b_in, v_in, sb, &n_b_in, ax));
+        FK_TRY(compact_scalars(ctx, d_z + v_in, d_b_aux, v_aux, sb + n_b_in, &n_b_aux, ax));
         if (n_b_in + n_b_aux != key->n_b) FK_SET_ERR(ctx, FK_ERR_KEY_MISMATCH, "prove: b query needs %llu points, key holds %llu",
                                                      (unsigned long long)(n_b_in + n_b_aux), (unsigned long long)key->n_b);
-        FK_TRY(msm_g1_begin(ctx, key->d_b1, sb + key->b_lo, key->b_hi - key->b_lo, &t_b1));
-        const double t3 = now_ms();
-        FK_TRY(msm_g2_begin(ctx, key->d_b2, sb + key->b_lo, key->b_hi - key->b_lo, /*reuse_sort=*/true, &t_b2));   // same scalars as B1
-        const double t4 = now_ms();
-        FK_TRY(msm_g1_begin(ctx, key->d_l, d_z + v_in + key->l_lo, key->l_hi - key->l_lo, &t_l));
-        const double t5 = now_ms();
-        // A query: all inputs, then the aux variables that occur in some A-side LC
-        FK_HIP(ctx, ctx->sc_a.reserve(((size_t)v_in + v_aux) * sizeof(Fr)));
-        Fr *sa = ctx->sc_a.as<Fr>();
-        FK_HIP(ctx, hipMemcpyAsync(sa, d_z, (size_t)v_in * sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream));
-        uint64_t n_a_aux = 0;
-        FK_TRY(compact_scalars(ctx, d_z + v_in, d_a_aux, v_aux, sa + v_in, &n_a_aux));
+        FK_HIP(ctx, hipMemcpyAsync(sa, d_z, (size_t)v_in * sizeof(Fr), hipMemcpyDeviceToDevice, ax));
+        FK_TRY(compact_scalars(ctx, d_z + v_in, d_a_aux, v_aux, sa + v_in, &n_a_aux, ax));
         if (v_in + n_a_aux != key->n_a) FK_SET_ERR(ctx, FK_ERR_KEY_MISMATCH, "prove: a query needs %llu points, key holds %llu",
                                                    (unsigned long long)(v_in + n_a_aux), (unsigned long long)key->n_a);
-        FK_TRY(msm_g1_begin(ctx, key->d_a, sa + key->a_lo, key->a_hi - key->a_lo, &t_a));
-        if (tail_h >= 0) FK_TRY(msm_g1_end(ctx, tail_h, H));
-        FK_TRY(msm_g1_end(ctx, t_b1, &B1));
-        FK_TRY(msm_g2_end(ctx, t_b2, &B2));
-        FK_TRY(msm_g1_end(ctx, t_l, &L));
-        FK_TRY(msm_g1_end(ctx, t_a, &A));
-        const double t6 = now_ms();
-        if (tm) { tm->msm_b1_ms = t3 - t2; tm->msm_b2_ms = t4 - t3; tm->msm_l_ms = t5 - t4; tm->msm_a_ms = t6 - t5; }
+        FK_HIP(ctx, hipEventRecord(ctx->ev_aux, ax));
+        FK_TRY(msm_g1_begin(ctx, key->d_b1, sb + key->b_lo, key->b_hi - key->b_lo, &ctx->wit_tail[0], ctx->ev_aux));
+        FK_TRY(msm_g2_begin(ctx, key->d_b2, sb + key->b_lo, key->b_hi - key->b_lo, /*reuse_sort=*/true, &ctx->wit_tail[1], ctx->ev_aux));   // same scalars as B1
+        FK_TRY(msm_g1_begin(ctx, key->d_l, d_z + v_in + key->l_lo, key->l_hi - key->l_lo, &ctx->wit_tail[2], ctx->ev_aux));
+        FK_TRY(msm_g1_begin(ctx, key->d_a, sa + key->a_lo, key->a_hi - key->a_lo, &ctx->wit_tail[3], ctx->ev_aux));
         return FK_OK;
     };
     const int rc = body();
     if (rc != FK_OK) { msm_abandon(ctx); return rc; }
-    memset(out, 0, FK_G1_BYTES);   // H slot: identity
-    g1_to_raw(out + 64, L); g1_to_raw(out + 128, A); g1_to_raw(out + 192, B1); g2_to_raw(out + 256, B2);
+    ctx->wit_active = true;
+    return FK_OK;
+}
+
+static int witness_end(fk_ctx *ctx, uint8_t out[FK_MSM_RESULT_BYTES], int tail_h = -1) {
+    if (!ctx->wit_active) { msm_abandon(ctx); FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "prove: no witness multiplications in flight"); }
+    ctx->wit_active = false;
+    G1Xyzz H = G1Xyzz::inf(), L, A, B1; G2Xyzz B2;
+    auto body = [&]() -> int {
+        FK_TRY(msm_g1_end(ctx, ctx->wit_tail[0], &B1));
+        FK_TRY(msm_g2_end(ctx, ctx->wit_tail[1], &B2));
+        FK_TRY(msm_g1_end(ctx, ctx->wit_tail[2], &L));
+        FK_TRY(msm_g1_end(ctx, ctx->wit_tail[3], &A));
+        if (tail_h >= 0) FK_TRY(msm_g1_end(ctx, tail_h, &H));
+        return FK_OK;
+    };
+    const int rc = body();
+    if (rc != FK_OK) { msm_abandon(ctx); return rc; }
+    g1_to_raw(out, H); g1_to_raw(out + 64, L); g1_to_raw(out + 128, A); g1_to_raw(out + 192, B1); g2_to_raw(out + 256, B2);
+    return FK_OK;
+}
+
+static int prove_msms_z(fk_ctx *ctx, const fk_key *key, const Fr *d_z, const uint8_t *d_a_aux, const uint8_t *d_b_in,
+                        const uint8_t *d_b_aux, uint8_t out[FK_MSM_RESULT_BYTES], fk_timings *tm) {
+    if (!out) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "prove: null argument");
+    const double t0 = now_ms();
+    FK_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->ev_main) FK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_main, hipEventDisableTiming));
+    FK_HIP(ctx, hipEventRecord(ctx->ev_main, ctx->stream));       // whatever produced z on the main stream
+    FK_TRY(witness_begin(ctx, key, d_z, d_a_aux, d_b_in, d_b_aux, ctx->ev_main));
+    FK_TRY(witness_end(ctx, out));
+    if (tm) tm->msm_l_ms = now_ms() - t0;      // the four run interleaved; the sum is reported in the L slot
     return FK_OK;
 }
 
@@ -330,16 +355,19 @@ static int prove_msms_dev(fk_ctx *ctx, const fk_key *key, Fr *d_a, Fr *d_b, Fr *
     FK_HIP(ctx, ctx->hbuf.reserve(key->m * sizeof(Fr)));
     Fr *d_h = ctx->hbuf.as<Fr>();
     uint64_t m = 0;
-    FK_TRY(quotient_dev(ctx, d_a, d_b, d_c, n, d_h, &m));
-    FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    FK_TRY(quotient_dev(ctx, d_a, d_b, d_c, n, d_h, &m));          // queued on the main stream, not waited for
     const double t1 = now_ms();
-    G1Xyzz H = G1Xyzz::inf();
+    // Single GPU: the multiplications start after the quotient.  Running the witness multiplications underneath it was
+    // measured (2^20 .. 2^25): both sides are VALU-bound, nothing is gained at 2^25 and 10 % is lost at 2^20 / 2^22.
+    if (!ctx->ev_main) FK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_main, hipEventDisableTiming));
+    FK_HIP(ctx, hipEventRecord(ctx->ev_main, ctx->stream));
     int t_h = -1;
-    FK_TRY(msm_g1_begin(ctx, key->d_h, d_h + key->h_lo, key->h_hi - key->h_lo, &t_h));
+    FK_TRY(msm_g1_begin(ctx, key->d_h, d_h + key->h_lo, key->h_hi - key->h_lo, &t_h, ctx->ev_main));
+    const int rc = witness_begin(ctx, key, d_z, d_a_aux, d_b_in, d_b_aux, ctx->ev_main);
+    if (rc != FK_OK) { msm_abandon(ctx); return rc; }
     const double t2 = now_ms();
-    FK_TRY(prove_msms_z(ctx, key, d_z, d_a_aux, d_b_in, d_b_aux, out, tm, t_h, &H));
-    g1_to_raw(out, H);
-    if (tm) { tm->ntt_ms = t1 - t0; tm->msm_h_ms = t2 - t1; tm->total_ms = now_ms() - t0; }
+    FK_TRY(witness_end(ctx, out, t_h));
+    if (tm) { tm->ntt_ms = t1 - t0; tm->msm_l_ms = t2 - t1; tm->msm_h_ms = now_ms() - t2; tm->total_ms = now_ms() - t0; }
     return FK_OK;
 }
 
@@ -360,18 +388,30 @@ int fk_prove_msm_h_dev(fk_ctx *ctx, const fk_key *key, const void *d_h_slice, ui
     return FK_OK;
 }
 
+int fk_prove_msms_z_begin_dev(fk_ctx *ctx, const fk_key *key, const void *d_z, const void *d_a_aux, const void *d_b_in, const void *d_b_aux) {
+    if (!ctx) return FK_ERR_BAD_ARG;
+    FK_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->ev_main) FK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_main, hipEventDisableTiming));
+    FK_HIP(ctx, hipEventRecord(ctx->ev_main, ctx->stream));
+    return witness_begin(ctx, key, (const Fr *)d_z, (const uint8_t *)d_a_aux, (const uint8_t *)d_b_in, (const uint8_t *)d_b_aux, ctx->ev_main);
+}
+
+int fk_prove_msms_finish_dev(fk_ctx *ctx, const fk_key *key, const void *d_h_slice, uint8_t out[FK_MSM_RESULT_BYTES]) {
+    if (!ctx) return FK_ERR_BAD_ARG;
+    if (!key || !out || (!d_h_slice && key->h_hi > key->h_lo)) { msm_abandon(ctx); FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "prove: null argument"); }
+    FK_HIP(ctx, hipSetDevice(ctx->device));
+    int t_h = -1;
+    const int rc = msm_g1_begin(ctx, key->d_h, (const Fr *)d_h_slice, key->h_hi - key->h_lo, &t_h);
+    if (rc != FK_OK) { msm_abandon(ctx); return rc; }
+    return witness_end(ctx, out, t_h);
+}
+
 int fk_prove_msms_hz_dev(fk_ctx *ctx, const fk_key *key, const void *d_h_slice, const void *d_z, const void *d_a_aux, const void *d_b_in,
                          const void *d_b_aux, uint8_t out[FK_MSM_RESULT_BYTES], fk_timings *tm) {
     if (!ctx) return FK_ERR_BAD_ARG;
     if (tm) memset(tm, 0, sizeof *tm);
-    if (!key || !out || (!d_h_slice && key->h_hi > key->h_lo)) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "prove: null argument");
-    FK_HIP(ctx, hipSetDevice(ctx->device));
-    G1Xyzz H = G1Xyzz::inf();
-    int t_h = -1;
-    FK_TRY(msm_g1_begin(ctx, key->d_h, (const Fr *)d_h_slice, key->h_hi - key->h_lo, &t_h));
-    FK_TRY(prove_msms_z(ctx, key, (const Fr *)d_z, (const uint8_t *)d_a_aux, (const uint8_t *)d_b_in, (const uint8_t *)d_b_aux, out, tm, t_h, &H));
-    g1_to_raw(out, H);
-    return FK_OK;
+    FK_TRY(fk_prove_msms_z_begin_dev(ctx, key, d_z, d_a_aux, d_b_in, d_b_aux));
+    return fk_prove_msms_finish_dev(ctx, key, d_h_slice, out);
 }
 
 int fk_prove_msms_dev(fk_ctx *ctx, const fk_key *key, void *d_a, void *d_b, void *d_c, uint64_t n, const void *d_z,

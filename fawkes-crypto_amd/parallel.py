@@ -25,6 +25,8 @@ themselves are cut across the ranks -- L = m/W-point transforms stay inside one 
 transform, and rank g ends up with exactly the block of h coefficients whose bases its key shard holds.  Every rank
 does 1/W of the quotient and 1/W of all five MSMs; this is the default for `bench.py --gpus N`.
 """
+import os
+
 import numpy as np
 
 from . import api
@@ -230,7 +232,15 @@ def prove_distributed_dev(ctx, key, rank, world, d_full, n, log_m, d_z, d_a_aux,
         eval_fn()
     if a2a is None:
         a2a = torch_all_to_all(ctx, group)
-    h_blk = quotient_distributed(ctx, rank, world, d_full, n, log_m, send, recv, a2a)
-    part = ctx.prove_msms_hz_dev(key, h_blk.data_ptr(), d_z, d_a_aux, d_b_in, d_b_aux)
+    # The witness MSMs do not need the quotient, so they can be begun first and fill the GPU during the quotient's
+    # all-to-all phases (FK_OVERLAP_WITNESS=1).  Off by default: on one GPU the overlap measured neutral at 2^25 and
+    # 10 % slower at 2^20 / 2^22 (both sides are VALU-bound), and it cannot be measured across GPUs here.
+    if os.environ.get('FK_OVERLAP_WITNESS') == '1':
+        ctx.prove_msms_z_begin_dev(key, d_z, d_a_aux, d_b_in, d_b_aux)
+        h_blk = quotient_distributed(ctx, rank, world, d_full, n, log_m, send, recv, a2a)
+        part = ctx.prove_msms_finish_dev(key, h_blk.data_ptr())
+    else:
+        h_blk = quotient_distributed(ctx, rank, world, d_full, n, log_m, send, recv, a2a)
+        part = ctx.prove_msms_hz_dev(key, h_blk.data_ptr(), d_z, d_a_aux, d_b_in, d_b_aux)
     parts = all_gather_parts(part, group=group, device=device)
     return ctx.prove_assemble(key, parts, r, s)

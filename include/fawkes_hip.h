@@ -148,6 +148,13 @@ int fk_prove_msms_z_dev(fk_ctx *ctx, const fk_key *key, const void *d_z, const v
                         const void *d_b_input_density, const void *d_b_aux_density,
                         uint8_t out_msms[FK_MSM_RESULT_BYTES], fk_timings *timings);
 int fk_prove_msm_h_dev(fk_ctx *ctx, const fk_key *key, const void *d_h_slice, uint8_t out[FK_G1_BYTES]);
+/* Split form for schedules that compute the quotient while the witness multiplications run: _begin queues L, A, B1, B2
+ * of this key's slices on the library's MSM streams (nothing is put on the main stream, so fk_quotient_h_dev / fk_dq_*
+ * calls issued next overlap with them) and returns at once; _finish adds H over d_h_slice and writes the complete
+ * record.  Exactly one _finish per _begin. */
+int fk_prove_msms_z_begin_dev(fk_ctx *ctx, const fk_key *key, const void *d_z, const void *d_a_aux,
+                              const void *d_b_input_density, const void *d_b_aux_density);
+int fk_prove_msms_finish_dev(fk_ctx *ctx, const fk_key *key, const void *d_h_slice, uint8_t out_msms[FK_MSM_RESULT_BYTES]);
 /* both at once (the five multiplications are pipelined against each other): the complete FK_MSM_RESULT_BYTES record of
  * this key's slices, given this rank's block of quotient coefficients (distributed quotient, fk_dq_*). */
 int fk_prove_msms_hz_dev(fk_ctx *ctx, const fk_key *key, const void *d_h_slice, const void *d_z, const void *d_a_aux,

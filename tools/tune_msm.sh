@@ -6,4 +6,11 @@ run() { # sizes, env...
     echo "$* L=$L -> $r"
   done
 }
-run "20 22 24 25" FK_X=0
+if [ -n "$TUNE_SET" ]; then
+  run "24 25" FK_MSM_C_DELTA=3
+  run "24 25" FK_MSM_C_DELTA=4
+  run "20 22" FK_MSM_C_SMALL=18
+  run "20 22" FK_MSM_C_SMALL=16
+else
+  run "20 22 24 25" FK_X=0
+fi
