@@ -82,7 +82,12 @@ static MsmPlan make_plan(size_t n, unsigned forced_c) {
     p.cap = (uint32_t)std::min<size_t>(2 * mean + 64, 1u << 30);
     if (t_sig > 0) { uint32_t sq = 1; while ((size_t)sq * sq < mean) sq++; p.cap = (uint32_t)std::min<size_t>(mean + (size_t)t_sig * sq + 8, 1u << 30); }
     p.cap_top = p.cap;
-    p.L = p.B >= 4096 ? (p.B >= (1u << 18) ? 64 : p.B / 2048) : 1;     // <= 64 buckets per lane
+    // bucket reduction: buckets per lane (<= 64).  L = 8 everywhere below 2^18 buckets (shorter serial chains) was measured
+    // neutral-to-worse: the reduction already runs underneath the next multiplication.  FK_MSM_RED_L overrides (tuning).
+    static int t_redl = -1;
+    if (t_redl < 0) { const char *e = getenv("FK_MSM_RED_L"); t_redl = e ? atoi(e) : 0; }
+    p.L = p.B >= 4096 ? (p.B >= (1u << 18) ? 64 : p.B / 2048) : 1;
+    if (t_redl > 0 && (uint32_t)t_redl <= p.B) p.L = (uint32_t)t_redl;
     p.T = p.B / p.L;
     p.nblk = (p.T + 255) / 256;
     p.LB = (c - 1) < 10 ? (c - 1) : 10;
