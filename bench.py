@@ -212,7 +212,7 @@ def main():
         if dist_q:
             return parallel.prove_distributed_dev(
                 ctx, key, rank, world, wp, n, args.log2n, d_z.data_ptr(), d_dens[0], d_dens[1], d_dens[2], r, s, send, recv,
-                device=comm_dev, a2a=a2a, eval_fn=lambda: ctx.r1cs_eval_dev(dr, d_z.data_ptr(), wp[0], wp[1], wp[2]))
+                device=comm_dev, a2a=a2a, device_r1cs=dr, eval_fn=lambda: ctx.r1cs_eval_dev(dr, d_z.data_ptr(), wp[0], wp[1], wp[2]))
         return parallel.prove_balanced_dev(
             ctx, key, rank, world, wp[0], wp[1], wp[2], n, d_z.data_ptr(), d_dens[0], d_dens[1], d_dens[2], r, s,
             h_ranges, h_full_buf, recv_buf, device=comm_dev,

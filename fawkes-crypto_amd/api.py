@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = [
     'fk_dev_alloc', 'fk_dev_free', 'fk_upload', 'fk_download', 'fk_dev_copy', 'fk_sync',
     'fk_key_load', 'fk_key_synthetic', 'fk_key_shard_info', 'fk_key_host_vk', 'fk_key_free',
     'fk_prove', 'fk_prove_dev', 'fk_prove_msms', 'fk_prove_msms_dev', 'fk_prove_msms_z_dev', 'fk_prove_msm_h_dev', 'fk_prove_msms_hz_dev',
-    'fk_prove_msms_z_begin_dev', 'fk_prove_msms_finish_dev',
+    'fk_prove_msms_z_begin_dev', 'fk_prove_msms_finish_dev', 'fk_prove_msms_hz_r1cs_dev',
     'fk_prove_assemble',
     'fk_fr_mul_batch', 'fk_ntt', 'fk_ntt_dev', 'fk_quotient_h', 'fk_quotient_h_dev',
     'fk_msm_g1', 'fk_msm_g2', 'fk_msm_g1_dev', 'fk_msm_g2_dev',
@@ -549,6 +549,12 @@ class Context:
         out = np.zeros(FK_MSM_RESULT_BYTES, np.uint8)
         self._ck(self.lib.fk_prove_msms_hz_dev(self.handle, key.handle, C.c_void_p(d_h_slice), C.c_void_p(d_z), C.c_void_p(d_a_aux),
                                                C.c_void_p(d_b_in), C.c_void_p(d_b_aux), _vp(out), None))
+        return out
+
+    def prove_msms_hz_r1cs_dev(self, key, device_r1cs, d_h_slice, d_z):
+        """all five MSMs of this key's slices for a resident constraint system -> 384-byte record"""
+        out = np.zeros(FK_MSM_RESULT_BYTES, np.uint8)
+        self._ck(self.lib.fk_prove_msms_hz_r1cs_dev(self.handle, key.handle, device_r1cs.handle, C.c_void_p(d_h_slice), C.c_void_p(d_z), _vp(out)))
         return out
 
     def prove_msms_z_begin_dev(self, key, d_z, d_a_aux, d_b_in, d_b_aux):

@@ -57,6 +57,14 @@ struct MsmTail {
 };
 static constexpr int MSM_TAILS = 8;
 
+// Which variables feed the A and the B query, as index lists (they are structural: a resident constraint system
+// computes them once at load).  With them the per-proof scalar compaction is one gather per query, no host round trip.
+struct QueryIdx {
+    const uint8_t *d_a_aux = nullptr, *d_b_in = nullptr, *d_b_aux = nullptr;   // the density maps the lists were made from
+    const uint32_t *a = nullptr, *b = nullptr;                                 // variable indices, query order
+    uint64_t n_a = 0, n_b = 0;
+};
+
 }  // namespace fk
 
 struct fk_ctx {
@@ -75,6 +83,7 @@ struct fk_ctx {
     hipStream_t aux = nullptr;          // scalar compaction for the A / B queries
     hipEvent_t ev_aux = nullptr, ev_main = nullptr;
     bool wit_active = false;
+    const fk::QueryIdx *qidx = nullptr;   // set by the resident-constraint-system entry points for the duration of a call
     int wit_tail[4] = {-1, -1, -1, -1}; // B1, B2, L, A
     // NTT / prover scratch
     fk::DevBuf ntt_s1, ntt_s2, ntt_io, hbuf, sc_a, sc_b, scan_tmp, stage_a, stage_b, stage_c, stage_z, stage_d;
@@ -176,6 +185,7 @@ int gen_points_g1(fk_ctx *ctx, G1Affine *d_out, size_t n, uint64_t seed);
 int gen_points_g2(fk_ctx *ctx, G2Affine *d_out, size_t n, uint64_t seed);
 int gen_scalars(fk_ctx *ctx, Fr *d_out, size_t n, uint64_t seed, int kind);
 // out[k] = z[j] for the k-th j with density[j] != 0 (device pointers); returns count via *n_out
+int gather_scalars(fk_ctx *ctx, const Fr *d_z, const uint32_t *d_idx, size_t n, Fr *d_out, hipStream_t st);
 int compact_scalars(fk_ctx *ctx, const Fr *d_z, const uint8_t *d_density, size_t n, Fr *d_out, uint64_t *n_out, hipStream_t st = nullptr);
 
 }  // namespace fk

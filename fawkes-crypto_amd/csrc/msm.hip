@@ -981,6 +981,18 @@ __global__ __launch_bounds__(256) void compact_scatter_kernel(const Fr *z, const
     for (int k = 0; k < 8; k++) if (base + k < n && dens[base + k]) out[pos++] = z[base + k];
 }
 
+__global__ __launch_bounds__(256) void gather_scalars_kernel(const Fr *z, const uint32_t *idx, size_t n, Fr *out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = z[idx[i]];
+}
+
+int gather_scalars(fk_ctx *ctx, const Fr *d_z, const uint32_t *d_idx, size_t n, Fr *d_out, hipStream_t st) {
+    if (!n) return FK_OK;
+    hipLaunchKernelGGL(gather_scalars_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_z, d_idx, n, d_out);
+    FK_HIP(ctx, hipGetLastError());
+    return FK_OK;
+}
+
 int compact_scalars(fk_ctx *ctx, const Fr *d_z, const uint8_t *d_density, size_t n, Fr *d_out, uint64_t *n_out, hipStream_t st) {
     *n_out = 0;
     if (!n) return FK_OK;

@@ -291,15 +291,26 @@ static int witness_begin(fk_ctx *ctx, const fk_key *key, const Fr *d_z, const ui
         FK_HIP(ctx, ctx->sc_b.reserve(((size_t)v_in + v_aux) * sizeof(Fr)));
         FK_HIP(ctx, ctx->sc_a.reserve(((size_t)v_in + v_aux) * sizeof(Fr)));
         Fr *sb = ctx->sc_b.as<Fr>(), *sa = ctx->sc_a.as<Fr>();
-        uint64_t n_b_in = 0, n_b_aux = 0, n_a_aux = 0;
-        FK_TRY(compact_scalars(ctx, d_z, d_b_in, v_in, sb, &n_b_in, ax));
-        FK_TRY(compact_scalars(ctx, d_z + v_in, d_b_aux, v_aux, sb + n_b_in, &n_b_aux, ax));
-        if (n_b_in + n_b_aux != key->n_b) FK_SET_ERR(ctx, FK_ERR_KEY_MISMATCH, "prove: b query needs %llu points, key holds %llu",
-                                                     (unsigned long long)(n_b_in + n_b_aux), (unsigned long long)key->n_b);
-        FK_HIP(ctx, hipMemcpyAsync(sa, d_z, (size_t)v_in * sizeof(Fr), hipMemcpyDeviceToDevice, ax));
-        FK_TRY(compact_scalars(ctx, d_z + v_in, d_a_aux, v_aux, sa + v_in, &n_a_aux, ax));
-        if (v_in + n_a_aux != key->n_a) FK_SET_ERR(ctx, FK_ERR_KEY_MISMATCH, "prove: a query needs %llu points, key holds %llu",
-                                                   (unsigned long long)(v_in + n_a_aux), (unsigned long long)key->n_a);
+        const QueryIdx *qi = ctx->qidx;
+        if (qi && qi->d_a_aux == d_a_aux && qi->d_b_in == d_b_in && qi->d_b_aux == d_b_aux) {
+            // resident constraint system: gather this key's slice of each query straight from the index lists
+            if (qi->n_b != key->n_b) FK_SET_ERR(ctx, FK_ERR_KEY_MISMATCH, "prove: b query needs %llu points, key holds %llu",
+                                                (unsigned long long)qi->n_b, (unsigned long long)key->n_b);
+            if (qi->n_a != key->n_a) FK_SET_ERR(ctx, FK_ERR_KEY_MISMATCH, "prove: a query needs %llu points, key holds %llu",
+                                                (unsigned long long)qi->n_a, (unsigned long long)key->n_a);
+            FK_TRY(gather_scalars(ctx, d_z, qi->b + key->b_lo, key->b_hi - key->b_lo, sb + key->b_lo, ax));
+            FK_TRY(gather_scalars(ctx, d_z, qi->a + key->a_lo, key->a_hi - key->a_lo, sa + key->a_lo, ax));
+        } else {
+            uint64_t n_b_in = 0, n_b_aux = 0, n_a_aux = 0;
+            FK_TRY(compact_scalars(ctx, d_z, d_b_in, v_in, sb, &n_b_in, ax));
+            FK_TRY(compact_scalars(ctx, d_z + v_in, d_b_aux, v_aux, sb + n_b_in, &n_b_aux, ax));
+            if (n_b_in + n_b_aux != key->n_b) FK_SET_ERR(ctx, FK_ERR_KEY_MISMATCH, "prove: b query needs %llu points, key holds %llu",
+                                                         (unsigned long long)(n_b_in + n_b_aux), (unsigned long long)key->n_b);
+            FK_HIP(ctx, hipMemcpyAsync(sa, d_z, (size_t)v_in * sizeof(Fr), hipMemcpyDeviceToDevice, ax));
+            FK_TRY(compact_scalars(ctx, d_z + v_in, d_a_aux, v_aux, sa + v_in, &n_a_aux, ax));
+            if (v_in + n_a_aux != key->n_a) FK_SET_ERR(ctx, FK_ERR_KEY_MISMATCH, "prove: a query needs %llu points, key holds %llu",
+                                                       (unsigned long long)(v_in + n_a_aux), (unsigned long long)key->n_a);
+        }
         FK_HIP(ctx, hipEventRecord(ctx->ev_aux, ax));
         FK_TRY(msm_g1_begin(ctx, key->d_b1, sb + key->b_lo, key->b_hi - key->b_lo, &ctx->wit_tail[0], ctx->ev_aux));
         FK_TRY(msm_g2_begin(ctx, key->d_b2, sb + key->b_lo, key->b_hi - key->b_lo, /*reuse_sort=*/true, &ctx->wit_tail[1], ctx->ev_aux));   // same scalars as B1

@@ -29,6 +29,8 @@ struct fk_r1cs_dev {
     uint64_t n_table = 0, nnz[3] = {0, 0, 0};
     uint8_t *d_a_aux = nullptr, *d_b_in = nullptr, *d_b_aux = nullptr;
     uint64_t n_a_aux = 0, n_b_in = 0, n_b_aux = 0;   // popcounts
+    uint32_t *d_idx_a = nullptr, *d_idx_b = nullptr; // variables of the A / B query in query order
+    fk::QueryIdx qidx;
 };
 
 namespace fk {
@@ -70,7 +72,7 @@ void fk_r1cs_free(fk_ctx *ctx, fk_r1cs_dev *r) {
     if (!r) return;
     if (ctx) (void)hipSetDevice(ctx->device);
     for (int k = 0; k < 3; k++) { if (r->ptr[k]) (void)hipFree(r->ptr[k]); if (r->col[k]) (void)hipFree(r->col[k]); if (r->cidx[k]) (void)hipFree(r->cidx[k]); }
-    for (void *p : {(void *)r->table, (void *)r->d_a_aux, (void *)r->d_b_in, (void *)r->d_b_aux}) if (p) (void)hipFree(p);
+    for (void *p : {(void *)r->table, (void *)r->d_a_aux, (void *)r->d_b_in, (void *)r->d_b_aux, (void *)r->d_idx_a, (void *)r->d_idx_b}) if (p) (void)hipFree(p);
     delete r;
 }
 
@@ -146,6 +148,19 @@ int fk_r1cs_load(fk_ctx *ctx, const fk_r1cs *cs, fk_r1cs_dev **out) {
         hipMemcpy(r->d_b_aux, b_aux.data(), b_aux.size(), hipMemcpyHostToDevice) != hipSuccess) { ctx->err = "r1cs: upload failed"; return fail(FK_ERR_HIP); }
     for (uint32_t j = 0; j < cs->num_aux; j++) { r->n_a_aux += a_aux[j]; r->n_b_aux += b_aux[j]; }
     for (uint32_t i = 0; i < cs->num_input; i++) r->n_b_in += b_in[i];
+    {   // query index lists (bellman's order: inputs first, then the aux variables the density map selects)
+        std::vector<uint32_t> ia, ib;
+        ia.reserve(cs->num_input + r->n_a_aux); ib.reserve(r->n_b_in + r->n_b_aux);
+        for (uint32_t i = 0; i < cs->num_input; i++) { ia.push_back(i); if (b_in[i]) ib.push_back(i); }
+        for (uint32_t j = 0; j < cs->num_aux; j++) { if (a_aux[j]) ia.push_back(cs->num_input + j); if (b_aux[j]) ib.push_back(cs->num_input + j); }
+        if (hipMalloc((void **)&r->d_idx_a, ia.size() * 4 + 4) != hipSuccess || hipMalloc((void **)&r->d_idx_b, ib.size() * 4 + 4) != hipSuccess) {
+            ctx->err = "r1cs: device allocation failed"; return fail(FK_ERR_OOM);
+        }
+        if ((ia.size() && hipMemcpy(r->d_idx_a, ia.data(), ia.size() * 4, hipMemcpyHostToDevice) != hipSuccess) ||
+            (ib.size() && hipMemcpy(r->d_idx_b, ib.data(), ib.size() * 4, hipMemcpyHostToDevice) != hipSuccess)) { ctx->err = "r1cs: upload failed"; return fail(FK_ERR_HIP); }
+        r->qidx.d_a_aux = r->d_a_aux; r->qidx.d_b_in = r->d_b_in; r->qidx.d_b_aux = r->d_b_aux;
+        r->qidx.a = r->d_idx_a; r->qidx.b = r->d_idx_b; r->qidx.n_a = ia.size(); r->qidx.n_b = ib.size();
+    }
     *out = r;
     return FK_OK;
 }
@@ -192,7 +207,22 @@ int fk_prove_r1cs_dev(fk_ctx *ctx, const fk_key *key, const fk_r1cs_dev *r, cons
     const size_t mb = key->m * sizeof(Fr);
     FK_HIP(ctx, ctx->stage_a.reserve(mb)); FK_HIP(ctx, ctx->stage_b.reserve(mb)); FK_HIP(ctx, ctx->stage_c.reserve(mb));
     FK_TRY(fk_r1cs_eval_dev(ctx, r, d_z, ctx->stage_a.p, ctx->stage_b.p, ctx->stage_c.p));
-    return fk_prove_dev(ctx, key, ctx->stage_a.p, ctx->stage_b.p, ctx->stage_c.p, rows, d_z, r->d_a_aux, r->d_b_in, r->d_b_aux, rr, ss, out_proof, tm);
+    ctx->qidx = &r->qidx;      // the queries' index lists are known: no per-proof density compaction
+    const int rc = fk_prove_dev(ctx, key, ctx->stage_a.p, ctx->stage_b.p, ctx->stage_c.p, rows, d_z, r->d_a_aux, r->d_b_in, r->d_b_aux, rr, ss, out_proof, tm);
+    ctx->qidx = nullptr;
+    return rc;
+}
+
+// multi-GPU: all five multiplications of this key's slices for a resident constraint system (see fk_prove_msms_hz_dev)
+int fk_prove_msms_hz_r1cs_dev(fk_ctx *ctx, const fk_key *key, const fk_r1cs_dev *r, const void *d_h_slice, const void *d_z,
+                              uint8_t out[FK_MSM_RESULT_BYTES]) {
+    if (!ctx) return FK_ERR_BAD_ARG;
+    if (!key || !r || !d_z) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "prove: null argument");
+    if (r->num_input != key->num_input || r->num_aux != key->num_aux) FK_SET_ERR(ctx, FK_ERR_KEY_MISMATCH, "prove: constraint system and key disagree on the variable counts");
+    ctx->qidx = &r->qidx;
+    const int rc = fk_prove_msms_hz_dev(ctx, key, d_h_slice, d_z, r->d_a_aux, r->d_b_in, r->d_b_aux, out, nullptr);
+    ctx->qidx = nullptr;
+    return rc;
 }
 
 int fk_prove_r1cs(fk_ctx *ctx, const fk_key *key, const fk_r1cs_dev *r, const uint64_t *z, const uint64_t rr[4], const uint64_t ss[4],

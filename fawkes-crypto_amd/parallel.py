@@ -225,7 +225,7 @@ def quotient_distributed(ctx, rank, world, d_full, n, log_m, send, recv, a2a):
 
 
 def prove_distributed_dev(ctx, key, rank, world, d_full, n, log_m, d_z, d_a_aux, d_b_in, d_b_aux, r, s, send, recv,
-                          group=None, device=None, eval_fn=None, a2a=None):
+                          group=None, device=None, eval_fn=None, a2a=None, device_r1cs=None):
     """One proof over `world` GPUs with the quotient AND the five MSMs cut 1/world each.  key: this rank's equal shard
     (shard_index = rank, shard_count = world, no z fractions).  eval_fn(): fills d_full (device SpMV)."""
     if eval_fn is not None:
@@ -241,6 +241,9 @@ def prove_distributed_dev(ctx, key, rank, world, d_full, n, log_m, d_z, d_a_aux,
         part = ctx.prove_msms_finish_dev(key, h_blk.data_ptr())
     else:
         h_blk = quotient_distributed(ctx, rank, world, d_full, n, log_m, send, recv, a2a)
-        part = ctx.prove_msms_hz_dev(key, h_blk.data_ptr(), d_z, d_a_aux, d_b_in, d_b_aux)
+        if device_r1cs is not None:      # resident constraint system: its query index lists replace the density compaction
+            part = ctx.prove_msms_hz_r1cs_dev(key, device_r1cs, h_blk.data_ptr(), d_z)
+        else:
+            part = ctx.prove_msms_hz_dev(key, h_blk.data_ptr(), d_z, d_a_aux, d_b_in, d_b_aux)
     parts = all_gather_parts(part, group=group, device=device)
     return ctx.prove_assemble(key, parts, r, s)

@@ -242,6 +242,10 @@ int fk_r1cs_density_ptrs(const fk_r1cs_dev *r1cs, const void *out[3]);
 int fk_r1cs_eval_dev(fk_ctx *ctx, const fk_r1cs_dev *r1cs, const void *d_z, void *d_a, void *d_b, void *d_c);
 int fk_prove_r1cs(fk_ctx *ctx, const fk_key *key, const fk_r1cs_dev *r1cs, const uint64_t *z,
                   const uint64_t r[4], const uint64_t s[4], uint8_t out_proof[FK_PROOF_BYTES], fk_timings *timings);
+/* multi-GPU counterpart of fk_prove_msms_hz_dev for a resident constraint system (its A / B query index lists replace
+ * the per-proof density compaction) */
+int fk_prove_msms_hz_r1cs_dev(fk_ctx *ctx, const fk_key *key, const fk_r1cs_dev *r1cs, const void *d_h_slice, const void *d_z,
+                              uint8_t out_msms[FK_MSM_RESULT_BYTES]);
 int fk_prove_r1cs_dev(fk_ctx *ctx, const fk_key *key, const fk_r1cs_dev *r1cs, const void *d_z,
                       const uint64_t r[4], const uint64_t s[4], uint8_t out_proof[FK_PROOF_BYTES], fk_timings *timings);
 

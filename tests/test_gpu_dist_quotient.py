@@ -152,6 +152,7 @@ def test_distributed_proof_bit_exact(ctx, oracle, world):
         blk = parallel.quotient_distributed(c_, rank, world, [f.data_ptr() for f in full], n, log_m, send, recv, ex.a2a_for(c_, rank))
         part = c_.prove_msms_finish_dev(key, blk.data_ptr())
         assert c_.prove_msms_hz_dev(key, blk.data_ptr(), d_z.data_ptr(), *dens).tobytes() == part.tobytes()
+        assert c_.prove_msms_hz_r1cs_dev(key, dr, blk.data_ptr(), d_z.data_ptr()).tobytes() == part.tobytes()     # index-list gathers
         split = np.array(c_.prove_msms_z_dev(key, d_z.data_ptr(), *dens), dtype=np.uint8, copy=True)     # the two-call form agrees
         split[:64] = c_.prove_msm_h_dev(key, blk.data_ptr())
         assert split.tobytes() == part.tobytes()
