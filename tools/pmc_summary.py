@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Summarises rocprofv3 --pmc counter_collection CSVs (one directory per pass) into the JSON files under profiles/.
+
+    python tools/pmc_summary.py traffic  <fetch_dir> <write_dir> <log2n> <points_per_proof> <out.json>
+    python tools/pmc_summary.py valu     <sq_dir> <derived_dir> <out.json>
+
+FETCH_SIZE / WRITE_SIZE are in KB (x1024 = bytes).  FETCH_SIZE of wide coalesced streams under-reports by 2x on gfx950
+(/opt/skills/guides/MI355X_MICROARCH.md); the gather width of the MSM accumulate kernel is uncalibrated, so the raw
+figure is recorded and labelled as such.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+
+def short(name):
+    name = re.sub(r'\(.*$', '', name)
+    return name.replace('void ', '').replace('fk::', '')
+
+
+def load(d):
+    rows = []
+    for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
+        rows += list(csv.DictReader(open(f)))
+    if not rows:
+        raise SystemExit('no counter_collection.csv under ' + d)
+    return rows
+
+
+def per_kernel(rows):
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    disp = collections.defaultdict(set)
+    for r in rows:
+        k = short(r['Kernel_Name'])
+        agg[k][r['Counter_Name']] += float(r['Counter_Value'])
+        disp[k].add(r['Dispatch_Id'])
+    return agg, {k: len(v) for k, v in disp.items()}
+
+
+def traffic(fetch_dir, write_dir, log2n, points, out):
+    fa, fl = per_kernel(load(fetch_dir))
+    wa, _ = per_kernel(load(write_dir))
+    ks = sorted(fa, key=lambda k: -(fa[k]['FETCH_SIZE'] + wa.get(k, {}).get('WRITE_SIZE', 0)))
+    per = [dict(kernel=k, launches=fl[k], FETCH_SIZE_KB=fa[k]['FETCH_SIZE'], WRITE_SIZE_KB=wa.get(k, {}).get('WRITE_SIZE', 0.0)) for k in ks[:24]]
+    dom = next(k for k in ks if k.startswith('msm_accumulate_kernel<Fp<FqParams'))
+    j = dict(
+        _doc='rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python3 bench.py --steps 1 --warmup 0 '
+             '--no-cpu-baseline` (2^%d rows, 1 proof).  Counter units: KB (x1024 = bytes), summed over launches.' % log2n,
+        log2n=log2n, per_kernel=per,
+        dominant_kernel=dict(
+            name='msm_accumulate_kernel<Fq>', launches_per_proof=fl[dom], points_per_proof=points,
+            fetch_bytes_per_proof_raw=fa[dom]['FETCH_SIZE'] * 1024, write_bytes_per_proof=wa[dom]['WRITE_SIZE'] * 1024,
+            note='WRITE_SIZE is exact (W*B XYZZ buckets of 128 B per launch).  FETCH_SIZE is reported RAW: the guide\'s x2 gfx950 '
+                 'correction is calibrated for wide coalesced streams (it holds for ntt_pass_kernel in this same pass), while this '
+                 'kernel gathers 64-byte points at random 64-B-aligned addresses -- an uncalibrated width.  Expected demand: 13 windows x '
+                 '(64 B point + 4 B index) = 884 B per non-trivial point.  Traffic is several times the 96 B/point algorithmic bytes '
+                 'because Pippenger re-gathers every base once per window; the rate stays far below HBM peak: the kernel is VALU-bound.'))
+    json.dump(j, open(out, 'w'), indent=1)
+    print('wrote', out, 'dominant fetch GB', fa[dom]['FETCH_SIZE'] * 1024 / 1e9)
+
+
+def valu(sq_dir, derived_dir, out):
+    sa, sl = per_kernel(load(sq_dir))
+    da, dl = per_kernel(load(derived_dir))
+    res = {}
+    for k in sorted(sa, key=lambda k: -sa[k].get('SQ_BUSY_CYCLES', 0))[:16]:
+        e = dict(launches=sl[k])
+        e.update({c: v for c, v in sa[k].items()})
+        for c in ('VALUBusy', 'VALUUtilization', 'MemUnitBusy'):
+            if k in da and c in da[k]:
+                e[c + '_avg'] = da[k][c] / dl[k]
+        wc = sa[k].get('SQ_WAVE_CYCLES', 0)
+        if wc:
+            e['valu_active_share_of_wave_cycles'] = sa[k].get('SQ_ACTIVE_INST_VALU', 0) / wc
+            e['wait_any_share_of_wave_cycles'] = sa[k].get('SQ_WAIT_ANY', 0) / wc
+            e['wait_inst_share_of_wave_cycles'] = sa[k].get('SQ_WAIT_INST_ANY', 0) / wc
+        res[k] = e
+    json.dump(dict(_doc='rocprofv3 --pmc passes over `python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline` (2^25 rows). Pass 1: SQ_BUSY_CYCLES '
+                        'SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE; pass 2: derived '
+                        'VALUBusy VALUUtilization MemUnitBusy.  Sums over launches; *_avg are per-launch means.', kernels=res), open(out, 'w'), indent=1)
+    print('wrote', out)
+
+
+if __name__ == '__main__':
+    if sys.argv[1] == 'traffic':
+        traffic(sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), sys.argv[6])
+    else:
+        valu(sys.argv[2], sys.argv[3], sys.argv[4])
