@@ -38,6 +38,9 @@ struct NttDomain {
     Fr *tw_lo[2] = {nullptr, nullptr}, *tw_hi[2] = {nullptr, nullptr};   // [0] forward, [1] inverse
     Fr *pq[2] = {nullptr, nullptr};                                       // omega_Rmax^e, e < Rmax/2
     ScaleTable t_g, t_ginv_minv, t_g_minv, t_ginv_minv_zinv;
+    // single-level inter-pass twiddles: tw_full[dir][pass][k * r] = w^((k * r) << (log_n - lgp - deg)); one product per
+    // element instead of two (lo * hi, then the element).  nullptr: fall back to the two-level tables.
+    std::vector<Fr *> tw_full[2];
     std::map<uint64_t, ScaleTable> dist_post;   // distributed quotient: (omega_m^-rank)^k tables, key = log_w << 32 | rank
     std::vector<void *> allocs;
 };
@@ -47,6 +50,7 @@ struct PassArgs {
     Fr *y;
     uint32_t log_n, deg, lgp, logC;
     const Fr *tw_lo, *tw_hi;
+    const Fr *tw_full;
     uint32_t L;
     const Fr *pq;
     uint32_t pq_shift;
@@ -102,10 +106,15 @@ __global__ __launch_bounds__(NTT_MAX_THREADS) void ntt_pass_kernel(PassArgs a) {
             Fr::mul2(v0, s0, v1, s1, v0, v1);
         }
         if (a.lgp) {
-            const uint64_t x0 = ((i0 & pmask) * r0) << (a.log_n - a.lgp - a.deg), x1 = ((i1 & pmask) * r1) << (a.log_n - a.lgp - a.deg);
-            Fr w0, w1;
-            Fr::mul2(a.tw_lo[x0 & Lmask], a.tw_hi[x0 >> a.L], a.tw_lo[x1 & Lmask], a.tw_hi[x1 >> a.L], w0, w1);
-            Fr::mul2(v0, w0, v1, w1, v0, v1);
+            const uint64_t y0 = (i0 & pmask) * r0, y1 = (i1 & pmask) * r1;
+            if (a.tw_full) {
+                Fr::mul2(v0, a.tw_full[y0], v1, a.tw_full[y1], v0, v1);
+            } else {
+                const uint64_t x0 = y0 << (a.log_n - a.lgp - a.deg), x1 = y1 << (a.log_n - a.lgp - a.deg);
+                Fr w0, w1;
+                Fr::mul2(a.tw_lo[x0 & Lmask], a.tw_hi[x0 >> a.L], a.tw_lo[x1 & Lmask], a.tw_hi[x1 >> a.L], w0, w1);
+                Fr::mul2(v0, w0, v1, w1, v0, v1);
+            }
         }
         lds_put(p0, p1, e0, v0);
         if (has1) lds_put(p0, p1, e1, v1);
@@ -190,6 +199,13 @@ __global__ void fr_mul_batch_kernel(const Fr *a, const Fr *b, Fr *o, size_t n) {
     if (i < n) o[i] = Fr::mul(a[i], b[i]);
 }
 
+__global__ void tw_full_kernel(const Fr *lo, const Fr *hi, uint32_t L, uint32_t shift, uint64_t n, Fr *out) {
+    const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= n) return;
+    const uint64_t e = x << shift;
+    out[x] = Fr::mul(lo[e & ((1u << L) - 1)], hi[e >> L]);
+}
+
 int fr_mul_batch_dev(fk_ctx *ctx, const Fr *a, const Fr *b, Fr *o, size_t n) {
     if (!n) return FK_OK;
     hipLaunchKernelGGL(fr_mul_batch_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, a, b, o, n);
@@ -259,6 +275,36 @@ static int get_domain(fk_ctx *ctx, uint32_t log_n, NttDomain **out) {
         for (uint32_t e = 0; e < half; e++) { pq[e] = cur; cur = Fr::mul(cur, wr); }
         rc = upload_table(ctx, d, pq, &d->pq[dir]);
     }
+    // single-level twiddles for every pass but the first (sizes 2^(lgp + deg): the last one is the whole domain, 32 B per
+    // point and direction).  FK_NTT_FULL_TW=0 disables them; they are skipped when they would not fit comfortably.
+    {
+        const char *e = getenv("FK_NTT_FULL_TW");
+        const bool want = !(e && e[0] == '0');
+        size_t free_b = 0, total_b = 0;
+        (void)hipMemGetInfo(&free_b, &total_b);
+        uint64_t need = 0;
+        { uint32_t lgp = 0; for (size_t i = 0; i < d->degs.size(); i++) { if (i) need += (uint64_t)2 * sizeof(Fr) << (lgp + d->degs[i]); lgp += d->degs[i]; } }
+        const bool fits = need < free_b / 8;
+        for (int dir = 0; dir < 2 && rc == FK_OK; dir++) {
+            d->tw_full[dir].assign(d->degs.size(), nullptr);
+            if (!want || !fits) continue;
+            uint32_t lgp = 0;
+            for (size_t i = 0; i < d->degs.size() && rc == FK_OK; i++) {
+                if (i) {
+                    const uint64_t cnt = (uint64_t)1 << (lgp + d->degs[i]);
+                    void *p = nullptr;
+                    if (hipMalloc(&p, cnt * sizeof(Fr)) != hipSuccess) { rc = FK_ERR_OOM; break; }
+                    d->allocs.push_back(p);
+                    hipLaunchKernelGGL(tw_full_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream, d->tw_lo[dir], d->tw_hi[dir], d->L,
+                                       log_n - lgp - d->degs[i], cnt, (Fr *)p);
+                    if (hipGetLastError() != hipSuccess) { rc = FK_ERR_HIP; break; }
+                    d->tw_full[dir][i] = (Fr *)p;
+                }
+                lgp += d->degs[i];
+            }
+        }
+        if (rc == FK_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = FK_ERR_HIP;
+    }
     if (rc == FK_OK) rc = make_scale_table(ctx, d, g, Fr::one(), &d->t_g);
     if (rc == FK_OK) rc = make_scale_table(ctx, d, ginv, d->minv, &d->t_ginv_minv);
     if (rc == FK_OK) rc = make_scale_table(ctx, d, g, d->minv, &d->t_g_minv);
@@ -301,6 +347,7 @@ static int ntt_exec(fk_ctx *ctx, NttDomain *d, const NttOp &op, const Fr *in, Fr
         if (logC > d->log_n - deg) logC = d->log_n - deg;
         a.logC = logC;
         a.tw_lo = d->tw_lo[dir]; a.tw_hi = d->tw_hi[dir]; a.L = d->L;
+        a.tw_full = d->tw_full[dir].empty() ? nullptr : d->tw_full[dir][i];
         a.pq = d->pq[dir]; a.pq_shift = d->maxdeg - deg;
         a.pre_mode = (i == 0) ? op.pre_mode : PRE_NONE;
         if (op.pre) { a.pre_lo = op.pre->lo; a.pre_hi = op.pre->hi; }
