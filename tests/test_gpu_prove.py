@@ -197,3 +197,25 @@ def test_synthetic_key_full_pipeline_2_16(ctx):
         for p in list(bufs.values()) + [d_z, d_da, d_dbi, d_dba]:
             ctx.dev_free(p)
         key.free()
+
+
+def test_repeated_proofs_are_deterministic(ctx, oracle):
+    """The five MSMs of a proof run on two streams with overlapped tails and reused scratch: 40 back-to-back proofs of
+    alternating systems (so every buffer is reused with different sizes) must each equal the oracle's bytes."""
+    import fawkes_crypto_amd as fk
+    cases = []
+    for seed, gates, nin, naux in ((901, 700, 2, 650), (902, 3000, 3, 3300), (903, 90, 1, 120)):
+        cs, z_in, z_aux = ref.random_r1cs(seed, gates, nin, naux)
+        csr = fx.r1cs_to_csr(cs)
+        key = oracle.setup(csr, **TOXIC)
+        params = params_from_oracle_key(key, r1cs_product(csr))
+        z = fx.witness_mont(z_in, z_aux)
+        r, s = fx.mont_fr(seed), fx.mont_fr(seed * 7)
+        a, b, c, aa, bi, ba = oracle.synthesize(csr, z)
+        want = oracle.prove(key, a, b, c, z, aa, bi, ba, r, s).tobytes()
+        cases.append((ctx.load_key(params), ctx.load_r1cs(params.r1cs), z, r, s, want))
+    for it in range(40):
+        dk, dr, z, r, s, want = cases[it % 3]
+        assert ctx.prove_witness(dk, dr, z, r, s).tobytes() == want, it
+    for dk, dr, *_ in cases:
+        dr.free(); dk.free()
