@@ -18,8 +18,9 @@ region is checked afterwards with the Groth16 pairing equation.
 N > 1: one process per GPU, strong scaling of a single proof: every rank holds 1/N of each key array (MSM sharded
 by points) and computes 1/N of the quotient -- the seven transforms are cut across the ranks with one all-to-all
 (RCCL over xGMI) each -- then ONE all-gather of 384 bytes per rank exchanges the partial MSM sums and the proof is
-folded locally (fawkes-crypto_amd/parallel.py: prove_distributed_dev).  FK_DIST_QUOTIENT=0 or a rank count that
-is not a power of two selects the older schedule (rank 0 computes the quotient and ships h slices point to point).
+folded locally (fawkes-crypto_amd/parallel.py: prove_distributed_dev).  With 2 ranks, or a rank count that is not a
+power of two, rank 0 computes the quotient while the other ranks start on the witness MSMs, and h slices travel point
+to point (prove_balanced_dev); FK_DIST_QUOTIENT=1 / 0 forces either schedule.
 
 The CPU oracle (oracle/) appears here only in the `cpu_baseline` leg: the timed CPU baseline, a live parity
 check of that same sample, and the pairing check of the benchmarked proof; it is never the thing measured.
@@ -181,7 +182,12 @@ def main():
     n_a, n_b = info['n_a'], info['n_b']
     # N > 1, N a power of two: quotient and MSMs cut 1/N each (parallel.prove_distributed_dev); otherwise (or with
     # FK_DIST_QUOTIENT=0) rank 0 computes the quotient and ships h slices (parallel.prove_balanced_dev)
-    dist_q = world > 1 and (world & (world - 1)) == 0 and world <= 8 and os.environ.get('FK_DIST_QUOTIENT', '1') != '0'
+    # Default by rank count: at N = 2 every all-to-all of the distributed quotient moves m*32/4 bytes over ONE xGMI link
+    # (256 MiB at 2^25, ~3.5 ms, eight times per proof), more than the quotient it saves; from N = 4 on the chunks are
+    # small and spread over N-1 links.  FK_DIST_QUOTIENT=1 / 0 forces either schedule.
+    dq_env = os.environ.get('FK_DIST_QUOTIENT', '')
+    dq_ok = world > 1 and (world & (world - 1)) == 0 and world <= 8
+    dist_q = dq_ok and (dq_env == '1' or (dq_env != '0' and world >= 4))
     fracs = parallel.plan_z_fractions(world, m, v_aux, n_a, n_b)
     tox = {k: mont(v) for k, v in TOXIC.items()}
     key, vk = ctx.setup(r1cs, shard_index=rank, shard_count=world, z_frac=fracs[rank] if (world > 1 and not dist_q) else (0.0, 0.0), **tox)
