@@ -161,9 +161,13 @@ def main():
         local_rank = 0                      # dry run: all ranks share GPU 0 (needs --backend gloo)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    # FK_BENCH_REHEARSE=1 with --gpus 1: run the multi-GPU code path (process group, all-to-all, all-gather, distributed
+    # quotient with one rank) on a single GPU -- a rehearsal of the N > 1 plumbing over real RCCL, not a benchmark mode
+    multi = world > 1 or os.environ.get('FK_BENCH_REHEARSE') == '1'
+    if multi:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
         if args.backend == 'nccl':
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
         else:
@@ -186,8 +190,8 @@ def main():
     # (256 MiB at 2^25, ~3.5 ms, eight times per proof), more than the quotient it saves; from N = 4 on the chunks are
     # small and spread over N-1 links.  FK_DIST_QUOTIENT=1 / 0 forces either schedule.
     dq_env = os.environ.get('FK_DIST_QUOTIENT', '')
-    dq_ok = world > 1 and (world & (world - 1)) == 0 and world <= 8
-    dist_q = dq_ok and (dq_env == '1' or (dq_env != '0' and world >= 4))
+    dq_ok = multi and (world & (world - 1)) == 0 and world <= 8
+    dist_q = dq_ok and (dq_env == '1' or (dq_env != '0' and (world >= 4 or world == 1)))
     fracs = parallel.plan_z_fractions(world, m, v_aux, n_a, n_b)
     tox = {k: mont(v) for k, v in TOXIC.items()}
     key, vk = ctx.setup(r1cs, shard_index=rank, shard_count=world, z_frac=fracs[rank] if (world > 1 and not dist_q) else (0.0, 0.0), **tox)
@@ -204,7 +208,7 @@ def main():
         send = [torch.empty(m // world * 32, dtype=torch.uint8, device=dev) for _ in range(3)]
         recv = [torch.empty(m // world * 32, dtype=torch.uint8, device=dev) for _ in range(3)]
         a2a = parallel.torch_all_to_all(ctx)
-    elif world > 1:
+    elif multi:
         h_ranges = [fk.api.h_shard_range(m - 1, g, world) for g in range(world)]
         h_full_buf = torch.empty(m * 32, dtype=torch.uint8, device=dev) if rank == 0 else None
         recv_buf = torch.empty(max(h_ranges[rank][1] - h_ranges[rank][0], 1) * 32, dtype=torch.uint8, device=dev) if rank > 0 else None
@@ -212,7 +216,7 @@ def main():
     prep_s = time.time() - t_prep
 
     def step():
-        if world == 1:
+        if not multi:
             return ctx.prove_witness_dev(key, dr, d_z.data_ptr(), r, s)
         wp = [w_.data_ptr() if w_ is not None else 0 for w_ in work]
         if dist_q:
@@ -225,7 +229,7 @@ def main():
             eval_fn=(lambda: ctx.r1cs_eval_dev(dr, d_z.data_ptr(), wp[0], wp[1], wp[2])) if rank == 0 else None)
 
     def barrier():
-        if world > 1:
+        if multi:
             import torch.distributed as dist
             dist.barrier()
         ctx.sync()
@@ -244,7 +248,7 @@ def main():
     stats = ctx.stats()
     if len(set(proofs)) != 1 or proofs[0] == bytes(256):
         raise AssertionError('bench: proofs differ between steps (non-deterministic result)')
-    if world > 1:
+    if multi:
         import torch.distributed as dist
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == 'nccl' else 'cpu')
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -283,7 +287,7 @@ def main():
                        'gates': '40% boolean b*(b-1)=0, 10% linear, 50% products', 'nnz': list(info['nnz']),
                        'a_query_points': n_a, 'b_query_points': n_b,
                        'witness': '%.0f%% zeros, %.0f%% ones, rest dense 254-bit' % (100.0 * zeros / (v_in + v_aux), 100.0 * ones / (v_in + v_aux)),
-                       'parallelism': 'msm-shard%d%s' % (world, '' if world == 1 else
+                       'parallelism': 'msm-shard%d%s' % (world, '' if not multi else
                                                          '+distributed-quotient (8 all-to-all per proof)' if dist_q else '+balanced-quotient')},
             'msm_scalar_muls_per_sec': msm_units / sec_per_step,
             'roofline': {
@@ -304,9 +308,9 @@ def main():
             },
             'prep_seconds': prep_s,
         }
-        if world > 1 and not args.no_cpu_baseline:
+        if multi and not args.no_cpu_baseline:
             out['proof_verified_by_pairing_check'] = pairing_check(vk, z_in1, proofs[-1])
-        if world == 1 and not args.no_cpu_baseline:
+        if not multi and not args.no_cpu_baseline:
             cpu_s, cpu_m, verified = cpu_baseline_leg(ctx, fk, args.cpu_log2n, (vk, z_in1, proofs[-1]))
             scale = m / cpu_m
             out['proof_verified_by_pairing_check'] = verified
@@ -321,7 +325,7 @@ def main():
 
     dr.free()
     key.free()
-    if world > 1:
+    if multi:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
