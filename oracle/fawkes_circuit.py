@@ -1,7 +1,8 @@
 """
 ORACLE (test infrastructure, not product code): restatement of the part of fawkes-crypto's circuit DSL that the
 reference's own Groth16 test exercises -- BASELINE.json configs[0] / SURVEY.md section 8f row 3:
-`tests/bellman_groth16.rs:19-48` (poseidon merkle proof, depth 32, PoseidonParams::new(3, 8, 53)).
+`tests/bellman_groth16.rs:19-48` (poseidon merkle proof, depth 32, PoseidonParams::new(3, 8, 53)) -- and, in the second
+half of the file, of configs[2]: the eddsa-poseidon signature check over JubJubBN256.
 
 It produces the constraint system (a bn254_ref.R1CS) and a satisfying witness in the exact variable / gate order
 the reference emits, so that the product path can be run on the reference's real configs[0] workload instead of a
@@ -362,3 +363,384 @@ def poseidon_merkle_circuit(leaf, sibling, path, depth=32, params=None):
     res = c_poseidon_merkle_proof_root(c_leaf, c_sib, c_path, params)
     res.assert_eq(public)
     return cs, root_value
+
+
+# =========================================================================== BASELINE configs[2]: poseidon eddsa
+# Restated from (file:line under /root/reference/fawkes-crypto/src):
+#   engines/bn256/mod.rs:28-75      Fs modulus, JubJubBN256::new (edwards_d, montgomery_a/b/u, generator from the seedbox)
+#   native/ecc.rs:56-353            Edwards / Montgomery points, subgroup_decompress, from_scalar_raw, scalar multiplication
+#   native/eddsaposeidon.rs:42-79   sign / verify (the nonce here is any scalar: a signature's validity does not depend on
+#                                   how rho was derived, so the Blake2s step is not restated)
+#   circuit/ecc.rs:25-283           CEdwardsPoint / CMontgomeryPoint gadgets, fixed-base (mux3 windows) and variable-base mul
+#   circuit/mux.rs:8-32, circuit/bitify.rs:9-113, circuit/eddsaposeidon.rs:17-47, circuit/r1cs/num.rs:40-78 (div, is_zero)
+# Pinned by the reference's published gate counts (README.md:46-53): ecmul_const 254 bits = 513, ecmul 254 bits = 2296,
+# poseidon eddsa = 3860.  The curve constants themselves are unpinned (no vector in the reference).
+FS = 2736030358979909402780800718157159386076813972158567259200215660948447373041     # jubjub scalar field, 251 bits
+FR_BITS, FS_BITS = 254, 251
+
+
+def fr_inv(a):
+    return pow(a % R, -1, R)
+
+
+def fr_sqrt(a):
+    """any square root mod R (every use in the reference normalises the sign afterwards), None for a non-residue"""
+    a %= R
+    if a == 0:
+        return 0
+    if pow(a, (R - 1) // 2, R) != 1:
+        return None
+    s, t = 0, R - 1
+    while t % 2 == 0:
+        s, t = s + 1, t // 2
+    z = 5
+    while pow(z, (R - 1) // 2, R) == 1:
+        z += 1
+    c, r, tt, m = pow(z, t, R), pow(a, (t + 1) // 2, R), pow(a, t, R), s
+    while tt != 1:
+        i, t2 = 0, tt
+        while t2 != 1:
+            t2, i = t2 * t2 % R, i + 1
+        b = pow(c, 1 << (m - i - 1), R)
+        r, c = r * b % R, b * b % R
+        tt, m = tt * c % R, i
+    return r
+
+
+class JubJubBN256:
+    """engines/bn256/mod.rs:48-75; points are affine (x, y) tuples on  -x^2 + y^2 = 1 + d x^2 y^2"""
+
+    def __init__(self):
+        self.d = (-168696) * fr_inv(168700) % R
+        self.ma = 2 * (1 - self.d) * fr_inv(1 + self.d) % R
+        self.mb = (-4) * fr_inv(1 + self.d) % R
+        self.mu = 337401
+        self.g = self.from_scalar_raw(SeedboxChaCha20(b'edwards_g').gen_fr())
+
+    def add(self, p, q):                      # unified addition (ecc.rs:309-333 in affine form)
+        (x1, y1), (x2, y2) = p, q
+        t = self.d * x1 * x2 % R * y1 * y2 % R
+        return ((x1 * y2 + y1 * x2) * fr_inv(1 + t) % R, (y1 * y2 + x1 * x2) * fr_inv(1 - t) % R)
+
+    def mul(self, p, k):                      # ecc.rs:339-352
+        res = (0, 1)
+        for b in bin(k)[2:] if k else '':
+            res = self.add(res, res)
+            if b == '1':
+                res = self.add(res, p)
+        return res
+
+    def cofactor(self, p):
+        return self.mul(p, 8)
+
+    @staticmethod
+    def into_montgomery(p):                   # ecc.rs:182-197
+        x, y = p
+        if x == 0:
+            return None if y == 1 else (0, 0)
+        mx = (1 + y) * fr_inv(1 - y) % R
+        return (mx, mx * fr_inv(x) % R)
+
+    @staticmethod
+    def mont_into_edwards(p):                 # ecc.rs:213-224
+        x, y = p
+        if x == 0:
+            return (0, R - 1)
+        return (x * fr_inv(y) % R, (x - 1) * fr_inv(x + 1) % R)
+
+    def from_scalar_raw(self, t):             # ecc.rs:103-132
+        g = lambda x: (x * x % R * (x + self.ma) + x) * fr_inv(self.mb) % R
+        t2g1 = t * t % R * self.mu % R
+        x2 = (-1) * fr_inv(self.ma) * (1 + fr_inv(t2g1)) % R
+        y = fr_sqrt(g(x2))
+        mx = x2
+        if y is None:
+            mx = x2 * t2g1 % R
+            y = fr_sqrt(g(mx))
+        if (y * t % R) & 1:
+            y = (-y) % R
+        return self.cofactor(self.mont_into_edwards((mx, y)))
+
+    def subgroup_decompress(self, x):         # ecc.rs:71-93
+        x2 = x * x % R
+        y = fr_sqrt((x2 + 1) * fr_inv(1 - self.d * x2) % R)
+        if y is None:
+            return None
+        lx, ly = self.mul((x, y), FS)
+        if lx != 0:
+            return None
+        return (x, y) if ly == 1 else (x, (-y) % R)
+
+
+def eddsaposeidon_sign(sk, m, rho, pparams, jj):        # eddsaposeidon.rs:42-53 with the nonce given
+    r_x = jj.mul(jj.g, rho)[0]
+    a_x = jj.mul(jj.g, sk)[0]
+    s = (rho + (poseidon([r_x, a_x, m], pparams) % FS) * sk) % FS
+    return s, r_x, a_x
+
+
+def eddsaposeidon_verify(s, r, a, m, pparams, jj):      # eddsaposeidon.rs:55-79
+    p_a, p_r = jj.subgroup_decompress(a), jj.subgroup_decompress(r)
+    if p_a is None or p_r is None:
+        return False
+    ha = jj.mul(p_a, poseidon([r, a, m], pparams) % FS)
+    return jj.mul(jj.g, s) == jj.add(ha, p_r)
+
+
+# ---- more of the DSL (num.rs / bool.rs / bitify.rs / mux.rs / ecc.rs)
+def _neg(a):
+    return CNum(a.cs, {k: (-v) % R for k, v in a.lc.items()}, (-a.value) % R)
+
+
+def _rsub(k, a):                              # Num - CNum
+    return _neg(a).add_const(k)
+
+
+def c_square(a):
+    return a.mul(a)
+
+
+def c_div_unchecked(a, b):                    # num.rs:40-51
+    ca, cb = a.as_const(), b.as_const()
+    if cb is not None:
+        return a.scale(fr_inv(cb))
+    signal = a.cs.alloc(a.value * (fr_inv(b.value) if b.value else 0) % R)
+    a.cs.enforce(signal, b, a)
+    return signal
+
+
+def c_assert_const(a, k):                     # num.rs:153-159 (also CBool::assert_const, bool.rs:73-79)
+    a.cs.enforce(a, a.cs.const(1), a.cs.const(k))
+
+
+def c_is_zero(a):                             # num.rs:69-85 -> CBool (a CNum that is 0 or 1)
+    c = a.as_const()
+    if c is not None:
+        return a.cs.const(1 if c == 0 else 0)
+    inv = a.cs.alloc(fr_inv(a.value) if a.value else 0)
+    res = _neg(inv).mul(a).add_const(1)
+    c_assert_const(res.mul(a), 0)
+    return res
+
+
+def c_into_bits_le(signal, limit):            # bitify.rs:9-48
+    cs = signal.cs
+    c = signal.as_const()
+    if c is not None:
+        assert c >> limit == 0
+        return [cs.const((c >> i) & 1) for i in range(limit)]
+    remained, k = signal, 1
+    bits = [cs.const(0)] * limit
+    for i in range(1, limit):
+        k = 2 * k % R
+        s = alloc_bool(cs, (signal.value >> i) & 1)
+        remained = remained.sub(s.scale(k))
+        bits[i] = s
+    remained.assert_bit()                     # to_bool
+    bits[0] = remained
+    return bits
+
+
+def c_comp_constant(signal, ct):              # bitify.rs:62-104: true if signal > ct
+    siglen = len(signal)
+    cs = signal[0].cs
+    c_false = cs.const(0)
+    if ct >> siglen:
+        return c_false
+    nsteps = (siglen + 1) >> 1
+    k, acc = 1, cs.const(0)
+    for i in range(nsteps):
+        ct_l, ct_u = (ct >> (2 * i)) & 1, (ct >> (2 * i + 1)) & 1
+        sig_l = signal[2 * i]
+        sig_u = signal[2 * i + 1] if 2 * i + 1 < siglen else c_false
+        sig_lu = sig_l.mul(sig_u)
+        if (ct_l, ct_u) == (0, 0):
+            term = sig_l.add(sig_u).sub(sig_lu)
+        elif (ct_l, ct_u) == (1, 0):
+            term = sig_l.add(sig_u.scale(2)).sub(sig_lu).add_const(-1)
+        elif (ct_l, ct_u) == (0, 1):
+            term = sig_lu.add(sig_u).add_const(-1)
+        else:
+            term = sig_lu.add_const(-1)
+        acc = acc.add(term.scale(k))
+        k = 2 * k % R
+    acc = acc.add_const(k - 1)
+    return c_into_bits_le(acc, nsteps + 1)[nsteps]
+
+
+def c_into_bits_le_strict(signal):            # bitify.rs:106-111
+    bits = c_into_bits_le(signal, FR_BITS)
+    c_assert_const(c_comp_constant(bits, R - 1), 0)
+    return bits
+
+
+def c_mux3(s, c):                             # mux.rs:8-32
+    s10 = s[0].mul(s[1])
+    res = []
+    for ci in c:
+        a210 = s10.scale(ci[7] - ci[6] - ci[5] + ci[4] - ci[3] + ci[2] + ci[1] - ci[0])
+        a21 = s[1].scale(ci[6] - ci[4] - ci[2] + ci[0])
+        a20 = s[0].scale(ci[5] - ci[4] - ci[1] + ci[0])
+        a2 = ci[4] - ci[0]
+        a10 = s10.scale(ci[3] - ci[2] - ci[1] + ci[0])
+        a1 = s[1].scale(ci[2] - ci[0])
+        a0 = s[0].scale(ci[1] - ci[0])
+        res.append(a210.add(a21).add(a20).add_const(a2).mul(s[2]).add(a10).add(a1).add(a0).add_const(ci[0]))
+    return res
+
+
+class CEdwards:
+    def __init__(self, x, y):
+        self.x, self.y = x, y
+
+    @property
+    def cs(self):
+        return self.x.cs
+
+    def value(self):
+        return (self.x.value, self.y.value)
+
+    def as_const(self):                       # derived Signal::as_const: field by field, short-circuit
+        x = self.x.as_const()
+        if x is None:
+            return None
+        y = self.y.as_const()
+        return None if y is None else (x, y)
+
+    def switch(self, bit, if_else):
+        return CEdwards(self.x.switch(bit, if_else.x), self.y.switch(bit, if_else.y))
+
+    def double(self, jj):                     # ecc.rs:25-33
+        v = self.x.mul(self.y)
+        v2 = c_square(v)
+        u = c_square(self.x.add(self.y))
+        return CEdwards(c_div_unchecked(v.scale(2), v2.scale(jj.d).add_const(1)),
+                        c_div_unchecked(u.sub(v.scale(2)), _rsub(1, v2.scale(jj.d))))
+
+    def mul_by_cofactor(self, jj):
+        return self.double(jj).double(jj).double(jj)
+
+    def add(self, p, jj):                     # ecc.rs:39-48
+        v1 = self.x.mul(p.y)
+        v2 = p.x.mul(self.y)
+        v12 = v1.mul(v2)
+        u = self.x.add(self.y).mul(p.x.add(p.y))
+        return CEdwards(c_div_unchecked(v1.add(v2), v12.scale(jj.d).add_const(1)),
+                        c_div_unchecked(u.sub(v1).sub(v2), _rsub(1, v12.scale(jj.d))))
+
+    def assert_in_curve(self, jj):            # ecc.rs:50-55
+        x2, y2 = c_square(self.x), c_square(self.y)
+        x2.scale(jj.d).mul(y2).assert_eq(y2.sub(x2).add_const(-1))
+
+    @staticmethod
+    def subgroup_decompress(x, jj):           # ecc.rs:69-80
+        p = jj.subgroup_decompress(x.value) or jj.g
+        pre = jj.mul(p, fr_inv_mod(8, FS))
+        preimage = CEdwards(x.cs.alloc(pre[0]), x.cs.alloc(pre[1]))
+        preimage.assert_in_curve(jj)
+        p8 = preimage.mul_by_cofactor(jj)
+        c_assert_const(x.sub(p8.x), 0)
+        return p8
+
+    def into_montgomery(self):                # ecc.rs:83-87
+        x = c_div_unchecked(self.y.add_const(1), _rsub(1, self.y))
+        return CMont(x, c_div_unchecked(x, self.x))
+
+    def mul(self, bits, jj):                  # ecc.rs:90-186
+        cs = self.cs
+        c_base = self.as_const()
+        if c_base is not None:
+            if c_base == (0, 1):
+                return CEdwards(cs.const(0), cs.const(1))
+            all_bits = list(bits) + [cs.const(0)] * ((2 * len(bits)) % 3)
+            nwindows = len(all_bits) // 3
+            acc, base = (0, R - 1), c_base
+            for _ in range(nwindows):
+                acc = jj.add(acc, base)
+                base = jj.cofactor(base)
+            mp = jj.into_montgomery(((-acc[0]) % R, acc[1]))
+            cacc = CMont(cs.const(mp[0]), cs.const(mp[1]))
+            base = c_base
+            for i in range(nwindows):
+                xs, ys, q = [], [], base
+                for _ in range(8):
+                    mx, my = jj.into_montgomery(q)
+                    xs.append(mx); ys.append(my)
+                    q = jj.add(q, base)
+                res = c_mux3(all_bits[3 * i:3 * i + 3], [xs, ys])
+                cacc = cacc.add(CMont(res[0], res[1]), jj)
+                base = jj.cofactor(base)
+            r = cacc.into_edwards()
+            return CEdwards(_neg(r.x), _neg(r.y))
+        base_is_zero = c_is_zero(self.x)
+        dummy = CEdwards(cs.const(jj.g[0]), cs.const(jj.g[1]))
+        base_point = dummy.switch(base_is_zero, self).into_montgomery()
+        exponents = [base_point]
+        for _ in range(1, len(bits)):
+            base_point = base_point.double(jj)
+            exponents.append(base_point)
+        empty = CMont(cs.const(0), cs.const(0))
+        acc = empty
+        for i in range(len(bits)):
+            acc = acc.add(exponents[i], jj).switch(bits[i], acc)
+        acc = empty.switch(base_is_zero, acc)
+        r = acc.into_edwards()
+        return CEdwards(_neg(r.x), _neg(r.y))
+
+
+def fr_inv_mod(a, mod):
+    return pow(a, -1, mod)
+
+
+class CMont:
+    def __init__(self, x, y):
+        self.x, self.y = x, y
+
+    def switch(self, bit, if_else):
+        return CMont(self.x.switch(bit, if_else.x), self.y.switch(bit, if_else.y))
+
+    def double(self, jj):                     # ecc.rs:245-256
+        x2 = c_square(self.x)
+        l = c_div_unchecked(x2.scale(3).add(self.x.scale(2 * jj.ma)).add_const(1), self.y.scale(2 * jj.mb))
+        b_l2 = c_square(l).scale(jj.mb)
+        return CMont(b_l2.add_const(-jj.ma).sub(self.x.scale(2)),
+                     l.mul(self.x.scale(3).add_const(jj.ma).sub(b_l2)).sub(self.y))
+
+    def add(self, p, jj):                     # ecc.rs:259-268
+        l = c_div_unchecked(p.y.sub(self.y), p.x.sub(self.x))
+        b_l2 = c_square(l).scale(jj.mb)
+        return CMont(b_l2.add_const(-jj.ma).sub(self.x).sub(p.x),
+                     l.mul(self.x.scale(2).add(p.x).add_const(jj.ma).sub(b_l2)).sub(self.y))
+
+    def into_edwards(self):                   # ecc.rs:271-277
+        y_is_zero = c_is_zero(self.y)
+        return CEdwards(c_div_unchecked(self.x, self.y.add(y_is_zero)),
+                        c_div_unchecked(self.x.add_const(-1), self.x.add_const(1)))
+
+
+def c_eddsaposeidon_verify(s, r, a, m, pparams, jj):    # circuit/eddsaposeidon.rs:17-47 -> CBool
+    cs = s.cs
+    p_a = CEdwards.subgroup_decompress(a, jj)
+    p_r = CEdwards.subgroup_decompress(r, jj)
+    h = c_poseidon([r, a, m], pparams)
+    ha = p_a.mul(c_into_bits_le_strict(h), jj)
+    s_bits = c_into_bits_le(s, FS_BITS)
+    c_assert_const(c_comp_constant(s_bits, FS - 1), 0)
+    sb = CEdwards(cs.const(jj.g[0]), cs.const(jj.g[1])).mul(s_bits, jj)
+    ha_plus_r = ha.add(p_r, jj)
+    return c_is_zero(ha_plus_r.x.sub(sb.x))
+
+
+def eddsa_circuit(sk, m, rho, pparams=None, jj=None):
+    """One signature check as a circuit under the backend's prove(): public input m, secrets (s, r, a), the verifier's
+    result asserted true.  Returns (CS, (s, r_x, a_x))."""
+    pparams = pparams or PoseidonParams(4, 8, 54)
+    jj = jj or JubJubBN256()
+    s, r_x, a_x = eddsaposeidon_sign(sk, m, rho, pparams, jj)
+    cs = CS()
+    c_m = cs.alloc(m)
+    cs.inputize(c_m)
+    c_s, c_r, c_a = cs.alloc(s), cs.alloc(r_x), cs.alloc(a_x)
+    ok = c_eddsaposeidon_verify(c_s, c_r, c_a, c_m, pparams, jj)
+    c_assert_const(ok, 1)
+    return cs, (s, r_x, a_x)

@@ -84,3 +84,27 @@ def fast_r1cs(seed, num_gates, num_input, num_aux):
     cs = co.R1csC(num_input, num_aux, A, B, Cm)
     z = co.limbs_arr([x * MONT % R for x in zs])
     return cs, z, z_in, z_aux
+
+
+def tile_r1cs(csr, copies):
+    """`copies` independent instances of one constraint system as ONE system (a batch circuit): the constant ONE is
+    shared, every copy gets its own public inputs and aux variables.  Variable order: ONE, copy 0's inputs, copy 1's
+    inputs, ..., copy 0's aux, copy 1's aux, ...  Returns a c_oracle.R1csC."""
+    nin1, naux1 = csr.num_input - 1, csr.num_aux
+    nin, naux = 1 + copies * nin1, copies * naux1
+
+    def tile(m):
+        per = len(m.col)
+        col = np.tile(m.col.astype(np.int64), copies).reshape(copies, per)
+        k = np.arange(copies, dtype=np.int64)[:, None]
+        is_one, is_in = col == 0, (col > 0) & (col < csr.num_input)
+        out = np.where(is_one, 0, np.where(is_in, col + k * nin1, nin + k * naux1 + (col - csr.num_input)))
+        ptr = (m.ptr[None, :-1].astype(np.int64) + k * per).reshape(-1)
+        return co.Csr(np.append(ptr, copies * per).astype(np.uint64), out.reshape(-1).astype(np.uint32), np.tile(m.val, (copies, 1)))
+
+    return co.R1csC(nin, naux, tile(csr.A), tile(csr.B), tile(csr.C))
+
+
+def tile_witness(z_ins, z_auxs):
+    """witness of tile_r1cs from the per-copy (z_in, z_aux) lists (z_in[0] == 1 in each)"""
+    return witness_mont([1] + [v for zi in z_ins for v in zi[1:]], [v for za in z_auxs for v in za])
