@@ -612,7 +612,9 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
     }
     const size_t WB = (size_t)p.W * p.B;
     const size_t wp_bytes = (size_t)p.W * p.nblk * sizeof(Xyzz<F>);
-    const uint32_t over_cap = 1u << 16;
+    // every oversized bucket holds more than `cap` of the W * n entries, so there can be at most W * n / cap of them: the
+    // list is sized for that worst case (witnesses with many repeated values put thousands of buckets over the cap)
+    const uint32_t over_cap = (uint32_t)std::min<uint64_t>((uint64_t)p.W * n / (p.cap ? p.cap : 1) + 64, 0x7fffffffu);
     // Growing a buffer frees the old one: everything queued on this lane must be finished first.
     const uint32_t nseg = p.W * p.nhi;
     const size_t max_tiles = (size_t)p.W * ((n + S2_TILE - 1) / S2_TILE) + nseg + 1;
@@ -695,7 +697,7 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
         FK_HIP(ctx, hipStreamSynchronize(st));
         n_over = *h_nover;
         if (ctx->debug) { fprintf(stderr, "[fk] msm n=%zu c=%u (W=%u: %u x %u bits + %u x %u bits) cap=%u: %u oversized buckets\n", n, p.c, p.W, p.wide, p.cb + 1, p.W - p.wide, p.cb, p.cap, n_over); fflush(stderr); }
-        if (n_over > over_cap) { ln.last_sort_scalars = nullptr; FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "msm: %u oversized buckets exceed the table (pathological scalar distribution)", n_over); }
+        if (n_over > over_cap) { ln.last_sort_scalars = nullptr; FK_SET_ERR(ctx, FK_ERR_HIP, "msm: %u oversized buckets exceed the bound %u", n_over, over_cap); }
         n_tasks = n_obs = tb_al = 0; SEG = SEG_MIN;
         if (n_over) {
             FK_HIP(ctx, hipMemcpyAsync(h_over, ln.overlist.p, n_over * sizeof(OverEntry), hipMemcpyDeviceToHost, st));

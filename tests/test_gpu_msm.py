@@ -160,3 +160,14 @@ def test_gen_points_g2_on_curve(ctx):
             assert ref.G2.on_curve(ref.g2_from_raw_le(row.tobytes()))
     finally:
         ctx.dev_free(d)
+
+
+def test_msm_many_repeated_scalars(ctx, oracle):
+    """6000 distinct scalars, 48 copies each: ~90 000 buckets exceed the statistical cap at once (a tiled batch witness does
+    this).  The oversized-bucket list is sized for the worst case W * n / cap, so the path must neither fail nor truncate."""
+    rng = np.random.default_rng(4848)
+    base = rand_fr_mont(rng, 6000)
+    sc = np.tile(base, (48, 1))
+    n = sc.shape[0]
+    bases = g1_bases(n, seed=9)
+    assert ctx.msm_g1(bases, sc).tobytes() == oracle.msm_g1(bases, sc).tobytes()
