@@ -43,7 +43,7 @@ struct MsmLane {
     size_t h_cap = 0;
     const void *last_sort_scalars = nullptr; size_t last_sort_n = 0; unsigned last_sort_c = 0;   // what `sorted` currently holds
     // ... and the oversized-bucket tables that belong to it (already in tasktab on the device)
-    uint32_t last_n_over = 0, last_seg = 0; size_t last_n_tasks = 0, last_n_obs = 0, last_tb_al = 0;
+    uint32_t last_n_over = 0, last_seg = 0, last_cap = 0; size_t last_n_tasks = 0, last_n_obs = 0, last_tb_al = 0;
 };
 
 // One outstanding multiplication: everything is queued, `done` fires when its window sums are in h_wp.

@@ -321,6 +321,18 @@ __global__ __launch_bounds__(1024) void s2_prefix2_kernel(uint32_t *cnt2, uint32
     }
 }
 
+// Re-lists the buckets longer than `cap` (used when the statistical cap turned out too tight for the actual scalars and is
+// being raised): one lane per bucket.
+__global__ __launch_bounds__(256) void msm_over_scan_kernel(const uint32_t *totals, size_t WB, uint32_t cap, OverEntry *over, uint32_t *n_over, uint32_t over_cap) {
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= WB) return;
+    const uint32_t sz = totals[g];
+    if (sz > cap) {
+        const uint32_t k = atomicAdd(n_over, 1u);
+        if (k < over_cap) { over[k].g = (uint32_t)g; over[k].size = sz; }
+    }
+}
+
 // Second-pass scatter with LDS staging: entries of the tile are ranked per low bin (LDS counters), placed in bin order in
 // an LDS staging buffer and then written out so that consecutive lanes store consecutive addresses of one bucket run
 // (64-byte runs on average) instead of one 4-byte store per lane to an arbitrary line.
@@ -677,18 +689,11 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
         }
         FK_HIP(ctx, hipGetLastError());
         FK_DBG_ST(ctx, st, "msm_sort_pass2");
-        // size-ordered bucket -> lane assignment
-        FK_HIP(ctx, hipMemsetAsync(size_bins, 0, SIZE_BINS * 4, st));
-        hipLaunchKernelGGL(msm_size_hist_kernel, dim3((unsigned)std::min<size_t>((WB + 255) / 256, 1024)), dim3(256), 0, st, totals, WB, p.cap_top, size_bins);
-        hipLaunchKernelGGL(msm_size_scan_kernel, dim3(1), dim3(SIZE_BINS), 0, st, size_bins);
-        hipLaunchKernelGGL(msm_size_scatter_kernel, dim3((unsigned)((WB + 1023) / 1024)), dim3(1024), 0, st, totals, WB, p.cap_top, size_bins, perm);
-        FK_HIP(ctx, hipGetLastError());
-        FK_DBG_ST(ctx, st, "msm_size_order");
         ln.last_sort_scalars = (const void *)d_scalars; ln.last_sort_n = n; ln.last_sort_c = p.c;
     }
     // oversized buckets (skewed scalars): known once the sort is done -- the host builds the segment table now, so that
     // nothing has to wait for the accumulation.  With a reused sort the tables of the previous call are still valid.
-    uint32_t n_over = ln.last_n_over, SEG = ln.last_seg;
+    uint32_t n_over = ln.last_n_over, SEG = ln.last_seg, cap = ln.last_cap;
     size_t n_tasks = ln.last_n_tasks, n_obs = ln.last_n_obs, tb_al = ln.last_tb_al;
     if (!have_sort) {
         uint32_t *h_nover = (uint32_t *)ln.h_stage + 4;
@@ -696,7 +701,27 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
         FK_HIP(ctx, hipMemcpyAsync(h_nover, d_nover, 4, hipMemcpyDeviceToHost, st));
         FK_HIP(ctx, hipStreamSynchronize(st));
         n_over = *h_nover;
-        if (ctx->debug) { fprintf(stderr, "[fk] msm n=%zu c=%u (W=%u: %u x %u bits + %u x %u bits) cap=%u: %u oversized buckets\n", n, p.c, p.W, p.wide, p.cb + 1, p.W - p.wide, p.cb, p.cap, n_over); fflush(stderr); }
+        cap = p.cap;
+        // The cap assumes Poisson bucket loads.  Scalars with many repeated values (a batch witness) put tens of thousands of
+        // buckets a little over it, and one wave per such bucket is a poor trade: double the cap until few remain.
+        const uint32_t many = (uint32_t)std::max<size_t>(4096, WB / 64);
+        while (n_over > many && cap < (1u << 20)) {
+            cap *= 2;
+            FK_HIP(ctx, hipMemsetAsync(d_nover, 0, 4, st));
+            hipLaunchKernelGGL(msm_over_scan_kernel, dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, totals, WB, cap, ln.overlist.as<OverEntry>(), d_nover, over_cap);
+            FK_HIP(ctx, hipGetLastError());
+            FK_HIP(ctx, hipMemcpyAsync(h_nover, d_nover, 4, hipMemcpyDeviceToHost, st));
+            FK_HIP(ctx, hipStreamSynchronize(st));
+            n_over = *h_nover;
+        }
+        // size-ordered bucket -> lane assignment
+        FK_HIP(ctx, hipMemsetAsync(size_bins, 0, SIZE_BINS * 4, st));
+        hipLaunchKernelGGL(msm_size_hist_kernel, dim3((unsigned)std::min<size_t>((WB + 255) / 256, 1024)), dim3(256), 0, st, totals, WB, cap, size_bins);
+        hipLaunchKernelGGL(msm_size_scan_kernel, dim3(1), dim3(SIZE_BINS), 0, st, size_bins);
+        hipLaunchKernelGGL(msm_size_scatter_kernel, dim3((unsigned)((WB + 1023) / 1024)), dim3(1024), 0, st, totals, WB, cap, size_bins, perm);
+        FK_HIP(ctx, hipGetLastError());
+        FK_DBG_ST(ctx, st, "msm_size_order");
+        if (ctx->debug) { fprintf(stderr, "[fk] msm n=%zu c=%u (W=%u: %u x %u bits + %u x %u bits) cap=%u (plan %u): %u oversized buckets\n", n, p.c, p.W, p.wide, p.cb + 1, p.W - p.wide, p.cb, cap, p.cap, n_over); fflush(stderr); }
         if (n_over > over_cap) { ln.last_sort_scalars = nullptr; FK_SET_ERR(ctx, FK_ERR_HIP, "msm: %u oversized buckets exceed the bound %u", n_over, over_cap); }
         n_tasks = n_obs = tb_al = 0; SEG = SEG_MIN;
         if (n_over) {
@@ -709,10 +734,10 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
             // segment length: about two waves per SIMD over all oversized entries, so that a lone giant bucket (all the
             // scalars equal to 1 meet in one) is a few additions per lane instead of a 64-addition serial walk
             uint64_t extra_total = 0;
-            for (const OverEntry &e : ov) extra_total += e.size - ((e.g / p.B == p.W - 1) ? p.cap_top : p.cap);
+            for (const OverEntry &e : ov) extra_total += e.size - cap;
             SEG = (uint32_t)std::min<uint64_t>(SEG_MAX, std::max<uint64_t>(SEG_MIN, ((extra_total / 2048 + 63) / 64) * 64));
             for (const OverEntry &e : ov) {
-                const uint32_t cap_w = (e.g / p.B == p.W - 1) ? p.cap_top : p.cap;
+                const uint32_t cap_w = cap;
                 const uint32_t extra = e.size - cap_w;
                 const uint32_t nt = (extra + SEG - 1) / SEG;
                 obs.push_back(OverBucket{e.g, (uint32_t)tasks.size(), nt});
@@ -728,7 +753,7 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
             memcpy((char *)ln.h_stage + 64 + tb_al, obs.data(), ob);
             FK_HIP(ctx, hipMemcpyAsync(ln.tasktab.p, (char *)ln.h_stage + 64, tb_al + ob, hipMemcpyHostToDevice, st));
         }
-        ln.last_n_over = n_over; ln.last_seg = SEG; ln.last_n_tasks = n_tasks; ln.last_n_obs = n_obs; ln.last_tb_al = tb_al;
+        ln.last_n_over = n_over; ln.last_seg = SEG; ln.last_cap = cap; ln.last_n_tasks = n_tasks; ln.last_n_obs = n_obs; ln.last_tb_al = tb_al;
     }
     Task *d_tasks = ln.tasktab.as<Task>();
     OverBucket *d_obs = (OverBucket *)((char *)ln.tasktab.p + tb_al);
@@ -741,14 +766,14 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
     std::vector<EventPair> &evv = (sizeof(F) == sizeof(Fq)) ? ctx->ev_acc : ctx->ev_acc2;
     FK_TRY(stats_begin(ctx, evv, (uint64_t)n, st));
     hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_kernel<F, (sizeof(F) == sizeof(Fq) ? 4 : 2)>), dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, d_bases, sorted, n,
-                       starts, totals, p.B, p.W, p.cap, p.cap_top, perm, buckets);
+                       starts, totals, p.B, p.W, cap, cap, perm, buckets);
     FK_HIP(ctx, hipGetLastError());
     FK_TRY(stats_end(ctx, evv, st));
     FK_DBG_ST(ctx, st, "msm_accumulate");
     if (n_over) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_overflow_kernel<F, FC>), dim3((unsigned)n_tasks), dim3(64), 0, st,
                            d_bases, sorted, n, starts,
-                           totals, p.B, p.W, p.cap, p.cap_top, SEG, d_tasks, ln.partials.as<Xyzz<FC>>());
+                           totals, p.B, p.W, cap, cap, SEG, d_tasks, ln.partials.as<Xyzz<FC>>());
         FK_HIP(ctx, hipGetLastError());
         FK_DBG_ST(ctx, st, "msm_overflow");
         hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_overflow_fold_kernel<FC>), dim3((unsigned)n_obs), dim3(256), 0, st, d_obs,
