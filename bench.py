@@ -96,6 +96,75 @@ def build_workload(ctx, fk, log2n, seed=2026):
     return r1cs, z
 
 
+def build_workload_dense(ctx, fk, log2n, terms, seed=2026):
+    """Same size and witness mix as build_workload, but with LONG linear combinations, like the circuits fawkes-crypto
+    is used for (poseidon merkle: 26 matrix terms per gate, eddsa: 133): every product gate is
+    (sum of `terms` variables) * (sum of `terms` variables) = new variable, the operands drawn from the boolean and free
+    variables.  The new variables' values are computed with the library itself (device SpMV + batched products)."""
+    import torch
+    m = 1 << log2n
+    v_in = 2
+    G = m - v_in
+    nb = int(0.4 * G); nf = max(int(0.1 * G), 1); npr = G - nb - nf
+    v_aux = G
+    rng = np.random.default_rng(seed)
+    one, minus_one = mont(1), mont(-1)
+    z = np.zeros((v_in + v_aux, 4), np.uint64)
+    z[0] = one
+    z[1] = mont(0x5eed5eed5eed)
+    bits = rng.integers(0, 2, nb, dtype=np.uint8)
+    z[v_in:v_in + nb][bits == 1] = one
+    free = rng.integers(0, 1 << 63, size=(nf, 4), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=(nf, 4), dtype=np.uint64)
+    free[:, 3] &= np.uint64((1 << 60) - 1)
+    z[v_in + nb:v_in + nb + nf] = free
+    # boolean gates b*(b-1)=0 and linear gates as in build_workload; product gates with `terms` operands per side
+    src = v_in + rng.integers(0, nb + nf, size=(2, npr, terms), dtype=np.int64)          # operands: booleans and free values
+    a_col = np.concatenate([v_in + np.arange(nb, dtype=np.uint32), (v_in + nb + np.arange(nf)).astype(np.uint32), src[0].reshape(-1).astype(np.uint32)])
+    a_len = np.concatenate([np.ones(nb + nf, np.uint64), np.full(npr, terms, np.uint64)])
+    a_ptr = np.zeros(G + 1, np.uint64); a_ptr[1:] = np.cumsum(a_len)
+    b_len = np.concatenate([np.full(nb, 2, np.uint64), np.ones(nf, np.uint64), np.full(npr, terms, np.uint64)])
+    b_ptr = np.zeros(G + 1, np.uint64); b_ptr[1:] = np.cumsum(b_len)
+    b_col = np.zeros(int(b_ptr[-1]), np.uint32)
+    b_col[0:2 * nb:2] = v_in + np.arange(nb, dtype=np.uint32)
+    b_col[1:2 * nb:2] = 0
+    b_col[2 * nb:2 * nb + nf] = 0
+    b_col[2 * nb + nf:] = src[1].reshape(-1).astype(np.uint32)
+    del src
+    # B needs the coefficient -1 on the boolean gates only: dictionary of two values, everything else ONE
+    b_val = np.tile(one, (int(b_ptr[-1]), 1)) if terms * npr < (1 << 27) else None
+    if b_val is not None:
+        b_val[1:2 * nb:2] = minus_one
+    c_len = np.concatenate([np.zeros(nb, np.uint64), np.ones(nf + npr, np.uint64)])
+    c_ptr = np.zeros(G + 1, np.uint64); c_ptr[1:] = np.cumsum(c_len)
+    c_col = np.concatenate([(v_in + nb + np.arange(nf)).astype(np.uint32), (v_in + nb + nf + np.arange(npr)).astype(np.uint32)])
+    if b_val is None:
+        # too many terms for a 32-byte-per-term host array: express b*(b-1) as b*b = b instead (all coefficients ONE)
+        b_len = np.concatenate([np.ones(nb + nf, np.uint64), np.full(npr, terms, np.uint64)])
+        b_ptr = np.zeros(G + 1, np.uint64); b_ptr[1:] = np.cumsum(b_len)
+        b_col = np.concatenate([b_col[0:2 * nb:2], b_col[2 * nb:]])
+        c_len = np.ones(G, np.uint64)
+        c_ptr = np.zeros(G + 1, np.uint64); c_ptr[1:] = np.cumsum(c_len)
+        c_col = np.concatenate([v_in + np.arange(nb, dtype=np.uint32), c_col])
+    r1cs = fk.R1cs(v_in, v_aux, (a_ptr, a_col, None), (b_ptr, b_col, b_val), (c_ptr, c_col, None))
+    # product gates' outputs: c = (A z)(B z), evaluated by the device SpMV on the partial witness
+    dr = ctx.load_r1cs(r1cs)
+    dbuf = [ctx.dev_alloc(m * 32) for _ in range(3)]
+    d_z = ctx.dev_alloc(z.nbytes)
+    ctx.upload(d_z, z)
+    ctx.r1cs_eval_dev(dr, d_z, *dbuf)
+    lo = nb + nf
+    CH = 1 << 22
+    for off in range(0, npr, CH):
+        hi = min(off + CH, npr)
+        av = ctx.download(dbuf[0] + (lo + off) * 32, (hi - off) * 32, np.uint64).reshape(-1, 4)
+        bv = ctx.download(dbuf[1] + (lo + off) * 32, (hi - off) * 32, np.uint64).reshape(-1, 4)
+        z[v_in + lo + off:v_in + lo + hi] = ctx.fr_mul_batch(av, bv)
+    for p_ in dbuf + [d_z]:
+        ctx.dev_free(p_)
+    dr.free()
+    return r1cs, z
+
+
 def cpu_baseline_leg(ctx, fk, log2_sample, full):
     """(1) times the C oracle (bellman's algorithm restated, single thread = the reference's configured worker,
     SURVEY fact 3) proving a 2^log2_sample instance of the same workload family; (2) the GPU proof of that same
@@ -138,6 +207,8 @@ def pairing_check(vk_full, z_in1, proof):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--lc-terms', type=int, default=0, help='operands per side of every product gate (default: the 1-2 term rollup shape); '
+                                                             'e.g. 16 gives the long linear combinations real circuits have')
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--log2n', type=int, default=25, help='log2 of the row count handed to the prover')
@@ -178,7 +249,7 @@ def main():
     # ---------------------------------------------------------------- workload: constraint system, witness, valid key
     t_prep = time.time()
     m = 1 << args.log2n
-    r1cs, z = build_workload(ctx, fk, args.log2n)
+    r1cs, z = build_workload(ctx, fk, args.log2n) if args.lc_terms <= 1 else build_workload_dense(ctx, fk, args.log2n, args.lc_terms)
     v_in, v_aux, n = r1cs.num_input, r1cs.num_aux, r1cs.n_rows
     assert n == m
     dr = ctx.load_r1cs(r1cs)
@@ -284,7 +355,8 @@ def main():
                                    'device SpMV + 7-NTT quotient + G1 MSMs H/L/A/B1 + G2 MSM B2 + assembly; witness, constraint system '
                                    'and key resident in HBM' % args.log2n,
                        'log2_constraints': args.log2n, 'num_input': v_in, 'num_aux': v_aux,
-                       'gates': '40% boolean b*(b-1)=0, 10% linear, 50% products', 'nnz': list(info['nnz']),
+                       'gates': '40% boolean b*(b-1)=0, 10% linear, 50% products' + (' of %d-term sums' % args.lc_terms if args.lc_terms > 1 else ''),
+                       'nnz': list(info['nnz']),
                        'a_query_points': n_a, 'b_query_points': n_b,
                        'witness': '%.0f%% zeros, %.0f%% ones, rest dense 254-bit' % (100.0 * zeros / (v_in + v_aux), 100.0 * ones / (v_in + v_aux)),
                        'parallelism': 'msm-shard%d%s' % (world, '' if not multi else
