@@ -372,6 +372,8 @@ static int prove_msms_dev(fk_ctx *ctx, const fk_key *key, Fr *d_a, Fr *d_b, Fr *
     // measured (2^20 .. 2^25): both sides are VALU-bound, nothing is gained at 2^25 and 10 % is lost at 2^20 / 2^22.
     if (!ctx->ev_main) FK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_main, hipEventDisableTiming));
     FK_HIP(ctx, hipEventRecord(ctx->ev_main, ctx->stream));
+    // H first: it is the longest accumulation and hides the sorts of the multiplications behind it (B1, B2, H, L, A -- H after
+    // the B pair, so that only B1's smaller sort is exposed -- measured 3 % slower at 2^25 and 13 % slower at 2^22)
     int t_h = -1;
     FK_TRY(msm_g1_begin(ctx, key->d_h, d_h + key->h_lo, key->h_hi - key->h_lo, &t_h, ctx->ev_main));
     const int rc = witness_begin(ctx, key, d_z, d_a_aux, d_b_in, d_b_aux, ctx->ev_main);
