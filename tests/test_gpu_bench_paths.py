@@ -1,0 +1,43 @@
+"""bench.py end to end at a small size (subprocesses): the default single-GPU path with its cpu_baseline leg, and the
+multi-GPU code path rehearsed with ONE rank over real RCCL (FK_BENCH_REHEARSE=1: process group 'nccl', all_to_all_single /
+all_gather on device tensors, distributed quotient and balanced schedule)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra_env, *args):
+    env = dict(os.environ, **extra_env)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1', *args],
+                         env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_default_path_small():
+    j = _run({}, '--log2n', '14', '--cpu-log2n', '12')
+    assert j['unit'] == 'proofs/s' and j['n_gpus'] == 1 and j['value'] > 0 and j['proof_verified_by_pairing_check'] is True
+    assert j['roofline']['bound'] == 'hbm' and 0 < j['roofline']['frac'] < 1 and j['cpu_baseline']['kind'] == 'port' and j['cpu_baseline']['cores'] == 1
+    assert j['config']['workload'] and 'model' not in j['config']
+
+
+@pytest.mark.parametrize('dist_q', ['1', '0'])
+def test_bench_multi_gpu_path_rehearsed_over_rccl(dist_q):
+    env = {'FK_BENCH_REHEARSE': '1', 'FK_DIST_QUOTIENT': dist_q, 'RANK': '0', 'WORLD_SIZE': '1', 'LOCAL_RANK': '0',
+           'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': '29541'}
+    j = _run(env, '--log2n', '14')
+    assert j['proof_verified_by_pairing_check'] is True
+    assert ('distributed-quotient' in j['config']['parallelism']) == (dist_q == '1')
+
+
+def test_bench_long_linear_combinations():
+    j = _run({}, '--log2n', '14', '--lc-terms', '8', '--cpu-log2n', '12')
+    assert j['proof_verified_by_pairing_check'] is True and j['config']['nnz'][0] > 4 * (1 << 14) * 0.4
