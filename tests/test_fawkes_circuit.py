@@ -197,3 +197,18 @@ def test_tiled_batch_is_satisfied_by_tiled_witness(oracle):
 def _ints(arr):
     import c_oracle as co
     return [ref.from_mont(x, ref.R) for x in co.ints(arr)]
+
+
+def test_eddsa_golden_matches_oracle(oracle):
+    g = golden('eddsa_golden.json')
+    cs, (s, r_x, a_x) = fc.eddsa_circuit(int(g['sk'], 16), int(g['m'], 16), int(g['rho'], 16))
+    assert ('%064x' % s, '%064x' % r_x, '%064x' % a_x) == (g['signature']['s'], g['signature']['r_x'], g['signature']['a_x'])
+    assert hashlib.sha256(bytes(cs.const_tracker)).hexdigest() == g['const_tracker_sha256']
+    csr = fx.r1cs_to_csr(cs.r1cs())
+    key = oracle.setup(csr, **TOXIC)
+    z = fx.witness_mont(cs.z_in, cs.z_aux)
+    a, b, c, aa, bi, ba = oracle.synthesize(csr, z)
+    assert int(aa.sum()) == g['a_aux_density'] and int(ba.sum()) == g['b_aux_density']
+    proof = oracle.prove(key, a, b, c, z, aa, bi, ba, fx.mont_fr(int(g['r'], 16)), fx.mont_fr(int(g['s'], 16)))
+    assert proof.tobytes().hex() == g['proof']
+    assert ref.verify(fx.key_to_py(key), [int(g['m'], 16)], ref.proof_from_borsh(proof.tobytes()))

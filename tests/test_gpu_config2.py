@@ -47,6 +47,20 @@ def test_one_signature(ctx, oracle, signatures):
     _prove_and_check(ctx, oracle, csr, fx.witness_mont(cs.z_in, cs.z_aux), cs.z_in[1:])
 
 
+def test_golden_signature_proof(ctx):
+    """the committed golden vector (tests/golden/eddsa_golden.json): GPU setup + proof bytes for a fixed signature and fixed (r, s)"""
+    from helpers import golden
+    g = golden('eddsa_golden.json')
+    cs, (s_, r_x, a_x) = fc.eddsa_circuit(int(g['sk'], 16), int(g['m'], 16), int(g['rho'], 16))
+    assert '%064x' % r_x == g['signature']['r_x'] and len(cs.gates) == g['num_gates']
+    r1cs = r1cs_product(fx.r1cs_to_csr(cs.r1cs()))
+    dk, _ = ctx.setup(r1cs, **{k: fx.mont_fr(v) for k, v in TOXIC.items()})
+    dr = ctx.load_r1cs(r1cs)
+    got = ctx.prove_witness(dk, dr, fx.witness_mont(cs.z_in, cs.z_aux), fx.mont_fr(int(g['r'], 16)), fx.mont_fr(int(g['s'], 16)))
+    assert got.tobytes().hex() == g['proof']
+    dr.free(); dk.free()
+
+
 def test_batch_of_16_signatures_as_one_system(ctx, oracle, signatures):
     one = fx.r1cs_to_csr(signatures[0].r1cs())
     copies = 16
