@@ -32,7 +32,7 @@ struct NttDomain;
 
 struct EventPair { hipEvent_t a, b; uint64_t units; };
 
-// Multi-scalar multiplications run on two independent "lanes" (stream + private scratch) used in turn, so that the
+// Multi-scalar multiplications run on MSM_LANES independent "lanes" (stream + private scratch) used in turn, so that the
 // memory-bound digit sort of multiplication k+1 and the latency-bound overflow / bucket-reduction kernels of
 // multiplication k run underneath the VALU-bound bucket accumulation of the other lane (msm.hip).
 struct MsmLane {
@@ -56,6 +56,7 @@ struct MsmTail {
     DevBuf d_wp;
 };
 static constexpr int MSM_TAILS = 8;
+static constexpr int MSM_LANES = 3;   // a third lane keeps a multiplication from queueing behind the long G2 tail (msm.hip)
 
 // Which variables feed the A and the B query, as index lists (they are structural: a resident constraint system
 // computes them once at load).  With them the per-proof scalar compaction is one gather per query, no host round trip.
@@ -75,8 +76,9 @@ struct fk_ctx {
     unsigned ntt_threads = 512;  // workgroup size cap of the NTT pass kernel (FK_NTT_THREADS overrides)
     std::map<uint32_t, fk::NttDomain *> domains;
     // MSM: two lanes used in turn, one record per outstanding multiplication
-    fk::MsmLane lanes[2];
+    fk::MsmLane lanes[fk::MSM_LANES];
     int lane_next = 0, lane_prev = 0;
+    int lanes_in_use = fk::MSM_LANES;   // the provers use 2 for the largest domains (measured, prover.hip)
     fk::MsmTail tails[fk::MSM_TAILS];
     fk::DevBuf misc;
     // witness multiplications (L, A, B1, B2) in flight: begun before / while the quotient runs on the main stream

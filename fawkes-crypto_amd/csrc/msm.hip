@@ -608,13 +608,15 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
     MsmTail &tl = ctx->tails[ti];
     if (!tl.done) FK_HIP(ctx, hipEventCreateWithFlags(&tl.done, hipEventDisableTiming));
     const MsmPlan p = make_plan(n, ctx->window_bits);
-    // lane: the other one than last time, unless this call reuses the previous call's sort (B2 after B1)
+    // lane: the next one in turn, unless this call reuses the previous call's sort (B2 after B1).  With three lanes the
+    // multiplication after the G2 one does not queue behind its long overflow / reduction tail (at 2^22 that tail was 5.4 ms
+    // during which nothing else ran: 31 % of the proof).
     MsmLane &prev = ctx->lanes[ctx->lane_prev];
     const bool have_sort = reuse_sort && prev.st && prev.last_sort_scalars == (const void *)d_scalars && prev.last_sort_n == n && prev.last_sort_c == p.c;
     const int li = have_sort ? ctx->lane_prev : ctx->lane_next;
     MsmLane &ln = ctx->lanes[li];
     FK_TRY(lane_init(ctx, ln));
-    ctx->lane_prev = li; ctx->lane_next = li ^ 1;
+    ctx->lane_prev = li; ctx->lane_next = (li + 1) % (ctx->lanes_in_use >= 2 && ctx->lanes_in_use <= MSM_LANES ? ctx->lanes_in_use : MSM_LANES);
     hipStream_t st = ln.st;
     if (ready) {
         FK_HIP(ctx, hipStreamWaitEvent(st, ready, 0));

@@ -276,6 +276,12 @@ static int witness_begin(fk_ctx *ctx, const fk_key *key, const Fr *d_z, const ui
                          const uint8_t *d_b_aux, hipEvent_t z_ready) {
     if (!key || !d_z) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "prove: null argument");
     if (ctx->wit_active) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "prove: witness multiplications already in flight");
+    bool any_tail = false;
+    for (int i = 0; i < MSM_TAILS; i++) any_tail = any_tail || ctx->tails[i].active;
+    if (!any_tail) ctx->lane_next = 0;      // nothing outstanding: start the rotation over (same lanes in every proof)
+    // Three lanes keep A from queueing behind B2's long G2 tail: 2^20 14.9 -> 13.3 ms, 2^22 28.0 -> 25.6 ms per proof.  At
+    // 2^25 the tails are short next to the accumulations and the third lane's extra co-running costs 1 %: two lanes there.
+    ctx->lanes_in_use = (key->h_hi - key->h_lo) + 1 >= ((uint64_t)1 << 25) ? 2 : MSM_LANES;      // this shard's H size
     FK_HIP(ctx, hipSetDevice(ctx->device));
     if (!ctx->aux) {
         FK_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
@@ -366,6 +372,8 @@ static int prove_msms_dev(fk_ctx *ctx, const fk_key *key, Fr *d_a, Fr *d_b, Fr *
     FK_HIP(ctx, ctx->hbuf.reserve(key->m * sizeof(Fr)));
     Fr *d_h = ctx->hbuf.as<Fr>();
     uint64_t m = 0;
+    ctx->lane_next = 0;     // same lane for the same multiplication in every proof: lane buffers keep their sizes
+    ctx->lanes_in_use = (key->h_hi - key->h_lo) + 1 >= ((uint64_t)1 << 25) ? 2 : MSM_LANES;      // this shard's H size
     FK_TRY(quotient_dev(ctx, d_a, d_b, d_c, n, d_h, &m));          // queued on the main stream, not waited for
     const double t1 = now_ms();
     // Single GPU: the multiplications start after the quotient.  Running the witness multiplications underneath it was
