@@ -5,20 +5,24 @@
 // /root/reference/fawkes-crypto/src/backend/bellman_groth16/prover.rs:80).  Any correct MSM yields the
 // same group element, so the result is bit-identical to bellman's after `into_affine`.
 //
-// MI355X pipeline (all on one stream, no MFMA -- 256-bit modular integer work):
-//   1. msm_digits      scalars leave Montgomery form (bellman's `into_repr`) and are cut into W signed
-//                      c-bit digits (buckets 1..2^(c-1), sign bit) -- halves the bucket count.
+// MI355X pipeline (no MFMA -- 256-bit modular integer work).  A multiplication is queued completely on one of
+// MSM_LANES lanes (stream + private scratch); consecutive multiplications use different lanes, so the latency-bound
+// steps 4-5 of one run underneath steps 1-3 of the next (msm_*_begin / msm_*_end):
+//   1. msm_digits      scalars leave Montgomery form (bellman's `into_repr`) and are cut into W signed digits; the 255
+//                      bits are split evenly into windows of cb or cb + 1 bits (no short top window).
 //   2. bucket sort     two-pass radix sort on the bucket index (high bits, then the low 10 bits inside each
 //                      segment): LDS histograms and cursors, every tile ranked and staged in LDS and written as
 //                      contiguous runs.  No global atomics, so skewed witness scalars (many 0/1) cost nothing extra.
+//                      The host reads back the tile count and, at the end, the list of oversized buckets.
 //   2b. size order     buckets are counting-sorted by length so the 64 lanes of a wave run equally long.
 //   3. msm_accumulate  one lane per bucket walks its run with XYZZ mixed additions (8M+2S), gathering
-//                      64-byte affine bases; buckets above `cap` entries hand the excess to
-//   4. msm_overflow    one wave per fixed 4096-entry segment, reduced with wavefront shuffles; then one
-//                      wave per oversized bucket folds the partials.
+//                      64-byte affine bases; buckets above `cap` = mean + 6 sigma + 8 entries hand the excess to
+//   4. msm_overflow    one wave per segment (sized so that all oversized entries give ~2 waves per SIMD), reduced with
+//                      wavefront shuffles; then 256 lanes per oversized bucket fold the partials.
 //   5. msm_bucket_reduce  sum_b b*S_b per window: each lane runs the running-sum trick over L buckets,
-//                      adds its offset multiple by double-and-add, then wave64 shuffle + LDS reduction.
-//   6. host            W window sums are Horner-combined (c doublings each) -- microseconds.
+//                      adds its offset multiple by double-and-add, then wave64 shuffle + LDS reduction; the window
+//                      sums are copied to pinned host memory.
+//   6. host            W window sums are Horner-combined (cw doublings each) -- microseconds.
 #include "common.hpp"
 #include <algorithm>
 #include <string.h>
