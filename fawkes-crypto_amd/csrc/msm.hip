@@ -104,21 +104,34 @@ static MsmPlan make_plan(size_t n, unsigned forced_c) {
 // Signed digits over W windows that split the 255 bits (254-bit scalar + recoding carry) as evenly as possible: the
 // first `wide` windows are cb + 1 bits, the rest cb bits.  A uniform width would leave a short top window (14 bits at
 // c = 20) whose few buckets each receive thousands of entries and all have to go through the oversized-bucket path.
-__global__ void msm_digits_kernel(const Fr *scalars, size_t n, uint32_t cb, uint32_t wide, uint32_t W, uint32_t *digits) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    Fr s = Fr::from_mont(scalars[i]);   // canonical integer, 254 bits
-    uint32_t carry = 0;
-    for (uint32_t w = 0; w < W; w++) {
-        const uint32_t cw = cb + (w < wide ? 1 : 0);
-        const uint32_t o = w * cb + (w < wide ? w : wide), limb = o >> 5, sh = o & 31;
-        const uint32_t B = 1u << (cw - 1), mask = (1u << cw) - 1;
-        uint32_t lo = limb < 8 ? s.v[limb] : 0, hi = limb + 1 < 8 ? s.v[limb + 1] : 0;
-        uint32_t raw = (uint32_t)((((uint64_t)hi << 32) | lo) >> sh) & mask;
-        raw += carry;
-        uint32_t d, neg;
-        if (raw > B) { d = (1u << cw) - raw; neg = 1; carry = 1; } else { d = raw; neg = 0; carry = 0; }
-        digits[(size_t)w * n + i] = d | (neg << 31);
+// Two scalars per lane, both loaded before either is processed: the kernel usually runs underneath another lane's
+// accumulation with a single wave per SIMD, where bytes in flight per wave are what its speed depends on.
+__global__ __launch_bounds__(256) void msm_digits_kernel(const Fr *scalars, size_t n, uint32_t cb, uint32_t wide, uint32_t W, uint32_t *digits) {
+    const size_t half = (n + 1) / 2;
+    const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i0 >= half) return;
+    const size_t i1 = i0 + half;
+    const bool has1 = i1 < n;
+    Fr in[2];
+    in[0] = scalars[i0];
+    in[1] = scalars[has1 ? i1 : i0];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        if (u == 1 && !has1) break;
+        const size_t i = u ? i1 : i0;
+        Fr s = Fr::from_mont(in[u]);   // canonical integer, 254 bits
+        uint32_t carry = 0;
+        for (uint32_t w = 0; w < W; w++) {
+            const uint32_t cw = cb + (w < wide ? 1 : 0);
+            const uint32_t o = w * cb + (w < wide ? w : wide), limb = o >> 5, sh = o & 31;
+            const uint32_t B = 1u << (cw - 1), mask = (1u << cw) - 1;
+            uint32_t lo = limb < 8 ? s.v[limb] : 0, hi = limb + 1 < 8 ? s.v[limb + 1] : 0;
+            uint32_t raw = (uint32_t)((((uint64_t)hi << 32) | lo) >> sh) & mask;
+            raw += carry;
+            uint32_t d, neg;
+            if (raw > B) { d = (1u << cw) - raw; neg = 1; carry = 1; } else { d = raw; neg = 0; carry = 0; }
+            digits[(size_t)w * n + i] = d | (neg << 31);
+        }
     }
 }
 
@@ -138,9 +151,12 @@ __global__ __launch_bounds__(SORT_THREADS) void s2_hist1_kernel(const uint32_t *
     __syncthreads();
     const size_t lo = (size_t)ch * chunk, hi = lo + chunk < n ? lo + chunk : n;
     const uint32_t *dg = digits + (size_t)w * n;
-    for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        const uint32_t d = dg[i] & 0x7fffffffu;
-        if (d) atomicAdd(&hist[(d - 1) >> LB], 1u);
+    for (size_t i = lo + threadIdx.x; i < hi; i += (size_t)blockDim.x * 8) {     // eight independent loads in flight per lane
+        uint32_t d[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const size_t k = i + (size_t)u * blockDim.x; d[u] = k < hi ? (dg[k] & 0x7fffffffu) : 0; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) if (d[u]) atomicAdd(&hist[(d[u] - 1) >> LB], 1u);
     }
     __syncthreads();
     uint32_t *out = cnt1 + ((size_t)w * nchunks + ch) * nhi;
@@ -664,7 +680,7 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
 
     if (!have_sort) {
         ln.last_sort_scalars = nullptr;
-        hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, p.cb, p.wide, p.W, digits);
+        hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)(((n + 1) / 2 + 255) / 256)), dim3(256), 0, st, d_scalars, n, p.cb, p.wide, p.W, digits);
         FK_HIP(ctx, hipGetLastError());
         FK_DBG_ST(ctx, st, "msm_digits");
         FK_HIP(ctx, hipMemsetAsync(d_nover, 0, 4, st));
