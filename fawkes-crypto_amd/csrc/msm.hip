@@ -30,7 +30,7 @@
 namespace fk {
 
 static constexpr uint32_t SEG_MAX = 4096, SEG_MIN = 256;   // overflow segment (entries) per wave: 4..64 per lane, sized per call
-static constexpr uint32_t SORT_THREADS = 1024;
+static constexpr uint32_t SORT_THREADS = 256;     // first-pass histogram: small workgroups are placed more easily underneath an accumulation (profiles/r01_corun_experiment.log)
 
 struct MsmPlan {
     size_t n;
@@ -680,7 +680,7 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
 
     if (!have_sort) {
         ln.last_sort_scalars = nullptr;
-        hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)(((n + 1) / 2 + 255) / 256)), dim3(256), 0, st, d_scalars, n, p.cb, p.wide, p.W, digits);
+        hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)(((n + 1) / 2 + 63) / 64)), dim3(64), 0, st, d_scalars, n, p.cb, p.wide, p.W, digits);
         FK_HIP(ctx, hipGetLastError());
         FK_DBG_ST(ctx, st, "msm_digits");
         FK_HIP(ctx, hipMemsetAsync(d_nover, 0, 4, st));
@@ -1037,7 +1037,7 @@ __global__ __launch_bounds__(256) void gather_scalars_kernel(const Fr *z, const 
 
 int gather_scalars(fk_ctx *ctx, const Fr *d_z, const uint32_t *d_idx, size_t n, Fr *d_out, hipStream_t st) {
     if (!n) return FK_OK;
-    hipLaunchKernelGGL(gather_scalars_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_z, d_idx, n, d_out);
+    hipLaunchKernelGGL(gather_scalars_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, d_z, d_idx, n, d_out);
     FK_HIP(ctx, hipGetLastError());
     return FK_OK;
 }

@@ -70,5 +70,19 @@ int main() {
     run(stream_hist<8>, 256, 4096, "8 loads/lane");
     run(stream_hist<16>, 256, 2048, "16 loads/lane");
     run(stream_hist<8>, 64, 16384, "8 loads/lane");
+    {   // two streaming kernels on two streams underneath the heavy kernel: fixed pool of leftover capacity, or per-queue trickle?
+        hipStream_t sc; CK(hipStreamCreateWithFlags(&sc, hipStreamNonBlocking));
+        hipEvent_t c0, c1; CK(hipEventCreate(&c0)); CK(hipEventCreate(&c1));
+        uint32_t *din2; CK(hipMalloc(&din2, n * 4)); CK(hipMemset(din2, 2, n * 4));
+        for (int wg : {64, 256, 1024}) {
+            const int grid = (int)(1024 * 1024 / wg);
+            hipEventRecord(a0, sa); hipLaunchKernelGGL(heavy, dim3(hb), dim3(ht), 0, sa, qin, qout, 1500); hipEventRecord(a1, sa);
+            hipEventRecord(e0, sb); hipLaunchKernelGGL(stream_hist<8>, dim3(grid), dim3(wg), 0, sb, din, n, dout); hipEventRecord(e1, sb);
+            hipEventRecord(c0, sc); hipLaunchKernelGGL(stream_hist<8>, dim3(grid), dim3(wg), 0, sc, din2, n, dout); hipEventRecord(c1, sc);
+            hipEventSynchronize(e1); hipEventSynchronize(c1); hipEventSynchronize(a1);
+            float t1, t2, hv; hipEventElapsedTime(&t1, e0, e1); hipEventElapsedTime(&t2, c0, c1); hipEventElapsedTime(&hv, a0, a1);
+            printf("two streaming kernels (wg %d) under the heavy kernel: %.2f ms and %.2f ms (heavy %.1f ms)\n", wg, t1, t2, hv);
+        }
+    }
     return 0;
 }
