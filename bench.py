@@ -212,7 +212,7 @@ def main():
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--log2n', type=int, default=25, help='log2 of the row count handed to the prover')
-    ap.add_argument('--cpu-log2n', type=int, default=18, help='size of the CPU-baseline sample instance')
+    ap.add_argument('--cpu-log2n', type=int, default=20, help='size of the CPU-baseline sample instance')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend ('nccl' = RCCL; 'gloo' only for single-GPU dry runs of the N>1 code path with FK_BENCH_SAME_DEVICE=1)")
     args = ap.parse_args()
