@@ -18,6 +18,10 @@ namespace fk {
 
 int stats_begin(fk_ctx *ctx, std::vector<EventPair> &v, uint64_t units, hipStream_t st) {
     if (!ctx->stats_on) return FK_OK;
+    if (v.size() >= 4096) {      // nobody is reading the statistics: recycle the events instead of growing without bound
+        for (auto &old : v) { ctx->ev_pool.push_back(old.a); ctx->ev_pool.push_back(old.b); }
+        v.clear();
+    }
     EventPair ep{};
     ep.units = units;
     for (hipEvent_t *e : {&ep.a, &ep.b}) {
