@@ -798,13 +798,13 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
                            totals, p.B, p.W, cap, cap, SEG, d_tasks, ln.partials.as<Xyzz<FC>>());
         FK_HIP(ctx, hipGetLastError());
         FK_DBG_ST(ctx, st, "msm_overflow");
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_overflow_fold_kernel<FC>), dim3((unsigned)n_obs), dim3(256), 0, st, d_obs,
-                           ln.partials.as<Xyzz<FC>>(), reinterpret_cast<Xyzz<FC> *>(buckets));
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_overflow_fold_kernel<F>), dim3((unsigned)n_obs), dim3(256), 0, st, d_obs,
+                           ln.partials.as<Xyzz<F>>(), buckets);
         FK_HIP(ctx, hipGetLastError());
         FK_DBG_ST(ctx, st, "msm_overflow_fold");
     }
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_bucket_reduce_kernel<FC>), dim3(p.nblk, p.W), dim3(256), 0, st,
-                       reinterpret_cast<const Xyzz<FC> *>(buckets), p.B, p.L, p.T, p.nblk, reinterpret_cast<Xyzz<FC> *>(winparts));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_bucket_reduce_kernel<F>), dim3(p.nblk, p.W), dim3(256), 0, st,
+                       buckets, p.B, p.L, p.T, p.nblk, winparts);
     FK_HIP(ctx, hipGetLastError());
     FK_HIP(ctx, hipMemcpyAsync(tl.h_wp, winparts, wp_bytes, hipMemcpyDeviceToHost, st));
     FK_HIP(ctx, hipEventRecord(tl.done, st));
