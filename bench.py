@@ -381,7 +381,7 @@ def main():
             },
             'prep_seconds': prep_s,
         }
-        if z_host is not None:
+        if z_host is not None and not args.no_cpu_baseline:
             # not `value`: the same proof with the witness handed over in HOST memory (fk_prove_r1cs: one H2D copy of the
             # witness, (num_input + num_aux) * 32 bytes, inside the call)
             ctx.prove_witness(key, dr, z_host, r, s)

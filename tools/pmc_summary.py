@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarises rocprofv3 --pmc counter_collection CSVs (one directory per pass) into the JSON files under profiles/.
 
-    python tools/pmc_summary.py traffic  <fetch_dir> <write_dir> <log2n> <points_per_proof> <out.json>
+    python tools/pmc_summary.py traffic  <fetch_dir> <write_dir> <log2n> <points_per_proof> <out.json> [proofs in the pass]
     python tools/pmc_summary.py valu     <sq_dir> <derived_dir> <out.json>
 
 FETCH_SIZE / WRITE_SIZE are in KB (x1024 = bytes).  FETCH_SIZE of wide coalesced streams under-reports by 2x on gfx950
@@ -41,7 +41,7 @@ def per_kernel(rows):
     return agg, {k: len(v) for k, v in disp.items()}
 
 
-def traffic(fetch_dir, write_dir, log2n, points, out):
+def traffic(fetch_dir, write_dir, log2n, points, out, proofs=1):
     fa, fl = per_kernel(load(fetch_dir))
     wa, _ = per_kernel(load(write_dir))
     ks = sorted(fa, key=lambda k: -(fa[k]['FETCH_SIZE'] + wa.get(k, {}).get('WRITE_SIZE', 0)))
@@ -49,11 +49,12 @@ def traffic(fetch_dir, write_dir, log2n, points, out):
     dom = next(k for k in ks if k.startswith('msm_accumulate_kernel<Fp<FqParams'))
     j = dict(
         _doc='rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python3 bench.py --steps 1 --warmup 0 '
-             '--no-cpu-baseline` (2^%d rows, 1 proof).  Counter units: KB (x1024 = bytes), summed over launches.' % log2n,
+             '--no-cpu-baseline` (2^%d rows).  Counter units: KB (x1024 = bytes), summed over the launches of the whole pass (per_kernel); '
+             'dominant_kernel is per proof.' % log2n,
         log2n=log2n, per_kernel=per,
         dominant_kernel=dict(
-            name='msm_accumulate_kernel<Fq>', launches_per_proof=fl[dom], points_per_proof=points,
-            fetch_bytes_per_proof_raw=fa[dom]['FETCH_SIZE'] * 1024, write_bytes_per_proof=wa[dom]['WRITE_SIZE'] * 1024,
+            name='msm_accumulate_kernel<Fq>', launches_per_proof=fl[dom] // proofs, points_per_proof=points, proofs_in_the_pass=proofs,
+            fetch_bytes_per_proof_raw=fa[dom]['FETCH_SIZE'] * 1024 / proofs, write_bytes_per_proof=wa[dom]['WRITE_SIZE'] * 1024 / proofs,
             note='WRITE_SIZE is exact (W*B XYZZ buckets of 128 B per launch).  FETCH_SIZE is reported RAW: the guide\'s x2 gfx950 '
                  'correction is calibrated for wide coalesced streams (it holds for ntt_pass_kernel in this same pass), while this '
                  'kernel gathers 64-byte points at random 64-B-aligned addresses -- an uncalibrated width.  Expected demand: 13 windows x '
@@ -87,6 +88,6 @@ def valu(sq_dir, derived_dir, out):
 
 if __name__ == '__main__':
     if sys.argv[1] == 'traffic':
-        traffic(sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), sys.argv[6])
+        traffic(sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), sys.argv[6], int(sys.argv[7]) if len(sys.argv) > 7 else 1)
     else:
         valu(sys.argv[2], sys.argv[3], sys.argv[4])
