@@ -34,7 +34,7 @@ EXPORTED_SYMBOLS = [
     'fk_gen_points_g1_dev', 'fk_gen_points_g2_dev', 'fk_gen_scalars_dev',
     'fk_synthesize', 'fk_stats_reset', 'fk_stats_get', 'fk_shard_range', 'fk_h_shard_range',
     'fk_dq_gather_dev', 'fk_dq_local_dev', 'fk_dq_cross_dev',
-    'fk_setup', 'fk_key_download', 'fk_key_load_bellman', 'fk_key_vk', 'fk_key_counts',
+    'fk_setup', 'fk_setup_tiled', 'fk_r1cs_load_tiled', 'fk_key_download', 'fk_key_load_bellman', 'fk_key_vk', 'fk_key_counts',
     'fk_r1cs_load', 'fk_r1cs_free', 'fk_r1cs_info', 'fk_r1cs_density_ptrs', 'fk_r1cs_eval_dev', 'fk_prove_r1cs', 'fk_prove_r1cs_dev',
 ]
 
@@ -593,24 +593,33 @@ class Context:
                                               C.byref(n_ic)))
         return DeviceKey(self, h, shard_index, shard_count), gamma, ic[:min(n_ic.value, cap)].copy()
 
-    def setup(self, r1cs, tau, alpha, beta, gamma, delta, shard_index=0, shard_count=1, z_frac=(0.0, 0.0)):
+    def setup(self, r1cs, tau, alpha, beta, gamma, delta, shard_index=0, shard_count=1, z_frac=(0.0, 0.0), copies=None):
         """fk_setup: GPU key generation with explicit toxic waste (Montgomery limbs).  Returns (DeviceKey, vk dict)
-        with vk = alpha_g1, beta_g1, beta_g2, gamma_g2, delta_g1, delta_g2 (raw LE uint8 arrays) and ic (num_input, 64)."""
+        with vk = alpha_g1, beta_g1, beta_g2, gamma_g2, delta_g1, delta_g2 (raw LE uint8 arrays) and ic (num_input, 64).
+        copies: fk_setup_tiled -- r1cs is one instance of a batch circuit, the key is for `copies` of it."""
         h = C.c_void_p()
         vk = np.zeros(6 * 128, np.uint8)
-        ic = np.zeros((r1cs.num_input, 64), np.uint8)
-        self._ck(self.lib.fk_setup(self.handle, C.byref(r1cs.struct), _vp(_fr(tau, 1)), _vp(_fr(alpha, 1)), _vp(_fr(beta, 1)),
-                                   _vp(_fr(gamma, 1)), _vp(_fr(delta, 1)), C.c_uint32(shard_index), C.c_uint32(shard_count),
-                                   C.c_double(z_frac[0]), C.c_double(z_frac[1]), C.byref(h), _vp(vk), _vp(ic)))
+        tail = (_vp(_fr(tau, 1)), _vp(_fr(alpha, 1)), _vp(_fr(beta, 1)), _vp(_fr(gamma, 1)), _vp(_fr(delta, 1)), C.c_uint32(shard_index),
+                C.c_uint32(shard_count), C.c_double(z_frac[0]), C.c_double(z_frac[1]), C.byref(h), _vp(vk))
+        if copies is None:
+            ic = np.zeros((r1cs.num_input, 64), np.uint8)
+            self._ck(self.lib.fk_setup(self.handle, C.byref(r1cs.struct), *tail, _vp(ic)))
+        else:
+            ic = np.zeros((1 + int(copies) * (r1cs.num_input - 1), 64), np.uint8)
+            self._ck(self.lib.fk_setup_tiled(self.handle, C.byref(r1cs.struct), C.c_uint32(int(copies)), *tail, _vp(ic)))
         names = (('alpha_g1', 64), ('beta_g1', 64), ('beta_g2', 128), ('gamma_g2', 128), ('delta_g1', 64), ('delta_g2', 128))
         out = {n: vk[i * 128:i * 128 + w].copy() for i, (n, w) in enumerate(names)}
         out['ic'] = ic
         return DeviceKey(self, h, shard_index, shard_count), out
 
     # ---- device-resident constraint system: only the witness crosses the boundary
-    def load_r1cs(self, r1cs):
+    def load_r1cs(self, r1cs, copies=None):
+        """copies: fk_r1cs_load_tiled -- r1cs is one instance, the resident system stands for `copies` of it"""
         h = C.c_void_p()
-        self._ck(self.lib.fk_r1cs_load(self.handle, C.byref(r1cs.struct), C.byref(h)))
+        if copies is None:
+            self._ck(self.lib.fk_r1cs_load(self.handle, C.byref(r1cs.struct), C.byref(h)))
+        else:
+            self._ck(self.lib.fk_r1cs_load_tiled(self.handle, C.byref(r1cs.struct), C.c_uint32(int(copies)), C.byref(h)))
         return DeviceR1cs(self, h)
 
     def r1cs_eval_dev(self, dr, d_z, d_a, d_b, d_c):

@@ -51,6 +51,43 @@ __global__ __launch_bounds__(256) void csc_eval_kernel(CscArgs a, const Fr *tabl
     a.out[mtx][v] = acc;
 }
 
+// Batch circuits (fk_setup_tiled): the CSC describes ONE instance and the system is `copies` of it, copy j's gates being
+// rows [j*base_gates, (j+1)*base_gates).  sc[mtx][j*nvb + v] = sum over instance column v of table[cidx] * lag[j*base_gates + row];
+// tile_assemble_kernel then lays the values out in the batch's variable order (ONE shared -> the sum over the copies).
+__global__ __launch_bounds__(256) void csc_eval_tiled_kernel(CscArgs a, const Fr *table, const Fr *lag, uint32_t base_gates, uint32_t nvb) {
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x, mtx = blockIdx.y, copy = blockIdx.z;
+    if (v >= nvb) return;
+    const Fr *lg = lag + (uint64_t)copy * base_gates;
+    Fr acc = Fr::zero();
+    for (uint64_t k = a.ptr[mtx][v], e = a.ptr[mtx][v + 1]; k < e; k++) {
+        Fr t = lg[a.row[mtx][k]];
+        const uint32_t ci = a.cidx[mtx][k];
+        if (ci) t = Fr::mul(t, table[ci]);
+        acc = Fr::add(acc, t);
+    }
+    a.out[mtx][(uint64_t)copy * nvb + v] = acc;
+}
+struct TileAsm { const Fr *sc[3]; Fr *out[3]; };
+__global__ __launch_bounds__(256) void tile_assemble_kernel(TileAsm a, const Fr *lag, uint32_t base_input, uint32_t base_aux, uint32_t copies, uint64_t num_gates,
+                                                            uint32_t num_input, uint64_t nv) {
+    const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t mtx = blockIdx.y, nvb = base_input + base_aux;
+    if (v >= nv) return;
+    Fr acc;
+    if (v == 0) {
+        acc = Fr::zero();
+        for (uint32_t j = 0; j < copies; j++) acc = Fr::add(acc, a.sc[mtx][(uint64_t)j * nvb]);
+    } else if (v < num_input) {
+        const uint32_t j = (uint32_t)(v - 1) / (base_input - 1), i = 1 + (uint32_t)(v - 1) % (base_input - 1);
+        acc = a.sc[mtx][(uint64_t)j * nvb + i];
+    } else {
+        const uint32_t q = (uint32_t)(v - num_input), j = q / base_aux, i = q % base_aux;
+        acc = a.sc[mtx][(uint64_t)j * nvb + base_input + i];
+    }
+    if (mtx == 0 && v < num_input) acc = Fr::add(acc, lag[num_gates + v]);      // bellman's input_i * 0 = 0 rows
+    a.out[mtx][v] = acc;
+}
+
 // one workgroup per CSC_SEG-entry segment of a heavy column: partial[seg] = sum table[cidx] * lag[row]
 struct HeavySeg { uint32_t mtx; uint32_t pad; uint64_t lo, hi; };
 __global__ __launch_bounds__(256) void csc_heavy_kernel(CscArgs a, const Fr *table, const Fr *lag, const HeavySeg *segs, Fr *partial) {
@@ -204,9 +241,10 @@ struct DevFree { std::vector<void *> v; ~DevFree() { for (void *p : v) if (p) (v
 
 extern "C" {
 
-int fk_setup(fk_ctx *ctx, const fk_r1cs *cs, const uint64_t tau_[4], const uint64_t alpha_[4], const uint64_t beta_[4],
-             const uint64_t gamma_[4], const uint64_t delta_[4], uint32_t shard_index, uint32_t shard_count, double z_frac_lo, double z_frac_hi,
-             fk_key **out_key, uint8_t vk_out[6 * 128], uint8_t *ic_out) {
+// cs: one instance; the key is for `copies` of it as one system (1 = the system itself)
+static int setup_impl(fk_ctx *ctx, const fk_r1cs *cs, uint32_t copies, const uint64_t tau_[4], const uint64_t alpha_[4], const uint64_t beta_[4],
+                      const uint64_t gamma_[4], const uint64_t delta_[4], uint32_t shard_index, uint32_t shard_count, double z_frac_lo, double z_frac_hi,
+                      fk_key **out_key, uint8_t vk_out[6 * 128], uint8_t *ic_out) {
     if (!ctx) return FK_ERR_BAD_ARG;
     if (!cs || !tau_ || !alpha_ || !beta_ || !gamma_ || !delta_ || !out_key || !vk_out || !ic_out) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "setup: null argument");
     *out_key = nullptr;
@@ -216,18 +254,25 @@ int fk_setup(fk_ctx *ctx, const fk_r1cs *cs, const uint64_t tau_[4], const uint6
     const Fr tau = fr_load(tau_), alpha = fr_load(alpha_), beta = fr_load(beta_), gamma = fr_load(gamma_), delta = fr_load(delta_);
     if (gamma.is_zero() || delta.is_zero()) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "setup: gamma and delta must be non-zero");
     if (cs->num_input == 0) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "setup: num_input must include the constant ONE");
-    const uint64_t rows = cs->num_gates + cs->num_input;
+    if (copies == 0) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "setup: copies must be at least 1");
+    // totals of the batch: ONE is shared, inputs and aux variables are per copy (spmv.hip: fk_r1cs_load_tiled)
+    const uint64_t t_in = 1 + (uint64_t)copies * (cs->num_input - 1), t_aux = (uint64_t)copies * cs->num_aux, t_gates = (uint64_t)copies * cs->num_gates;
+    const uint64_t nvb = (uint64_t)cs->num_input + cs->num_aux;     // variables of one instance
+    if (t_in + t_aux > 0xffffffffull || t_gates + t_in > 0xffffffffull || (copies > 1 && (cs->num_gates == 0 || copies > 65535)))
+        FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "setup: %u copies of this system are out of range", copies);
+    const uint32_t num_input = (uint32_t)t_in, num_aux = (uint32_t)t_aux;
+    const uint64_t rows = t_gates + t_in;
     const uint32_t log_m = ceil_log2_u64(rows);
     if (log_m >= FK_FR_S) FK_SET_ERR(ctx, FK_ERR_DOMAIN_TOO_LARGE, "setup: evaluation domain 2^%u too large (max 2^%d)", log_m, FK_FR_S - 1);
     const uint64_t m = (uint64_t)1 << log_m;
-    const uint64_t nv = (uint64_t)cs->num_input + cs->num_aux;
+    const uint64_t nv = t_in + t_aux;
     const uint64_t *ptrs[3] = {cs->a_ptr, cs->b_ptr, cs->c_ptr};
     const uint32_t *cols[3] = {cs->a_col, cs->b_col, cs->c_col};
     const uint64_t *vals[3] = {cs->a_val, cs->b_val, cs->c_val};
     for (int k = 0; k < 3; k++) {
         if (!ptrs[k]) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "setup: null row pointer");
         const uint64_t nnz = ptrs[k][cs->num_gates];
-        for (uint64_t i = 0; i < nnz; i++) if (cols[k][i] >= nv) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "setup: variable index %u out of range", cols[k][i]);
+        for (uint64_t i = 0; i < nnz; i++) if (cols[k][i] >= nvb) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "setup: variable index %u out of range", cols[k][i]);
     }
     DevFree tmp;
     auto dalloc = [&](size_t bytes) -> void * { void *p = nullptr; if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return nullptr; tmp.v.push_back(p); return p; };
@@ -243,9 +288,9 @@ int fk_setup(fk_ctx *ctx, const fk_r1cs *cs, const uint64_t tau_[4], const uint6
     std::vector<HeavySeg> heavy_segs; std::vector<uint64_t> heavy_var;
     for (int k = 0; k < 3; k++) {
         const uint64_t nnz = ptrs[k][cs->num_gates];
-        std::vector<uint64_t> cptr(nv + 1, 0);
+        std::vector<uint64_t> cptr(nvb + 1, 0);
         for (uint64_t i = 0; i < nnz; i++) cptr[cols[k][i] + 1]++;
-        for (uint64_t v = 0; v < nv; v++) cptr[v + 1] += cptr[v];
+        for (uint64_t v = 0; v < nvb; v++) cptr[v + 1] += cptr[v];
         std::vector<uint32_t> crow(nnz ? nnz : 1), cidx(nnz ? nnz : 1);
         std::vector<uint64_t> cur(cptr.begin(), cptr.end() - 1);
         for (uint64_t g = 0; g < cs->num_gates; g++)
@@ -263,13 +308,13 @@ int fk_setup(fk_ctx *ctx, const fk_r1cs *cs, const uint64_t tau_[4], const uint6
                 const uint64_t pos = cur[cols[k][i]]++;
                 crow[pos] = (uint32_t)g; cidx[pos] = ci;
             }
-        uint64_t *dp = (uint64_t *)dalloc((nv + 1) * 8); uint32_t *dr = (uint32_t *)dalloc((nnz + 1) * 4), *di = (uint32_t *)dalloc((nnz + 1) * 4);
+        uint64_t *dp = (uint64_t *)dalloc((nvb + 1) * 8); uint32_t *dr = (uint32_t *)dalloc((nnz + 1) * 4), *di = (uint32_t *)dalloc((nnz + 1) * 4);
         d_abc[k] = (Fr *)dalloc(nv * sizeof(Fr));
         if (!dp || !dr || !di || !d_abc[k]) FK_SET_ERR(ctx, FK_ERR_OOM, "setup: device allocation failed");
-        FK_HIP(ctx, hipMemcpy(dp, cptr.data(), (nv + 1) * 8, hipMemcpyHostToDevice));
+        FK_HIP(ctx, hipMemcpy(dp, cptr.data(), (nvb + 1) * 8, hipMemcpyHostToDevice));
         if (nnz) { FK_HIP(ctx, hipMemcpy(dr, crow.data(), nnz * 4, hipMemcpyHostToDevice)); FK_HIP(ctx, hipMemcpy(di, cidx.data(), nnz * 4, hipMemcpyHostToDevice)); }
         ca.ptr[k] = dp; ca.row[k] = dr; ca.cidx[k] = di; ca.out[k] = d_abc[k];
-        for (uint64_t v = 0; v < nv; v++)
+        for (uint64_t v = 0; v < nvb && copies == 1; v++)
             if (cptr[v + 1] - cptr[v] > CSC_HEAVY) {
                 for (uint64_t lo_ = cptr[v]; lo_ < cptr[v + 1]; lo_ += CSC_SEG) {
                     heavy_segs.push_back(HeavySeg{(uint32_t)k, 0, lo_, lo_ + CSC_SEG < cptr[v + 1] ? lo_ + CSC_SEG : cptr[v + 1]});
@@ -301,6 +346,17 @@ int fk_setup(fk_ctx *ctx, const fk_r1cs *cs, const uint64_t tau_[4], const uint6
     FK_TRY(ntt_exec_simple(ctx, d_pt, log_m, /*inverse=*/true, /*coset=*/false));      // d_pt := L_j(tau)
 
     // ---- A_k, B_k, C_k and the combined exponent
+    if (copies > 1) {
+        TileAsm ta;
+        for (int k = 0; k < 3; k++) {
+            Fr *sc = (Fr *)dalloc((size_t)copies * nvb * sizeof(Fr));
+            if (!sc) FK_SET_ERR(ctx, FK_ERR_OOM, "setup: device allocation failed");
+            ta.sc[k] = sc; ta.out[k] = d_abc[k]; ca.out[k] = sc;
+        }
+        hipLaunchKernelGGL(csc_eval_tiled_kernel, dim3((unsigned)((nvb + 255) / 256), 3, copies), dim3(256), 0, st, ca, d_table, d_pt, (uint32_t)cs->num_gates, (uint32_t)nvb);
+        hipLaunchKernelGGL(tile_assemble_kernel, dim3((unsigned)((nv + 255) / 256), 3), dim3(256), 0, st, ta, d_pt, cs->num_input, cs->num_aux, copies, t_gates, num_input, nv);
+        FK_HIP(ctx, hipGetLastError());
+    } else
     hipLaunchKernelGGL(csc_eval_kernel, dim3((unsigned)((nv + 255) / 256), 3), dim3(256), 0, st, ca, d_table, d_pt, cs->num_gates, cs->num_input, nv);
     if (!heavy_segs.empty()) {      // heavy columns: segment partial sums on the device, folded on the host (a handful of values)
         HeavySeg *d_segs = (HeavySeg *)dalloc(heavy_segs.size() * sizeof(HeavySeg));
@@ -326,7 +382,7 @@ int fk_setup(fk_ctx *ctx, const fk_r1cs *cs, const uint64_t tau_[4], const uint6
     uint8_t *d_fa = (uint8_t *)dalloc(nv), *d_fb = (uint8_t *)dalloc(nv);
     if (!d_e || !d_fa || !d_fb) FK_SET_ERR(ctx, FK_ERR_OOM, "setup: device allocation failed");
     hipLaunchKernelGGL(combine_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, st, d_abc[0], d_abc[1], d_abc[2], beta, alpha, gamma_inv, delta_inv,
-                       cs->num_input, nv, d_e, d_fa, d_fb);
+                       num_input, nv, d_e, d_fa, d_fb);
     FK_HIP(ctx, hipGetLastError());
 
     // ---- fixed-base tables (host) and the scalar multiplications
@@ -341,13 +397,13 @@ int fk_setup(fk_ctx *ctx, const fk_r1cs *cs, const uint64_t tau_[4], const uint6
     FK_HIP(ctx, hipMemcpy(d_t2, t2.data(), t2.size() * sizeof(G2Affine), hipMemcpyHostToDevice));
 
     fk_key *k = new fk_key();
-    k->m = m; k->num_input = cs->num_input; k->num_aux = cs->num_aux; k->shard_index = 0; k->shard_count = 1;
-    k->n_h = m - 1; k->n_l = cs->num_aux;
+    k->m = m; k->num_input = num_input; k->num_aux = num_aux; k->shard_index = 0; k->shard_count = 1;
+    k->n_h = m - 1; k->n_l = num_aux;
     auto fail = [&](int code, const char *msg) { ctx->err = msg; fk_key_free(ctx, k); return code; };
     G1Affine *d_a_all = (G1Affine *)dalloc(nv * sizeof(G1Affine)), *d_b1_all = (G1Affine *)dalloc(nv * sizeof(G1Affine)), *d_el = (G1Affine *)dalloc(nv * sizeof(G1Affine));
     G2Affine *d_b2_all = (G2Affine *)dalloc(nv * sizeof(G2Affine));
     if (!d_a_all || !d_b1_all || !d_el || !d_b2_all) return fail(FK_ERR_OOM, "setup: device allocation failed");
-    if (hipMalloc((void **)&k->d_h, m * sizeof(G1Affine)) != hipSuccess || hipMalloc((void **)&k->d_l, (cs->num_aux + 1) * sizeof(G1Affine)) != hipSuccess ||
+    if (hipMalloc((void **)&k->d_h, m * sizeof(G1Affine)) != hipSuccess || hipMalloc((void **)&k->d_l, (num_aux + 1) * sizeof(G1Affine)) != hipSuccess ||
         hipMalloc((void **)&k->d_a, (nv + 1) * sizeof(G1Affine)) != hipSuccess || hipMalloc((void **)&k->d_b1, (nv + 1) * sizeof(G1Affine)) != hipSuccess ||
         hipMalloc((void **)&k->d_b2, (nv + 1) * sizeof(G2Affine)) != hipSuccess) return fail(FK_ERR_OOM, "setup: device allocation failed");
     const unsigned fb_threads = 128;
@@ -359,8 +415,8 @@ int fk_setup(fk_ctx *ctx, const fk_r1cs *cs, const uint64_t tau_[4], const uint6
     if (nv) hipLaunchKernelGGL(HIP_KERNEL_NAME(fixed_base_kernel<Fq2>), dim3((unsigned)((nv + fb_threads - 1) / fb_threads)), dim3(fb_threads), 0, st, d_t2, d_abc[1], (size_t)nv, d_b2_all);
     if (hipGetLastError() != hipSuccess) return fail(FK_ERR_HIP, "setup: kernel launch failed");
     // l = exponent points of the aux variables; ic = those of the inputs
-    if (hipMemcpyAsync(k->d_l, d_el + cs->num_input, (size_t)cs->num_aux * sizeof(G1Affine), hipMemcpyDeviceToDevice, st) != hipSuccess ||
-        hipMemcpyAsync(ic_out, d_el, (size_t)cs->num_input * sizeof(G1Affine), hipMemcpyDeviceToHost, st) != hipSuccess) return fail(FK_ERR_HIP, "setup: copy failed");
+    if (hipMemcpyAsync(k->d_l, d_el + num_input, (size_t)num_aux * sizeof(G1Affine), hipMemcpyDeviceToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(ic_out, d_el, (size_t)num_input * sizeof(G1Affine), hipMemcpyDeviceToHost, st) != hipSuccess) return fail(FK_ERR_HIP, "setup: copy failed");
     // a, b_g1, b_g2: drop identity points, keep order
     uint64_t n_a = 0, n_b1 = 0, n_b2 = 0;
     int rc = compact_elems<G1Affine>(ctx, d_a_all, d_fa, nv, k->d_a, &n_a);
@@ -402,6 +458,18 @@ int fk_setup(fk_ctx *ctx, const fk_r1cs *cs, const uint64_t tau_[4], const uint6
     }
     *out_key = k;
     return FK_OK;
+}
+
+int fk_setup(fk_ctx *ctx, const fk_r1cs *cs, const uint64_t tau[4], const uint64_t alpha[4], const uint64_t beta[4], const uint64_t gamma[4],
+             const uint64_t delta[4], uint32_t shard_index, uint32_t shard_count, double z_frac_lo, double z_frac_hi, fk_key **out_key,
+             uint8_t vk_out[6 * 128], uint8_t *ic_out) {
+    return setup_impl(ctx, cs, 1, tau, alpha, beta, gamma, delta, shard_index, shard_count, z_frac_lo, z_frac_hi, out_key, vk_out, ic_out);
+}
+
+int fk_setup_tiled(fk_ctx *ctx, const fk_r1cs *instance, uint32_t copies, const uint64_t tau[4], const uint64_t alpha[4], const uint64_t beta[4],
+                   const uint64_t gamma[4], const uint64_t delta[4], uint32_t shard_index, uint32_t shard_count, double z_frac_lo, double z_frac_hi,
+                   fk_key **out_key, uint8_t vk_out[6 * 128], uint8_t *ic_out) {
+    return setup_impl(ctx, instance, copies, tau, alpha, beta, gamma, delta, shard_index, shard_count, z_frac_lo, z_frac_hi, out_key, vk_out, ic_out);
 }
 
 // which: 0 = h, 1 = l, 2 = a, 3 = b_g1, 4 = b_g2.  Copies this key's slice of the array to the host.

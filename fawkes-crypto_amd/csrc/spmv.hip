@@ -31,6 +31,9 @@ struct fk_r1cs_dev {
     uint64_t n_a_aux = 0, n_b_in = 0, n_b_aux = 0;   // popcounts
     uint32_t *d_idx_a = nullptr, *d_idx_b = nullptr; // variables of the A / B query in query order
     fk::QueryIdx qidx;
+    // tiled system (fk_r1cs_load_tiled): the CSR above is ONE instance (base_gates rows, base_input / base_aux variables)
+    // and stands for `copies` of it; num_input / num_aux / num_gates / nnz are the totals
+    uint32_t copies = 1, base_input = 0, base_aux = 0, base_gates = 0;
 };
 
 namespace fk {
@@ -45,8 +48,14 @@ struct SpmvArgs {
 // G = 2^lg lanes share one row: lane s takes terms s, s + G, ... and the partial sums are folded with wave64 shuffles.
 // Real circuits have long linear combinations (the eddsa verifier: 133 terms per gate on average, rows of up to 512), and
 // with one lane per row a wave runs as long as its longest row; the synthetic rollup shape (1-2 terms per row) keeps G = 1.
+//
+// TILED: the CSR describes one instance of a batch circuit and row t is row t % base_gates of copy t / base_gates; the
+// copy's variables are found by arithmetic (ONE shared, then every copy's inputs, then every copy's aux variables: the
+// layout of a circuit that allocates the same gadget `copies` times), so a 4096-signature batch costs the memory of one.
+struct TileDims { uint32_t base_gates, base_input, base_aux; };
+template <bool TILED>
 __global__ __launch_bounds__(256) void spmv_kernel(SpmvArgs a, const Fr *table, const Fr *z, uint64_t num_gates, uint32_t num_input, uint32_t lg0, uint32_t lg1,
-                                                   uint32_t lg2) {
+                                                   uint32_t lg2, TileDims td) {
     const uint32_t mtx = blockIdx.y;
     const uint32_t lg = mtx == 0 ? lg0 : (mtx == 1 ? lg1 : lg2);
     const uint64_t t = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> lg;
@@ -56,8 +65,13 @@ __global__ __launch_bounds__(256) void spmv_kernel(SpmvArgs a, const Fr *table, 
     const uint64_t *ptr = a.ptr[mtx]; const uint32_t *col = a.col[mtx]; const uint32_t *cidx = a.cidx[mtx];
     Fr acc = Fr::zero();
     if (t < num_gates) {
-        for (uint64_t k = ptr[t] + sub, e = ptr[t + 1]; k < e; k += (uint64_t)1 << lg) {
-            Fr v = z[col[k]];
+        uint32_t copy = 0; uint64_t row = t;
+        if (TILED) { copy = (uint32_t)t / td.base_gates; row = (uint32_t)t - copy * td.base_gates; }
+        const uint32_t in_off = copy * (td.base_input - 1), aux_off = num_input + copy * td.base_aux - td.base_input;
+        for (uint64_t k = ptr[row] + sub, e = ptr[row + 1]; k < e; k += (uint64_t)1 << lg) {
+            uint32_t cv = col[k];
+            if (TILED && cv) cv += cv < td.base_input ? in_off : aux_off;
+            Fr v = z[cv];
             const uint32_t ci = cidx[k];
             if (ci) v = Fr::mul(v, table[ci]);
             acc = Fr::add(acc, v);
@@ -88,9 +102,11 @@ void fk_r1cs_free(fk_ctx *ctx, fk_r1cs_dev *r) {
     delete r;
 }
 
-int fk_r1cs_load(fk_ctx *ctx, const fk_r1cs *cs, fk_r1cs_dev **out) {
+// cs: one instance; the resident system stands for `copies` of it (1 = the system itself)
+static int r1cs_load_impl(fk_ctx *ctx, const fk_r1cs *cs, uint32_t copies, fk_r1cs_dev **out) {
     if (!ctx || !cs || !out) return FK_ERR_BAD_ARG;
     *out = nullptr;
+    if (copies == 0) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "r1cs: copies must be at least 1");
     FK_HIP(ctx, hipSetDevice(ctx->device));
     const uint64_t *ptrs[3] = {cs->a_ptr, cs->b_ptr, cs->c_ptr};
     const uint32_t *cols[3] = {cs->a_col, cs->b_col, cs->c_col};
@@ -105,8 +121,13 @@ int fk_r1cs_load(fk_ctx *ctx, const fk_r1cs *cs, fk_r1cs_dev **out) {
         if (nnz && !cols[k]) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "r1cs: null column array");   // vals[k] == NULL: all coefficients ONE
         for (uint64_t i = 0; i < nnz; i++) if (cols[k][i] >= nv) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "r1cs: variable index %u out of range", cols[k][i]);
     }
+    // totals of the tiled system: ONE is shared, inputs and aux variables are per copy
+    const uint64_t t_in = 1 + (uint64_t)copies * (cs->num_input - 1), t_aux = (uint64_t)copies * cs->num_aux, t_gates = (uint64_t)copies * cs->num_gates;
+    if (t_in + t_aux > 0xffffffffull || t_gates + t_in > 0xffffffffull || (copies > 1 && cs->num_gates == 0))
+        FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "r1cs: %u copies of this system do not fit 32-bit variable / row indices", copies);
     fk_r1cs_dev *r = new fk_r1cs_dev();
-    r->num_input = cs->num_input; r->num_aux = cs->num_aux; r->num_gates = cs->num_gates;
+    r->num_input = (uint32_t)t_in; r->num_aux = (uint32_t)t_aux; r->num_gates = t_gates;
+    r->copies = copies; r->base_input = cs->num_input; r->base_aux = cs->num_aux; r->base_gates = (uint32_t)cs->num_gates;
     // coefficient dictionary; slot 0 = ONE
     std::unordered_map<std::string, uint32_t> dict;
     std::vector<Fr> table;
@@ -118,7 +139,7 @@ int fk_r1cs_load(fk_ctx *ctx, const fk_r1cs *cs, fk_r1cs_dev **out) {
     auto fail = [&](int code) { fk_r1cs_free(ctx, r); return code; };
     for (int k = 0; k < 3 && rc == FK_OK; k++) {
         const uint64_t nnz = ptrs[k][cs->num_gates];
-        r->nnz[k] = nnz;
+        r->nnz[k] = nnz * copies;
         std::vector<uint32_t> cidx(nnz ? nnz : 1);
         Fr last = one; uint32_t last_idx = 0;        // one-entry cache in front of the hash map
         for (uint64_t i = 0; i < nnz; i++) {
@@ -149,6 +170,15 @@ int fk_r1cs_load(fk_ctx *ctx, const fk_r1cs *cs, fk_r1cs_dev **out) {
         if (nnz && hipMemcpy(r->cidx[k], cidx.data(), nnz * 4, hipMemcpyHostToDevice) != hipSuccess) rc = FK_ERR_HIP;
     }
     if (rc != FK_OK) { ctx->err = "r1cs: upload failed"; return fail(rc); }
+    if (copies > 1) {      // density maps of the whole batch: every copy repeats the instance's pattern, ONE is shared
+        auto rep = [&](std::vector<uint8_t> &f, size_t skip, size_t per) {
+            std::vector<uint8_t> o(skip + per * copies + (skip + per * copies == 0));
+            for (size_t i = 0; i < skip; i++) o[i] = f[i];
+            for (uint32_t j = 0; j < copies; j++) for (size_t i = 0; i < per; i++) o[skip + j * per + i] = f[skip + i];
+            f.swap(o);
+        };
+        rep(a_aux, 0, cs->num_aux); rep(b_aux, 0, cs->num_aux); rep(b_in, 1, cs->num_input - 1);
+    }
     r->n_table = table.size();
     if (hipMalloc((void **)&r->table, table.size() * sizeof(Fr)) != hipSuccess || hipMalloc((void **)&r->d_a_aux, a_aux.size()) != hipSuccess ||
         hipMalloc((void **)&r->d_b_in, b_in.size()) != hipSuccess || hipMalloc((void **)&r->d_b_aux, b_aux.size()) != hipSuccess) {
@@ -158,13 +188,13 @@ int fk_r1cs_load(fk_ctx *ctx, const fk_r1cs *cs, fk_r1cs_dev **out) {
         hipMemcpy(r->d_a_aux, a_aux.data(), a_aux.size(), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(r->d_b_in, b_in.data(), b_in.size(), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(r->d_b_aux, b_aux.data(), b_aux.size(), hipMemcpyHostToDevice) != hipSuccess) { ctx->err = "r1cs: upload failed"; return fail(FK_ERR_HIP); }
-    for (uint32_t j = 0; j < cs->num_aux; j++) { r->n_a_aux += a_aux[j]; r->n_b_aux += b_aux[j]; }
-    for (uint32_t i = 0; i < cs->num_input; i++) r->n_b_in += b_in[i];
+    for (uint32_t j = 0; j < r->num_aux; j++) { r->n_a_aux += a_aux[j]; r->n_b_aux += b_aux[j]; }
+    for (uint32_t i = 0; i < r->num_input; i++) r->n_b_in += b_in[i];
     {   // query index lists (bellman's order: inputs first, then the aux variables the density map selects)
         std::vector<uint32_t> ia, ib;
-        ia.reserve(cs->num_input + r->n_a_aux); ib.reserve(r->n_b_in + r->n_b_aux);
-        for (uint32_t i = 0; i < cs->num_input; i++) { ia.push_back(i); if (b_in[i]) ib.push_back(i); }
-        for (uint32_t j = 0; j < cs->num_aux; j++) { if (a_aux[j]) ia.push_back(cs->num_input + j); if (b_aux[j]) ib.push_back(cs->num_input + j); }
+        ia.reserve(r->num_input + r->n_a_aux); ib.reserve(r->n_b_in + r->n_b_aux);
+        for (uint32_t i = 0; i < r->num_input; i++) { ia.push_back(i); if (b_in[i]) ib.push_back(i); }
+        for (uint32_t j = 0; j < r->num_aux; j++) { if (a_aux[j]) ia.push_back(r->num_input + j); if (b_aux[j]) ib.push_back(r->num_input + j); }
         if (hipMalloc((void **)&r->d_idx_a, ia.size() * 4 + 4) != hipSuccess || hipMalloc((void **)&r->d_idx_b, ib.size() * 4 + 4) != hipSuccess) {
             ctx->err = "r1cs: device allocation failed"; return fail(FK_ERR_OOM);
         }
@@ -176,6 +206,9 @@ int fk_r1cs_load(fk_ctx *ctx, const fk_r1cs *cs, fk_r1cs_dev **out) {
     *out = r;
     return FK_OK;
 }
+
+int fk_r1cs_load(fk_ctx *ctx, const fk_r1cs *cs, fk_r1cs_dev **out) { return r1cs_load_impl(ctx, cs, 1, out); }
+int fk_r1cs_load_tiled(fk_ctx *ctx, const fk_r1cs *instance, uint32_t copies, fk_r1cs_dev **out) { return r1cs_load_impl(ctx, instance, copies, out); }
 
 int fk_r1cs_density_ptrs(const fk_r1cs_dev *r, const void *out[3]) {
     if (!r || !out) return FK_ERR_BAD_ARG;
@@ -211,8 +244,13 @@ int fk_r1cs_eval_dev(fk_ctx *ctx, const fk_r1cs_dev *r, const void *d_z, void *d
         if (lg[k] > lgmax) lgmax = lg[k];
     }
     const uint64_t lanes = rows << lgmax;
-    hipLaunchKernelGGL(spmv_kernel, dim3((unsigned)((lanes + 255) / 256), 3), dim3(256), 0, ctx->stream, a, r->table, (const Fr *)d_z, r->num_gates, r->num_input,
-                       lg[0], lg[1], lg[2]);
+    const TileDims td{r->base_gates, r->base_input, r->base_aux};
+    if (r->copies > 1)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_kernel<true>), dim3((unsigned)((lanes + 255) / 256), 3), dim3(256), 0, ctx->stream, a, r->table, (const Fr *)d_z, r->num_gates,
+                           r->num_input, lg[0], lg[1], lg[2], td);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_kernel<false>), dim3((unsigned)((lanes + 255) / 256), 3), dim3(256), 0, ctx->stream, a, r->table, (const Fr *)d_z, r->num_gates,
+                           r->num_input, lg[0], lg[1], lg[2], td);
     FK_HIP(ctx, hipGetLastError());
     FK_DBG(ctx, "spmv");
     return FK_OK;

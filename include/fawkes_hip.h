@@ -233,6 +233,12 @@ int fk_synthesize(fk_ctx *ctx, const fk_r1cs *cs, const uint64_t *z, uint64_t *a
  * (mod.rs:92-99).  z: num_input + num_aux Montgomery elements, inputs first, z[0] = ONE. */
 typedef struct fk_r1cs_dev fk_r1cs_dev;
 int fk_r1cs_load(fk_ctx *ctx, const fk_r1cs *cs, fk_r1cs_dev **out);
+/* Batch circuits (BASELINE configs[2]: one R1CS holding 4096 eddsa verifiers): `instance` is ONE copy of the gadget and
+ * the resident system stands for `copies` of it -- the gates of copy j are rows [j*G, (j+1)*G), the constant ONE is shared,
+ * the variables are ordered ONE, copy 0's inputs, copy 1's inputs, ..., copy 0's aux, copy 1's aux, ... -- without
+ * materialising copies x nnz terms (2.2e9 for that batch): the kernel maps a copy's variables by arithmetic.  The
+ * result is indistinguishable from fk_r1cs_load of the explicitly replicated system (tests/test_gpu_tiled.py). */
+int fk_r1cs_load_tiled(fk_ctx *ctx, const fk_r1cs *instance, uint32_t copies, fk_r1cs_dev **out);
 void fk_r1cs_free(fk_ctx *ctx, fk_r1cs_dev *r1cs);
 /* out[8] = rows, nnz(A), nnz(B), nnz(C), distinct coefficients, points the a query needs, points the b query needs, 0 */
 int fk_r1cs_info(const fk_r1cs_dev *r1cs, uint64_t out[8]);
@@ -258,6 +264,11 @@ int fk_prove_r1cs_dev(fk_ctx *ctx, const fk_key *key, const fk_r1cs_dev *r1cs, c
 int fk_setup(fk_ctx *ctx, const fk_r1cs *cs, const uint64_t tau[4], const uint64_t alpha[4], const uint64_t beta[4],
              const uint64_t gamma[4], const uint64_t delta[4], uint32_t shard_index, uint32_t shard_count,
              double z_frac_lo, double z_frac_hi, fk_key **out_key, uint8_t vk_out[6 * 128], uint8_t *ic_out);
+/* the key of `copies` instances as one system (layout of fk_r1cs_load_tiled); ic_out: (1 + copies*(num_input-1)) x 64 bytes */
+int fk_setup_tiled(fk_ctx *ctx, const fk_r1cs *instance, uint32_t copies, const uint64_t tau[4], const uint64_t alpha[4],
+                   const uint64_t beta[4], const uint64_t gamma[4], const uint64_t delta[4], uint32_t shard_index,
+                   uint32_t shard_count, double z_frac_lo, double z_frac_hi, fk_key **out_key, uint8_t vk_out[6 * 128],
+                   uint8_t *ic_out);
 /* copies this key's slice of one array to the host; which: 0 = h, 1 = l, 2 = a, 3 = b_g1, 4 = b_g2 */
 int fk_key_download(fk_ctx *ctx, const fk_key *key, int which, void *host, size_t host_bytes);
 
