@@ -19,6 +19,15 @@
 #include <unordered_map>
 #include <string>
 
+namespace fk {
+// launch plan of spmv_binned_kernel: up to 3 length classes for each of the 3 matrices
+struct BinArgs {
+    uint32_t nseg = 0, mask = 0;            // mask: bit k = matrix k is binned
+    uint32_t first_block[10] = {0}, lg[9] = {0}, mtx[9] = {0}, n_rows[9] = {0}, list_off[9] = {0};
+    const uint32_t *rowlist[3] = {nullptr, nullptr, nullptr};
+};
+}  // namespace fk
+
 struct fk_r1cs_dev {
     uint32_t num_input = 0, num_aux = 0;
     uint64_t num_gates = 0;
@@ -34,6 +43,9 @@ struct fk_r1cs_dev {
     // tiled system (fk_r1cs_load_tiled): the CSR above is ONE instance (base_gates rows, base_input / base_aux variables)
     // and stands for `copies` of it; num_input / num_aux / num_gates / nnz are the totals
     uint32_t copies = 1, base_input = 0, base_aux = 0, base_gates = 0;
+    // matrices with long rows: the (instance's) rows in classes by length, sorted by length inside a class (see spmv_binned_kernel)
+    uint32_t *rowlist[3] = {nullptr, nullptr, nullptr};
+    fk::BinArgs bins;
 };
 
 namespace fk {
@@ -53,15 +65,17 @@ struct SpmvArgs {
 // copy's variables are found by arithmetic (ONE shared, then every copy's inputs, then every copy's aux variables: the
 // layout of a circuit that allocates the same gadget `copies` times), so a 4096-signature batch costs the memory of one.
 struct TileDims { uint32_t base_gates, base_input, base_aux; };
+// binned: bit k set = matrix k's gate rows belong to spmv_binned_kernel; this kernel then only writes the rows behind them
 template <bool TILED>
 __global__ __launch_bounds__(256) void spmv_kernel(SpmvArgs a, const Fr *table, const Fr *z, uint64_t num_gates, uint32_t num_input, uint32_t lg0, uint32_t lg1,
-                                                   uint32_t lg2, TileDims td) {
+                                                   uint32_t lg2, TileDims td, uint32_t binned) {
     const uint32_t mtx = blockIdx.y;
     const uint32_t lg = mtx == 0 ? lg0 : (mtx == 1 ? lg1 : lg2);
     const uint64_t t = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> lg;
     const uint32_t sub = threadIdx.x & ((1u << lg) - 1);
     const uint64_t rows = num_gates + num_input;
     if (t >= rows) return;                   // the lanes of a row group leave together (256 is a multiple of G)
+    if (((binned >> mtx) & 1) && t < num_gates) return;
     const uint64_t *ptr = a.ptr[mtx]; const uint32_t *col = a.col[mtx]; const uint32_t *cidx = a.cidx[mtx];
     Fr acc = Fr::zero();
     if (t < num_gates) {
@@ -88,6 +102,55 @@ __global__ __launch_bounds__(256) void spmv_kernel(SpmvArgs a, const Fr *table, 
     if (sub == 0) a.out[mtx][t] = acc;
 }
 
+// Circuits built from Poseidon are bimodal: three quarters of the eddsa verifier's rows hold ONE term, the rest 128-512 (the
+// MDS mixing is kept as lazily expanded linear combinations).  A wave runs as long as its longest row, so one lane-group
+// size for a whole matrix wastes most lanes either way.  Here the rows of a matrix are split by length into classes with
+// their own group size (1, 4 or 16 lanes per row) and sorted by length inside a class, so that the rows sharing a wave
+// have (nearly) the same length; long rows take two terms per step through the dual-chain multiplier.  Segment s of the
+// launch is one (matrix, class); a tiled system walks its copies in the outer order, so a copy's z stays in cache.
+template <bool TILED>
+__global__ __launch_bounds__(256) void spmv_binned_kernel(SpmvArgs a, BinArgs b, const Fr *table, const Fr *z, uint32_t num_input, TileDims td, uint32_t copies) {
+    uint32_t s = 0;
+    while (s + 1 < b.nseg && blockIdx.x >= b.first_block[s + 1]) s++;
+    const uint32_t lg = b.lg[s], mtx = b.mtx[s], nr = b.n_rows[s];
+    const uint64_t gidx = (uint64_t)(blockIdx.x - b.first_block[s]) * (256u >> lg) + (threadIdx.x >> lg);
+    const uint32_t sub = threadIdx.x & ((1u << lg) - 1);
+    if (gidx >= (uint64_t)nr * copies) return;
+    uint32_t copy = 0, li = (uint32_t)gidx;
+    if (TILED) { copy = (uint32_t)(gidx / nr); li = (uint32_t)(gidx - (uint64_t)copy * nr); }
+    const uint32_t row = b.rowlist[mtx][b.list_off[s] + li];
+    const uint32_t in_off = copy * (td.base_input - 1), aux_off = num_input + copy * td.base_aux - td.base_input;
+    const uint64_t *ptr = a.ptr[mtx]; const uint32_t *col = a.col[mtx]; const uint32_t *cidx = a.cidx[mtx];
+    const uint64_t e = ptr[row + 1];
+    uint64_t k = ptr[row] + sub;
+    const uint32_t G = 1u << lg;
+    auto var = [&](uint32_t cv) -> uint32_t { if (TILED && cv) cv += cv < td.base_input ? in_off : aux_off; return cv; };
+    Fr acc = Fr::zero();
+    if (lg) {
+        Fr acc1 = Fr::zero();
+        for (; k + G < e; k += 2 * G) {        // table[0] is ONE: multiplying by it returns the (reduced) value itself
+            const uint32_t c0 = var(col[k]), c1 = var(col[k + G]), i0 = cidx[k], i1 = cidx[k + G];
+            Fr p0, p1;
+            Fr::mul2(z[c0], table[i0], z[c1], table[i1], p0, p1);
+            Fr::add2(acc, p0, acc1, p1, acc, acc1);
+        }
+        acc = Fr::add(acc, acc1);
+    }
+    for (; k < e; k += G) {
+        Fr v = z[var(col[k])];
+        const uint32_t ci = cidx[k];
+        if (ci) v = Fr::mul(v, table[ci]);
+        acc = Fr::add(acc, v);
+    }
+    for (uint32_t off = G >> 1; off; off >>= 1) {
+        Fr o;
+#pragma unroll
+        for (int i = 0; i < 8; i++) o.v[i] = (uint32_t)__shfl_down((int)acc.v[i], off, 64);
+        acc = Fr::add(acc, o);
+    }
+    if (sub == 0) a.out[mtx][(uint64_t)copy * td.base_gates + row] = acc;
+}
+
 }  // namespace fk
 
 using namespace fk;
@@ -97,7 +160,7 @@ extern "C" {
 void fk_r1cs_free(fk_ctx *ctx, fk_r1cs_dev *r) {
     if (!r) return;
     if (ctx) (void)hipSetDevice(ctx->device);
-    for (int k = 0; k < 3; k++) { if (r->ptr[k]) (void)hipFree(r->ptr[k]); if (r->col[k]) (void)hipFree(r->col[k]); if (r->cidx[k]) (void)hipFree(r->cidx[k]); }
+    for (int k = 0; k < 3; k++) { if (r->ptr[k]) (void)hipFree(r->ptr[k]); if (r->col[k]) (void)hipFree(r->col[k]); if (r->cidx[k]) (void)hipFree(r->cidx[k]); if (r->rowlist[k]) (void)hipFree(r->rowlist[k]); }
     for (void *p : {(void *)r->table, (void *)r->d_a_aux, (void *)r->d_b_in, (void *)r->d_b_aux, (void *)r->d_idx_a, (void *)r->d_idx_b}) if (p) (void)hipFree(p);
     delete r;
 }
@@ -137,6 +200,8 @@ static int r1cs_load_impl(fk_ctx *ctx, const fk_r1cs *cs, uint32_t copies, fk_r1
     std::vector<uint8_t> a_aux(cs->num_aux ? cs->num_aux : 1, 0), b_in(cs->num_input, 0), b_aux(cs->num_aux ? cs->num_aux : 1, 0);
     int rc = FK_OK;
     auto fail = [&](int code) { fk_r1cs_free(ctx, r); return code; };
+    uint64_t bin_min = 8;          // rows this long make a matrix binned; FK_SPMV_BIN_MIN=0 turns the binned product off
+    if (const char *e = getenv("FK_SPMV_BIN_MIN")) { bin_min = strtoull(e, nullptr, 10); if (!bin_min) bin_min = ~0ull; }
     for (int k = 0; k < 3 && rc == FK_OK; k++) {
         const uint64_t nnz = ptrs[k][cs->num_gates];
         r->nnz[k] = nnz * copies;
@@ -168,6 +233,34 @@ static int r1cs_load_impl(fk_ctx *ctx, const fk_r1cs *cs, uint32_t copies, fk_r1
         if (hipMemcpy(r->ptr[k], ptrs[k], (cs->num_gates + 1) * 8, hipMemcpyHostToDevice) != hipSuccess) rc = FK_ERR_HIP;
         if (nnz && hipMemcpy(r->col[k], cols[k], nnz * 4, hipMemcpyHostToDevice) != hipSuccess) rc = FK_ERR_HIP;
         if (nnz && hipMemcpy(r->cidx[k], cidx.data(), nnz * 4, hipMemcpyHostToDevice) != hipSuccess) rc = FK_ERR_HIP;
+        // length classes (spmv_binned_kernel) when the matrix has long rows: < 4 terms -> 1 lane, < 32 -> 4 lanes, else 16
+        uint64_t maxlen = 0;
+        for (uint64_t g = 0; g < cs->num_gates; g++) if (ptrs[k][g + 1] - ptrs[k][g] > maxlen) maxlen = ptrs[k][g + 1] - ptrs[k][g];
+        if (maxlen >= bin_min && cs->num_gates && cs->num_gates < 0xffffffffull && rc == FK_OK) {
+            const uint32_t ng = (uint32_t)cs->num_gates, CAP = 1024;            // counting sort by min(length, CAP), descending, stable
+            std::vector<uint32_t> cnt(CAP + 2, 0), list(ng);
+            auto key = [&](uint32_t g) { const uint64_t l = ptrs[k][g + 1] - ptrs[k][g]; return (uint32_t)(l < CAP ? l : CAP); };
+            for (uint32_t g = 0; g < ng; g++) cnt[CAP - key(g) + 1]++;
+            for (uint32_t i = 0; i <= CAP; i++) cnt[i + 1] += cnt[i];
+            for (uint32_t g = 0; g < ng; g++) list[cnt[CAP - key(g)]++] = g;
+            const uint32_t n16 = cnt[CAP - 32], n4 = cnt[CAP - 4] - n16, n1 = ng - n16 - n4;     // cnt[i] is now the END of key CAP - i
+            if (hipMalloc((void **)&r->rowlist[k], (size_t)ng * 4) != hipSuccess) { ctx->err = "r1cs: device allocation failed"; return fail(FK_ERR_OOM); }
+            if (hipMemcpy(r->rowlist[k], list.data(), (size_t)ng * 4, hipMemcpyHostToDevice) != hipSuccess) rc = FK_ERR_HIP;
+            BinArgs &b = r->bins;
+            b.rowlist[k] = r->rowlist[k]; b.mask |= 1u << k;
+            const uint32_t cls_n[3] = {n16, n4, n1}, cls_lg[3] = {4, 2, 0};
+            uint32_t off = 0;
+            for (int c = 0; c < 3; c++) {
+                if (cls_n[c]) {
+                    const uint64_t groups = (uint64_t)cls_n[c] * copies, per = 256u >> cls_lg[c], blocks = (groups + per - 1) / per;
+                    if (b.first_block[b.nseg] + blocks > 0x7fffffffull) { ctx->err = "r1cs: system too large for the binned product"; return fail(FK_ERR_BAD_ARG); }
+                    b.lg[b.nseg] = cls_lg[c]; b.mtx[b.nseg] = k; b.n_rows[b.nseg] = cls_n[c]; b.list_off[b.nseg] = off;
+                    b.first_block[b.nseg + 1] = b.first_block[b.nseg] + (uint32_t)blocks;
+                    b.nseg++;
+                }
+                off += cls_n[c];
+            }
+        }
     }
     if (rc != FK_OK) { ctx->err = "r1cs: upload failed"; return fail(rc); }
     if (copies > 1) {      // density maps of the whole batch: every copy repeats the instance's pattern, ONE is shared
@@ -240,17 +333,23 @@ int fk_r1cs_eval_dev(fk_ctx *ctx, const fk_r1cs_dev *r, const void *d_z, void *d
     for (int k = 0; k < 3; k++) {
         const uint64_t mean = r->num_gates ? r->nnz[k] / r->num_gates : 0;
         lg[k] = 0;
-        while (lg[k] < 6 && ((uint64_t)t_div << lg[k]) <= mean) lg[k]++;
+        while (!((r->bins.mask >> k) & 1) && lg[k] < 6 && ((uint64_t)t_div << lg[k]) <= mean) lg[k]++;
         if (lg[k] > lgmax) lgmax = lg[k];
     }
     const uint64_t lanes = rows << lgmax;
     const TileDims td{r->base_gates, r->base_input, r->base_aux};
+    const uint32_t binned = r->bins.mask;
     if (r->copies > 1)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_kernel<true>), dim3((unsigned)((lanes + 255) / 256), 3), dim3(256), 0, ctx->stream, a, r->table, (const Fr *)d_z, r->num_gates,
-                           r->num_input, lg[0], lg[1], lg[2], td);
+                           r->num_input, lg[0], lg[1], lg[2], td, binned);
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_kernel<false>), dim3((unsigned)((lanes + 255) / 256), 3), dim3(256), 0, ctx->stream, a, r->table, (const Fr *)d_z, r->num_gates,
-                           r->num_input, lg[0], lg[1], lg[2], td);
+                           r->num_input, lg[0], lg[1], lg[2], td, binned);
+    if (binned) {
+        const unsigned blocks = r->bins.first_block[r->bins.nseg];
+        if (r->copies > 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_binned_kernel<true>), dim3(blocks), dim3(256), 0, ctx->stream, a, r->bins, r->table, (const Fr *)d_z, r->num_input, td, r->copies);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_binned_kernel<false>), dim3(blocks), dim3(256), 0, ctx->stream, a, r->bins, r->table, (const Fr *)d_z, r->num_input, td, r->copies);
+    }
     FK_HIP(ctx, hipGetLastError());
     FK_DBG(ctx, "spmv");
     return FK_OK;

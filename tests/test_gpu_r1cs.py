@@ -74,3 +74,56 @@ def test_r1cs_load_rejects_bad_input(ctx):
     bad = (ptr, np.array([9], np.uint32), one.reshape(1, 4))
     with pytest.raises(fk.FkError):
         ctx.load_r1cs(fk.R1cs(1, 1, bad, good, good))
+
+
+def _ragged_system(seed, lens_choices, gates, nin, naux):
+    """random matrices with the given row lengths (zero-length rows and ONE coefficients included); not satisfiable, the
+    product does not need it"""
+    rng = np.random.default_rng(seed)
+    nv = nin + naux
+    coeffs = fx.co.limbs_arr([1, ref.R - 1, 2] + [int(x) for x in rng.integers(3, 2**62, 40)])
+    coeffs = np.stack([fx.mont_fr(int.from_bytes(c.tobytes(), 'little')) for c in coeffs])
+
+    def mat():
+        lens = rng.choice(lens_choices, size=gates)
+        ptr = np.zeros(gates + 1, np.uint64)
+        ptr[1:] = np.cumsum(lens)
+        nnz = int(ptr[-1])
+        return fx.co.Csr(ptr, rng.integers(0, nv, nnz).astype(np.uint32), np.ascontiguousarray(coeffs[rng.integers(0, len(coeffs), nnz)]))
+
+    return fx.co.R1csC(nin, naux, mat(), mat(), mat())
+
+
+@pytest.mark.parametrize('lens', [[0, 1, 1, 1, 2, 3, 4, 5, 31, 32, 33, 100, 257, 512], [1, 1, 1, 7, 8, 9], [40, 41, 1500]])
+@pytest.mark.parametrize('copies', [1, 5])
+def test_spmv_long_rows_vs_oracle(ctx, oracle, monkeypatch, lens, copies):
+    """rows of very different lengths (the Poseidon shape) go through the length-class kernel: same result as the oracle,
+    as the single-class kernel (FK_SPMV_BIN_MIN=0), and as a tiled system"""
+    base = _ragged_system(len(lens) * 10 + copies, lens, 700, 3, 300)
+    csr = fx.tile_r1cs(base, copies) if copies > 1 else base
+    nv, rows = csr.num_input + csr.num_aux, csr.num_gates + csr.num_input
+    rnd = np.random.default_rng(copies)
+    z = fx.co.limbs_arr([int(x) % ref.R for x in rnd.integers(0, 2**63, nv).astype(object) * (2**190 + 12345)])
+    want = oracle.synthesize(csr, z)
+    m = 1 << max(rows - 1, 1).bit_length()
+    d = [ctx.dev_alloc(m * 32) for _ in range(3)]
+    d_z = ctx.dev_alloc(z.nbytes)
+    ctx.upload(d_z, z)
+    loads = [lambda: ctx.load_r1cs(r1cs_product(csr))]
+    if copies > 1:
+        loads.append(lambda: ctx.load_r1cs(r1cs_product(base), copies=copies))
+    try:
+        for env in ('', '0'):
+            if env:
+                monkeypatch.setenv('FK_SPMV_BIN_MIN', env)
+            for load in loads:
+                dr = load()
+                for p in d:
+                    ctx.upload(p, np.full(rows * 4, 0xdeadbeefdeadbeef, np.uint64))
+                ctx.r1cs_eval_dev(dr, d_z, *d)
+                for k in range(3):
+                    assert np.array_equal(ctx.download(d[k], rows * 32, np.uint64).reshape(-1, 4), want[k]), (env, k)
+                dr.free()
+    finally:
+        for p in d + [d_z]:
+            ctx.dev_free(p)
