@@ -1,7 +1,7 @@
 """BASELINE configs[2] on the GPU: the eddsa-poseidon signature check (circuit/eddsaposeidon.rs:17-47) produced by the
-restated DSL (oracle/fawkes_circuit.py) -- one signature, and a batch of 16 signatures tiled into ONE constraint system
-(the shape of "batch of 4096 signatures as one R1CS"; 4096 copies are 2.2 G matrix terms, which the host-side CSR
-interface of this round cannot carry).  LCs here are long (133 terms per gate on average, up to 512): this is the
+restated DSL (oracle/fawkes_circuit.py) -- one signature, and a batch of 16 signatures replicated into ONE constraint
+system (the shape of "batch of 4096 signatures as one R1CS"; the full 4096 go through the tiled entry points,
+tests/test_gpu_tiled.py).  LCs here are long (133 terms per gate on average, up to 512): this is the
 workload that exercises the device SpMV, unlike the synthetic rollup shape."""
 import random
 
