@@ -266,6 +266,7 @@ def main():
     fracs = parallel.plan_z_fractions(world, m, v_aux, n_a, n_b)
     tox = {k: mont(v) for k, v in TOXIC.items()}
     key, vk = ctx.setup(r1cs, shard_index=rank, shard_count=world, z_frac=fracs[rank] if (world > 1 and not dist_q) else (0.0, 0.0), **tox)
+    pre_levels = key.precomputed()        # fixed-base window levels per key array (0 = none: FK_MSM_PRECOMP=0 or HBM short)
     d_z = torch.empty((v_in + v_aux) * 32, dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
     ctx.upload(d_z.data_ptr(), z)
@@ -359,12 +360,13 @@ def main():
                        'gates': '40% boolean b*(b-1)=0, 10% linear, 50% products' + (' of %d-term sums' % args.lc_terms if args.lc_terms > 1 else ''),
                        'nnz': list(info['nnz']),
                        'a_query_points': n_a, 'b_query_points': n_b,
+                       'msm_fixed_base_levels': pre_levels,
                        'witness': '%.0f%% zeros, %.0f%% ones, rest dense 254-bit' % (100.0 * zeros / (v_in + v_aux), 100.0 * ones / (v_in + v_aux)),
                        'parallelism': 'msm-shard%d%s' % (world, '' if not multi else
                                                          '+distributed-quotient (8 all-to-all per proof)' if dist_q else '+balanced-quotient')},
             'msm_scalar_muls_per_sec': msm_units / sec_per_step,
             'roofline': {
-                'bound': 'hbm', 'kernel': 'msm_accumulate_kernel<Fq> (G1 bucket accumulation)',
+                'bound': 'hbm', 'kernel': '%s<Fq> (G1 bucket accumulation)' % ('msm_accumulate_merged_kernel' if pre_levels.get('h') else 'msm_accumulate_kernel'),
                 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                 'traffic': traffic,
                 'traffic_source': ('rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/r01_pmc_traffic_bench_2p25.json '

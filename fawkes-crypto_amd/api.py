@@ -34,7 +34,7 @@ EXPORTED_SYMBOLS = [
     'fk_gen_points_g1_dev', 'fk_gen_points_g2_dev', 'fk_gen_scalars_dev',
     'fk_synthesize', 'fk_stats_reset', 'fk_stats_get', 'fk_shard_range', 'fk_h_shard_range',
     'fk_dq_gather_dev', 'fk_dq_local_dev', 'fk_dq_cross_dev',
-    'fk_setup', 'fk_setup_tiled', 'fk_r1cs_load_tiled', 'fk_key_download', 'fk_key_load_bellman', 'fk_key_vk', 'fk_key_counts',
+    'fk_setup', 'fk_setup_tiled', 'fk_r1cs_load_tiled', 'fk_key_download', 'fk_key_load_bellman', 'fk_key_vk', 'fk_key_counts', 'fk_key_precomputed',
     'fk_r1cs_load', 'fk_r1cs_free', 'fk_r1cs_info', 'fk_r1cs_density_ptrs', 'fk_r1cs_eval_dev', 'fk_prove_r1cs', 'fk_prove_r1cs_dev',
 ]
 
@@ -281,6 +281,14 @@ class DeviceKey:
             raise FkError(rc, 'fk_key_counts')
         v = list(out)
         return dict(m=v[0], num_input=v[1], num_aux=v[2], n_h=v[3], n_l=v[4], n_a=v[5], n_b=v[6], shard_count=v[7])
+
+    def precomputed(self):
+        """fk_key_precomputed: window levels held per array (0 = the ordinary W-bucket-set path)"""
+        out = (C.c_uint32 * 5)()
+        rc = self.ctx.lib.fk_key_precomputed(self.handle, out)
+        if rc != 0:
+            raise FkError(rc, 'fk_key_precomputed')
+        return dict(zip(('h', 'l', 'a', 'b_g1', 'b_g2'), list(out)))
 
     def vk(self):
         """prover-side vk points as raw Montgomery LE uint8 arrays"""

@@ -41,7 +41,7 @@ struct MsmLane {
     DevBuf digits, sorted, totals, starts, perm, overlist, tasktab, partials, s2_cnt1, s2_seg, s2_cnt2, s2_tmp_idx, s2_tmp_lo, buckets;
     void *h_stage = nullptr;        // pinned host staging: counters read back, oversized-bucket list, task tables
     size_t h_cap = 0;
-    const void *last_sort_scalars = nullptr; size_t last_sort_n = 0; unsigned last_sort_c = 0;   // what `sorted` currently holds
+    const void *last_sort_scalars = nullptr; size_t last_sort_n = 0; unsigned last_sort_c = 0; bool last_merged = false;   // what `sorted` currently holds
     // ... and the oversized-bucket tables that belong to it (already in tasktab on the device)
     uint32_t last_n_over = 0, last_seg = 0, last_cap = 0; size_t last_n_tasks = 0, last_n_obs = 0, last_tb_al = 0;
 };
@@ -64,6 +64,15 @@ struct QueryIdx {
     const uint8_t *d_a_aux = nullptr, *d_b_in = nullptr, *d_b_aux = nullptr;   // the density maps the lists were made from
     const uint32_t *a = nullptr, *b = nullptr;                                 // variable indices, query order
     uint64_t n_a = 0, n_b = 0;
+};
+
+// Fixed-base precomputation of one key array (msm.hip): level w holds 2^(offset of window w) * P for every base P, so that
+// the buckets of ALL windows carry the same weights and are accumulated as ONE bucket set (one reduction instead of W).
+// lev: levels 1 .. W-1, n points each (level 0 is the key array itself).  Tied to the window plan (cb, wide, W) of n.
+struct KeyPre {
+    void *lev = nullptr;
+    size_t n = 0;
+    uint32_t cb = 0, wide = 0, W = 0;
 };
 
 }  // namespace fk
@@ -107,6 +116,7 @@ struct fk_key {
     fk::G2Affine *d_b2 = nullptr;
     fk::G1Affine alpha_g1, beta_g1, delta_g1;
     fk::G2Affine beta_g2, delta_g2;
+    fk::KeyPre pre_h, pre_l, pre_a, pre_b1, pre_b2;       // optional (memory permitting), see key_precompute
 };
 
 #define FK_SET_ERR(ctx, code, ...)                                   \
@@ -168,21 +178,25 @@ int dq_local(fk_ctx *ctx, Fr *d_x, const Fr *d_xb, const Fr *d_xc, uint32_t log_
 int dq_cross(fk_ctx *ctx, Fr *d_buf, uint32_t log_m, uint32_t rank, uint32_t log_w, int mode);
 
 // msm.hip
-int msm_g1_dev(fk_ctx *ctx, const G1Affine *d_bases, const Fr *d_scalars, size_t n, G1Xyzz *out);
+int msm_g1_dev(fk_ctx *ctx, const G1Affine *d_bases, const Fr *d_scalars, size_t n, G1Xyzz *out, const KeyPre *pre = nullptr);
 // split form: *_begin queues the whole multiplication on one of the two lanes and returns a tail handle (-1 for an
 // empty sum); *_end waits for it and folds the window sums on the host.  Several multiplications may be outstanding;
 // msm_abandon drops them all (error paths); msm_sync waits for both lanes.
 // ready: event after which bases / scalars are valid (nullptr: everything queued on ctx->stream so far)
-int msm_g1_begin(fk_ctx *ctx, const G1Affine *d_bases, const Fr *d_scalars, size_t n, int *tail, hipEvent_t ready = nullptr);
+// pre: the bases' precomputed levels (nullptr / empty / made for another n: the ordinary W-bucket-set path)
+int msm_g1_begin(fk_ctx *ctx, const G1Affine *d_bases, const Fr *d_scalars, size_t n, int *tail, hipEvent_t ready = nullptr, const KeyPre *pre = nullptr);
 int msm_g1_end(fk_ctx *ctx, int tail, G1Xyzz *out);
-int msm_g2_begin(fk_ctx *ctx, const G2Affine *d_bases, const Fr *d_scalars, size_t n, bool reuse_sort, int *tail, hipEvent_t ready = nullptr);
+int msm_g2_begin(fk_ctx *ctx, const G2Affine *d_bases, const Fr *d_scalars, size_t n, bool reuse_sort, int *tail, hipEvent_t ready = nullptr, const KeyPre *pre = nullptr);
+// fills key->pre_* for the slices the key holds (FK_MSM_PRECOMP=0 disables; skipped silently when HBM is short); key_pre_free undoes
+int key_precompute(fk_ctx *ctx, fk_key *key);
+void key_pre_free(fk_key *key);
 int msm_g2_end(fk_ctx *ctx, int tail, G2Xyzz *out);
 void msm_abandon(fk_ctx *ctx);
 void msm_release(fk_ctx *ctx);
 int msm_sync(fk_ctx *ctx);
 // reuse_sort: the scalars are the ones of the immediately preceding MSM call on this context (same pointer
 // and n), so its digits / bucket sort are still valid and are not recomputed (B1 and B2 share scalars)
-int msm_g2_dev(fk_ctx *ctx, const G2Affine *d_bases, const Fr *d_scalars, size_t n, G2Xyzz *out, bool reuse_sort = false);
+int msm_g2_dev(fk_ctx *ctx, const G2Affine *d_bases, const Fr *d_scalars, size_t n, G2Xyzz *out, bool reuse_sort = false, const KeyPre *pre = nullptr);
 int gen_points_g1(fk_ctx *ctx, G1Affine *d_out, size_t n, uint64_t seed);
 int gen_points_g2(fk_ctx *ctx, G2Affine *d_out, size_t n, uint64_t seed);
 int gen_scalars(fk_ctx *ctx, Fr *d_out, size_t n, uint64_t seed, int kind);

@@ -157,6 +157,7 @@ int fk_key_load_bellman(fk_ctx *ctx, const uint8_t *buf, size_t len, uint32_t sh
     if (gamma_g2_out) memcpy(gamma_g2_out, &vk2[1], 128);
     if (n_ic) *n_ic = cnt[0];
     if (ic_out) memcpy(ic_out, ic.data(), (size_t)(cnt[0] < ic_cap ? cnt[0] : ic_cap) * 64);
+    if ((rc = key_precompute(ctx, k)) != FK_OK) { fk_key_free(ctx, k); return rc; }
     *out = k;
     return FK_OK;
 }

@@ -48,21 +48,25 @@ static constexpr uint32_t S2_EPT = S2_TILE / 1024;      // entries per lane (102
 // Windows are sized from n.  Sizing them from the number of non-trivial scalars (0 and 1 never reach the ordinary
 // buckets) was measured slower on the witness MSMs: fewer windows win even at bucket loads of ~6 once lanes are
 // size-ordered (G2 accumulate 22.6 ms at c = 20 vs 26.2 ms at c = 16 for 16.7M scalars of which 3.3M are dense).
-static MsmPlan make_plan(size_t n, unsigned forced_c) {
+// merged: the bases carry precomputed levels (KeyPre), all windows share ONE bucket set -- the reduction costs a W-th, so the
+// windows can be wider (FK_MSM_PRE_DC, default +2 bits, up to the sort's limit of 22)
+static MsmPlan make_plan(size_t n, unsigned forced_c, bool merged = false) {
     MsmPlan p{};
     p.n = n;
     const size_t nd = n ? n : 1;
     uint32_t lg = 0; while (((size_t)1 << (lg + 1)) <= nd + nd / 2) lg++;     // log2 rounded (2^25 - 1 counts as 2^25)
     // large MSMs: bucket loads of ~64 are enough now that lanes are size-ordered, so c grows with n (fewer digits
     // per scalar: 13 at c = 20 instead of 16)
-    static int t_small = -1, t_delta = -1, t_sig = -1;
+    static int t_small = -1, t_delta = -1, t_sig = -1, t_pre_dc = 2;
     if (t_small < 0) {   // tuning knobs (environment, read once)
         const char *e;
         t_small = (e = getenv("FK_MSM_C_SMALL")) ? atoi(e) : 17;
         t_delta = (e = getenv("FK_MSM_C_DELTA")) ? atoi(e) : 5;
         t_sig = (e = getenv("FK_MSM_CAP_SIGMA")) ? atoi(e) : 6;
+        t_pre_dc = (e = getenv("FK_MSM_PRE_DC")) ? atoi(e) : 2;
     }
     uint32_t c = forced_c ? forced_c : (lg >= 22 ? lg - t_delta : (lg >= 18 ? (uint32_t)t_small : (lg >= 6 ? lg - 2 : 4)));
+    if (merged && !forced_c) c = (uint32_t)std::max(2, (int)c + t_pre_dc);
     if (c < 2) c = 2;
     if (c > 22) c = 22;
     p.c = c;
@@ -513,6 +517,59 @@ __global__ __launch_bounds__(256, MINW) void msm_accumulate_kernel(const Affine<
     buckets[g] = acc;
 }
 
+// Merged form (precomputed levels): lane t owns bucket b = perm[t] of the ONE bucket set and walks that bucket's entries in
+// every window, taking window w's points from level w (2^offset_w * P) -- the weights of all windows' buckets coincide.
+// The walk is ONE loop over the bucket's merged length mt[b] with a (window, position) cursor: the lanes of a wave are
+// size-ordered by that merged length, so they stay in step; a loop per window would run every window to the longest of the 64
+// per-window counts (Poisson: 1.6 x the mean at a load of 16).
+template <class F, int MINW>
+__global__ __launch_bounds__(256, MINW) void msm_accumulate_merged_kernel(const Affine<F> *bases, const Affine<F> *lev, const uint32_t *sorted, size_t n,
+                                                                    const uint32_t *starts, const uint32_t *totals, uint32_t B,
+                                                                    uint32_t W, uint32_t cap, const uint32_t *perm, const uint32_t *mt, Xyzz<F> *buckets) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B) return;
+    const uint32_t b = perm[t];
+    const uint32_t total = mt[b];
+    Xyzz<F> acc = Xyzz<F>::inf();
+    uint32_t w = 0, k = 0, cnt = 0;
+    const uint32_t *src = nullptr;
+    const Affine<F> *bw = bases;
+    bool first = true;
+    for (uint32_t i = 0; i < total; i++) {
+        while (first || k == cnt) {          // next window that holds entries of this bucket (total > i guarantees there is one)
+            if (!first) w++;
+            first = false;
+            const size_t g = (size_t)w * B + b;
+            cnt = totals[g];
+            if (cnt > cap) cnt = cap;
+            src = sorted + (size_t)w * n + starts[g];
+            bw = w ? lev + (size_t)(w - 1) * n : bases;
+            k = 0;
+        }
+        const uint32_t e = src[k++];
+        Affine<F> p = bw[e & 0x7fffffffu];
+        acc.add_mixed(affine_neg_if(p, (e >> 31) != 0));
+    }
+    buckets[b] = acc;
+}
+// mt[b] = sum over the windows of min(totals[w][b], cap): the merged bucket's length, for the size ordering
+__global__ __launch_bounds__(256) void msm_merge_totals_kernel(const uint32_t *totals, uint32_t B, uint32_t W, uint32_t cap, uint32_t *mt) {
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    uint32_t s = 0;
+    for (uint32_t w = 0; w < W; w++) { const uint32_t v = totals[(size_t)w * B + b]; s += v < cap ? v : cap; }
+    mt[b] = s;
+}
+// level w+1 = 2^bits * level w, affine in, affine out
+template <class F>
+__global__ __launch_bounds__(256) void msm_level_kernel(const Affine<F> *in, size_t n, uint32_t bits, Affine<F> *out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Xyzz<F> p = Xyzz<F>::from_affine(in[i]);
+    for (uint32_t k = 0; k < bits; k++) p = Xyzz<F>::dbl(p);
+    out[i] = p.to_affine();
+}
+
 struct Task { uint32_t g, seg; };
 
 // one WAVE per SEG-entry segment of an oversized bucket (entries beyond `cap`): many small workgroups keep
@@ -520,11 +577,12 @@ struct Task { uint32_t g, seg; };
 // The per-lane walk uses the inlined multiply (F); the wave64 shuffle reduction runs on the
 // layout-identical cold twin (FC).
 template <class F, class FC>
-__global__ __launch_bounds__(64) void msm_overflow_kernel(const Affine<F> *bases, const uint32_t *sorted, size_t n,
+__global__ __launch_bounds__(64) void msm_overflow_kernel(const Affine<F> *bases0, const Affine<F> *lev, const uint32_t *sorted, size_t n,
                                                           const uint32_t *starts, const uint32_t *totals, uint32_t B,
                                                           uint32_t W, uint32_t cap_all, uint32_t cap_top, uint32_t SEG, const Task *tasks, Xyzz<FC> *partials) {
     const Task t = tasks[blockIdx.x];
     const uint32_t w = t.g / B;
+    const Affine<F> *bases = (lev && w) ? lev + (size_t)(w - 1) * n : bases0;      // merged form: window w's points come from level w
     const uint32_t cap = (w == W - 1) ? cap_top : cap_all;
     const uint32_t *src = sorted + (size_t)w * n + starts[t.g];
     const uint32_t size = totals[t.g];
@@ -617,7 +675,7 @@ static int lane_stage(fk_ctx *ctx, MsmLane &ln, size_t bytes) {     // pinned st
 // involvement.  While the host sits in the sort's read-backs of multiplication k+1, the GPU works on the
 // accumulation of multiplication k on the other lane.
 template <class F>
-static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars, size_t n, bool reuse_sort, int *tail_out, hipEvent_t ready) {
+static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars, size_t n, bool reuse_sort, int *tail_out, hipEvent_t ready, const KeyPre *pre = nullptr) {
     using FC = typename ColdOf<F>::type;   // layout-identical field with an out-of-line multiply
     *tail_out = -1;
     if (n == 0) return FK_OK;
@@ -627,12 +685,18 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
     if (ti < 0) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "msm: too many outstanding multiplications");
     MsmTail &tl = ctx->tails[ti];
     if (!tl.done) FK_HIP(ctx, hipEventCreateWithFlags(&tl.done, hipEventDisableTiming));
-    const MsmPlan p = make_plan(n, ctx->window_bits);
+    MsmPlan p = make_plan(n, ctx->window_bits);
+    bool merged = false;
+    if (pre && pre->lev && pre->n == n) {      // the levels were made for exactly this plan; anything else takes the ordinary path
+        const MsmPlan pm = make_plan(n, ctx->window_bits, true);
+        if (pm.cb == pre->cb && pm.wide == pre->wide && pm.W == pre->W) { p = pm; merged = true; }
+    }
+    const Affine<F> *d_lev = merged ? (const Affine<F> *)pre->lev : nullptr;
     // lane: the next one in turn, unless this call reuses the previous call's sort (B2 after B1).  With three lanes the
     // multiplication after the G2 one does not queue behind its long overflow / reduction tail (at 2^22 that tail was 5.4 ms
     // during which nothing else ran: 31 % of the proof).
     MsmLane &prev = ctx->lanes[ctx->lane_prev];
-    const bool have_sort = reuse_sort && prev.st && prev.last_sort_scalars == (const void *)d_scalars && prev.last_sort_n == n && prev.last_sort_c == p.c;
+    const bool have_sort = reuse_sort && prev.st && prev.last_sort_scalars == (const void *)d_scalars && prev.last_sort_n == n && prev.last_sort_c == p.c && prev.last_merged == merged;
     const int li = have_sort ? ctx->lane_prev : ctx->lane_next;
     MsmLane &ln = ctx->lanes[li];
     FK_TRY(lane_init(ctx, ln));
@@ -645,7 +709,8 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
         FK_HIP(ctx, hipStreamWaitEvent(st, ln.ev_in, 0));
     }
     const size_t WB = (size_t)p.W * p.B;
-    const size_t wp_bytes = (size_t)p.W * p.nblk * sizeof(Xyzz<F>);
+    const uint32_t WR = merged ? 1 : p.W;      // bucket sets to reduce
+    const size_t wp_bytes = (size_t)WR * p.nblk * sizeof(Xyzz<F>);
     // every oversized bucket holds more than `cap` of the W * n entries, so there can be at most W * n / cap of them: the
     // list is sized for that worst case (witnesses with many repeated values put thousands of buckets over the cap)
     const uint32_t over_cap = (uint32_t)std::min<uint64_t>((uint64_t)p.W * n / (p.cap ? p.cap : 1) + 64, 0x7fffffffu);
@@ -711,7 +776,7 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
         }
         FK_HIP(ctx, hipGetLastError());
         FK_DBG_ST(ctx, st, "msm_sort_pass2");
-        ln.last_sort_scalars = (const void *)d_scalars; ln.last_sort_n = n; ln.last_sort_c = p.c;
+        ln.last_sort_scalars = (const void *)d_scalars; ln.last_sort_n = n; ln.last_sort_c = p.c; ln.last_merged = merged;
     }
     // oversized buckets (skewed scalars): known once the sort is done -- the host builds the segment table now, so that
     // nothing has to wait for the accumulation.  With a reused sort the tables of the previous call are still valid.
@@ -738,9 +803,18 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
         }
         // size-ordered bucket -> lane assignment
         FK_HIP(ctx, hipMemsetAsync(size_bins, 0, SIZE_BINS * 4, st));
+        if (merged) {     // one bucket set: order its B buckets by their length over all windows (perm[0, B); lengths kept behind it)
+            uint32_t *mt = perm + p.B;
+            const uint32_t mcap = (uint32_t)std::min<uint64_t>((uint64_t)cap * p.W, 1u << 30);
+            hipLaunchKernelGGL(msm_merge_totals_kernel, dim3((p.B + 255) / 256), dim3(256), 0, st, totals, p.B, p.W, cap, mt);
+            hipLaunchKernelGGL(msm_size_hist_kernel, dim3((unsigned)std::min<size_t>((p.B + 255) / 256, 1024)), dim3(256), 0, st, mt, (size_t)p.B, mcap, size_bins);
+            hipLaunchKernelGGL(msm_size_scan_kernel, dim3(1), dim3(SIZE_BINS), 0, st, size_bins);
+            hipLaunchKernelGGL(msm_size_scatter_kernel, dim3((unsigned)((p.B + 1023) / 1024)), dim3(1024), 0, st, mt, (size_t)p.B, mcap, size_bins, perm);
+        } else {
         hipLaunchKernelGGL(msm_size_hist_kernel, dim3((unsigned)std::min<size_t>((WB + 255) / 256, 1024)), dim3(256), 0, st, totals, WB, cap, size_bins);
         hipLaunchKernelGGL(msm_size_scan_kernel, dim3(1), dim3(SIZE_BINS), 0, st, size_bins);
         hipLaunchKernelGGL(msm_size_scatter_kernel, dim3((unsigned)((WB + 1023) / 1024)), dim3(1024), 0, st, totals, WB, cap, size_bins, perm);
+        }
         FK_HIP(ctx, hipGetLastError());
         FK_DBG_ST(ctx, st, "msm_size_order");
         if (ctx->debug) { fprintf(stderr, "[fk] msm n=%zu c=%u (W=%u: %u x %u bits + %u x %u bits) cap=%u (plan %u): %u oversized buckets\n", n, p.c, p.W, p.wide, p.cb + 1, p.W - p.wide, p.cb, cap, p.cap, n_over); fflush(stderr); }
@@ -750,7 +824,9 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
             FK_HIP(ctx, hipMemcpyAsync(h_over, ln.overlist.p, n_over * sizeof(OverEntry), hipMemcpyDeviceToHost, st));
             FK_HIP(ctx, hipStreamSynchronize(st));
             std::vector<OverEntry> ov(h_over, h_over + n_over);
-            std::sort(ov.begin(), ov.end(), [](const OverEntry &a, const OverEntry &b) { return a.g < b.g; });
+            const uint32_t Bm = p.B;
+            if (merged) std::sort(ov.begin(), ov.end(), [Bm](const OverEntry &a, const OverEntry &b) { return a.g % Bm != b.g % Bm ? a.g % Bm < b.g % Bm : a.g < b.g; });
+            else std::sort(ov.begin(), ov.end(), [](const OverEntry &a, const OverEntry &b) { return a.g < b.g; });
             std::vector<Task> tasks;
             std::vector<OverBucket> obs;
             // segment length: about two waves per SIMD over all oversized entries, so that a lone giant bucket (all the
@@ -762,7 +838,9 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
                 const uint32_t cap_w = cap;
                 const uint32_t extra = e.size - cap_w;
                 const uint32_t nt = (extra + SEG - 1) / SEG;
-                obs.push_back(OverBucket{e.g, (uint32_t)tasks.size(), nt});
+                // merged form: the oversized (window, bucket) pairs of one bucket fold into the same sum -> one fold workgroup for them all
+                if (merged && !obs.empty() && obs.back().g == e.g % Bm) obs.back().ntask += nt;
+                else obs.push_back(OverBucket{merged ? e.g % Bm : e.g, (uint32_t)tasks.size(), nt});
                 for (uint32_t s = 0; s < nt; s++) tasks.push_back(Task{e.g, s});
             }
             n_tasks = tasks.size(); n_obs = obs.size();
@@ -787,6 +865,10 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
     // ---- from here on nothing waits for the host
     std::vector<EventPair> &evv = (sizeof(F) == sizeof(Fq)) ? ctx->ev_acc : ctx->ev_acc2;
     FK_TRY(stats_begin(ctx, evv, (uint64_t)n, st));
+    if (merged)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_merged_kernel<F, (sizeof(F) == sizeof(Fq) ? 4 : 2)>), dim3((p.B + 255) / 256), dim3(256), 0, st, d_bases, d_lev, sorted, n,
+                           starts, totals, p.B, p.W, cap, perm, perm + p.B, buckets);
+    else
     hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_kernel<F, (sizeof(F) == sizeof(Fq) ? 4 : 2)>), dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, d_bases, sorted, n,
                        starts, totals, p.B, p.W, cap, cap, perm, buckets);
     FK_HIP(ctx, hipGetLastError());
@@ -794,7 +876,7 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
     FK_DBG_ST(ctx, st, "msm_accumulate");
     if (n_over) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_overflow_kernel<F, FC>), dim3((unsigned)n_tasks), dim3(64), 0, st,
-                           d_bases, sorted, n, starts,
+                           d_bases, d_lev, sorted, n, starts,
                            totals, p.B, p.W, cap, cap, SEG, d_tasks, ln.partials.as<Xyzz<FC>>());
         FK_HIP(ctx, hipGetLastError());
         FK_DBG_ST(ctx, st, "msm_overflow");
@@ -803,13 +885,13 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
         FK_HIP(ctx, hipGetLastError());
         FK_DBG_ST(ctx, st, "msm_overflow_fold");
     }
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_bucket_reduce_kernel<F>), dim3(p.nblk, p.W), dim3(256), 0, st,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_bucket_reduce_kernel<F>), dim3(p.nblk, WR), dim3(256), 0, st,
                        buckets, p.B, p.L, p.T, p.nblk, winparts);
     FK_HIP(ctx, hipGetLastError());
     FK_HIP(ctx, hipMemcpyAsync(tl.h_wp, winparts, wp_bytes, hipMemcpyDeviceToHost, st));
     FK_HIP(ctx, hipEventRecord(tl.done, st));
     FK_DBG_ST(ctx, st, "msm_bucket_reduce");
-    tl.active = true; tl.cb = p.cb; tl.wide = p.wide; tl.W = p.W; tl.nblk = p.nblk;
+    tl.active = true; tl.cb = p.cb; tl.wide = p.wide; tl.W = WR; tl.nblk = p.nblk;     // merged: one "window" of weight 1
     *tail_out = ti;
     return FK_OK;
 }
@@ -871,28 +953,77 @@ void msm_release(fk_ctx *ctx) {
     }
 }
 
-int msm_g1_begin(fk_ctx *ctx, const G1Affine *d_bases, const Fr *d_scalars, size_t n, int *tail, hipEvent_t ready) {
-    return msm_begin<Fq>(ctx, d_bases, d_scalars, n, false, tail, ready);
+int msm_g1_begin(fk_ctx *ctx, const G1Affine *d_bases, const Fr *d_scalars, size_t n, int *tail, hipEvent_t ready, const KeyPre *pre) {
+    return msm_begin<Fq>(ctx, d_bases, d_scalars, n, false, tail, ready, pre);
 }
 int msm_g1_end(fk_ctx *ctx, int tail, G1Xyzz *out) { return msm_end<Fq>(ctx, tail, out); }
-int msm_g2_begin(fk_ctx *ctx, const G2Affine *d_bases, const Fr *d_scalars, size_t n, bool reuse_sort, int *tail, hipEvent_t ready) {
-    return msm_begin<Fq2>(ctx, d_bases, d_scalars, n, reuse_sort, tail, ready);
+int msm_g2_begin(fk_ctx *ctx, const G2Affine *d_bases, const Fr *d_scalars, size_t n, bool reuse_sort, int *tail, hipEvent_t ready, const KeyPre *pre) {
+    return msm_begin<Fq2>(ctx, d_bases, d_scalars, n, reuse_sort, tail, ready, pre);
 }
 int msm_g2_end(fk_ctx *ctx, int tail, G2Xyzz *out) { return msm_end<Fq2>(ctx, tail, out); }
 
 template <class F>
-static int msm_run(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars, size_t n, Xyzz<F> *out, bool reuse_sort = false) {
+static int msm_run(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars, size_t n, Xyzz<F> *out, bool reuse_sort = false, const KeyPre *pre = nullptr) {
     int tail = -1;
     *out = Xyzz<F>::inf();
-    FK_TRY(msm_begin<F>(ctx, d_bases, d_scalars, n, reuse_sort, &tail, nullptr));
+    FK_TRY(msm_begin<F>(ctx, d_bases, d_scalars, n, reuse_sort, &tail, nullptr, pre));
     return msm_end<F>(ctx, tail, out);
 }
 
-int msm_g1_dev(fk_ctx *ctx, const G1Affine *d_bases, const Fr *d_scalars, size_t n, G1Xyzz *out) {
-    return msm_run<Fq>(ctx, d_bases, d_scalars, n, out);
+int msm_g1_dev(fk_ctx *ctx, const G1Affine *d_bases, const Fr *d_scalars, size_t n, G1Xyzz *out, const KeyPre *pre) {
+    return msm_run<Fq>(ctx, d_bases, d_scalars, n, out, false, pre);
 }
-int msm_g2_dev(fk_ctx *ctx, const G2Affine *d_bases, const Fr *d_scalars, size_t n, G2Xyzz *out, bool reuse_sort) {
-    return msm_run<Fq2>(ctx, d_bases, d_scalars, n, out, reuse_sort);
+int msm_g2_dev(fk_ctx *ctx, const G2Affine *d_bases, const Fr *d_scalars, size_t n, G2Xyzz *out, bool reuse_sort, const KeyPre *pre) {
+    return msm_run<Fq2>(ctx, d_bases, d_scalars, n, out, reuse_sort, pre);
+}
+
+// ------------------------------------------------------------------------------------------ fixed-base precomputation of a key
+template <class F>
+static int precompute_levels(fk_ctx *ctx, const Affine<F> *d_bases, size_t n, KeyPre *out) {
+    *out = KeyPre();
+    // Arrays below 2^24 points (rounded as the window rule rounds) keep the ordinary path: measured per proof with / without
+    // levels -- 2^20: 15.5 / 13.1 ms, 2^22: 29.9 / 25.8, 2^23: 45.7 / 44.1, 2^24: 79.0 / 80.6, 2^25: 139.5 / 148.2.  (Read per call:
+    // the tests lower it to run the merged path on small keys.)
+    const char *e = getenv("FK_MSM_PRE_MIN_LOG2");
+    const int min_lg = e ? atoi(e) : 24;
+    if (min_lg < 6 || min_lg > 40 || n + n / 2 < ((size_t)1 << min_lg)) return FK_OK;
+    const MsmPlan p = make_plan(n, ctx->window_bits, true);
+    if (p.W < 2) return FK_OK;
+    const size_t bytes = (size_t)(p.W - 1) * n * sizeof(Affine<F>);
+    size_t fr = 0, tot = 0;
+    FK_HIP(ctx, hipMemGetInfo(&fr, &tot));
+    // leave room for the lanes' scratch (about 0.6 KB per scalar of the largest multiplication), the NTT tables and the caller
+    if (bytes + (size_t)n * 640 * MSM_LANES + ((size_t)8 << 30) > fr) return FK_OK;
+    void *lev = nullptr;
+    if (hipMalloc(&lev, bytes) != hipSuccess) { (void)hipGetLastError(); return FK_OK; }
+    const Affine<F> *prev = d_bases;
+    for (uint32_t w = 1; w < p.W; w++) {
+        Affine<F> *cur = (Affine<F> *)lev + (size_t)(w - 1) * n;
+        const uint32_t bits = p.cb + ((w - 1) < p.wide ? 1 : 0);       // width of window w-1
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_level_kernel<F>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, prev, n, bits, cur);
+        prev = cur;
+    }
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { (void)hipFree(lev); FK_SET_ERR(ctx, FK_ERR_HIP, "msm: level precomputation failed"); }
+    out->lev = lev; out->n = n; out->cb = p.cb; out->wide = p.wide; out->W = p.W;
+    return FK_OK;
+}
+
+void key_pre_free(fk_key *k) {
+    for (KeyPre *p : {&k->pre_h, &k->pre_l, &k->pre_a, &k->pre_b1, &k->pre_b2}) { if (p->lev) (void)hipFree(p->lev); *p = KeyPre(); }
+}
+
+int key_precompute(fk_ctx *ctx, fk_key *k) {
+    const char *e = getenv("FK_MSM_PRECOMP");
+    const int on = e ? atoi(e) : 1;
+    key_pre_free(k);
+    if (!on) return FK_OK;
+    // the long G1 accumulations first: if HBM runs short the later arrays simply stay on the ordinary path
+    if (k->d_h) FK_TRY(precompute_levels<Fq>(ctx, k->d_h, k->h_hi - k->h_lo, &k->pre_h));
+    if (k->d_l) FK_TRY(precompute_levels<Fq>(ctx, k->d_l, k->l_hi - k->l_lo, &k->pre_l));
+    if (k->d_b2) FK_TRY(precompute_levels<Fq2>(ctx, k->d_b2, k->b_hi - k->b_lo, &k->pre_b2));
+    if (k->d_b1 && (k->pre_b2.lev || !k->d_b2)) FK_TRY(precompute_levels<Fq>(ctx, k->d_b1, k->b_hi - k->b_lo, &k->pre_b1));   // B1 and B2 share one sort: same plan or none
+    if (k->d_a) FK_TRY(precompute_levels<Fq>(ctx, k->d_a, k->a_hi - k->a_lo, &k->pre_a));
+    return FK_OK;
 }
 
 // ------------------------------------------------------------------------------------------ generators (bench/test inputs)

@@ -168,6 +168,7 @@ void fk_key_free(fk_ctx *ctx, fk_key *k) {
     if (!k) return;
     if (ctx) (void)hipSetDevice(ctx->device);
     for (void *p : {(void *)k->d_h, (void *)k->d_l, (void *)k->d_a, (void *)k->d_b1, (void *)k->d_b2}) if (p) (void)hipFree(p);
+    key_pre_free(k);
     delete k;
 }
 
@@ -211,6 +212,7 @@ int fk_key_load(fk_ctx *ctx, const fk_key_desc *d, fk_key **out) {
     if (rc == FK_OK) rc = up(k->d_a, d->a, k->a_lo, k->a_hi, 64);
     if (rc == FK_OK) rc = up(k->d_b1, d->b_g1, k->b_lo, k->b_hi, 64);
     if (rc == FK_OK) rc = up(k->d_b2, d->b_g2, k->b_lo, k->b_hi, 128);
+    if (rc == FK_OK) rc = key_precompute(ctx, k);
     if (rc != FK_OK) { fk_key_free(ctx, k); return rc; }
     *out = k;
     return FK_OK;
@@ -223,6 +225,13 @@ int fk_key_host_vk(const uint8_t *alpha_g1, const uint8_t *beta_g1, const uint8_
     k->alpha_g1 = g1_from_raw(alpha_g1); k->beta_g1 = g1_from_raw(beta_g1); k->delta_g1 = g1_from_raw(delta_g1);
     k->beta_g2 = g2_from_raw(beta_g2); k->delta_g2 = g2_from_raw(delta_g2);
     *out = k;
+    return FK_OK;
+}
+
+int fk_key_precomputed(const fk_key *k, uint32_t out[5]) {
+    if (!k || !out) return FK_ERR_BAD_ARG;
+    const KeyPre *p[5] = {&k->pre_h, &k->pre_l, &k->pre_a, &k->pre_b1, &k->pre_b2};
+    for (int i = 0; i < 5; i++) out[i] = p[i]->lev ? p[i]->W : 0;
     return FK_OK;
 }
 
@@ -265,6 +274,7 @@ int fk_key_synthetic(fk_ctx *ctx, uint64_t m, uint32_t num_input, uint32_t num_a
         k->alpha_g1 = h1[0]; k->beta_g1 = h1[1]; k->delta_g1 = h1[2]; k->beta_g2 = h2[0]; k->delta_g2 = h2[1];
     }
     if (rc == FK_OK) { if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = FK_ERR_HIP; }
+    if (rc == FK_OK) rc = key_precompute(ctx, k);
     if (rc != FK_OK) { fk_key_free(ctx, k); return rc; }
     *out = k;
     return FK_OK;
@@ -322,10 +332,10 @@ static int witness_begin(fk_ctx *ctx, const fk_key *key, const Fr *d_z, const ui
                                                        (unsigned long long)(v_in + n_a_aux), (unsigned long long)key->n_a);
         }
         FK_HIP(ctx, hipEventRecord(ctx->ev_aux, ax));
-        FK_TRY(msm_g1_begin(ctx, key->d_b1, sb + key->b_lo, key->b_hi - key->b_lo, &ctx->wit_tail[0], ctx->ev_aux));
-        FK_TRY(msm_g2_begin(ctx, key->d_b2, sb + key->b_lo, key->b_hi - key->b_lo, /*reuse_sort=*/true, &ctx->wit_tail[1], ctx->ev_aux));   // same scalars as B1
-        FK_TRY(msm_g1_begin(ctx, key->d_l, d_z + v_in + key->l_lo, key->l_hi - key->l_lo, &ctx->wit_tail[2], ctx->ev_aux));
-        FK_TRY(msm_g1_begin(ctx, key->d_a, sa + key->a_lo, key->a_hi - key->a_lo, &ctx->wit_tail[3], ctx->ev_aux));
+        FK_TRY(msm_g1_begin(ctx, key->d_b1, sb + key->b_lo, key->b_hi - key->b_lo, &ctx->wit_tail[0], ctx->ev_aux, &key->pre_b1));
+        FK_TRY(msm_g2_begin(ctx, key->d_b2, sb + key->b_lo, key->b_hi - key->b_lo, /*reuse_sort=*/true, &ctx->wit_tail[1], ctx->ev_aux, &key->pre_b2));   // same scalars as B1
+        FK_TRY(msm_g1_begin(ctx, key->d_l, d_z + v_in + key->l_lo, key->l_hi - key->l_lo, &ctx->wit_tail[2], ctx->ev_aux, &key->pre_l));
+        FK_TRY(msm_g1_begin(ctx, key->d_a, sa + key->a_lo, key->a_hi - key->a_lo, &ctx->wit_tail[3], ctx->ev_aux, &key->pre_a));
         return FK_OK;
     };
     const int rc = body();
@@ -381,13 +391,14 @@ static int prove_msms_dev(fk_ctx *ctx, const fk_key *key, Fr *d_a, Fr *d_b, Fr *
     FK_TRY(quotient_dev(ctx, d_a, d_b, d_c, n, d_h, &m));          // queued on the main stream, not waited for
     const double t1 = now_ms();
     // Single GPU: the multiplications start after the quotient.  Running the witness multiplications underneath it was
-    // measured (2^20 .. 2^25): both sides are VALU-bound, nothing is gained at 2^25 and 10 % is lost at 2^20 / 2^22.
+    // measured (2^20 .. 2^25): both sides are VALU-bound, nothing is gained at 2^25 and 10 % is lost at 2^20 / 2^22.  So was
+    // running only their SORTS underneath it, accumulations held back until it is done: 2^25 139.5 -> 148.1 ms, 2^22 29.2 -> 34.0.
     if (!ctx->ev_main) FK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_main, hipEventDisableTiming));
     FK_HIP(ctx, hipEventRecord(ctx->ev_main, ctx->stream));
     // H first: it is the longest accumulation and hides the sorts of the multiplications behind it (B1, B2, H, L, A -- H after
     // the B pair, so that only B1's smaller sort is exposed -- measured 3 % slower at 2^25 and 13 % slower at 2^22)
     int t_h = -1;
-    FK_TRY(msm_g1_begin(ctx, key->d_h, d_h + key->h_lo, key->h_hi - key->h_lo, &t_h, ctx->ev_main));
+    FK_TRY(msm_g1_begin(ctx, key->d_h, d_h + key->h_lo, key->h_hi - key->h_lo, &t_h, ctx->ev_main, &key->pre_h));
     const int rc = witness_begin(ctx, key, d_z, d_a_aux, d_b_in, d_b_aux, ctx->ev_main);
     if (rc != FK_OK) { msm_abandon(ctx); return rc; }
     const double t2 = now_ms();
@@ -408,7 +419,7 @@ int fk_prove_msm_h_dev(fk_ctx *ctx, const fk_key *key, const void *d_h_slice, ui
     if (!key || !out || (!d_h_slice && key->h_hi > key->h_lo)) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "prove: null argument");
     FK_HIP(ctx, hipSetDevice(ctx->device));
     G1Xyzz H;
-    FK_TRY(msm_g1_dev(ctx, key->d_h, (const Fr *)d_h_slice, key->h_hi - key->h_lo, &H));
+    FK_TRY(msm_g1_dev(ctx, key->d_h, (const Fr *)d_h_slice, key->h_hi - key->h_lo, &H, &key->pre_h));
     g1_to_raw(out, H);
     return FK_OK;
 }
@@ -426,7 +437,7 @@ int fk_prove_msms_finish_dev(fk_ctx *ctx, const fk_key *key, const void *d_h_sli
     if (!key || !out || (!d_h_slice && key->h_hi > key->h_lo)) { msm_abandon(ctx); FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "prove: null argument"); }
     FK_HIP(ctx, hipSetDevice(ctx->device));
     int t_h = -1;
-    const int rc = msm_g1_begin(ctx, key->d_h, (const Fr *)d_h_slice, key->h_hi - key->h_lo, &t_h);
+    const int rc = msm_g1_begin(ctx, key->d_h, (const Fr *)d_h_slice, key->h_hi - key->h_lo, &t_h, nullptr, &key->pre_h);
     if (rc != FK_OK) { msm_abandon(ctx); return rc; }
     return witness_end(ctx, out, t_h);
 }

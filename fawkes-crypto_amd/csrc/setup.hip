@@ -456,6 +456,7 @@ static int setup_impl(fk_ctx *ctx, const fk_r1cs *cs, uint32_t copies, const uin
         if (rc2 == FK_OK) rc2 = shrink((void **)&k->d_b2, k->b_lo, k->b_hi, 128);
         if (rc2 != FK_OK) return fail(rc2, "setup: resharding failed");
     }
+    { const int rc3 = key_precompute(ctx, k); if (rc3 != FK_OK) { fk_key_free(ctx, k); return rc3; } }
     *out_key = k;
     return FK_OK;
 }

@@ -101,6 +101,13 @@ int fk_key_synthetic(fk_ctx *ctx, uint64_t m, uint32_t num_input, uint32_t num_a
                      double z_frac_lo, double z_frac_hi, fk_key **out);
 /* out[8] = h_lo, h_hi, l_lo, l_hi, a_lo, a_hi, b_lo, b_hi: the slices this key holds */
 int fk_key_shard_info(const fk_key *key, uint64_t out[8]);
+/* Fixed-base precomputation.  The key arrays are fixed bases, and an MI355X has room for more than the key: every
+ * loader (fk_key_load, fk_key_load_bellman, fk_setup*, fk_key_synthetic) also derives, HBM permitting, the multiples
+ * 2^(offset of window w) * P of each array it holds (W - 1 further copies, W = 11..15), so that the buckets of all
+ * Pippenger windows carry the same weights and a multiplication keeps ONE bucket set: one bucket reduction instead of
+ * W, and wider windows.  Same group elements, so the proof bytes do not change.  FK_MSM_PRECOMP=0 turns it off; an
+ * array whose levels do not fit simply keeps the ordinary path.  out[5] = levels held for h, l, a, b_g1, b_g2 (0 = none). */
+int fk_key_precomputed(const fk_key *key, uint32_t out[5]);
 /* Host-only key holding just the vk points fk_prove_assemble needs (no device memory, no GPU).
  * Free with fk_key_free(NULL, key). */
 int fk_key_host_vk(const uint8_t *alpha_g1, const uint8_t *beta_g1, const uint8_t *delta_g1,

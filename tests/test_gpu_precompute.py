@@ -1,0 +1,84 @@
+"""Fixed-base precomputation of the key (fk_key_precomputed; msm.hip: merged bucket set): with the window levels
+2^(offset_w) * P resident, all Pippenger windows share ONE bucket set.  Same group elements, so every proof must stay
+bit-identical to the oracle's.  By default only arrays of >= 2^24 points get levels; the tests lower the threshold
+(FK_MSM_PRE_MIN_LOG2) so that the merged path -- G1 and G2, oversized buckets included -- runs on small keys."""
+import numpy as np
+import pytest
+
+import bn254_ref as ref
+import fixtures as fx
+from helpers import params_from_oracle_key, r1cs_product, TOXIC
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def low_threshold(monkeypatch):
+    monkeypatch.setenv('FK_MSM_PRE_MIN_LOG2', '8')
+
+
+def _instance(oracle, seed, gates, nin, naux):
+    csr, z, z_in, z_aux = fx.fast_r1cs(seed, gates, nin, naux)
+    key = oracle.setup(csr, **TOXIC)
+    return csr, key, z, z_in
+
+
+@pytest.mark.parametrize('shape', [(31, 1500, 2, 1400), (32, 20000, 3, 21000), (33, 40000, 2, 36000)])
+def test_merged_path_bit_exact(ctx, oracle, low_threshold, shape):
+    """half of fast_r1cs's aux values are 0 / 1: the bucket of digit 1 is far over the cap, so the oversized-bucket path runs
+    in merged form too"""
+    csr, key, z, z_in = _instance(oracle, *shape)
+    params = params_from_oracle_key(key, r1cs_product(csr))
+    dk = ctx.load_key(params)
+    lev = dk.precomputed()
+    assert all(v > 1 for v in lev.values()), lev
+    dr = ctx.load_r1cs(params.r1cs)
+    r, s = fx.mont_fr(0x1234 + shape[0]), fx.mont_fr(0x4321)
+    a, b, c, aa, bi, ba = oracle.synthesize(csr, z)
+    want = oracle.prove(key, a, b, c, z, aa, bi, ba, r, s).tobytes()
+    assert ctx.prove_witness(dk, dr, z, r, s).tobytes() == want
+    assert ctx.prove_witness(dk, dr, z, r, s).tobytes() == want          # lanes reused
+    assert ref.verify(fx.key_to_py(key), z_in[1:], ref.proof_from_borsh(want))
+    # the GPU-generated key of the same system carries levels as well
+    dk2, _ = ctx.setup(params.r1cs, **{k: fx.mont_fr(v) for k, v in TOXIC.items()})
+    assert all(v > 1 for v in dk2.precomputed().values())
+    assert ctx.prove_witness(dk2, dr, z, r, s).tobytes() == want
+    dk2.free(); dr.free(); dk.free()
+
+
+def test_merged_shards_fold_to_the_same_proof(ctx, oracle, low_threshold):
+    csr, key, z, _ = _instance(oracle, 41, 6000, 3, 6500)
+    params = params_from_oracle_key(key, r1cs_product(csr))
+    r, s = fx.mont_fr(5), fx.mont_fr(6)
+    a, b, c, aa, bi, ba = oracle.synthesize(csr, z)
+    want = oracle.prove(key, a, b, c, z, aa, bi, ba, r, s).tobytes()
+    dk = ctx.load_key(params)
+    parts = []
+    for i in range(3):
+        sk = ctx.load_key(params, shard_index=i, shard_count=3)
+        assert all(v > 1 for v in sk.precomputed().values())
+        parts.append(ctx.prove_msms(sk, a, b, c, z, aa, bi, ba))
+        sk.free()
+    assert ctx.prove_assemble(dk, np.stack(parts), r, s).tobytes() == want
+    dk.free()
+
+
+def test_switches(ctx, oracle, monkeypatch):
+    csr, key, z, _ = _instance(oracle, 51, 3000, 2, 3100)
+    params = params_from_oracle_key(key, r1cs_product(csr))
+    dk = ctx.load_key(params)                       # default threshold: a key this small keeps the ordinary path
+    assert not any(dk.precomputed().values())
+    r, s = fx.mont_fr(9), fx.mont_fr(10)
+    a, b, c, aa, bi, ba = oracle.synthesize(csr, z)
+    want = ctx.prove_raw(dk, a, b, c, z, aa, bi, ba, r, s).tobytes()
+    assert want == oracle.prove(key, a, b, c, z, aa, bi, ba, r, s).tobytes()
+    monkeypatch.setenv('FK_MSM_PRE_MIN_LOG2', '8')
+    dk1 = ctx.load_key(params)
+    assert all(dk1.precomputed().values())
+    assert ctx.prove_raw(dk1, a, b, c, z, aa, bi, ba, r, s).tobytes() == want
+    monkeypatch.setenv('FK_MSM_PRECOMP', '0')
+    dk0 = ctx.load_key(params)
+    assert not any(dk0.precomputed().values())
+    assert ctx.prove_raw(dk0, a, b, c, z, aa, bi, ba, r, s).tobytes() == want
+    for k in (dk, dk0, dk1):
+        k.free()
