@@ -46,19 +46,21 @@ def traffic(fetch_dir, write_dir, log2n, points, out, proofs=1):
     wa, _ = per_kernel(load(write_dir))
     ks = sorted(fa, key=lambda k: -(fa[k]['FETCH_SIZE'] + wa.get(k, {}).get('WRITE_SIZE', 0)))
     per = [dict(kernel=k, launches=fl[k], FETCH_SIZE_KB=fa[k]['FETCH_SIZE'], WRITE_SIZE_KB=wa.get(k, {}).get('WRITE_SIZE', 0.0)) for k in ks[:24]]
-    dom = next(k for k in ks if k.startswith('msm_accumulate_kernel<Fp<FqParams'))
+    # the G1 accumulation: the merged form (fixed-base levels, one bucket set) when the key carries levels, else the W-set form
+    dom = next(k for k in ks if k.startswith(('msm_accumulate_merged_kernel<Fp<FqParams', 'msm_accumulate_kernel<Fp<FqParams')))
+    merged = dom.startswith('msm_accumulate_merged')
     j = dict(
         _doc='rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python3 bench.py --steps 1 --warmup 0 '
              '--no-cpu-baseline` (2^%d rows).  Counter units: KB (x1024 = bytes), summed over the launches of the whole pass (per_kernel); '
              'dominant_kernel is per proof.' % log2n,
         log2n=log2n, per_kernel=per,
         dominant_kernel=dict(
-            name='msm_accumulate_kernel<Fq>', launches_per_proof=fl[dom] // proofs, points_per_proof=points, proofs_in_the_pass=proofs,
+            name='msm_accumulate_merged_kernel<Fq>' if merged else 'msm_accumulate_kernel<Fq>', launches_per_proof=fl[dom] // proofs, points_per_proof=points, proofs_in_the_pass=proofs,
             fetch_bytes_per_proof_raw=fa[dom]['FETCH_SIZE'] * 1024 / proofs, write_bytes_per_proof=wa[dom]['WRITE_SIZE'] * 1024 / proofs,
-            note='WRITE_SIZE is exact (W*B XYZZ buckets of 128 B per launch).  FETCH_SIZE is reported RAW: the guide\'s x2 gfx950 '
+            note='WRITE_SIZE is exact (XYZZ buckets of 128 B: W*B per launch, B in the merged form).  FETCH_SIZE is reported RAW: the guide\'s x2 gfx950 '
                  'correction is calibrated for wide coalesced streams (it holds for ntt_pass_kernel in this same pass), while this '
-                 'kernel gathers 64-byte points at random 64-B-aligned addresses -- an uncalibrated width.  Expected demand: 13 windows x '
-                 '(64 B point + 4 B index) = 884 B per non-trivial point.  Traffic is several times the 96 B/point algorithmic bytes '
+                 'kernel gathers 64-byte points at random 64-B-aligned addresses -- an uncalibrated width.  Expected demand: W (12-13) windows x '
+                 '(64 B point + 4 B index), about 850 B per non-trivial point.  Traffic is several times the 96 B/point algorithmic bytes '
                  'because Pippenger re-gathers every base once per window; the rate stays far below HBM peak: the kernel is VALU-bound.'))
     json.dump(j, open(out, 'w'), indent=1)
     print('wrote', out, 'dominant fetch GB', fa[dom]['FETCH_SIZE'] * 1024 / 1e9)
