@@ -406,7 +406,9 @@ def main():
                           'the GPU proof of the same sample matched byte for byte' % (args.cpu_log2n, cpu_s, scale, args.log2n),
                 'sample_seconds': cpu_s,
             }
-        print(json.dumps(out), flush=True)
+        line = json.dumps(out)
+    else:
+        line = None
 
     dr.free()
     key.free()
@@ -414,6 +416,13 @@ def main():
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
+    if line is not None:
+        # the JSON line is the LAST thing on stdout: native libraries (RCCL's version banner) write through C stdio, whose
+        # buffer would otherwise be flushed behind it at exit
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        print(line, flush=True)
 
 
 if __name__ == '__main__':

@@ -19,6 +19,7 @@ def _run(extra_env, *args):
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1, out.stdout[-2000:]
+    assert out.stdout.strip().splitlines()[-1] == lines[0], 'the JSON line must be the last line on stdout: ' + out.stdout[-500:]
     return json.loads(lines[0])
 
 

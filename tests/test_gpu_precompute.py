@@ -82,3 +82,23 @@ def test_switches(ctx, oracle, monkeypatch):
     assert ctx.prove_raw(dk0, a, b, c, z, aa, bi, ba, r, s).tobytes() == want
     for k in (dk, dk0, dk1):
         k.free()
+
+
+def test_merged_sharded_setup_and_weighted_shards(ctx, oracle, low_threshold):
+    """keys made by fk_setup for a shard (the bench's multi-GPU path), by points and by weighted witness fractions"""
+    csr, key, z, _ = _instance(oracle, 61, 5000, 2, 5200)
+    r1cs = r1cs_product(csr)
+    tox = {k: fx.mont_fr(v) for k, v in TOXIC.items()}
+    r, s = fx.mont_fr(21), fx.mont_fr(22)
+    a, b, c, aa, bi, ba = oracle.synthesize(csr, z)
+    want = oracle.prove(key, a, b, c, z, aa, bi, ba, r, s).tobytes()
+    dk, _ = ctx.setup(r1cs, **tox)
+    for fracs in (None, [(0.0, 0.3), (0.3, 0.55), (0.55, 1.0)]):
+        parts = []
+        for i in range(3):
+            sk, _ = ctx.setup(r1cs, shard_index=i, shard_count=3, z_frac=fracs[i] if fracs else (0.0, 0.0), **tox)
+            assert sk.precomputed()['h'] > 1
+            parts.append(ctx.prove_msms(sk, a, b, c, z, aa, bi, ba))
+            sk.free()
+        assert ctx.prove_assemble(dk, np.stack(parts), r, s).tobytes() == want
+    dk.free()
