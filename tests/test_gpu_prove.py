@@ -219,3 +219,31 @@ def test_repeated_proofs_are_deterministic(ctx, oracle):
         assert ctx.prove_witness(dk, dr, z, r, s).tobytes() == want, it
     for dk, dr, *_ in cases:
         dr.free(); dk.free()
+
+
+def test_two_contexts_prove_concurrently_from_one_key(ctx, oracle):
+    """A proving service keeps the device busy with several contexts (own streams and scratch) in as many host threads; the
+    key and the resident constraint system are plain read-only device memory and are shared.  Same bytes from every thread."""
+    import threading
+    import fawkes_crypto_amd as fk
+    csr, z, _, _ = fx.fast_r1cs(91, 30000, 2, 31000)
+    r1cs = r1cs_product(csr)
+    dk, _ = ctx.setup(r1cs, **{k: fx.mont_fr(v) for k, v in TOXIC.items()})
+    dr = ctx.load_r1cs(r1cs)
+    r, s = fx.mont_fr(31), fx.mont_fr(32)
+    want = ctx.prove_witness(dk, dr, z, r, s).tobytes()
+    others = [fk.Context(0) for _ in range(2)]
+    got = {}
+
+    def work(i, c):
+        got[i] = [c.prove_witness(dk, dr, z, r, s).tobytes() for _ in range(6)]
+
+    th = [threading.Thread(target=work, args=(i, c)) for i, c in enumerate([ctx] + others)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert len(got) == 3 and all(p == want for v in got.values() for p in v)
+    for c in others:
+        c.close()
+    dr.free(); dk.free()
