@@ -94,7 +94,7 @@ static MsmPlan make_plan(size_t n, unsigned forced_c, bool merged = false) {
     // neutral-to-worse: the reduction already runs underneath the next multiplication.  FK_MSM_RED_L overrides (tuning).
     static int t_redl = -1;
     if (t_redl < 0) { const char *e = getenv("FK_MSM_RED_L"); t_redl = e ? atoi(e) : 0; }
-    p.L = p.B >= 4096 ? (p.B >= (1u << 18) ? 64 : p.B / 2048) : 1;
+    p.L = p.B >= (1u << 18) ? 64 : (p.B >= (1u << 17) ? p.B / 2048 : (p.B >= 8192 ? p.B / 4096 : 1));      // 2^16 buckets: 16 per lane (32: 2^20 13.0 -> 12.0 ms per proof, 8: 15.4); 2^17: 64 (32: 2^23 44.1 -> 45.1)
     if (t_redl > 0 && (uint32_t)t_redl <= p.B) p.L = (uint32_t)t_redl;
     p.T = p.B / p.L;
     p.nblk = (p.T + 255) / 256;
