@@ -560,14 +560,42 @@ __global__ __launch_bounds__(256) void msm_merge_totals_kernel(const uint32_t *t
     for (uint32_t w = 0; w < W; w++) { const uint32_t v = totals[(size_t)w * B + b]; s += v < cap ? v : cap; }
     mt[b] = s;
 }
-// level w+1 = 2^bits * level w, affine in, affine out
+// level w+1 = 2^bits * level w, affine in, affine out.  NB (4 for G1, 2 for G2: registers) points per lane share one
+// inversion (Montgomery's trick on the products zz * zzz; a point at infinity takes part with the factor 1) and their
+// doubling chains run in step.  Written without arrays: a dynamically indexed array of points would live in scratch.
 template <class F>
+static __device__ __forceinline__ Xyzz<F> level_load(const Affine<F> *in, size_t i, size_t n) { return i < n ? Xyzz<F>::from_affine(in[i]) : Xyzz<F>::inf(); }
+template <class F>
+static __device__ __forceinline__ F level_den(const Xyzz<F> &p) { return p.is_inf() ? F::one() : F::mul(p.zz, p.zzz); }
+template <class F>
+static __device__ __forceinline__ void level_store(Affine<F> *out, size_t i, size_t n, const Xyzz<F> &p, const F &ti) {      // ti = 1 / (zz zzz)
+    if (i < n) out[i] = p.is_inf() ? Affine<F>::inf() : Affine<F>{F::mul(p.x, F::mul(ti, p.zzz)), F::mul(p.y, F::mul(ti, p.zz))};
+}
+template <class F, int NB>
 __global__ __launch_bounds__(256) void msm_level_kernel(const Affine<F> *in, size_t n, uint32_t bits, Affine<F> *out) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    Xyzz<F> p = Xyzz<F>::from_affine(in[i]);
-    for (uint32_t k = 0; k < bits; k++) p = Xyzz<F>::dbl(p);
-    out[i] = p.to_affine();
+    const size_t i0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * NB;
+    if (i0 >= n) return;
+    Xyzz<F> p0 = level_load(in, i0, n), p1 = level_load(in, i0 + 1, n), p2 = Xyzz<F>::inf(), p3 = Xyzz<F>::inf();
+    if (NB == 4) { p2 = level_load(in, i0 + 2, n); p3 = level_load(in, i0 + 3, n); }
+    for (uint32_t k = 0; k < bits; k++) {
+        p0 = Xyzz<F>::dbl(p0); p1 = Xyzz<F>::dbl(p1);
+        if (NB == 4) { p2 = Xyzz<F>::dbl(p2); p3 = Xyzz<F>::dbl(p3); }
+    }
+    const F t0 = level_den(p0), t1 = level_den(p1);
+    const F pre2 = F::mul(t0, t1);
+    if (NB == 4) {
+        const F t2 = level_den(p2), t3 = level_den(p3);
+        const F pre3 = F::mul(pre2, t2);
+        F inv = F::inv(F::mul(pre3, t3));
+        level_store(out, i0 + 3, n, p3, F::mul(inv, pre3)); inv = F::mul(inv, t3);
+        level_store(out, i0 + 2, n, p2, F::mul(inv, pre2)); inv = F::mul(inv, t2);
+        level_store(out, i0 + 1, n, p1, F::mul(inv, t0)); inv = F::mul(inv, t1);
+        level_store(out, i0, n, p0, inv);
+    } else {
+        F inv = F::inv(pre2);
+        level_store(out, i0 + 1, n, p1, F::mul(inv, t0)); inv = F::mul(inv, t1);
+        level_store(out, i0, n, p0, inv);
+    }
 }
 
 struct Task { uint32_t g, seg; };
@@ -1000,7 +1028,8 @@ static int precompute_levels(fk_ctx *ctx, const Affine<F> *d_bases, size_t n, Ke
     for (uint32_t w = 1; w < p.W; w++) {
         Affine<F> *cur = (Affine<F> *)lev + (size_t)(w - 1) * n;
         const uint32_t bits = p.cb + ((w - 1) < p.wide ? 1 : 0);       // width of window w-1
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_level_kernel<F>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, prev, n, bits, cur);
+        constexpr int NB = sizeof(F) == sizeof(Fq) ? 4 : 2;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_level_kernel<F, NB>), dim3((unsigned)(((n + NB - 1) / NB + 255) / 256)), dim3(256), 0, ctx->stream, prev, n, bits, cur);
         prev = cur;
     }
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { (void)hipFree(lev); FK_SET_ERR(ctx, FK_ERR_HIP, "msm: level precomputation failed"); }
