@@ -379,7 +379,9 @@ def main():
                 'msm_accumulate_g1': stats['acc_g1']['ms'] / args.steps,
                 'msm_accumulate_g2': stats['acc_g2']['ms'] / args.steps,
                 'ntt_passes': stats['ntt']['ms'] / args.steps,
+                # one launch = one pass over 2^log2n elements, 64 B (read + write) each; a transform is ceil(log2n / 9) passes
                 'ntt_algorithmic_GBps': (stats['ntt']['units'] * 64) / (stats['ntt']['ms'] * 1e-3) / 1e9 if stats['ntt']['ms'] > 0 else 0.0,
+                'ntt_GBps_is': 'data moved per pass (64 B per element per pass)',
             },
             'prep_seconds': prep_s,
         }

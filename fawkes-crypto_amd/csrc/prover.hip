@@ -393,7 +393,7 @@ static int prove_msms_dev(fk_ctx *ctx, const fk_key *key, Fr *d_a, Fr *d_b, Fr *
     // Single GPU: the multiplications start after the quotient.  Running the witness multiplications underneath it was
     // measured (2^20 .. 2^25): both sides are VALU-bound, nothing is gained at 2^25 and 10 % is lost at 2^20 / 2^22.  So was
     // running only their SORTS underneath it, accumulations held back until it is done: 2^25 139.5 -> 148.1 ms, 2^22 29.2 -> 34.0
-    // (the B pair's sort alone: 138.6 -> 152.0 ms) -- the NTT passes move 3.8 TB/s and are not indifferent to a sort's traffic.
+    // (the B pair's sort alone: 138.6 -> 152.0 ms) -- an NTT pass moves 2.2 TB/s and holds 64 KB of LDS per workgroup, which the sort's workgroups compete for.
     if (!ctx->ev_main) FK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_main, hipEventDisableTiming));
     FK_HIP(ctx, hipEventRecord(ctx->ev_main, ctx->stream));
     // H first: it is the longest accumulation and hides the sorts of the multiplications behind it (B1, B2, H, L, A -- H after
