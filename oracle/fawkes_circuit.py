@@ -744,3 +744,35 @@ def eddsa_circuit(sk, m, rho, pparams=None, jj=None):
     ok = c_eddsaposeidon_verify(c_s, c_r, c_a, c_m, pparams, jj)
     c_assert_const(ok, 1)
     return cs, (s, r_x, a_x)
+
+
+# =========================================================================== BASELINE configs[3]: a rollup-style transaction
+# NOT a circuit of the reference (its rollup lives in other repositories; the README only quotes its size): a transaction
+# gadget COMPOSED from the reference's own gadgets restated above, so that "rollup-style R1CS (1024-tx shape)" can be
+# exercised with real linear combinations instead of gate statistics.  One transaction updates one account leaf:
+#   leaf_old = poseidon(a_x, bal_old), leaf_new = poseidon(a_x, bal_new)
+#   merkle(leaf_old, sibling, path) == old_root (public);  merkle(leaf_new, sibling, path) == new_root (public)
+#   the owner's eddsa-poseidon signature (s, r) under a_x over the message leaf_new verifies.
+def rollup_tx_circuit(sk, bal_old, bal_new, sibling, path, rho, depth=32):
+    """Returns the CS of one transaction (2 public inputs besides ONE: old_root, new_root)."""
+    assert len(sibling) == depth and len(path) == depth
+    p3, p4, jj = PoseidonParams(3, 8, 53), PoseidonParams(4, 8, 54), JubJubBN256()
+    a_x = jj.mul(jj.g, sk)[0]
+    leaf_old, leaf_new = poseidon([a_x, bal_old], p3), poseidon([a_x, bal_new], p3)
+    old_root = poseidon_merkle_proof_root(leaf_old, sibling, path, p3)
+    new_root = poseidon_merkle_proof_root(leaf_new, sibling, path, p3)
+    s, r_x, a_chk = eddsaposeidon_sign(sk, leaf_new, rho, p4, jj)
+    assert a_chk == a_x
+    cs = CS()
+    c_old_root, c_new_root = cs.alloc(old_root), cs.alloc(new_root)
+    cs.inputize(c_old_root)
+    cs.inputize(c_new_root)
+    c_a, c_bo, c_bn = cs.alloc(a_x), cs.alloc(bal_old), cs.alloc(bal_new)
+    c_sib = [cs.alloc(v) for v in sibling]
+    c_path = [alloc_bool(cs, p) for p in path]
+    c_leaf_old, c_leaf_new = c_poseidon([c_a, c_bo], p3), c_poseidon([c_a, c_bn], p3)
+    c_poseidon_merkle_proof_root(c_leaf_old, c_sib, c_path, p3).assert_eq(c_old_root)
+    c_poseidon_merkle_proof_root(c_leaf_new, c_sib, c_path, p3).assert_eq(c_new_root)
+    c_s, c_r = cs.alloc(s), cs.alloc(r_x)
+    c_assert_const(c_eddsaposeidon_verify(c_s, c_r, c_a, c_leaf_new, p4, jj), 1)
+    return cs

@@ -212,3 +212,16 @@ def test_eddsa_golden_matches_oracle(oracle):
     proof = oracle.prove(key, a, b, c, z, aa, bi, ba, fx.mont_fr(int(g['r'], 16)), fx.mont_fr(int(g['s'], 16)))
     assert proof.tobytes().hex() == g['proof']
     assert ref.verify(fx.key_to_py(key), [int(g['m'], 16)], ref.proof_from_borsh(proof.tobytes()))
+
+
+def test_rollup_style_transaction_gadget():
+    """the composed transaction (two depth-32 merkle proofs over one sibling path + one eddsa signature, rollup_tx_circuit):
+    satisfied, witness-independent structure, and a wrong balance breaks it"""
+    rnd = random.Random(33)
+    mk = lambda: fc.rollup_tx_circuit(rnd.randrange(fc.FS), rnd.randrange(1 << 40), rnd.randrange(1 << 40), [rnd.randrange(ref.R) for _ in range(32)],
+                                      [rnd.randrange(2) for _ in range(32)], rnd.randrange(fc.FS))
+    a, b = mk(), mk()
+    assert len(a.gates) == 19270 and a.num_input == 3 and a.num_aux == 19298 and a.satisfied() and b.satisfied()
+    assert [[[v for _, v in lc] for lc in g] for g in a.gates] == [[[v for _, v in lc] for lc in g] for g in b.gates]
+    a.z_aux[3] = (a.z_aux[3] + 1) % ref.R          # bal_old
+    assert not a.satisfied()

@@ -138,3 +138,26 @@ def test_config2_full_batch_4096_signatures(ctx, signatures):
     public[1234] = signatures[(picks[1234] + 1) % 3].z_in[1]
     assert not ref.verify(pk, public, P)
     dr.free(); dk.free()
+
+
+def test_rollup_style_transactions_tiled_equals_oracle(ctx, oracle):
+    """BASELINE configs[3]'s "1024-tx shape" with real gadgets (oracle/fawkes_circuit.py: rollup_tx_circuit, 19270 gates and
+    942 k matrix terms per transaction): 3 distinct transactions as one tiled system, proof == the oracle's proof of the
+    replicated system, and it verifies against the 6 public roots"""
+    rnd = random.Random(2025)
+    txs = [fc.rollup_tx_circuit(rnd.randrange(fc.FS), 500 + k, 400 + k, [rnd.randrange(ref.R) for _ in range(32)], [rnd.randrange(2) for _ in range(32)],
+                                rnd.randrange(fc.FS)) for k in range(3)]
+    one = fx.r1cs_to_csr(txs[0].r1cs())
+    zs = [fx.witness_mont(c.z_in, c.z_aux) for c in txs]
+    z = _tile_z(zs, one.num_input, [0, 1, 2])
+    base_p = r1cs_product(one)
+    dk, vk = ctx.setup(base_p, copies=3, **TOX)
+    dr = ctx.load_r1cs(base_p, copies=3)
+    r, s = fx.mont_fr(0x70110), fx.mont_fr(0x7a)
+    got = ctx.prove_witness(dk, dr, z, r, s)
+    batch = fx.tile_r1cs(one, 3)
+    okey = oracle.setup(batch, **TOXIC)
+    a, b, c, aa, bi, ba = oracle.synthesize(batch, z)
+    assert got.tobytes() == oracle.prove(okey, a, b, c, z, aa, bi, ba, r, s).tobytes()
+    assert ref.verify(fx.key_to_py(okey), [v for c_ in txs for v in c_.z_in[1:]], ref.proof_from_borsh(got.tobytes()))
+    dr.free(); dk.free()
