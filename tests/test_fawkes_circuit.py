@@ -225,3 +225,25 @@ def test_rollup_style_transaction_gadget():
     assert [[[v for _, v in lc] for lc in g] for g in a.gates] == [[[v for _, v in lc] for lc in g] for g in b.gates]
     a.z_aux[3] = (a.z_aux[3] + 1) % ref.R          # bal_old
     assert not a.satisfied()
+
+
+def _golden_rollup_tx():
+    g = golden('rollup_tx_golden.json')
+    rnd = random.Random(g['seed'])
+    sibling, path = [rnd.randrange(ref.R) for _ in range(32)], [rnd.randrange(2) for _ in range(32)]
+    return g, fc.rollup_tx_circuit(int(g['sk'], 16), g['bal_old'], g['bal_new'], sibling, path, int(g['rho'], 16))
+
+
+def test_rollup_tx_golden_matches_oracle(oracle):
+    from fawkes_crypto_amd import params_io
+    from helpers import r1cs_product
+    g, cs = _golden_rollup_tx()
+    assert ('%064x' % cs.z_in[1], '%064x' % cs.z_in[2]) == (g['old_root'], g['new_root']) and len(cs.gates) == g['num_gates']
+    csr = fx.r1cs_to_csr(cs.r1cs())
+    assert hashlib.sha256(params_io.encode_gate_stream(r1cs_product(csr))).hexdigest() == g['gate_stream_sha256']
+    key = oracle.setup(csr, **TOXIC)
+    z = fx.witness_mont(cs.z_in, cs.z_aux)
+    a, b, c, aa, bi, ba = oracle.synthesize(csr, z)
+    assert int(aa.sum()) == g['a_aux_density'] and int(ba.sum()) == g['b_aux_density']
+    proof = oracle.prove(key, a, b, c, z, aa, bi, ba, fx.mont_fr(int(g['r'], 16)), fx.mont_fr(int(g['s'], 16)))
+    assert proof.tobytes().hex() == g['proof']

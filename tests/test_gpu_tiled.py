@@ -161,3 +161,20 @@ def test_rollup_style_transactions_tiled_equals_oracle(ctx, oracle):
     assert got.tobytes() == oracle.prove(okey, a, b, c, z, aa, bi, ba, r, s).tobytes()
     assert ref.verify(fx.key_to_py(okey), [v for c_ in txs for v in c_.z_in[1:]], ref.proof_from_borsh(got.tobytes()))
     dr.free(); dk.free()
+
+
+def test_rollup_tx_golden_proof(ctx):
+    """the committed golden vector (tests/golden/rollup_tx_golden.json, made by the C oracle): GPU setup + proof bytes of one
+    rollup-style transaction for fixed inputs and fixed (r, s) -- 19270 gates, 942 k matrix terms through the length-class SpMV"""
+    from helpers import golden
+    g = golden('rollup_tx_golden.json')
+    rnd = random.Random(g['seed'])
+    sibling, path = [rnd.randrange(ref.R) for _ in range(32)], [rnd.randrange(2) for _ in range(32)]
+    cs = fc.rollup_tx_circuit(int(g['sk'], 16), g['bal_old'], g['bal_new'], sibling, path, int(g['rho'], 16))
+    assert '%064x' % cs.z_in[1] == g['old_root'] and len(cs.gates) == g['num_gates']
+    r1cs = r1cs_product(fx.r1cs_to_csr(cs.r1cs()))
+    dk, _ = ctx.setup(r1cs, **TOX)
+    dr = ctx.load_r1cs(r1cs)
+    got = ctx.prove_witness(dk, dr, fx.witness_mont(cs.z_in, cs.z_aux), fx.mont_fr(int(g['r'], 16)), fx.mont_fr(int(g['s'], 16)))
+    assert got.tobytes().hex() == g['proof']
+    dr.free(); dk.free()
