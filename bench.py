@@ -2,14 +2,23 @@
 """
 bench.py -- Groth16 proofs/sec on MI355X through the C ABI (include/fawkes_hip.h).
 
-One "step" = one complete Groth16 proof for a satisfiable rollup-shaped BN254 R1CS of 2^LOG2 rows (default
-2^25, the size BASELINE.json's metric is quoted on), starting from the WITNESS VECTOR: device SpMV
-(a = Az, b = Bz, c = Cz), the 7-NTT quotient, the four G1 MSMs (H, L, A, B1), the G2 MSM (B2) and the
-proof assembly -- the work behind `create_random_proof`
-(/root/reference/fawkes-crypto/src/backend/bellman_groth16/prover.rs:80), including bellman's `synthesize`
-evaluation (mod.rs:92-99).  The witness, the constraint system and the proving key are resident in HBM before
-the timed region.  The key is a VALID key (fk_setup, fixed toxic waste), so the proof produced in the timed
-region is checked afterwards with the Groth16 pairing equation.
+One "step" = one complete Groth16 proof on the 2^25 evaluation domain BASELINE.json's metric is quoted on, starting from
+the WITNESS VECTOR IN HOST MEMORY -- what prover.rs:69-80 hands to `create_random_proof`
+(/root/reference/fawkes-crypto/src/backend/bellman_groth16/prover.rs:80): upload of the witness, device SpMV (a = Az,
+b = Bz, c = Cz; bellman's `synthesize` evaluation, mod.rs:92-99), the 7-NTT quotient, the four G1 MSMs (H, L, A, B1),
+the G2 MSM (B2) and the proof assembly.  The constraint system and the proving key are resident in HBM; the witness is
+handed over per proof from pinned host memory through the two-slot pipeline of the C ABI (fk_prove_r1cs_submit / _wait:
+the upload of proof k+1 runs underneath proof k), so K steps contain K uploads and K proofs.  The same proof with the
+witness already resident in HBM is reported beside it (`device_resident_ms_per_step`).
+
+Default workload (`--workload rollup1024`): BASELINE configs[3]'s "1024-tx shape" with real gadgets -- 1024 rollup-style
+transactions (two depth-32 poseidon merkle proofs + one eddsa-poseidon signature each, 19 270 gates and 942 k matrix
+terms per transaction) as ONE R1CS of 19.7 M gates / 9.6e8 matrix terms through fk_setup_tiled / fk_r1cs_load_tiled.  The
+transaction comes from the committed data fixture tests/golden/rollup_tx_instance.npz (made by
+tests/golden/make_rollup_tx_fixture.py; the circuit builder itself is oracle-side and is NOT imported here).
+`--workload synthetic` is the round-1 shape (1-2 term rows, m = 2^LOG2 exactly; `--lc-terms` for longer combinations).
+The key is a VALID key (fk_setup*, fixed toxic waste), so the proof produced in the timed region is checked afterwards
+with the Groth16 pairing equation.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -22,8 +31,9 @@ folded locally (fawkes-crypto_amd/parallel.py: prove_distributed_dev).  With 2 r
 power of two, rank 0 computes the quotient while the other ranks start on the witness MSMs, and h slices travel point
 to point (prove_balanced_dev); FK_DIST_QUOTIENT=1 / 0 forces either schedule.
 
-The CPU oracle (oracle/) appears here only in the `cpu_baseline` leg: the timed CPU baseline, a live parity
-check of that same sample, and the pairing check of the benchmarked proof; it is never the thing measured.
+The CPU oracle (oracle/) appears here only in the `cpu_baseline` leg: the timed CPU baseline (one thread = the
+reference's configured worker, and all host cores = bellman's multicore split), a live parity check of that same
+sample, and the pairing check of the benchmarked proof; it is never the thing measured.
 """
 import argparse
 import json
@@ -38,6 +48,9 @@ for p in (ROOT, os.path.join(ROOT, 'oracle'), os.path.join(ROOT, 'tests')):
 
 import numpy as np  # noqa: E402
 
+MUL_PIPE_OPS_PER_MODMUL = 136    # 8 x 8 products + 8 x 8 reduction products (v_mad_u64_u32) + 8 x (lo * INV) (v_mul_lo_u32): the fewest
+                                 # 32-bit multiplier operations of a 256-bit Montgomery product
+MODMUL_PER_G1_MIXED_ADD = 10     # XYZZ mixed addition: 8 M + 2 S (csrc/curve.hpp)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 achievable
 G1_BYTES_PER_SCALAR_MUL = 96     # 64 B affine base + 32 B scalar
 FR_MODULUS = 21888242871839275222246405745257275088548364400416034343698204186575808495617
@@ -165,41 +178,95 @@ def build_workload_dense(ctx, fk, log2n, terms, seed=2026):
     return r1cs, z
 
 
-def cpu_baseline_leg(ctx, fk, log2_sample, full):
-    """(1) times the C oracle (bellman's algorithm restated, single thread = the reference's configured worker,
-    SURVEY fact 3) proving a 2^log2_sample instance of the same workload family; (2) the GPU proof of that same
-    sample must match byte for byte; (3) the benchmarked full-size proof must satisfy the pairing equation."""
-    import bn254_ref as ref
+def load_rollup_instance(path=None):
+    """ONE rollup-style transaction from the committed data fixture: (fk.R1cs, witnesses (k, nv, 4) uint64 Montgomery)."""
+    import fawkes_crypto_amd as fk
+    d = np.load(path or os.path.join(ROOT, 'tests', 'golden', 'rollup_tx_instance.npz'))
+    table = d['table']
+    mats = [(d[nm + '_ptr'].astype(np.uint64), d[nm + '_col'], table[d[nm + '_cidx']]) for nm in 'abc']
+    return fk.R1cs(int(d['num_input']), int(d['num_aux']), *mats), np.ascontiguousarray(d['z'])
+
+
+def tile_witness(zs, num_input, copies, out=None):
+    """witness of `copies` instances as one system, fk_r1cs_load_tiled's variable order: ONE, every copy's inputs, every
+    copy's aux; copy j carries witness j mod len(zs)."""
+    k, ni1, naux = len(zs), num_input - 1, zs.shape[1] - num_input
+    nv = 1 + copies * (ni1 + naux)
+    out = np.empty((nv, 4), np.uint64) if out is None else out
+    assert out.shape == (nv, 4)
+    out[0] = zs[0][0]
+    ins = out[1:1 + copies * ni1].reshape(copies, ni1, 4)
+    aux = out[1 + copies * ni1:].reshape(copies, naux, 4)
+    for j in range(k):
+        ins[j::k] = zs[j][1:num_input]
+        aux[j::k] = zs[j][num_input:]
+    return out
+
+
+def oracle_key(dk, vk, m, num_input, num_aux):
     import c_oracle as co
-    r1cs, z = build_workload(ctx, fk, log2_sample, seed=77)
+    return co.ArrayKey(m, num_input, num_aux, vk, dk.download('h'), dk.download('l'), dk.download('a'), dk.download('b_g1'),
+                       dk.download('b_g2'), ic=vk['ic'])
+
+
+def cpu_baseline_leg(ctx, fk, args):
+    """Times the C oracle (bellman's algorithm restated: oracle/groth16_oracle.c) on a bounded sample of the SAME workload
+    family -- synthesis (bellman's serial `synthesize` evaluation) + create_proof -- with ONE thread (the worker fawkes-crypto
+    configures) and with ALL host cores (bellman's multicore split restated: parallel_fft, one task per
+    multiexp region); the GPU proof of that same sample must match byte for byte."""
+    import c_oracle as co
+    import fixtures as fx
+    cores = os.cpu_count() or 1
     tox = {k: mont(v) for k, v in TOXIC.items()}
-    dk, vk = ctx.setup(r1cs, **tox)
-    okey = co.ArrayKey(1 << log2_sample, r1cs.num_input, r1cs.num_aux, vk, dk.download('h'), dk.download('l'), dk.download('a'),
-                       dk.download('b_g1'), dk.download('b_g2'), ic=vk['ic'])
-    a, b, c, aa, bi, ba = fk.api.synthesize(r1cs, z)
     r, s = mont(0x1234567), mont(0x89abcdef)
-    t0 = time.time()
-    want = co.prove(okey, a, b, c, z, aa, bi, ba, r, s)
-    cpu_s = time.time() - t0
-    dr = ctx.load_r1cs(r1cs)
+    if args.workload == 'rollup1024':
+        inst, zs = load_rollup_instance()
+        copies = args.cpu_copies
+        z = tile_witness(zs, inst.num_input, copies)
+        dk, vk = ctx.setup(inst, copies=copies, **tox)
+        dr = ctx.load_r1cs(inst, copies=copies)
+        one = co.R1csC(inst.num_input, inst.num_aux, *[co.Csr(p_, c_, v_) for p_, c_, v_ in inst.mats])
+        csr = fx.tile_r1cs(one, copies)          # the oracle proves the explicitly replicated system
+        what = '%d rollup-style transactions as one R1CS' % copies
+        scale = args.copies / copies
+    else:
+        r1cs, z = build_workload(ctx, fk, args.cpu_log2n, seed=77)
+        dk, vk = ctx.setup(r1cs, **tox)
+        dr = ctx.load_r1cs(r1cs)
+        csr = co.R1csC(r1cs.num_input, r1cs.num_aux, *[co.Csr(p_, c_, v_ if v_ is not None else np.tile(mont(1), (len(c_), 1))) for p_, c_, v_ in r1cs.mats])
+        what = 'a 2^%d-row instance of the same synthetic family' % args.cpu_log2n
+        scale = (1 << args.log2n) / (1 << args.cpu_log2n)
+    cnt = dk.counts()
+    okey = oracle_key(dk, vk, cnt['m'], cnt['num_input'], cnt['num_aux'])
     got = ctx.prove_witness(dk, dr, z, r, s)
     dr.free(); dk.free()
-    if got.tobytes() != want.tobytes():
-        raise AssertionError('bench parity check failed: HIP proof != oracle proof on the CPU-baseline sample')
-    verified = pairing_check(*full) if full is not None else None
-    return cpu_s, 1 << log2_sample, verified
+    t0 = time.time()
+    a, b, c, aa, bi, ba = co.synthesize(csr, z)
+    synth_s = time.time() - t0
+    times = {}
+    for th in ([cores, 1] if cores > 1 else [1]):
+        t0 = time.time()
+        want = co.prove(okey, a, b, c, z, aa, bi, ba, r, s, threads=th)
+        times[th] = time.time() - t0
+        if got.tobytes() != want.tobytes():
+            raise AssertionError('bench parity check failed: HIP proof != oracle proof (%d threads) on the CPU-baseline sample' % th)
+    return dict(what=what, scale=scale, cores=cores, synth_s=synth_s, prove_s=times, log2_m=int(cnt['m']).bit_length() - 1)
 
 
-def pairing_check(vk_full, z_in1, proof):
-    """the benchmarked proof must satisfy the Groth16 pairing equation (checker: oracle/bn254_ref.py verifier)"""
+def pairing_check(vk_full, z_inputs, proof):
+    """the benchmarked proof must satisfy the Groth16 pairing equation (checker: oracle/bn254_ref.py verifier; the public
+    inputs -- 2048 roots for the 1024-transaction system -- are folded into one point by the C oracle's multiexp first)"""
     import bn254_ref as ref
+    import c_oracle as co
     g1 = lambda b_: ref.g1_from_raw_le(bytes(b_))
     g2 = lambda b_: ref.g2_from_raw_le(bytes(b_))
+    ic = np.ascontiguousarray(vk_full['ic'], np.uint8).reshape(-1, 64)
+    z_inputs = np.ascontiguousarray(z_inputs, np.uint64).reshape(-1, 4)
+    assert len(z_inputs) + 1 == len(ic)
+    acc = co.g1_add(ic[0], co.msm_g1(ic[1:], z_inputs)) if len(z_inputs) else ic[0]
     pk = dict(alpha_g1=g1(vk_full['alpha_g1']), beta_g2=g2(vk_full['beta_g2']), gamma_g2=g2(vk_full['gamma_g2']),
-              delta_g2=g2(vk_full['delta_g2']), ic=[g1(x.tobytes()) for x in vk_full['ic']])
-    Rinv = pow(MONT_R, -1, FR_MODULUS)
-    pub = [int.from_bytes(z_in1.tobytes(), 'little') * Rinv % FR_MODULUS]
-    if not ref.verify(pk, pub, ref.proof_from_borsh(proof)):
+              delta_g2=g2(vk_full['delta_g2']), ic=[g1(acc)])
+    if not ref.verify(pk, [], ref.proof_from_borsh(proof)):
         raise AssertionError('bench: the benchmarked proof does not satisfy the Groth16 pairing equation')
     return True
 
@@ -207,13 +274,16 @@ def pairing_check(vk_full, z_in1, proof):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--lc-terms', type=int, default=0, help='operands per side of every product gate (default: the 1-2 term rollup shape); '
-                                                             'e.g. 16 gives the long linear combinations real circuits have')
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--log2n', type=int, default=25, help='log2 of the row count handed to the prover')
-    ap.add_argument('--cpu-log2n', type=int, default=20, help='size of the CPU-baseline sample instance')
+    ap.add_argument('--workload', choices=('rollup1024', 'synthetic'), default='rollup1024')
+    ap.add_argument('--copies', type=int, default=1024, help='rollup1024: transactions in the one R1CS (1024 -> 19.7 M gates, domain 2^25)')
+    ap.add_argument('--lc-terms', type=int, default=0, help='synthetic: operands per side of every product gate (default: the 1-2 term shape)')
+    ap.add_argument('--log2n', type=int, default=25, help='synthetic: log2 of the row count handed to the prover')
+    ap.add_argument('--cpu-log2n', type=int, default=20, help='synthetic: size of the CPU-baseline sample instance')
+    ap.add_argument('--cpu-copies', type=int, default=32, help='rollup1024: transactions in the CPU-baseline sample (32 -> domain 2^20)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-replicas', action='store_true', help='N > 1: skip the one-proof-per-GPU throughput leg')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend ('nccl' = RCCL; 'gloo' only for single-GPU dry runs of the N>1 code path with FK_BENCH_SAME_DEVICE=1)")
     args = ap.parse_args()
 
@@ -248,11 +318,31 @@ def main():
 
     # ---------------------------------------------------------------- workload: constraint system, witness, valid key
     t_prep = time.time()
-    m = 1 << args.log2n
-    r1cs, z = build_workload(ctx, fk, args.log2n) if args.lc_terms <= 1 else build_workload_dense(ctx, fk, args.log2n, args.lc_terms)
-    v_in, v_aux, n = r1cs.num_input, r1cs.num_aux, r1cs.n_rows
-    assert n == m
-    dr = ctx.load_r1cs(r1cs)
+    copies = None
+    if args.workload == 'rollup1024':
+        r1cs, zs = load_rollup_instance()
+        copies = args.copies
+        num_input, num_aux = 1 + copies * (r1cs.num_input - 1), copies * r1cs.num_aux
+        n = copies * r1cs.num_gates + num_input
+        log_m = max(n - 1, 1).bit_length()
+    else:
+        r1cs, z = build_workload(ctx, fk, args.log2n) if args.lc_terms <= 1 else build_workload_dense(ctx, fk, args.log2n, args.lc_terms)
+        num_input, num_aux, n, log_m = r1cs.num_input, r1cs.num_aux, r1cs.n_rows, args.log2n
+        assert n == 1 << log_m
+    m = 1 << log_m
+    nv = num_input + num_aux
+    # the witness lives in PINNED host memory, two buffers used in turn (the host side of a proving loop fills one while the
+    # other is in flight)
+    z_pin = [ctx.host_alloc((nv, 4)) for _ in range(2)]
+    if copies is not None:
+        tile_witness(zs, r1cs.num_input, copies, out=z_pin[0])
+    else:
+        z_pin[0][:] = z
+        del z
+    z_pin[1][:] = z_pin[0]
+    z_inputs = z_pin[0][1:num_input].copy()
+    zeros = int((~z_pin[0].any(axis=1)).sum()); ones = int((z_pin[0] == mont(1)).all(axis=1).sum())
+    dr = ctx.load_r1cs(r1cs, copies=copies)
     info = dr.info()
     n_a, n_b = info['n_a'], info['n_b']
     # N > 1, N a power of two: quotient and MSMs cut 1/N each (parallel.prove_distributed_dev); otherwise (or with
@@ -263,17 +353,11 @@ def main():
     dq_env = os.environ.get('FK_DIST_QUOTIENT', '')
     dq_ok = multi and (world & (world - 1)) == 0 and world <= 8
     dist_q = dq_ok and (dq_env == '1' or (dq_env != '0' and (world >= 4 or world == 1)))
-    fracs = parallel.plan_z_fractions(world, m, v_aux, n_a, n_b)
+    fracs = parallel.plan_z_fractions(world, m, num_aux, n_a, n_b)
     tox = {k: mont(v) for k, v in TOXIC.items()}
-    key, vk = ctx.setup(r1cs, shard_index=rank, shard_count=world, z_frac=fracs[rank] if (world > 1 and not dist_q) else (0.0, 0.0), **tox)
+    key, vk = ctx.setup(r1cs, shard_index=rank, shard_count=world, copies=copies,
+                        z_frac=fracs[rank] if (world > 1 and not dist_q) else fk.api.Z_EQUAL_SPLIT, **tox)
     pre_levels = key.precomputed()        # fixed-base window levels per key array (0 = none: FK_MSM_PRECOMP=0 or HBM short)
-    d_z = torch.empty((v_in + v_aux) * 32, dtype=torch.uint8, device=dev)
-    torch.cuda.synchronize()
-    ctx.upload(d_z.data_ptr(), z)
-    z_in1 = z[1].copy()
-    zeros = int((~z.any(axis=1)).sum()); ones = int((z == mont(1)).all(axis=1).sum())
-    z_host = z if not multi else None      # kept for the PCIe-inclusive measurement after the timed region (N = 1)
-    del z
     r, s = mont(0xA11CE), mont(0xB0B)
     d_dens = dr.density_ptrs()
     if dist_q:
@@ -286,20 +370,42 @@ def main():
         h_full_buf = torch.empty(m * 32, dtype=torch.uint8, device=dev) if rank == 0 else None
         recv_buf = torch.empty(max(h_ranges[rank][1] - h_ranges[rank][0], 1) * 32, dtype=torch.uint8, device=dev) if rank > 0 else None
         work = [torch.empty(m * 32, dtype=torch.uint8, device=dev) for _ in range(3)] if rank == 0 else [None] * 3
+    torch.cuda.synchronize()
     prep_s = time.time() - t_prep
 
-    def step():
-        if not multi:
-            return ctx.prove_witness_dev(key, dr, d_z.data_ptr(), r, s)
+    # ---------------------------------------------------------------- one step = one witness upload + one proof, pipelined
+    state = {'i': 0, 'ticket': None}
+
+    def prove_multi(d_z):
         wp = [w_.data_ptr() if w_ is not None else 0 for w_ in work]
+        ev = lambda: ctx.r1cs_eval_dev(dr, d_z, wp[0], wp[1], wp[2])
         if dist_q:
-            return parallel.prove_distributed_dev(
-                ctx, key, rank, world, wp, n, args.log2n, d_z.data_ptr(), d_dens[0], d_dens[1], d_dens[2], r, s, send, recv,
-                device=comm_dev, a2a=a2a, device_r1cs=dr, eval_fn=lambda: ctx.r1cs_eval_dev(dr, d_z.data_ptr(), wp[0], wp[1], wp[2]))
-        return parallel.prove_balanced_dev(
-            ctx, key, rank, world, wp[0], wp[1], wp[2], n, d_z.data_ptr(), d_dens[0], d_dens[1], d_dens[2], r, s,
-            h_ranges, h_full_buf, recv_buf, device=comm_dev,
-            eval_fn=(lambda: ctx.r1cs_eval_dev(dr, d_z.data_ptr(), wp[0], wp[1], wp[2])) if rank == 0 else None)
+            return parallel.prove_distributed_dev(ctx, key, rank, world, wp, n, log_m, d_z, d_dens[0], d_dens[1], d_dens[2], r, s, send, recv,
+                                                  device=comm_dev, a2a=a2a, device_r1cs=dr, eval_fn=ev)
+        return parallel.prove_balanced_dev(ctx, key, rank, world, wp[0], wp[1], wp[2], n, d_z, d_dens[0], d_dens[1], d_dens[2], r, s,
+                                           h_ranges, h_full_buf, recv_buf, device=comm_dev, eval_fn=ev if rank == 0 else None)
+
+    def prime():
+        """hand over the first witness (before the timed region: the pipeline is one upload ahead)"""
+        if not multi:
+            state['ticket'] = ctx.prove_witness_submit(key, dr, z_pin[0], r, s)
+        else:
+            ctx.witness_upload_async(0, z_pin[0])
+        state['i'] = 0
+
+    def step():
+        i = state['i']; state['i'] = i + 1
+        if not multi:
+            nxt = ctx.prove_witness_submit(key, dr, z_pin[(i + 1) & 1], r, s)      # upload of the NEXT proof's witness ...
+            proof = ctx.prove_witness_wait(state['ticket'])                          # ... runs underneath this proof
+            state['ticket'] = nxt
+            return proof
+        ctx.witness_upload_async((i + 1) & 1, z_pin[(i + 1) & 1])                    # every rank evaluates the full constraint system
+        return prove_multi(ctx.witness_ptr(i & 1))
+
+    def drain():
+        if not multi and state['ticket'] is not None:
+            ctx.prove_witness_wait(state['ticket']); state['ticket'] = None
 
     def barrier():
         if multi:
@@ -309,6 +415,7 @@ def main():
         torch.cuda.synchronize()
 
     proofs = []
+    prime()
     for _ in range(args.warmup):
         proofs.append(step().tobytes())
     barrier()
@@ -319,6 +426,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     stats = ctx.stats()
+    drain()
     if len(set(proofs)) != 1 or proofs[0] == bytes(256):
         raise AssertionError('bench: proofs differ between steps (non-deterministic result)')
     if multi:
@@ -327,23 +435,85 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    # ---- not `value`: the same proof with the witness already resident in HBM
+    d_z0 = ctx.dev_alloc(nv * 32)
+    ctx.upload(d_z0, z_pin[0])
+    dev_steps = max(2, min(args.steps, 5))
+    if not multi:
+        ctx.prove_witness_dev(key, dr, d_z0, r, s)
+        ctx.sync()
+        t1 = time.perf_counter()
+        for _ in range(dev_steps):
+            p_dev = ctx.prove_witness_dev(key, dr, d_z0, r, s)
+        dev_ms = (time.perf_counter() - t1) / dev_steps * 1e3
+        if p_dev.tobytes() != proofs[-1]:
+            raise AssertionError('bench: device-resident proof differs from the host-witness proof')
+    else:
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(dev_steps):
+            p_dev = prove_multi(d_z0)
+        barrier()
+        dev_ms = (time.perf_counter() - t1) / dev_steps * 1e3
+        if p_dev.tobytes() != proofs[-1]:
+            raise AssertionError('bench: device-resident proof differs from the host-witness proof')
+
+    # ---- N > 1: throughput mode, one whole proof per GPU (replicas of the single-GPU prover; no collective in the data path)
+    replica = None
+    if world > 1 and not args.no_replicas:
+        import torch.distributed as dist
+        key.free()
+        key, _ = ctx.setup(r1cs, copies=copies, **tox)           # the whole key on every GPU
+        ctx.prove_witness_dev(key, dr, d_z0, r, s)
+        barrier()
+        t1 = time.perf_counter()
+        state['ticket'] = ctx.prove_witness_submit(key, dr, z_pin[0], r, s)
+        for i in range(dev_steps):
+            nxt = ctx.prove_witness_submit(key, dr, z_pin[(i + 1) & 1], r, s)
+            p_rep = ctx.prove_witness_wait(state['ticket'])
+            state['ticket'] = nxt
+        ctx.prove_witness_wait(state['ticket']); state['ticket'] = None
+        barrier()
+        rep_t = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev if args.backend == 'nccl' else 'cpu')
+        dist.all_reduce(rep_t, op=dist.ReduceOp.MAX)
+        if p_rep.tobytes() != proofs[-1]:
+            raise AssertionError('bench: replica proof differs from the distributed proof')
+        replica = world * (dev_steps + 1) / float(rep_t.item())
+    ctx.dev_free(d_z0)
+
     if rank == 0:
         sec_per_step = elapsed / args.steps
-        msm_units = (m - 1) + v_aux + n_a + 2 * n_b       # scalar-muls per proof: H, L, A, B1 (G1) and B2 (G2)
+        msm_units = (m - 1) + num_aux + n_a + 2 * n_b       # scalar-muls per proof: H, L, A, B1 (G1) and B2 (G2)
         acc = stats['acc_g1']
-        # dominant kernel: msm_accumulate_kernel<Fq>; achieved = algorithmic bytes / its HIP-event time
-        achieved = (acc['units'] * G1_BYTES_PER_SCALAR_MUL) / (acc['ms'] * 1e-3) / 1e9 if acc['ms'] > 0 else 0.0
-        traffic = None
-        try:   # HBM traffic of the dominant kernel from the committed PMC pass (profiles/), if taken at this size
-            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic_bench_2p25.json')))
-            if pmc['log2n'] == args.log2n and world == 1 and acc['ms'] > 0:
-                dkk = pmc['dominant_kernel']
-                per_pt = (dkk['fetch_bytes_per_proof_raw'] + dkk['write_bytes_per_proof']) / dkk['points_per_proof']
-                traffic = per_pt * (acc['units'] / args.steps) / (acc['ms'] / args.steps * 1e-3) / 1e9
-        except Exception:
-            traffic = None
+        acc_s = acc['ms'] * 1e-3
+        # dominant kernel: G1 bucket accumulation; achieved = algorithmic bytes / its HIP-event time
+        achieved = (acc['units'] * G1_BYTES_PER_SCALAR_MUL) / acc_s / 1e9 if acc_s > 0 else 0.0
+        traffic, traffic_src = None, None
+        for cand in sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('.json') and 'pmc_traffic' in f)[::-1]:
+            try:   # HBM traffic of the dominant kernel from the newest committed PMC pass taken on this workload
+                pmc = json.load(open(os.path.join(ROOT, 'profiles', cand)))
+                if pmc.get('workload', 'synthetic') == args.workload and pmc['log2n'] == log_m and world == 1 and acc_s > 0:
+                    dkk = pmc['dominant_kernel']
+                    per_pt = (dkk['fetch_bytes_per_proof_raw'] * dkk.get('fetch_correction', 1.0) + dkk['write_bytes_per_proof']) / dkk['points_per_proof']
+                    traffic = per_pt * acc['units'] / acc_s / 1e9
+                    traffic_src = ('rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/%s (bytes per point from that pass x this run\'s '
+                                   'points; FETCH_SIZE x %.2f, the factor calibrated for 64-byte gathers)' % (cand, dkk.get('fetch_correction', 1.0)))
+                    break
+            except Exception:
+                continue
+        cal = ctx.calibrate()
+        modmul = acc['adds'] * MODMUL_PER_G1_MIXED_ADD
+        valu_peak = cal['mad_lane_ops_per_s'] / MUL_PIPE_OPS_PER_MODMUL
+        merged = bool(pre_levels.get('h'))
+        kname = '%s<Fq> (G1 bucket accumulation)' % ('msm_accumulate_merged_kernel' if merged else 'msm_accumulate_kernel')
+        if args.workload == 'rollup1024':
+            wl = ('%d rollup-style transactions (two depth-32 poseidon merkle proofs + one eddsa-poseidon signature each; a composition of the '
+                  'reference\'s gadgets, tests/golden/rollup_tx_instance.npz) as ONE R1CS through fk_setup_tiled / fk_r1cs_load_tiled, domain 2^%d '
+                  '(BASELINE configs[3] shape)' % (copies, log_m))
+        else:
+            wl = 'synthetic satisfiable R1CS, 2^%d rows, 1-2 term rows%s' % (log_m, ' / %d-term product gates' % args.lc_terms if args.lc_terms > 1 else '')
         out = {
-            'metric': 'Groth16 proofs/sec (BN254, 2^%d constraints)' % args.log2n,
+            'metric': 'Groth16 proofs/sec (BN254, 2^%d constraints)' % log_m,
             'value': args.steps / elapsed,
             'unit': 'proofs/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -353,27 +523,40 @@ def main():
             'vs_baseline': None,
             'dtype': 'u32',
             'data': 'synthetic',
-            'config': {'workload': 'satisfiable rollup-shape R1CS, 2^%d rows (BASELINE configs[3] shape), valid key: witness -> '
-                                   'device SpMV + 7-NTT quotient + G1 MSMs H/L/A/B1 + G2 MSM B2 + assembly; witness, constraint system '
-                                   'and key resident in HBM' % args.log2n,
-                       'log2_constraints': args.log2n, 'num_input': v_in, 'num_aux': v_aux,
-                       'gates': '40% boolean b*(b-1)=0, 10% linear, 50% products' + (' of %d-term sums' % args.lc_terms if args.lc_terms > 1 else ''),
-                       'nnz': list(info['nnz']),
+            'config': {'workload': wl + '; per step: witness from pinned HOST memory (two-slot pipeline) -> device SpMV + 7-NTT quotient + G1 MSMs '
+                                      'H/L/A/B1 + G2 MSM B2 + assembly; constraint system and valid key resident in HBM',
+                       'log2_constraints': log_m, 'rows': n, 'num_input': num_input, 'num_aux': num_aux,
+                       'nnz': list(info['nnz']), 'witness_bytes_per_proof': nv * 32,
                        'a_query_points': n_a, 'b_query_points': n_b,
                        'msm_fixed_base_levels': pre_levels,
-                       'witness': '%.0f%% zeros, %.0f%% ones, rest dense 254-bit' % (100.0 * zeros / (v_in + v_aux), 100.0 * ones / (v_in + v_aux)),
+                       'witness': '%.1f%% zeros, %.1f%% ones, rest dense 254-bit' % (100.0 * zeros / nv, 100.0 * ones / nv),
                        'parallelism': 'msm-shard%d%s' % (world, '' if not multi else
                                                          '+distributed-quotient (8 all-to-all per proof)' if dist_q else '+balanced-quotient')},
             'msm_scalar_muls_per_sec': msm_units / sec_per_step,
+            'msm_scalar_muls_per_sec_counts': 'every (scalar, base) pair of the five multiplications, trivial scalars (0 and 1) included',
+            'device_resident_ms_per_step': dev_ms,
             'roofline': {
-                'bound': 'hbm', 'kernel': '%s<Fq> (G1 bucket accumulation)' % ('msm_accumulate_merged_kernel' if pre_levels.get('h') else 'msm_accumulate_kernel'),
+                'bound': 'hbm', 'kernel': kname,
                 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                'traffic': traffic,
-                'traffic_source': ('rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/r01_pmc_traffic_bench_2p25.json '
-                                   '(bytes per point from that pass x this run\'s points; raw FETCH_SIZE, gather width uncalibrated)') if traffic else None,
+                'traffic': traffic, 'traffic_source': traffic_src,
                 'launches': acc['launches'], 'avg_launch_ms': acc['ms'] / max(acc['launches'], 1),
                 'algorithmic_bytes_per_scalar_mul': G1_BYTES_PER_SCALAR_MUL,
-                'note': 'MSM is 256-bit modular integer work: VALU-bound, not HBM-bound; see DESIGN.md',
+                'binding_resource': 'VALU integer multiplier, not HBM: see roofline_valu',
+                'note': 'quoted against HBM as north_star asks.  96 B feed ~12 mixed additions = ~120 modular products = ~4e4 integer '
+                        'instructions, so the algorithmic-byte fraction is necessarily ~2 %; the traffic above it is structural (every base '
+                        'is gathered once per window from its fixed-base level: W x 64 B + scalar)',
+            },
+            'roofline_valu': {
+                'bound': 'valu-int-mul', 'kernel': kname,
+                'achieved': modmul / acc_s / 1e9 if acc_s > 0 else 0.0, 'peak': valu_peak / 1e9, 'unit': 'G modmul/s',
+                'frac': (modmul / acc_s) / valu_peak if acc_s > 0 else 0.0,
+                'mixed_additions': acc['adds'], 'modmul_per_mixed_addition': MODMUL_PER_G1_MIXED_ADD,
+                'peak_is': 'v_mad_u64_u32 issue rate measured live on this device (fk_calibrate: %.2f T lane-ops/s) / %d multiplier operations '
+                           'per 256-bit Montgomery product (the minimum for 32-bit limbs)' % (cal['mad_lane_ops_per_s'] / 1e12, MUL_PIPE_OPS_PER_MODMUL),
+                'multiplier_alone': cal['modmul_per_s'] / 1e9,
+                'frac_of_multiplier_alone': (modmul / acc_s) / cal['modmul_per_s'] if acc_s > 0 else 0.0,
+                'multiplier_alone_is': 'the library\'s Montgomery product looping in registers, measured live (fk_calibrate), G modmul/s: what the '
+                                       'carry handling around the multiplies (v_addc, moves, hazard padding) leaves of the peak',
             },
             'kernel_ms_per_step': {
                 'msm_accumulate_g1': stats['acc_g1']['ms'] / args.steps,
@@ -385,33 +568,32 @@ def main():
             },
             'prep_seconds': prep_s,
         }
-        if z_host is not None and not args.no_cpu_baseline:
-            # not `value`: the same proof with the witness handed over in HOST memory (fk_prove_r1cs: one H2D copy of the
-            # witness, (num_input + num_aux) * 32 bytes, inside the call)
-            ctx.prove_witness(key, dr, z_host, r, s)
-            t1 = time.perf_counter()
-            for _ in range(2):
-                p_host = ctx.prove_witness(key, dr, z_host, r, s)
-            out['host_witness_ms_per_step'] = (time.perf_counter() - t1) / 2 * 1e3
-            if p_host.tobytes() != proofs[-1]:
-                raise AssertionError('bench: host-witness proof differs from the device-witness proof')
-        if multi and not args.no_cpu_baseline:
-            out['proof_verified_by_pairing_check'] = pairing_check(vk, z_in1, proofs[-1])
+        if replica is not None:
+            out['replica_proofs_per_sec'] = replica
+            out['replica_proofs_per_sec_is'] = 'throughput mode: every GPU holds the whole key and proves its own witnesses (host-witness pipeline), no collective'
+        if not args.no_cpu_baseline:
+            out['proof_verified_by_pairing_check'] = pairing_check(vk, z_inputs, proofs[-1])
         if not multi and not args.no_cpu_baseline:
-            cpu_s, cpu_m, verified = cpu_baseline_leg(ctx, fk, args.cpu_log2n, (vk, z_in1, proofs[-1]))
-            scale = m / cpu_m
-            out['proof_verified_by_pairing_check'] = verified
+            cb = cpu_baseline_leg(ctx, fk, args)
+            cores = cb['cores']
+            full = lambda th: (cb['synth_s'] + cb['prove_s'][th]) * cb['scale']
             out['cpu_baseline'] = {
-                'value': 1.0 / (cpu_s * scale), 'unit': 'proofs/s', 'cores': 1, 'kind': 'port',
-                'sample': 'oracle/groth16_oracle.c (bellman algorithm restated, 1 thread) proving a 2^%d-row instance of the same '
-                          'workload family in %.2f s; scaled linearly by %d to 2^%d rows (optimistic for the CPU: NTT is n log n); '
-                          'the GPU proof of the same sample matched byte for byte' % (args.cpu_log2n, cpu_s, scale, args.log2n),
-                'sample_seconds': cpu_s,
+                'value': 1.0 / full(cores), 'unit': 'proofs/s', 'cores': cores, 'kind': 'port',
+                'sample': 'oracle/groth16_oracle.c (bellman\'s algorithm restated; %d threads = bellman\'s multicore split: parallel_fft + one task per '
+                          'multiexp region; synthesis serial as in the reference) on %s (domain 2^%d): synthesis %.2f s + proof %.2f s; scaled linearly '
+                          'by %g to the benchmarked size (optimistic for the CPU: the NTT is n log n); the GPU proof of the same sample matched byte for '
+                          'byte' % (cores, cb['what'], cb['log2_m'], cb['synth_s'], cb['prove_s'][cores], cb['scale']),
+                'sample_seconds': cb['synth_s'] + cb['prove_s'][cores],
+                'single_thread': {'value': 1.0 / full(1), 'unit': 'proofs/s', 'cores': 1,
+                                  'sample_seconds': cb['synth_s'] + cb['prove_s'][1],
+                                  'note': 'the worker fawkes-crypto configures (SURVEY fact 3): same sample, one thread'},
             }
         line = json.dumps(out)
     else:
         line = None
 
+    for zp in z_pin:
+        ctx.host_free(zp)
     dr.free()
     key.free()
     if multi:

@@ -17,6 +17,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 FK_PROOF_BYTES = 256
+Z_EQUAL_SPLIT = (-1.0, -1.0)     # FK_Z_EQUAL_SPLIT: l / a / b sliced like h; any (lo, hi) with lo >= 0 is a fraction range, (0, 0) = empty
 FK_MSM_RESULT_BYTES = 4 * 64 + 128
 FR_MODULUS = 21888242871839275222246405745257275088548364400416034343698204186575808495617
 FQ_MODULUS = 21888242871839275222246405745257275088696311157297823662689037894645226208583
@@ -25,6 +26,7 @@ FQ_MODULUS = 2188824287183927522224640574525727508869631115729782366268903789464
 EXPORTED_SYMBOLS = [
     'fk_init', 'fk_free', 'fk_last_error', 'fk_set_window_bits',
     'fk_dev_alloc', 'fk_dev_free', 'fk_upload', 'fk_download', 'fk_dev_copy', 'fk_sync',
+    'fk_host_alloc', 'fk_host_free', 'fk_witness_upload_async', 'fk_witness_ptr', 'fk_prove_r1cs_submit', 'fk_prove_r1cs_wait',
     'fk_key_load', 'fk_key_synthetic', 'fk_key_shard_info', 'fk_key_host_vk', 'fk_key_free',
     'fk_prove', 'fk_prove_dev', 'fk_prove_msms', 'fk_prove_msms_dev', 'fk_prove_msms_z_dev', 'fk_prove_msm_h_dev', 'fk_prove_msms_hz_dev',
     'fk_prove_msms_z_begin_dev', 'fk_prove_msms_finish_dev', 'fk_prove_msms_hz_r1cs_dev',
@@ -32,7 +34,7 @@ EXPORTED_SYMBOLS = [
     'fk_fr_mul_batch', 'fk_ntt', 'fk_ntt_dev', 'fk_quotient_h', 'fk_quotient_h_dev',
     'fk_msm_g1', 'fk_msm_g2', 'fk_msm_g1_dev', 'fk_msm_g2_dev',
     'fk_gen_points_g1_dev', 'fk_gen_points_g2_dev', 'fk_gen_scalars_dev',
-    'fk_synthesize', 'fk_stats_reset', 'fk_stats_get', 'fk_shard_range', 'fk_h_shard_range',
+    'fk_synthesize', 'fk_stats_reset', 'fk_stats_get', 'fk_calibrate', 'fk_shard_range', 'fk_h_shard_range',
     'fk_dq_gather_dev', 'fk_dq_local_dev', 'fk_dq_cross_dev',
     'fk_setup', 'fk_setup_tiled', 'fk_r1cs_load_tiled', 'fk_key_download', 'fk_key_load_bellman', 'fk_key_vk', 'fk_key_counts', 'fk_key_precomputed',
     'fk_r1cs_load', 'fk_r1cs_free', 'fk_r1cs_info', 'fk_r1cs_density_ptrs', 'fk_r1cs_eval_dev', 'fk_prove_r1cs', 'fk_prove_r1cs_dev',
@@ -239,7 +241,7 @@ class Parameters:
         self.r1cs = r1cs
         self._handles = {}
 
-    def desc(self, shard_index=0, shard_count=1, z_frac=(0.0, 0.0)):
+    def desc(self, shard_index=0, shard_count=1, z_frac=Z_EQUAL_SPLIT):
         d = KeyDesc()
         d.z_frac_lo, d.z_frac_hi = float(z_frac[0]), float(z_frac[1])
         d.m, d.num_input, d.num_aux = self.m, self.num_input, self.num_aux
@@ -420,17 +422,62 @@ class Context:
     def sync(self):
         self._ck(self.lib.fk_sync(self.handle))
 
+    # ---- witness hand-over from host memory (pinned buffers, two device slots filled on a copy stream)
+    def host_alloc(self, shape, dtype=np.uint64):
+        """fk_host_alloc: a numpy array over pinned host memory (free with host_free(arr))."""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        self._ck(self.lib.fk_host_alloc(self.handle, C.c_size_t(n), C.byref(p)))
+        arr = np.frombuffer((C.c_uint8 * max(n, 1)).from_address(p.value), dtype=np.uint8, count=n).view(dtype).reshape(shape)
+        self._pinned = getattr(self, '_pinned', {})
+        self._pinned[arr.ctypes.data] = p.value
+        return arr
+
+    def host_free(self, arr):
+        p = getattr(self, '_pinned', {}).pop(arr.ctypes.data, None)
+        if p is not None:
+            self._ck(self.lib.fk_host_free(self.handle, C.c_void_p(p)))
+
+    def witness_upload_async(self, slot, z):
+        """fk_witness_upload_async: z must stay alive (and should be pinned) until the proof that reads the slot returns"""
+        assert z.flags['C_CONTIGUOUS']
+        self._ck(self.lib.fk_witness_upload_async(self.handle, C.c_int(slot), _vp(z), C.c_size_t(z.nbytes)))
+
+    def witness_ptr(self, slot):
+        p = C.c_void_p()
+        self._ck(self.lib.fk_witness_ptr(self.handle, C.c_int(slot), C.byref(p)))
+        return p.value
+
+    def prove_witness_submit(self, key, dr, z, r, s):
+        """fk_prove_r1cs_submit -> ticket.  z, r, s are kept referenced until prove_witness_wait(ticket)."""
+        assert z.dtype == np.uint64 and z.flags['C_CONTIGUOUS']
+        r, s = _fr(r, 1), _fr(s, 1)
+        t = C.c_int(-1)
+        self._ck(self.lib.fk_prove_r1cs_submit(self.handle, key.handle, dr.handle, _vp(z), _vp(r), _vp(s), C.byref(t)))
+        self._tickets = getattr(self, '_tickets', {})
+        self._tickets[t.value] = (z, r, s, key, dr)
+        return t.value
+
+    def prove_witness_wait(self, ticket, want_timings=False):
+        out = np.zeros(FK_PROOF_BYTES, np.uint8)
+        tm = Timings()
+        try:
+            self._ck(self.lib.fk_prove_r1cs_wait(self.handle, C.c_int(ticket), _vp(out), C.byref(tm)))
+        finally:
+            getattr(self, '_tickets', {}).pop(ticket, None)
+        return (out, tm.as_dict()) if want_timings else out
+
     def set_window_bits(self, c):
         self._ck(self.lib.fk_set_window_bits(self.handle, C.c_uint(c)))
 
     # ---- keys
-    def load_key(self, params, shard_index=0, shard_count=1, z_frac=(0.0, 0.0)):
+    def load_key(self, params, shard_index=0, shard_count=1, z_frac=Z_EQUAL_SPLIT):
         d = params.desc(shard_index, shard_count, z_frac)
         h = C.c_void_p()
         self._ck(self.lib.fk_key_load(self.handle, C.byref(d), C.byref(h)))
         return DeviceKey(self, h, shard_index, shard_count)
 
-    def synthetic_key(self, m, num_input, num_aux, n_a, n_b, seed=1, shard_index=0, shard_count=1, z_frac=(0.0, 0.0)):
+    def synthetic_key(self, m, num_input, num_aux, n_a, n_b, seed=1, shard_index=0, shard_count=1, z_frac=Z_EQUAL_SPLIT):
         h = C.c_void_p()
         self._ck(self.lib.fk_key_synthetic(self.handle, C.c_uint64(m), C.c_uint32(num_input), C.c_uint32(num_aux),
                                            C.c_uint64(n_a), C.c_uint64(n_b), C.c_uint64(seed), C.c_uint32(shard_index),
@@ -521,19 +568,23 @@ class Context:
 
     def prove_raw(self, key, a, b, c, z, a_aux, b_in, b_aux, r, s, want_timings=False):
         """fk_prove: returns the 256-byte proof (numpy uint8)."""
+        # every converted array is bound to a local for the duration of the call: np.ascontiguousarray may copy, and
+        # the address of a temporary would dangle
         a, b, c, z = _fr(a), _fr(b), _fr(c), _fr(z)
+        a_aux, b_in, b_aux, r, s = _u8(a_aux), _u8(b_in), _u8(b_aux), _fr(r, 1), _fr(s, 1)
         out = np.zeros(FK_PROOF_BYTES, np.uint8)
         tm = Timings()
         self._ck(self.lib.fk_prove(self.handle, key.handle, _vp(a), _vp(b), _vp(c), C.c_uint64(a.shape[0]), _vp(z),
-                                   C.c_void_p(_u8(a_aux).ctypes.data), _vp(_u8(b_in)), C.c_void_p(_u8(b_aux).ctypes.data),
-                                   _vp(_fr(r, 1)), _vp(_fr(s, 1)), _vp(out), C.byref(tm)))
+                                   C.c_void_p(a_aux.ctypes.data), _vp(b_in), C.c_void_p(b_aux.ctypes.data),
+                                   _vp(r), _vp(s), _vp(out), C.byref(tm)))
         return (out, tm.as_dict()) if want_timings else out
 
     def prove_msms(self, key, a, b, c, z, a_aux, b_in, b_aux):
         a, b, c, z = _fr(a), _fr(b), _fr(c), _fr(z)
+        a_aux, b_in, b_aux = _u8(a_aux), _u8(b_in), _u8(b_aux)
         out = np.zeros(FK_MSM_RESULT_BYTES, np.uint8)
         self._ck(self.lib.fk_prove_msms(self.handle, key.handle, _vp(a), _vp(b), _vp(c), C.c_uint64(a.shape[0]), _vp(z),
-                                        C.c_void_p(_u8(a_aux).ctypes.data), _vp(_u8(b_in)), C.c_void_p(_u8(b_aux).ctypes.data),
+                                        C.c_void_p(a_aux.ctypes.data), _vp(b_in), C.c_void_p(b_aux.ctypes.data),
                                         _vp(out), None))
         return out
 
@@ -583,12 +634,13 @@ class Context:
     def prove_dev(self, key, d_a, d_b, d_c, n, d_z, d_a_aux, d_b_in, d_b_aux, r, s, want_timings=False):
         out = np.zeros(FK_PROOF_BYTES, np.uint8)
         tm = Timings()
+        r, s = _fr(r, 1), _fr(s, 1)
         self._ck(self.lib.fk_prove_dev(self.handle, key.handle, C.c_void_p(d_a), C.c_void_p(d_b), C.c_void_p(d_c),
                                        C.c_uint64(n), C.c_void_p(d_z), C.c_void_p(d_a_aux), C.c_void_p(d_b_in),
-                                       C.c_void_p(d_b_aux), _vp(_fr(r, 1)), _vp(_fr(s, 1)), _vp(out), C.byref(tm)))
+                                       C.c_void_p(d_b_aux), _vp(r), _vp(s), _vp(out), C.byref(tm)))
         return (out, tm.as_dict()) if want_timings else out
 
-    def load_key_bellman(self, data, shard_index=0, shard_count=1, z_frac=(0.0, 0.0)):
+    def load_key_bellman(self, data, shard_index=0, shard_count=1, z_frac=Z_EQUAL_SPLIT):
         """fk_key_load_bellman: `data` = bytes of bellman's Parameters::write.  Returns (DeviceKey, gamma_g2, ic)."""
         buf = np.frombuffer(bytes(data), np.uint8)
         h = C.c_void_p()
@@ -601,13 +653,14 @@ class Context:
                                               C.byref(n_ic)))
         return DeviceKey(self, h, shard_index, shard_count), gamma, ic[:min(n_ic.value, cap)].copy()
 
-    def setup(self, r1cs, tau, alpha, beta, gamma, delta, shard_index=0, shard_count=1, z_frac=(0.0, 0.0), copies=None):
+    def setup(self, r1cs, tau, alpha, beta, gamma, delta, shard_index=0, shard_count=1, z_frac=Z_EQUAL_SPLIT, copies=None):
         """fk_setup: GPU key generation with explicit toxic waste (Montgomery limbs).  Returns (DeviceKey, vk dict)
         with vk = alpha_g1, beta_g1, beta_g2, gamma_g2, delta_g1, delta_g2 (raw LE uint8 arrays) and ic (num_input, 64).
         copies: fk_setup_tiled -- r1cs is one instance of a batch circuit, the key is for `copies` of it."""
         h = C.c_void_p()
         vk = np.zeros(6 * 128, np.uint8)
-        tail = (_vp(_fr(tau, 1)), _vp(_fr(alpha, 1)), _vp(_fr(beta, 1)), _vp(_fr(gamma, 1)), _vp(_fr(delta, 1)), C.c_uint32(shard_index),
+        tau, alpha, beta, gamma, delta = _fr(tau, 1), _fr(alpha, 1), _fr(beta, 1), _fr(gamma, 1), _fr(delta, 1)
+        tail = (_vp(tau), _vp(alpha), _vp(beta), _vp(gamma), _vp(delta), C.c_uint32(shard_index),
                 C.c_uint32(shard_count), C.c_double(z_frac[0]), C.c_double(z_frac[1]), C.byref(h), _vp(vk))
         if copies is None:
             ic = np.zeros((r1cs.num_input, 64), np.uint8)
@@ -635,16 +688,17 @@ class Context:
 
     def prove_witness(self, key, dr, z, r, s, want_timings=False):
         """fk_prove_r1cs: z (host, (num_input+num_aux, 4) uint64 Montgomery) -> 256-byte proof."""
-        z = _fr(z)
+        z, r, s = _fr(z), _fr(r, 1), _fr(s, 1)
         out = np.zeros(FK_PROOF_BYTES, np.uint8)
         tm = Timings()
-        self._ck(self.lib.fk_prove_r1cs(self.handle, key.handle, dr.handle, _vp(z), _vp(_fr(r, 1)), _vp(_fr(s, 1)), _vp(out), C.byref(tm)))
+        self._ck(self.lib.fk_prove_r1cs(self.handle, key.handle, dr.handle, _vp(z), _vp(r), _vp(s), _vp(out), C.byref(tm)))
         return (out, tm.as_dict()) if want_timings else out
 
     def prove_witness_dev(self, key, dr, d_z, r, s, want_timings=False):
         out = np.zeros(FK_PROOF_BYTES, np.uint8)
         tm = Timings()
-        self._ck(self.lib.fk_prove_r1cs_dev(self.handle, key.handle, dr.handle, C.c_void_p(d_z), _vp(_fr(r, 1)), _vp(_fr(s, 1)), _vp(out), C.byref(tm)))
+        r, s = _fr(r, 1), _fr(s, 1)
+        self._ck(self.lib.fk_prove_r1cs_dev(self.handle, key.handle, dr.handle, C.c_void_p(d_z), _vp(r), _vp(s), _vp(out), C.byref(tm)))
         return (out, tm.as_dict()) if want_timings else out
 
     def prove_assemble(self, key, parts, r, s):
@@ -660,7 +714,17 @@ class Context:
             ms, n, u = C.c_double(), C.c_uint64(), C.c_uint64()
             self._ck(self.lib.fk_stats_get(self.handle, C.c_int(which), C.byref(ms), C.byref(n), C.byref(u)))
             out[name] = dict(ms=ms.value, launches=n.value, units=u.value)
+        for which, name in ((3, 'acc_g1'), (4, 'acc_g2')):     # the same kernels, counted in mixed point additions
+            u = C.c_uint64()
+            self._ck(self.lib.fk_stats_get(self.handle, C.c_int(which), None, None, C.byref(u)))
+            out[name]['adds'] = u.value
         return out
+
+    def calibrate(self):
+        """fk_calibrate: dict(mad_lane_ops_per_s, modmul_per_s) measured live on this device"""
+        out = (C.c_double * 2)()
+        self._ck(self.lib.fk_calibrate(self.handle, out))
+        return dict(mad_lane_ops_per_s=out[0], modmul_per_s=out[1])
 
     def dev_copy(self, dst, src, nbytes):
         self._ck(self.lib.fk_dev_copy(self.handle, C.c_void_p(dst), C.c_void_p(src), C.c_size_t(nbytes)))
@@ -689,8 +753,9 @@ def assemble(key_handle, parts, r, s, ctx=None):
     lib = load_library()
     parts = np.ascontiguousarray(parts, np.uint8).reshape(-1, FK_MSM_RESULT_BYTES)
     out = np.zeros(FK_PROOF_BYTES, np.uint8)
+    r, s = _fr(r, 1), _fr(s, 1)
     rc = lib.fk_prove_assemble(ctx.handle if ctx else None, key_handle, _vp(parts), C.c_uint32(parts.shape[0]),
-                               _vp(_fr(r, 1)), _vp(_fr(s, 1)), _vp(out))
+                               _vp(r), _vp(s), _vp(out))
     if rc != 0:
         msg = lib.fk_last_error(ctx.handle) if ctx else b''
         raise FkError(rc, msg.decode() if msg else '')

@@ -7,7 +7,7 @@
 #include <string>
 #include <vector>
 #include "../../include/fawkes_hip.h"
-#include "curve.cuh"
+#include "curve.hpp"
 
 namespace fk {
 
@@ -96,11 +96,20 @@ struct fk_ctx {
     bool wit_active = false;
     const fk::QueryIdx *qidx = nullptr;   // set by the resident-constraint-system entry points for the duration of a call
     int wit_tail[4] = {-1, -1, -1, -1}; // B1, B2, L, A
+    // witness hand-over from host memory (fk_witness_upload_async / fk_prove_r1cs_submit): two device slots filled on a copy
+    // stream of their own, so that the upload of proof k+1's witness runs underneath proof k
+    hipStream_t copy_st = nullptr;
+    struct WitSlot {
+        fk::DevBuf buf; hipEvent_t ready = nullptr; bool pending = false;        // pending: a submitted proof waits in this slot
+        const fk_key *key = nullptr; const struct fk_r1cs_dev *r1cs = nullptr; uint64_t r[4], s[4];
+    } wslot[2];
+    int wslot_next = 0;
     // NTT / prover scratch
     fk::DevBuf ntt_s1, ntt_s2, ntt_io, hbuf, sc_a, sc_b, scan_tmp, stage_a, stage_b, stage_c, stage_z, stage_d;
     // stats
     std::vector<fk::EventPair> ev_acc, ev_acc2, ev_ntt;   // G1 accumulate, G2 accumulate, NTT passes
     std::vector<hipEvent_t> ev_pool;
+    uint64_t acc_adds[2] = {0, 0};        // mixed additions done by the G1 / G2 accumulate kernels since the last reset
     bool stats_on = true;
     bool debug = false;   // FK_DEBUG=1: synchronise and log after every launch
 };
@@ -162,6 +171,31 @@ static inline void h_slice(uint64_t n_h, uint32_t idx, uint32_t cnt, uint64_t *l
     if (a > n_h) a = n_h;
     if (b > n_h) b = n_h;
     *lo = a; *hi = b;
+}
+
+// Which part of l, a, b_g1, b_g2 a key holds (one rule for fk_key_load, fk_key_load_bellman, fk_setup*, fk_key_synthetic).
+// zlo < 0 (FK_Z_EQUAL_SPLIT): the equal split [index/count, (index+1)/count).  Otherwise the fractions [zlo, zhi) of
+// every array -- and (0, 0) then IS the empty slice (the rank that computes the quotient may hold no witness points at
+// all).  A lone shard must hold everything: a zero-initialised descriptor is refused instead of proving from nothing.
+static inline int key_plan_slices(fk_ctx *ctx, fk_key *k, double zlo, double zhi) {
+    h_slice(k->n_h, k->shard_index, k->shard_count, &k->h_lo, &k->h_hi);
+    auto eq = [&](uint64_t n, uint64_t *lo, uint64_t *hi) {
+        *lo = (uint64_t)((unsigned __int128)n * k->shard_index / k->shard_count);
+        *hi = (uint64_t)((unsigned __int128)n * (k->shard_index + 1) / k->shard_count);
+    };
+    auto fr = [&](uint64_t n, uint64_t *olo, uint64_t *ohi) {
+        uint64_t a = (uint64_t)((long double)n * zlo + 0.5L), b = zhi >= 1.0 ? n : (uint64_t)((long double)n * zhi + 0.5L);
+        if (a > n) a = n;
+        if (b > n) b = n;
+        if (b < a) b = a;
+        *olo = a; *ohi = b;
+    };
+    if (zlo < 0.0) { eq(k->n_l, &k->l_lo, &k->l_hi); eq(k->n_a, &k->a_lo, &k->a_hi); eq(k->n_b, &k->b_lo, &k->b_hi); return FK_OK; }
+    if (!(zhi <= 1.0 && zlo <= zhi)) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "key: bad z fraction range [%g, %g)", zlo, zhi);
+    if (k->shard_count == 1 && !(zlo == 0.0 && zhi >= 1.0))
+        FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "key: a single shard holds the whole arrays (z_frac_lo = FK_Z_EQUAL_SPLIT or [0, 1)), got [%g, %g)", zlo, zhi);
+    fr(k->n_l, &k->l_lo, &k->l_hi); fr(k->n_a, &k->a_lo, &k->a_hi); fr(k->n_b, &k->b_lo, &k->b_hi);
+    return FK_OK;
 }
 
 // stats helpers (HIP events on the library stream)

@@ -7,7 +7,7 @@
 // needs no inversion.  Any correct group law yields the same affine result, so the 256 proof bytes
 // are independent of the coordinate system.
 #pragma once
-#include "field.cuh"
+#include "field.hpp"
 
 namespace fk {
 

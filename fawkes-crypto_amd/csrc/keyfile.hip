@@ -83,19 +83,12 @@ int fk_key_load_bellman(fk_ctx *ctx, const uint8_t *buf, size_t len, uint32_t sh
     if (m & (m - 1)) FK_SET_ERR(ctx, FK_ERR_KEY_MISMATCH, "key file: h holds %u points, not 2^k - 1", cnt[1]);
     if (m > ((uint64_t)1 << (FK_FR_S - 1))) FK_SET_ERR(ctx, FK_ERR_DOMAIN_TOO_LARGE, "key file: domain exceeds 2^%d", FK_FR_S - 1);
     if (shard_count == 0 || shard_index >= shard_count) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "key file: bad shard %u/%u", shard_index, shard_count);
-    if (!(z_frac_lo >= 0.0 && z_frac_hi <= 1.0 && z_frac_lo <= z_frac_hi)) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "key file: bad z fraction range");
 
     fk_key *k = new fk_key();
     k->m = m; k->num_input = cnt[0]; k->num_aux = cnt[2];
     k->n_h = cnt[1]; k->n_l = cnt[2]; k->n_a = cnt[3]; k->n_b = cnt[4];
     k->shard_index = shard_index; k->shard_count = shard_count;
-    auto sl = [](uint64_t n, uint32_t i, uint32_t cc, uint64_t *lo, uint64_t *hi) { *lo = (uint64_t)((unsigned __int128)n * i / cc); *hi = (uint64_t)((unsigned __int128)n * (i + 1) / cc); };
-    auto fr = [](uint64_t n, double lo, double hi, uint64_t *olo, uint64_t *ohi) {
-        uint64_t a = (uint64_t)((long double)n * lo + 0.5L), b = hi >= 1.0 ? n : (uint64_t)((long double)n * hi + 0.5L);
-        if (a > n) a = n; if (b > n) b = n; if (b < a) b = a; *olo = a; *ohi = b; };
-    h_slice(k->n_h, shard_index, shard_count, &k->h_lo, &k->h_hi);
-    if (z_frac_lo == 0.0 && z_frac_hi == 0.0) { sl(k->n_l, shard_index, shard_count, &k->l_lo, &k->l_hi); sl(k->n_a, shard_index, shard_count, &k->a_lo, &k->a_hi); sl(k->n_b, shard_index, shard_count, &k->b_lo, &k->b_hi); }
-    else { fr(k->n_l, z_frac_lo, z_frac_hi, &k->l_lo, &k->l_hi); fr(k->n_a, z_frac_lo, z_frac_hi, &k->a_lo, &k->a_hi); fr(k->n_b, z_frac_lo, z_frac_hi, &k->b_lo, &k->b_hi); }
+    { const int rcs = key_plan_slices(ctx, k, z_frac_lo, z_frac_hi); if (rcs != FK_OK) { delete k; return rcs; } }
     auto fail = [&](int code, const char *msg) { ctx->err = msg; fk_key_free(ctx, k); return code; };
 
     uint32_t *d_bad = nullptr;

@@ -419,13 +419,28 @@ static __device__ __forceinline__ uint32_t size_class(uint32_t size, uint32_t ca
     const uint32_t span = cap > 768 ? cap - 768 : 1;
     return 255u - (uint32_t)(((uint64_t)(s - 768) * 255u) / span);
 }
-__global__ __launch_bounds__(256) void msm_size_hist_kernel(const uint32_t *totals, size_t WB, uint32_t cap, uint32_t *bins) {   // cap = the larger (top-window) cap
+// wave64 sum, result in lane 0
+static __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += (unsigned long long)__shfl_down((long long)v, off, 64);
+    return v;
+}
+// adds (may be null): += sum over the buckets of min(size, cap) - 1, i.e. the mixed additions the accumulate kernel will do
+// (a bucket's first entry is a copy) -- the unit of the VALU roofline in bench.py.  `count_adds`: off for the merged form,
+// whose buckets span the windows (msm_merge_totals_kernel counts there).
+__global__ __launch_bounds__(256) void msm_size_hist_kernel(const uint32_t *totals, size_t WB, uint32_t cap, uint32_t *bins, unsigned long long *adds) {   // cap = the larger (top-window) cap
     __shared__ uint32_t sh[SIZE_BINS];
     for (uint32_t i = threadIdx.x; i < SIZE_BINS; i += 256) sh[i] = 0;
     __syncthreads();
-    for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < WB; g += (size_t)gridDim.x * 256) atomicAdd(&sh[size_class(totals[g], cap)], 1u);
+    unsigned long long mine = 0;
+    for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < WB; g += (size_t)gridDim.x * 256) {
+        const uint32_t t = totals[g];
+        atomicAdd(&sh[size_class(t, cap)], 1u);
+        if (t) mine += (t < cap ? t : cap) - 1;
+    }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < SIZE_BINS; i += 256) if (sh[i]) atomicAdd(&bins[i], sh[i]);
+    if (adds) { mine = wave_sum_u64(mine); if ((threadIdx.x & 63) == 0 && mine) atomicAdd(adds, mine); }
 }
 __global__ __launch_bounds__(SIZE_BINS) void msm_size_scan_kernel(uint32_t *bins) {      // exclusive scan in place
     __shared__ uint32_t sh[SIZE_BINS];
@@ -493,9 +508,9 @@ static __device__ __forceinline__ void block_reduce_256(Xyzz<F> &acc, Xyzz<F> *s
 
 // ------------------------------------------------------------------------------------------ bucket accumulation
 // MINW = minimum waves per SIMD the register allocator must leave room for.  G1: 4 (<= 128 registers, no spills).
-// G2: the inlined Fq2 mixed addition wants 256 VGPRs + ~180 AGPRs; forcing 2 waves spills ~260 registers to
-// scratch and is slower (41 ms vs 33 ms at 2^25) -- also with the accumulator staged in LDS (160 spills) or with the
-// out-of-line multiply (+14 %) -- so G2 runs at MINW = 1.
+// G2: 2.  With the compiler's own add/sub code the inlined Fq2 mixed addition wanted 256 VGPRs + ~180 AGPRs and forcing 2
+// waves spilled ~260 registers (41 ms vs 33 ms at 2^25); since the generated carry-chain add/sub (addsub_gfx950.inc) it
+// needs 226 VGPRs and runs at 2 waves per SIMD without spills: 23.4 -> 13.7 ms.
 template <class F, int MINW>
 __global__ __launch_bounds__(256, MINW) void msm_accumulate_kernel(const Affine<F> *bases, const uint32_t *sorted, size_t n,
                                                              const uint32_t *starts, const uint32_t *totals, uint32_t B,
@@ -553,12 +568,15 @@ __global__ __launch_bounds__(256, MINW) void msm_accumulate_merged_kernel(const 
     buckets[b] = acc;
 }
 // mt[b] = sum over the windows of min(totals[w][b], cap): the merged bucket's length, for the size ordering
-__global__ __launch_bounds__(256) void msm_merge_totals_kernel(const uint32_t *totals, uint32_t B, uint32_t W, uint32_t cap, uint32_t *mt) {
+__global__ __launch_bounds__(256) void msm_merge_totals_kernel(const uint32_t *totals, uint32_t B, uint32_t W, uint32_t cap, uint32_t *mt, unsigned long long *adds) {
     const uint32_t b = blockIdx.x * 256 + threadIdx.x;
-    if (b >= B) return;
     uint32_t s = 0;
-    for (uint32_t w = 0; w < W; w++) { const uint32_t v = totals[(size_t)w * B + b]; s += v < cap ? v : cap; }
-    mt[b] = s;
+    if (b < B) {
+        for (uint32_t w = 0; w < W; w++) { const uint32_t v = totals[(size_t)w * B + b]; s += v < cap ? v : cap; }
+        mt[b] = s;
+    }
+    const unsigned long long all = wave_sum_u64(s ? s - 1 : 0);      // mixed additions of this bucket (the first entry is a copy)
+    if ((threadIdx.x & 63) == 0 && all) atomicAdd(adds, all);
 }
 // level w+1 = 2^bits * level w, affine in, affine out.  NB (4 for G1, 2 for G2: registers) points per lane share one
 // inversion (Montgomery's trick on the products zz * zzz; a point at infinity takes part with the factor 1) and their
@@ -748,7 +766,7 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
     struct Need { DevBuf *b; size_t bytes; };
     const Need needs[] = {
         {&ln.digits, (size_t)p.W * n * 4}, {&ln.sorted, (size_t)p.W * n * 4}, {&ln.totals, WB * 4}, {&ln.starts, WB * 4},
-        {&ln.perm, WB * 4 + SIZE_BINS * 4}, {&ln.overlist, over_cap * sizeof(OverEntry) + 16}, {&ln.buckets, WB * sizeof(Xyzz<F>)},
+        {&ln.perm, WB * 4 + SIZE_BINS * 4}, {&ln.overlist, over_cap * sizeof(OverEntry) + 32}, {&ln.buckets, WB * sizeof(Xyzz<F>)},
         {&ln.s2_cnt1, (size_t)p.W * p.nchunks * p.nhi * 4}, {&ln.s2_seg, ((size_t)nseg * 4 + 2) * 4}, {&ln.s2_cnt2, max_tiles * p.nlo * 4},
         {&ln.s2_tmp_idx, (size_t)p.W * n * 4}, {&ln.s2_tmp_lo, (size_t)p.W * n * 2}};
     bool grow = false;
@@ -759,12 +777,13 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
         if (!have_sort) ln.last_sort_scalars = nullptr;
     }
     FK_HIP(ctx, tl.d_wp.reserve(wp_bytes));
-    if (wp_bytes > tl.h_cap) {
+    if (wp_bytes + 8 > tl.h_cap) {          // + the additions counter
         if (tl.h_wp) { FK_HIP(ctx, hipHostFree(tl.h_wp)); tl.h_wp = nullptr; tl.h_cap = 0; }
-        FK_HIP(ctx, hipHostMalloc(&tl.h_wp, wp_bytes + (wp_bytes >> 2), hipHostMallocDefault));
-        tl.h_cap = wp_bytes + (wp_bytes >> 2);
+        FK_HIP(ctx, hipHostMalloc(&tl.h_wp, wp_bytes + (wp_bytes >> 2) + 8, hipHostMallocDefault));
+        tl.h_cap = wp_bytes + (wp_bytes >> 2) + 8;
     }
     uint32_t *d_nover = (uint32_t *)((char *)ln.overlist.p + over_cap * sizeof(OverEntry));
+    unsigned long long *d_adds = (unsigned long long *)(d_nover + 2);      // mixed additions of the accumulate kernel (statistics); lives as long as the sort
     uint32_t *digits = ln.digits.as<uint32_t>(), *sorted = ln.sorted.as<uint32_t>();
     uint32_t *totals = ln.totals.as<uint32_t>(), *starts = ln.starts.as<uint32_t>();
     Xyzz<F> *buckets = ln.buckets.as<Xyzz<F>>(), *winparts = tl.d_wp.as<Xyzz<F>>();
@@ -831,15 +850,16 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
         }
         // size-ordered bucket -> lane assignment
         FK_HIP(ctx, hipMemsetAsync(size_bins, 0, SIZE_BINS * 4, st));
+        FK_HIP(ctx, hipMemsetAsync(d_adds, 0, 8, st));
         if (merged) {     // one bucket set: order its B buckets by their length over all windows (perm[0, B); lengths kept behind it)
             uint32_t *mt = perm + p.B;
             const uint32_t mcap = (uint32_t)std::min<uint64_t>((uint64_t)cap * p.W, 1u << 30);
-            hipLaunchKernelGGL(msm_merge_totals_kernel, dim3((p.B + 255) / 256), dim3(256), 0, st, totals, p.B, p.W, cap, mt);
-            hipLaunchKernelGGL(msm_size_hist_kernel, dim3((unsigned)std::min<size_t>((p.B + 255) / 256, 1024)), dim3(256), 0, st, mt, (size_t)p.B, mcap, size_bins);
+            hipLaunchKernelGGL(msm_merge_totals_kernel, dim3((p.B + 255) / 256), dim3(256), 0, st, totals, p.B, p.W, cap, mt, d_adds);
+            hipLaunchKernelGGL(msm_size_hist_kernel, dim3((unsigned)std::min<size_t>((p.B + 255) / 256, 1024)), dim3(256), 0, st, mt, (size_t)p.B, mcap, size_bins, (unsigned long long *)nullptr);
             hipLaunchKernelGGL(msm_size_scan_kernel, dim3(1), dim3(SIZE_BINS), 0, st, size_bins);
             hipLaunchKernelGGL(msm_size_scatter_kernel, dim3((unsigned)((p.B + 1023) / 1024)), dim3(1024), 0, st, mt, (size_t)p.B, mcap, size_bins, perm);
         } else {
-        hipLaunchKernelGGL(msm_size_hist_kernel, dim3((unsigned)std::min<size_t>((WB + 255) / 256, 1024)), dim3(256), 0, st, totals, WB, cap, size_bins);
+        hipLaunchKernelGGL(msm_size_hist_kernel, dim3((unsigned)std::min<size_t>((WB + 255) / 256, 1024)), dim3(256), 0, st, totals, WB, cap, size_bins, d_adds);
         hipLaunchKernelGGL(msm_size_scan_kernel, dim3(1), dim3(SIZE_BINS), 0, st, size_bins);
         hipLaunchKernelGGL(msm_size_scatter_kernel, dim3((unsigned)((WB + 1023) / 1024)), dim3(1024), 0, st, totals, WB, cap, size_bins, perm);
         }
@@ -917,6 +937,7 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
                        buckets, p.B, p.L, p.T, p.nblk, winparts);
     FK_HIP(ctx, hipGetLastError());
     FK_HIP(ctx, hipMemcpyAsync(tl.h_wp, winparts, wp_bytes, hipMemcpyDeviceToHost, st));
+    FK_HIP(ctx, hipMemcpyAsync((char *)tl.h_wp + wp_bytes, d_adds, 8, hipMemcpyDeviceToHost, st));
     FK_HIP(ctx, hipEventRecord(tl.done, st));
     FK_DBG_ST(ctx, st, "msm_bucket_reduce");
     tl.active = true; tl.cb = p.cb; tl.wide = p.wide; tl.W = WR; tl.nblk = p.nblk;     // merged: one "window" of weight 1
@@ -933,6 +954,7 @@ static int msm_end(fk_ctx *ctx, int tail, Xyzz<F> *out) {
     tl.active = false;
     FK_HIP(ctx, hipEventSynchronize(tl.done));
     const Xyzz<F> *wp = (const Xyzz<F> *)tl.h_wp;
+    { uint64_t adds; memcpy(&adds, (const char *)tl.h_wp + (size_t)tl.W * tl.nblk * sizeof(Xyzz<F>), 8); ctx->acc_adds[sizeof(F) == sizeof(Fq) ? 0 : 1] += adds; }
     // Horner over windows, most significant first
     Xyzz<F> acc = Xyzz<F>::inf();
     for (uint32_t w = tl.W; w-- > 0;) {

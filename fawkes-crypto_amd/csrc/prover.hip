@@ -87,6 +87,8 @@ void fk_free(fk_ctx *ctx) {
         b->release();
     for (auto &v : {&ctx->ev_acc, &ctx->ev_acc2, &ctx->ev_ntt}) for (auto &ep : *v) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
+    if (ctx->copy_st) { (void)hipStreamSynchronize(ctx->copy_st); (void)hipStreamDestroy(ctx->copy_st); }
+    for (auto &w : ctx->wslot) { w.buf.release(); if (w.ready) (void)hipEventDestroy(w.ready); }
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -135,27 +137,49 @@ int fk_sync(fk_ctx *ctx) {
     return msm_sync(ctx);
 }
 
-// ------------------------------------------------------------------------------------------ key
-static void frac_slice(uint64_t n, double lo, double hi, uint64_t *olo, uint64_t *ohi) {
-    uint64_t a = (uint64_t)((long double)n * lo + 0.5L), b = (uint64_t)((long double)n * hi + 0.5L);
-    if (hi >= 1.0) b = n;
-    if (a > n) a = n;
-    if (b > n) b = n;
-    if (b < a) b = a;
-    *olo = a; *ohi = b;
+// ------------------------------------------------------------------------------------------ witness hand-over
+// prover.rs:69-76 produces the witness on the host for every proof.  Pinned buffers + two device slots filled on a copy
+// stream let the (num_input + num_aux) * 32-byte upload of proof k+1 run underneath proof k.
+int fk_host_alloc(fk_ctx *ctx, size_t bytes, void **hptr) {
+    if (!ctx || !hptr) return FK_ERR_BAD_ARG;
+    FK_HIP(ctx, hipSetDevice(ctx->device));
+    FK_HIP(ctx, hipHostMalloc(hptr, bytes ? bytes : 16, hipHostMallocDefault));
+    return FK_OK;
+}
+int fk_host_free(fk_ctx *ctx, void *hptr) {
+    if (!ctx) return FK_ERR_BAD_ARG;
+    if (hptr) FK_HIP(ctx, hipHostFree(hptr));
+    return FK_OK;
+}
+int fk_witness_upload_async(fk_ctx *ctx, int slot, const void *z_host, size_t bytes) {
+    if (!ctx) return FK_ERR_BAD_ARG;
+    if (slot < 0 || slot > 1 || (bytes && !z_host)) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "witness upload: slot must be 0 or 1, buffer non-null");
+    FK_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->copy_st) FK_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_st, hipStreamNonBlocking));
+    fk_ctx::WitSlot &w = ctx->wslot[slot];
+    if (!w.ready) FK_HIP(ctx, hipEventCreateWithFlags(&w.ready, hipEventDisableTiming));
+    if (bytes > w.buf.cap) {                      // growing frees the old buffer: nothing may still be reading or filling it
+        FK_HIP(ctx, hipStreamSynchronize(ctx->copy_st));
+        FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        FK_TRY(msm_sync(ctx));
+        FK_HIP(ctx, w.buf.reserve(bytes));
+    }
+    if (bytes) FK_HIP(ctx, hipMemcpyAsync(w.buf.p, z_host, bytes, hipMemcpyHostToDevice, ctx->copy_st));
+    FK_HIP(ctx, hipEventRecord(w.ready, ctx->copy_st));
+    return FK_OK;
+}
+int fk_witness_ptr(fk_ctx *ctx, int slot, void **dptr) {
+    if (!ctx || !dptr) return FK_ERR_BAD_ARG;
+    if (slot < 0 || slot > 1 || !ctx->wslot[slot].ready) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "witness slot %d holds nothing", slot);
+    FK_HIP(ctx, hipSetDevice(ctx->device));
+    FK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->wslot[slot].ready, 0));      // stream-ordered: the host does not wait
+    *dptr = ctx->wslot[slot].buf.p;
+    return FK_OK;
 }
 
+// ------------------------------------------------------------------------------------------ key
 static int key_alloc_slices(fk_ctx *ctx, fk_key *k, double zlo, double zhi) {
-    h_slice(k->n_h, k->shard_index, k->shard_count, &k->h_lo, &k->h_hi);
-    if (zlo == 0.0 && zhi == 0.0) {
-        slice(k->n_l, k->shard_index, k->shard_count, &k->l_lo, &k->l_hi);
-        slice(k->n_a, k->shard_index, k->shard_count, &k->a_lo, &k->a_hi);
-        slice(k->n_b, k->shard_index, k->shard_count, &k->b_lo, &k->b_hi);
-    } else {
-        frac_slice(k->n_l, zlo, zhi, &k->l_lo, &k->l_hi);
-        frac_slice(k->n_a, zlo, zhi, &k->a_lo, &k->a_hi);
-        frac_slice(k->n_b, zlo, zhi, &k->b_lo, &k->b_hi);
-    }
+    FK_TRY(key_plan_slices(ctx, k, zlo, zhi));
     FK_HIP(ctx, hipMalloc((void **)&k->d_h, (k->h_hi - k->h_lo) * 64 + 64));
     FK_HIP(ctx, hipMalloc((void **)&k->d_l, (k->l_hi - k->l_lo) * 64 + 64));
     FK_HIP(ctx, hipMalloc((void **)&k->d_a, (k->a_hi - k->a_lo) * 64 + 64));
@@ -182,11 +206,6 @@ static int key_check_shape(fk_ctx *ctx, uint64_t m, uint32_t num_input, uint64_t
     if (shard_count == 0 || shard_index >= shard_count) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "key: bad shard %u/%u", shard_index, shard_count);
     return FK_OK;
 }
-static int key_check_frac(fk_ctx *ctx, double lo, double hi) {
-    if (!(lo >= 0.0 && hi <= 1.0 && lo <= hi)) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "key: bad z fraction range [%g, %g)", lo, hi);
-    return FK_OK;
-}
-
 int fk_key_load(fk_ctx *ctx, const fk_key_desc *d, fk_key **out) {
     if (!ctx || !d || !out) return FK_ERR_BAD_ARG;
     *out = nullptr;
@@ -201,7 +220,6 @@ int fk_key_load(fk_ctx *ctx, const fk_key_desc *d, fk_key **out) {
     k->shard_index = d->shard_index; k->shard_count = d->shard_count;
     k->alpha_g1 = g1_from_raw(d->alpha_g1); k->beta_g1 = g1_from_raw(d->beta_g1); k->delta_g1 = g1_from_raw(d->delta_g1);
     k->beta_g2 = g2_from_raw(d->beta_g2); k->delta_g2 = g2_from_raw(d->delta_g2);
-    FK_TRY(key_check_frac(ctx, d->z_frac_lo, d->z_frac_hi));
     int rc = key_alloc_slices(ctx, k, d->z_frac_lo, d->z_frac_hi);
     auto up = [&](void *dst, const uint8_t *src, uint64_t lo, uint64_t hi, size_t w) -> int {
         if (hi > lo) FK_HIP(ctx, hipMemcpy(dst, src + lo * w, (hi - lo) * w, hipMemcpyHostToDevice));
@@ -252,8 +270,7 @@ int fk_key_synthetic(fk_ctx *ctx, uint64_t m, uint32_t num_input, uint32_t num_a
     k->m = m; k->num_input = num_input; k->num_aux = num_aux;
     k->n_h = m - 1; k->n_l = num_aux; k->n_a = n_a; k->n_b = n_b;
     k->shard_index = shard_index; k->shard_count = shard_count;
-    int rc = key_check_frac(ctx, z_frac_lo, z_frac_hi);
-    if (rc == FK_OK) rc = key_alloc_slices(ctx, k, z_frac_lo, z_frac_hi);
+    int rc = key_alloc_slices(ctx, k, z_frac_lo, z_frac_hi);
     const uint64_t sd = seed * 1000003ull + shard_index * 7919ull;
     if (rc == FK_OK) rc = gen_points_g1(ctx, k->d_h, k->h_hi - k->h_lo, sd + 1);
     if (rc == FK_OK) rc = gen_points_g1(ctx, k->d_l, k->l_hi - k->l_lo, sd + 2);
@@ -765,16 +782,18 @@ int fk_stats_reset(fk_ctx *ctx) {
         for (auto &ep : *v) { ctx->ev_pool.push_back(ep.a); ctx->ev_pool.push_back(ep.b); }
         v->clear();
     }
+    ctx->acc_adds[0] = ctx->acc_adds[1] = 0;
     return FK_OK;
 }
 int fk_stats_get(fk_ctx *ctx, int which, double *ms, uint64_t *launches, uint64_t *units) {
     if (!ctx) return FK_ERR_BAD_ARG;
-    if (which < 0 || which > 2) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "stats: which must be 0 (G1 accumulate), 1 (G2 accumulate) or 2 (NTT pass)");
+    if (which < 0 || which > 4) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "stats: which must be 0 / 3 (G1 accumulate), 1 / 4 (G2 accumulate) or 2 (NTT pass)");
     FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     FK_TRY(msm_sync(ctx));
-    std::vector<EventPair> &v = which == 0 ? ctx->ev_acc : (which == 1 ? ctx->ev_acc2 : ctx->ev_ntt);
+    std::vector<EventPair> &v = (which == 0 || which == 3) ? ctx->ev_acc : ((which == 1 || which == 4) ? ctx->ev_acc2 : ctx->ev_ntt);
     double t = 0; uint64_t u = 0;
     for (auto &ep : v) { float x = 0; FK_HIP(ctx, hipEventElapsedTime(&x, ep.a, ep.b)); t += x; u += ep.units; }
+    if (which >= 3) u = ctx->acc_adds[which - 3];
     if (ms) *ms = t;
     if (launches) *launches = v.size();
     if (units) *units = u;

@@ -249,7 +249,8 @@ static int setup_impl(fk_ctx *ctx, const fk_r1cs *cs, uint32_t copies, const uin
     if (!cs || !tau_ || !alpha_ || !beta_ || !gamma_ || !delta_ || !out_key || !vk_out || !ic_out) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "setup: null argument");
     *out_key = nullptr;
     if (shard_count == 0 || shard_index >= shard_count) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "setup: bad shard %u/%u", shard_index, shard_count);
-    if (!(z_frac_lo >= 0.0 && z_frac_hi <= 1.0 && z_frac_lo <= z_frac_hi)) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "setup: bad z fraction range");
+    if (z_frac_lo >= 0.0 && (!(z_frac_hi <= 1.0 && z_frac_lo <= z_frac_hi) || (shard_count == 1 && !(z_frac_lo == 0.0 && z_frac_hi >= 1.0))))
+        FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "setup: bad z fraction range [%g, %g)", z_frac_lo, z_frac_hi);
     FK_HIP(ctx, hipSetDevice(ctx->device));
     const Fr tau = fr_load(tau_), alpha = fr_load(alpha_), beta = fr_load(beta_), gamma = fr_load(gamma_), delta = fr_load(delta_);
     if (gamma.is_zero() || delta.is_zero()) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "setup: gamma and delta must be non-zero");
@@ -397,34 +398,36 @@ static int setup_impl(fk_ctx *ctx, const fk_r1cs *cs, uint32_t copies, const uin
     FK_HIP(ctx, hipMemcpy(d_t2, t2.data(), t2.size() * sizeof(G2Affine), hipMemcpyHostToDevice));
 
     fk_key *k = new fk_key();
-    k->m = m; k->num_input = num_input; k->num_aux = num_aux; k->shard_index = 0; k->shard_count = 1;
+    k->m = m; k->num_input = num_input; k->num_aux = num_aux; k->shard_index = shard_index; k->shard_count = shard_count;
     k->n_h = m - 1; k->n_l = num_aux;
     auto fail = [&](int code, const char *msg) { ctx->err = msg; fk_key_free(ctx, k); return code; };
-    G1Affine *d_a_all = (G1Affine *)dalloc(nv * sizeof(G1Affine)), *d_b1_all = (G1Affine *)dalloc(nv * sizeof(G1Affine)), *d_el = (G1Affine *)dalloc(nv * sizeof(G1Affine));
-    G2Affine *d_b2_all = (G2Affine *)dalloc(nv * sizeof(G2Affine));
-    if (!d_a_all || !d_b1_all || !d_el || !d_b2_all) return fail(FK_ERR_OOM, "setup: device allocation failed");
-    if (hipMalloc((void **)&k->d_h, m * sizeof(G1Affine)) != hipSuccess || hipMalloc((void **)&k->d_l, (num_aux + 1) * sizeof(G1Affine)) != hipSuccess ||
-        hipMalloc((void **)&k->d_a, (nv + 1) * sizeof(G1Affine)) != hipSuccess || hipMalloc((void **)&k->d_b1, (nv + 1) * sizeof(G1Affine)) != hipSuccess ||
-        hipMalloc((void **)&k->d_b2, (nv + 1) * sizeof(G2Affine)) != hipSuccess) return fail(FK_ERR_OOM, "setup: device allocation failed");
+    // a, b_g1, b_g2 hold only the variables whose A_v (B_v) is non-zero, in variable order: compact the SCALARS first, so
+    // that the counts are known before anything is allocated and only this shard's slice of every array is ever derived
+    // (W ranks deriving a key do 1/W of the fixed-base work each; the points of a variable are the same either way)
+    Fr *d_sa = (Fr *)dalloc((nv + 1) * sizeof(Fr)), *d_sb = (Fr *)dalloc((nv + 1) * sizeof(Fr));
+    if (!d_sa || !d_sb) return fail(FK_ERR_OOM, "setup: device allocation failed");
+    uint64_t n_a = 0, n_b = 0;
+    int rc = compact_elems<Fr>(ctx, d_abc[0], d_fa, nv, d_sa, &n_a);
+    if (rc == FK_OK) rc = compact_elems<Fr>(ctx, d_abc[1], d_fb, nv, d_sb, &n_b);
+    if (rc != FK_OK) { fk_key_free(ctx, k); return rc; }
+    k->n_a = n_a; k->n_b = n_b;
+    if ((rc = key_plan_slices(ctx, k, z_frac_lo, z_frac_hi)) != FK_OK) { fk_key_free(ctx, k); return rc; }
+    const uint64_t c_h = k->h_hi - k->h_lo, c_l = k->l_hi - k->l_lo, c_a = k->a_hi - k->a_lo, c_b = k->b_hi - k->b_lo;
+    G1Affine *d_ic = (G1Affine *)dalloc((size_t)num_input * sizeof(G1Affine));
+    if (!d_ic) return fail(FK_ERR_OOM, "setup: device allocation failed");
+    if (hipMalloc((void **)&k->d_h, (c_h + 1) * sizeof(G1Affine)) != hipSuccess || hipMalloc((void **)&k->d_l, (c_l + 1) * sizeof(G1Affine)) != hipSuccess ||
+        hipMalloc((void **)&k->d_a, (c_a + 1) * sizeof(G1Affine)) != hipSuccess || hipMalloc((void **)&k->d_b1, (c_b + 1) * sizeof(G1Affine)) != hipSuccess ||
+        hipMalloc((void **)&k->d_b2, (c_b + 1) * sizeof(G2Affine)) != hipSuccess) return fail(FK_ERR_OOM, "setup: device allocation failed");
     const unsigned fb_threads = 128;
     auto fb1 = [&](const Fr *sc, size_t n, G1Affine *o) { if (n) hipLaunchKernelGGL(HIP_KERNEL_NAME(fixed_base_kernel<Fq>), dim3((unsigned)((n + fb_threads - 1) / fb_threads)), dim3(fb_threads), 0, st, d_t1, sc, n, o); };
-    fb1(d_hs, m - 1, k->d_h);
-    fb1(d_abc[0], nv, d_a_all);
-    fb1(d_abc[1], nv, d_b1_all);
-    fb1(d_e, nv, d_el);
-    if (nv) hipLaunchKernelGGL(HIP_KERNEL_NAME(fixed_base_kernel<Fq2>), dim3((unsigned)((nv + fb_threads - 1) / fb_threads)), dim3(fb_threads), 0, st, d_t2, d_abc[1], (size_t)nv, d_b2_all);
+    fb1(d_hs + k->h_lo, c_h, k->d_h);
+    fb1(d_e + num_input + k->l_lo, c_l, k->d_l);            // l = exponent points of the aux variables
+    fb1(d_e, num_input, d_ic);                              // ic = those of the inputs
+    fb1(d_sa + k->a_lo, c_a, k->d_a);
+    fb1(d_sb + k->b_lo, c_b, k->d_b1);
+    if (c_b) hipLaunchKernelGGL(HIP_KERNEL_NAME(fixed_base_kernel<Fq2>), dim3((unsigned)((c_b + fb_threads - 1) / fb_threads)), dim3(fb_threads), 0, st, d_t2, d_sb + k->b_lo, (size_t)c_b, k->d_b2);
     if (hipGetLastError() != hipSuccess) return fail(FK_ERR_HIP, "setup: kernel launch failed");
-    // l = exponent points of the aux variables; ic = those of the inputs
-    if (hipMemcpyAsync(k->d_l, d_el + num_input, (size_t)num_aux * sizeof(G1Affine), hipMemcpyDeviceToDevice, st) != hipSuccess ||
-        hipMemcpyAsync(ic_out, d_el, (size_t)num_input * sizeof(G1Affine), hipMemcpyDeviceToHost, st) != hipSuccess) return fail(FK_ERR_HIP, "setup: copy failed");
-    // a, b_g1, b_g2: drop identity points, keep order
-    uint64_t n_a = 0, n_b1 = 0, n_b2 = 0;
-    int rc = compact_elems<G1Affine>(ctx, d_a_all, d_fa, nv, k->d_a, &n_a);
-    if (rc == FK_OK) rc = compact_elems<G1Affine>(ctx, d_b1_all, d_fb, nv, k->d_b1, &n_b1);
-    if (rc == FK_OK) rc = compact_elems<G2Affine>(ctx, d_b2_all, d_fb, nv, k->d_b2, &n_b2);
-    if (rc != FK_OK) { fk_key_free(ctx, k); return rc; }
-    k->n_a = n_a; k->n_b = n_b1;
-    k->h_lo = 0; k->h_hi = k->n_h; k->l_lo = 0; k->l_hi = k->n_l; k->a_lo = 0; k->a_hi = n_a; k->b_lo = 0; k->b_hi = n_b1;
+    if (hipMemcpyAsync(ic_out, d_ic, (size_t)num_input * sizeof(G1Affine), hipMemcpyDeviceToHost, st) != hipSuccess) return fail(FK_ERR_HIP, "setup: copy failed");
     // vk
     k->alpha_g1 = host_mul<Fq>(g1, alpha); k->beta_g1 = host_mul<Fq>(g1, beta); k->delta_g1 = host_mul<Fq>(g1, delta);
     k->beta_g2 = host_mul<Fq2>(g2, beta); k->delta_g2 = host_mul<Fq2>(g2, delta);
@@ -433,29 +436,8 @@ static int setup_impl(fk_ctx *ctx, const fk_r1cs *cs, uint32_t copies, const uin
     memcpy(vk_out + 0 * 128, &k->alpha_g1, 64); memcpy(vk_out + 1 * 128, &k->beta_g1, 64); memcpy(vk_out + 2 * 128, &k->beta_g2, 128);
     memcpy(vk_out + 3 * 128, &gamma_g2, 128); memcpy(vk_out + 4 * 128, &k->delta_g1, 64); memcpy(vk_out + 5 * 128, &k->delta_g2, 128);
     if (hipStreamSynchronize(st) != hipSuccess) return fail(FK_ERR_HIP, "setup: synchronize failed");
-    // multi-GPU: keep only this rank's slices (every rank derives the same key deterministically)
-    if (shard_count > 1 || z_frac_lo != 0.0 || z_frac_hi != 0.0) {
-        k->shard_index = shard_index; k->shard_count = shard_count;
-        auto sl = [](uint64_t n, uint32_t i, uint32_t c, uint64_t *lo, uint64_t *hi) { *lo = (uint64_t)((unsigned __int128)n * i / c); *hi = (uint64_t)((unsigned __int128)n * (i + 1) / c); };
-        auto fr = [](uint64_t n, double lo, double hi, uint64_t *olo, uint64_t *ohi) {
-            uint64_t a = (uint64_t)((long double)n * lo + 0.5L), b = hi >= 1.0 ? n : (uint64_t)((long double)n * hi + 0.5L);
-            if (a > n) a = n; if (b > n) b = n; if (b < a) b = a; *olo = a; *ohi = b; };
-        h_slice(k->n_h, shard_index, shard_count, &k->h_lo, &k->h_hi);
-        if (z_frac_lo == 0.0 && z_frac_hi == 0.0) { sl(k->n_l, shard_index, shard_count, &k->l_lo, &k->l_hi); sl(k->n_a, shard_index, shard_count, &k->a_lo, &k->a_hi); sl(k->n_b, shard_index, shard_count, &k->b_lo, &k->b_hi); }
-        else { fr(k->n_l, z_frac_lo, z_frac_hi, &k->l_lo, &k->l_hi); fr(k->n_a, z_frac_lo, z_frac_hi, &k->a_lo, &k->a_hi); fr(k->n_b, z_frac_lo, z_frac_hi, &k->b_lo, &k->b_hi); }
-        auto shrink = [&](void **p, uint64_t lo, uint64_t hi, size_t w) -> int {
-            void *q = nullptr;
-            if (hipMalloc(&q, (hi - lo) * w + w) != hipSuccess) return FK_ERR_OOM;
-            if (hi > lo && hipMemcpy(q, (char *)*p + lo * w, (hi - lo) * w, hipMemcpyDeviceToDevice) != hipSuccess) { (void)hipFree(q); return FK_ERR_HIP; }
-            (void)hipFree(*p); *p = q; return FK_OK;
-        };
-        int rc2 = shrink((void **)&k->d_h, k->h_lo, k->h_hi, 64);
-        if (rc2 == FK_OK) rc2 = shrink((void **)&k->d_l, k->l_lo, k->l_hi, 64);
-        if (rc2 == FK_OK) rc2 = shrink((void **)&k->d_a, k->a_lo, k->a_hi, 64);
-        if (rc2 == FK_OK) rc2 = shrink((void **)&k->d_b1, k->b_lo, k->b_hi, 64);
-        if (rc2 == FK_OK) rc2 = shrink((void **)&k->d_b2, k->b_lo, k->b_hi, 128);
-        if (rc2 != FK_OK) return fail(rc2, "setup: resharding failed");
-    }
+    // the scalar-side temporaries (a few GB at 2^25) go before the fixed-base levels are sized against free memory
+    for (void *&p : tmp.v) { if (p) (void)hipFree(p); p = nullptr; }
     { const int rc3 = key_precompute(ctx, k); if (rc3 != FK_OK) { fk_key_free(ctx, k); return rc3; } }
     *out_key = k;
     return FK_OK;

@@ -397,4 +397,29 @@ int fk_prove_r1cs(fk_ctx *ctx, const fk_key *key, const fk_r1cs_dev *r, const ui
     return fk_prove_r1cs_dev(ctx, key, r, ctx->stage_z.p, rr, ss, out_proof, tm);
 }
 
+// Pipelined form of fk_prove_r1cs: _submit starts the upload of the witness into one of the two slots and returns at once;
+// _wait computes that proof.  Calling submit(k+1) before wait(k) hides the upload of proof k+1 underneath proof k.
+int fk_prove_r1cs_submit(fk_ctx *ctx, const fk_key *key, const fk_r1cs_dev *r, const uint64_t *z, const uint64_t rr[4], const uint64_t ss[4], int *ticket) {
+    if (!ctx) return FK_ERR_BAD_ARG;
+    if (!key || !r || !z || !rr || !ss || !ticket) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "prove: null argument");
+    const int slot = ctx->wslot_next;
+    if (ctx->wslot[slot].pending) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "prove: two proofs are already submitted (call fk_prove_r1cs_wait first)");
+    FK_TRY(fk_witness_upload_async(ctx, slot, z, ((size_t)r->num_input + r->num_aux) * sizeof(Fr)));
+    fk_ctx::WitSlot &w = ctx->wslot[slot];
+    w.pending = true; w.key = key; w.r1cs = r;
+    memcpy(w.r, rr, 32); memcpy(w.s, ss, 32);
+    ctx->wslot_next = slot ^ 1;
+    *ticket = slot;
+    return FK_OK;
+}
+int fk_prove_r1cs_wait(fk_ctx *ctx, int ticket, uint8_t out_proof[FK_PROOF_BYTES], fk_timings *tm) {
+    if (!ctx) return FK_ERR_BAD_ARG;
+    if (ticket < 0 || ticket > 1 || !ctx->wslot[ticket].pending) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "prove: no submitted proof with ticket %d", ticket);
+    fk_ctx::WitSlot &w = ctx->wslot[ticket];
+    w.pending = false;
+    void *d_z = nullptr;
+    FK_TRY(fk_witness_ptr(ctx, ticket, &d_z));
+    return fk_prove_r1cs_dev(ctx, w.key, w.r1cs, d_z, w.r, w.s, out_proof, tm);
+}
+
 }  // extern "C"

@@ -175,7 +175,7 @@ def read_parameters(data):
     return dict(num_gates=num_gates, gates_blob=gates_blob, const_tracker=bytes_to_bits(bv, nbits), bellman=data[pos:])
 
 
-def load_parameters(ctx, data, decompress=None, shard_index=0, shard_count=1, z_frac=(0.0, 0.0)):
+def load_parameters(ctx, data, decompress=None, shard_index=0, shard_count=1, z_frac=(-1.0, -1.0)):
     """File bytes -> (DeviceKey resident in HBM, api.R1cs or None, header dict incl. gamma_g2 / ic for a verifier).
     The constraint system is decoded when the blob can be decompressed (`decompress=brotli.decompress`) or was
     written raw by `store_parameters`."""

@@ -52,6 +52,7 @@ enum {
     FK_ERR_KEY_MISMATCH = 6          /* key arrays do not match m / densities (bellman: get_* errors) */
 };
 
+#define FK_Z_EQUAL_SPLIT (-1.0)   /* z_frac_lo of every key loader: equal split by shard_index / shard_count */
 #define FK_PROOF_BYTES 256
 #define FK_G1_BYTES 64
 #define FK_G2_BYTES 128
@@ -73,6 +74,15 @@ int fk_download(fk_ctx *ctx, void *host, const void *dptr, size_t bytes);
 /* asynchronous device-to-device copy on the library stream */
 int fk_dev_copy(fk_ctx *ctx, void *dst, const void *src, size_t bytes);
 int fk_sync(fk_ctx *ctx);
+/* pinned host memory (hipHostMalloc): witness buffers handed to fk_prove_r1cs_submit / fk_witness_upload_async */
+int fk_host_alloc(fk_ctx *ctx, size_t bytes, void **hptr);
+int fk_host_free(fk_ctx *ctx, void *hptr);
+/* Two witness slots in device memory, filled on the library's copy stream.  _upload_async returns at once; fk_witness_ptr
+ * makes the library's main stream wait for that slot's copy (stream-ordered, the host does not block) and returns the
+ * device pointer, to be passed as d_z to the *_dev provers (multi-GPU schedules: every rank uploads the next proof's
+ * witness underneath the current proof).  A slot may be refilled once the proof that read it has returned. */
+int fk_witness_upload_async(fk_ctx *ctx, int slot, const void *z_host, size_t bytes);
+int fk_witness_ptr(fk_ctx *ctx, int slot, void **dptr);
 
 /* ---------------------------------------------------------------- proving key
  * Replaces the `params.0` argument of prover.rs:80, i.e. bellman's `Parameters` { vk, h, l, a, b_g1,
@@ -90,9 +100,11 @@ typedef struct {
     const uint8_t *a;   uint64_t n_a;               /* num_input + popcount(a_aux) points */
     const uint8_t *b_g1; const uint8_t *b_g2; uint64_t n_b;  /* popcount(b_input)+popcount(b_aux) */
     uint32_t shard_index, shard_count;              /* 0,1 for a single GPU: slice of h */
-    /* slice of l, a, b_g1, b_g2 as fractions of each array: [z_frac_lo, z_frac_hi).  Both 0 = the same
-     * equal split as h.  Unequal fractions let the rank that computes the quotient take fewer witness
-     * points (work-balanced multi-GPU schedule, fawkes-crypto_amd/parallel.py). */
+    /* slice of l, a, b_g1, b_g2: z_frac_lo = FK_Z_EQUAL_SPLIT (any negative value; z_frac_hi ignored) = the same equal
+     * split as h.  Otherwise the fractions [z_frac_lo, z_frac_hi) of each array; (0, 0) is the EMPTY slice.  Unequal
+     * fractions let the rank that computes the quotient take fewer witness points, possibly none (work-balanced
+     * multi-GPU schedule, fawkes-crypto_amd/parallel.py).  A lone shard (shard_count = 1) must hold everything:
+     * FK_Z_EQUAL_SPLIT or [0, 1) -- a zero-initialised descriptor is refused with FK_ERR_BAD_ARG. */
     double z_frac_lo, z_frac_hi;
 } fk_key_desc;
 
@@ -264,11 +276,22 @@ int fk_prove_msms_hz_r1cs_dev(fk_ctx *ctx, const fk_key *key, const fk_r1cs_dev 
                               uint8_t out_msms[FK_MSM_RESULT_BYTES]);
 int fk_prove_r1cs_dev(fk_ctx *ctx, const fk_key *key, const fk_r1cs_dev *r1cs, const void *d_z,
                       const uint64_t r[4], const uint64_t s[4], uint8_t out_proof[FK_PROOF_BYTES], fk_timings *timings);
+/* The same proof, pipelined over the host boundary.  The reference produces the witness on the host for every proof
+ * (prover.rs:69-76: the circuit closure fills WitnessCS, then prover.rs:80 consumes it), so a proving loop hands over
+ * (num_input + num_aux) * 32 bytes per proof -- 1 GiB at 2^25 variables.  _submit starts the host-to-device copy into one
+ * of two witness slots on a copy stream and returns at once; _wait computes the proof of that ticket.  With
+ * submit(k+1) issued before wait(k) the upload of the next witness runs underneath the current proof.  At most two
+ * tickets are outstanding; z must stay valid until the matching _wait returns and should be pinned memory
+ * (fk_host_alloc) -- pageable memory works but is staged by the runtime and does not overlap. */
+int fk_prove_r1cs_submit(fk_ctx *ctx, const fk_key *key, const fk_r1cs_dev *r1cs, const uint64_t *z,
+                         const uint64_t r[4], const uint64_t s[4], int *ticket);
+int fk_prove_r1cs_wait(fk_ctx *ctx, int ticket, uint8_t out_proof[FK_PROOF_BYTES], fk_timings *timings);
 
 /* ---------------------------------------------------------------- key generation on the GPU
  * (SURVEY section 8f row 4): bellman's generate_parameters (reached from setup.rs:20) for EXPLICIT toxic
  * waste tau, alpha, beta, gamma, delta (Montgomery Fr) and the standard BN254 generators.  Produces a
- * resident proving key (the full key is derived, then only the requested shard is kept; 0,1,0,0 = whole key).  vk_out: six 128-byte slots alpha_g1, beta_g1, beta_g2, gamma_g2, delta_g1,
+ * resident proving key; with shard_count > 1 only the requested shard of every array is derived (W ranks do 1/W of the fixed-base work
+ * each); shard 0 of 1 with z_frac_lo = FK_Z_EQUAL_SPLIT = whole key.  vk_out: six 128-byte slots alpha_g1, beta_g1, beta_g2, gamma_g2, delta_g1,
  * delta_g2 (G1 points use the first 64 bytes); ic_out: num_input x 64 bytes.  For tests and benchmarks:
  * a real deployment runs an MPC ceremony, never a setup with known toxic waste. */
 int fk_setup(fk_ctx *ctx, const fk_r1cs *cs, const uint64_t tau[4], const uint64_t alpha[4], const uint64_t beta[4],
@@ -299,8 +322,14 @@ int fk_key_counts(const fk_key *key, uint64_t out[8]);
 
 /* Kernel timing measured with HIP events on the library's stream since the last reset, summed over
  * launches.  which: 0 = msm_accumulate_kernel<Fq> (G1 bucket accumulation; units = points per launch),
- * 1 = msm_accumulate_kernel<Fq2> (G2), 2 = ntt_pass_kernel (units = elements per pass). */
+ * 1 = msm_accumulate_kernel<Fq2> (G2), 2 = ntt_pass_kernel (units = elements per pass); 3 / 4 = the same kernels as 0 / 1
+ * with units = the mixed point additions they performed (the work unit of the VALU roofline: 10 modular products each
+ * in G1), counted on the device from the sorted bucket sizes. */
 int fk_stats_reset(fk_ctx *ctx);
+/* Live calibration of the VALU ceilings the measurement quotes (a few milliseconds): out[0] = v_mad_u64_u32 lane-operations
+ * per second (the 32 x 32 -> 64-bit multiply-accumulate every Montgomery product is made of), out[1] = Montgomery products
+ * per second of the library's multiplier running alone in registers. */
+int fk_calibrate(fk_ctx *ctx, double out[2]);
 int fk_stats_get(fk_ctx *ctx, int which, double *ms, uint64_t *launches, uint64_t *units);
 
 #ifdef __cplusplus

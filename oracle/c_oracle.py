@@ -273,7 +273,10 @@ def setup(cs, tau, alpha, beta, gamma, delta, g1=None, g2=None):
     return Key(ptr)
 
 
-def prove(key, a, b, c, z, a_aux, b_in, b_aux, r_mont, s_mont, want_msm=False):
+def prove(key, a, b, c, z, a_aux, b_in, b_aux, r_mont, s_mont, want_msm=False, threads=1):
+    """threads: bellman's Worker size.  1 = the serial prover (fawkes-crypto's configuration); more = bellman's multicore
+    split restated (parallel_fft, one task per multiexp region) -- same proof bytes."""
+    lib().orc_set_threads(C.c_int(int(threads)))
     a = np.ascontiguousarray(a, np.uint64); b = np.ascontiguousarray(b, np.uint64); c = np.ascontiguousarray(c, np.uint64)
     z = np.ascontiguousarray(z, np.uint64)
     out = np.zeros(256, np.uint8)
@@ -283,6 +286,7 @@ def prove(key, a, b, c, z, a_aux, b_in, b_aux, r_mont, s_mont, want_msm=False):
                          _p(np.ascontiguousarray(b_aux, np.uint8)),
                          _p(np.ascontiguousarray(r_mont, np.uint64)), _p(np.ascontiguousarray(s_mont, np.uint64)),
                          _p(out), _p(msm))
+    lib().orc_set_threads(C.c_int(1))
     if rc != 0:
         raise RuntimeError('orc_prove rc=%d' % rc)
     return (out, msm) if want_msm else out

@@ -112,54 +112,63 @@ static void CT_NAME(jac_mul)(CT_NAME(jac) *o, const CT_NAME(jac) *p, const uint6
  * high -> low with c doublings.  `density` (may be NULL = FullDensity) selects which scalars take part;
  * bases are consumed one per *selected* scalar (the key arrays are compacted).
  * exps: canonical 4x64 LE per scalar. */
-static void CT_NAME(multiexp)(CT_NAME(jac) *out, const CT_NAME(aff) *bases, const uint8_t *density,
-                              const uint64_t *exps, size_t n_exps) {
-    size_t n_sel = 0;
-    if (density) { for (size_t i = 0; i < n_exps; i++) n_sel += density[i] ? 1 : 0; } else n_sel = n_exps;
-    /* bellman sizes c from exponents.len() (the un-filtered length) */
-    unsigned c;
-    if (n_exps < 32) c = 3; else c = (unsigned)ceil(log((double)(uint32_t)n_exps));
-    (void)n_sel;
-    size_t nb = ((size_t)1 << c) - 1;
-    CT_NAME(jac) *buckets = (CT_NAME(jac) *)malloc(nb * sizeof(CT_NAME(jac)));
+static unsigned CT_NAME(multiexp_window)(size_t n_exps) {      /* bellman sizes c from exponents.len() (the un-filtered length) */
+    return n_exps < 32 ? 3 : (unsigned)ceil(log((double)(uint32_t)n_exps));
+}
+static unsigned CT_NAME(multiexp_regions)(unsigned c) {
     unsigned nregions = 0;
     for (unsigned skip = 0; ; skip += c) { nregions++; if (skip + c >= 254) break; }
-    CT_NAME(jac) *regions = (CT_NAME(jac) *)malloc(nregions * sizeof(CT_NAME(jac)));
-    unsigned skip = 0;
-    for (unsigned reg = 0; reg < nregions; reg++, skip += c) {
-        CT_NAME(jac) acc; CT_NAME(jac_set_inf)(&acc);
-        for (size_t i = 0; i < nb; i++) CT_NAME(jac_set_inf)(&buckets[i]);
-        size_t bi = 0;
-        for (size_t i = 0; i < n_exps; i++) {
-            if (density && !density[i]) continue;
-            const uint64_t *e = exps + 4 * i;
-            const CT_NAME(aff) *base = &bases[bi++];
-            if ((e[0] | e[1] | e[2] | e[3]) == 0) continue;
-            if (e[0] == 1 && (e[1] | e[2] | e[3]) == 0) {
-                if (reg == 0) CT_NAME(jac_add_mixed)(&acc, base);
-                continue;
-            }
-            /* (e >> skip) mod 2^c */
-            unsigned limb = skip >> 6, off = skip & 63;
-            uint64_t v = e[limb] >> off;
-            if (off && limb + 1 < 4) v |= e[limb + 1] << (64 - off);
-            v &= ((uint64_t)1 << c) - 1;
-            if (v) CT_NAME(jac_add_mixed)(&buckets[v - 1], base);
+    return nregions;
+}
+/* one region (window) of the sum: bellman spawns exactly this unit of work on its thread pool (multiexp_inner) */
+static void CT_NAME(multiexp_region)(CT_NAME(jac) *out, const CT_NAME(aff) *bases, const uint8_t *density,
+                                     const uint64_t *exps, size_t n_exps, unsigned c, unsigned reg) {
+    const size_t nb = ((size_t)1 << c) - 1;
+    const unsigned skip = reg * c;
+    CT_NAME(jac) *buckets = (CT_NAME(jac) *)malloc(nb * sizeof(CT_NAME(jac)));
+    CT_NAME(jac) acc; CT_NAME(jac_set_inf)(&acc);
+    for (size_t i = 0; i < nb; i++) CT_NAME(jac_set_inf)(&buckets[i]);
+    size_t bi = 0;
+    for (size_t i = 0; i < n_exps; i++) {
+        if (density && !density[i]) continue;
+        const uint64_t *e = exps + 4 * i;
+        const CT_NAME(aff) *base = &bases[bi++];
+        if ((e[0] | e[1] | e[2] | e[3]) == 0) continue;
+        if (e[0] == 1 && (e[1] | e[2] | e[3]) == 0) {
+            if (reg == 0) CT_NAME(jac_add_mixed)(&acc, base);
+            continue;
         }
-        CT_NAME(jac) running; CT_NAME(jac_set_inf)(&running);
-        for (size_t i = nb; i-- > 0;) {
-            CT_NAME(jac_add)(&running, &buckets[i]);
-            CT_NAME(jac_add)(&acc, &running);
-        }
-        regions[reg] = acc;
+        /* (e >> skip) mod 2^c */
+        unsigned limb = skip >> 6, off = skip & 63;
+        uint64_t v = e[limb] >> off;
+        if (off && limb + 1 < 4) v |= e[limb + 1] << (64 - off);
+        v &= ((uint64_t)1 << c) - 1;
+        if (v) CT_NAME(jac_add_mixed)(&buckets[v - 1], base);
     }
+    CT_NAME(jac) running; CT_NAME(jac_set_inf)(&running);
+    for (size_t i = nb; i-- > 0;) {
+        CT_NAME(jac_add)(&running, &buckets[i]);
+        CT_NAME(jac_add)(&acc, &running);
+    }
+    *out = acc;
+    free(buckets);
+}
+/* regions joined high -> low with c doublings */
+static void CT_NAME(multiexp_join)(CT_NAME(jac) *out, const CT_NAME(jac) *regions, unsigned nregions, unsigned c) {
     CT_NAME(jac) res = regions[nregions - 1];
     for (unsigned reg = nregions - 1; reg-- > 0;) {
         for (unsigned k = 0; k < c; k++) CT_NAME(jac_double)(&res);
         CT_NAME(jac_add)(&res, &regions[reg]);
     }
     *out = res;
-    free(buckets); free(regions);
+}
+static void CT_NAME(multiexp)(CT_NAME(jac) *out, const CT_NAME(aff) *bases, const uint8_t *density,
+                              const uint64_t *exps, size_t n_exps) {
+    const unsigned c = CT_NAME(multiexp_window)(n_exps), nregions = CT_NAME(multiexp_regions)(c);
+    CT_NAME(jac) *regions = (CT_NAME(jac) *)malloc(nregions * sizeof(CT_NAME(jac)));
+    for (unsigned reg = 0; reg < nregions; reg++) CT_NAME(multiexp_region)(&regions[reg], bases, density, exps, n_exps, c, reg);
+    CT_NAME(multiexp_join)(out, regions, nregions, c);
+    free(regions);
 }
 
 /* fixed-base table for key generation: tbl[w][d] = d * 2^(8w) * G, d in 1..255 (affine).  bellman

@@ -297,6 +297,57 @@ static void serial_fft(fe *a, const fe *omega, uint32_t log_n) {
     }
 }
 
+/* Worker threads of the prover (bellman's `Worker`).  1 = the serial path, which is also what fawkes-crypto configures
+ * (single-core worker); > 1 = bellman's multicore split, restated below: the FFT is cut into
+ * 2^log_cpus sub-FFTs (domain.rs: parallel_fft), the pointwise passes into chunks, and every multiexp region is one task
+ * (multiexp.rs: multiexp_inner spawns a task per region).  All of it is exact field / group arithmetic: the proof bytes do
+ * not depend on the thread count (tests/test_oracle.py). */
+static int ORC_THREADS = 1;
+void orc_set_threads(int t) {
+#ifdef _OPENMP
+    ORC_THREADS = t < 1 ? 1 : t;
+#else
+    (void)t; ORC_THREADS = 1;
+#endif
+}
+static uint32_t log2_floor_u32(uint32_t v) { uint32_t l = 0; while ((2u << l) <= v) l++; return l; }
+
+/* bellman_ce domain.rs: parallel_fft.  2^log_cpus sub-FFTs of size n / 2^log_cpus: sub-FFT j collects
+ * tmp[i] = sum_s a[(i + s * new_n) mod n] * omega^(j * (i + s * new_n)), transforms with omega^num_cpus, and the results
+ * are interleaved back: a[idx] = tmp[idx mod num_cpus][idx / num_cpus]. */
+static void parallel_fft(fe *a, const fe *omega, uint32_t log_n, uint32_t log_cpus) {
+    const uint32_t num_cpus = 1u << log_cpus, log_new_n = log_n - log_cpus;
+    const uint64_t new_n = (uint64_t)1 << log_new_n, n = (uint64_t)1 << log_n;
+    fe *tmp = (fe *)calloc(n, sizeof(fe));
+    fe new_omega; fr_pow_u64(&new_omega, omega, num_cpus);
+    #pragma omp parallel for schedule(dynamic, 1) num_threads(ORC_THREADS)
+    for (uint32_t j = 0; j < num_cpus; j++) {
+        fe *t = tmp + (uint64_t)j * new_n;
+        fe omega_j, omega_step, elt = FR.r;
+        fr_pow_u64(&omega_j, omega, j);
+        fr_pow_u64(&omega_step, omega, (uint64_t)j << log_new_n);
+        for (uint64_t i = 0; i < new_n; i++) {
+            for (uint32_t s_ = 0; s_ < num_cpus; s_++) {
+                const uint64_t idx = (i + ((uint64_t)s_ << log_new_n)) & (n - 1);
+                fe x; fe_mul(&FR, &x, &a[idx], &elt);
+                fe_add(&FR, &t[i], &t[i], &x);
+                fe_mul(&FR, &elt, &elt, &omega_step);
+            }
+            fe_mul(&FR, &elt, &elt, &omega_j);
+        }
+        serial_fft(t, &new_omega, log_new_n);
+    }
+    #pragma omp parallel for schedule(static) num_threads(ORC_THREADS)
+    for (uint64_t idx = 0; idx < n; idx++) a[idx] = tmp[(idx & (num_cpus - 1)) * new_n + (idx >> log_cpus)];
+    free(tmp);
+}
+/* domain.rs: best_fft -- serial when the transform is no larger than the core count */
+static void best_fft(fe *a, const fe *omega, uint32_t log_n) {
+    const uint32_t log_cpus = log2_floor_u32((uint32_t)ORC_THREADS);
+    if (ORC_THREADS <= 1 || log_n <= log_cpus) serial_fft(a, omega, log_n);
+    else parallel_fft(a, omega, log_n, log_cpus);
+}
+
 typedef struct { uint32_t exp; uint64_t m; fe omega, omegainv, geninv, minv; } domain_t;
 
 /* EvaluationDomain::from_coeffs: m = 2^exp >= n; error once exp >= S (PolynomialDegreeTooLarge) */
@@ -311,19 +362,28 @@ static int domain_init(domain_t *d, uint64_t n) {
     fe mm; fe_from_u64(&FR, &mm, m); fe_inv(&FR, &d->minv, &mm);
     return 0;
 }
-static void dom_fft(const domain_t *d, fe *a) { serial_fft(a, &d->omega, d->exp); }
+static void dom_fft(const domain_t *d, fe *a) { best_fft(a, &d->omega, d->exp); }
 static void dom_ifft(const domain_t *d, fe *a) {
-    serial_fft(a, &d->omegainv, d->exp);
+    best_fft(a, &d->omegainv, d->exp);
+    #pragma omp parallel for schedule(static) num_threads(ORC_THREADS)
     for (uint64_t i = 0; i < d->m; i++) fe_mul(&FR, &a[i], &a[i], &d->minv);
 }
+/* domain.rs: distribute_powers -- every worker chunk starts from g^(first index of the chunk) */
 static void dom_distribute_powers(const domain_t *d, fe *a, const fe *g) {
-    fe u = FR.r;
-    for (uint64_t i = 0; i < d->m; i++) { fe_mul(&FR, &a[i], &a[i], &u); fe_mul(&FR, &u, &u, g); }
+    const uint64_t nch = ORC_THREADS > 1 ? (uint64_t)ORC_THREADS : 1, chunk = (d->m + nch - 1) / nch;
+    #pragma omp parallel for schedule(static) num_threads(ORC_THREADS)
+    for (uint64_t ch = 0; ch < nch; ch++) {
+        const uint64_t lo = ch * chunk, hi = lo + chunk < d->m ? lo + chunk : d->m;
+        if (lo >= hi) continue;
+        fe u; fr_pow_u64(&u, g, lo);
+        for (uint64_t i = lo; i < hi; i++) { fe_mul(&FR, &a[i], &a[i], &u); fe_mul(&FR, &u, &u, g); }
+    }
 }
 static void dom_coset_fft(const domain_t *d, fe *a) { dom_distribute_powers(d, a, &FR_GEN); dom_fft(d, a); }
 static void dom_icoset_fft(const domain_t *d, fe *a) { dom_ifft(d, a); dom_distribute_powers(d, a, &d->geninv); }
 static void dom_divide_by_z_on_coset(const domain_t *d, fe *a) {
     fe i; fr_pow_u64(&i, &FR_GEN, d->m); fe_sub(&FR, &i, &i, &FR.r); fe_inv(&FR, &i, &i);
+    #pragma omp parallel for schedule(static) num_threads(ORC_THREADS)
     for (uint64_t k = 0; k < d->m; k++) fe_mul(&FR, &a[k], &a[k], &i);
 }
 
@@ -348,6 +408,7 @@ uint64_t orc_quotient_h(const uint64_t *a, const uint64_t *b, const uint64_t *c,
     dom_ifft(&d, A); dom_coset_fft(&d, A);
     dom_ifft(&d, B); dom_coset_fft(&d, B);
     dom_ifft(&d, C); dom_coset_fft(&d, C);
+    #pragma omp parallel for schedule(static) num_threads(ORC_THREADS)
     for (uint64_t i = 0; i < d.m; i++) { fe_mul(&FR, &A[i], &A[i], &B[i]); fe_sub(&FR, &A[i], &A[i], &C[i]); }
     dom_divide_by_z_on_coset(&d, A);
     dom_icoset_fft(&d, A);
@@ -359,6 +420,7 @@ uint64_t orc_quotient_h(const uint64_t *a, const uint64_t *b, const uint64_t *c,
 /* ------------------------------------------------------------------ MSM entry points */
 static uint64_t *scalars_to_canon(const uint64_t *mont, size_t n) {
     uint64_t *c = (uint64_t *)malloc(n * 32 + 32);
+    #pragma omp parallel for schedule(static) num_threads(ORC_THREADS)
     for (size_t i = 0; i < n; i++) fe_to_canon(&FR, c + 4 * i, (const fe *)(mont + 4 * i));
     return c;
 }
@@ -569,22 +631,45 @@ int orc_prove(const orc_key *K, const uint64_t *a, const uint64_t *b, const uint
     uint64_t *zc = scalars_to_canon(z, (size_t)v_in + v_aux);
     const uint64_t *zin = zc, *zaux = zc + 4 * (size_t)v_in;
 
-    g1_aff *tmp = (g1_aff *)malloc((K->m + v_in + v_aux + 8) * sizeof(g1_aff));
+    /* the eight multiexps of bellman's prover (H; L; A over inputs / aux; B1 and B2 over inputs / aux).  Each is a list of
+     * independent regions; bellman queues them all on its worker pool at once (create_proof starts every multiexp before it
+     * waits for any), so they run here as ONE task list -- serially in order with one thread. */
+    g1_aff *bh = (g1_aff *)malloc((K->n_h + 1) * sizeof(g1_aff)), *bl = (g1_aff *)malloc((K->n_l + 1) * sizeof(g1_aff));
+    g1_aff *ba = (g1_aff *)malloc((K->n_a + 1) * sizeof(g1_aff)), *bb1 = (g1_aff *)malloc((K->n_b + 1) * sizeof(g1_aff));
+    g2_aff *bb2 = (g2_aff *)malloc((K->n_b + 1) * sizeof(g2_aff));
+    #pragma omp parallel num_threads(ORC_THREADS)
+    {
+        #pragma omp for schedule(static) nowait
+        for (uint64_t i = 0; i < K->n_h; i++) g1_load(&bh[i], K->h + 64 * i);
+        #pragma omp for schedule(static) nowait
+        for (uint64_t i = 0; i < K->n_l; i++) g1_load(&bl[i], K->l + 64 * i);
+        #pragma omp for schedule(static) nowait
+        for (uint64_t i = 0; i < K->n_a; i++) g1_load(&ba[i], K->a + 64 * i);
+        #pragma omp for schedule(static) nowait
+        for (uint64_t i = 0; i < K->n_b; i++) g1_load(&bb1[i], K->b_g1 + 64 * i);
+        #pragma omp for schedule(static)
+        for (uint64_t i = 0; i < K->n_b; i++) g2_load(&bb2[i], K->b_g2 + 128 * i);
+    }
+    struct mexp { int g2; const void *bases; const uint8_t *dens; const uint64_t *exps; size_t n; unsigned c, nreg, first; } me[8] = {
+        {0, bh, NULL, hc, d.m - 1, 0, 0, 0}, {0, bl, NULL, zaux, v_aux, 0, 0, 0},
+        {0, ba, NULL, zin, v_in, 0, 0, 0}, {0, ba + v_in, a_aux, zaux, v_aux, 0, 0, 0},
+        {0, bb1, b_input, zin, v_in, 0, 0, 0}, {0, bb1 + n_b_in, b_aux, zaux, v_aux, 0, 0, 0},
+        {1, bb2, b_input, zin, v_in, 0, 0, 0}, {1, bb2 + n_b_in, b_aux, zaux, v_aux, 0, 0, 0}};
+    unsigned ntask = 0;
+    for (int k = 0; k < 8; k++) { me[k].c = g1_multiexp_window(me[k].n); me[k].nreg = g1_multiexp_regions(me[k].c); me[k].first = ntask; ntask += me[k].nreg; }
+    g1_jac *reg1 = (g1_jac *)malloc(ntask * sizeof(g1_jac)); g2_jac *reg2 = (g2_jac *)malloc(ntask * sizeof(g2_jac));
+    #pragma omp parallel for schedule(dynamic, 1) num_threads(ORC_THREADS)
+    for (unsigned t = 0; t < ntask; t++) {
+        int k = 7; while (me[k].first > t) k--;
+        const unsigned reg = t - me[k].first;
+        if (me[k].g2) g2_multiexp_region(&reg2[t], (const g2_aff *)me[k].bases, me[k].dens, me[k].exps, me[k].n, me[k].c, reg);
+        else g1_multiexp_region(&reg1[t], (const g1_aff *)me[k].bases, me[k].dens, me[k].exps, me[k].n, me[k].c, reg);
+    }
     g1_jac H, L, Ain, Aaux, B1in, B1aux; g2_jac B2in, B2aux;
-    for (uint64_t i = 0; i < K->n_h; i++) g1_load(&tmp[i], K->h + 64 * i);
-    g1_multiexp(&H, tmp, NULL, hc, d.m - 1);
-    for (uint64_t i = 0; i < K->n_l; i++) g1_load(&tmp[i], K->l + 64 * i);
-    g1_multiexp(&L, tmp, NULL, zaux, v_aux);
-    for (uint64_t i = 0; i < K->n_a; i++) g1_load(&tmp[i], K->a + 64 * i);
-    g1_multiexp(&Ain, tmp, NULL, zin, v_in);
-    g1_multiexp(&Aaux, tmp + v_in, a_aux, zaux, v_aux);
-    for (uint64_t i = 0; i < K->n_b; i++) g1_load(&tmp[i], K->b_g1 + 64 * i);
-    g1_multiexp(&B1in, tmp, b_input, zin, v_in);
-    g1_multiexp(&B1aux, tmp + n_b_in, b_aux, zaux, v_aux);
-    g2_aff *tmp2 = (g2_aff *)malloc((K->n_b + 8) * sizeof(g2_aff));
-    for (uint64_t i = 0; i < K->n_b; i++) g2_load(&tmp2[i], K->b_g2 + 128 * i);
-    g2_multiexp(&B2in, tmp2, b_input, zin, v_in);
-    g2_multiexp(&B2aux, tmp2 + n_b_in, b_aux, zaux, v_aux);
+    g1_jac *o1[6] = {&H, &L, &Ain, &Aaux, &B1in, &B1aux}; g2_jac *o2[2] = {&B2in, &B2aux};
+    for (int k = 0; k < 6; k++) g1_multiexp_join(o1[k], reg1 + me[k].first, me[k].nreg, me[k].c);
+    for (int k = 6; k < 8; k++) g2_multiexp_join(o2[k - 6], reg2 + me[k].first, me[k].nreg, me[k].c);
+    free(reg1); free(reg2);
 
     g1_aff alpha1, beta1, delta1; g2_aff beta2, delta2;
     g1_load(&alpha1, K->alpha_g1); g1_load(&beta1, K->beta_g1); g1_load(&delta1, K->delta_g1);
@@ -629,7 +714,7 @@ int orc_prove(const orc_key *K, const uint64_t *a, const uint64_t *b, const uint
             g2_jac_to_aff(&t2, &b2_ans); g2_store(msm_out + 256, &t2);
         }
     }
-    free(h); free(hc); free(zc); free(tmp); free(tmp2);
+    free(h); free(hc); free(zc); free(bh); free(bl); free(ba); free(bb1); free(bb2);
     return rc;
 }
 

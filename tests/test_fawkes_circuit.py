@@ -247,3 +247,22 @@ def test_rollup_tx_golden_matches_oracle(oracle):
     assert int(aa.sum()) == g['a_aux_density'] and int(ba.sum()) == g['b_aux_density']
     proof = oracle.prove(key, a, b, c, z, aa, bi, ba, fx.mont_fr(int(g['r'], 16)), fx.mont_fr(int(g['s'], 16)))
     assert proof.tobytes().hex() == g['proof']
+
+
+def test_rollup_tx_fixture_matches_golden(oracle):
+    """tests/golden/rollup_tx_instance.npz (what `bench.py --workload rollup1024` tiles 1024 times, loaded WITHOUT the
+    circuit builder) is the golden transaction's constraint system, and all three of its witnesses satisfy it."""
+    import bench
+    from fawkes_crypto_amd import params_io
+    g, cs = _golden_rollup_tx()
+    r1cs, zs = bench.load_rollup_instance()
+    assert hashlib.sha256(params_io.encode_gate_stream(r1cs)).hexdigest() == g['gate_stream_sha256']
+    assert (r1cs.num_input, r1cs.num_aux, r1cs.num_gates) == (g['num_input'], g['num_aux'], g['num_gates'])
+    assert np.array_equal(zs[0], fx.witness_mont(cs.z_in, cs.z_aux))
+    csr = oracle.R1csC(r1cs.num_input, r1cs.num_aux, *[oracle.Csr(p, c, v) for p, c, v in r1cs.mats])
+    roots = set()
+    for z in zs:
+        a, b, c, *_ = oracle.synthesize(csr, z)
+        assert np.array_equal(oracle.fe_mul_batch(1, a, b), c)
+        roots.add(z[1:3].tobytes())
+    assert len(roots) == 3          # three different transactions

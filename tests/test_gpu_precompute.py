@@ -96,7 +96,7 @@ def test_merged_sharded_setup_and_weighted_shards(ctx, oracle, low_threshold):
     for fracs in (None, [(0.0, 0.3), (0.3, 0.55), (0.55, 1.0)]):
         parts = []
         for i in range(3):
-            sk, _ = ctx.setup(r1cs, shard_index=i, shard_count=3, z_frac=fracs[i] if fracs else (0.0, 0.0), **tox)
+            sk, _ = ctx.setup(r1cs, shard_index=i, shard_count=3, z_frac=fracs[i] if fracs else (-1.0, -1.0), **tox)
             assert sk.precomputed()['h'] > 1
             parts.append(ctx.prove_msms(sk, a, b, c, z, aa, bi, ba))
             sk.free()

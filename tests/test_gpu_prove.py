@@ -135,6 +135,65 @@ def test_balanced_schedule_pieces(ctx, oracle):
             ctx.dev_free(p_)
 
 
+@pytest.mark.parametrize('loader', ['key_load', 'setup'])
+def test_balanced_schedule_rank0_holds_no_witness_points(ctx, oracle, loader):
+    """World 4 with rank 0's witness share clamped to nothing -- what plan_z_fractions gives the bench workload from 4
+    ranks on.  (0, 0) must be the EMPTY slice (it used to alias "equal split": rank 0 then re-counted the first quarter
+    of L, A, B1, B2 and the proof was invalid).  Through fk_key_load and through fk_setup."""
+    from fawkes_crypto_amd import api
+    cs, csr, key, z_in, z_aux = _instance(oracle, 29, 600, 2, 650)
+    r1cs = r1cs_product(csr)
+    params = params_from_oracle_key(key, r1cs)
+    z = fx.witness_mont(z_in, z_aux)
+    r, s = fx.mont_fr(4321), fx.mont_fr(8765)
+    a, b, c, aa, bi, ba = ctx.synthesize(params.r1cs, z)
+    dk = ctx.load_key(params)
+    want = ctx.prove_raw(dk, a, b, c, z, aa, bi, ba, r, s)
+    assert want.tobytes() == oracle.prove(key, a, b, c, z, aa, bi, ba, r, s).tobytes()
+    world = 4
+    fracs = [(0.0, 0.0), (0.0, 1 / 3), (1 / 3, 2 / 3), (2 / 3, 1.0)]
+    tox = {k: fx.mont_fr(v) for k, v in TOXIC.items()}
+    m = params.m
+    d = {k: ctx.dev_alloc(m * 32) for k in 'abch'}
+    d_z = ctx.dev_alloc(z.nbytes)
+    d_aa, d_bi, d_ba = ctx.dev_alloc(max(len(aa), 1)), ctx.dev_alloc(len(bi)), ctx.dev_alloc(max(len(ba), 1))
+    try:
+        for k, v in (('a', a), ('b', b), ('c', c)):
+            ctx.upload(d[k], v)
+        ctx.upload(d_z, z); ctx.upload(d_aa, aa); ctx.upload(d_bi, bi); ctx.upload(d_ba, ba)
+        ctx.quotient_h_dev(d['a'], d['b'], d['c'], a.shape[0], d['h'])
+        parts, covered = [], {'l': 0, 'a': 0, 'b': 0}
+        for g in range(world):
+            if loader == 'key_load':
+                sk = ctx.load_key(params, shard_index=g, shard_count=world, z_frac=fracs[g])
+            else:
+                sk, _ = ctx.setup(r1cs, shard_index=g, shard_count=world, z_frac=fracs[g], **tox)
+            info = sk.shard_info()
+            assert info['h'] == api.h_shard_range(m - 1, g, world)
+            for nm in 'lab':
+                assert info[nm][0] == covered[nm], (g, nm, info)        # slices tile the arrays without overlap
+                covered[nm] = info[nm][1]
+            if g == 0:
+                assert info['l'] == (0, 0) and info['a'] == (0, 0) and info['b'] == (0, 0)
+            part = ctx.prove_msms_z_dev(sk, d_z, d_aa, d_bi, d_ba)
+            part[:64] = ctx.prove_msm_h_dev(sk, d['h'] + info['h'][0] * 32)
+            parts.append(part)
+            sk.free()
+        assert covered == {'l': params.num_aux, 'a': params.a.shape[0], 'b': params.b_g1.shape[0]}
+        got = ctx.prove_assemble(dk, np.stack(parts), r, s)
+        assert got.tobytes() == want.tobytes()
+    finally:
+        for p_ in list(d.values()) + [d_z, d_aa, d_bi, d_ba]:
+            ctx.dev_free(p_)
+    # a lone shard must hold everything: a zero-initialised fraction range is refused, not proved from
+    import fawkes_crypto_amd as fk
+    for bad in ((0.0, 0.0), (0.0, 0.5), (0.5, 0.25), (0.0, 1.5)):
+        with pytest.raises(fk.FkError) as e:
+            ctx.load_key(params, z_frac=bad)
+        assert e.value.code == 1
+    ctx.load_key(params, z_frac=(0.0, 1.0)).free()
+
+
 def test_error_behaviour(ctx, oracle):
     """C ABI returns codes where bellman returns SynthesisError."""
     import fawkes_crypto_amd as fk

@@ -159,3 +159,15 @@ def test_config1_shape_prove_verify(oracle):
     a, b, c, aa, bi, ba = oracle.synthesize(csr, z)
     proof = oracle.prove(key, a, b, c, z, aa, bi, ba, fx.mont_fr(0x1111), fx.mont_fr(0x2222))
     assert ref.verify(fx.key_to_py(key), z_in[1:], ref.proof_from_borsh(proof.tobytes()))
+
+
+def test_threaded_prover_same_bytes(oracle):
+    """bellman's multicore split restated (parallel_fft, one task per multiexp region; the all-cores CPU baseline of
+    bench.py) gives the serial prover's bytes for every thread count, including ones that are not a power of two."""
+    cs, z, _, _ = fx.fast_r1cs(5, 3000, 3, 3100)
+    key = oracle.setup(cs, **TOXIC)
+    a, b, c, aa, bi, ba = oracle.synthesize(cs, z)
+    r, s = fx.mont_fr(5), fx.mont_fr(6)
+    want = oracle.prove(key, a, b, c, z, aa, bi, ba, r, s)
+    for t in (2, 3, 8, 64):
+        assert oracle.prove(key, a, b, c, z, aa, bi, ba, r, s, threads=t).tobytes() == want.tobytes(), t

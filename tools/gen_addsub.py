@@ -2,7 +2,7 @@
 """Generates fawkes-crypto_amd/csrc/addsub_gfx950.inc: modular addition / subtraction of 8 x u32 limb field
 elements as real carry chains.
 
-hipcc does not emit carry chains for the C loop in field.cuh (a VALU instruction that reads a carry written by the
+hipcc does not emit carry chains for the C loop in field.hpp (a VALU instruction that reads a carry written by the
 previous VALU instruction needs 2 wait states on gfx90a+/gfx950, so it falls back to 64-bit adds and moves: 91 VALU
 instructions per addition, 84 per subtraction -- a quarter of a Montgomery product).  Here every operation is two
 chains: the primary one (a + b, or a - b) and a secondary one running one step behind it on the primary's output

@@ -7,7 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <vector>
-#include "field.cuh"
+#include "field.hpp"
 using namespace fk;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 

@@ -4,7 +4,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
-#include "field.cuh"
+#include "field.hpp"
 using namespace fk;
 
 // ---- V1: product scanning, 96-bit accumulator, carry-out of v_mad_u64_u32 consumed by v_addc
