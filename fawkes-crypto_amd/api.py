@@ -37,12 +37,13 @@ EXPORTED_SYMBOLS = [
     'fk_synthesize', 'fk_stats_reset', 'fk_stats_get', 'fk_calibrate', 'fk_shard_range', 'fk_h_shard_range',
     'fk_dq_gather_dev', 'fk_dq_local_dev', 'fk_dq_cross_dev',
     'fk_setup', 'fk_setup_tiled', 'fk_r1cs_load_tiled', 'fk_key_download', 'fk_key_load_bellman', 'fk_key_vk', 'fk_key_counts', 'fk_key_precomputed',
+    'fk_gates_decode', 'fk_gates_free', 'fk_gates_info', 'fk_gates_export', 'fk_r1cs_load_gates',
     'fk_r1cs_load', 'fk_r1cs_free', 'fk_r1cs_info', 'fk_r1cs_density_ptrs', 'fk_r1cs_eval_dev', 'fk_prove_r1cs', 'fk_prove_r1cs_dev',
 ]
 
 _ERR = {1: 'FK_ERR_BAD_ARG', 2: 'FK_ERR_DOMAIN_TOO_LARGE (bellman: PolynomialDegreeTooLarge)',
         3: 'FK_ERR_UNEXPECTED_IDENTITY (bellman: UnexpectedIdentity)', 4: 'FK_ERR_HIP', 5: 'FK_ERR_OOM',
-        6: 'FK_ERR_KEY_MISMATCH'}
+        6: 'FK_ERR_KEY_MISMATCH', 7: 'FK_ERR_FORMAT (InvalidData / GroupDecodingError)', 8: 'FK_ERR_UNSUPPORTED'}
 
 
 class FkError(RuntimeError):
@@ -103,6 +104,8 @@ def load_library():
         lib.fk_free.restype = None
         lib.fk_key_free.argtypes = [C.c_void_p, C.c_void_p]
         lib.fk_key_free.restype = None
+        lib.fk_gates_free.argtypes = [C.c_void_p]
+        lib.fk_gates_free.restype = None
         _LIB = lib
     return _LIB
 
@@ -342,6 +345,65 @@ class DeviceR1cs:
     def free(self):
         if self.handle:
             self.ctx.lib.fk_r1cs_free(self.ctx.handle, self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+FK_GATES_RAW, FK_GATES_BROTLI = 0, 1
+FK_KEY_CHECKED, FK_KEY_NO_INFINITY = 1, 2
+
+
+class Gates:
+    """fk_gates: the constraint system decoded from the gate blob of a `Parameters` file (host memory, native decoder).
+    fmt: FK_GATES_BROTLI (what the reference writes, setup.rs:25-32) or FK_GATES_RAW (the bare Borsh gate stream)."""
+
+    def __init__(self, blob, fmt, num_gates, num_input, num_aux, ctx=None):
+        self.lib = load_library()
+        buf = np.frombuffer(bytes(blob), np.uint8)
+        h = C.c_void_p()
+        rc = self.lib.fk_gates_decode(ctx.handle if ctx else None, _vp(buf), C.c_size_t(buf.size), C.c_int(fmt), C.c_uint32(num_gates),
+                                      C.c_uint32(num_input), C.c_uint32(num_aux), C.byref(h))
+        if rc != 0:
+            msg = self.lib.fk_last_error(ctx.handle) if ctx else b''
+            raise FkError(rc, msg.decode() if msg else 'fk_gates_decode')
+        self.handle = h
+
+    def info(self):
+        out = (C.c_uint64 * 8)()
+        rc = self.lib.fk_gates_info(self.handle, out)
+        if rc != 0:
+            raise FkError(rc, 'fk_gates_info')
+        v = list(out)
+        return dict(num_gates=v[0], nnz=(v[1], v[2], v[3]), distinct_coefficients=v[4], decoded_bytes=v[5], num_input=v[6], num_aux=v[7])
+
+    def to_r1cs(self):
+        """the decoded system as an api.R1cs (explicit 32-byte coefficients: for tests and for fk_setup)"""
+        i = self.info()
+        mats = []
+        for k in range(3):
+            ptr = np.zeros(i['num_gates'] + 1, np.uint64)
+            col = np.zeros(max(i['nnz'][k], 1), np.uint32)[:i['nnz'][k]]
+            val = np.zeros((max(i['nnz'][k], 1), 4), np.uint64)[:i['nnz'][k]]
+            rc = self.lib.fk_gates_export(self.handle, C.c_int(k), _vp(ptr), C.c_void_p(col.ctypes.data), C.c_void_p(val.ctypes.data))
+            if rc != 0:
+                raise FkError(rc, 'fk_gates_export')
+            mats.append((ptr, col, val))
+        return R1cs(i['num_input'], i['num_aux'], *mats)
+
+    def load(self, ctx):
+        """fk_r1cs_load_gates: resident constraint system straight from the decoded stream"""
+        h = C.c_void_p()
+        ctx._ck(ctx.lib.fk_r1cs_load_gates(ctx.handle, self.handle, C.byref(h)))
+        return DeviceR1cs(ctx, h)
+
+    def free(self):
+        if getattr(self, 'handle', None):
+            self.lib.fk_gates_free(self.handle)
             self.handle = None
 
     def __del__(self):
@@ -640,15 +702,16 @@ class Context:
                                        C.c_void_p(d_b_aux), _vp(r), _vp(s), _vp(out), C.byref(tm)))
         return (out, tm.as_dict()) if want_timings else out
 
-    def load_key_bellman(self, data, shard_index=0, shard_count=1, z_frac=Z_EQUAL_SPLIT):
-        """fk_key_load_bellman: `data` = bytes of bellman's Parameters::write.  Returns (DeviceKey, gamma_g2, ic)."""
+    def load_key_bellman(self, data, shard_index=0, shard_count=1, z_frac=Z_EQUAL_SPLIT, flags=FK_KEY_CHECKED):
+        """fk_key_load_bellman: `data` = bytes of bellman's Parameters::write; flags = FK_KEY_CHECKED | FK_KEY_NO_INFINITY (the
+        `checked` / `disallow_points_at_infinity` arguments of Parameters::read, mod.rs:159).  Returns (DeviceKey, gamma_g2, ic)."""
         buf = np.frombuffer(bytes(data), np.uint8)
         h = C.c_void_p()
         gamma = np.zeros(128, np.uint8)
         n_ic = C.c_uint32()
         cap = 1 << 16
         ic = np.zeros((cap, 64), np.uint8)
-        self._ck(self.lib.fk_key_load_bellman(self.handle, _vp(buf), C.c_size_t(buf.size), C.c_uint32(shard_index), C.c_uint32(shard_count),
+        self._ck(self.lib.fk_key_load_bellman(self.handle, _vp(buf), C.c_size_t(buf.size), C.c_uint32(flags), C.c_uint32(shard_index), C.c_uint32(shard_count),
                                               C.c_double(z_frac[0]), C.c_double(z_frac[1]), C.byref(h), _vp(gamma), _vp(ic), C.c_uint32(cap),
                                               C.byref(n_ic)))
         return DeviceKey(self, h, shard_index, shard_count), gamma, ic[:min(n_ic.value, cap)].copy()

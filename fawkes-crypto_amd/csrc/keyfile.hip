@@ -16,35 +16,81 @@
 
 namespace fk {
 
-static __device__ __forceinline__ Fq be32_to_mont(const uint8_t *p) {
-    Fq v;
+// error counters of one load (device): what pairing_ce's GroupDecodingError distinguishes
+struct KeyErr { uint32_t flag, range, inf_rest, curve, subgroup, infinity; };
+
+// 32 big-endian bytes -> canonical limbs; false when the integer is not below q (CoordinateDecodingError: "not in field")
+static __device__ __forceinline__ bool be32_to_mont(const uint8_t *p, FqC *out) {
+    FqC v;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         const uint8_t *q = p + 28 - 4 * i;
         v.v[i] = ((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | (uint32_t)q[3];
     }
-    return Fq::to_mont(v);
+    bool below = false;
+    for (int i = 7; i >= 0; i--) {
+        if (v.v[i] < FqParams::p(i)) { below = true; break; }
+        if (v.v[i] > FqParams::p(i)) break;
+    }
+    *out = FqC::to_mont(v);
+    return below;
 }
+static __device__ __forceinline__ bool rest_is_zero(const uint8_t *p, int n) {      // infinity encoding: 0x40, then zeros
+    uint32_t o = p[0] & 0x3f;
+    for (int i = 1; i < n; i++) o |= p[i];
+    return o == 0;
+}
+static __device__ __forceinline__ FqC fq_const(const uint32_t (&w)[8]) { FqC t; for (int i = 0; i < 8; i++) t.v[i] = w[i]; return t; }
 
-// in: n points of 64 bytes (BE x || y); out: Affine<Fq> raw Montgomery LE, infinity -> zeros
-__global__ void convert_g1_kernel(const uint8_t *in, size_t n, G1Affine *out, uint32_t *bad) {
+// in: n points of 64 bytes (BE x || y); out: raw Montgomery LE, infinity -> zeros.  Always: flag bits, coordinates < q, a clean
+// infinity encoding (what pairing_ce's `into_affine_unchecked` enforces).  FK_KEY_CHECKED: y^2 = x^3 + 3 (the cofactor of G1 is
+// 1, so on the curve is in the group).  FK_KEY_NO_INFINITY: no identity points.
+__global__ void convert_g1_kernel(const uint8_t *in, size_t n, Affine<FqC> *out, uint32_t flags, KeyErr *err) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint8_t *p = in + 64 * i;
-    if (p[0] & 0x40) { out[i] = G1Affine::inf(); return; }
-    if (p[0] & 0x80) atomicAdd(bad, 1u);          // compression flag in an uncompressed encoding
-    out[i] = G1Affine{be32_to_mont(p), be32_to_mont(p + 32)};
+    if (p[0] & 0x40) {
+        if (!rest_is_zero(p, 64)) atomicAdd(&err->inf_rest, 1u);
+        if (flags & FK_KEY_NO_INFINITY) atomicAdd(&err->infinity, 1u);
+        out[i] = Affine<FqC>::inf();
+        return;
+    }
+    if (p[0] & 0x80) atomicAdd(&err->flag, 1u);          // compression flag in an uncompressed encoding
+    Affine<FqC> a;
+    const bool okx = be32_to_mont(p, &a.x), oky = be32_to_mont(p + 32, &a.y), ok = okx && oky;
+    if (!ok) atomicAdd(&err->range, 1u);
+    if (ok && (flags & FK_KEY_CHECKED)) {
+        const uint32_t bw[8] = FK_G1_B;
+        const FqC rhs = FqC::add(FqC::mul(FqC::sqr(a.x), a.x), fq_const(bw));
+        if (FqC::sqr(a.y) != rhs) atomicAdd(&err->curve, 1u);
+    }
+    out[i] = a;
 }
-__global__ void convert_g2_kernel(const uint8_t *in, size_t n, G2Affine *out, uint32_t *bad) {
+// G2: x.c1 || x.c0 || y.c1 || y.c0; curve y^2 = x^3 + 3/(9+u) over Fq2 and -- checked -- membership of the order-r subgroup
+// (the twist has a large cofactor): r * P = identity, one double-and-add per point.
+__global__ __launch_bounds__(128) void convert_g2_kernel(const uint8_t *in, size_t n, Affine<Fq2C> *out, uint32_t flags, KeyErr *err) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint8_t *p = in + 128 * i;
-    if (p[0] & 0x40) { out[i] = G2Affine::inf(); return; }
-    if (p[0] & 0x80) atomicAdd(bad, 1u);
-    G2Affine a;
-    a.x.c1 = be32_to_mont(p); a.x.c0 = be32_to_mont(p + 32);
-    a.y.c1 = be32_to_mont(p + 64); a.y.c0 = be32_to_mont(p + 96);
+    if (p[0] & 0x40) {
+        if (!rest_is_zero(p, 128)) atomicAdd(&err->inf_rest, 1u);
+        if (flags & FK_KEY_NO_INFINITY) atomicAdd(&err->infinity, 1u);
+        out[i] = Affine<Fq2C>::inf();
+        return;
+    }
+    if (p[0] & 0x80) atomicAdd(&err->flag, 1u);
+    Affine<Fq2C> a;
+    const bool ok0 = be32_to_mont(p, &a.x.c1), ok1 = be32_to_mont(p + 32, &a.x.c0), ok2 = be32_to_mont(p + 64, &a.y.c1), ok3 = be32_to_mont(p + 96, &a.y.c0);
+    const bool ok = ok0 && ok1 && ok2 && ok3;
+    if (!ok) atomicAdd(&err->range, 1u);
     out[i] = a;
+    if (ok && (flags & FK_KEY_CHECKED)) {
+        const uint32_t b0[8] = FK_G2_B0, b1[8] = FK_G2_B1;
+        const Fq2C rhs = Fq2C::add(Fq2C::mul(Fq2C::sqr(a.x), a.x), Fq2C{fq_const(b0), fq_const(b1)});
+        if (Fq2C::sqr(a.y) != rhs) { atomicAdd(&err->curve, 1u); return; }
+        const uint32_t r[8] = FK_R_CANON;
+        if (!Xyzz<Fq2C>::mul_scalar(Xyzz<Fq2C>::from_affine(a), r).is_inf()) atomicAdd(&err->subgroup, 1u);
+    }
 }
 
 struct Cursor {
@@ -61,21 +107,22 @@ extern "C" {
 
 // buf/len: bellman `Parameters::write` bytes.  ic_out (may be NULL): receives up to ic_cap raw 64-byte points;
 // *n_ic gets the count; gamma_g2_out (may be NULL): 128 bytes raw.  shard arguments as in fk_key_desc.
-int fk_key_load_bellman(fk_ctx *ctx, const uint8_t *buf, size_t len, uint32_t shard_index, uint32_t shard_count, double z_frac_lo,
+int fk_key_load_bellman(fk_ctx *ctx, const uint8_t *buf, size_t len, uint32_t flags, uint32_t shard_index, uint32_t shard_count, double z_frac_lo,
                         double z_frac_hi, fk_key **out, uint8_t *gamma_g2_out, uint8_t *ic_out, uint32_t ic_cap, uint32_t *n_ic) {
     if (!ctx) return FK_ERR_BAD_ARG;
     if (!buf || !out) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "key file: null argument");
+    if (flags & ~(uint32_t)(FK_KEY_CHECKED | FK_KEY_NO_INFINITY)) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "key file: unknown flags 0x%x", flags);
     *out = nullptr;
     FK_HIP(ctx, hipSetDevice(ctx->device));
     Cursor c{buf, len};
     const uint8_t *vkp[6];
     const size_t vkw[6] = {64, 64, 128, 128, 64, 128};    // alpha_g1, beta_g1, beta_g2, gamma_g2, delta_g1, delta_g2
-    for (int i = 0; i < 6; i++) if (!c.take(vkw[i], &vkp[i])) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "key file: truncated verifying key");
+    for (int i = 0; i < 6; i++) if (!c.take(vkw[i], &vkp[i])) FK_SET_ERR(ctx, FK_ERR_FORMAT, "key file: truncated verifying key");
     uint32_t cnt[6]; const uint8_t *arr[6];
     const size_t w[6] = {64, 64, 64, 64, 64, 128};        // ic, h, l, a, b_g1, b_g2
     static const char *nm[6] = {"ic", "h", "l", "a", "b_g1", "b_g2"};
     for (int i = 0; i < 6; i++) {
-        if (!c.u32be(&cnt[i]) || !c.take((size_t)cnt[i] * w[i], &arr[i])) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "key file: truncated %s array", nm[i]);
+        if (!c.u32be(&cnt[i]) || !c.take((size_t)cnt[i] * w[i], &arr[i])) FK_SET_ERR(ctx, FK_ERR_FORMAT, "key file: truncated %s array", nm[i]);
     }
     if (cnt[0] == 0) FK_SET_ERR(ctx, FK_ERR_KEY_MISMATCH, "key file: empty ic (no constant ONE input)");
     if (cnt[4] != cnt[5]) FK_SET_ERR(ctx, FK_ERR_KEY_MISMATCH, "key file: b_g1 and b_g2 differ in length");
@@ -91,9 +138,9 @@ int fk_key_load_bellman(fk_ctx *ctx, const uint8_t *buf, size_t len, uint32_t sh
     { const int rcs = key_plan_slices(ctx, k, z_frac_lo, z_frac_hi); if (rcs != FK_OK) { delete k; return rcs; } }
     auto fail = [&](int code, const char *msg) { ctx->err = msg; fk_key_free(ctx, k); return code; };
 
-    uint32_t *d_bad = nullptr;
-    if (hipMalloc((void **)&d_bad, 4) != hipSuccess) return fail(FK_ERR_OOM, "key file: device allocation failed");
-    (void)hipMemset(d_bad, 0, 4);
+    KeyErr *d_bad = nullptr;
+    if (hipMalloc((void **)&d_bad, sizeof(KeyErr)) != hipSuccess) return fail(FK_ERR_OOM, "key file: device allocation failed");
+    (void)hipMemset(d_bad, 0, sizeof(KeyErr));
     // staged conversion: raw big-endian bytes go up in chunks, converted points are written in place
     const size_t CH = (size_t)1 << 22;   // points per chunk
     auto conv = [&](const uint8_t *src, uint64_t lo, uint64_t hi, size_t width, void **dst) -> int {
@@ -103,8 +150,8 @@ int fk_key_load_bellman(fk_ctx *ctx, const uint8_t *buf, size_t len, uint32_t sh
             const size_t cn = (size_t)((n - off) < CH ? (n - off) : CH);
             if (ctx->misc.reserve(cn * width) != hipSuccess) return FK_ERR_OOM;
             if (hipMemcpyAsync(ctx->misc.p, src + (lo + off) * width, cn * width, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return FK_ERR_HIP;
-            if (width == 64) hipLaunchKernelGGL(convert_g1_kernel, dim3((unsigned)((cn + 255) / 256)), dim3(256), 0, ctx->stream, ctx->misc.as<uint8_t>(), cn, (G1Affine *)*dst + off, d_bad);
-            else hipLaunchKernelGGL(convert_g2_kernel, dim3((unsigned)((cn + 255) / 256)), dim3(256), 0, ctx->stream, ctx->misc.as<uint8_t>(), cn, (G2Affine *)*dst + off, d_bad);
+            if (width == 64) hipLaunchKernelGGL(convert_g1_kernel, dim3((unsigned)((cn + 255) / 256)), dim3(256), 0, ctx->stream, ctx->misc.as<uint8_t>(), cn, (Affine<FqC> *)*dst + off, flags, d_bad);
+            else hipLaunchKernelGGL(convert_g2_kernel, dim3((unsigned)((cn + 127) / 128)), dim3(128), 0, ctx->stream, ctx->misc.as<uint8_t>(), cn, (Affine<Fq2C> *)*dst + off, flags, d_bad);
             if (hipStreamSynchronize(ctx->stream) != hipSuccess) return FK_ERR_HIP;   // misc is reused by the next chunk
         }
         return FK_OK;
@@ -131,8 +178,9 @@ int fk_key_load_bellman(fk_ctx *ctx, const uint8_t *buf, size_t len, uint32_t sh
             std::vector<G1Affine> o1(n1);
             if (hipMemcpy(d_in1, g1buf.data(), g1buf.size(), hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d_in2, g2buf.data(), g2buf.size(), hipMemcpyHostToDevice) != hipSuccess) rc = FK_ERR_HIP;
             else {
-                hipLaunchKernelGGL(convert_g1_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, ctx->stream, d_in1, n1, d_o1, d_bad);
-                hipLaunchKernelGGL(convert_g2_kernel, dim3(1), dim3(256), 0, ctx->stream, d_in2, (size_t)3, d_o2, d_bad);
+                // the verifying key never holds the identity (bellman's VerifyingKey::read rejects it), whatever the flags say
+                hipLaunchKernelGGL(convert_g1_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, ctx->stream, d_in1, n1, (Affine<FqC> *)d_o1, flags | FK_KEY_NO_INFINITY, d_bad);
+                hipLaunchKernelGGL(convert_g2_kernel, dim3(1), dim3(128), 0, ctx->stream, d_in2, (size_t)3, (Affine<Fq2C> *)d_o2, flags | FK_KEY_NO_INFINITY, d_bad);
                 if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipMemcpy(o1.data(), d_o1, n1 * 64, hipMemcpyDeviceToHost) != hipSuccess ||
                     hipMemcpy(vk2, d_o2, 3 * 128, hipMemcpyDeviceToHost) != hipSuccess) rc = FK_ERR_HIP;
                 else { vk1[0] = o1[0]; vk1[1] = o1[1]; vk1[2] = o1[2]; for (uint32_t i = 0; i < cnt[0]; i++) ic[i] = o1[3 + i]; }
@@ -140,11 +188,17 @@ int fk_key_load_bellman(fk_ctx *ctx, const uint8_t *buf, size_t len, uint32_t sh
             (void)hipFree(d_tmp);
         }
     }
-    uint32_t bad = 0;
-    if (rc == FK_OK && hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost) != hipSuccess) rc = FK_ERR_HIP;
+    KeyErr bad{};
+    if (rc == FK_OK && hipMemcpy(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost) != hipSuccess) rc = FK_ERR_HIP;
     (void)hipFree(d_bad);
     if (rc != FK_OK) return fail(rc, "key file: conversion failed");
-    if (bad) return fail(FK_ERR_BAD_ARG, "key file: compressed-point flag found in an uncompressed key");
+    if (bad.flag || bad.range || bad.inf_rest || bad.curve || bad.subgroup || bad.infinity) {       // GroupDecodingError
+        char msg[320];
+        snprintf(msg, sizeof msg, "key file: %u points with the compression flag set, %u coordinates not below q, %u malformed infinity encodings, "
+                 "%u points not on the curve, %u G2 points outside the order-r subgroup, %u identity points where none are allowed",
+                 bad.flag, bad.range, bad.inf_rest, bad.curve, bad.subgroup, bad.infinity);
+        return fail(FK_ERR_FORMAT, msg);
+    }
     k->alpha_g1 = vk1[0]; k->beta_g1 = vk1[1]; k->delta_g1 = vk1[2];
     k->beta_g2 = vk2[0]; k->delta_g2 = vk2[2];
     if (gamma_g2_out) memcpy(gamma_g2_out, &vk2[1], 128);

@@ -165,8 +165,10 @@ void fk_r1cs_free(fk_ctx *ctx, fk_r1cs_dev *r) {
     delete r;
 }
 
-// cs: one instance; the resident system stands for `copies` of it (1 = the system itself)
-static int r1cs_load_impl(fk_ctx *ctx, const fk_r1cs *cs, uint32_t copies, fk_r1cs_dev **out) {
+// cs: one instance; the resident system stands for `copies` of it (1 = the system itself).  pre_cidx / pre_table: the
+// coefficients already dictionary-coded (gatestream.hip: slot 0 = ONE), cs->*_val then unused.
+static int r1cs_load_impl(fk_ctx *ctx, const fk_r1cs *cs, uint32_t copies, fk_r1cs_dev **out, const uint32_t *const *pre_cidx = nullptr,
+                          const Fr *pre_table = nullptr, uint64_t n_pre_table = 0) {
     if (!ctx || !cs || !out) return FK_ERR_BAD_ARG;
     *out = nullptr;
     if (copies == 0) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "r1cs: copies must be at least 1");
@@ -197,6 +199,10 @@ static int r1cs_load_impl(fk_ctx *ctx, const fk_r1cs *cs, uint32_t copies, fk_r1
     const Fr one = Fr::one();
     table.push_back(one);
     dict.emplace(std::string((const char *)&one, 32), 0u);
+    if (pre_cidx) {
+        if (!pre_table || !n_pre_table || pre_table[0] != one) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "r1cs: coefficient table must start with ONE");
+        table.assign(pre_table, pre_table + n_pre_table);
+    }
     std::vector<uint8_t> a_aux(cs->num_aux ? cs->num_aux : 1, 0), b_in(cs->num_input, 0), b_aux(cs->num_aux ? cs->num_aux : 1, 0);
     int rc = FK_OK;
     auto fail = [&](int code) { fk_r1cs_free(ctx, r); return code; };
@@ -209,7 +215,10 @@ static int r1cs_load_impl(fk_ctx *ctx, const fk_r1cs *cs, uint32_t copies, fk_r1
         Fr last = one; uint32_t last_idx = 0;        // one-entry cache in front of the hash map
         for (uint64_t i = 0; i < nnz; i++) {
             uint32_t ci = 0;
-            if (vals[k] && memcmp(vals[k] + 4 * i, &one, 32) != 0) {
+            if (pre_cidx) {
+                ci = pre_cidx[k][i];
+                if (ci >= n_pre_table) { ctx->err = "r1cs: coefficient index out of range"; return fail(FK_ERR_BAD_ARG); }
+            } else if (vals[k] && memcmp(vals[k] + 4 * i, &one, 32) != 0) {
                 if (memcmp(vals[k] + 4 * i, &last, 32) == 0) ci = last_idx;
                 else {
                     std::string key((const char *)(vals[k] + 4 * i), 32);
@@ -301,6 +310,17 @@ static int r1cs_load_impl(fk_ctx *ctx, const fk_r1cs *cs, uint32_t copies, fk_r1
 }
 
 int fk_r1cs_load(fk_ctx *ctx, const fk_r1cs *cs, fk_r1cs_dev **out) { return r1cs_load_impl(ctx, cs, 1, out); }
+}  // extern "C"
+namespace fk {
+int r1cs_load_coded(fk_ctx *ctx, uint32_t num_input, uint32_t num_aux, uint64_t num_gates, const uint64_t *const ptr[3], const uint32_t *const col[3],
+                    const uint32_t *const cidx[3], const Fr *table, uint64_t n_table, fk_r1cs_dev **out) {
+    fk_r1cs cs{};
+    cs.num_input = num_input; cs.num_aux = num_aux; cs.num_gates = num_gates;
+    cs.a_ptr = ptr[0]; cs.a_col = col[0]; cs.b_ptr = ptr[1]; cs.b_col = col[1]; cs.c_ptr = ptr[2]; cs.c_col = col[2];
+    return r1cs_load_impl(ctx, &cs, 1, out, cidx, table, n_table);
+}
+}  // namespace fk
+extern "C" {
 int fk_r1cs_load_tiled(fk_ctx *ctx, const fk_r1cs *instance, uint32_t copies, fk_r1cs_dev **out) { return r1cs_load_impl(ctx, instance, copies, out); }
 
 int fk_r1cs_density_ptrs(const fk_r1cs_dev *r, const void *out[3]) {

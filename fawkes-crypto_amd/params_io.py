@@ -10,10 +10,11 @@ File layout (fawkes header: /root/reference/fawkes-crypto/src/backend/bellman_gr
 Gate stream inside the blob (circuit/r1cs/cs.rs:193-223): per gate three parts, each
     u32 LE count, then count x ( 32 B canonical LE Fr | u8 tag 0 = Input / 1 = Aux (lc.rs:144-149) | u32 LE index ).
 
-The brotli codec is a third-party dependency that is not in this image: pass `decompress=` / `compress=` callables
-(e.g. `brotli.decompress`) when reading / writing real files; without them the blob is kept as opaque bytes
-and only raw (uncompressed) gate streams written by this module can be decoded.  The bellman part and the bit-vector
-packing are restated from the un-vendored crates and could not be checked against a file written by the reference.
+The gate blob is decoded natively (csrc/gatestream.hip: streaming brotli through the system's libbrotlidec.so.1 -> CSR with
+dictionary-coded coefficients -> resident constraint system); `decode_gate_stream` below is the slow per-term restatement
+the tests compare it with.  Writing a reference-format blob needs a brotli ENCODER: pass `compress=` (the tests bind
+libbrotlienc.so.1); without it `store_parameters` stores the raw gate stream behind RAW_MAGIC.  The bellman part and the
+bit-vector packing are restated from the un-vendored crates and could not be checked against a file written by the reference.
 """
 import struct
 
@@ -175,28 +176,30 @@ def read_parameters(data):
     return dict(num_gates=num_gates, gates_blob=gates_blob, const_tracker=bytes_to_bits(bv, nbits), bellman=data[pos:])
 
 
-def load_parameters(ctx, data, decompress=None, shard_index=0, shard_count=1, z_frac=(-1.0, -1.0)):
-    """File bytes -> (DeviceKey resident in HBM, api.R1cs or None, header dict incl. gamma_g2 / ic for a verifier).
-    The constraint system is decoded when the blob can be decompressed (`decompress=brotli.decompress`) or was
-    written raw by `store_parameters`."""
+def load_parameters(ctx, data, shard_index=0, shard_count=1, z_frac=(-1.0, -1.0), checked=True, disallow_points_at_infinity=False,
+                    want_host_r1cs=False):
+    """`Parameters::read(reader, disallow_points_at_infinity, checked)` (mod.rs:159-175) for the GPU prover: file bytes ->
+    (DeviceKey resident in HBM, DeviceR1cs resident in HBM, header dict incl. gamma_g2 / ic / const_tracker for a verifier
+    and for the witness generator).  The key part is converted and checked on the GPU (fk_key_load_bellman), the gate blob
+    is decoded natively (api.Gates).  want_host_r1cs: also return the decoded system as an api.R1cs in hdr['r1cs']."""
     hdr = read_parameters(data)
-    key, gamma_g2, ic = ctx.load_key_bellman(hdr['bellman'], shard_index, shard_count, z_frac)
+    flags = (api.FK_KEY_CHECKED if checked else 0) | (api.FK_KEY_NO_INFINITY if disallow_points_at_infinity else 0)
+    key, gamma_g2, ic = ctx.load_key_bellman(hdr['bellman'], shard_index, shard_count, z_frac, flags=flags)
     c = key.counts()
     blob = hdr['gates_blob']
-    stream = None
-    if blob.startswith(RAW_MAGIC):
-        stream = blob[len(RAW_MAGIC):]
-    elif decompress is not None:
-        stream = decompress(blob)
-    else:
-        try:
-            import brotli                      # not in this image; used when present
-            stream = brotli.decompress(blob)
-        except ImportError:
-            stream = None
-    r1cs = decode_gate_stream(stream, hdr['num_gates'], c['num_input'], c['num_aux']) if stream is not None else None
-    hdr.update(gamma_g2=gamma_g2, ic=ic)
-    return key, r1cs, hdr
+    raw = blob.startswith(RAW_MAGIC)
+    try:
+        gates = api.Gates(blob[len(RAW_MAGIC):] if raw else blob, api.FK_GATES_RAW if raw else api.FK_GATES_BROTLI, hdr['num_gates'],
+                          c['num_input'], c['num_aux'], ctx=ctx)
+    except Exception:
+        key.free()
+        raise
+    dr = gates.load(ctx)
+    hdr.update(gamma_g2=gamma_g2, ic=ic, gates_info=gates.info())
+    if want_host_r1cs:
+        hdr['r1cs'] = gates.to_r1cs()
+    gates.free()
+    return key, dr, hdr
 
 
 def store_parameters(key_arrays, r1cs, const_tracker_bits=(), compress=None):

@@ -49,7 +49,9 @@ enum {
     FK_ERR_UNEXPECTED_IDENTITY = 3,  /* bellman SynthesisError::UnexpectedIdentity (delta is identity) */
     FK_ERR_HIP = 4,
     FK_ERR_OOM = 5,
-    FK_ERR_KEY_MISMATCH = 6          /* key arrays do not match m / densities (bellman: get_* errors) */
+    FK_ERR_KEY_MISMATCH = 6,         /* key arrays do not match m / densities (bellman: get_* errors) */
+    FK_ERR_FORMAT = 7,               /* malformed file data: std::io::ErrorKind::InvalidData / bellman GroupDecodingError */
+    FK_ERR_UNSUPPORTED = 8           /* a run-time dependency is absent (libbrotlidec.so.1 for brotli gate blobs) */
 };
 
 #define FK_Z_EQUAL_SPLIT (-1.0)   /* z_frac_lo of every key loader: equal split by shard_index / shard_count */
@@ -287,6 +289,26 @@ int fk_prove_r1cs_submit(fk_ctx *ctx, const fk_key *key, const fk_r1cs_dev *r1cs
                          const uint64_t r[4], const uint64_t s[4], int *ticket);
 int fk_prove_r1cs_wait(fk_ctx *ctx, int ticket, uint8_t out_proof[FK_PROOF_BYTES], fk_timings *timings);
 
+/* ---------------------------------------------------------------- the circuit half of a `Parameters` file
+ * fawkes stores the constraint system as `Parameters.2`: brotli(concatenated Borsh gates) (setup.rs:25-32) and replays it
+ * for every proof through WitnessCS::get_gate_iterator / GateStreamedIterator (cs.rs:184-223, 243-245).  Here it is decoded
+ * ONCE, streamed and native: blob -> CSR with dictionary-coded coefficients (host) -> resident constraint system.
+ * FK_GATES_BROTLI binds the system's libbrotlidec.so.1 at run time (FK_ERR_UNSUPPORTED if absent); FK_GATES_RAW is the bare
+ * gate stream.  Malformed input (bad tag, index out of range, coefficient >= r, truncation, trailing bytes) is FK_ERR_FORMAT.
+ * num_gates is `Parameters.1`; num_input / num_aux come from the key (ic and l lengths).  ctx may be NULL for fk_gates_decode. */
+#define FK_GATES_RAW 0
+#define FK_GATES_BROTLI 1
+typedef struct fk_gates fk_gates;
+int fk_gates_decode(fk_ctx *ctx, const uint8_t *blob, size_t len, int format, uint32_t num_gates, uint32_t num_input,
+                    uint32_t num_aux, fk_gates **out);
+void fk_gates_free(fk_gates *gates);
+/* out[8] = num_gates, nnz(A), nnz(B), nnz(C), distinct coefficients, decoded bytes, num_input, num_aux */
+int fk_gates_info(const fk_gates *gates, uint64_t out[8]);
+/* matrix mtx (0 = A, 1 = B, 2 = C) as the arrays of an fk_r1cs: ptr[num_gates + 1], col[nnz] and (if non-NULL) val[nnz x 4] */
+int fk_gates_export(const fk_gates *gates, int mtx, uint64_t *ptr, uint32_t *col, uint64_t *val);
+/* the resident constraint system of the decoded stream (as fk_r1cs_load; the dictionary is taken over as is) */
+int fk_r1cs_load_gates(fk_ctx *ctx, const fk_gates *gates, fk_r1cs_dev **out);
+
 /* ---------------------------------------------------------------- key generation on the GPU
  * (SURVEY section 8f row 4): bellman's generate_parameters (reached from setup.rs:20) for EXPLICIT toxic
  * waste tau, alpha, beta, gamma, delta (Montgomery Fr) and the standard BN254 generators.  Produces a
@@ -311,8 +333,14 @@ int fk_key_download(fk_ctx *ctx, const fk_key *key, int which, void *host, size_
  * the upstream crate, NOT verifiable against the reference here) into the resident device layout; the
  * big-endian -> Montgomery conversion runs on the GPU.  gamma_g2_out (128 B, may be NULL) and ic_out (ic_cap x 64 B,
  * may be NULL) receive the verifier-only parts as raw Montgomery LE.  The fawkes header in front of it
- * (num_gates, gate blob, const_tracker) is parsed by the host layer (fawkes-crypto_amd/params_io.py). */
-int fk_key_load_bellman(fk_ctx *ctx, const uint8_t *buf, size_t len, uint32_t shard_index, uint32_t shard_count,
+ * (num_gates, gate blob, const_tracker) is parsed by the host layer (fawkes-crypto_amd/params_io.py), the gate blob by
+ * fk_gates_decode.  `flags` carries the two arguments of `Parameters::read(reader, disallow_points_at_infinity, checked)`
+ * (mod.rs:159): FK_KEY_NO_INFINITY | FK_KEY_CHECKED.  Whatever the flags, coordinates must be canonical (< q), the
+ * compression bit clear and an infinity encoding clean -- what the unchecked decoding of pairing_ce enforces too.  Any
+ * violation is FK_ERR_FORMAT (bellman: io::Error from GroupDecodingError) with the counts in fk_last_error. */
+#define FK_KEY_CHECKED 1u       /* `checked`: every point on its curve, G2 points in the order-r subgroup (checked on the GPU) */
+#define FK_KEY_NO_INFINITY 2u   /* `disallow_points_at_infinity`: no identity point in h, l, a, b_g1, b_g2 */
+int fk_key_load_bellman(fk_ctx *ctx, const uint8_t *buf, size_t len, uint32_t flags, uint32_t shard_index, uint32_t shard_count,
                         double z_frac_lo, double z_frac_hi, fk_key **out, uint8_t *gamma_g2_out, uint8_t *ic_out,
                         uint32_t ic_cap, uint32_t *n_ic);
 /* alpha_g1, beta_g1, delta_g1 (64 B each) then beta_g2, delta_g2 (128 B each), raw Montgomery LE */

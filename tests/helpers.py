@@ -81,3 +81,23 @@ def golden_instance():
 
 
 TOXIC = dict(tau=0x1f2e3d4c5b6a79880123456789abcdef0fedcba987654321, alpha=0xa11ce, beta=0xb0b, gamma=0xc0ffee, delta=0xdec0de)
+
+
+def brotli_compress(data, quality=9, lgwin=22):
+    """what fawkes' setup writes (setup.rs:26: CompressorWriter::new(_, 4096, 9, 22)), through the system's libbrotlienc.so.1
+    (test-side only: the product binds the DECODER, csrc/gatestream.hip).  Returns None when the library is absent."""
+    import ctypes as C
+    import ctypes.util
+    try:
+        enc = C.CDLL(ctypes.util.find_library('brotlienc') or 'libbrotlienc.so.1')
+    except OSError:
+        return None
+    enc.BrotliEncoderMaxCompressedSize.restype = C.c_size_t
+    enc.BrotliEncoderMaxCompressedSize.argtypes = [C.c_size_t]
+    cap = enc.BrotliEncoderMaxCompressedSize(len(data)) or (len(data) + 1024)
+    out = C.create_string_buffer(cap)
+    n = C.c_size_t(cap)
+    enc.BrotliEncoderCompress.argtypes = [C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_char_p, C.POINTER(C.c_size_t), C.c_char_p]
+    ok = enc.BrotliEncoderCompress(quality, lgwin, 0, len(data), bytes(data), C.byref(n), out)
+    assert ok == 1, 'BrotliEncoderCompress failed'
+    return out.raw[:n.value]

@@ -44,11 +44,13 @@ def test_config0_bit_exact_and_verifies(ctx, oracle, instance):
     for name in ('alpha_g1', 'beta_g1', 'beta_g2', 'gamma_g2', 'delta_g1', 'delta_g2'):
         arrays[name] = vk[name]
     arrays.update(ic=vk['ic'], m=1 << 13, num_input=2, num_aux=cs.num_aux)
-    data = pio.store_parameters(arrays, r1cs, const_tracker_bits=cs.const_tracker)
-    dk2, r1cs2, hdr = pio.load_parameters(ctx, data)
-    assert hdr['num_gates'] == 7362 and hdr['const_tracker'] == cs.const_tracker
+    from helpers import brotli_compress
+    # the reference's blob format (brotli quality 9 / lgwin 22, setup.rs:26) when the system has the encoder, else the raw stream
+    data = pio.store_parameters(arrays, r1cs, const_tracker_bits=cs.const_tracker, compress=brotli_compress if brotli_compress(b'x') else None)
+    dk2, dr, hdr = pio.load_parameters(ctx, data, checked=True, disallow_points_at_infinity=False, want_host_r1cs=True)
+    r1cs2 = hdr['r1cs']
+    assert hdr['num_gates'] == 7362 and hdr['const_tracker'] == cs.const_tracker and hdr['gates_info']['nnz'] == tuple(len(c) for _, c, _ in r1cs.mats)
     params = fk.Parameters(dict(arrays), r1cs2)
-    dr = ctx.load_r1cs(r1cs2)
     z_in, z_aux = fx.witness_mont(cs.z_in, []), fx.witness_mont([], cs.z_aux)
     r, s = fx.mont_fr(int(g['r'], 16)), fx.mont_fr(int(g['s'], 16))
     # prove: resident constraint system, and the host-synthesis entry, both against the committed golden proof

@@ -47,6 +47,54 @@ def test_wrapper_and_gate_stream_roundtrip(oracle):
     assert pio.g1_uncompressed(bytes(64))[0] == 0x40
 
 
+def _same_system(x, y):
+    assert (x.num_input, x.num_aux, x.num_gates) == (y.num_input, y.num_aux, y.num_gates)
+    for (p0, c0, v0), (p1, c1, v1) in zip(x.mats, y.mats):
+        assert np.array_equal(p0, p1) and np.array_equal(c0, c1) and np.array_equal(v0, v1)
+
+
+def test_native_gate_decoder_raw_brotli_and_malformed(oracle):
+    """csrc/gatestream.hip (host code, no GPU): the reference's blob format -- brotli(quality 9, lgwin 22) over the Borsh gate
+    stream, written here with the system's brotli ENCODER -- decodes to the system that was written, also across the
+    decoder's 4 MiB output chunks; malformed streams are FK_ERR_FORMAT the way the reference's reader fails."""
+    import fawkes_crypto_amd as fk
+    from fawkes_crypto_amd import api, params_io as pio
+    from helpers import brotli_compress
+    cs, _, _, _ = fx.fast_r1cs(77, 40000, 3, 41000)        # 160 k terms = 5.9 MB of gate stream: more than one output chunk
+    r1cs = r1cs_product(cs)
+    stream = pio.encode_gate_stream(r1cs)
+    assert len(stream) > (5 << 20)
+    g = api.Gates(stream, api.FK_GATES_RAW, r1cs.num_gates, r1cs.num_input, r1cs.num_aux)
+    info = g.info()
+    assert info['nnz'] == tuple(len(c) for _, c, _ in r1cs.mats) and info['decoded_bytes'] == len(stream)
+    _same_system(g.to_r1cs(), r1cs)
+    blob = brotli_compress(stream)
+    if blob is None:
+        pytest.skip('libbrotlienc.so.1 not present: cannot write a reference-format blob')
+    assert len(blob) < len(stream)
+    gb = api.Gates(blob, api.FK_GATES_BROTLI, r1cs.num_gates, r1cs.num_input, r1cs.num_aux)
+    assert gb.info() == info
+    _same_system(gb.to_r1cs(), r1cs)
+    # the slow per-term restatement of GateStreamedIterator agrees on a small system
+    cs2, _, _ = ref.random_r1cs(5, 40, 3, 50)
+    small = r1cs_product(fx.r1cs_to_csr(cs2))
+    st2 = pio.encode_gate_stream(small)
+    _same_system(api.Gates(brotli_compress(st2), api.FK_GATES_BROTLI, small.num_gates, 3, 50).to_r1cs(), pio.decode_gate_stream(st2, small.num_gates, 3, 50))
+
+    def rejects(data, fmt=api.FK_GATES_RAW, gates=small.num_gates, code=7):
+        with pytest.raises(fk.FkError) as e:
+            api.Gates(data, fmt, gates, 3, 50)
+        assert e.value.code == code
+    rejects(st2[:-3])                                       # truncated
+    rejects(st2 + b'\x00')                                  # trailing bytes
+    rejects(st2, gates=small.num_gates + 1)                 # fewer gates than announced
+    bad = bytearray(st2); bad[4 + 32] = 2; rejects(bytes(bad))                                 # "enum elements overflow" (cs.rs:209)
+    bad = bytearray(st2); bad[4 + 33:4 + 37] = (1 << 20).to_bytes(4, 'little'); rejects(bytes(bad))     # variable index out of range
+    bad = bytearray(st2); bad[4:4 + 32] = ref.R.to_bytes(32, 'little'); rejects(bytes(bad))   # coefficient not below r (from_uint fails)
+    rejects(brotli_compress(st2)[:-5], fmt=api.FK_GATES_BROTLI)                               # brotli stream cut short
+    rejects(b'\xff' * 64, fmt=api.FK_GATES_BROTLI)                                            # not brotli at all
+
+
 @pytest.mark.gpu
 def test_key_file_roundtrip_and_prove(ctx, oracle):
     """oracle key -> file bytes -> fk_key_load_bellman (GPU conversion) -> identical device arrays -> identical proof"""
@@ -59,7 +107,9 @@ def test_key_file_roundtrip_and_prove(ctx, oracle):
     arrays = _key_arrays(key)
     arrays['l'] = arrays['l'].copy(); arrays['l'][5] = 0          # an identity point inside an array (0x40 flag path)
     data = pio.store_parameters(arrays, r1cs, const_tracker_bits=[True, False, True])
-    dk, r1cs2, hdr = pio.load_parameters(ctx, data)
+    dk, dr2, hdr = pio.load_parameters(ctx, data, want_host_r1cs=True)
+    r1cs2 = hdr['r1cs']
+    assert dr2.info()['nnz'] == tuple(len(c) for _, c, _ in r1cs.mats)
     assert hdr['const_tracker'] == [True, False, True] and hdr['num_gates'] == r1cs.num_gates
     assert dk.counts()['m'] == key.m and dk.counts()['num_input'] == 3
     for name in ('h', 'l', 'a', 'b_g1', 'b_g2'):
@@ -74,9 +124,67 @@ def test_key_file_roundtrip_and_prove(ctx, oracle):
     sk, _, _ = pio.load_parameters(ctx, data, shard_index=1, shard_count=3)
     lo, hi = sk.shard_info()['h']
     assert sk.download('h').tobytes() == arrays['h'][lo:hi].tobytes()
-    # malformed files are rejected with a status code
-    with pytest.raises(fk.FkError):
-        ctx.load_key_bellman(hdr['bellman'][:1000])
-    bad = bytearray(hdr['bellman']); bad[576 + 4 + 3 * 64 + 4] |= 0x80     # compression flag on h[0]
-    with pytest.raises(fk.FkError):
-        ctx.load_key_bellman(bytes(bad))
+    # the proof from the loaded file (reference-format brotli blob when the encoder is present) equals the oracle's
+    from helpers import brotli_compress
+    if brotli_compress(b'x') is not None:
+        data_b = pio.store_parameters(arrays, r1cs, const_tracker_bits=[True], compress=brotli_compress)
+        assert len(data_b) < len(data)
+        dk_b, dr_b, _ = pio.load_parameters(ctx, data_b)
+        z = fx.witness_mont(z_in, z_aux)
+        r, s = fx.mont_fr(3), fx.mont_fr(4)
+        want = ctx.prove_witness(dk, dr2, z, r, s)             # same key (l[5] replaced by the identity in both files)
+        assert ctx.prove_witness(dk_b, dr_b, z, r, s).tobytes() == want.tobytes()
+        dk_b.free(); dr_b.free()
+    # malformed files are rejected with a status code: Parameters::read(reader, disallow_points_at_infinity, checked) (mod.rs:159)
+    bell = hdr['bellman']
+    H0 = 576 + 4 + 3 * 64 + 4                  # offset of h[0]: vk (576 B), ic count + 3 points, h count
+    with pytest.raises(fk.FkError) as e:
+        ctx.load_key_bellman(bell[:1000])
+    assert e.value.code == 7
+
+    def rejected(mut, flags=fk.api.FK_KEY_CHECKED, code=7):
+        bad = bytearray(bell); mut(bad)
+        with pytest.raises(fk.FkError) as e:
+            ctx.load_key_bellman(bytes(bad), flags=flags)
+        assert e.value.code == code, e.value
+    def setb(off, val):
+        return lambda b: b.__setitem__(slice(off, off + len(val)), val)
+    rejected(lambda b: b.__setitem__(H0, b[H0] | 0x80), flags=0)                         # compression flag on h[0]: always an error
+    rejected(setb(H0, ref.Q.to_bytes(32, 'big')), flags=0)                              # x = q: not a field element, checked or not
+    L5 = H0 + len(arrays['h']) * 64 + 4 + 5 * 64
+    assert bell[L5] == 0x40
+    rejected(setb(L5 + 40, b'\x01'), flags=0)                                            # infinity flag with a non-zero rest
+    rejected(lambda b: None, flags=fk.api.FK_KEY_NO_INFINITY)                            # l[5] IS the identity: disallow_points_at_infinity
+    ctx.load_key_bellman(bell, flags=0)[0].free()                                       # ... and is fine otherwise
+    ctx.load_key_bellman(bell, flags=fk.api.FK_KEY_CHECKED)[0].free()
+    flip = lambda b: b.__setitem__(H0 + 63, b[H0 + 63] ^ 1)                              # y of h[0] changed: off the curve
+    rejected(flip)
+    bad = bytearray(bell); flip(bad)
+    ctx.load_key_bellman(bytes(bad), flags=0)[0].free()                                 # `checked = false` does not look (bellman: into_affine_unchecked)
+    # a point ON the twist but outside the order-r subgroup in b_g2[0]: only the checked read rejects it
+    def fq_sqrt(v):
+        y = pow(v, (ref.Q + 1) // 4, ref.Q)
+        return y if y * y % ref.Q == v % ref.Q else None
+    def fq2_sqrt(a0, a1):
+        alpha = fq_sqrt((a0 * a0 + a1 * a1) % ref.Q)
+        if alpha is None:
+            return None
+        for dlt in ((a0 + alpha) * pow(2, -1, ref.Q) % ref.Q, (a0 - alpha) * pow(2, -1, ref.Q) % ref.Q):
+            x0 = fq_sqrt(dlt)
+            if x0:
+                return x0, a1 * pow(2 * x0, -1, ref.Q) % ref.Q
+        return None
+    F2, b2 = ref.F2, ref.G2.b
+    x = (5, 7)
+    while True:
+        rhs = F2.add(F2.mul(F2.sqr(x), x), b2)
+        y = fq2_sqrt(*rhs)
+        if y is not None and F2.sqr(y) == rhs:
+            break
+        x = (x[0] + 1, x[1])
+    assert ref.G2.on_curve((x, y)) and ref.G2.mul((x, y), ref.R) is not None       # on the curve, r * P != identity
+    B2 = L5 - 5 * 64 + len(arrays['l']) * 64 + 4 + len(arrays['a']) * 64 + 4 + len(arrays['b_g1']) * 64 + 4
+    enc = b''.join(v.to_bytes(32, 'big') for v in (x[1], x[0], y[1], y[0]))
+    rejected(setb(B2, enc))
+    bad = bytearray(bell); bad[B2:B2 + 128] = enc
+    ctx.load_key_bellman(bytes(bad), flags=0)[0].free()
