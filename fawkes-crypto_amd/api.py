@@ -25,11 +25,11 @@ FQ_MODULUS = 2188824287183927522224640574525727508869631115729782366268903789464
 # every symbol include/fawkes_hip.h declares (tests check the .so exports all of them)
 EXPORTED_SYMBOLS = [
     'fk_init', 'fk_free', 'fk_last_error', 'fk_set_window_bits',
-    'fk_dev_alloc', 'fk_dev_free', 'fk_upload', 'fk_download', 'fk_dev_copy', 'fk_sync',
+    'fk_dev_alloc', 'fk_dev_free', 'fk_upload', 'fk_download', 'fk_dev_copy', 'fk_sync', 'fk_stream',
     'fk_host_alloc', 'fk_host_free', 'fk_witness_upload_async', 'fk_witness_ptr', 'fk_prove_r1cs_submit', 'fk_prove_r1cs_wait',
     'fk_key_load', 'fk_key_synthetic', 'fk_key_shard_info', 'fk_key_host_vk', 'fk_key_free',
     'fk_prove', 'fk_prove_dev', 'fk_prove_msms', 'fk_prove_msms_dev', 'fk_prove_msms_z_dev', 'fk_prove_msm_h_dev', 'fk_prove_msms_hz_dev',
-    'fk_prove_msms_z_begin_dev', 'fk_prove_msms_finish_dev', 'fk_prove_msms_hz_r1cs_dev',
+    'fk_prove_msms_z_begin_dev', 'fk_prove_msms_finish_dev', 'fk_prove_msms_hz_r1cs_dev', 'fk_prove_msms_z_begin_r1cs_dev',
     'fk_prove_assemble',
     'fk_fr_mul_batch', 'fk_ntt', 'fk_ntt_dev', 'fk_quotient_h', 'fk_quotient_h_dev',
     'fk_msm_g1', 'fk_msm_g2', 'fk_msm_g1_dev', 'fk_msm_g2_dev',
@@ -484,6 +484,12 @@ class Context:
     def sync(self):
         self._ck(self.lib.fk_sync(self.handle))
 
+    def stream_handle(self):
+        """fk_stream: the library's main HIP stream as an integer (for torch.cuda.ExternalStream)"""
+        p = C.c_void_p()
+        self._ck(self.lib.fk_stream(self.handle, C.byref(p)))
+        return p.value or 0
+
     # ---- witness hand-over from host memory (pinned buffers, two device slots filled on a copy stream)
     def host_alloc(self, shape, dtype=np.uint64):
         """fk_host_alloc: a numpy array over pinned host memory (free with host_free(arr))."""
@@ -682,6 +688,10 @@ class Context:
         """queue L, A, B1, B2 on the MSM streams and return; pair with prove_msms_finish_dev"""
         self._ck(self.lib.fk_prove_msms_z_begin_dev(self.handle, key.handle, C.c_void_p(d_z), C.c_void_p(d_a_aux), C.c_void_p(d_b_in),
                                                     C.c_void_p(d_b_aux)))
+
+    def prove_msms_z_begin_r1cs_dev(self, key, device_r1cs, d_z):
+        """the same for a resident constraint system (index-list gathers instead of the density compaction)"""
+        self._ck(self.lib.fk_prove_msms_z_begin_r1cs_dev(self.handle, key.handle, device_r1cs.handle, C.c_void_p(d_z)))
 
     def prove_msms_finish_dev(self, key, d_h_slice):
         out = np.zeros(FK_MSM_RESULT_BYTES, np.uint8)

@@ -93,6 +93,7 @@ struct fk_ctx {
     // witness multiplications (L, A, B1, B2) in flight: begun before / while the quotient runs on the main stream
     hipStream_t aux = nullptr;          // scalar compaction for the A / B queries
     hipEvent_t ev_aux = nullptr, ev_main = nullptr;
+    hipEvent_t ev_acc_done = nullptr; bool ev_acc_done_valid = false;   // behind the most recent bucket accumulation (any lane)
     bool wit_active = false;
     const fk::QueryIdx *qidx = nullptr;   // set by the resident-constraint-system entry points for the duration of a call
     int wit_tail[4] = {-1, -1, -1, -1}; // B1, B2, L, A

@@ -24,8 +24,10 @@
 //                      sums are copied to pinned host memory.
 //   6. host            W window sums are Horner-combined (cw doublings each) -- microseconds.
 #include "common.hpp"
+#include "field29.hpp"
 #include <algorithm>
 #include <string.h>
+#include <type_traits>
 
 namespace fk {
 
@@ -302,6 +304,7 @@ __global__ __launch_bounds__(256) void s2_hist2_kernel(const uint16_t *tmp_lo, s
                                                         uint32_t nseg, const uint32_t *seg_start, const uint32_t *seg_size, uint32_t *cnt2) {
     extern __shared__ uint32_t hist[];
     const uint32_t tile = blockIdx.x;
+    if (tile >= tile_start[nseg]) return;        // the grid is the host's upper bound on the tile count (no read-back)
     const uint32_t sgm = s2_find_segment(tile_start, nseg, tile), w = sgm / nhi, t = tile - tile_start[sgm];
     for (uint32_t b = threadIdx.x; b < nlo; b += 256) hist[b] = 0;
     __syncthreads();
@@ -368,6 +371,7 @@ __global__ __launch_bounds__(1024) void s2_scatter2_kernel(const uint32_t *tmp_i
     __shared__ uint32_t stage_idx[S2_TILE];
     __shared__ uint16_t stage_lo[S2_TILE];
     const uint32_t tile = blockIdx.x, tid = threadIdx.x;
+    if (tile >= tile_start[nseg]) return;        // see s2_hist2_kernel
     const uint32_t sgm = s2_find_segment(tile_start, nseg, tile), w = sgm / nhi, h = sgm % nhi, t = tile - tile_start[sgm];
     lcnt[tid] = 0;
     gbase[tid] = tid < nlo ? starts[(size_t)w * B + (size_t)h * nlo + tid] + cnt2[(size_t)tile * nlo + tid] : 0;
@@ -507,11 +511,31 @@ static __device__ __forceinline__ void block_reduce_256(Xyzz<F> &acc, Xyzz<F> *s
 }
 
 // ------------------------------------------------------------------------------------------ bucket accumulation
+// The per-lane walk of a bucket.  G1 with L29: the accumulator lives on 9 x 29-bit limbs (field29.hpp: no carry-out per
+// multiply-accumulate, no conditional subtractions); points are re-sliced on load, the bucket on store.  Otherwise the 8 x 32
+// XYZZ accumulator of curve.hpp.
+#if defined(__HIP_DEVICE_COMPILE__)
+template <class F, bool L29> struct Walker {
+    Xyzz<F> acc = Xyzz<F>::inf();
+    __device__ __forceinline__ void add(const Affine<F> &p, bool neg) { acc.add_mixed(affine_neg_if(p, neg)); }
+    __device__ __forceinline__ Xyzz<F> result() const { return acc; }
+};
+template <> struct Walker<Fq, true> {
+    Xyzz29 acc = Xyzz29::inf();
+    __device__ __forceinline__ void add(const G1Affine &p, bool neg) { acc.add_mixed(p, neg); }
+    __device__ __forceinline__ G1Xyzz result() const { return acc.to_resident(); }
+};
+#else
+template <class F, bool L29> struct Walker {       // host pass: declarations only
+    void add(const Affine<F> &, bool) {}
+    Xyzz<F> result() const { return Xyzz<F>::inf(); }
+};
+#endif
 // MINW = minimum waves per SIMD the register allocator must leave room for.  G1: 4 (<= 128 registers, no spills).
 // G2: 2.  With the compiler's own add/sub code the inlined Fq2 mixed addition wanted 256 VGPRs + ~180 AGPRs and forcing 2
 // waves spilled ~260 registers (41 ms vs 33 ms at 2^25); since the generated carry-chain add/sub (addsub_gfx950.inc) it
 // needs 226 VGPRs and runs at 2 waves per SIMD without spills: 23.4 -> 13.7 ms.
-template <class F, int MINW>
+template <class F, int MINW, bool L29>
 __global__ __launch_bounds__(256, MINW) void msm_accumulate_kernel(const Affine<F> *bases, const uint32_t *sorted, size_t n,
                                                              const uint32_t *starts, const uint32_t *totals, uint32_t B,
                                                              uint32_t W, uint32_t cap_all, uint32_t cap_top, const uint32_t *perm, Xyzz<F> *buckets) {
@@ -523,13 +547,13 @@ __global__ __launch_bounds__(256, MINW) void msm_accumulate_kernel(const Affine<
     const uint32_t *src = sorted + (size_t)w * n + starts[g];
     uint32_t cnt = totals[g];
     if (cnt > cap) cnt = cap;
-    Xyzz<F> acc = Xyzz<F>::inf();
+    Walker<F, L29> acc;
     for (uint32_t k = 0; k < cnt; k++) {
         const uint32_t e = src[k];
         Affine<F> p = bases[e & 0x7fffffffu];
-        acc.add_mixed(affine_neg_if(p, (e >> 31) != 0));
+        acc.add(p, (e >> 31) != 0);
     }
-    buckets[g] = acc;
+    buckets[g] = acc.result();
 }
 
 // Merged form (precomputed levels): lane t owns bucket b = perm[t] of the ONE bucket set and walks that bucket's entries in
@@ -537,7 +561,7 @@ __global__ __launch_bounds__(256, MINW) void msm_accumulate_kernel(const Affine<
 // The walk is ONE loop over the bucket's merged length mt[b] with a (window, position) cursor: the lanes of a wave are
 // size-ordered by that merged length, so they stay in step; a loop per window would run every window to the longest of the 64
 // per-window counts (Poisson: 1.6 x the mean at a load of 16).
-template <class F, int MINW>
+template <class F, int MINW, bool L29>
 __global__ __launch_bounds__(256, MINW) void msm_accumulate_merged_kernel(const Affine<F> *bases, const Affine<F> *lev, const uint32_t *sorted, size_t n,
                                                                     const uint32_t *starts, const uint32_t *totals, uint32_t B,
                                                                     uint32_t W, uint32_t cap, const uint32_t *perm, const uint32_t *mt, Xyzz<F> *buckets) {
@@ -545,7 +569,7 @@ __global__ __launch_bounds__(256, MINW) void msm_accumulate_merged_kernel(const 
     if (t >= B) return;
     const uint32_t b = perm[t];
     const uint32_t total = mt[b];
-    Xyzz<F> acc = Xyzz<F>::inf();
+    Walker<F, L29> acc;
     uint32_t w = 0, k = 0, cnt = 0;
     const uint32_t *src = nullptr;
     const Affine<F> *bw = bases;
@@ -563,9 +587,9 @@ __global__ __launch_bounds__(256, MINW) void msm_accumulate_merged_kernel(const 
         }
         const uint32_t e = src[k++];
         Affine<F> p = bw[e & 0x7fffffffu];
-        acc.add_mixed(affine_neg_if(p, (e >> 31) != 0));
+        acc.add(p, (e >> 31) != 0);
     }
-    buckets[b] = acc;
+    buckets[b] = acc.result();
 }
 // mt[b] = sum over the windows of min(totals[w][b], cap): the merged bucket's length, for the size ordering
 __global__ __launch_bounds__(256) void msm_merge_totals_kernel(const uint32_t *totals, uint32_t B, uint32_t W, uint32_t cap, uint32_t *mt, unsigned long long *adds) {
@@ -622,7 +646,7 @@ struct Task { uint32_t g, seg; };
 // several waves per SIMD in flight (the multiply is a serial chain, one wave alone cannot fill the VALU).
 // The per-lane walk uses the inlined multiply (F); the wave64 shuffle reduction runs on the
 // layout-identical cold twin (FC).
-template <class F, class FC>
+template <class F, class FC, bool L29>
 __global__ __launch_bounds__(64) void msm_overflow_kernel(const Affine<F> *bases0, const Affine<F> *lev, const uint32_t *sorted, size_t n,
                                                           const uint32_t *starts, const uint32_t *totals, uint32_t B,
                                                           uint32_t W, uint32_t cap_all, uint32_t cap_top, uint32_t SEG, const Task *tasks, Xyzz<FC> *partials) {
@@ -634,11 +658,12 @@ __global__ __launch_bounds__(64) void msm_overflow_kernel(const Affine<F> *bases
     const uint32_t size = totals[t.g];
     const uint32_t lo = cap + t.seg * SEG;
     const uint32_t hi = lo + SEG < size ? lo + SEG : size;
-    Xyzz<F> acc = Xyzz<F>::inf();
+    Walker<F, L29> wk;
     for (uint32_t k = lo + threadIdx.x; k < hi; k += 64) {
         const uint32_t e = src[k];
-        acc.add_mixed(affine_neg_if(bases[e & 0x7fffffffu], (e >> 31) != 0));
+        wk.add(bases[e & 0x7fffffffu], (e >> 31) != 0);
     }
+    const Xyzz<F> acc = wk.result();
     static_assert(sizeof(Xyzz<F>) == sizeof(Xyzz<FC>), "layout");
     Xyzz<FC> accc;
     __builtin_memcpy(&accc, &acc, sizeof acc);
@@ -746,8 +771,14 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
     const int li = have_sort ? ctx->lane_prev : ctx->lane_next;
     MsmLane &ln = ctx->lanes[li];
     FK_TRY(lane_init(ctx, ln));
-    ctx->lane_prev = li; ctx->lane_next = (li + 1) % (ctx->lanes_in_use >= 2 && ctx->lanes_in_use <= MSM_LANES ? ctx->lanes_in_use : MSM_LANES);
+    static int t_lanes = -1, t_serial_sort = -1;      // experiments: FK_MSM_LANES = 1..3 overrides the lane count; FK_MSM_SORT_ALONE=1 see below
+    if (t_lanes < 0) { const char *e = getenv("FK_MSM_LANES"); t_lanes = e ? atoi(e) : 0; e = getenv("FK_MSM_SORT_ALONE"); t_serial_sort = e ? atoi(e) : 0; }
+    const int n_lanes = (t_lanes >= 1 && t_lanes <= MSM_LANES) ? t_lanes : (ctx->lanes_in_use >= 2 && ctx->lanes_in_use <= MSM_LANES ? ctx->lanes_in_use : MSM_LANES);
+    ctx->lane_prev = li; ctx->lane_next = (li + 1) % n_lanes;
     hipStream_t st = ln.st;
+    // FK_MSM_SORT_ALONE=1: this multiplication's digits / sort do not start before the previous multiplication's accumulation
+    // has finished (they then run at full memory speed instead of crawling underneath it); its latency-bound tail still overlaps
+    if (t_serial_sort == 1 && !have_sort && ctx->ev_acc_done_valid) FK_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_acc_done, 0));
     if (ready) {
         FK_HIP(ctx, hipStreamWaitEvent(st, ready, 0));
     } else {
@@ -806,21 +837,18 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
         hipLaunchKernelGGL(s2_scatter1_kernel, dim3(p.nchunks, p.W), dim3(1024), 0, st, digits, n, p.chunk, p.nchunks, p.LB, p.nhi, cnt1,
                            seg_start, tmp_idx, tmp_lo);
         FK_HIP(ctx, hipGetLastError());
-        uint32_t *h_cnt = (uint32_t *)ln.h_stage;
-        FK_HIP(ctx, hipMemcpyAsync(h_cnt, tile_start + nseg, 4, hipMemcpyDeviceToHost, st));
-        FK_HIP(ctx, hipStreamSynchronize(st));
-        const uint32_t n_tiles = h_cnt[0];
         FK_DBG_ST(ctx, st, "msm_sort_pass1");
-        if (n_tiles > max_tiles) FK_SET_ERR(ctx, FK_ERR_HIP, "msm: tile count %u exceeds the bound %zu", n_tiles, max_tiles);
-        if (n_tiles) {
+        // The second pass is launched over the host's BOUND on the tile count (every segment's last tile may be partial:
+        // W * ceil(n / tile) + #segments); workgroups beyond the actual count leave at once.  Reading the count back cost a
+        // host round trip in the middle of every sort.
+        const uint32_t n_tiles = (uint32_t)max_tiles;
+        {
             hipLaunchKernelGGL(s2_hist2_kernel, dim3(n_tiles), dim3(256), p.nlo * 4, st, tmp_lo, n, p.nhi, p.nlo, tile_start, nseg, seg_start, seg_size, cnt2);
         }
         hipLaunchKernelGGL(s2_prefix2_kernel, dim3(nseg), dim3(1024), 0, st, cnt2, p.nhi, p.nlo, p.B, tile_start, seg_start, p.cap, p.cap_top, p.W, totals, starts,
                            ln.overlist.as<OverEntry>(), d_nover, over_cap);
-        if (n_tiles) {
-            hipLaunchKernelGGL(s2_scatter2_kernel, dim3(n_tiles), dim3(1024), 0, st, tmp_idx, tmp_lo, n, p.nhi, p.nlo, p.B, tile_start, nseg, seg_start,
-                               seg_size, cnt2, starts, sorted);
-        }
+        hipLaunchKernelGGL(s2_scatter2_kernel, dim3(n_tiles), dim3(1024), 0, st, tmp_idx, tmp_lo, n, p.nhi, p.nlo, p.B, tile_start, nseg, seg_start,
+                           seg_size, cnt2, starts, sorted);
         FK_HIP(ctx, hipGetLastError());
         FK_DBG_ST(ctx, st, "msm_sort_pass2");
         ln.last_sort_scalars = (const void *)d_scalars; ln.last_sort_n = n; ln.last_sort_c = p.c; ln.last_merged = merged;
@@ -838,7 +866,11 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
         cap = p.cap;
         // The cap assumes Poisson bucket loads.  Scalars with many repeated values (a batch witness) put tens of thousands of
         // buckets a little over it, and one wave per such bucket is a poor trade: double the cap until few remain.
-        const uint32_t many = (uint32_t)std::max<size_t>(4096, WB / 64);
+        // ("few": every oversized bucket costs a wave per segment plus a 256-lane fold workgroup -- with 4e5 of them, what WB / 64
+        // used to allow at 2^25, the overflow + fold kernels took 70 ms of a proof whose witness held each value 341 times)
+        static int t_many = -1;
+        if (t_many < 0) { const char *e = getenv("FK_MSM_OVER_MANY"); t_many = e ? atoi(e) : 2048; }
+        const uint32_t many = (uint32_t)std::max<size_t>((size_t)t_many, WB / 8192);
         while (n_over > many && cap < (1u << 20)) {
             cap *= 2;
             FK_HIP(ctx, hipMemsetAsync(d_nover, 0, 4, st));
@@ -913,19 +945,37 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
     // ---- from here on nothing waits for the host
     std::vector<EventPair> &evv = (sizeof(F) == sizeof(Fq)) ? ctx->ev_acc : ctx->ev_acc2;
     FK_TRY(stats_begin(ctx, evv, (uint64_t)n, st));
-    if (merged)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_merged_kernel<F, (sizeof(F) == sizeof(Fq) ? 4 : 2)>), dim3((p.B + 255) / 256), dim3(256), 0, st, d_bases, d_lev, sorted, n,
-                           starts, totals, p.B, p.W, cap, perm, perm + p.B, buckets);
-    else
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_kernel<F, (sizeof(F) == sizeof(Fq) ? 4 : 2)>), dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, d_bases, sorted, n,
-                       starts, totals, p.B, p.W, cap, cap, perm, buckets);
+    // FK_MSM_LIMB29=1: G1 accumulator on 9 x 29-bit limbs (field29.hpp).  Measured and NOT the default: the product alone is
+    // 155 against 134 G/s, but the mixed addition around it (re-slicing two coordinates per point, signed carry chains for the
+    // five differences, 20 % more multiplier operations at an eighth of the simple-ALU rate) comes out at 11.9 against 12.1 G
+    // additions/s in registers (tools/mulbench/addbench.hip) and 234 against 216 ms per proof in place
+    // (profiles/r02_limb29_in_situ.log).
+    static int t_l29 = -1;
+    if (t_l29 < 0) { const char *e = getenv("FK_MSM_LIMB29"); t_l29 = e ? atoi(e) : 0; }
+    constexpr bool IS_G1 = std::is_same<F, Fq>::value;
+    const bool l29 = IS_G1 && t_l29 != 0;
+    constexpr int MINW_ = IS_G1 ? 4 : 2;
+    if (merged) {
+        if (l29) hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_merged_kernel<F, (IS_G1 ? 3 : 2), IS_G1>), dim3((p.B + 255) / 256), dim3(256), 0, st, d_bases, d_lev, sorted, n,
+                                    starts, totals, p.B, p.W, cap, perm, perm + p.B, buckets);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_merged_kernel<F, MINW_, false>), dim3((p.B + 255) / 256), dim3(256), 0, st, d_bases, d_lev, sorted, n,
+                                starts, totals, p.B, p.W, cap, perm, perm + p.B, buckets);
+    } else {
+        if (l29) hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_kernel<F, (IS_G1 ? 3 : 2), IS_G1>), dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, d_bases, sorted, n,
+                                    starts, totals, p.B, p.W, cap, cap, perm, buckets);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_kernel<F, MINW_, false>), dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, d_bases, sorted, n,
+                                starts, totals, p.B, p.W, cap, cap, perm, buckets);
+    }
     FK_HIP(ctx, hipGetLastError());
     FK_TRY(stats_end(ctx, evv, st));
+    if (!ctx->ev_acc_done) FK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_acc_done, hipEventDisableTiming));
+    FK_HIP(ctx, hipEventRecord(ctx->ev_acc_done, st)); ctx->ev_acc_done_valid = true;
     FK_DBG_ST(ctx, st, "msm_accumulate");
     if (n_over) {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_overflow_kernel<F, FC>), dim3((unsigned)n_tasks), dim3(64), 0, st,
-                           d_bases, d_lev, sorted, n, starts,
-                           totals, p.B, p.W, cap, cap, SEG, d_tasks, ln.partials.as<Xyzz<FC>>());
+        if (l29) hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_overflow_kernel<F, FC, IS_G1>), dim3((unsigned)n_tasks), dim3(64), 0, st,
+                                    d_bases, d_lev, sorted, n, starts, totals, p.B, p.W, cap, cap, SEG, d_tasks, ln.partials.as<Xyzz<FC>>());
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_overflow_kernel<F, FC, false>), dim3((unsigned)n_tasks), dim3(64), 0, st,
+                                d_bases, d_lev, sorted, n, starts, totals, p.B, p.W, cap, cap, SEG, d_tasks, ln.partials.as<Xyzz<FC>>());
         FK_HIP(ctx, hipGetLastError());
         FK_DBG_ST(ctx, st, "msm_overflow");
         hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_overflow_fold_kernel<F>), dim3((unsigned)n_obs), dim3(256), 0, st, d_obs,
@@ -984,6 +1034,7 @@ void msm_release(fk_ctx *ctx) {
     if (ctx->aux) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamDestroy(ctx->aux); ctx->aux = nullptr; }
     if (ctx->ev_aux) { (void)hipEventDestroy(ctx->ev_aux); ctx->ev_aux = nullptr; }
     if (ctx->ev_main) { (void)hipEventDestroy(ctx->ev_main); ctx->ev_main = nullptr; }
+    if (ctx->ev_acc_done) { (void)hipEventDestroy(ctx->ev_acc_done); ctx->ev_acc_done = nullptr; ctx->ev_acc_done_valid = false; }
     for (MsmLane &ln : ctx->lanes) {
         if (ln.st) (void)hipStreamSynchronize(ln.st);
         for (DevBuf *b : {&ln.digits, &ln.sorted, &ln.totals, &ln.starts, &ln.perm, &ln.overlist, &ln.tasktab, &ln.partials, &ln.s2_cnt1, &ln.s2_seg,

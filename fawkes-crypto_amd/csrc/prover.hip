@@ -131,6 +131,13 @@ int fk_dev_copy(fk_ctx *ctx, void *dst, const void *src, size_t bytes) {
     if (bytes) FK_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     return FK_OK;
 }
+// the HIP stream the library queues its main-path work on (quotient, SpMV, fk_dq_*): lets a host that owns other streams
+// (RCCL collectives issued by torch.distributed) order against it with events instead of host-side synchronisation
+int fk_stream(fk_ctx *ctx, void **out) {
+    if (!ctx || !out) return FK_ERR_BAD_ARG;
+    *out = (void *)ctx->stream;
+    return FK_OK;
+}
 int fk_sync(fk_ctx *ctx) {
     if (!ctx) return FK_ERR_BAD_ARG;
     FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -310,9 +317,11 @@ static int witness_begin(fk_ctx *ctx, const fk_key *key, const Fr *d_z, const ui
     bool any_tail = false;
     for (int i = 0; i < MSM_TAILS; i++) any_tail = any_tail || ctx->tails[i].active;
     if (!any_tail) ctx->lane_next = 0;      // nothing outstanding: start the rotation over (same lanes in every proof)
-    // Three lanes keep A from queueing behind B2's long G2 tail: 2^20 14.9 -> 13.3 ms, 2^22 28.0 -> 25.6 ms per proof.  At
-    // 2^25 the tails are short next to the accumulations and the third lane's extra co-running costs 1 %: two lanes there.
-    ctx->lanes_in_use = (key->h_hi - key->h_lo) + 1 >= ((uint64_t)1 << 25) ? 2 : MSM_LANES;      // this shard's H size
+    // Three lanes keep A from queueing behind B2's long G2 tail: 2^20 14.9 -> 13.3 ms, 2^22 28.0 -> 25.6 ms per proof.  At 2^25
+    // it depends on the witness: with mostly trivial B-query scalars (the synthetic shape) the tails are short and a third
+    // lane's co-running costs 1 %, with dense ones (1024 rollup transactions: G2 accumulation 35 ms) it gains 2 % -- 216.0 ->
+    // 211.2 ms (profiles/r02_lanes_probe.log; one lane, no overlap at all: 227.3).  Three everywhere.
+    ctx->lanes_in_use = MSM_LANES;
     FK_HIP(ctx, hipSetDevice(ctx->device));
     if (!ctx->aux) {
         FK_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
@@ -404,7 +413,7 @@ static int prove_msms_dev(fk_ctx *ctx, const fk_key *key, Fr *d_a, Fr *d_b, Fr *
     Fr *d_h = ctx->hbuf.as<Fr>();
     uint64_t m = 0;
     ctx->lane_next = 0;     // same lane for the same multiplication in every proof: lane buffers keep their sizes
-    ctx->lanes_in_use = (key->h_hi - key->h_lo) + 1 >= ((uint64_t)1 << 25) ? 2 : MSM_LANES;      // this shard's H size
+    ctx->lanes_in_use = MSM_LANES;
     FK_TRY(quotient_dev(ctx, d_a, d_b, d_c, n, d_h, &m));          // queued on the main stream, not waited for
     const double t1 = now_ms();
     // Single GPU: the multiplications start after the quotient.  Running the witness multiplications underneath it was

@@ -406,6 +406,18 @@ int fk_prove_msms_hz_r1cs_dev(fk_ctx *ctx, const fk_key *key, const fk_r1cs_dev 
     return rc;
 }
 
+// ... and of fk_prove_msms_z_begin_dev: the witness multiplications are queued (index-list gathers), the caller runs the
+// (distributed) quotient and finishes with fk_prove_msms_finish_dev
+int fk_prove_msms_z_begin_r1cs_dev(fk_ctx *ctx, const fk_key *key, const fk_r1cs_dev *r, const void *d_z) {
+    if (!ctx) return FK_ERR_BAD_ARG;
+    if (!key || !r || !d_z) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "prove: null argument");
+    if (r->num_input != key->num_input || r->num_aux != key->num_aux) FK_SET_ERR(ctx, FK_ERR_KEY_MISMATCH, "prove: constraint system and key disagree on the variable counts");
+    ctx->qidx = &r->qidx;
+    const int rc = fk_prove_msms_z_begin_dev(ctx, key, d_z, r->d_a_aux, r->d_b_in, r->d_b_aux);
+    ctx->qidx = nullptr;
+    return rc;
+}
+
 int fk_prove_r1cs(fk_ctx *ctx, const fk_key *key, const fk_r1cs_dev *r, const uint64_t *z, const uint64_t rr[4], const uint64_t ss[4],
                   uint8_t out_proof[FK_PROOF_BYTES], fk_timings *tm) {
     if (!ctx) return FK_ERR_BAD_ARG;

@@ -177,26 +177,44 @@ def log2_world(world):
 
 def torch_all_to_all(ctx, group=None):
     """all-to-all of lists of equally sized uint8 device tensors over torch.distributed (nccl = RCCL over xGMI).
-    The library computes on its own HIP stream, the collective runs on torch's: both sides are fenced.
-    Under gloo (CPU tests, single-device dry runs) the tensors are staged through the host."""
+
+    Returns a callable `a2a(dst, src)` (blocking form) that also carries the split form `h = a2a.begin(dst, src)` /
+    `a2a.end(h)` the pipelined quotient uses.  Over RCCL nothing waits on the host: the library's main stream is wrapped as
+    a torch stream (fk_stream -> torch.cuda.ExternalStream) and made current while the collective is issued, so
+    ProcessGroupNCCL orders its own stream behind everything the library has queued (begin) and the library's stream
+    behind the collective (end) with events.  Work queued on the library stream between begin and end runs while the
+    bytes are on the links.  Under gloo (CPU tests, single-device dry runs) the tensors are staged through the host."""
     import torch
     import torch.distributed as dist
     stage = dist.get_backend(group) == 'gloo'
+    lib_stream = None
 
-    def a2a(dst, src):
-        ctx.sync()
-        if stage:
+    def begin(dst, src):
+        nonlocal lib_stream
+        if stage or not src[0].is_cuda:
+            ctx.sync()
             for d, s_ in zip(dst, src):
                 hs = s_.cpu()
                 hd = torch.empty_like(hs)
                 dist.all_to_all_single(hd, hs, group=group)
                 d.copy_(hd)
-        else:
-            works = [dist.all_to_all_single(d, s_, group=group, async_op=True) for d, s_ in zip(dst, src)]
-            for w in works:
-                w.wait()
-        if dst[0].is_cuda:
-            torch.cuda.synchronize()
+            if dst[0].is_cuda:
+                torch.cuda.synchronize()
+            return None
+        if lib_stream is None:
+            lib_stream = torch.cuda.ExternalStream(ctx.stream_handle(), device=src[0].device)
+        with torch.cuda.stream(lib_stream):
+            return [dist.all_to_all_single(d, s_, group=group, async_op=True) for d, s_ in zip(dst, src)]
+
+    def end(works):
+        if works:
+            with torch.cuda.stream(lib_stream):
+                for w in works:
+                    w.wait()            # stream-ordered for NCCL work: the library stream waits, the host does not
+
+    def a2a(dst, src):
+        end(begin(dst, src))
+    a2a.begin, a2a.end = begin, end
     return a2a
 
 
@@ -204,19 +222,31 @@ def quotient_distributed(ctx, rank, world, d_full, n, log_m, send, recv, a2a):
     """h = (A*B - C)/Z over `world` ranks.  d_full: device pointers of the three row-evaluation vectors a, b, c (n valid
     rows; every rank holds them -- the SpMV is ~1 % of a proof).  send, recv: 3 + 3 buffers of (m/world)*32 bytes with
     .data_ptr() (torch uint8 device tensors); a2a(dst_list, src_list): the exchange.  Returns the buffer that holds
-    this rank's block h[rank*m/world, (rank+1)*m/world) (Montgomery, 32 B per coefficient)."""
+    this rank's block h[rank*m/world, (rank+1)*m/world) (Montgomery, 32 B per coefficient).
+
+    The three polynomials are independent until the pointwise step, so when the exchange has a split form (a2a.begin /
+    a2a.end: torch_all_to_all over RCCL) they are pipelined: polynomial k's all-to-all is on the links while polynomial
+    k+1's rank-local transform runs.  Same calls, same bytes as the plain order."""
     lw = log2_world(world)
     p = lambda t: t.data_ptr()
-    for k in range(3):                                   # ifft, first half
+    begin = getattr(a2a, 'begin', None)
+    end = getattr(a2a, 'end', None)
+    if begin is None:
+        begin = lambda dst, src: a2a(dst, src)
+        end = lambda h: None
+    h1 = []
+    for k in range(3):                                   # ifft, first half; its exchange starts at once
         ctx.dq_gather_dev(d_full[k], n, log_m, rank, lw, p(send[k]))
         ctx.dq_local_dev(p(send[k]), log_m, rank, lw, 0)
-    a2a(recv, send)
+        h1.append(begin(recv[k:k + 1], send[k:k + 1]))
+    h2 = []
     for k in range(3):                                   # ifft second half, coset shift, coset_fft first half
+        end(h1[k])
         ctx.dq_cross_dev(p(recv[k]), log_m, rank, lw, 0)
-    a2a(send, recv)
-    for k in range(1, 3):                                # coset_fft, second half
+        h2.append(begin(send[k:k + 1], recv[k:k + 1]))
+    for k in (1, 2, 0):                                  # coset_fft, second half (b and c first: a is transformed in place last)
+        end(h2[k])
         ctx.dq_local_dev(p(send[k]), log_m, rank, lw, 1)
-    ctx.dq_local_dev(p(send[0]), log_m, rank, lw, 1)
     ctx.dq_local_dev(p(send[0]), log_m, rank, lw, 2, p(send[1]), p(send[2]))     # a*b - c, icoset_fft first half
     a2a(recv[:1], send[:1])
     ctx.dq_cross_dev(p(recv[0]), log_m, rank, lw, 1)     # icoset_fft second half, / Z(g)
@@ -233,10 +263,15 @@ def prove_distributed_dev(ctx, key, rank, world, d_full, n, log_m, d_z, d_a_aux,
     if a2a is None:
         a2a = torch_all_to_all(ctx, group)
     # The witness MSMs do not need the quotient, so they can be begun first and fill the GPU during the quotient's
-    # all-to-all phases (FK_OVERLAP_WITNESS=1).  Off by default: on one GPU the overlap measured neutral at 2^25 and
-    # 10 % slower at 2^20 / 2^22 (both sides are VALU-bound), and it cannot be measured across GPUs here.
-    if os.environ.get('FK_OVERLAP_WITNESS') == '1':
-        ctx.prove_msms_z_begin_dev(key, d_z, d_a_aux, d_b_in, d_b_aux)
+    # all-to-all phases.  On ONE GPU the overlap measured neutral at 2^25 and 10 % slower at 2^20 / 2^22 (both sides are
+    # VALU-bound and there is nothing to wait for); from 4 ranks on the per-rank transforms are short next to the eight
+    # exchanges, so the default there is to overlap.  FK_OVERLAP_WITNESS=1 / 0 forces either.
+    ov = os.environ.get('FK_OVERLAP_WITNESS', '')
+    if ov == '1' or (ov != '0' and world >= 4):
+        if device_r1cs is not None:
+            ctx.prove_msms_z_begin_r1cs_dev(key, device_r1cs, d_z)
+        else:
+            ctx.prove_msms_z_begin_dev(key, d_z, d_a_aux, d_b_in, d_b_aux)
         h_blk = quotient_distributed(ctx, rank, world, d_full, n, log_m, send, recv, a2a)
         part = ctx.prove_msms_finish_dev(key, h_blk.data_ptr())
     else:

@@ -76,6 +76,10 @@ int fk_download(fk_ctx *ctx, void *host, const void *dptr, size_t bytes);
 /* asynchronous device-to-device copy on the library stream */
 int fk_dev_copy(fk_ctx *ctx, void *dst, const void *src, size_t bytes);
 int fk_sync(fk_ctx *ctx);
+/* the hipStream_t (as void *) of the library's main path -- quotient, SpMV, fk_dq_* are queued there.  A host that runs
+ * collectives on streams of its own (RCCL through torch.distributed) orders them against it with stream events
+ * (torch.cuda.ExternalStream) instead of fk_sync. */
+int fk_stream(fk_ctx *ctx, void **out);
 /* pinned host memory (hipHostMalloc): witness buffers handed to fk_prove_r1cs_submit / fk_witness_upload_async */
 int fk_host_alloc(fk_ctx *ctx, size_t bytes, void **hptr);
 int fk_host_free(fk_ctx *ctx, void *hptr);
@@ -276,6 +280,8 @@ int fk_prove_r1cs(fk_ctx *ctx, const fk_key *key, const fk_r1cs_dev *r1cs, const
  * the per-proof density compaction) */
 int fk_prove_msms_hz_r1cs_dev(fk_ctx *ctx, const fk_key *key, const fk_r1cs_dev *r1cs, const void *d_h_slice, const void *d_z,
                               uint8_t out_msms[FK_MSM_RESULT_BYTES]);
+/* ... and of fk_prove_msms_z_begin_dev (finish with fk_prove_msms_finish_dev) */
+int fk_prove_msms_z_begin_r1cs_dev(fk_ctx *ctx, const fk_key *key, const fk_r1cs_dev *r1cs, const void *d_z);
 int fk_prove_r1cs_dev(fk_ctx *ctx, const fk_key *key, const fk_r1cs_dev *r1cs, const void *d_z,
                       const uint64_t r[4], const uint64_t s[4], uint8_t out_proof[FK_PROOF_BYTES], fk_timings *timings);
 /* The same proof, pipelined over the host boundary.  The reference produces the witness on the host for every proof

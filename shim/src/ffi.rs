@@ -1,0 +1,52 @@
+//! `extern "C"` mirror of include/fawkes_hip.h -- only the entry points the shim uses.
+//! Layouts are `#[repr(C)]` images of the C structs; every function returns FK_OK (0) or an error code.
+#![allow(non_camel_case_types, dead_code)]
+use std::os::raw::{c_char, c_int, c_void};
+
+#[repr(C)] pub struct fk_ctx { _p: [u8; 0] }
+#[repr(C)] pub struct fk_key { _p: [u8; 0] }
+#[repr(C)] pub struct fk_r1cs_dev { _p: [u8; 0] }
+#[repr(C)] pub struct fk_gates { _p: [u8; 0] }
+
+pub const FK_OK: c_int = 0;
+pub const FK_PROOF_BYTES: usize = 256;
+pub const FK_Z_EQUAL_SPLIT: f64 = -1.0;
+pub const FK_GATES_BROTLI: c_int = 1;
+
+/// `fk_key_desc` (fawkes_hip.h): host pointers to the raw little-endian Montgomery images of bellman's
+/// `Parameters { vk, h, l, a, b_g1, b_g2 }` (mod.rs:139), i.e. `into_raw_uncompressed_le` per point (group.rs:57-66,97-103).
+#[repr(C)]
+pub struct fk_key_desc {
+    pub m: u64, pub num_input: u32, pub num_aux: u32,
+    pub alpha_g1: *const u8, pub beta_g1: *const u8, pub delta_g1: *const u8,
+    pub beta_g2: *const u8, pub delta_g2: *const u8,
+    pub h: *const u8, pub n_h: u64,
+    pub l: *const u8, pub n_l: u64,
+    pub a: *const u8, pub n_a: u64,
+    pub b_g1: *const u8, pub b_g2: *const u8, pub n_b: u64,
+    pub shard_index: u32, pub shard_count: u32,
+    pub z_frac_lo: f64, pub z_frac_hi: f64,
+}
+
+extern "C" {
+    pub fn fk_init(device_id: c_int, out: *mut *mut fk_ctx) -> c_int;
+    pub fn fk_free(ctx: *mut fk_ctx);
+    pub fn fk_last_error(ctx: *const fk_ctx) -> *const c_char;
+    pub fn fk_key_load(ctx: *mut fk_ctx, desc: *const fk_key_desc, out: *mut *mut fk_key) -> c_int;
+    pub fn fk_key_free(ctx: *mut fk_ctx, key: *mut fk_key);
+    // the circuit half of Parameters: brotli gate blob -> resident constraint system (decoded once, not per proof)
+    pub fn fk_gates_decode(ctx: *mut fk_ctx, blob: *const u8, len: usize, format: c_int, num_gates: u32, num_input: u32,
+                           num_aux: u32, out: *mut *mut fk_gates) -> c_int;
+    pub fn fk_gates_free(gates: *mut fk_gates);
+    pub fn fk_r1cs_load_gates(ctx: *mut fk_ctx, gates: *const fk_gates, out: *mut *mut fk_r1cs_dev) -> c_int;
+    pub fn fk_r1cs_free(ctx: *mut fk_ctx, r1cs: *mut fk_r1cs_dev);
+    // witness in -> 256-byte Borsh proof out
+    pub fn fk_prove_r1cs(ctx: *mut fk_ctx, key: *const fk_key, r1cs: *const fk_r1cs_dev, z: *const u64,
+                         r: *const u64, s: *const u64, out_proof: *mut u8, timings: *mut c_void) -> c_int;
+    // pipelined form: the upload of proof k+1's witness runs underneath proof k (pinned buffers: fk_host_alloc)
+    pub fn fk_host_alloc(ctx: *mut fk_ctx, bytes: usize, hptr: *mut *mut c_void) -> c_int;
+    pub fn fk_host_free(ctx: *mut fk_ctx, hptr: *mut c_void) -> c_int;
+    pub fn fk_prove_r1cs_submit(ctx: *mut fk_ctx, key: *const fk_key, r1cs: *const fk_r1cs_dev, z: *const u64,
+                                r: *const u64, s: *const u64, ticket: *mut c_int) -> c_int;
+    pub fn fk_prove_r1cs_wait(ctx: *mut fk_ctx, ticket: c_int, out_proof: *mut u8, timings: *mut c_void) -> c_int;
+}

@@ -1,0 +1,151 @@
+//! Drop-in for `fawkes_crypto::backend::bellman_groth16::prover::prove`
+//! (/root/reference/fawkes-crypto/src/backend/bellman_groth16/prover.rs:63-90) with the one heavy call,
+//! `bellman::groth16::create_random_proof(bcs, &params.0, rng)` (prover.rs:80), replaced by libfawkes_hip.so.
+//!
+//! Everything above that line (running the circuit closure on `WitnessCS` to obtain the witness, prover.rs:69-76) and
+//! below it (`Proof`, the const-tracker assertion, the public inputs, prover.rs:82-89) is the reference's own code path.
+//!
+//! UNCOMPILED: the build image has no Rust toolchain (see README.md).  The C ABI underneath is exercised by the
+//! repository's test-suite through the ctypes mirror fawkes-crypto_amd/api.py.
+pub mod ffi;
+
+use std::ffi::CStr;
+use std::ptr;
+
+use borsh::BorshDeserialize;
+use fawkes_crypto::backend::bellman_groth16::{
+    bellman_fp_to_num, engines::Engine, osrng::OsRng, prover::Proof, Parameters,
+};
+use fawkes_crypto::circuit::cs::{WitnessCS, CS};
+use fawkes_crypto::circuit::lc::Index;
+use fawkes_crypto::core::signal::Signal;
+use fawkes_crypto::ff_uint::Num;
+
+use bellman::pairing::{CurveAffine, RawEncodable};
+
+/// A proving key and its constraint system resident in the HBM of one MI355X: built once per `Parameters`.
+pub struct HipProver {
+    ctx: *mut ffi::fk_ctx,
+    key: *mut ffi::fk_key,
+    r1cs: *mut ffi::fk_r1cs_dev,
+}
+
+unsafe impl Send for HipProver {}
+
+fn last_error(ctx: *const ffi::fk_ctx) -> String {
+    unsafe { CStr::from_ptr(ffi::fk_last_error(ctx)).to_string_lossy().into_owned() }
+}
+
+/// `into_raw_uncompressed_le` per point (the call group.rs:59,97 already uses), the identity as zeros (group.rs:55)
+fn raw_points<G: CurveAffine + RawEncodable>(v: &[G], width: usize) -> Vec<u8> {
+    let mut out = Vec::with_capacity(v.len() * width);
+    for p in v {
+        if p.is_zero() { out.extend(std::iter::repeat(0u8).take(width)); }
+        else { out.extend_from_slice(p.into_raw_uncompressed_le().as_ref()); }
+    }
+    out
+}
+
+impl HipProver {
+    /// Uploads `params.0` (bellman's key) and decodes `params.2` (the brotli gate blob, setup.rs:25-32) into the resident
+    /// constraint system -- ONCE, instead of once per proof (cs.rs:243-245).
+    pub fn new<E: Engine>(device_id: i32, params: &Parameters<E>) -> Self {
+        let bp = &params.0;
+        let num_input = bp.vk.ic.len() as u32;                     // includes the constant ONE (cs.rs:111)
+        let num_aux = bp.l.len() as u32;
+        let m = (params.1 as u64 + num_input as u64).next_power_of_two();
+        let (h, l, a) = (raw_points(&bp.h, 64), raw_points(&bp.l, 64), raw_points(&bp.a, 64));
+        let (b1, b2) = (raw_points(&bp.b_g1, 64), raw_points(&bp.b_g2, 128));
+        let vk1 = raw_points(&[bp.vk.alpha_g1, bp.vk.beta_g1, bp.vk.delta_g1], 64);
+        let vk2 = raw_points(&[bp.vk.beta_g2, bp.vk.delta_g2], 128);
+        let desc = ffi::fk_key_desc {
+            m, num_input, num_aux,
+            alpha_g1: vk1.as_ptr(), beta_g1: vk1[64..].as_ptr(), delta_g1: vk1[128..].as_ptr(),
+            beta_g2: vk2.as_ptr(), delta_g2: vk2[128..].as_ptr(),
+            h: h.as_ptr(), n_h: bp.h.len() as u64, l: l.as_ptr(), n_l: bp.l.len() as u64,
+            a: a.as_ptr(), n_a: bp.a.len() as u64,
+            b_g1: b1.as_ptr(), b_g2: b2.as_ptr(), n_b: bp.b_g1.len() as u64,
+            shard_index: 0, shard_count: 1, z_frac_lo: ffi::FK_Z_EQUAL_SPLIT, z_frac_hi: ffi::FK_Z_EQUAL_SPLIT,
+        };
+        unsafe {
+            let (mut ctx, mut key, mut gates, mut r1cs) = (ptr::null_mut(), ptr::null_mut(), ptr::null_mut(), ptr::null_mut());
+            assert!(ffi::fk_init(device_id, &mut ctx) == ffi::FK_OK, "fk_init: no usable MI355X (there is no CPU fallback)");
+            let rc = ffi::fk_key_load(ctx, &desc, &mut key);
+            assert!(rc == ffi::FK_OK, "fk_key_load: {}", last_error(ctx));
+            let rc = ffi::fk_gates_decode(ctx, params.2.as_ptr(), params.2.len(), ffi::FK_GATES_BROTLI, params.1, num_input, num_aux, &mut gates);
+            assert!(rc == ffi::FK_OK, "fk_gates_decode: {}", last_error(ctx));
+            let rc = ffi::fk_r1cs_load_gates(ctx, gates, &mut r1cs);
+            ffi::fk_gates_free(gates);
+            assert!(rc == ffi::FK_OK, "fk_r1cs_load_gates: {}", last_error(ctx));
+            HipProver { ctx, key, r1cs }
+        }
+    }
+
+    /// `create_proof(circuit, params, r, s)` on the GPU: z = values_input ++ values_aux, r and s as `Num<Fr>`
+    /// (4 x u64 Montgomery limbs, the in-memory image the C ABI reads: ff-uint/src/num/mod.rs:21-23, mod.rs:105-137).
+    fn prove_bytes<Fr: fawkes_crypto::ff_uint::PrimeField>(&self, z: &[Num<Fr>], r: &Num<Fr>, s: &Num<Fr>) -> [u8; ffi::FK_PROOF_BYTES] {
+        let mut out = [0u8; ffi::FK_PROOF_BYTES];
+        let rc = unsafe {
+            ffi::fk_prove_r1cs(self.ctx, self.key, self.r1cs, z.as_ptr() as *const u64, r as *const _ as *const u64,
+                               s as *const _ as *const u64, out.as_mut_ptr(), ptr::null_mut())
+        };
+        // the reference `.unwrap()`s bellman's SynthesisError at prover.rs:80: a non-zero status panics here as well
+        assert!(rc == ffi::FK_OK, "fk_prove_r1cs ({}): {}", rc, last_error(self.ctx));
+        out
+    }
+}
+
+impl Drop for HipProver {
+    fn drop(&mut self) {
+        unsafe { ffi::fk_r1cs_free(self.ctx, self.r1cs); ffi::fk_key_free(self.ctx, self.key); ffi::fk_free(self.ctx); }
+    }
+}
+
+/// Deterministic twin of `prove_hip`: r, s given -- what `bellman::groth16::create_proof(circuit, params, r, s)` takes.
+/// Same signature as prover.rs:63-68 plus the resident prover and (r, s).
+pub fn prove_hip_with_rs<'a, E: Engine, Pub: Signal<WitnessCS<'a, E::Fr>>, Sec: Signal<WitnessCS<'a, E::Fr>>, C: Fn(Pub, Sec)>(
+    params: &'a Parameters<E>,
+    hip: &HipProver,
+    input_pub: &Pub::Value,
+    input_sec: &Sec::Value,
+    circuit: C,
+    r: Num<E::Fr>,
+    s: Num<E::Fr>,
+) -> (Vec<Num<E::Fr>>, Proof<E>) {
+    let ref rcs = params.get_witness_rcs();                                  // prover.rs:69
+    let signal_pub = Pub::alloc(rcs, Some(input_pub));
+    signal_pub.inputize();
+    let signal_sec = Sec::alloc(rcs, Some(input_sec));
+    circuit(signal_pub, signal_sec);                                         // prover.rs:74: fills WitnessCS
+
+    let cs = rcs.borrow();
+    // z = values_input ++ values_aux (variable order of cs.rs:255-268): `Num<Fr>` is #[repr(transparent)] over the limbs
+    let mut z: Vec<Num<E::Fr>> = Vec::with_capacity(cs.num_input() + cs.num_aux());
+    for i in 0..cs.num_input() as u32 { z.push(cs.get_value(Index::Input(i)).unwrap()); }
+    for j in 0..cs.num_aux() as u32 { z.push(cs.get_value(Index::Aux(j)).unwrap()); }
+
+    let bytes = hip.prove_bytes(&z, &r, &s);
+    // the 256 bytes ARE fawkes' Borsh `Proof` (prover.rs:39-60: a, b, c; canonical little-endian coordinates)
+    let proof = Proof::<E>::try_from_slice(&bytes).expect("proof bytes");
+
+    assert!(cs.const_tracker_index == cs.const_tracker.len(), "not all cached data used");    // prover.rs:83
+    let mut inputs = Vec::with_capacity(cs.num_input());
+    for i in 1..cs.num_input() as u32 { inputs.push(cs.get_value(Index::Input(i)).unwrap()); }  // prover.rs:84-87
+    (inputs, proof)
+}
+
+/// `prover::prove` with the GPU behind it: r, s drawn exactly as `create_random_proof` draws them (prover.rs:78-80:
+/// `Fr::rand` over fawkes' OsRng; the accepted limbs are the Montgomery representation).
+pub fn prove_hip<'a, E: Engine, Pub: Signal<WitnessCS<'a, E::Fr>>, Sec: Signal<WitnessCS<'a, E::Fr>>, C: Fn(Pub, Sec)>(
+    params: &'a Parameters<E>,
+    hip: &HipProver,
+    input_pub: &Pub::Value,
+    input_sec: &Sec::Value,
+    circuit: C,
+) -> (Vec<Num<E::Fr>>, Proof<E>) {
+    use bellman::pairing::ff::Field;
+    let ref mut rng = OsRng::new();
+    let r = <<E::BE as bellman::pairing::ff::ScalarEngine>::Fr as Field>::rand(rng);
+    let s = <<E::BE as bellman::pairing::ff::ScalarEngine>::Fr as Field>::rand(rng);
+    prove_hip_with_rs(params, hip, input_pub, input_sec, circuit, bellman_fp_to_num(r), bellman_fp_to_num(s))
+}
