@@ -211,6 +211,25 @@ def tile_witness(zs, num_input, copies, out=None):
     return out
 
 
+def usable_cores():
+    """host cores this process may actually use: the affinity mask, capped by the cgroup CPU quota (a container can show 256
+    CPUs and be allowed the time of two)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            txt = open(path).read().split()
+            if path.endswith('cpu.max'):
+                quota, period = txt[0], int(txt[1])
+            else:
+                quota, period = txt[0], int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if quota not in ('max', '-1'):
+                n = min(n, max(1, int(quota) // period))
+            break
+        except Exception:
+            continue
+    return max(1, n)
+
+
 def oracle_key(dk, vk, m, num_input, num_aux):
     import c_oracle as co
     return co.ArrayKey(m, num_input, num_aux, vk, dk.download('h'), dk.download('l'), dk.download('a'), dk.download('b_g1'),
@@ -224,7 +243,7 @@ def cpu_baseline_leg(ctx, fk, args):
     multiexp region); the GPU proof of that same sample must match byte for byte."""
     import c_oracle as co
     import fixtures as fx
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     tox = {k: mont(v) for k, v in TOXIC.items()}
     r, s = mont(0x1234567), mont(0x89abcdef)
     if args.workload == 'rollup1024':
@@ -258,7 +277,8 @@ def cpu_baseline_leg(ctx, fk, args):
         times[th] = time.time() - t0
         if got.tobytes() != want.tobytes():
             raise AssertionError('bench parity check failed: HIP proof != oracle proof (%d threads) on the CPU-baseline sample' % th)
-    return dict(what=what, scale=scale, cores=cores, synth_s=synth_s, prove_s=times, log2_m=int(cnt['m']).bit_length() - 1)
+    return dict(what=what, scale=scale, cores=cores, synth_s=synth_s, prove_s=times, log2_m=int(cnt['m']).bit_length() - 1,
+                host=dict(cpu_count=os.cpu_count(), affinity=len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else None))
 
 
 def pairing_check(vk_full, z_inputs, proof):
@@ -592,7 +612,7 @@ def main():
                           'multiexp region; synthesis serial as in the reference) on %s (domain 2^%d): synthesis %.2f s + proof %.2f s; scaled linearly '
                           'by %g to the benchmarked size (optimistic for the CPU: the NTT is n log n); the GPU proof of the same sample matched byte for '
                           'byte' % (cores, cb['what'], cb['log2_m'], cb['synth_s'], cb['prove_s'][cores], cb['scale']),
-                'sample_seconds': cb['synth_s'] + cb['prove_s'][cores],
+                'sample_seconds': cb['synth_s'] + cb['prove_s'][cores], 'host': cb['host'],
                 'single_thread': {'value': 1.0 / full(1), 'unit': 'proofs/s', 'cores': 1,
                                   'sample_seconds': cb['synth_s'] + cb['prove_s'][1],
                                   'note': 'the worker fawkes-crypto configures (SURVEY fact 3): same sample, one thread'},

@@ -34,7 +34,7 @@ EXPORTED_SYMBOLS = [
     'fk_fr_mul_batch', 'fk_ntt', 'fk_ntt_dev', 'fk_quotient_h', 'fk_quotient_h_dev',
     'fk_msm_g1', 'fk_msm_g2', 'fk_msm_g1_dev', 'fk_msm_g2_dev',
     'fk_gen_points_g1_dev', 'fk_gen_points_g2_dev', 'fk_gen_scalars_dev',
-    'fk_synthesize', 'fk_stats_reset', 'fk_stats_get', 'fk_calibrate', 'fk_shard_range', 'fk_h_shard_range',
+    'fk_synthesize', 'fk_stats_reset', 'fk_stats_get', 'fk_calibrate', 'fk_verify', 'fk_verify_batch_dev', 'fk_shard_range', 'fk_h_shard_range',
     'fk_dq_gather_dev', 'fk_dq_local_dev', 'fk_dq_cross_dev',
     'fk_setup', 'fk_setup_tiled', 'fk_r1cs_load_tiled', 'fk_key_download', 'fk_key_load_bellman', 'fk_key_vk', 'fk_key_counts', 'fk_key_precomputed',
     'fk_gates_decode', 'fk_gates_free', 'fk_gates_info', 'fk_gates_export', 'fk_r1cs_load_gates',
@@ -848,6 +848,49 @@ def h_shard_range(n_h, index, count):
     lo, hi = C.c_uint64(), C.c_uint64()
     lib.fk_h_shard_range(C.c_uint64(n_h), C.c_uint32(index), C.c_uint32(count), C.byref(lo), C.byref(hi))
     return lo.value, hi.value
+
+
+# ------------------------------------------------------------------------------------------ verifier
+_FQ_RINV = pow(1 << 256, -1, FQ_MODULUS)
+
+
+def vk_to_borsh(vk):
+    """fawkes' Borsh `VK` (verifier.rs:46-54) from raw Montgomery-LE points (what fk_setup / fk_key_load_bellman hand out):
+    vk = dict(alpha_g1 (64 B), beta_g2, gamma_g2, delta_g2 (128 B), ic (n, 64)).  Coordinates become canonical LE integers."""
+    def canon(raw):
+        raw = bytes(raw)
+        return b''.join((int.from_bytes(raw[i:i + 32], 'little') * _FQ_RINV % FQ_MODULUS).to_bytes(32, 'little') for i in range(0, len(raw), 32))
+    ic = np.ascontiguousarray(vk['ic'], np.uint8).reshape(-1, 64)
+    return (canon(vk['alpha_g1']) + canon(vk['beta_g2']) + canon(vk['gamma_g2']) + canon(vk['delta_g2']) +
+            len(ic).to_bytes(4, 'little') + b''.join(canon(r) for r in ic))
+
+
+def verify(vk_borsh, inputs, proof, ctx=None):
+    """`verifier::verify(vk, proof, inputs)` (verifier.rs:75-81) on the host (fk_verify; no GPU needed).  inputs: Montgomery Fr
+    (n, 4) uint64 without the leading ONE; proof: 256 bytes or a Proof.  Returns True / False."""
+    lib = load_library()
+    vkb = np.frombuffer(bytes(vk_borsh), np.uint8)
+    pr = np.frombuffer(proof.to_bytes() if isinstance(proof, Proof) else bytes(proof), np.uint8)
+    assert pr.size == FK_PROOF_BYTES
+    inp = np.ascontiguousarray(inputs, np.uint64).reshape(-1, 4)
+    ok = C.c_int(0)
+    rc = lib.fk_verify(ctx.handle if ctx else None, _vp(vkb), C.c_size_t(vkb.size), _vp(inp), C.c_uint32(inp.shape[0]), _vp(pr), C.byref(ok))
+    if rc != 0:
+        msg = lib.fk_last_error(ctx.handle) if ctx else b''
+        raise FkError(rc, msg.decode() if msg else 'fk_verify')
+    return bool(ok.value)
+
+
+def verify_batch(ctx, vk_borsh, inputs, proofs):
+    """fk_verify_batch_dev: `count` proofs of one key on the GPU, one lane per proof.  inputs (count, n_inputs, 4) uint64,
+    proofs (count, 256) uint8.  Returns a bool array."""
+    vkb = np.frombuffer(bytes(vk_borsh), np.uint8)
+    pr = np.ascontiguousarray(proofs, np.uint8).reshape(-1, FK_PROOF_BYTES)
+    inp = np.ascontiguousarray(inputs, np.uint64).reshape(pr.shape[0], -1, 4)
+    out = np.zeros(pr.shape[0], np.uint8)
+    ctx._ck(ctx.lib.fk_verify_batch_dev(ctx.handle, _vp(vkb), C.c_size_t(vkb.size), _vp(inp), C.c_uint32(inp.shape[1]), _vp(pr),
+                                        C.c_uint32(pr.shape[0]), _vp(out)))
+    return out.astype(bool)
 
 
 # ------------------------------------------------------------------------------------------ r, s sampling

@@ -37,7 +37,10 @@ struct EventPair { hipEvent_t a, b; uint64_t units; };
 // multiplication k run underneath the VALU-bound bucket accumulation of the other lane (msm.hip).
 struct MsmLane {
     hipStream_t st = nullptr;
+    hipStream_t st_sort = nullptr;  // FK_MSM_CU_SPLIT: digits / sort / size ordering on a CU subset of their own (else == st)
     hipEvent_t ev_in = nullptr;     // main stream -> lane: the scalars are ready
+    hipEvent_t ev_sorted = nullptr, ev_lane_done = nullptr;   // sort stream -> lane stream; lane stream -> next sort on this lane
+    bool ev_lane_done_valid = false;
     DevBuf digits, sorted, totals, starts, perm, overlist, tasktab, partials, s2_cnt1, s2_seg, s2_cnt2, s2_tmp_idx, s2_tmp_lo, buckets;
     void *h_stage = nullptr;        // pinned host staging: counters read back, oversized-bucket list, task tables
     size_t h_cap = 0;
@@ -92,7 +95,7 @@ struct fk_ctx {
     fk::DevBuf misc;
     // witness multiplications (L, A, B1, B2) in flight: begun before / while the quotient runs on the main stream
     hipStream_t aux = nullptr;          // scalar compaction for the A / B queries
-    hipEvent_t ev_aux = nullptr, ev_main = nullptr;
+    hipEvent_t ev_aux = nullptr, ev_main = nullptr, ev_z = nullptr;
     hipEvent_t ev_acc_done = nullptr; bool ev_acc_done_valid = false;   // behind the most recent bucket accumulation (any lane)
     bool wit_active = false;
     const fk::QueryIdx *qidx = nullptr;   // set by the resident-constraint-system entry points for the duration of a call

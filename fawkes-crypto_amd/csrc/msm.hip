@@ -725,9 +725,31 @@ __global__ __launch_bounds__(256) void msm_bucket_reduce_kernel(const Xyzz<F> *b
         }                                                                                         \
     } while (0)
 
+// FK_MSM_CU_SPLIT=k (1..4, experiment): of every 8 compute units k run only the memory-bound front of a multiplication
+// (digits, sort, size ordering: a stream with that CU mask), the other 8 - k only its accumulation and tail.  Without it a sort
+// workgroup (1024 lanes, > 100 KB of LDS) and the accumulation's workgroups evict each other from whole CUs.
+static int cu_split() {
+    static int k = -1;
+    if (k < 0) { const char *e = getenv("FK_MSM_CU_SPLIT"); k = e ? atoi(e) : 0; if (k < 0 || k > 4) k = 0; }
+    return k;
+}
 static int lane_init(fk_ctx *ctx, MsmLane &ln) {
     if (ln.st) return FK_OK;
-    FK_HIP(ctx, hipStreamCreateWithFlags(&ln.st, hipStreamNonBlocking));
+    const int k = cu_split();
+    if (k) {
+        int ncu = 0;
+        FK_HIP(ctx, hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device));
+        const uint32_t words = (uint32_t)((ncu + 31) / 32);
+        std::vector<uint32_t> m_sort(words, 0), m_acc(words, 0);
+        for (int i = 0; i < ncu; i++) { if ((i & 7) < k) m_sort[i >> 5] |= 1u << (i & 31); else m_acc[i >> 5] |= 1u << (i & 31); }
+        FK_HIP(ctx, hipExtStreamCreateWithCUMask(&ln.st, words, m_acc.data()));
+        FK_HIP(ctx, hipExtStreamCreateWithCUMask(&ln.st_sort, words, m_sort.data()));
+        FK_HIP(ctx, hipEventCreateWithFlags(&ln.ev_sorted, hipEventDisableTiming));
+        FK_HIP(ctx, hipEventCreateWithFlags(&ln.ev_lane_done, hipEventDisableTiming));
+    } else {
+        FK_HIP(ctx, hipStreamCreateWithFlags(&ln.st, hipStreamNonBlocking));
+        ln.st_sort = ln.st;
+    }
     FK_HIP(ctx, hipEventCreateWithFlags(&ln.ev_in, hipEventDisableTiming));
     return FK_OK;
 }
@@ -776,15 +798,21 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
     const int n_lanes = (t_lanes >= 1 && t_lanes <= MSM_LANES) ? t_lanes : (ctx->lanes_in_use >= 2 && ctx->lanes_in_use <= MSM_LANES ? ctx->lanes_in_use : MSM_LANES);
     ctx->lane_prev = li; ctx->lane_next = (li + 1) % n_lanes;
     hipStream_t st = ln.st;
+    const bool split = ln.st_sort != ln.st;
+    hipStream_t ss = ln.st_sort;              // the front of the multiplication (== st unless FK_MSM_CU_SPLIT)
     // FK_MSM_SORT_ALONE=1: this multiplication's digits / sort do not start before the previous multiplication's accumulation
     // has finished (they then run at full memory speed instead of crawling underneath it); its latency-bound tail still overlaps
-    if (t_serial_sort == 1 && !have_sort && ctx->ev_acc_done_valid) FK_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_acc_done, 0));
+    if (t_serial_sort == 1 && !have_sort && ctx->ev_acc_done_valid) FK_HIP(ctx, hipStreamWaitEvent(ss, ctx->ev_acc_done, 0));
     if (ready) {
-        FK_HIP(ctx, hipStreamWaitEvent(st, ready, 0));
+        FK_HIP(ctx, hipStreamWaitEvent(ss, ready, 0));
+        if (split) FK_HIP(ctx, hipStreamWaitEvent(st, ready, 0));
     } else {
         FK_HIP(ctx, hipEventRecord(ln.ev_in, ctx->stream));        // scalars / bases produced on the main stream
-        FK_HIP(ctx, hipStreamWaitEvent(st, ln.ev_in, 0));
+        FK_HIP(ctx, hipStreamWaitEvent(ss, ln.ev_in, 0));
+        if (split) FK_HIP(ctx, hipStreamWaitEvent(st, ln.ev_in, 0));
     }
+    // the lane's sort buffers are read by its previous multiplication's accumulation / overflow kernels
+    if (split && !have_sort && ln.ev_lane_done_valid) FK_HIP(ctx, hipStreamWaitEvent(ss, ln.ev_lane_done, 0));
     const size_t WB = (size_t)p.W * p.B;
     const uint32_t WR = merged ? 1 : p.W;      // bucket sets to reduce
     const size_t wp_bytes = (size_t)WR * p.nblk * sizeof(Xyzz<F>);
@@ -804,6 +832,7 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
     for (const Need &nd : needs) grow = grow || nd.bytes > nd.b->cap;
     if (grow) {
         FK_HIP(ctx, hipStreamSynchronize(st));
+        if (split) FK_HIP(ctx, hipStreamSynchronize(ss));
         for (const Need &nd : needs) FK_HIP(ctx, nd.b->reserve(nd.bytes));
         if (!have_sort) ln.last_sort_scalars = nullptr;
     }
@@ -823,34 +852,34 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
 
     if (!have_sort) {
         ln.last_sort_scalars = nullptr;
-        hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)(((n + 1) / 2 + 63) / 64)), dim3(64), 0, st, d_scalars, n, p.cb, p.wide, p.W, digits);
+        hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)(((n + 1) / 2 + 63) / 64)), dim3(64), 0, ss, d_scalars, n, p.cb, p.wide, p.W, digits);
         FK_HIP(ctx, hipGetLastError());
-        FK_DBG_ST(ctx, st, "msm_digits");
-        FK_HIP(ctx, hipMemsetAsync(d_nover, 0, 4, st));
+        FK_DBG_ST(ctx, ss, "msm_digits");
+        FK_HIP(ctx, hipMemsetAsync(d_nover, 0, 4, ss));
         uint32_t *cnt1 = ln.s2_cnt1.as<uint32_t>();
         uint32_t *seg_size = ln.s2_seg.as<uint32_t>(), *seg_start = seg_size + nseg, *seg_tiles = seg_start + nseg, *tile_start = seg_tiles + nseg;
         uint32_t *cnt2 = ln.s2_cnt2.as<uint32_t>(), *tmp_idx = ln.s2_tmp_idx.as<uint32_t>();
         uint16_t *tmp_lo = ln.s2_tmp_lo.as<uint16_t>();
-        hipLaunchKernelGGL(s2_hist1_kernel, dim3(p.nchunks, p.W), dim3(SORT_THREADS), p.nhi * 4, st, digits, n, p.chunk, p.nchunks, p.LB, p.nhi, cnt1);
-        hipLaunchKernelGGL(s2_prefix1_kernel, dim3(p.W), dim3(1024), p.nhi * 4, st, cnt1, p.nchunks, p.nhi, seg_size, seg_start, seg_tiles);
-        hipLaunchKernelGGL(s2_tile_prefix_kernel, dim3(1), dim3(1024), 0, st, seg_tiles, nseg, tile_start);
-        hipLaunchKernelGGL(s2_scatter1_kernel, dim3(p.nchunks, p.W), dim3(1024), 0, st, digits, n, p.chunk, p.nchunks, p.LB, p.nhi, cnt1,
+        hipLaunchKernelGGL(s2_hist1_kernel, dim3(p.nchunks, p.W), dim3(SORT_THREADS), p.nhi * 4, ss, digits, n, p.chunk, p.nchunks, p.LB, p.nhi, cnt1);
+        hipLaunchKernelGGL(s2_prefix1_kernel, dim3(p.W), dim3(1024), p.nhi * 4, ss, cnt1, p.nchunks, p.nhi, seg_size, seg_start, seg_tiles);
+        hipLaunchKernelGGL(s2_tile_prefix_kernel, dim3(1), dim3(1024), 0, ss, seg_tiles, nseg, tile_start);
+        hipLaunchKernelGGL(s2_scatter1_kernel, dim3(p.nchunks, p.W), dim3(1024), 0, ss, digits, n, p.chunk, p.nchunks, p.LB, p.nhi, cnt1,
                            seg_start, tmp_idx, tmp_lo);
         FK_HIP(ctx, hipGetLastError());
-        FK_DBG_ST(ctx, st, "msm_sort_pass1");
+        FK_DBG_ST(ctx, ss, "msm_sort_pass1");
         // The second pass is launched over the host's BOUND on the tile count (every segment's last tile may be partial:
         // W * ceil(n / tile) + #segments); workgroups beyond the actual count leave at once.  Reading the count back cost a
         // host round trip in the middle of every sort.
         const uint32_t n_tiles = (uint32_t)max_tiles;
         {
-            hipLaunchKernelGGL(s2_hist2_kernel, dim3(n_tiles), dim3(256), p.nlo * 4, st, tmp_lo, n, p.nhi, p.nlo, tile_start, nseg, seg_start, seg_size, cnt2);
+            hipLaunchKernelGGL(s2_hist2_kernel, dim3(n_tiles), dim3(256), p.nlo * 4, ss, tmp_lo, n, p.nhi, p.nlo, tile_start, nseg, seg_start, seg_size, cnt2);
         }
-        hipLaunchKernelGGL(s2_prefix2_kernel, dim3(nseg), dim3(1024), 0, st, cnt2, p.nhi, p.nlo, p.B, tile_start, seg_start, p.cap, p.cap_top, p.W, totals, starts,
+        hipLaunchKernelGGL(s2_prefix2_kernel, dim3(nseg), dim3(1024), 0, ss, cnt2, p.nhi, p.nlo, p.B, tile_start, seg_start, p.cap, p.cap_top, p.W, totals, starts,
                            ln.overlist.as<OverEntry>(), d_nover, over_cap);
-        hipLaunchKernelGGL(s2_scatter2_kernel, dim3(n_tiles), dim3(1024), 0, st, tmp_idx, tmp_lo, n, p.nhi, p.nlo, p.B, tile_start, nseg, seg_start,
+        hipLaunchKernelGGL(s2_scatter2_kernel, dim3(n_tiles), dim3(1024), 0, ss, tmp_idx, tmp_lo, n, p.nhi, p.nlo, p.B, tile_start, nseg, seg_start,
                            seg_size, cnt2, starts, sorted);
         FK_HIP(ctx, hipGetLastError());
-        FK_DBG_ST(ctx, st, "msm_sort_pass2");
+        FK_DBG_ST(ctx, ss, "msm_sort_pass2");
         ln.last_sort_scalars = (const void *)d_scalars; ln.last_sort_n = n; ln.last_sort_c = p.c; ln.last_merged = merged;
     }
     // oversized buckets (skewed scalars): known once the sort is done -- the host builds the segment table now, so that
@@ -860,8 +889,8 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
     if (!have_sort) {
         uint32_t *h_nover = (uint32_t *)ln.h_stage + 4;
         OverEntry *h_over = (OverEntry *)((char *)ln.h_stage + 64);
-        FK_HIP(ctx, hipMemcpyAsync(h_nover, d_nover, 4, hipMemcpyDeviceToHost, st));
-        FK_HIP(ctx, hipStreamSynchronize(st));
+        FK_HIP(ctx, hipMemcpyAsync(h_nover, d_nover, 4, hipMemcpyDeviceToHost, ss));
+        FK_HIP(ctx, hipStreamSynchronize(ss));
         n_over = *h_nover;
         cap = p.cap;
         // The cap assumes Poisson bucket loads.  Scalars with many repeated values (a batch witness) put tens of thousands of
@@ -873,36 +902,36 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
         const uint32_t many = (uint32_t)std::max<size_t>((size_t)t_many, WB / 8192);
         while (n_over > many && cap < (1u << 20)) {
             cap *= 2;
-            FK_HIP(ctx, hipMemsetAsync(d_nover, 0, 4, st));
-            hipLaunchKernelGGL(msm_over_scan_kernel, dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, totals, WB, cap, ln.overlist.as<OverEntry>(), d_nover, over_cap);
+            FK_HIP(ctx, hipMemsetAsync(d_nover, 0, 4, ss));
+            hipLaunchKernelGGL(msm_over_scan_kernel, dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, ss, totals, WB, cap, ln.overlist.as<OverEntry>(), d_nover, over_cap);
             FK_HIP(ctx, hipGetLastError());
-            FK_HIP(ctx, hipMemcpyAsync(h_nover, d_nover, 4, hipMemcpyDeviceToHost, st));
-            FK_HIP(ctx, hipStreamSynchronize(st));
+            FK_HIP(ctx, hipMemcpyAsync(h_nover, d_nover, 4, hipMemcpyDeviceToHost, ss));
+            FK_HIP(ctx, hipStreamSynchronize(ss));
             n_over = *h_nover;
         }
         // size-ordered bucket -> lane assignment
-        FK_HIP(ctx, hipMemsetAsync(size_bins, 0, SIZE_BINS * 4, st));
-        FK_HIP(ctx, hipMemsetAsync(d_adds, 0, 8, st));
+        FK_HIP(ctx, hipMemsetAsync(size_bins, 0, SIZE_BINS * 4, ss));
+        FK_HIP(ctx, hipMemsetAsync(d_adds, 0, 8, ss));
         if (merged) {     // one bucket set: order its B buckets by their length over all windows (perm[0, B); lengths kept behind it)
             uint32_t *mt = perm + p.B;
             const uint32_t mcap = (uint32_t)std::min<uint64_t>((uint64_t)cap * p.W, 1u << 30);
-            hipLaunchKernelGGL(msm_merge_totals_kernel, dim3((p.B + 255) / 256), dim3(256), 0, st, totals, p.B, p.W, cap, mt, d_adds);
-            hipLaunchKernelGGL(msm_size_hist_kernel, dim3((unsigned)std::min<size_t>((p.B + 255) / 256, 1024)), dim3(256), 0, st, mt, (size_t)p.B, mcap, size_bins, (unsigned long long *)nullptr);
-            hipLaunchKernelGGL(msm_size_scan_kernel, dim3(1), dim3(SIZE_BINS), 0, st, size_bins);
-            hipLaunchKernelGGL(msm_size_scatter_kernel, dim3((unsigned)((p.B + 1023) / 1024)), dim3(1024), 0, st, mt, (size_t)p.B, mcap, size_bins, perm);
+            hipLaunchKernelGGL(msm_merge_totals_kernel, dim3((p.B + 255) / 256), dim3(256), 0, ss, totals, p.B, p.W, cap, mt, d_adds);
+            hipLaunchKernelGGL(msm_size_hist_kernel, dim3((unsigned)std::min<size_t>((p.B + 255) / 256, 1024)), dim3(256), 0, ss, mt, (size_t)p.B, mcap, size_bins, (unsigned long long *)nullptr);
+            hipLaunchKernelGGL(msm_size_scan_kernel, dim3(1), dim3(SIZE_BINS), 0, ss, size_bins);
+            hipLaunchKernelGGL(msm_size_scatter_kernel, dim3((unsigned)((p.B + 1023) / 1024)), dim3(1024), 0, ss, mt, (size_t)p.B, mcap, size_bins, perm);
         } else {
-        hipLaunchKernelGGL(msm_size_hist_kernel, dim3((unsigned)std::min<size_t>((WB + 255) / 256, 1024)), dim3(256), 0, st, totals, WB, cap, size_bins, d_adds);
-        hipLaunchKernelGGL(msm_size_scan_kernel, dim3(1), dim3(SIZE_BINS), 0, st, size_bins);
-        hipLaunchKernelGGL(msm_size_scatter_kernel, dim3((unsigned)((WB + 1023) / 1024)), dim3(1024), 0, st, totals, WB, cap, size_bins, perm);
+        hipLaunchKernelGGL(msm_size_hist_kernel, dim3((unsigned)std::min<size_t>((WB + 255) / 256, 1024)), dim3(256), 0, ss, totals, WB, cap, size_bins, d_adds);
+        hipLaunchKernelGGL(msm_size_scan_kernel, dim3(1), dim3(SIZE_BINS), 0, ss, size_bins);
+        hipLaunchKernelGGL(msm_size_scatter_kernel, dim3((unsigned)((WB + 1023) / 1024)), dim3(1024), 0, ss, totals, WB, cap, size_bins, perm);
         }
         FK_HIP(ctx, hipGetLastError());
-        FK_DBG_ST(ctx, st, "msm_size_order");
+        FK_DBG_ST(ctx, ss, "msm_size_order");
         if (ctx->debug) { fprintf(stderr, "[fk] msm n=%zu c=%u (W=%u: %u x %u bits + %u x %u bits) cap=%u (plan %u): %u oversized buckets\n", n, p.c, p.W, p.wide, p.cb + 1, p.W - p.wide, p.cb, cap, p.cap, n_over); fflush(stderr); }
         if (n_over > over_cap) { ln.last_sort_scalars = nullptr; FK_SET_ERR(ctx, FK_ERR_HIP, "msm: %u oversized buckets exceed the bound %u", n_over, over_cap); }
         n_tasks = n_obs = tb_al = 0; SEG = SEG_MIN;
         if (n_over) {
-            FK_HIP(ctx, hipMemcpyAsync(h_over, ln.overlist.p, n_over * sizeof(OverEntry), hipMemcpyDeviceToHost, st));
-            FK_HIP(ctx, hipStreamSynchronize(st));
+            FK_HIP(ctx, hipMemcpyAsync(h_over, ln.overlist.p, n_over * sizeof(OverEntry), hipMemcpyDeviceToHost, ss));
+            FK_HIP(ctx, hipStreamSynchronize(ss));
             std::vector<OverEntry> ov(h_over, h_over + n_over);
             const uint32_t Bm = p.B;
             if (merged) std::sort(ov.begin(), ov.end(), [Bm](const OverEntry &a, const OverEntry &b) { return a.g % Bm != b.g % Bm ? a.g % Bm < b.g % Bm : a.g < b.g; });
@@ -931,18 +960,19 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
             FK_TRY(lane_stage(ctx, ln, 64 + tb_al + ob));
             memcpy((char *)ln.h_stage + 64, tasks.data(), tb);
             memcpy((char *)ln.h_stage + 64 + tb_al, obs.data(), ob);
-            FK_HIP(ctx, hipMemcpyAsync(ln.tasktab.p, (char *)ln.h_stage + 64, tb_al + ob, hipMemcpyHostToDevice, st));
+            FK_HIP(ctx, hipMemcpyAsync(ln.tasktab.p, (char *)ln.h_stage + 64, tb_al + ob, hipMemcpyHostToDevice, ss));
         }
         ln.last_n_over = n_over; ln.last_seg = SEG; ln.last_cap = cap; ln.last_n_tasks = n_tasks; ln.last_n_obs = n_obs; ln.last_tb_al = tb_al;
     }
     Task *d_tasks = ln.tasktab.as<Task>();
     OverBucket *d_obs = (OverBucket *)((char *)ln.tasktab.p + tb_al);
     if (n_tasks * sizeof(Xyzz<F>) > ln.partials.cap) {      // growing frees the old array: the lane must be idle
-        FK_HIP(ctx, hipStreamSynchronize(st));
+        FK_HIP(ctx, hipStreamSynchronize(ss));
         FK_HIP(ctx, ln.partials.reserve(n_tasks * sizeof(Xyzz<F>)));
     }
 
     // ---- from here on nothing waits for the host
+    if (split) { FK_HIP(ctx, hipEventRecord(ln.ev_sorted, ss)); FK_HIP(ctx, hipStreamWaitEvent(st, ln.ev_sorted, 0)); }
     std::vector<EventPair> &evv = (sizeof(F) == sizeof(Fq)) ? ctx->ev_acc : ctx->ev_acc2;
     FK_TRY(stats_begin(ctx, evv, (uint64_t)n, st));
     // FK_MSM_LIMB29=1: G1 accumulator on 9 x 29-bit limbs (field29.hpp).  Measured and NOT the default: the product alone is
@@ -989,6 +1019,7 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
     FK_HIP(ctx, hipMemcpyAsync(tl.h_wp, winparts, wp_bytes, hipMemcpyDeviceToHost, st));
     FK_HIP(ctx, hipMemcpyAsync((char *)tl.h_wp + wp_bytes, d_adds, 8, hipMemcpyDeviceToHost, st));
     FK_HIP(ctx, hipEventRecord(tl.done, st));
+    if (split) { FK_HIP(ctx, hipEventRecord(ln.ev_lane_done, st)); ln.ev_lane_done_valid = true; }
     FK_DBG_ST(ctx, st, "msm_bucket_reduce");
     tl.active = true; tl.cb = p.cb; tl.wide = p.wide; tl.W = WR; tl.nblk = p.nblk;     // merged: one "window" of weight 1
     *tail_out = ti;
@@ -1019,7 +1050,7 @@ static int msm_end(fk_ctx *ctx, int tail, Xyzz<F> *out) {
 
 int msm_sync(fk_ctx *ctx) {
     if (ctx->aux) FK_HIP(ctx, hipStreamSynchronize(ctx->aux));
-    for (MsmLane &ln : ctx->lanes) if (ln.st) FK_HIP(ctx, hipStreamSynchronize(ln.st));
+    for (MsmLane &ln : ctx->lanes) if (ln.st) { FK_HIP(ctx, hipStreamSynchronize(ln.st)); if (ln.st_sort != ln.st) FK_HIP(ctx, hipStreamSynchronize(ln.st_sort)); }
     return FK_OK;
 }
 
@@ -1027,13 +1058,14 @@ void msm_abandon(fk_ctx *ctx) {
     ctx->wit_active = false;
     if (ctx->aux) (void)hipStreamSynchronize(ctx->aux);
     for (int i = 0; i < MSM_TAILS; i++) ctx->tails[i].active = false;
-    for (MsmLane &ln : ctx->lanes) { if (ln.st) (void)hipStreamSynchronize(ln.st); ln.last_sort_scalars = nullptr; }
+    for (MsmLane &ln : ctx->lanes) { if (ln.st) { (void)hipStreamSynchronize(ln.st); if (ln.st_sort != ln.st) (void)hipStreamSynchronize(ln.st_sort); } ln.last_sort_scalars = nullptr; }
 }
 
 void msm_release(fk_ctx *ctx) {
     if (ctx->aux) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamDestroy(ctx->aux); ctx->aux = nullptr; }
     if (ctx->ev_aux) { (void)hipEventDestroy(ctx->ev_aux); ctx->ev_aux = nullptr; }
     if (ctx->ev_main) { (void)hipEventDestroy(ctx->ev_main); ctx->ev_main = nullptr; }
+    if (ctx->ev_z) { (void)hipEventDestroy(ctx->ev_z); ctx->ev_z = nullptr; }
     if (ctx->ev_acc_done) { (void)hipEventDestroy(ctx->ev_acc_done); ctx->ev_acc_done = nullptr; ctx->ev_acc_done_valid = false; }
     for (MsmLane &ln : ctx->lanes) {
         if (ln.st) (void)hipStreamSynchronize(ln.st);
@@ -1042,6 +1074,9 @@ void msm_release(fk_ctx *ctx) {
             b->release();
         if (ln.h_stage) (void)hipHostFree(ln.h_stage);
         if (ln.ev_in) (void)hipEventDestroy(ln.ev_in);
+        if (ln.ev_sorted) (void)hipEventDestroy(ln.ev_sorted);
+        if (ln.ev_lane_done) (void)hipEventDestroy(ln.ev_lane_done);
+        if (ln.st_sort && ln.st_sort != ln.st) { (void)hipStreamSynchronize(ln.st_sort); (void)hipStreamDestroy(ln.st_sort); }
         if (ln.st) (void)hipStreamDestroy(ln.st);
         ln = MsmLane();
     }

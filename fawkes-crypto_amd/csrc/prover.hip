@@ -55,6 +55,7 @@ static double now_ms() {
 }  // namespace fk
 
 static_assert(sizeof(G1Affine) == 64 && sizeof(G2Affine) == 128 && sizeof(Fr) == 32, "raw layouts");
+static constexpr int FK_WITNESS_FIRST_MIN_LOG2 = 24;
 
 extern "C" {
 
@@ -414,8 +415,30 @@ static int prove_msms_dev(fk_ctx *ctx, const fk_key *key, Fr *d_a, Fr *d_b, Fr *
     uint64_t m = 0;
     ctx->lane_next = 0;     // same lane for the same multiplication in every proof: lane buffers keep their sizes
     ctx->lanes_in_use = MSM_LANES;
+    // The witness multiplications depend on z only: on large domains they are begun right behind the QUEUED quotient, so that their
+    // sorts (and what fits of their accumulations) fill the transforms' gaps: 214.5 -> 206.9 ms per proof on the 1024-transaction
+    // system (profiles/r02_cusplit_witness_first_probe.log).  Small domains keep the quotient first (measured in round 1:
+    // 10 % slower at 2^20 / 2^22 the other way).  FK_PROVE_WITNESS_FIRST=1 / 0 forces either.
+    static int t_wfirst = -1;
+    if (t_wfirst < 0) { const char *e = getenv("FK_PROVE_WITNESS_FIRST"); t_wfirst = e ? atoi(e) : -2; }
+    const bool wfirst = t_wfirst == 1 || (t_wfirst == -2 && key->m >= ((uint64_t)1 << FK_WITNESS_FIRST_MIN_LOG2));
+    if (!ctx->ev_main) FK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_main, hipEventDisableTiming));
+    if (!ctx->ev_z) FK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_z, hipEventDisableTiming));
+    FK_HIP(ctx, hipEventRecord(ctx->ev_z, ctx->stream));           // z (and a, b, c) are complete here
     FK_TRY(quotient_dev(ctx, d_a, d_b, d_c, n, d_h, &m));          // queued on the main stream, not waited for
     const double t1 = now_ms();
+    if (wfirst) {
+        FK_HIP(ctx, hipEventRecord(ctx->ev_main, ctx->stream));
+        const int rcw = witness_begin(ctx, key, d_z, d_a_aux, d_b_in, d_b_aux, ctx->ev_z);
+        if (rcw != FK_OK) { msm_abandon(ctx); return rcw; }
+        int t_h0 = -1;
+        const int rch = msm_g1_begin(ctx, key->d_h, d_h + key->h_lo, key->h_hi - key->h_lo, &t_h0, ctx->ev_main, &key->pre_h);
+        if (rch != FK_OK) { msm_abandon(ctx); return rch; }
+        const double t2w = now_ms();
+        FK_TRY(witness_end(ctx, out, t_h0));
+        if (tm) { tm->ntt_ms = t1 - t0; tm->msm_l_ms = t2w - t1; tm->msm_h_ms = now_ms() - t2w; tm->total_ms = now_ms() - t0; }
+        return FK_OK;
+    }
     // Single GPU: the multiplications start after the quotient.  Running the witness multiplications underneath it was
     // measured (2^20 .. 2^25): both sides are VALU-bound, nothing is gained at 2^25 and 10 % is lost at 2^20 / 2^22.  So was
     // running only their SORTS underneath it, accumulations held back until it is done: 2^25 139.5 -> 148.1 ms, 2^22 29.2 -> 34.0

@@ -354,6 +354,18 @@ int fk_key_vk(const fk_key *key, uint8_t out[3 * 64 + 2 * 128]);
 /* out[8] = m, num_input, num_aux, n_h, n_l, n_a, n_b, shard_count */
 int fk_key_counts(const fk_key *key, uint64_t out[8]);
 
+/* ---------------------------------------------------------------- verifier
+ * `verifier::verify(vk, proof, inputs)` (verifier.rs:75-81 -> bellman's verify_proof).  vk: fawkes' Borsh `VK`
+ * (verifier.rs:46-54: alpha G1 | beta, gamma, delta G2 | u32 LE count | ic G1 points; canonical little-endian coordinates);
+ * proof: the 256-byte Borsh `Proof`; inputs: n_inputs Montgomery Fr, the public inputs without the leading ONE.
+ * *accept = 1 / 0.  n_inputs + 1 != #ic is FK_ERR_KEY_MISMATCH (bellman: MalformedVerifyingKey), a non-canonical
+ * coordinate FK_ERR_FORMAT.  fk_verify runs on the host (ctx may be NULL, ~25 ms); fk_verify_batch_dev checks `count`
+ * proofs of the same key on the GPU, one lane per proof (inputs: count x n_inputs, proofs: count x 256 B, host memory). */
+int fk_verify(fk_ctx *ctx, const uint8_t *vk, size_t vk_len, const uint64_t *inputs, uint32_t n_inputs,
+              const uint8_t proof[FK_PROOF_BYTES], int *accept);
+int fk_verify_batch_dev(fk_ctx *ctx, const uint8_t *vk, size_t vk_len, const uint64_t *inputs, uint32_t n_inputs,
+                        const uint8_t *proofs, uint32_t count, uint8_t *accept);
+
 /* Kernel timing measured with HIP events on the library's stream since the last reset, summed over
  * launches.  which: 0 = msm_accumulate_kernel<Fq> (G1 bucket accumulation; units = points per launch),
  * 1 = msm_accumulate_kernel<Fq2> (G2), 2 = ntt_pass_kernel (units = elements per pass); 3 / 4 = the same kernels as 0 / 1

@@ -261,8 +261,8 @@ def test_rollup_tx_fixture_matches_golden(oracle):
     assert np.array_equal(zs[0], fx.witness_mont(cs.z_in, cs.z_aux))
     csr = oracle.R1csC(r1cs.num_input, r1cs.num_aux, *[oracle.Csr(p, c, v) for p, c, v in r1cs.mats])
     roots = set()
-    for z in zs:
+    for z in zs:                    # the fixture's 3 witnesses, or the 32 of tests/golden/_generated (made by __graft_entry__.build())
         a, b, c, *_ = oracle.synthesize(csr, z)
         assert np.array_equal(oracle.fe_mul_batch(1, a, b), c)
         roots.add(z[1:3].tobytes())
-    assert len(roots) == 3          # three different transactions
+    assert len(roots) == len(zs) >= 3          # all different transactions

@@ -29,7 +29,7 @@ def _check_line(j):
     rv = j['roofline_valu']
     assert rv['mixed_additions'] > 0 and 0 < rv['frac'] < 1 and rv['peak'] > rv['multiplier_alone'] > 0
     cb = j['cpu_baseline']
-    assert cb['kind'] == 'port' and cb['cores'] == (os.cpu_count() or 1) and cb['value'] > 0
+    assert cb['kind'] == 'port' and 1 <= cb['cores'] <= (os.cpu_count() or 1) and cb['value'] > 0
     assert cb['single_thread']['cores'] == 1 and cb['single_thread']['value'] > 0
     assert j['device_resident_ms_per_step'] > 0
     assert j['config']['workload'] and 'model' not in j['config']

@@ -4,8 +4,9 @@ the Groth16 pairing equation (oracle/bn254_ref.py verifier -- an independent big
 proof (single GPU vs 8 thread-ranks with sharded keys and the distributed quotient).
 
   configs[4]  2^27-row synthetic R1CS with the G2 MSM included -- the largest domain bellman accepts (SURVEY fact 10);
-              the fixed-base levels do not fit beside a 48 GiB key, so this is the W-bucket-set path at scale and the
-              largest index arithmetic of every kernel.
+              proved once with FK_MSM_PRECOMP=0 (the W-bucket-set path for all five multiplications at the largest index
+              arithmetic of every kernel) and once with the key the loader makes by default (fixed-base levels for the
+              arrays that fit beside the 48 GiB key): same bytes.
   configs[3]  2^25 rollup-style R1CS, 1024-transaction shape: 1024 tiled rollup transactions (19.7 M gates, 9.6e8 matrix
               terms), the workload bench.py reports.
 """
@@ -97,6 +98,11 @@ def test_config3_2p25_rollup1024_single_gpu_and_8_thread_ranks(ctx):
     assert key.precomputed()['h'] > 0          # the single-GPU key carries the fixed-base levels (merged bucket sets)
     want = ctx.prove_witness_dev(key, dr, d_z, r, s)
     assert _verifies(bench, vk, z[1:num_input], want)
+    # the product's own verifier (fk_verify, host) agrees with the oracle's, also on a proof for other public inputs
+    vkb = fk.api.vk_to_borsh(vk)
+    assert fk.api.verify(vkb, z[1:num_input], want.tobytes()) is True
+    swapped = z[1:num_input].copy(); swapped[[0, 1]] = swapped[[1, 0]]
+    assert fk.api.verify(vkb, swapped, want.tobytes()) is False
     # the host-witness pipeline gives the same bytes
     zp = ctx.host_alloc(z.shape)
     zp[:] = z

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarises rocprofv3 --pmc counter_collection CSVs (one directory per pass) into the JSON files under profiles/.
 
-    python tools/pmc_summary.py traffic  <fetch_dir> <write_dir> <log2n> <points_per_proof> <out.json> [proofs in the pass]
+    python tools/pmc_summary.py traffic  <fetch_dir> <write_dir> <log2n> <points_per_proof> <out.json> [proofs in the pass] [workload] [gathercal dir]
     python tools/pmc_summary.py valu     <sq_dir> <derived_dir> <out.json>
 
 FETCH_SIZE / WRITE_SIZE are in KB (x1024 = bytes).  FETCH_SIZE of wide coalesced streams under-reports by 2x on gfx950
@@ -41,7 +41,18 @@ def per_kernel(rows):
     return agg, {k: len(v) for k, v in disp.items()}
 
 
-def traffic(fetch_dir, write_dir, log2n, points, out, proofs=1):
+def gather_correction(gcal_dir):
+    """demand / FETCH_SIZE of tools/mulbench/gathercal's 64-byte gather kernel (None without the pass)"""
+    if not gcal_dir:
+        return None, {}
+    agg, _ = per_kernel(load(gcal_dir))
+    blocks, threads, per = 256 * 16, 256, 64
+    demand = {'gather_kernel<4>': blocks * threads * per * 64, 'gather_kernel<8>': blocks * threads * per * 128, 'stream_kernel': 4 << 30}
+    res = {k: demand[k] / (agg[k]['FETCH_SIZE'] * 1024) for k in demand if k in agg and agg[k]['FETCH_SIZE'] > 0}
+    return res.get('gather_kernel<4>'), res
+
+
+def traffic(fetch_dir, write_dir, log2n, points, out, proofs=1, workload='synthetic', gcal_dir=None):
     fa, fl = per_kernel(load(fetch_dir))
     wa, _ = per_kernel(load(write_dir))
     ks = sorted(fa, key=lambda k: -(fa[k]['FETCH_SIZE'] + wa.get(k, {}).get('WRITE_SIZE', 0)))
@@ -49,7 +60,9 @@ def traffic(fetch_dir, write_dir, log2n, points, out, proofs=1):
     # the G1 accumulation: the merged form (fixed-base levels, one bucket set) when the key carries levels, else the W-set form
     dom = next(k for k in ks if k.startswith(('msm_accumulate_merged_kernel<Fp<FqParams', 'msm_accumulate_kernel<Fp<FqParams')))
     merged = dom.startswith('msm_accumulate_merged')
+    corr, corr_all = gather_correction(gcal_dir)
     j = dict(
+        workload=workload, fetch_size_calibration=corr_all,
         _doc='rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python3 bench.py --steps 1 --warmup 0 '
              '--no-cpu-baseline` (2^%d rows).  Counter units: KB (x1024 = bytes), summed over the launches of the whole pass (per_kernel); '
              'dominant_kernel is per proof.' % log2n,
@@ -57,6 +70,7 @@ def traffic(fetch_dir, write_dir, log2n, points, out, proofs=1):
         dominant_kernel=dict(
             name='msm_accumulate_merged_kernel<Fq>' if merged else 'msm_accumulate_kernel<Fq>', launches_per_proof=fl[dom] // proofs, points_per_proof=points, proofs_in_the_pass=proofs,
             fetch_bytes_per_proof_raw=fa[dom]['FETCH_SIZE'] * 1024 / proofs, write_bytes_per_proof=wa[dom]['WRITE_SIZE'] * 1024 / proofs,
+            fetch_correction=corr if corr else 1.0,
             note='WRITE_SIZE is exact (XYZZ buckets of 128 B: W*B per launch, B in the merged form).  FETCH_SIZE is reported RAW: the guide\'s x2 gfx950 '
                  'correction is calibrated for wide coalesced streams (it holds for ntt_pass_kernel in this same pass), while this '
                  'kernel gathers 64-byte points at random 64-B-aligned addresses -- an uncalibrated width.  Expected demand: W (12-13) windows x '
@@ -90,6 +104,7 @@ def valu(sq_dir, derived_dir, out):
 
 if __name__ == '__main__':
     if sys.argv[1] == 'traffic':
-        traffic(sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), sys.argv[6], int(sys.argv[7]) if len(sys.argv) > 7 else 1)
+        traffic(sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), sys.argv[6], int(sys.argv[7]) if len(sys.argv) > 7 else 1,
+                sys.argv[8] if len(sys.argv) > 8 else 'synthetic', sys.argv[9] if len(sys.argv) > 9 else None)
     else:
         valu(sys.argv[2], sys.argv[3], sys.argv[4])

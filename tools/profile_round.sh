@@ -1,14 +1,20 @@
-# Final measurement pass of a round (run on the GPU box through gpurun): bench line, kernel trace, PMC passes.
-# Counter passes are separate runs and never combined with other trace domains.
+# Measurement pass of a round (run on the GPU box through gpurun): GPU tests, bench line, kernel trace, PMC passes.
+# Counter passes are separate runs and never combined with other trace domains; the program after `--` is python3 itself.
+# Usage: bash tools/profile_round.sh [tag]      -> gpurun_out/<tag>/
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/final; mkdir -p $O
+TAG=${1:-r02}; O=gpurun_out/$TAG; mkdir -p $O
 B="bench.py --steps 1 --warmup 0 --no-cpu-baseline"
-python3 bench.py --steps 5 --warmup 2 > $O/bench_2p25.log 2>&1
+python3 -m pytest tests -m gpu -q --durations=10 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log; tail -4 $O/pytest_gpu.log
+python3 bench.py --steps 10 --warmup 3 > $O/bench.log 2>&1; tail -c 1500 $O/bench.log; echo
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o k -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline > $O/kt.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -o f -- python3 $B > $O/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -o w -- python3 $B > $O/write.log 2>&1
 rocprofv3 --pmc VALUBusy VALUUtilization MemUnitBusy --output-format csv -d $O/derived -o d -- python3 $B > $O/derived.log 2>&1
 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/sq -o s -- python3 $B > $O/sq.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/gcal -o g -- tools/mulbench/gathercal > $O/gathercal.log 2>&1
+# the kernel trace itself is tens of MB: keep the statistics, compute the busy fraction first
+python3 tools/trace_busy.py $O/kt > $O/kt_busy.txt 2>&1; cat $O/kt_busy.txt
+find $O -name "*kernel_trace.csv" -delete
 find $O -name "*.csv" -size +20M -delete
-ls -la $O $O/*/ | head -40
+ls -la $O | head -40
