@@ -144,6 +144,24 @@ __global__ __launch_bounds__(256) void msm_digits_kernel(const Fr *scalars, size
 // ------------------------------------------------------------------------------------------ bucket sort
 struct OverEntry { uint32_t g, size; };
 
+// Exclusive scan over the 1024 lanes of a workgroup, one value per lane: wave64 shuffles inside a wave, the 16 wave sums through
+// LDS -- two barriers instead of the twenty of a ten-step Hillis-Steele scan (the scatter kernels scan once per 16 K-entry tile).
+// wsum: 16 words of LDS.  Returns the exclusive prefix; *total = sum over the workgroup.
+static __device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint32_t *wsum, uint32_t *total) {
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, off, 64); if (lane >= (uint32_t)off) incl += t; }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    uint32_t base = 0, all = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 16; w++) { const uint32_t x = wsum[w]; all += x; if (w < wv) base += x; }
+    __syncthreads();                 // wsum may be reused by the caller's next scan
+    *total = all;
+    return base + incl - v;
+}
+
 // ------------------------------------------------------------------------------------------ two-pass radix sort
 // Pass 1 partitions each window's entries by the high bits of the bucket index (<= 2^11 bins, LDS counters and
 // cursors), pass 2 sorts every high-bin segment by the low bits (<= 2^10 bins) in tiles of S2_TILE entries.  Both
@@ -231,9 +249,10 @@ __global__ __launch_bounds__(1024) void s2_scatter1_kernel(const uint32_t *digit
     __shared__ uint32_t cursor[S2_MAX_HI];      // next free slot of the bin (window-relative)
     __shared__ uint32_t lcnt[S2_MAX_HI];        // entries of the sub-tile in the bin
     __shared__ uint32_t lexc[S2_MAX_HI];        // exclusive offsets inside the sub-tile
-    __shared__ uint32_t part[1024];
+    __shared__ uint32_t part[16];
     __shared__ uint32_t stage_idx[S2_TILE];
     __shared__ uint16_t stage_lo[S2_TILE];
+    __shared__ uint16_t stage_bin[S2_TILE];
     const uint32_t ch = blockIdx.x, w = blockIdx.y, tid = threadIdx.x;
     const uint32_t *cnt = cnt1 + ((size_t)w * nchunks + ch) * nhi;
     for (uint32_t b = tid; b < S2_MAX_HI; b += 1024) cursor[b] = b < nhi ? seg_start[(size_t)w * nhi + b] + cnt[b] : 0;
@@ -263,27 +282,18 @@ __global__ __launch_bounds__(1024) void s2_scatter1_kernel(const uint32_t *digit
         __syncthreads();
         // exclusive scan over the (<= 2048) bins: two bins per lane
         const uint32_t c0 = lcnt[2 * tid], c1 = lcnt[2 * tid + 1];
-        part[tid] = c0 + c1;
-        __syncthreads();
-        for (uint32_t off = 1; off < 1024; off <<= 1) {
-            const uint32_t v = tid >= off ? part[tid - off] : 0;
-            __syncthreads();
-            part[tid] += v;
-            __syncthreads();
-        }
-        const uint32_t ex = part[tid] - (c0 + c1);
+        uint32_t total;
+        const uint32_t ex = block_excl_scan_1024(c0 + c1, part, &total);
         lexc[2 * tid] = ex; lexc[2 * tid + 1] = ex + c0;
-        const uint32_t total = part[1023];
         __syncthreads();
 #pragma unroll
         for (uint32_t j = 0; j < S2_EPT; j++) {
-            if (e_bin[j] != 0xffffffffu) { const uint32_t q = lexc[e_bin[j]] + e_rank[j]; stage_idx[q] = e_idx[j]; stage_lo[q] = (uint16_t)e_lo[j]; }
+            if (e_bin[j] != 0xffffffffu) { const uint32_t q = lexc[e_bin[j]] + e_rank[j]; stage_idx[q] = e_idx[j]; stage_lo[q] = (uint16_t)e_lo[j]; stage_bin[q] = (uint16_t)e_bin[j]; }
         }
         __syncthreads();
         for (uint32_t q = tid; q < total; q += 1024) {
-            uint32_t lo_ = 0, hi_ = S2_MAX_HI;          // last bin with lexc[bin] <= q (empty bins share the next bin's offset)
-            while (hi_ - lo_ > 1) { const uint32_t mid = (lo_ + hi_) >> 1; if (lexc[mid] <= q) lo_ = mid; else hi_ = mid; }
-            const uint32_t dst = cursor[lo_] + (q - lexc[lo_]);
+            const uint32_t bn = stage_bin[q];            // (a binary search over lexc cost 11 LDS reads per entry here)
+            const uint32_t dst = cursor[bn] + (q - lexc[bn]);
             oidx[dst] = stage_idx[q];
             olo[dst] = stage_lo[q];
         }
@@ -319,7 +329,7 @@ __global__ __launch_bounds__(256) void s2_hist2_kernel(const uint16_t *tmp_lo, s
 __global__ __launch_bounds__(1024) void s2_prefix2_kernel(uint32_t *cnt2, uint32_t nhi, uint32_t nlo, uint32_t B, const uint32_t *tile_start,
                                                            const uint32_t *seg_start, uint32_t cap_all, uint32_t cap_top, uint32_t W, uint32_t *totals, uint32_t *starts,
                                                            OverEntry *over, uint32_t *n_over, uint32_t over_cap) {
-    __shared__ uint32_t part[1024];
+    __shared__ uint32_t part[16];
     const uint32_t sgm = blockIdx.x, w = sgm / nhi, h = sgm % nhi, b = threadIdx.x;
     const uint32_t cap = (w == W - 1) ? cap_top : cap_all;
     uint32_t run = 0;
@@ -329,18 +339,12 @@ __global__ __launch_bounds__(1024) void s2_prefix2_kernel(uint32_t *cnt2, uint32
             const uint32_t v = *p; *p = run; run += v;
         }
     }
-    part[b] = run;
-    __syncthreads();
-    for (uint32_t off = 1; off < 1024; off <<= 1) {
-        const uint32_t v = b >= off ? part[b - off] : 0;
-        __syncthreads();
-        part[b] += v;
-        __syncthreads();
-    }
+    uint32_t all_;
+    const uint32_t excl = block_excl_scan_1024(run, part, &all_);
     if (b < nlo) {
         const size_t g = (size_t)w * B + (size_t)h * nlo + b;
         totals[g] = run;
-        starts[g] = seg_start[sgm] + part[b] - run;
+        starts[g] = seg_start[sgm] + excl;
         if (run > cap) {
             const uint32_t k = atomicAdd(n_over, 1u);
             if (k < over_cap) { over[k].g = (uint32_t)g; over[k].size = run; }
@@ -367,6 +371,7 @@ __global__ __launch_bounds__(1024) void s2_scatter2_kernel(const uint32_t *tmp_i
                                                             const uint32_t *tile_start, uint32_t nseg, const uint32_t *seg_start, const uint32_t *seg_size,
                                                             const uint32_t *cnt2, const uint32_t *starts, uint32_t *sorted) {
     __shared__ uint32_t lcnt[1024];          // per-bin count, then exclusive offset inside the tile
+    __shared__ uint32_t wsum[16];
     __shared__ uint32_t gbase[1024];         // global position (window-relative) of this tile's first entry of the bin
     __shared__ uint32_t stage_idx[S2_TILE];
     __shared__ uint16_t stage_lo[S2_TILE];
@@ -387,15 +392,8 @@ __global__ __launch_bounds__(1024) void s2_scatter2_kernel(const uint32_t *tmp_i
     __syncthreads();
     // exclusive scan of the 1024 bin counts
     const uint32_t mine = lcnt[tid];
-    __syncthreads();
-    for (uint32_t off = 1; off < 1024; off <<= 1) {
-        const uint32_t v = tid >= off ? lcnt[tid - off] : 0;
-        __syncthreads();
-        lcnt[tid] += v;
-        __syncthreads();
-    }
-    const uint32_t excl = lcnt[tid] - mine;
-    __syncthreads();
+    uint32_t all_;
+    const uint32_t excl = block_excl_scan_1024(mine, wsum, &all_);
     lcnt[tid] = excl;
     __syncthreads();
 #pragma unroll

@@ -55,7 +55,6 @@ static double now_ms() {
 }  // namespace fk
 
 static_assert(sizeof(G1Affine) == 64 && sizeof(G2Affine) == 128 && sizeof(Fr) == 32, "raw layouts");
-static constexpr int FK_WITNESS_FIRST_MIN_LOG2 = 24;
 
 extern "C" {
 
@@ -415,13 +414,14 @@ static int prove_msms_dev(fk_ctx *ctx, const fk_key *key, Fr *d_a, Fr *d_b, Fr *
     uint64_t m = 0;
     ctx->lane_next = 0;     // same lane for the same multiplication in every proof: lane buffers keep their sizes
     ctx->lanes_in_use = MSM_LANES;
-    // The witness multiplications depend on z only: on large domains they are begun right behind the QUEUED quotient, so that their
-    // sorts (and what fits of their accumulations) fill the transforms' gaps: 214.5 -> 206.9 ms per proof on the 1024-transaction
-    // system (profiles/r02_cusplit_witness_first_probe.log).  Small domains keep the quotient first (measured in round 1:
-    // 10 % slower at 2^20 / 2^22 the other way).  FK_PROVE_WITNESS_FIRST=1 / 0 forces either.
+    // The witness multiplications depend on z only: they are begun right behind the QUEUED quotient, so that their sorts (and what
+    // fits of their accumulations) fill the transforms' gaps: 214.5 -> 206.9 ms per proof on the 1024-transaction system
+    // (profiles/r02_cusplit_witness_first_probe.log), and at every smaller size measured -- synthetic 2^20 13.4 -> 11.1 ms,
+    // 2^22 26.2 -> 23.7, 2^24 80.4 -> 78.0; 64 transactions 21.0 -> 19.1 (profiles/r02_witness_first_by_size.log).  (Round 1
+    // measured an earlier form of this overlap as a loss below 2^24.)  FK_PROVE_WITNESS_FIRST=0 puts the quotient first again.
     static int t_wfirst = -1;
     if (t_wfirst < 0) { const char *e = getenv("FK_PROVE_WITNESS_FIRST"); t_wfirst = e ? atoi(e) : -2; }
-    const bool wfirst = t_wfirst == 1 || (t_wfirst == -2 && key->m >= ((uint64_t)1 << FK_WITNESS_FIRST_MIN_LOG2));
+    const bool wfirst = t_wfirst != 0;
     if (!ctx->ev_main) FK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_main, hipEventDisableTiming));
     if (!ctx->ev_z) FK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_z, hipEventDisableTiming));
     FK_HIP(ctx, hipEventRecord(ctx->ev_z, ctx->stream));           // z (and a, b, c) are complete here
