@@ -5,7 +5,7 @@ bench.py -- Groth16 proofs/sec on MI355X through the C ABI (include/fawkes_hip.h
 One "step" = one complete Groth16 proof on the 2^25 evaluation domain BASELINE.json's metric is quoted on, starting from
 the WITNESS VECTOR IN HOST MEMORY -- what prover.rs:69-80 hands to `create_random_proof`
 (/root/reference/fawkes-crypto/src/backend/bellman_groth16/prover.rs:80): upload of the witness, device SpMV (a = Az,
-b = Bz, c = Cz; bellman's `synthesize` evaluation, mod.rs:92-99), the 7-NTT quotient, the four G1 MSMs (H, L, A, B1),
+b = Bz, c = Cz; bellman's `synthesize` evaluation, mod.rs:92-99), the quotient (bellman's 7 transforms computed as 6, csrc/ntt.hip), the four G1 MSMs (H, L, A, B1),
 the G2 MSM (B2) and the proof assembly.  The constraint system and the proving key are resident in HBM; the witness is
 handed over per proof from pinned host memory through the two-slot pipeline of the C ABI (fk_prove_r1cs_submit / _wait:
 the upload of proof k+1 runs underneath proof k), so K steps contain K uploads and K proofs.  The same proof with the
@@ -25,7 +25,7 @@ with the Groth16 pairing equation.
         bench.py --gpus N --steps K --warmup W
 
 N > 1: one process per GPU, strong scaling of a single proof: every rank holds 1/N of each key array (MSM sharded
-by points) and computes 1/N of the quotient -- the seven transforms are cut across the ranks with one all-to-all
+by points) and computes 1/N of the quotient -- the transforms are cut across the ranks with one all-to-all
 (RCCL over xGMI) each -- then ONE all-gather of 384 bytes per rank exchanges the partial MSM sums and the proof is
 folded locally (fawkes-crypto_amd/parallel.py: prove_distributed_dev).  With 2 ranks, or a rank count that is not a
 power of two, rank 0 computes the quotient while the other ranks start on the witness MSMs, and h slices travel point
@@ -376,7 +376,7 @@ def main():
     # N > 1, N a power of two: quotient and MSMs cut 1/N each (parallel.prove_distributed_dev); otherwise (or with
     # FK_DIST_QUOTIENT=0) rank 0 computes the quotient and ships h slices (parallel.prove_balanced_dev)
     # Default by rank count: at N = 2 every all-to-all of the distributed quotient moves m*32/4 bytes over ONE xGMI link
-    # (256 MiB at 2^25, ~3.5 ms, eight times per proof), more than the quotient it saves; from N = 4 on the chunks are
+    # (256 MiB at 2^25, ~3.5 ms, seven times per proof), more than the quotient it saves; from N = 4 on the chunks are
     # small and spread over N-1 links.  FK_DIST_QUOTIENT=1 / 0 forces either schedule.
     dq_env = os.environ.get('FK_DIST_QUOTIENT', '')
     dq_ok = multi and (world & (world - 1)) == 0 and world <= 8
@@ -551,7 +551,7 @@ def main():
             'vs_baseline': None,
             'dtype': 'u32',
             'data': 'synthetic',
-            'config': {'workload': wl + '; per step: witness from pinned HOST memory (two-slot pipeline) -> device SpMV + 7-NTT quotient + G1 MSMs '
+            'config': {'workload': wl + '; per step: witness from pinned HOST memory (two-slot pipeline) -> device SpMV + quotient (6 NTTs) + G1 MSMs '
                                       'H/L/A/B1 + G2 MSM B2 + assembly; constraint system and valid key resident in HBM',
                        'log2_constraints': log_m, 'rows': n, 'num_input': num_input, 'num_aux': num_aux,
                        'nnz': list(info['nnz']), 'witness_bytes_per_proof': nv * 32,
@@ -560,7 +560,7 @@ def main():
                        'msm_fixed_base_levels': pre_levels,
                        'witness': '%.1f%% zeros, %.1f%% ones, rest dense 254-bit' % (100.0 * zeros / nv, 100.0 * ones / nv),
                        'parallelism': 'msm-shard%d%s' % (world, '' if not multi else
-                                                         '+distributed-quotient (8 all-to-all per proof)' if dist_q else '+balanced-quotient')},
+                                                         '+distributed-quotient (7 all-to-all per proof)' if dist_q else '+balanced-quotient')},
             'msm_scalar_muls_per_sec': msm_units / sec_per_step,
             'msm_scalar_muls_per_sec_counts': 'every (scalar, base) pair of the five multiplications, trivial scalars (0 and 1) included',
             'device_resident_ms_per_step': dev_ms,

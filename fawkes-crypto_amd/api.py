@@ -35,7 +35,7 @@ EXPORTED_SYMBOLS = [
     'fk_msm_g1', 'fk_msm_g2', 'fk_msm_g1_dev', 'fk_msm_g2_dev',
     'fk_gen_points_g1_dev', 'fk_gen_points_g2_dev', 'fk_gen_scalars_dev',
     'fk_synthesize', 'fk_stats_reset', 'fk_stats_get', 'fk_calibrate', 'fk_verify', 'fk_verify_batch_dev', 'fk_shard_range', 'fk_h_shard_range',
-    'fk_dq_gather_dev', 'fk_dq_local_dev', 'fk_dq_cross_dev',
+    'fk_dq_gather_dev', 'fk_dq_local_dev', 'fk_dq_cross_dev', 'fk_dq_cross_sub_dev',
     'fk_setup', 'fk_setup_tiled', 'fk_r1cs_load_tiled', 'fk_key_download', 'fk_key_load_bellman', 'fk_key_vk', 'fk_key_counts', 'fk_key_precomputed',
     'fk_gates_decode', 'fk_gates_free', 'fk_gates_info', 'fk_gates_export', 'fk_r1cs_load_gates',
     'fk_r1cs_load', 'fk_r1cs_free', 'fk_r1cs_info', 'fk_r1cs_density_ptrs', 'fk_r1cs_eval_dev', 'fk_prove_r1cs', 'fk_prove_r1cs_dev',
@@ -596,6 +596,9 @@ class Context:
     def dq_cross_dev(self, d_buf, log_m, rank, log_w, mode):
         self._ck(self.lib.fk_dq_cross_dev(self.handle, C.c_void_p(d_buf), C.c_uint32(log_m), C.c_uint32(rank), C.c_uint32(log_w),
                                           C.c_int(mode)))
+
+    def dq_cross_sub_dev(self, d_buf, d_sub, log_m, rank, log_w):
+        self._ck(self.lib.fk_dq_cross_sub_dev(self.handle, C.c_void_p(d_buf), C.c_void_p(d_sub), C.c_uint32(log_m), C.c_uint32(rank), C.c_uint32(log_w)))
 
     def msm_g1(self, bases, scalars):
         bases = np.ascontiguousarray(bases, np.uint8).reshape(-1, 64)

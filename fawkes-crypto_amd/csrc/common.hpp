@@ -213,7 +213,7 @@ void ntt_free_domains(fk_ctx *ctx);
 int fr_mul_batch_dev(fk_ctx *ctx, const Fr *a, const Fr *b, Fr *o, size_t n);
 int dq_gather(fk_ctx *ctx, const Fr *d_full, uint64_t n, uint32_t log_m, uint32_t rank, uint32_t log_w, Fr *d_local);
 int dq_local(fk_ctx *ctx, Fr *d_x, const Fr *d_xb, const Fr *d_xc, uint32_t log_m, uint32_t rank, uint32_t log_w, int stage);
-int dq_cross(fk_ctx *ctx, Fr *d_buf, uint32_t log_m, uint32_t rank, uint32_t log_w, int mode);
+int dq_cross(fk_ctx *ctx, Fr *d_buf, uint32_t log_m, uint32_t rank, uint32_t log_w, int mode, const Fr *d_sub = nullptr);
 
 // msm.hip
 int msm_g1_dev(fk_ctx *ctx, const G1Affine *d_bases, const Fr *d_scalars, size_t n, G1Xyzz *out, const KeyPre *pre = nullptr);

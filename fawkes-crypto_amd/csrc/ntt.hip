@@ -14,8 +14,8 @@
 // bit-reversed inside the tile only), and writes the tile to its autosorted position.  Inter-pass
 // twiddles omega^(k*r*N/(pR)) come from a two-level table (2^L + 2^(k-L) entries, L2-resident).
 // The coset shift (g^i), the 1/m scaling, the 1/Z(g) factor and the pointwise a*b-c are fused into
-// the first/last pass of the neighbouring transform, so the whole quotient is 7 transforms =
-// 7*P passes, each reading and writing every element once (64 B/element/pass algorithmic traffic).
+// the first/last pass of the neighbouring transform; the whole quotient is 6 transforms (quotient_dev: c is subtracted in
+// coefficient space, bellman does 7) = 6*P passes, each reading and writing every element once (64 B/element/pass).
 #include "common.hpp"
 
 namespace fk {
@@ -24,8 +24,8 @@ static constexpr uint32_t NTT_MAXDEG = 9;       // R <= 512
 static constexpr uint32_t NTT_TILE_LOG = 11;    // R*C <= 2048 elements = 64 KiB of LDS
 static constexpr uint32_t NTT_MAX_THREADS = 1024;
 
-enum { PRE_NONE = 0, PRE_TABLE = 1, PRE_ABC = 2 };
-enum { POST_NONE = 0, POST_CONST = 1, POST_TABLE = 2 };
+enum { PRE_NONE = 0, PRE_TABLE = 1, PRE_ABC = 2, PRE_AB = 3 };
+enum { POST_NONE = 0, POST_CONST = 1, POST_TABLE = 2, POST_TABLE_SUB = 3 };      // _SUB: v * table - xc[out index]
 
 struct ScaleTable {          // value(i) = lo[i & (2^L - 1)] * hi[i >> L]
     Fr *lo = nullptr, *hi = nullptr;
@@ -100,6 +100,8 @@ __global__ __launch_bounds__(NTT_MAX_THREADS) void ntt_pass_kernel(PassArgs a) {
             Fr p0, p1;
             Fr::mul2(v0, a.xb[idx0], v1, a.xb[idx1], p0, p1);
             Fr::sub2(p0, a.xc[idx0], p1, a.xc[idx1], v0, v1);
+        } else if (a.pre_mode == PRE_AB) {
+            Fr::mul2(v0, a.xb[idx0], v1, a.xb[idx1], v0, v1);
         } else if (a.pre_mode == PRE_TABLE) {
             Fr s0, s1;
             Fr::mul2(a.pre_lo[idx0 & Lmask], a.pre_hi[idx0 >> a.L], a.pre_lo[idx1 & Lmask], a.pre_hi[idx1 >> a.L], s0, s1);
@@ -183,10 +185,11 @@ __global__ __launch_bounds__(NTT_MAX_THREADS) void ntt_pass_kernel(PassArgs a) {
         const uint64_t k0 = i0 & pmask, k1 = i1 & pmask;
         const uint64_t o0 = ((i0 - k0) << a.deg) + k0 + ((uint64_t)rr0 << a.lgp), o1 = ((i1 - k1) << a.deg) + k1 + ((uint64_t)rr1 << a.lgp);
         if (a.post_mode == POST_CONST) Fr::mul2(v0, a.post_const, v1, a.post_const, v0, v1);
-        else if (a.post_mode == POST_TABLE) {
+        else if (a.post_mode == POST_TABLE || a.post_mode == POST_TABLE_SUB) {
             Fr s0, s1;
             Fr::mul2(a.post_lo[o0 & Lmask], a.post_hi[o0 >> a.L], a.post_lo[o1 & Lmask], a.post_hi[o1 >> a.L], s0, s1);
             Fr::mul2(v0, s0, v1, s1, v0, v1);
+            if (a.post_mode == POST_TABLE_SUB) Fr::sub2(v0, a.xc[o0], v1, a.xc[o1], v0, v1);
         }
         a.y[o0] = v0;
         if (has1) a.y[o1] = v1;
@@ -404,9 +407,19 @@ int quotient_dev(fk_ctx *ctx, Fr *d_a, Fr *d_b, Fr *d_c, uint64_t n, Fr *d_h_out
     Fr *s1 = ctx->ntt_s1.as<Fr>(), *s2 = ctx->ntt_s2.as<Fr>();
     Fr *polys[3] = {d_a, d_b, d_c};
     const bool multi = d->degs.size() >= 2;
+    // SIX transforms, not bellman's seven.  bellman: h = icoset_fft((A_c o B_c - C_c) / Z(g)) with X_c = coset_fft(ifft(x)).
+    // icoset_fft is linear and undoes coset_fft exactly, so icoset_fft(C_c) is simply ifft(c): c never has to visit the coset,
+    //     h_i = [g^-i / (m Z(g))] * ifft(A_c o B_c)_i  -  [1 / Z(g)] * ifft(c)_i
+    // -- the same field elements (exact arithmetic: the identity holds for ANY a, b, c, satisfied system or not), one transform less.
     for (int k = 0; k < 3; k++) {
         Fr *x = polys[k];
         if (m > n) FK_HIP(ctx, hipMemsetAsync(x + n, 0, (m - n) * sizeof(Fr), ctx->stream));
+        if (k == 2) {       // c: ifft only, with 1 / (m Z(g)) on the way out
+            NttOp invc; invc.inverse = true; invc.post_mode = POST_CONST; invc.post_const = Fr::mul(d->minv, d->zinv);
+            if (multi) FK_TRY(ntt_exec(ctx, d, invc, x, s1, s2, x));
+            else { FK_TRY(ntt_exec(ctx, d, invc, x, s1, s2, s1)); FK_HIP(ctx, hipMemcpyAsync(x, s1, bytes, hipMemcpyDeviceToDevice, ctx->stream)); }
+            break;
+        }
         // ifft followed by the coset shift g^i (first half of coset_fft), fused: * g^i / m on the way out
         NttOp inv; inv.inverse = true; inv.post_mode = POST_TABLE; inv.post = &d->t_g_minv;
         NttOp fwd;  // the transform part of coset_fft
@@ -418,10 +431,9 @@ int quotient_dev(fk_ctx *ctx, Fr *d_a, Fr *d_b, Fr *d_c, uint64_t n, Fr *d_h_out
             FK_TRY(ntt_exec(ctx, d, fwd, s1, s2, s2, x));
         }
     }
-    // a*b - c on the coset (fused into the first pass), divide_by_z_on_coset and icoset_fft's g^-i / m
-    // (fused into the last pass)
-    NttOp fin; fin.inverse = true; fin.pre_mode = PRE_ABC; fin.xb = d_b; fin.xc = d_c;
-    fin.post_mode = POST_TABLE; fin.post = &d->t_ginv_minv_zinv;
+    // a*b on the coset (fused into the first pass); g^-i / (m Z(g)) and the subtraction of c's scaled coefficients (fused into the last)
+    NttOp fin; fin.inverse = true; fin.pre_mode = PRE_AB; fin.xb = d_b; fin.xc = d_c;
+    fin.post_mode = POST_TABLE_SUB; fin.post = &d->t_ginv_minv_zinv;
     FK_TRY(ntt_exec(ctx, d, fin, d_a, s1, s2, d_h_out));
     return FK_OK;
 }
@@ -454,7 +466,9 @@ __global__ void dq_gather_kernel(const Fr *full, uint64_t n, uint32_t log_w, uin
 struct CrossArgs {
     Fr *buf;
     uint32_t log_m, log_w, rank;
-    int mode;                              // 0: ifft tail + coset shift + coset_fft head, 1: icoset_fft tail
+    int mode;                              // 0: ifft tail + coset shift + coset_fft head, 1: icoset_fft tail (- sub), 2: ifft tail * post_const
+    const Fr *sub;                         // mode 1: subtracted from the result, same block-cyclic layout (c's scaled coefficients)
+    Fr post_const;                         // mode 2
     Fr w_fwd[4], w_inv[4];                 // w_W^e and w_W^-e, e < W/2
     const Fr *sc_lo, *sc_hi, *tw_lo, *tw_hi;
     uint32_t Lbits;
@@ -505,7 +519,9 @@ __global__ __launch_bounds__(256) void dq_cross_kernel(CrossArgs a) {
 #pragma unroll
     for (int k1 = 0; k1 < W; k1++) {
         const uint64_t i = k2 + (uint64_t)k1 * L;                  // coefficient index
-        v[k1] = Fr::mul(v[k1], Fr::mul(a.sc_lo[i & mask], a.sc_hi[i >> a.Lbits]));
+        if (a.mode == 2) v[k1] = Fr::mul(v[k1], a.post_const);
+        else v[k1] = Fr::mul(v[k1], Fr::mul(a.sc_lo[i & mask], a.sc_hi[i >> a.Lbits]));
+        if (a.mode == 1 && a.sub) v[k1] = Fr::sub(v[k1], a.sub[(uint64_t)k1 * Lc + t]);
     }
     if (a.mode == 0) {
         small_dft<LOGW>(v, a.w_fwd);
@@ -537,9 +553,10 @@ int dq_gather(fk_ctx *ctx, const Fr *d_full, uint64_t n, uint32_t log_m, uint32_
 
 // stage 0: inverse L-point transform + twiddle (ifft, first half)      stage 1: forward L-point transform
 // stage 2: x := x * xb - xc, then as stage 0 (icoset_fft, first half)  (coset_fft, second half)
+// stage 3: x := x * xb, then as stage 0 (six-transform form: c is subtracted in coefficient space, dq_cross mode 1 with `sub`)
 int dq_local(fk_ctx *ctx, Fr *d_x, const Fr *d_xb, const Fr *d_xc, uint32_t log_m, uint32_t rank, uint32_t log_w, int stage) {
     FK_TRY(dq_check(ctx, log_m, rank, log_w));
-    if (stage < 0 || stage > 2 || (stage == 2 && (!d_xb || !d_xc))) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "distributed quotient: bad stage");
+    if (stage < 0 || stage > 3 || (stage == 2 && (!d_xb || !d_xc)) || (stage == 3 && !d_xb)) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "distributed quotient: bad stage");
     NttDomain *dl = nullptr, *dm = nullptr;
     FK_TRY(get_domain(ctx, log_m - log_w, &dl));
     FK_TRY(get_domain(ctx, log_m, &dm));
@@ -549,6 +566,7 @@ int dq_local(fk_ctx *ctx, Fr *d_x, const Fr *d_xb, const Fr *d_xc, uint32_t log_
     NttOp op;
     op.inverse = stage != 1;
     if (stage == 2) { op.pre_mode = PRE_ABC; op.xb = d_xb; op.xc = d_xc; }
+    if (stage == 3) { op.pre_mode = PRE_AB; op.xb = d_xb; }
     if (stage != 1 && rank != 0) {
         const uint64_t key = ((uint64_t)log_w << 32) | rank;
         auto it = dl->dist_post.find(key);
@@ -566,13 +584,14 @@ int dq_local(fk_ctx *ctx, Fr *d_x, const Fr *d_xb, const Fr *d_xc, uint32_t log_
     return FK_OK;
 }
 
-int dq_cross(fk_ctx *ctx, Fr *d_buf, uint32_t log_m, uint32_t rank, uint32_t log_w, int mode) {
+int dq_cross(fk_ctx *ctx, Fr *d_buf, uint32_t log_m, uint32_t rank, uint32_t log_w, int mode, const Fr *d_sub) {
     FK_TRY(dq_check(ctx, log_m, rank, log_w));
-    if (mode < 0 || mode > 1) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "distributed quotient: bad mode");
+    if (mode < 0 || mode > 2 || (d_sub && mode != 1)) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "distributed quotient: bad mode");
     NttDomain *dm = nullptr;
     FK_TRY(get_domain(ctx, log_m, &dm));
     CrossArgs a{};
-    a.buf = d_buf; a.log_m = log_m; a.log_w = log_w; a.rank = rank; a.mode = mode;
+    a.buf = d_buf; a.log_m = log_m; a.log_w = log_w; a.rank = rank; a.mode = mode; a.sub = d_sub;
+    a.post_const = Fr::mul(dm->minv, dm->zinv);
     const uint64_t L = (uint64_t)1 << (log_m - log_w);
     const Fr ww = Fr::pow_u64(dm->omega, L), wwi = Fr::pow_u64(dm->omega_inv, L);     // w_W, w_W^-1
     Fr cf = Fr::one(), ci = Fr::one();

@@ -3,7 +3,7 @@
 // /root/reference/fawkes-crypto/src/backend/bellman_groth16/prover.rs:80 (algorithm: SURVEY.md App. A.1-A.5).
 //
 // Device pipeline per proof (one HIP stream, key resident in HBM):
-//   quotient (7 fused NTTs, ntt.hip)  ->  h
+//   quotient (6 fused NTTs for bellman's 7, ntt.hip)  ->  h
 //   scalar vectors: h | z_aux | z_in ++ compact(z_aux, a_aux) | compact(z_in, b_in) ++ compact(z_aux, b_aux)
 //   five Pippenger MSMs (msm.hip) against the resident key slices
 //   host: XYZZ -> affine, proof assembly with r, s and the vk points (a handful of group operations)
@@ -672,6 +672,14 @@ int fk_dq_cross_dev(fk_ctx *ctx, void *d_buf, uint32_t log_m, uint32_t rank, uin
     if (log_m >= FK_FR_S) FK_SET_ERR(ctx, FK_ERR_DOMAIN_TOO_LARGE, "evaluation domain 2^%u too large (max 2^%d)", log_m, FK_FR_S - 1);
     FK_HIP(ctx, hipSetDevice(ctx->device));
     return dq_cross(ctx, (Fr *)d_buf, log_m, rank, log_w, mode);
+}
+
+int fk_dq_cross_sub_dev(fk_ctx *ctx, void *d_buf, const void *d_sub, uint32_t log_m, uint32_t rank, uint32_t log_w) {
+    if (!ctx) return FK_ERR_BAD_ARG;
+    if (!d_buf || !d_sub) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "null argument");
+    if (log_m >= FK_FR_S) FK_SET_ERR(ctx, FK_ERR_DOMAIN_TOO_LARGE, "evaluation domain 2^%u too large (max 2^%d)", log_m, FK_FR_S - 1);
+    FK_HIP(ctx, hipSetDevice(ctx->device));
+    return dq_cross(ctx, (Fr *)d_buf, log_m, rank, log_w, 1, (const Fr *)d_sub);
 }
 
 int fk_quotient_h(fk_ctx *ctx, const uint64_t *a, const uint64_t *b, const uint64_t *c, uint64_t n, uint64_t *h_out) {

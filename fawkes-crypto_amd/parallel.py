@@ -19,9 +19,9 @@ Schedule (work-balanced, `prove_balanced`):
 
 `prove_sharded*` is the simpler variant (every rank runs the quotient itself; no h traffic).
 
-Distributed quotient (`quotient_distributed`, `prove_distributed_dev`; world a power of two <= 8): the seven transforms
+Distributed quotient (`quotient_distributed`, `prove_distributed_dev`; world a power of two <= 8): the transforms
 themselves are cut across the ranks -- L = m/W-point transforms stay inside one GPU, one all-to-all per transform
-(8 in total, m*32/W bytes per rank each: 128 MiB at 2^25 / 8 GPUs) moves the data between the two halves of every
+(7 in total, m*32/W bytes per rank each: 128 MiB at 2^25 / 8 GPUs) moves the data between the two halves of every
 transform, and rank g ends up with exactly the block of h coefficients whose bases its key shard holds.  Every rank
 does 1/W of the quotient and 1/W of all five MSMs; this is the default for `bench.py --gpus N`.
 """
@@ -234,22 +234,25 @@ def quotient_distributed(ctx, rank, world, d_full, n, log_m, send, recv, a2a):
     if begin is None:
         begin = lambda dst, src: a2a(dst, src)
         end = lambda h: None
+    # SIX transforms (csrc/ntt.hip: quotient_dev): c is subtracted in coefficient space, so it needs the inverse transform only
     h1 = []
     for k in range(3):                                   # ifft, first half; its exchange starts at once
         ctx.dq_gather_dev(d_full[k], n, log_m, rank, lw, p(send[k]))
         ctx.dq_local_dev(p(send[k]), log_m, rank, lw, 0)
         h1.append(begin(recv[k:k + 1], send[k:k + 1]))
-    h2 = []
-    for k in range(3):                                   # ifft second half, coset shift, coset_fft first half
+    h2 = [None, None]
+    for k in range(2):                                   # a, b: ifft second half, coset shift, coset_fft first half
         end(h1[k])
         ctx.dq_cross_dev(p(recv[k]), log_m, rank, lw, 0)
-        h2.append(begin(send[k:k + 1], recv[k:k + 1]))
-    for k in (1, 2, 0):                                  # coset_fft, second half (b and c first: a is transformed in place last)
+        h2[k] = begin(send[k:k + 1], recv[k:k + 1])
+    end(h1[2])
+    ctx.dq_cross_dev(p(recv[2]), log_m, rank, lw, 2)     # c: ifft second half * 1 / (m Z(g)); block-cyclic coefficients stay in recv[2]
+    for k in (1, 0):                                     # coset_fft, second half (b first: a is multiplied in place next)
         end(h2[k])
         ctx.dq_local_dev(p(send[k]), log_m, rank, lw, 1)
-    ctx.dq_local_dev(p(send[0]), log_m, rank, lw, 2, p(send[1]), p(send[2]))     # a*b - c, icoset_fft first half
+    ctx.dq_local_dev(p(send[0]), log_m, rank, lw, 3, p(send[1]))                 # a*b, icoset_fft first half
     a2a(recv[:1], send[:1])
-    ctx.dq_cross_dev(p(recv[0]), log_m, rank, lw, 1)     # icoset_fft second half, / Z(g)
+    ctx.dq_cross_sub_dev(p(recv[0]), p(recv[2]), log_m, rank, lw)                # icoset_fft second half, / Z(g), - c's coefficients
     a2a(send[:1], recv[:1])                              # block-cyclic -> blocks (the key's h sharding)
     return send[0]
 

@@ -215,6 +215,13 @@ void fk_h_shard_range(uint64_t n_h, uint32_t index, uint32_t count, uint64_t *lo
 int fk_dq_gather_dev(fk_ctx *ctx, const void *d_full, uint64_t n, uint32_t log_m, uint32_t rank, uint32_t log_w, void *d_local);
 int fk_dq_local_dev(fk_ctx *ctx, void *d_x, const void *d_xb, const void *d_xc, uint32_t log_m, uint32_t rank, uint32_t log_w, int stage);
 int fk_dq_cross_dev(fk_ctx *ctx, void *d_buf, uint32_t log_m, uint32_t rank, uint32_t log_w, int mode);
+/* The six-transform form (what the single-GPU quotient does as well): icoset_fft is linear and undoes coset_fft exactly, so
+ * c never has to visit the coset -- h_i = [g^-i / (m Z(g))] ifft(A_c o B_c)_i - [1 / Z(g)] ifft(c)_i, the same field elements.
+ *   fk_dq_cross_dev mode 2   ifft second half of c only, * 1 / (m Z(g)): c's scaled coefficients, block-cyclic, stay put
+ *   fk_dq_local_dev stage 3  x := x * xb, then as stage 0
+ *   fk_dq_cross_sub_dev      mode 1, then - d_sub (same block-cyclic layout)
+ * One all-to-all and one rank-local transform fewer per proof: 7 exchanges instead of 8 (parallel.quotient_distributed). */
+int fk_dq_cross_sub_dev(fk_ctx *ctx, void *d_buf, const void *d_sub, uint32_t log_m, uint32_t rank, uint32_t log_w);
 
 /* ---------------------------------------------------------------- building blocks (tests / benches)
  * bellman_ce::domain::EvaluationDomain pieces. */

@@ -152,6 +152,8 @@ class _CpuDq:
         if stage == 2:
             xb, xc = self._get(d_xb), self._get(d_xc)
             x = [(u * v - w) % R for u, v, w in zip(x, xb, xc)]
+        if stage == 3:                                   # six-transform form: a * b only
+            x = [u * v % R for u, v in zip(x, self._get(d_xb))]
         wm = self.ref.omega_for(1 << log_m)
         wl = pow(wm, 1 << log_w, R)
         if stage != 1:
@@ -160,6 +162,11 @@ class _CpuDq:
         if stage != 1:
             out = [o * pow(wm, rank * k, R) % R for k, o in enumerate(out)]
         self._put(d_x, out)
+
+    def dq_cross_sub_dev(self, d_buf, d_sub, log_m, rank, log_w):
+        self.dq_cross_dev(d_buf, log_m, rank, log_w, 1)
+        R = self.ref.R
+        self._put(d_buf, [(u - v) % R for u, v in zip(self._get(d_buf), self._get(d_sub))])
 
     def dq_cross_dev(self, d_buf, log_m, rank, log_w, mode):
         R = self.ref.R
@@ -178,7 +185,7 @@ class _CpuDq:
             u = [sum(v[j] * pow(ww, -j * k1, R) for j in range(W)) % R for k1 in range(W)]
             for k1 in range(W):
                 i = k2 + k1 * L
-                u[k1] = u[k1] * (pow(g, i, R) * minv if mode == 0 else pow(g, -i, R) * minv * zinv) % R
+                u[k1] = u[k1] * (pow(g, i, R) * minv if mode == 0 else (minv * zinv if mode == 2 else pow(g, -i, R) * minv * zinv)) % R
             if mode == 0:
                 u = [sum(u[j] * pow(ww, j * k1, R) for j in range(W)) * pow(wm, k2 * k1, R) % R for k1 in range(W)]
             for k1 in range(W):
