@@ -45,8 +45,7 @@ struct MsmLane {
     void *h_stage = nullptr;        // pinned host staging: counters read back, oversized-bucket list, task tables
     size_t h_cap = 0;
     const void *last_sort_scalars = nullptr; size_t last_sort_n = 0; unsigned last_sort_c = 0; bool last_merged = false;   // what `sorted` currently holds
-    // ... and the oversized-bucket tables that belong to it (already in tasktab on the device)
-    uint32_t last_n_over = 0, last_seg = 0, last_cap = 0; size_t last_n_tasks = 0, last_n_obs = 0, last_tb_al = 0;
+    // ... the oversized-bucket state and tables that belong to it live on the device (msm.hip: MsmDyn, tasktab)
 };
 
 // One outstanding multiplication: everything is queued, `done` fires when its window sums are in h_wp.

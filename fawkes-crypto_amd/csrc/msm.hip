@@ -13,7 +13,9 @@
 //   2. bucket sort     two-pass radix sort on the bucket index (high bits, then the low 10 bits inside each
 //                      segment): LDS histograms and cursors, every tile ranked and staged in LDS and written as
 //                      contiguous runs.  No global atomics, so skewed witness scalars (many 0/1) cost nothing extra.
-//                      The host reads back the tile count and, at the end, the list of oversized buckets.
+//                      The second pass is launched over the host's upper bound on the tile count; the cap of a bucket-lane,
+//                      the list of oversized buckets and their segment tasks are worked out by small kernels into a
+//                      device-side record (MsmDyn) the later kernels read -- the host never waits inside a multiplication.
 //   2b. size order     buckets are counting-sorted by length so the 64 lanes of a wave run equally long.
 //   3. msm_accumulate  one lane per bucket walks its run with XYZZ mixed additions (8M+2S), gathering
 //                      64-byte affine bases; buckets above `cap` = mean + 6 sigma + 8 entries hand the excess to
@@ -59,13 +61,13 @@ static MsmPlan make_plan(size_t n, unsigned forced_c, bool merged = false) {
     uint32_t lg = 0; while (((size_t)1 << (lg + 1)) <= nd + nd / 2) lg++;     // log2 rounded (2^25 - 1 counts as 2^25)
     // large MSMs: bucket loads of ~64 are enough now that lanes are size-ordered, so c grows with n (fewer digits
     // per scalar: 13 at c = 20 instead of 16)
-    static int t_small = -1, t_delta = -1, t_sig = -1, t_pre_dc = 2;
+    static int t_small = -1, t_delta = -1, t_sig = -1, t_pre_dc = 3;
     if (t_small < 0) {   // tuning knobs (environment, read once)
         const char *e;
         t_small = (e = getenv("FK_MSM_C_SMALL")) ? atoi(e) : 17;
         t_delta = (e = getenv("FK_MSM_C_DELTA")) ? atoi(e) : 5;
         t_sig = (e = getenv("FK_MSM_CAP_SIGMA")) ? atoi(e) : 6;
-        t_pre_dc = (e = getenv("FK_MSM_PRE_DC")) ? atoi(e) : 2;
+        t_pre_dc = (e = getenv("FK_MSM_PRE_DC")) ? atoi(e) : 3;
     }
     uint32_t c = forced_c ? forced_c : (lg >= 22 ? lg - t_delta : (lg >= 18 ? (uint32_t)t_small : (lg >= 6 ? lg - 2 : 4)));
     if (merged && !forced_c) c = (uint32_t)std::max(2, (int)c + t_pre_dc);
@@ -160,6 +162,32 @@ static __device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint
     __syncthreads();                 // wsum may be reused by the caller's next scan
     *total = all;
     return base + incl - v;
+}
+
+// ------------------------------------------------------------------------------------------ oversized buckets: device-side state
+// Everything a multiplication decides from its data -- the cap a bucket-lane walks to, the list of buckets beyond it, their
+// segment tasks -- is decided ON THE DEVICE and read by the following kernels from here, so that a whole multiplication is
+// queued without a single host round trip (round 1 waited twice per multiplication, and every wait kept the host from queueing
+// the NEXT multiplication's kernels).  One per lane; lives as long as the lane's sort (B2 reuses B1's).
+struct MsmDyn {
+    uint32_t cap, n_over, seg, n_tasks, n_obs, error, pad0, pad1;
+    uint32_t hist[16];              // buckets with cap0 << k < size (<= cap0 << (k + 1) for k < 15), from s2_prefix2_kernel
+    unsigned long long adds;        // mixed additions of the accumulate kernel (statistics)
+};
+static constexpr uint32_t OVER_MAX = 4096;      // oversized buckets a multiplication can table (the cap rule leaves at most ~3072)
+
+// Appends an entry to the oversized-bucket list for every lane with `take`: ONE global atomic per wave reserves the range.
+static __device__ __forceinline__ void over_append(bool take, uint32_t g, uint32_t size, OverEntry *over, MsmDyn *dyn) {
+    const unsigned long long m = __ballot(take);
+    if (!m) return;
+    const uint32_t lane = threadIdx.x & 63, leader = (uint32_t)__ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(&dyn->n_over, (uint32_t)__popcll(m));
+    base = (uint32_t)__shfl((int)base, (int)leader, 64);
+    if (take) {
+        const uint32_t k = base + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+        if (k < OVER_MAX) { over[k].g = g; over[k].size = size; } else dyn->error = 1;
+    }
 }
 
 // ------------------------------------------------------------------------------------------ two-pass radix sort
@@ -327,11 +355,11 @@ __global__ __launch_bounds__(256) void s2_hist2_kernel(const uint16_t *tmp_lo, s
 
 // one block per high-bin segment, one lane per low bin: prefix over the segment's tiles, bucket totals and starts
 __global__ __launch_bounds__(1024) void s2_prefix2_kernel(uint32_t *cnt2, uint32_t nhi, uint32_t nlo, uint32_t B, const uint32_t *tile_start,
-                                                           const uint32_t *seg_start, uint32_t cap_all, uint32_t cap_top, uint32_t W, uint32_t *totals, uint32_t *starts,
-                                                           OverEntry *over, uint32_t *n_over, uint32_t over_cap) {
+                                                           const uint32_t *seg_start, uint32_t cap0, uint32_t *totals, uint32_t *starts, MsmDyn *dyn) {
     __shared__ uint32_t part[16];
+    __shared__ uint32_t sh_hist[16];
     const uint32_t sgm = blockIdx.x, w = sgm / nhi, h = sgm % nhi, b = threadIdx.x;
-    const uint32_t cap = (w == W - 1) ? cap_top : cap_all;
+    if (b < 16) sh_hist[b] = 0;
     uint32_t run = 0;
     if (b < nlo) {
         for (uint32_t t = tile_start[sgm]; t < tile_start[sgm + 1]; t++) {
@@ -345,23 +373,34 @@ __global__ __launch_bounds__(1024) void s2_prefix2_kernel(uint32_t *cnt2, uint32
         const size_t g = (size_t)w * B + (size_t)h * nlo + b;
         totals[g] = run;
         starts[g] = seg_start[sgm] + excl;
-        if (run > cap) {
-            const uint32_t k = atomicAdd(n_over, 1u);
-            if (k < over_cap) { over[k].g = (uint32_t)g; over[k].size = run; }
+        if (run > cap0) {        // how far over the statistical cap: class k = the largest k with run > cap0 << k (msm_cap_kernel)
+            uint32_t k = 31u - (uint32_t)__clz((run - 1) / cap0);
+            atomicAdd(&sh_hist[k < 15 ? k : 15], 1u);
         }
     }
+    __syncthreads();
+    if (b < 16 && sh_hist[b]) atomicAdd(&dyn->hist[b], sh_hist[b]);
 }
 
-// Re-lists the buckets longer than `cap` (used when the statistical cap turned out too tight for the actual scalars and is
-// being raised): one lane per bucket.
-__global__ __launch_bounds__(256) void msm_over_scan_kernel(const uint32_t *totals, size_t WB, uint32_t cap, OverEntry *over, uint32_t *n_over, uint32_t over_cap) {
+// The cap assumes Poisson bucket loads.  Scalars with many repeated values (a batch witness) put thousands of buckets a little
+// over it, and a wave per segment plus a 256-lane fold workgroup per such bucket is a poor trade: the cap is doubled until at
+// most `many` buckets remain above it (or it reaches 2^20).  One lane; resets the rest of the state for this sort.
+__global__ void msm_cap_kernel(MsmDyn *dyn, uint32_t cap0, uint32_t many) {
+    if (threadIdx.x || blockIdx.x) return;
+    uint32_t above[17]; above[16] = 0;
+    for (int k = 15; k >= 0; k--) above[k] = above[k + 1] + dyn->hist[k];
+    uint32_t k = 0;
+    while (k < 15 && above[k] > many && ((unsigned long long)cap0 << k) < (1ull << 20)) k++;
+    const unsigned long long c = (unsigned long long)cap0 << k;
+    dyn->cap = c < (1ull << 30) ? (uint32_t)c : (1u << 30);
+    dyn->n_over = 0; dyn->seg = 0; dyn->n_tasks = 0; dyn->n_obs = 0; dyn->error = 0; dyn->adds = 0;
+}
+
+// Lists the buckets longer than the (final) cap.
+__global__ __launch_bounds__(256) void msm_over_list_kernel(const uint32_t *totals, size_t WB, OverEntry *over, MsmDyn *dyn) {
     const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= WB) return;
-    const uint32_t sz = totals[g];
-    if (sz > cap) {
-        const uint32_t k = atomicAdd(n_over, 1u);
-        if (k < over_cap) { over[k].g = (uint32_t)g; over[k].size = sz; }
-    }
+    const uint32_t sz = g < WB ? totals[g] : 0;
+    over_append(g < WB && sz > dyn->cap, (uint32_t)g, sz, over, dyn);
 }
 
 // Second-pass scatter with LDS staging: entries of the tile are ranked per low bin (LDS counters), placed in bin order in
@@ -430,8 +469,13 @@ static __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long 
 // adds (may be null): += sum over the buckets of min(size, cap) - 1, i.e. the mixed additions the accumulate kernel will do
 // (a bucket's first entry is a copy) -- the unit of the VALU roofline in bench.py.  `count_adds`: off for the merged form,
 // whose buckets span the windows (msm_merge_totals_kernel counts there).
-__global__ __launch_bounds__(256) void msm_size_hist_kernel(const uint32_t *totals, size_t WB, uint32_t cap, uint32_t *bins, unsigned long long *adds) {   // cap = the larger (top-window) cap
+static __device__ __forceinline__ uint32_t dyn_cap(const MsmDyn *dyn, uint32_t mult) {      // cap (x W for merged bucket lengths)
+    const unsigned long long c = (unsigned long long)dyn->cap * mult;
+    return c < (1ull << 30) ? (uint32_t)c : (1u << 30);
+}
+__global__ __launch_bounds__(256) void msm_size_hist_kernel(const uint32_t *totals, size_t WB, const MsmDyn *dyn, uint32_t mult, uint32_t *bins, unsigned long long *adds) {
     __shared__ uint32_t sh[SIZE_BINS];
+    const uint32_t cap = dyn_cap(dyn, mult);
     for (uint32_t i = threadIdx.x; i < SIZE_BINS; i += 256) sh[i] = 0;
     __syncthreads();
     unsigned long long mine = 0;
@@ -459,9 +503,10 @@ __global__ __launch_bounds__(SIZE_BINS) void msm_size_scan_kernel(uint32_t *bins
 }
 // ranks inside the workgroup come from LDS counters; one global atomic per (workgroup, non-empty class) reserves the
 // range -- with millions of similar-sized buckets a per-bucket global atomic serialises on a few dozen hot cursors
-__global__ __launch_bounds__(1024) void msm_size_scatter_kernel(const uint32_t *totals, size_t WB, uint32_t cap, uint32_t *cursor, uint32_t *perm) {
+__global__ __launch_bounds__(1024) void msm_size_scatter_kernel(const uint32_t *totals, size_t WB, const MsmDyn *dyn, uint32_t mult, uint32_t *cursor, uint32_t *perm) {
     __shared__ uint32_t cnt[SIZE_BINS];
     __shared__ uint32_t base[SIZE_BINS];
+    const uint32_t cap = dyn_cap(dyn, mult);
     const size_t g = (size_t)blockIdx.x * 1024 + threadIdx.x;
     cnt[threadIdx.x] = 0;                       // SIZE_BINS == blockDim.x == 1024
     __syncthreads();
@@ -536,12 +581,12 @@ template <class F, bool L29> struct Walker {       // host pass: declarations on
 template <class F, int MINW, bool L29>
 __global__ __launch_bounds__(256, MINW) void msm_accumulate_kernel(const Affine<F> *bases, const uint32_t *sorted, size_t n,
                                                              const uint32_t *starts, const uint32_t *totals, uint32_t B,
-                                                             uint32_t W, uint32_t cap_all, uint32_t cap_top, const uint32_t *perm, Xyzz<F> *buckets) {
+                                                             uint32_t W, const MsmDyn *dyn, const uint32_t *perm, Xyzz<F> *buckets) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (size_t)W * B) return;
     const size_t g = perm[t];                 // buckets of similar length share a wave
     const uint32_t w = (uint32_t)(g / B);
-    const uint32_t cap = (w == W - 1) ? cap_top : cap_all;
+    const uint32_t cap = dyn->cap;
     const uint32_t *src = sorted + (size_t)w * n + starts[g];
     uint32_t cnt = totals[g];
     if (cnt > cap) cnt = cap;
@@ -562,9 +607,10 @@ __global__ __launch_bounds__(256, MINW) void msm_accumulate_kernel(const Affine<
 template <class F, int MINW, bool L29>
 __global__ __launch_bounds__(256, MINW) void msm_accumulate_merged_kernel(const Affine<F> *bases, const Affine<F> *lev, const uint32_t *sorted, size_t n,
                                                                     const uint32_t *starts, const uint32_t *totals, uint32_t B,
-                                                                    uint32_t W, uint32_t cap, const uint32_t *perm, const uint32_t *mt, Xyzz<F> *buckets) {
+                                                                    uint32_t W, const MsmDyn *dyn, const uint32_t *perm, const uint32_t *mt, Xyzz<F> *buckets) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= B) return;
+    const uint32_t cap = dyn->cap;
     const uint32_t b = perm[t];
     const uint32_t total = mt[b];
     Walker<F, L29> acc;
@@ -590,8 +636,9 @@ __global__ __launch_bounds__(256, MINW) void msm_accumulate_merged_kernel(const 
     buckets[b] = acc.result();
 }
 // mt[b] = sum over the windows of min(totals[w][b], cap): the merged bucket's length, for the size ordering
-__global__ __launch_bounds__(256) void msm_merge_totals_kernel(const uint32_t *totals, uint32_t B, uint32_t W, uint32_t cap, uint32_t *mt, unsigned long long *adds) {
+__global__ __launch_bounds__(256) void msm_merge_totals_kernel(const uint32_t *totals, uint32_t B, uint32_t W, const MsmDyn *dyn, uint32_t *mt, unsigned long long *adds) {
     const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t cap = dyn->cap;
     uint32_t s = 0;
     if (b < B) {
         for (uint32_t w = 0; w < W; w++) { const uint32_t v = totals[(size_t)w * B + b]; s += v < cap ? v : cap; }
@@ -639,6 +686,7 @@ __global__ __launch_bounds__(256) void msm_level_kernel(const Affine<F> *in, siz
 }
 
 struct Task { uint32_t g, seg; };
+struct OverBucket { uint32_t g, task0, ntask; };
 
 // one WAVE per SEG-entry segment of an oversized bucket (entries beyond `cap`): many small workgroups keep
 // several waves per SIMD in flight (the multiply is a serial chain, one wave alone cannot fill the VALU).
@@ -647,39 +695,116 @@ struct Task { uint32_t g, seg; };
 template <class F, class FC, bool L29>
 __global__ __launch_bounds__(64) void msm_overflow_kernel(const Affine<F> *bases0, const Affine<F> *lev, const uint32_t *sorted, size_t n,
                                                           const uint32_t *starts, const uint32_t *totals, uint32_t B,
-                                                          uint32_t W, uint32_t cap_all, uint32_t cap_top, uint32_t SEG, const Task *tasks, Xyzz<FC> *partials) {
-    const Task t = tasks[blockIdx.x];
-    const uint32_t w = t.g / B;
-    const Affine<F> *bases = (lev && w) ? lev + (size_t)(w - 1) * n : bases0;      // merged form: window w's points come from level w
-    const uint32_t cap = (w == W - 1) ? cap_top : cap_all;
-    const uint32_t *src = sorted + (size_t)w * n + starts[t.g];
-    const uint32_t size = totals[t.g];
-    const uint32_t lo = cap + t.seg * SEG;
-    const uint32_t hi = lo + SEG < size ? lo + SEG : size;
-    Walker<F, L29> wk;
-    for (uint32_t k = lo + threadIdx.x; k < hi; k += 64) {
-        const uint32_t e = src[k];
-        wk.add(bases[e & 0x7fffffffu], (e >> 31) != 0);
+                                                          const MsmDyn *dyn, const Task *tasks, Xyzz<FC> *partials) {
+    const uint32_t cap = dyn->cap, SEG = dyn->seg, n_tasks = dyn->n_tasks;
+    for (uint32_t task = blockIdx.x; task < n_tasks; task += gridDim.x) {       // the grid is fixed: the host does not know the count
+        const Task t = tasks[task];
+        const uint32_t w = t.g / B;
+        const Affine<F> *bases = (lev && w) ? lev + (size_t)(w - 1) * n : bases0;      // merged form: window w's points come from level w
+        const uint32_t *src = sorted + (size_t)w * n + starts[t.g];
+        const uint32_t size = totals[t.g];
+        const uint32_t lo = cap + t.seg * SEG;
+        const uint32_t hi = lo + SEG < size ? lo + SEG : size;
+        Walker<F, L29> wk;
+        for (uint32_t k = lo + threadIdx.x; k < hi; k += 64) {
+            const uint32_t e = src[k];
+            wk.add(bases[e & 0x7fffffffu], (e >> 31) != 0);
+        }
+        const Xyzz<F> acc = wk.result();
+        static_assert(sizeof(Xyzz<F>) == sizeof(Xyzz<FC>), "layout");
+        Xyzz<FC> accc;
+        __builtin_memcpy(&accc, &acc, sizeof acc);
+        wave_reduce(accc);
+        if (threadIdx.x == 0) partials[task] = accc;
     }
-    const Xyzz<F> acc = wk.result();
-    static_assert(sizeof(Xyzz<F>) == sizeof(Xyzz<FC>), "layout");
-    Xyzz<FC> accc;
-    __builtin_memcpy(&accc, &acc, sizeof acc);
-    wave_reduce(accc);
-    if (threadIdx.x == 0) partials[blockIdx.x] = accc;
 }
-
-struct OverBucket { uint32_t g, task0, ntask; };
 
 // one 256-lane workgroup per oversized bucket: fold its partials into buckets[g]
 template <class F>
-__global__ __launch_bounds__(256) void msm_overflow_fold_kernel(const OverBucket *ob, const Xyzz<F> *partials, Xyzz<F> *buckets) {
+__global__ __launch_bounds__(256) void msm_overflow_fold_kernel(const OverBucket *ob, const MsmDyn *dyn, const Xyzz<F> *partials, Xyzz<F> *buckets) {
     __shared__ Xyzz<F> sh[4];
-    const OverBucket o = ob[blockIdx.x];
-    Xyzz<F> acc = Xyzz<F>::inf();
-    for (uint32_t k = threadIdx.x; k < o.ntask; k += 256) acc.add(partials[o.task0 + k]);
-    block_reduce_256(acc, sh);
-    if (threadIdx.x == 0) { Xyzz<F> b = buckets[o.g]; b.add(acc); buckets[o.g] = b; }
+    const uint32_t n_obs = dyn->n_obs;
+    for (uint32_t i = blockIdx.x; i < n_obs; i += gridDim.x) {
+        const OverBucket o = ob[i];
+        Xyzz<F> acc = Xyzz<F>::inf();
+        for (uint32_t k = threadIdx.x; k < o.ntask; k += 256) acc.add(partials[o.task0 + k]);
+        block_reduce_256(acc, sh);
+        if (threadIdx.x == 0) { Xyzz<F> b = buckets[o.g]; b.add(acc); buckets[o.g] = b; }
+        __syncthreads();             // sh is reused by the next bucket
+    }
+}
+
+// The segment table of the oversized buckets, built by ONE workgroup (there are at most OVER_MAX of them): the list is sorted by
+// (bucket, window) -- merged form: the oversized (window, bucket) pairs of one bucket fold into the same sum, one fold
+// workgroup for them all --, the segment length is chosen so that all oversized entries give about two waves per SIMD (a lone
+// giant bucket -- every scalar equal to 1 meets in one -- becomes a few additions per lane), and every segment gets a task.
+__global__ __launch_bounds__(1024) void msm_tasks_kernel(const OverEntry *over, MsmDyn *dyn, uint32_t B, int merged, Task *tasks, uint32_t max_tasks, OverBucket *obs) {
+    __shared__ unsigned long long key[OVER_MAX];      // (bucket << 32) | g
+    __shared__ uint32_t val[OVER_MAX];                 // size, then segments of the entry
+    __shared__ uint32_t t0[OVER_MAX + 1];              // first task of the entry
+    __shared__ uint32_t head[OVER_MAX + 1];            // start entry of every fold group
+    __shared__ uint32_t wsum[16];
+    __shared__ unsigned long long xsum[16];
+    const uint32_t tid = threadIdx.x;
+    uint32_t n = dyn->n_over; if (n > OVER_MAX) n = OVER_MAX;
+    if (n == 0) { if (tid == 0) { dyn->seg = SEG_MIN; dyn->n_tasks = 0; dyn->n_obs = 0; } return; }
+    const uint32_t cap = dyn->cap;
+    uint32_t npow = 1; while (npow < n) npow <<= 1;
+    for (uint32_t i = tid; i < npow; i += 1024) {
+        if (i < n) { const OverEntry e = over[i]; key[i] = ((unsigned long long)(merged ? e.g % B : e.g) << 32) | e.g; val[i] = e.size; }
+        else { key[i] = ~0ull; val[i] = 0; }
+    }
+    __syncthreads();
+    for (uint32_t k = 2; k <= npow; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = tid; i < npow; i += 1024) {
+                const uint32_t l = i ^ j;
+                if (l > i) {
+                    const bool up = (i & k) == 0;
+                    const unsigned long long a = key[i], b = key[l];
+                    if ((a > b) == up) { key[i] = b; key[l] = a; const uint32_t v = val[i]; val[i] = val[l]; val[l] = v; }
+                }
+            }
+            __syncthreads();
+        }
+    // total excess -> segment length
+    unsigned long long mine = 0;
+    for (uint32_t i = tid; i < n; i += 1024) mine += val[i] - cap;
+    mine = wave_sum_u64(mine);
+    if ((tid & 63) == 0) xsum[tid >> 6] = mine;
+    __syncthreads();
+    unsigned long long extra_total = 0;
+    for (int w = 0; w < 16; w++) extra_total += xsum[w];
+    unsigned long long sg = ((extra_total / 2048 + 63) / 64) * 64;
+    const uint32_t SEG = (uint32_t)(sg < SEG_MIN ? SEG_MIN : (sg > SEG_MAX ? SEG_MAX : sg));
+    // segments per entry, first task per entry (each lane owns a run of consecutive entries), fold groups
+    const uint32_t per = (n + 1023) / 1024, lo = tid * per, hi = lo + per < n ? lo + per : n;
+    uint32_t sum = 0, heads = 0;
+    for (uint32_t i = lo; i < hi && lo < n; i++) {
+        const uint32_t nt = (val[i] - cap + SEG - 1) / SEG;
+        val[i] = nt; sum += nt;
+        heads += (i == 0 || (key[i] >> 32) != (key[i - 1] >> 32)) ? 1u : 0u;
+    }
+    uint32_t n_tasks, n_obs;
+    uint32_t run = block_excl_scan_1024(sum, wsum, &n_tasks);
+    uint32_t hrun = block_excl_scan_1024(heads, wsum, &n_obs);
+    for (uint32_t i = lo; i < hi && lo < n; i++) {
+        t0[i] = run; run += val[i];
+        if (i == 0 || (key[i] >> 32) != (key[i - 1] >> 32)) head[hrun++] = i;
+    }
+    if (tid == 0) { t0[n] = n_tasks; head[n_obs] = n; }
+    __syncthreads();
+    if (n_tasks > max_tasks) { if (tid == 0) { dyn->error = 2; dyn->seg = SEG; dyn->n_tasks = 0; dyn->n_obs = 0; } return; }
+    for (uint32_t o = tid; o < n_obs; o += 1024) {
+        const uint32_t a = head[o], b = head[o + 1];
+        obs[o] = OverBucket{(uint32_t)(merged ? key[a] >> 32 : key[a] & 0xffffffffu), t0[a], t0[b] - t0[a]};
+    }
+    for (uint32_t t = tid; t < n_tasks; t += 1024) {
+        uint32_t l = 0, h = n;                 // the entry with t0[l] <= t < t0[l + 1]
+        while (h - l > 1) { const uint32_t mid = (l + h) >> 1; if (t0[mid] <= t) l = mid; else h = mid; }
+        tasks[t] = Task{(uint32_t)(key[l] & 0xffffffffu), t - t0[l]};
+    }
+    if (tid == 0) { dyn->seg = SEG; dyn->n_tasks = n_tasks; dyn->n_obs = n_obs; }
 }
 
 // ------------------------------------------------------------------------------------------ bucket reduction
@@ -760,11 +885,11 @@ static int lane_stage(fk_ctx *ctx, MsmLane &ln, size_t bytes) {     // pinned st
     return FK_OK;
 }
 
-// Queues one multiplication on a lane: digits, two-pass bucket sort, size ordering (host reads back the tile count
-// in the middle and the oversized-bucket list at the end -- the only two points where the host waits), then
-// accumulation, oversized buckets, bucket reduction and the download of the window sums, all without further host
-// involvement.  While the host sits in the sort's read-backs of multiplication k+1, the GPU works on the
-// accumulation of multiplication k on the other lane.
+// Queues one multiplication on a lane: digits, two-pass bucket sort, size ordering, accumulation, oversized buckets, bucket
+// reduction and the download of the window sums (with the addition count and the device-side error word behind them) -- all
+// without the host waiting anywhere (the only synchronisation left is when a lane's scratch buffers have to GROW, i.e. in
+// the first proof of a size).  The five multiplications of a proof are therefore in the lanes' queues microseconds after
+// the quotient's kernels, and the GPU decides what runs underneath what.
 template <class F>
 static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars, size_t n, bool reuse_sort, int *tail_out, hipEvent_t ready, const KeyPre *pre = nullptr) {
     using FC = typename ColdOf<F>::type;   // layout-identical field with an out-of-line multiply
@@ -814,16 +939,16 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
     const size_t WB = (size_t)p.W * p.B;
     const uint32_t WR = merged ? 1 : p.W;      // bucket sets to reduce
     const size_t wp_bytes = (size_t)WR * p.nblk * sizeof(Xyzz<F>);
-    // every oversized bucket holds more than `cap` of the W * n entries, so there can be at most W * n / cap of them: the
-    // list is sized for that worst case (witnesses with many repeated values put thousands of buckets over the cap)
-    const uint32_t over_cap = (uint32_t)std::min<uint64_t>((uint64_t)p.W * n / (p.cap ? p.cap : 1) + 64, 0x7fffffffu);
+    // oversized buckets: at most OVER_MAX are tabled; their segment tasks are bounded by max(2048, W n / SEG_MAX) + one per bucket
+    const size_t max_tasks = std::max<size_t>(2048, (size_t)p.W * n / SEG_MAX) + OVER_MAX + 64;
     // Growing a buffer frees the old one: everything queued on this lane must be finished first.
     const uint32_t nseg = p.W * p.nhi;
     const size_t max_tiles = (size_t)p.W * ((n + S2_TILE - 1) / S2_TILE) + nseg + 1;
     struct Need { DevBuf *b; size_t bytes; };
     const Need needs[] = {
         {&ln.digits, (size_t)p.W * n * 4}, {&ln.sorted, (size_t)p.W * n * 4}, {&ln.totals, WB * 4}, {&ln.starts, WB * 4},
-        {&ln.perm, WB * 4 + SIZE_BINS * 4}, {&ln.overlist, over_cap * sizeof(OverEntry) + 32}, {&ln.buckets, WB * sizeof(Xyzz<F>)},
+        {&ln.perm, WB * 4 + SIZE_BINS * 4}, {&ln.overlist, OVER_MAX * sizeof(OverEntry) + sizeof(MsmDyn) + 64}, {&ln.buckets, WB * sizeof(Xyzz<F>)},
+        {&ln.tasktab, max_tasks * sizeof(Task) + OVER_MAX * sizeof(OverBucket) + 64}, {&ln.partials, max_tasks * sizeof(Xyzz<F>)},
         {&ln.s2_cnt1, (size_t)p.W * p.nchunks * p.nhi * 4}, {&ln.s2_seg, ((size_t)nseg * 4 + 2) * 4}, {&ln.s2_cnt2, max_tiles * p.nlo * 4},
         {&ln.s2_tmp_idx, (size_t)p.W * n * 4}, {&ln.s2_tmp_lo, (size_t)p.W * n * 2}};
     bool grow = false;
@@ -835,25 +960,26 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
         if (!have_sort) ln.last_sort_scalars = nullptr;
     }
     FK_HIP(ctx, tl.d_wp.reserve(wp_bytes));
-    if (wp_bytes + 8 > tl.h_cap) {          // + the additions counter
+    if (wp_bytes + 16 > tl.h_cap) {         // + the additions counter and the error word
         if (tl.h_wp) { FK_HIP(ctx, hipHostFree(tl.h_wp)); tl.h_wp = nullptr; tl.h_cap = 0; }
-        FK_HIP(ctx, hipHostMalloc(&tl.h_wp, wp_bytes + (wp_bytes >> 2) + 8, hipHostMallocDefault));
-        tl.h_cap = wp_bytes + (wp_bytes >> 2) + 8;
+        FK_HIP(ctx, hipHostMalloc(&tl.h_wp, wp_bytes + (wp_bytes >> 2) + 16, hipHostMallocDefault));
+        tl.h_cap = wp_bytes + (wp_bytes >> 2) + 16;
     }
-    uint32_t *d_nover = (uint32_t *)((char *)ln.overlist.p + over_cap * sizeof(OverEntry));
-    unsigned long long *d_adds = (unsigned long long *)(d_nover + 2);      // mixed additions of the accumulate kernel (statistics); lives as long as the sort
+    MsmDyn *dyn = (MsmDyn *)((char *)ln.overlist.p + OVER_MAX * sizeof(OverEntry));       // device-side state of this lane's sort
+    unsigned long long *d_adds = &dyn->adds;
+    Task *d_tasks = ln.tasktab.as<Task>();
+    OverBucket *d_obs = (OverBucket *)((char *)ln.tasktab.p + ((max_tasks * sizeof(Task) + 15) & ~(size_t)15));
     uint32_t *digits = ln.digits.as<uint32_t>(), *sorted = ln.sorted.as<uint32_t>();
     uint32_t *totals = ln.totals.as<uint32_t>(), *starts = ln.starts.as<uint32_t>();
     Xyzz<F> *buckets = ln.buckets.as<Xyzz<F>>(), *winparts = tl.d_wp.as<Xyzz<F>>();
     uint32_t *perm = ln.perm.as<uint32_t>(), *size_bins = perm + WB;
-    FK_TRY(lane_stage(ctx, ln, 64 + (size_t)over_cap * sizeof(OverEntry)));
 
     if (!have_sort) {
         ln.last_sort_scalars = nullptr;
         hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)(((n + 1) / 2 + 63) / 64)), dim3(64), 0, ss, d_scalars, n, p.cb, p.wide, p.W, digits);
         FK_HIP(ctx, hipGetLastError());
         FK_DBG_ST(ctx, ss, "msm_digits");
-        FK_HIP(ctx, hipMemsetAsync(d_nover, 0, 4, ss));
+        FK_HIP(ctx, hipMemsetAsync(dyn, 0, sizeof(MsmDyn), ss));
         uint32_t *cnt1 = ln.s2_cnt1.as<uint32_t>();
         uint32_t *seg_size = ln.s2_seg.as<uint32_t>(), *seg_start = seg_size + nseg, *seg_tiles = seg_start + nseg, *tile_start = seg_tiles + nseg;
         uint32_t *cnt2 = ln.s2_cnt2.as<uint32_t>(), *tmp_idx = ln.s2_tmp_idx.as<uint32_t>();
@@ -872,101 +998,46 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
         {
             hipLaunchKernelGGL(s2_hist2_kernel, dim3(n_tiles), dim3(256), p.nlo * 4, ss, tmp_lo, n, p.nhi, p.nlo, tile_start, nseg, seg_start, seg_size, cnt2);
         }
-        hipLaunchKernelGGL(s2_prefix2_kernel, dim3(nseg), dim3(1024), 0, ss, cnt2, p.nhi, p.nlo, p.B, tile_start, seg_start, p.cap, p.cap_top, p.W, totals, starts,
-                           ln.overlist.as<OverEntry>(), d_nover, over_cap);
+        hipLaunchKernelGGL(s2_prefix2_kernel, dim3(nseg), dim3(1024), 0, ss, cnt2, p.nhi, p.nlo, p.B, tile_start, seg_start, p.cap ? p.cap : 1u, totals, starts, dyn);
         hipLaunchKernelGGL(s2_scatter2_kernel, dim3(n_tiles), dim3(1024), 0, ss, tmp_idx, tmp_lo, n, p.nhi, p.nlo, p.B, tile_start, nseg, seg_start,
                            seg_size, cnt2, starts, sorted);
         FK_HIP(ctx, hipGetLastError());
         FK_DBG_ST(ctx, ss, "msm_sort_pass2");
         ln.last_sort_scalars = (const void *)d_scalars; ln.last_sort_n = n; ln.last_sort_c = p.c; ln.last_merged = merged;
     }
-    // oversized buckets (skewed scalars): known once the sort is done -- the host builds the segment table now, so that
-    // nothing has to wait for the accumulation.  With a reused sort the tables of the previous call are still valid.
-    uint32_t n_over = ln.last_n_over, SEG = ln.last_seg, cap = ln.last_cap;
-    size_t n_tasks = ln.last_n_tasks, n_obs = ln.last_n_obs, tb_al = ln.last_tb_al;
+    // oversized buckets (skewed scalars), size ordering: all on the device (MsmDyn) -- nothing below waits for the host.  With a
+    // reused sort (B2 after B1) the lane's state and tables are still valid.
     if (!have_sort) {
-        uint32_t *h_nover = (uint32_t *)ln.h_stage + 4;
-        OverEntry *h_over = (OverEntry *)((char *)ln.h_stage + 64);
-        FK_HIP(ctx, hipMemcpyAsync(h_nover, d_nover, 4, hipMemcpyDeviceToHost, ss));
-        FK_HIP(ctx, hipStreamSynchronize(ss));
-        n_over = *h_nover;
-        cap = p.cap;
-        // The cap assumes Poisson bucket loads.  Scalars with many repeated values (a batch witness) put tens of thousands of
-        // buckets a little over it, and one wave per such bucket is a poor trade: double the cap until few remain.
-        // ("few": every oversized bucket costs a wave per segment plus a 256-lane fold workgroup -- with 4e5 of them, what WB / 64
-        // used to allow at 2^25, the overflow + fold kernels took 70 ms of a proof whose witness held each value 341 times)
         static int t_many = -1;
         if (t_many < 0) { const char *e = getenv("FK_MSM_OVER_MANY"); t_many = e ? atoi(e) : 2048; }
-        const uint32_t many = (uint32_t)std::max<size_t>((size_t)t_many, WB / 8192);
-        while (n_over > many && cap < (1u << 20)) {
-            cap *= 2;
-            FK_HIP(ctx, hipMemsetAsync(d_nover, 0, 4, ss));
-            hipLaunchKernelGGL(msm_over_scan_kernel, dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, ss, totals, WB, cap, ln.overlist.as<OverEntry>(), d_nover, over_cap);
-            FK_HIP(ctx, hipGetLastError());
-            FK_HIP(ctx, hipMemcpyAsync(h_nover, d_nover, 4, hipMemcpyDeviceToHost, ss));
-            FK_HIP(ctx, hipStreamSynchronize(ss));
-            n_over = *h_nover;
-        }
+        // "few": every oversized bucket costs a wave per segment plus a 256-lane fold workgroup -- with 4e5 of them, what round 1's
+        // WB / 64 allowed at 2^25, the overflow + fold kernels took 70 ms of a proof whose witness held each value 341 times
+        const uint32_t many = (uint32_t)std::min<size_t>(std::max<size_t>((size_t)t_many, WB / 8192), OVER_MAX - 64);
+        hipLaunchKernelGGL(msm_cap_kernel, dim3(1), dim3(64), 0, ss, dyn, p.cap ? p.cap : 1u, many);
+        hipLaunchKernelGGL(msm_over_list_kernel, dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, ss, totals, WB, ln.overlist.as<OverEntry>(), dyn);
+        hipLaunchKernelGGL(msm_tasks_kernel, dim3(1), dim3(1024), 0, ss, ln.overlist.as<OverEntry>(), dyn, p.B, merged ? 1 : 0, d_tasks, (uint32_t)max_tasks, d_obs);
         // size-ordered bucket -> lane assignment
         FK_HIP(ctx, hipMemsetAsync(size_bins, 0, SIZE_BINS * 4, ss));
-        FK_HIP(ctx, hipMemsetAsync(d_adds, 0, 8, ss));
         if (merged) {     // one bucket set: order its B buckets by their length over all windows (perm[0, B); lengths kept behind it)
             uint32_t *mt = perm + p.B;
-            const uint32_t mcap = (uint32_t)std::min<uint64_t>((uint64_t)cap * p.W, 1u << 30);
-            hipLaunchKernelGGL(msm_merge_totals_kernel, dim3((p.B + 255) / 256), dim3(256), 0, ss, totals, p.B, p.W, cap, mt, d_adds);
-            hipLaunchKernelGGL(msm_size_hist_kernel, dim3((unsigned)std::min<size_t>((p.B + 255) / 256, 1024)), dim3(256), 0, ss, mt, (size_t)p.B, mcap, size_bins, (unsigned long long *)nullptr);
+            hipLaunchKernelGGL(msm_merge_totals_kernel, dim3((p.B + 255) / 256), dim3(256), 0, ss, totals, p.B, p.W, dyn, mt, d_adds);
+            hipLaunchKernelGGL(msm_size_hist_kernel, dim3((unsigned)std::min<size_t>((p.B + 255) / 256, 1024)), dim3(256), 0, ss, mt, (size_t)p.B, dyn, p.W, size_bins, (unsigned long long *)nullptr);
             hipLaunchKernelGGL(msm_size_scan_kernel, dim3(1), dim3(SIZE_BINS), 0, ss, size_bins);
-            hipLaunchKernelGGL(msm_size_scatter_kernel, dim3((unsigned)((p.B + 1023) / 1024)), dim3(1024), 0, ss, mt, (size_t)p.B, mcap, size_bins, perm);
+            hipLaunchKernelGGL(msm_size_scatter_kernel, dim3((unsigned)((p.B + 1023) / 1024)), dim3(1024), 0, ss, mt, (size_t)p.B, dyn, p.W, size_bins, perm);
         } else {
-        hipLaunchKernelGGL(msm_size_hist_kernel, dim3((unsigned)std::min<size_t>((WB + 255) / 256, 1024)), dim3(256), 0, ss, totals, WB, cap, size_bins, d_adds);
-        hipLaunchKernelGGL(msm_size_scan_kernel, dim3(1), dim3(SIZE_BINS), 0, ss, size_bins);
-        hipLaunchKernelGGL(msm_size_scatter_kernel, dim3((unsigned)((WB + 1023) / 1024)), dim3(1024), 0, ss, totals, WB, cap, size_bins, perm);
+            hipLaunchKernelGGL(msm_size_hist_kernel, dim3((unsigned)std::min<size_t>((WB + 255) / 256, 1024)), dim3(256), 0, ss, totals, WB, dyn, 1u, size_bins, d_adds);
+            hipLaunchKernelGGL(msm_size_scan_kernel, dim3(1), dim3(SIZE_BINS), 0, ss, size_bins);
+            hipLaunchKernelGGL(msm_size_scatter_kernel, dim3((unsigned)((WB + 1023) / 1024)), dim3(1024), 0, ss, totals, WB, dyn, 1u, size_bins, perm);
         }
         FK_HIP(ctx, hipGetLastError());
         FK_DBG_ST(ctx, ss, "msm_size_order");
-        if (ctx->debug) { fprintf(stderr, "[fk] msm n=%zu c=%u (W=%u: %u x %u bits + %u x %u bits) cap=%u (plan %u): %u oversized buckets\n", n, p.c, p.W, p.wide, p.cb + 1, p.W - p.wide, p.cb, cap, p.cap, n_over); fflush(stderr); }
-        if (n_over > over_cap) { ln.last_sort_scalars = nullptr; FK_SET_ERR(ctx, FK_ERR_HIP, "msm: %u oversized buckets exceed the bound %u", n_over, over_cap); }
-        n_tasks = n_obs = tb_al = 0; SEG = SEG_MIN;
-        if (n_over) {
-            FK_HIP(ctx, hipMemcpyAsync(h_over, ln.overlist.p, n_over * sizeof(OverEntry), hipMemcpyDeviceToHost, ss));
-            FK_HIP(ctx, hipStreamSynchronize(ss));
-            std::vector<OverEntry> ov(h_over, h_over + n_over);
-            const uint32_t Bm = p.B;
-            if (merged) std::sort(ov.begin(), ov.end(), [Bm](const OverEntry &a, const OverEntry &b) { return a.g % Bm != b.g % Bm ? a.g % Bm < b.g % Bm : a.g < b.g; });
-            else std::sort(ov.begin(), ov.end(), [](const OverEntry &a, const OverEntry &b) { return a.g < b.g; });
-            std::vector<Task> tasks;
-            std::vector<OverBucket> obs;
-            // segment length: about two waves per SIMD over all oversized entries, so that a lone giant bucket (all the
-            // scalars equal to 1 meet in one) is a few additions per lane instead of a 64-addition serial walk
-            uint64_t extra_total = 0;
-            for (const OverEntry &e : ov) extra_total += e.size - cap;
-            SEG = (uint32_t)std::min<uint64_t>(SEG_MAX, std::max<uint64_t>(SEG_MIN, ((extra_total / 2048 + 63) / 64) * 64));
-            for (const OverEntry &e : ov) {
-                const uint32_t cap_w = cap;
-                const uint32_t extra = e.size - cap_w;
-                const uint32_t nt = (extra + SEG - 1) / SEG;
-                // merged form: the oversized (window, bucket) pairs of one bucket fold into the same sum -> one fold workgroup for them all
-                if (merged && !obs.empty() && obs.back().g == e.g % Bm) obs.back().ntask += nt;
-                else obs.push_back(OverBucket{merged ? e.g % Bm : e.g, (uint32_t)tasks.size(), nt});
-                for (uint32_t s = 0; s < nt; s++) tasks.push_back(Task{e.g, s});
-            }
-            n_tasks = tasks.size(); n_obs = obs.size();
-            const size_t tb = n_tasks * sizeof(Task), ob = n_obs * sizeof(OverBucket);
-            tb_al = (tb + 15) & ~(size_t)15;
-            // the lane is idle here (just synchronised), so its buffers and the pinned staging area can be regrown / reused
-            FK_HIP(ctx, ln.tasktab.reserve(tb_al + ob));
-            FK_TRY(lane_stage(ctx, ln, 64 + tb_al + ob));
-            memcpy((char *)ln.h_stage + 64, tasks.data(), tb);
-            memcpy((char *)ln.h_stage + 64 + tb_al, obs.data(), ob);
-            FK_HIP(ctx, hipMemcpyAsync(ln.tasktab.p, (char *)ln.h_stage + 64, tb_al + ob, hipMemcpyHostToDevice, ss));
+        if (ctx->debug) {
+            MsmDyn h{};
+            FK_HIP(ctx, hipMemcpy(&h, dyn, sizeof h, hipMemcpyDeviceToHost));
+            fprintf(stderr, "[fk] msm n=%zu c=%u (W=%u: %u x %u bits + %u x %u bits) cap=%u (plan %u): %u oversized buckets, %u tasks of %u entries, %u fold groups\n", n, p.c,
+                    p.W, p.wide, p.cb + 1, p.W - p.wide, p.cb, h.cap, p.cap, h.n_over, h.n_tasks, h.seg, h.n_obs);
+            fflush(stderr);
         }
-        ln.last_n_over = n_over; ln.last_seg = SEG; ln.last_cap = cap; ln.last_n_tasks = n_tasks; ln.last_n_obs = n_obs; ln.last_tb_al = tb_al;
-    }
-    Task *d_tasks = ln.tasktab.as<Task>();
-    OverBucket *d_obs = (OverBucket *)((char *)ln.tasktab.p + tb_al);
-    if (n_tasks * sizeof(Xyzz<F>) > ln.partials.cap) {      // growing frees the old array: the lane must be idle
-        FK_HIP(ctx, hipStreamSynchronize(ss));
-        FK_HIP(ctx, ln.partials.reserve(n_tasks * sizeof(Xyzz<F>)));
     }
 
     // ---- from here on nothing waits for the host
@@ -985,29 +1056,28 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
     constexpr int MINW_ = IS_G1 ? 4 : 2;
     if (merged) {
         if (l29) hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_merged_kernel<F, (IS_G1 ? 3 : 2), IS_G1>), dim3((p.B + 255) / 256), dim3(256), 0, st, d_bases, d_lev, sorted, n,
-                                    starts, totals, p.B, p.W, cap, perm, perm + p.B, buckets);
+                                    starts, totals, p.B, p.W, dyn, perm, perm + p.B, buckets);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_merged_kernel<F, MINW_, false>), dim3((p.B + 255) / 256), dim3(256), 0, st, d_bases, d_lev, sorted, n,
-                                starts, totals, p.B, p.W, cap, perm, perm + p.B, buckets);
+                                starts, totals, p.B, p.W, dyn, perm, perm + p.B, buckets);
     } else {
         if (l29) hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_kernel<F, (IS_G1 ? 3 : 2), IS_G1>), dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, d_bases, sorted, n,
-                                    starts, totals, p.B, p.W, cap, cap, perm, buckets);
+                                    starts, totals, p.B, p.W, dyn, perm, buckets);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_kernel<F, MINW_, false>), dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, d_bases, sorted, n,
-                                starts, totals, p.B, p.W, cap, cap, perm, buckets);
+                                starts, totals, p.B, p.W, dyn, perm, buckets);
     }
     FK_HIP(ctx, hipGetLastError());
     FK_TRY(stats_end(ctx, evv, st));
     if (!ctx->ev_acc_done) FK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_acc_done, hipEventDisableTiming));
     FK_HIP(ctx, hipEventRecord(ctx->ev_acc_done, st)); ctx->ev_acc_done_valid = true;
     FK_DBG_ST(ctx, st, "msm_accumulate");
-    if (n_over) {
-        if (l29) hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_overflow_kernel<F, FC, IS_G1>), dim3((unsigned)n_tasks), dim3(64), 0, st,
-                                    d_bases, d_lev, sorted, n, starts, totals, p.B, p.W, cap, cap, SEG, d_tasks, ln.partials.as<Xyzz<FC>>());
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_overflow_kernel<F, FC, false>), dim3((unsigned)n_tasks), dim3(64), 0, st,
-                                d_bases, d_lev, sorted, n, starts, totals, p.B, p.W, cap, cap, SEG, d_tasks, ln.partials.as<Xyzz<FC>>());
+    {   // oversized buckets: fixed grids looping over the device-built tables (they leave at once when there is nothing to do)
+        if (l29) hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_overflow_kernel<F, FC, IS_G1>), dim3(2048), dim3(64), 0, st,
+                                    d_bases, d_lev, sorted, n, starts, totals, p.B, dyn, d_tasks, ln.partials.as<Xyzz<FC>>());
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_overflow_kernel<F, FC, false>), dim3(2048), dim3(64), 0, st,
+                                d_bases, d_lev, sorted, n, starts, totals, p.B, dyn, d_tasks, ln.partials.as<Xyzz<FC>>());
         FK_HIP(ctx, hipGetLastError());
         FK_DBG_ST(ctx, st, "msm_overflow");
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_overflow_fold_kernel<F>), dim3((unsigned)n_obs), dim3(256), 0, st, d_obs,
-                           ln.partials.as<Xyzz<F>>(), buckets);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_overflow_fold_kernel<F>), dim3(256), dim3(256), 0, st, d_obs, dyn, ln.partials.as<Xyzz<F>>(), buckets);
         FK_HIP(ctx, hipGetLastError());
         FK_DBG_ST(ctx, st, "msm_overflow_fold");
     }
@@ -1016,6 +1086,7 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
     FK_HIP(ctx, hipGetLastError());
     FK_HIP(ctx, hipMemcpyAsync(tl.h_wp, winparts, wp_bytes, hipMemcpyDeviceToHost, st));
     FK_HIP(ctx, hipMemcpyAsync((char *)tl.h_wp + wp_bytes, d_adds, 8, hipMemcpyDeviceToHost, st));
+    FK_HIP(ctx, hipMemcpyAsync((char *)tl.h_wp + wp_bytes + 8, &dyn->error, 4, hipMemcpyDeviceToHost, st));
     FK_HIP(ctx, hipEventRecord(tl.done, st));
     if (split) { FK_HIP(ctx, hipEventRecord(ln.ev_lane_done, st)); ln.ev_lane_done_valid = true; }
     FK_DBG_ST(ctx, st, "msm_bucket_reduce");
@@ -1033,7 +1104,11 @@ static int msm_end(fk_ctx *ctx, int tail, Xyzz<F> *out) {
     tl.active = false;
     FK_HIP(ctx, hipEventSynchronize(tl.done));
     const Xyzz<F> *wp = (const Xyzz<F> *)tl.h_wp;
-    { uint64_t adds; memcpy(&adds, (const char *)tl.h_wp + (size_t)tl.W * tl.nblk * sizeof(Xyzz<F>), 8); ctx->acc_adds[sizeof(F) == sizeof(Fq) ? 0 : 1] += adds; }
+    { const char *extra = (const char *)tl.h_wp + (size_t)tl.W * tl.nblk * sizeof(Xyzz<F>);
+      uint64_t adds; uint32_t err;
+      memcpy(&adds, extra, 8); memcpy(&err, extra + 8, 4);
+      ctx->acc_adds[sizeof(F) == sizeof(Fq) ? 0 : 1] += adds;
+      if (err) FK_SET_ERR(ctx, FK_ERR_HIP, "msm: the oversized-bucket tables overflowed (%s)", err == 1 ? "more than OVER_MAX buckets above the cap" : "more segment tasks than the bound"); }
     // Horner over windows, most significant first
     Xyzz<F> acc = Xyzz<F>::inf();
     for (uint32_t w = tl.W; w-- > 0;) {

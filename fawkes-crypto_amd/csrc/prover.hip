@@ -320,8 +320,10 @@ static int witness_begin(fk_ctx *ctx, const fk_key *key, const Fr *d_z, const ui
     // Three lanes keep A from queueing behind B2's long G2 tail: 2^20 14.9 -> 13.3 ms, 2^22 28.0 -> 25.6 ms per proof.  At 2^25
     // it depends on the witness: with mostly trivial B-query scalars (the synthetic shape) the tails are short and a third
     // lane's co-running costs 1 %, with dense ones (1024 rollup transactions: G2 accumulation 35 ms) it gains 2 % -- 216.0 ->
-    // 211.2 ms (profiles/r02_lanes_probe.log; one lane, no overlap at all: 227.3).  Three everywhere.
-    ctx->lanes_in_use = MSM_LANES;
+    // 211.2 ms (profiles/r02_lanes_probe.log; one lane, no overlap at all: 227.3).  Since a multiplication is queued without
+    // a host round trip (msm.hip) the picture at the top end changed: at 2^25 two lanes are 1 % ahead of three (195.1 vs
+    // 197.5 ms, one lane 207.2), below that three still win by 1.5-5 % (profiles/r02_async_msm_ab_probe.log).
+    ctx->lanes_in_use = key->m >= (1ull << 25) ? 2 : MSM_LANES;
     FK_HIP(ctx, hipSetDevice(ctx->device));
     if (!ctx->aux) {
         FK_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
@@ -413,7 +415,7 @@ static int prove_msms_dev(fk_ctx *ctx, const fk_key *key, Fr *d_a, Fr *d_b, Fr *
     Fr *d_h = ctx->hbuf.as<Fr>();
     uint64_t m = 0;
     ctx->lane_next = 0;     // same lane for the same multiplication in every proof: lane buffers keep their sizes
-    ctx->lanes_in_use = MSM_LANES;
+    ctx->lanes_in_use = key->m >= (1ull << 25) ? 2 : MSM_LANES;      // measured, see fk_prove_msms_z_begin_dev
     // The witness multiplications depend on z only: they are begun right behind the QUEUED quotient, so that their sorts (and what
     // fits of their accumulations) fill the transforms' gaps: 214.5 -> 206.9 ms per proof on the 1024-transaction system
     // (profiles/r02_cusplit_witness_first_probe.log), and at every smaller size measured -- synthetic 2^20 13.4 -> 11.1 ms,
