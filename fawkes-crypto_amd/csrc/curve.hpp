@@ -65,6 +65,10 @@ struct alignas(16) Xyzz {
     // acc += q (affine), madd-2008-s with the exceptional cases handled
     FK_HD void add_mixed(const Affine<F> &q) {
         if (q.is_inf()) return;
+        add_mixed_nz(q);
+    }
+    // the same for a q known not to be the point at infinity
+    FK_HD void add_mixed_nz(const Affine<F> &q) {
         if (is_inf()) { x = q.x; y = q.y; zz = F::one(); zzz = F::one(); return; }
         // the ten multiplications form five independent pairs -> five dual-chain products (F::mul2)
         F u2, s2;

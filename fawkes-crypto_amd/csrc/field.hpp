@@ -28,13 +28,25 @@
 
 namespace fk {
 
+// p: the modulus of the Montgomery reduction.  q: the modulus additions and subtractions reduce by -- p for the canonical
+// form [0, p); 2p for the LAZY form [0, 2p), whose product skips the final conditional subtraction (4p < 2^256, so inputs
+// below 2p give a result below 2p) -- ~25 of the product's ~330 instructions.  Lazy values are congruent, not equal: only
+// accumulators that are canonicalised before they leave a kernel use them (msm.hip).
 struct FqParams {
+    static constexpr bool LAZY = false;
+    static constexpr FK_HD uint32_t q(int i) { constexpr uint32_t t[8] = FK_FQ_P; return t[i]; }
     static constexpr FK_HD uint32_t p(int i) { constexpr uint32_t t[8] = FK_FQ_P; return t[i]; }
     static constexpr FK_HD uint32_t one(int i) { constexpr uint32_t t[8] = FK_FQ_R; return t[i]; }
     static constexpr FK_HD uint32_t r2(int i) { constexpr uint32_t t[8] = FK_FQ_R2; return t[i]; }
     static constexpr uint32_t INV = FK_FQ_INV;
 };
+struct FqLazyParams : FqParams {
+    static constexpr bool LAZY = true;
+    static constexpr FK_HD uint32_t q(int i) { constexpr uint32_t t[8] = FK_FQ_2P; return t[i]; }
+};
 struct FrParams {
+    static constexpr bool LAZY = false;
+    static constexpr FK_HD uint32_t q(int i) { constexpr uint32_t t[8] = FK_FR_P; return t[i]; }
     static constexpr FK_HD uint32_t p(int i) { constexpr uint32_t t[8] = FK_FR_P; return t[i]; }
     static constexpr FK_HD uint32_t one(int i) { constexpr uint32_t t[8] = FK_FR_R; return t[i]; }
     static constexpr FK_HD uint32_t r2(int i) { constexpr uint32_t t[8] = FK_FR_R2; return t[i]; }
@@ -64,9 +76,16 @@ struct alignas(16) Fp {
         uint32_t o = 0;
 #pragma unroll
         for (int i = 0; i < 8; i++) o |= v[i];
+        if constexpr (P::LAZY) {        // 0 or p
+            uint32_t e = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) e |= v[i] ^ P::p(i);
+            return o == 0 || e == 0;
+        }
         return o == 0;
     }
     friend FK_HD bool operator==(const Fp &a, const Fp &b) {
+        if constexpr (P::LAZY) return sub(a, b).is_zero();
         uint32_t o = 0;
 #pragma unroll
         for (int i = 0; i < 8; i++) o |= a.v[i] ^ b.v[i];
@@ -87,6 +106,21 @@ struct alignas(16) Fp {
         for (int i = 0; i < 8; i++) r.v[i] = br ? a.v[i] : d.v[i];
         return r;
     }
+    // r = a - q if a >= q (a < 2q): the tail of an addition
+    static FK_HD Fp reduce_q(const Fp &a) {
+        Fp d; uint32_t br = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            uint64_t t = (uint64_t)a.v[i] - P::q(i) - br;
+            d.v[i] = (uint32_t)t; br = (uint32_t)(t >> 63);
+        }
+        Fp r;
+#pragma unroll
+        for (int i = 0; i < 8; i++) r.v[i] = br ? a.v[i] : d.v[i];
+        return r;
+    }
+    // the tail of a product: the conditional subtraction of p, or nothing in the lazy form
+    static FK_HD Fp fin(const Fp &a) { if constexpr (P::LAZY) return a; else return reduce_once(a); }
 
     // Addition / subtraction.  Device: generated carry chains (addsub_gfx950.inc, ~30 instructions instead of the ~90 hipcc
     // makes of the C loops below, which remain the host code and the reference).  The *2 forms run two independent
@@ -98,8 +132,8 @@ struct alignas(16) Fp {
             uint64_t t = (uint64_t)a.v[i] + b.v[i] + c;
             s.v[i] = (uint32_t)t; c = (uint32_t)(t >> 32);
         }
-        // p < 2^254 so a + b < 2^255: no carry out of limb 7
-        return reduce_once(s);
+        // p < 2^254 so a + b < 2^255 (lazy: < 2^256): no carry out of limb 7
+        return reduce_q(s);
     }
     static FK_HD Fp sub_c(const Fp &a, const Fp &b) {
         Fp d; uint32_t br = 0;
@@ -111,7 +145,7 @@ struct alignas(16) Fp {
         uint32_t mask = 0u - br, c = 0;
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-            uint64_t t = (uint64_t)d.v[i] + (P::p(i) & mask) + c;
+            uint64_t t = (uint64_t)d.v[i] + (P::q(i) & mask) + c;
             d.v[i] = (uint32_t)t; c = (uint32_t)(t >> 32);
         }
         return d;
@@ -144,6 +178,7 @@ struct alignas(16) Fp {
     }
 
 #if defined(__HIP_DEVICE_COMPILE__)
+    static FK_HD void fin2(const Fp &x, const Fp &y, Fp &r1, Fp &r2) { if constexpr (P::LAZY) { r1 = x; r2 = y; } else red2(x, y, r1, r2); }
 #include "mont_mul_gfx950.inc"
 #endif
 
@@ -182,11 +217,11 @@ struct alignas(16) Fp {
             top += c;
             t[7] = (uint32_t)top; t8 = (uint32_t)(top >> 32);
         }
-        // a, b < p < 2^254 keeps the running value < 2p, so t8 == 0 here
+        // a, b < 2p and 4p < 2^256 keep the running value < 2p, so t8 == 0 here
         Fp r;
 #pragma unroll
         for (int i = 0; i < 8; i++) r.v[i] = t[i];
-        return reduce_once(r);
+        return fin(r);
     }
     static FK_HD Fp sqr(const Fp &a) { return mul(a, a); }
 
@@ -233,6 +268,7 @@ __device__ __noinline__ Fp<P, false> mont_mul_call(Fp<P, false> a, Fp<P, false> 
 
 using Fq = Fp<FqParams, true>;
 using FqC = Fp<FqParams, false>;    // "cold": out-of-line multiply
+using FqL = Fp<FqLazyParams, true>; // lazily reduced [0, 2p): bucket accumulators only
 using Fr = Fp<FrParams, true>;
 
 // Fq2 = Fq[u]/(u^2 + 1)   (pairing_ce bn256 tower)
@@ -284,6 +320,13 @@ struct alignas(16) Fq2T {
 
 using Fq2 = Fq2T<Fq>;
 using Fq2C = Fq2T<FqC>;
+
+// lazily reduced twin of a coordinate field (same layout; a canonical value is a valid lazy one)
+template <class F> struct LazyOf;
+template <> struct LazyOf<Fq> { using type = FqL; };
+template <> struct LazyOf<Fq2T<Fq>> { using type = Fq2T<FqL>; };
+static FK_HD Fq canon(const FqL &a) { Fq r; for (int i = 0; i < 8; i++) r.v[i] = a.v[i]; return Fq::reduce_once(r); }
+static FK_HD Fq2T<Fq> canon(const Fq2T<FqL> &a) { return Fq2T<Fq>{canon(a.c0), canon(a.c1)}; }
 
 // cold twin of a coordinate field (same layout, out-of-line multiply)
 template <class F> struct ColdOf;

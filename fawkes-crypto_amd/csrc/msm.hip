@@ -353,33 +353,44 @@ __global__ __launch_bounds__(256) void s2_hist2_kernel(const uint16_t *tmp_lo, s
     for (uint32_t b = threadIdx.x; b < nlo; b += 256) cnt2[(size_t)tile * nlo + b] = hist[b];
 }
 
-// one block per high-bin segment, one lane per low bin: prefix over the segment's tiles, bucket totals and starts
-__global__ __launch_bounds__(1024) void s2_prefix2_kernel(uint32_t *cnt2, uint32_t nhi, uint32_t nlo, uint32_t B, const uint32_t *tile_start,
-                                                           const uint32_t *seg_start, uint32_t cap0, uint32_t *totals, uint32_t *starts, MsmDyn *dyn) {
-    __shared__ uint32_t part[16];
+// one WAVE per high-bin segment (a 1024-lane workgroup per segment spent its time being launched: 24 576 of them per
+// multiplication at 2^25, 1.9 ms): lane l owns the low bins l, l + 64, ...; per 64-bin chunk a prefix over the segment's tiles,
+// then a wave scan for the bucket starts.  Also bucket totals and the size histogram above the planned cap (msm_cap_kernel).
+__global__ __launch_bounds__(256) void s2_prefix2_kernel(uint32_t *cnt2, uint32_t nseg, uint32_t nhi, uint32_t nlo, uint32_t B, const uint32_t *tile_start,
+                                                          const uint32_t *seg_start, uint32_t cap0, uint32_t *totals, uint32_t *starts, MsmDyn *dyn) {
     __shared__ uint32_t sh_hist[16];
-    const uint32_t sgm = blockIdx.x, w = sgm / nhi, h = sgm % nhi, b = threadIdx.x;
-    if (b < 16) sh_hist[b] = 0;
-    uint32_t run = 0;
-    if (b < nlo) {
-        for (uint32_t t = tile_start[sgm]; t < tile_start[sgm + 1]; t++) {
-            uint32_t *p = cnt2 + (size_t)t * nlo + b;
-            const uint32_t v = *p; *p = run; run += v;
-        }
-    }
-    uint32_t all_;
-    const uint32_t excl = block_excl_scan_1024(run, part, &all_);
-    if (b < nlo) {
-        const size_t g = (size_t)w * B + (size_t)h * nlo + b;
-        totals[g] = run;
-        starts[g] = seg_start[sgm] + excl;
-        if (run > cap0) {        // how far over the statistical cap: class k = the largest k with run > cap0 << k (msm_cap_kernel)
-            uint32_t k = 31u - (uint32_t)__clz((run - 1) / cap0);
-            atomicAdd(&sh_hist[k < 15 ? k : 15], 1u);
+    const uint32_t lane = threadIdx.x & 63, sgm = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (threadIdx.x < 16) sh_hist[threadIdx.x] = 0;
+    __syncthreads();
+    if (sgm < nseg) {
+        const uint32_t w = sgm / nhi, h = sgm % nhi, t0 = tile_start[sgm], t1 = tile_start[sgm + 1];
+        uint32_t carry = seg_start[sgm];
+        for (uint32_t b0 = 0; b0 < nlo; b0 += 64) {
+            const uint32_t b = b0 + lane;
+            uint32_t run = 0;
+            if (b < nlo) {
+                for (uint32_t t = t0; t < t1; t++) {
+                    uint32_t *p = cnt2 + (size_t)t * nlo + b;
+                    const uint32_t v = *p; *p = run; run += v;
+                }
+            }
+            uint32_t incl = run;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const uint32_t x = (uint32_t)__shfl_up((int)incl, off, 64); if (lane >= (uint32_t)off) incl += x; }
+            if (b < nlo) {
+                const size_t g = (size_t)w * B + (size_t)h * nlo + b;
+                totals[g] = run;
+                starts[g] = carry + incl - run;
+                if (run > cap0) {        // how far over the statistical cap: class k = the largest k with run > cap0 << k (msm_cap_kernel)
+                    const uint32_t k = 31u - (uint32_t)__clz((run - 1) / cap0);
+                    atomicAdd(&sh_hist[k < 15 ? k : 15], 1u);
+                }
+            }
+            carry += (uint32_t)__shfl((int)incl, 63, 64);
         }
     }
     __syncthreads();
-    if (b < 16 && sh_hist[b]) atomicAdd(&dyn->hist[b], sh_hist[b]);
+    if (threadIdx.x < 16 && sh_hist[threadIdx.x]) atomicAdd(&dyn->hist[threadIdx.x], sh_hist[threadIdx.x]);
 }
 
 // The cap assumes Poisson bucket loads.  Scalars with many repeated values (a batch witness) put thousands of buckets a little
@@ -447,6 +458,149 @@ __global__ __launch_bounds__(1024) void s2_scatter2_kernel(const uint32_t *tmp_i
         out[gbase[b] + (q - lcnt[b])] = stage_idx[q];
     }
 }
+
+// The scatter kernels again, shaped to fit where ONE accumulate workgroup has left (256 lanes = one wave per SIMD, <= 120
+// registers; or 512 lanes at <= 60): the 1024-lane forms above need 128 / 70 registers x 4 waves per SIMD, i.e. a compute unit
+// that the accumulation (4 waves per SIMD at 115 registers -- the whole register file) has drained completely, and every
+// drained unit is VALU time lost.  A lane now owns S2_TILE / NT entries and keeps nothing about them between the phases: the
+// counting phase only counts, the placing phase reads the entries a second time (the tile was read a moment ago: L2) and draws
+// each one's slot from a per-bin LDS cursor.  Same output as the wide forms up to the order inside a bucket (both rank with
+// LDS atomics).
+template <uint32_t NT>
+static __device__ __forceinline__ uint32_t block_excl_scan_nt(uint32_t v, uint32_t *wsum, uint32_t *total) {
+    constexpr uint32_t NW = NT / 64;
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, off, 64); if (lane >= (uint32_t)off) incl += t; }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    uint32_t base = 0, all = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < NW; w++) { const uint32_t x = wsum[w]; all += x; if (w < wv) base += x; }
+    __syncthreads();
+    *total = all;
+    return base + incl - v;
+}
+
+template <uint32_t NT>
+static __device__ __forceinline__ void s2_scatter1n_body(const uint32_t *digits, size_t n, size_t chunk, uint32_t nchunks, uint32_t LB,
+                                                           uint32_t nhi, const uint32_t *cnt1, const uint32_t *seg_start, uint32_t *tmp_idx,
+                                                           uint16_t *tmp_lo) {
+    constexpr uint32_t BPL = S2_MAX_HI / NT;        // bins per lane
+    __shared__ uint32_t cursor[S2_MAX_HI];
+    __shared__ uint32_t lcnt[S2_MAX_HI];
+    __shared__ uint32_t lexc[S2_MAX_HI];        // exclusive offsets inside the sub-tile; advanced to the bins' ends by the placing phase
+    __shared__ uint32_t part[16];
+    __shared__ uint32_t stage_idx[S2_TILE];
+    __shared__ uint16_t stage_lo[S2_TILE];
+    __shared__ uint16_t stage_bin[S2_TILE];
+    const uint32_t ch = blockIdx.x, w = blockIdx.y, tid = threadIdx.x;
+    const uint32_t *cnt = cnt1 + ((size_t)w * nchunks + ch) * nhi;
+    for (uint32_t b = tid; b < S2_MAX_HI; b += NT) cursor[b] = b < nhi ? seg_start[(size_t)w * nhi + b] + cnt[b] : 0;
+    const size_t c_lo = (size_t)ch * chunk, c_hi = c_lo + chunk < n ? c_lo + chunk : n;
+    const uint32_t *dg = digits + (size_t)w * n;
+    const uint32_t lomask = (1u << LB) - 1;
+    uint32_t *oidx = tmp_idx + (size_t)w * n;
+    uint16_t *olo = tmp_lo + (size_t)w * n;
+    for (size_t sub = c_lo; sub < c_hi; sub += S2_TILE) {
+        const uint32_t cntt = (uint32_t)(c_hi - sub < S2_TILE ? c_hi - sub : S2_TILE);
+        const uint32_t *src = dg + sub;
+        for (uint32_t b = tid; b < S2_MAX_HI; b += NT) lcnt[b] = 0;
+        __syncthreads();
+#pragma unroll 8
+        for (uint32_t k = tid; k < cntt; k += NT) {
+            const uint32_t bkt = src[k] & 0x7fffffffu;
+            if (bkt) atomicAdd(&lcnt[(bkt - 1) >> LB], 1u);
+        }
+        __syncthreads();
+        uint32_t c[BPL], mine = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < BPL; i++) { c[i] = lcnt[tid * BPL + i]; mine += c[i]; }
+        uint32_t total;
+        uint32_t ex = block_excl_scan_nt<NT>(mine, part, &total);
+#pragma unroll
+        for (uint32_t i = 0; i < BPL; i++) { lexc[tid * BPL + i] = ex; ex += c[i]; }
+        __syncthreads();
+#pragma unroll 8
+        for (uint32_t k = tid; k < cntt; k += NT) {
+            const uint32_t d = src[k], bkt = d & 0x7fffffffu;
+            if (bkt) {
+                const uint32_t bin = (bkt - 1) >> LB, q = atomicAdd(&lexc[bin], 1u);
+                stage_idx[q] = (uint32_t)(sub + k) | (d & 0x80000000u); stage_lo[q] = (uint16_t)((bkt - 1) & lomask); stage_bin[q] = (uint16_t)bin;
+            }
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (uint32_t q = tid; q < total; q += NT) {
+            const uint32_t bn = stage_bin[q];
+            const uint32_t dst = cursor[bn] + (q - (lexc[bn] - lcnt[bn]));
+            oidx[dst] = stage_idx[q];
+            olo[dst] = stage_lo[q];
+        }
+        __syncthreads();
+        for (uint32_t b = tid; b < S2_MAX_HI; b += NT) cursor[b] += lcnt[b];
+        __syncthreads();
+    }
+}
+
+template <uint32_t NT>
+static __device__ __forceinline__ void s2_scatter2n_body(const uint32_t *tmp_idx, const uint16_t *tmp_lo, size_t n, uint32_t nhi, uint32_t nlo, uint32_t B,
+                                                           const uint32_t *tile_start, uint32_t nseg, const uint32_t *seg_start, const uint32_t *seg_size,
+                                                           const uint32_t *cnt2, const uint32_t *starts, uint32_t *sorted) {
+    constexpr uint32_t BPL = 1024 / NT;
+    __shared__ uint32_t lcnt[1024];          // per-bin count
+    __shared__ uint32_t lexc[1024];          // exclusive offset inside the tile, advanced to the bin's end by the placing phase
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t gbase[1024];
+    __shared__ uint32_t stage_idx[S2_TILE];
+    __shared__ uint16_t stage_lo[S2_TILE];
+    const uint32_t tile = blockIdx.x, tid = threadIdx.x;
+    if (tile >= tile_start[nseg]) return;
+    const uint32_t sgm = s2_find_segment(tile_start, nseg, tile), w = sgm / nhi, h = sgm % nhi, t = tile - tile_start[sgm];
+    for (uint32_t b = tid; b < 1024; b += NT) {
+        lcnt[b] = 0;
+        gbase[b] = b < nlo ? starts[(size_t)w * B + (size_t)h * nlo + b] + cnt2[(size_t)tile * nlo + b] : 0;
+    }
+    __syncthreads();
+    const uint32_t size = seg_size[sgm], lo = t * S2_TILE, cnt = (lo + S2_TILE < size ? lo + S2_TILE : size) - lo;
+    const uint16_t *src_lo = tmp_lo + (size_t)w * n + seg_start[sgm] + lo;
+    const uint32_t *src_idx = tmp_idx + (size_t)w * n + seg_start[sgm] + lo;
+#pragma unroll 8
+    for (uint32_t k = tid; k < cnt; k += NT) atomicAdd(&lcnt[src_lo[k]], 1u);
+    __syncthreads();
+    uint32_t c[BPL], mine = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < BPL; i++) { c[i] = lcnt[tid * BPL + i]; mine += c[i]; }
+    uint32_t all_;
+    uint32_t ex = block_excl_scan_nt<NT>(mine, wsum, &all_);
+#pragma unroll
+    for (uint32_t i = 0; i < BPL; i++) { lexc[tid * BPL + i] = ex; ex += c[i]; }
+    __syncthreads();
+#pragma unroll 8
+    for (uint32_t k = tid; k < cnt; k += NT) {
+        const uint32_t e_lo = src_lo[k], q = atomicAdd(&lexc[e_lo], 1u);
+        stage_idx[q] = src_idx[k]; stage_lo[q] = (uint16_t)e_lo;
+    }
+    __syncthreads();
+    uint32_t *out = sorted + (size_t)w * n;
+#pragma unroll 4
+    for (uint32_t q = tid; q < cnt; q += NT) {
+        const uint32_t b = stage_lo[q];
+        out[gbase[b] + (q - (lexc[b] - lcnt[b]))] = stage_idx[q];
+    }
+}
+
+#define S2N_ARGS1 const uint32_t *digits, size_t n, size_t chunk, uint32_t nchunks, uint32_t LB, uint32_t nhi, const uint32_t *cnt1, const uint32_t *seg_start, uint32_t *tmp_idx, uint16_t *tmp_lo
+#define S2N_PASS1 digits, n, chunk, nchunks, LB, nhi, cnt1, seg_start, tmp_idx, tmp_lo
+#define S2N_ARGS2 const uint32_t *tmp_idx, const uint16_t *tmp_lo, size_t n, uint32_t nhi, uint32_t nlo, uint32_t B, const uint32_t *tile_start, uint32_t nseg, const uint32_t *seg_start, const uint32_t *seg_size, const uint32_t *cnt2, const uint32_t *starts, uint32_t *sorted
+#define S2N_PASS2 tmp_idx, tmp_lo, n, nhi, nlo, B, tile_start, nseg, seg_start, seg_size, cnt2, starts, sorted
+__global__ __launch_bounds__(256) void s2_scatter1_n256_kernel(S2N_ARGS1) { s2_scatter1n_body<256>(S2N_PASS1); }
+__global__ __launch_bounds__(512) void s2_scatter1_n512_kernel(S2N_ARGS1) { s2_scatter1n_body<512>(S2N_PASS1); }
+__global__ __launch_bounds__(1024) void s2_scatter1_n1024_kernel(S2N_ARGS1) { s2_scatter1n_body<1024>(S2N_PASS1); }
+__global__ __launch_bounds__(256) void s2_scatter2_n256_kernel(S2N_ARGS2) { s2_scatter2n_body<256>(S2N_PASS2); }
+__global__ __launch_bounds__(512) void s2_scatter2_n512_kernel(S2N_ARGS2) { s2_scatter2n_body<512>(S2N_PASS2); }
+__global__ __launch_bounds__(1024) void s2_scatter2_n1024_kernel(S2N_ARGS2) { s2_scatter2n_body<1024>(S2N_PASS2); }
 
 // ------------------------------------------------------------------------------------------ bucket -> lane assignment
 // A wave runs as long as its longest bucket, so lanes are handed buckets of (nearly) equal length: buckets are
@@ -558,18 +712,36 @@ static __device__ __forceinline__ void block_reduce_256(Xyzz<F> &acc, Xyzz<F> *s
 // multiply-accumulate, no conditional subtractions); points are re-sliced on load, the bucket on store.  Otherwise the 8 x 32
 // XYZZ accumulator of curve.hpp.
 #if defined(__HIP_DEVICE_COMPILE__)
-template <class F, bool L29> struct Walker {
+template <class F, int MODE> struct Walker {       // MODE 0
     Xyzz<F> acc = Xyzz<F>::inf();
     __device__ __forceinline__ void add(const Affine<F> &p, bool neg) { acc.add_mixed(affine_neg_if(p, neg)); }
     __device__ __forceinline__ Xyzz<F> result() const { return acc; }
 };
-template <> struct Walker<Fq, true> {
+template <> struct Walker<Fq, 1> {
     Xyzz29 acc = Xyzz29::inf();
     __device__ __forceinline__ void add(const G1Affine &p, bool neg) { acc.add_mixed(p, neg); }
     __device__ __forceinline__ G1Xyzz result() const { return acc.to_resident(); }
 };
+// MODE 2: the accumulator's coordinates live in [0, 2p) (field.hpp, LAZY): no conditional subtraction behind any of the ten
+// products of a mixed addition; the bucket is made canonical when it is stored.  A loaded point is canonical, hence valid.
+template <class F> struct Walker<F, 2> {
+    using FL = typename LazyOf<F>::type;
+    Xyzz<FL> acc = Xyzz<FL>::inf();
+    __device__ __forceinline__ void add(const Affine<F> &p, bool neg) {
+        if (p.is_inf()) return;                 // tested on the canonical form (one compare chain instead of two)
+        static_assert(sizeof(Affine<FL>) == sizeof(Affine<F>), "layout");
+        Affine<FL> q;
+        __builtin_memcpy(&q, &p, sizeof q);
+        if (neg) q.y = FL::neg(q.y);
+        acc.add_mixed_nz(q);
+    }
+    __device__ __forceinline__ Xyzz<F> result() const {
+        if (acc.is_inf()) return Xyzz<F>::inf();
+        return Xyzz<F>{canon(acc.x), canon(acc.y), canon(acc.zz), canon(acc.zzz)};
+    }
+};
 #else
-template <class F, bool L29> struct Walker {       // host pass: declarations only
+template <class F, int MODE> struct Walker {       // host pass: declarations only
     void add(const Affine<F> &, bool) {}
     Xyzz<F> result() const { return Xyzz<F>::inf(); }
 };
@@ -578,7 +750,7 @@ template <class F, bool L29> struct Walker {       // host pass: declarations on
 // G2: 2.  With the compiler's own add/sub code the inlined Fq2 mixed addition wanted 256 VGPRs + ~180 AGPRs and forcing 2
 // waves spilled ~260 registers (41 ms vs 33 ms at 2^25); since the generated carry-chain add/sub (addsub_gfx950.inc) it
 // needs 226 VGPRs and runs at 2 waves per SIMD without spills: 23.4 -> 13.7 ms.
-template <class F, int MINW, bool L29>
+template <class F, int MINW, int MODE>
 __global__ __launch_bounds__(256, MINW) void msm_accumulate_kernel(const Affine<F> *bases, const uint32_t *sorted, size_t n,
                                                              const uint32_t *starts, const uint32_t *totals, uint32_t B,
                                                              uint32_t W, const MsmDyn *dyn, const uint32_t *perm, Xyzz<F> *buckets) {
@@ -590,7 +762,7 @@ __global__ __launch_bounds__(256, MINW) void msm_accumulate_kernel(const Affine<
     const uint32_t *src = sorted + (size_t)w * n + starts[g];
     uint32_t cnt = totals[g];
     if (cnt > cap) cnt = cap;
-    Walker<F, L29> acc;
+    Walker<F, MODE> acc;
     for (uint32_t k = 0; k < cnt; k++) {
         const uint32_t e = src[k];
         Affine<F> p = bases[e & 0x7fffffffu];
@@ -604,7 +776,7 @@ __global__ __launch_bounds__(256, MINW) void msm_accumulate_kernel(const Affine<
 // The walk is ONE loop over the bucket's merged length mt[b] with a (window, position) cursor: the lanes of a wave are
 // size-ordered by that merged length, so they stay in step; a loop per window would run every window to the longest of the 64
 // per-window counts (Poisson: 1.6 x the mean at a load of 16).
-template <class F, int MINW, bool L29>
+template <class F, int MINW, int MODE>
 __global__ __launch_bounds__(256, MINW) void msm_accumulate_merged_kernel(const Affine<F> *bases, const Affine<F> *lev, const uint32_t *sorted, size_t n,
                                                                     const uint32_t *starts, const uint32_t *totals, uint32_t B,
                                                                     uint32_t W, const MsmDyn *dyn, const uint32_t *perm, const uint32_t *mt, Xyzz<F> *buckets) {
@@ -613,7 +785,7 @@ __global__ __launch_bounds__(256, MINW) void msm_accumulate_merged_kernel(const 
     const uint32_t cap = dyn->cap;
     const uint32_t b = perm[t];
     const uint32_t total = mt[b];
-    Walker<F, L29> acc;
+    Walker<F, MODE> acc;
     uint32_t w = 0, k = 0, cnt = 0;
     const uint32_t *src = nullptr;
     const Affine<F> *bw = bases;
@@ -692,7 +864,7 @@ struct OverBucket { uint32_t g, task0, ntask; };
 // several waves per SIMD in flight (the multiply is a serial chain, one wave alone cannot fill the VALU).
 // The per-lane walk uses the inlined multiply (F); the wave64 shuffle reduction runs on the
 // layout-identical cold twin (FC).
-template <class F, class FC, bool L29>
+template <class F, class FC, int MODE>
 __global__ __launch_bounds__(64) void msm_overflow_kernel(const Affine<F> *bases0, const Affine<F> *lev, const uint32_t *sorted, size_t n,
                                                           const uint32_t *starts, const uint32_t *totals, uint32_t B,
                                                           const MsmDyn *dyn, const Task *tasks, Xyzz<FC> *partials) {
@@ -705,7 +877,7 @@ __global__ __launch_bounds__(64) void msm_overflow_kernel(const Affine<F> *bases
         const uint32_t size = totals[t.g];
         const uint32_t lo = cap + t.seg * SEG;
         const uint32_t hi = lo + SEG < size ? lo + SEG : size;
-        Walker<F, L29> wk;
+        Walker<F, MODE> wk;
         for (uint32_t k = lo + threadIdx.x; k < hi; k += 64) {
             const uint32_t e = src[k];
             wk.add(bases[e & 0x7fffffffu], (e >> 31) != 0);
@@ -987,8 +1159,17 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
         hipLaunchKernelGGL(s2_hist1_kernel, dim3(p.nchunks, p.W), dim3(SORT_THREADS), p.nhi * 4, ss, digits, n, p.chunk, p.nchunks, p.LB, p.nhi, cnt1);
         hipLaunchKernelGGL(s2_prefix1_kernel, dim3(p.W), dim3(1024), p.nhi * 4, ss, cnt1, p.nchunks, p.nhi, seg_size, seg_start, seg_tiles);
         hipLaunchKernelGGL(s2_tile_prefix_kernel, dim3(1), dim3(1024), 0, ss, seg_tiles, nseg, tile_start);
-        hipLaunchKernelGGL(s2_scatter1_kernel, dim3(p.nchunks, p.W), dim3(1024), 0, ss, digits, n, p.chunk, p.nchunks, p.LB, p.nhi, cnt1,
-                           seg_start, tmp_idx, tmp_lo);
+        static int t_nt = -1;         // FK_MSM_SORT_NT: lanes per scatter workgroup (1024 = the wide forms)
+        if (t_nt < 0) { const char *e = getenv("FK_MSM_SORT_NT"); t_nt = e ? atoi(e) : 1026; if (t_nt != 256 && t_nt != 512 && t_nt != 1025 && t_nt != 1026 && t_nt != 1027) t_nt = 1024; }      // 1025: two-atomic bodies at 1024 lanes (both passes), 1026: first pass only, 1027: second only
+        if (t_nt == 256)
+            hipLaunchKernelGGL(s2_scatter1_n256_kernel, dim3(p.nchunks, p.W), dim3(256), 0, ss, digits, n, p.chunk, p.nchunks, p.LB, p.nhi, cnt1, seg_start, tmp_idx, tmp_lo);
+        else if (t_nt == 512)
+            hipLaunchKernelGGL(s2_scatter1_n512_kernel, dim3(p.nchunks, p.W), dim3(512), 0, ss, digits, n, p.chunk, p.nchunks, p.LB, p.nhi, cnt1, seg_start, tmp_idx, tmp_lo);
+        else if (t_nt == 1025 || t_nt == 1026)
+            hipLaunchKernelGGL(s2_scatter1_n1024_kernel, dim3(p.nchunks, p.W), dim3(1024), 0, ss, digits, n, p.chunk, p.nchunks, p.LB, p.nhi, cnt1, seg_start, tmp_idx, tmp_lo);
+        else
+            hipLaunchKernelGGL(s2_scatter1_kernel, dim3(p.nchunks, p.W), dim3(1024), 0, ss, digits, n, p.chunk, p.nchunks, p.LB, p.nhi, cnt1,
+                               seg_start, tmp_idx, tmp_lo);
         FK_HIP(ctx, hipGetLastError());
         FK_DBG_ST(ctx, ss, "msm_sort_pass1");
         // The second pass is launched over the host's BOUND on the tile count (every segment's last tile may be partial:
@@ -998,9 +1179,16 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
         {
             hipLaunchKernelGGL(s2_hist2_kernel, dim3(n_tiles), dim3(256), p.nlo * 4, ss, tmp_lo, n, p.nhi, p.nlo, tile_start, nseg, seg_start, seg_size, cnt2);
         }
-        hipLaunchKernelGGL(s2_prefix2_kernel, dim3(nseg), dim3(1024), 0, ss, cnt2, p.nhi, p.nlo, p.B, tile_start, seg_start, p.cap ? p.cap : 1u, totals, starts, dyn);
-        hipLaunchKernelGGL(s2_scatter2_kernel, dim3(n_tiles), dim3(1024), 0, ss, tmp_idx, tmp_lo, n, p.nhi, p.nlo, p.B, tile_start, nseg, seg_start,
-                           seg_size, cnt2, starts, sorted);
+        hipLaunchKernelGGL(s2_prefix2_kernel, dim3((nseg + 3) / 4), dim3(256), 0, ss, cnt2, nseg, p.nhi, p.nlo, p.B, tile_start, seg_start, p.cap ? p.cap : 1u, totals, starts, dyn);
+        if (t_nt == 256)
+            hipLaunchKernelGGL(s2_scatter2_n256_kernel, dim3(n_tiles), dim3(256), 0, ss, tmp_idx, tmp_lo, n, p.nhi, p.nlo, p.B, tile_start, nseg, seg_start, seg_size, cnt2, starts, sorted);
+        else if (t_nt == 512)
+            hipLaunchKernelGGL(s2_scatter2_n512_kernel, dim3(n_tiles), dim3(512), 0, ss, tmp_idx, tmp_lo, n, p.nhi, p.nlo, p.B, tile_start, nseg, seg_start, seg_size, cnt2, starts, sorted);
+        else if (t_nt == 1025 || t_nt == 1027)
+            hipLaunchKernelGGL(s2_scatter2_n1024_kernel, dim3(n_tiles), dim3(1024), 0, ss, tmp_idx, tmp_lo, n, p.nhi, p.nlo, p.B, tile_start, nseg, seg_start, seg_size, cnt2, starts, sorted);
+        else
+            hipLaunchKernelGGL(s2_scatter2_kernel, dim3(n_tiles), dim3(1024), 0, ss, tmp_idx, tmp_lo, n, p.nhi, p.nlo, p.B, tile_start, nseg, seg_start,
+                               seg_size, cnt2, starts, sorted);
         FK_HIP(ctx, hipGetLastError());
         FK_DBG_ST(ctx, ss, "msm_sort_pass2");
         ln.last_sort_scalars = (const void *)d_scalars; ln.last_sort_n = n; ln.last_sort_c = p.c; ln.last_merged = merged;
@@ -1051,18 +1239,27 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
     // (profiles/r02_limb29_in_situ.log).
     static int t_l29 = -1;
     if (t_l29 < 0) { const char *e = getenv("FK_MSM_LIMB29"); t_l29 = e ? atoi(e) : 0; }
+    // FK_MSM_LAZY (default 1): accumulators in the lazily reduced form [0, 2p) (Walker<F, 2>); 0 = canonical after every product
+    static int t_lazy = -1;
+    if (t_lazy < 0) { const char *e = getenv("FK_MSM_LAZY"); t_lazy = e ? atoi(e) : 1; }
     constexpr bool IS_G1 = std::is_same<F, Fq>::value;
     const bool l29 = IS_G1 && t_l29 != 0;
+    const bool lazy = t_lazy != 0;
     constexpr int MINW_ = IS_G1 ? 4 : 2;
+    constexpr int M29 = IS_G1 ? 1 : 0;
     if (merged) {
-        if (l29) hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_merged_kernel<F, (IS_G1 ? 3 : 2), IS_G1>), dim3((p.B + 255) / 256), dim3(256), 0, st, d_bases, d_lev, sorted, n,
+        if (l29) hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_merged_kernel<F, (IS_G1 ? 3 : 2), M29>), dim3((p.B + 255) / 256), dim3(256), 0, st, d_bases, d_lev, sorted, n,
                                     starts, totals, p.B, p.W, dyn, perm, perm + p.B, buckets);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_merged_kernel<F, MINW_, false>), dim3((p.B + 255) / 256), dim3(256), 0, st, d_bases, d_lev, sorted, n,
+        else if (lazy) hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_merged_kernel<F, MINW_, 2>), dim3((p.B + 255) / 256), dim3(256), 0, st, d_bases, d_lev, sorted, n,
+                                          starts, totals, p.B, p.W, dyn, perm, perm + p.B, buckets);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_merged_kernel<F, MINW_, 0>), dim3((p.B + 255) / 256), dim3(256), 0, st, d_bases, d_lev, sorted, n,
                                 starts, totals, p.B, p.W, dyn, perm, perm + p.B, buckets);
     } else {
-        if (l29) hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_kernel<F, (IS_G1 ? 3 : 2), IS_G1>), dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, d_bases, sorted, n,
+        if (l29) hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_kernel<F, (IS_G1 ? 3 : 2), M29>), dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, d_bases, sorted, n,
                                     starts, totals, p.B, p.W, dyn, perm, buckets);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_kernel<F, MINW_, false>), dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, d_bases, sorted, n,
+        else if (lazy) hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_kernel<F, MINW_, 2>), dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, d_bases, sorted, n,
+                                          starts, totals, p.B, p.W, dyn, perm, buckets);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_kernel<F, MINW_, 0>), dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, d_bases, sorted, n,
                                 starts, totals, p.B, p.W, dyn, perm, buckets);
     }
     FK_HIP(ctx, hipGetLastError());
@@ -1071,9 +1268,11 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
     FK_HIP(ctx, hipEventRecord(ctx->ev_acc_done, st)); ctx->ev_acc_done_valid = true;
     FK_DBG_ST(ctx, st, "msm_accumulate");
     {   // oversized buckets: fixed grids looping over the device-built tables (they leave at once when there is nothing to do)
-        if (l29) hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_overflow_kernel<F, FC, IS_G1>), dim3(2048), dim3(64), 0, st,
+        if (l29) hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_overflow_kernel<F, FC, M29>), dim3(2048), dim3(64), 0, st,
                                     d_bases, d_lev, sorted, n, starts, totals, p.B, dyn, d_tasks, ln.partials.as<Xyzz<FC>>());
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_overflow_kernel<F, FC, false>), dim3(2048), dim3(64), 0, st,
+        else if (lazy) hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_overflow_kernel<F, FC, 2>), dim3(2048), dim3(64), 0, st,
+                                          d_bases, d_lev, sorted, n, starts, totals, p.B, dyn, d_tasks, ln.partials.as<Xyzz<FC>>());
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_overflow_kernel<F, FC, 0>), dim3(2048), dim3(64), 0, st,
                                 d_bases, d_lev, sorted, n, starts, totals, p.B, dyn, d_tasks, ln.partials.as<Xyzz<FC>>());
         FK_HIP(ctx, hipGetLastError());
         FK_DBG_ST(ctx, st, "msm_overflow");

@@ -49,7 +49,7 @@ def gen_single(o, op):
     for k in range(8):
         cs = '"=&s"(c), "=&s"(w)' if k == 0 else '"+s"(c), "+s"(w)'
         body = '\\n\\t'.join([prim(op, k, '%0', '%2', '%4', '%5'), sec(op, k, '%1', '%3', '%0', '%6'), 's_nop 0'])
-        o.append('        asm("%s" : "=&v"(x[%d]), "=&v"(t[%d]), %s : "v"(a.v[%d]), "v"(b.v[%d]), "v"(P::p(%d)));' % (body, k, k, cs, k, k, k))
+        o.append('        asm("%s" : "=&v"(x[%d]), "=&v"(t[%d]), %s : "v"(a.v[%d]), "v"(b.v[%d]), "v"(P::q(%d)));' % (body, k, k, cs, k, k, k))
     mask = 'w' if op == 'A' else 'c'
     for half in range(2):
         ks = range(4 * half, 4 * half + 4)
@@ -68,7 +68,7 @@ def gen_dual(o, op1, op2):
         cs = ', '.join('"%s"(%s)' % ('=&s' if k == 0 else '+s', n) for n in ('c1', 'c2', 'w1', 'w2'))
         body = '\\n\\t'.join([prim(op1, k, '%0', '%4', '%8', '%9'), prim(op2, k, '%1', '%5', '%10', '%11'),
                               sec(op1, k, '%2', '%6', '%0', '%12'), sec(op2, k, '%3', '%7', '%1', '%12')])
-        o.append('        asm("%s" : "=&v"(x1[%d]), "=&v"(x2[%d]), "=&v"(t1[%d]), "=&v"(t2[%d]), %s : "v"(a.v[%d]), "v"(b.v[%d]), "v"(c.v[%d]), "v"(d.v[%d]), "v"(P::p(%d)));'
+        o.append('        asm("%s" : "=&v"(x1[%d]), "=&v"(x2[%d]), "=&v"(t1[%d]), "=&v"(t2[%d]), %s : "v"(a.v[%d]), "v"(b.v[%d]), "v"(c.v[%d]), "v"(d.v[%d]), "v"(P::q(%d)));'
                  % (body, k, k, k, k, cs, k, k, k, k, k))
     first = True
     for op, x, t, res, c, w in ((op1, 'x1', 't1', 'u', 'c1', 'w1'), (op2, 'x2', 't2', 'v', 'c2', 'w2')):

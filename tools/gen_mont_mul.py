@@ -130,7 +130,7 @@ def gen_mul(o):
             o.append('        r.v[%d] = (uint32_t)lo;' % (k - 8))
         if mp or ab:      # `hi` is (re)written by the first v_addc of every column that has products
             o.append('        lo = (lo >> 32) | ((uint64_t)hi << 32);')
-    o.append('        return reduce_once(r);')
+    o.append('        return fin(r);')
     o.append('    }')
 
 
@@ -156,7 +156,7 @@ def gen_mul2(o):
             o.append('        x.v[%d] = (uint32_t)lo; y.v[%d] = (uint32_t)lo2;' % (k - 8, k - 8))
         if mp or ab:
             o.append('        lo = (lo >> 32) | ((uint64_t)hi << 32); lo2 = (lo2 >> 32) | ((uint64_t)hi2 << 32);')
-    o.append('        red2(x, y, r1, r2);')
+    o.append('        fin2(x, y, r1, r2);')
     o.append('    }')
 
 
