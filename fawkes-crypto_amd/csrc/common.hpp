@@ -6,6 +6,7 @@
 #include <map>
 #include <string>
 #include <vector>
+#include <functional>
 #include "../../include/fawkes_hip.h"
 #include "curve.hpp"
 
@@ -39,7 +40,8 @@ struct MsmLane {
     hipStream_t st = nullptr;
     hipStream_t st_sort = nullptr;  // FK_MSM_CU_SPLIT: digits / sort / size ordering on a CU subset of their own (else == st)
     hipEvent_t ev_in = nullptr;     // main stream -> lane: the scalars are ready
-    hipEvent_t ev_sorted = nullptr, ev_lane_done = nullptr;   // sort stream -> lane stream; lane stream -> next sort on this lane
+    hipEvent_t ev_sorted = nullptr, ev_lane_done = nullptr;   // the lane's latest sort is complete (sort stream -> lane stream; the prover gates the quotient on it); lane stream -> next sort on this lane
+    bool ev_sorted_valid = false;
     bool ev_lane_done_valid = false;
     DevBuf digits, sorted, totals, starts, perm, overlist, tasktab, partials, s2_cnt1, s2_seg, s2_cnt2, s2_tmp_idx, s2_tmp_lo, buckets;
     void *h_stage = nullptr;        // pinned host staging: counters read back, oversized-bucket list, task tables
@@ -58,7 +60,7 @@ struct MsmTail {
     DevBuf d_wp;
 };
 static constexpr int MSM_TAILS = 8;
-static constexpr int MSM_LANES = 3;   // a third lane keeps a multiplication from queueing behind the long G2 tail (msm.hip)
+static constexpr int MSM_LANES = 4;   // B pair, L, A and H each on a lane of their own in the sorts-first schedule (prover.hip)
 
 // Which variables feed the A and the B query, as index lists (they are structural: a resident constraint system
 // computes them once at load).  With them the per-proof scalar compaction is one gather per query, no host round trip.
@@ -95,6 +97,13 @@ struct fk_ctx {
     // witness multiplications (L, A, B1, B2) in flight: begun before / while the quotient runs on the main stream
     hipStream_t aux = nullptr;          // scalar compaction for the A / B queries
     hipEvent_t ev_aux = nullptr, ev_main = nullptr, ev_z = nullptr;
+    // sorts-first schedule (prover.hip): with defer_back set, msm_begin queues only the front of a multiplication (digits, sort,
+    // size ordering) and leaves the rest (accumulation, oversized buckets, reduction, download) here, to be queued by
+    // msm_run_deferred once the caller has put the quotient between the two
+    bool sort_under = false;        // the next multiplication's sort runs underneath accumulations (H in the sorts-first schedule): experiment switches in msm.hip
+    bool defer_back = false;
+    std::vector<std::function<int()>> deferred;
+    bool ev_z_recorded = false;     // fk_prove_r1cs_dev recorded ev_z BEFORE the constraint-system evaluation (z is complete there)
     hipEvent_t ev_acc_done = nullptr; bool ev_acc_done_valid = false;   // behind the most recent bucket accumulation (any lane)
     bool wit_active = false;
     const fk::QueryIdx *qidx = nullptr;   // set by the resident-constraint-system entry points for the duration of a call
@@ -229,6 +238,7 @@ int key_precompute(fk_ctx *ctx, fk_key *key);
 void key_pre_free(fk_key *key);
 int msm_g2_end(fk_ctx *ctx, int tail, G2Xyzz *out);
 void msm_abandon(fk_ctx *ctx);
+int msm_run_deferred(fk_ctx *ctx, hipEvent_t after);      // see fk_ctx::defer_back
 void msm_release(fk_ctx *ctx);
 int msm_sync(fk_ctx *ctx);
 // reuse_sort: the scalars are the ones of the immediately preceding MSM call on this context (same pointer

@@ -41,6 +41,7 @@ struct FqParams {
     static constexpr uint32_t INV = FK_FQ_INV;
 };
 struct FqLazyParams : FqParams {
+    using Base = FqParams;
     static constexpr bool LAZY = true;
     static constexpr FK_HD uint32_t q(int i) { constexpr uint32_t t[8] = FK_FQ_2P; return t[i]; }
 };
@@ -266,9 +267,15 @@ __device__ __noinline__ Fp<P, false> mont_mul_call(Fp<P, false> a, Fp<P, false> 
 }
 #endif
 
+struct FrLazyParams : FrParams {
+    using Base = FrParams;
+    static constexpr bool LAZY = true;
+    static constexpr FK_HD uint32_t q(int i) { constexpr uint32_t t[8] = FK_FR_2P; return t[i]; }
+};
 using Fq = Fp<FqParams, true>;
 using FqC = Fp<FqParams, false>;    // "cold": out-of-line multiply
 using FqL = Fp<FqLazyParams, true>; // lazily reduced [0, 2p): bucket accumulators only
+using FrL = Fp<FrLazyParams, true>; // the same for Fr: the butterflies of a transform pass
 using Fr = Fp<FrParams, true>;
 
 // Fq2 = Fq[u]/(u^2 + 1)   (pairing_ce bn256 tower)
@@ -325,7 +332,10 @@ using Fq2C = Fq2T<FqC>;
 template <class F> struct LazyOf;
 template <> struct LazyOf<Fq> { using type = FqL; };
 template <> struct LazyOf<Fq2T<Fq>> { using type = Fq2T<FqL>; };
-static FK_HD Fq canon(const FqL &a) { Fq r; for (int i = 0; i < 8; i++) r.v[i] = a.v[i]; return Fq::reduce_once(r); }
+template <class LP>
+static FK_HD Fp<typename LP::Base, true> canon(const Fp<LP, true> &a) { Fp<typename LP::Base, true> r; for (int i = 0; i < 8; i++) r.v[i] = a.v[i]; return Fp<typename LP::Base, true>::reduce_once(r); }
+template <class LP>
+static FK_HD Fp<LP, true> lazy_of(const Fp<typename LP::Base, true> &a) { Fp<LP, true> r; for (int i = 0; i < 8; i++) r.v[i] = a.v[i]; return r; }
 static FK_HD Fq2T<Fq> canon(const Fq2T<FqL> &a) { return Fq2T<Fq>{canon(a.c0), canon(a.c1)}; }
 
 // cold twin of a coordinate field (same layout, out-of-line multiply)

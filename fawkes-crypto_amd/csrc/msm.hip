@@ -531,7 +531,7 @@ static __device__ __forceinline__ void s2_scatter1n_body(const uint32_t *digits,
             }
         }
         __syncthreads();
-#pragma unroll 4
+#pragma unroll 1
         for (uint32_t q = tid; q < total; q += NT) {
             const uint32_t bn = stage_bin[q];
             const uint32_t dst = cursor[bn] + (q - (lexc[bn] - lcnt[bn]));
@@ -584,7 +584,7 @@ static __device__ __forceinline__ void s2_scatter2n_body(const uint32_t *tmp_idx
     }
     __syncthreads();
     uint32_t *out = sorted + (size_t)w * n;
-#pragma unroll 4
+#pragma unroll 1
     for (uint32_t q = tid; q < cnt; q += NT) {
         const uint32_t b = stage_lo[q];
         out[gbase[b] + (q - (lexc[b] - lcnt[b]))] = stage_idx[q];
@@ -1039,13 +1039,20 @@ static int lane_init(fk_ctx *ctx, MsmLane &ln) {
         for (int i = 0; i < ncu; i++) { if ((i & 7) < k) m_sort[i >> 5] |= 1u << (i & 31); else m_acc[i >> 5] |= 1u << (i & 31); }
         FK_HIP(ctx, hipExtStreamCreateWithCUMask(&ln.st, words, m_acc.data()));
         FK_HIP(ctx, hipExtStreamCreateWithCUMask(&ln.st_sort, words, m_sort.data()));
-        FK_HIP(ctx, hipEventCreateWithFlags(&ln.ev_sorted, hipEventDisableTiming));
         FK_HIP(ctx, hipEventCreateWithFlags(&ln.ev_lane_done, hipEventDisableTiming));
     } else {
-        FK_HIP(ctx, hipStreamCreateWithFlags(&ln.st, hipStreamNonBlocking));
+        // FK_MSM_H_PRIO=1 (experiment): the last lane -- H's in the sorts-first schedule -- gets a high-priority stream
+        static int t_hprio = -1;
+        if (t_hprio < 0) { const char *e = getenv("FK_MSM_H_PRIO"); t_hprio = e ? atoi(e) : 0; }
+        if (t_hprio && &ln == &ctx->lanes[MSM_LANES - 1]) {
+            int lo_ = 0, hi_ = 0;
+            FK_HIP(ctx, hipDeviceGetStreamPriorityRange(&lo_, &hi_));
+            FK_HIP(ctx, hipStreamCreateWithPriority(&ln.st, hipStreamNonBlocking, hi_));
+        } else FK_HIP(ctx, hipStreamCreateWithFlags(&ln.st, hipStreamNonBlocking));
         ln.st_sort = ln.st;
     }
     FK_HIP(ctx, hipEventCreateWithFlags(&ln.ev_in, hipEventDisableTiming));
+    FK_HIP(ctx, hipEventCreateWithFlags(&ln.ev_sorted, hipEventDisableTiming));
     return FK_OK;
 }
 
@@ -1143,7 +1150,7 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
     OverBucket *d_obs = (OverBucket *)((char *)ln.tasktab.p + ((max_tasks * sizeof(Task) + 15) & ~(size_t)15));
     uint32_t *digits = ln.digits.as<uint32_t>(), *sorted = ln.sorted.as<uint32_t>();
     uint32_t *totals = ln.totals.as<uint32_t>(), *starts = ln.starts.as<uint32_t>();
-    Xyzz<F> *buckets = ln.buckets.as<Xyzz<F>>(), *winparts = tl.d_wp.as<Xyzz<F>>();
+    Xyzz<F> *winparts = tl.d_wp.as<Xyzz<F>>();         // (the bucket buffer is bound in the back half, below)
     uint32_t *perm = ln.perm.as<uint32_t>(), *size_bins = perm + WB;
 
     if (!have_sort) {
@@ -1159,13 +1166,21 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
         hipLaunchKernelGGL(s2_hist1_kernel, dim3(p.nchunks, p.W), dim3(SORT_THREADS), p.nhi * 4, ss, digits, n, p.chunk, p.nchunks, p.LB, p.nhi, cnt1);
         hipLaunchKernelGGL(s2_prefix1_kernel, dim3(p.W), dim3(1024), p.nhi * 4, ss, cnt1, p.nchunks, p.nhi, seg_size, seg_start, seg_tiles);
         hipLaunchKernelGGL(s2_tile_prefix_kernel, dim3(1), dim3(1024), 0, ss, seg_tiles, nseg, tile_start);
-        static int t_nt = -1;         // FK_MSM_SORT_NT: lanes per scatter workgroup (1024 = the wide forms)
-        if (t_nt < 0) { const char *e = getenv("FK_MSM_SORT_NT"); t_nt = e ? atoi(e) : 1026; if (t_nt != 256 && t_nt != 512 && t_nt != 1025 && t_nt != 1026 && t_nt != 1027) t_nt = 1024; }      // 1025: two-atomic bodies at 1024 lanes (both passes), 1026: first pass only, 1027: second only
-        if (t_nt == 256)
+        // lanes per scatter workgroup, per pass: 0 = the wide register-ranked forms (1024 lanes), 256 / 512 / 1024 = the
+        // two-atomic forms (FK_MSM_SORT_NT1, FK_MSM_SORT_NT2)
+        static int t_nt1 = -1, t_nt2 = -1;
+        if (t_nt1 < 0) {
+            const char *e = getenv("FK_MSM_SORT_NT1"); t_nt1 = e ? atoi(e) : 1024;
+            e = getenv("FK_MSM_SORT_NT2"); t_nt2 = e ? atoi(e) : 0;
+        }
+        static int t_under1 = -1, t_under2 = -1;      // FK_MSM_UNDER_NT1 / _NT2: the same choice for a sort that runs underneath accumulations (ctx->sort_under)
+        if (t_under1 < 0) { const char *e = getenv("FK_MSM_UNDER_NT1"); t_under1 = e ? atoi(e) : t_nt1; e = getenv("FK_MSM_UNDER_NT2"); t_under2 = e ? atoi(e) : t_nt2; }
+        const int nt1 = ctx->sort_under ? t_under1 : t_nt1, nt2 = ctx->sort_under ? t_under2 : t_nt2;
+        if (nt1 == 256)
             hipLaunchKernelGGL(s2_scatter1_n256_kernel, dim3(p.nchunks, p.W), dim3(256), 0, ss, digits, n, p.chunk, p.nchunks, p.LB, p.nhi, cnt1, seg_start, tmp_idx, tmp_lo);
-        else if (t_nt == 512)
+        else if (nt1 == 512)
             hipLaunchKernelGGL(s2_scatter1_n512_kernel, dim3(p.nchunks, p.W), dim3(512), 0, ss, digits, n, p.chunk, p.nchunks, p.LB, p.nhi, cnt1, seg_start, tmp_idx, tmp_lo);
-        else if (t_nt == 1025 || t_nt == 1026)
+        else if (nt1 == 1024)
             hipLaunchKernelGGL(s2_scatter1_n1024_kernel, dim3(p.nchunks, p.W), dim3(1024), 0, ss, digits, n, p.chunk, p.nchunks, p.LB, p.nhi, cnt1, seg_start, tmp_idx, tmp_lo);
         else
             hipLaunchKernelGGL(s2_scatter1_kernel, dim3(p.nchunks, p.W), dim3(1024), 0, ss, digits, n, p.chunk, p.nchunks, p.LB, p.nhi, cnt1,
@@ -1180,11 +1195,11 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
             hipLaunchKernelGGL(s2_hist2_kernel, dim3(n_tiles), dim3(256), p.nlo * 4, ss, tmp_lo, n, p.nhi, p.nlo, tile_start, nseg, seg_start, seg_size, cnt2);
         }
         hipLaunchKernelGGL(s2_prefix2_kernel, dim3((nseg + 3) / 4), dim3(256), 0, ss, cnt2, nseg, p.nhi, p.nlo, p.B, tile_start, seg_start, p.cap ? p.cap : 1u, totals, starts, dyn);
-        if (t_nt == 256)
+        if (nt2 == 256)
             hipLaunchKernelGGL(s2_scatter2_n256_kernel, dim3(n_tiles), dim3(256), 0, ss, tmp_idx, tmp_lo, n, p.nhi, p.nlo, p.B, tile_start, nseg, seg_start, seg_size, cnt2, starts, sorted);
-        else if (t_nt == 512)
+        else if (nt2 == 512)
             hipLaunchKernelGGL(s2_scatter2_n512_kernel, dim3(n_tiles), dim3(512), 0, ss, tmp_idx, tmp_lo, n, p.nhi, p.nlo, p.B, tile_start, nseg, seg_start, seg_size, cnt2, starts, sorted);
-        else if (t_nt == 1025 || t_nt == 1027)
+        else if (nt2 == 1024)
             hipLaunchKernelGGL(s2_scatter2_n1024_kernel, dim3(n_tiles), dim3(1024), 0, ss, tmp_idx, tmp_lo, n, p.nhi, p.nlo, p.B, tile_start, nseg, seg_start, seg_size, cnt2, starts, sorted);
         else
             hipLaunchKernelGGL(s2_scatter2_kernel, dim3(n_tiles), dim3(1024), 0, ss, tmp_idx, tmp_lo, n, p.nhi, p.nlo, p.B, tile_start, nseg, seg_start,
@@ -1229,7 +1244,16 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
     }
 
     // ---- from here on nothing waits for the host
-    if (split) { FK_HIP(ctx, hipEventRecord(ln.ev_sorted, ss)); FK_HIP(ctx, hipStreamWaitEvent(st, ln.ev_sorted, 0)); }
+    if (!have_sort) { FK_HIP(ctx, hipEventRecord(ln.ev_sorted, ss)); ln.ev_sorted_valid = true; }
+    if (split) FK_HIP(ctx, hipStreamWaitEvent(st, ln.ev_sorted, 0));
+    tl.active = true; tl.cb = p.cb; tl.wide = p.wide; tl.W = WR; tl.nblk = p.nblk;     // merged: one "window" of weight 1
+    *tail_out = ti;
+    // the back of the multiplication: queued now, or by msm_run_deferred (ctx->defer_back)
+    MsmLane *lnp = &ln; MsmTail *tlp = &tl;
+    auto back = [=]() -> int {
+    MsmLane &ln = *lnp; MsmTail &tl = *tlp;
+    // bound late: a multiplication begun on this lane in between (B2 after B1) may have GROWN the bucket buffer, i.e. moved it
+    Xyzz<F> *buckets = ln.buckets.as<Xyzz<F>>();
     std::vector<EventPair> &evv = (sizeof(F) == sizeof(Fq)) ? ctx->ev_acc : ctx->ev_acc2;
     FK_TRY(stats_begin(ctx, evv, (uint64_t)n, st));
     // FK_MSM_LIMB29=1: G1 accumulator on 9 x 29-bit limbs (field29.hpp).  Measured and NOT the default: the product alone is
@@ -1289,8 +1313,18 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
     FK_HIP(ctx, hipEventRecord(tl.done, st));
     if (split) { FK_HIP(ctx, hipEventRecord(ln.ev_lane_done, st)); ln.ev_lane_done_valid = true; }
     FK_DBG_ST(ctx, st, "msm_bucket_reduce");
-    tl.active = true; tl.cb = p.cb; tl.wide = p.wide; tl.W = WR; tl.nblk = p.nblk;     // merged: one "window" of weight 1
-    *tail_out = ti;
+    return FK_OK;
+    };
+    if (ctx->defer_back) { ctx->deferred.push_back(back); return FK_OK; }
+    return back();
+}
+
+// queues the deferred backs in the order their multiplications were begun (the lane streams first wait for `after`, if given)
+int msm_run_deferred(fk_ctx *ctx, hipEvent_t after) {
+    if (after) for (MsmLane &ln : ctx->lanes) if (ln.st) FK_HIP(ctx, hipStreamWaitEvent(ln.st, after, 0));
+    std::vector<std::function<int()>> todo;
+    todo.swap(ctx->deferred);
+    for (auto &f : todo) FK_TRY(f());
     return FK_OK;
 }
 
@@ -1328,6 +1362,7 @@ int msm_sync(fk_ctx *ctx) {
 
 void msm_abandon(fk_ctx *ctx) {
     ctx->wit_active = false;
+    ctx->defer_back = false; ctx->deferred.clear();
     if (ctx->aux) (void)hipStreamSynchronize(ctx->aux);
     for (int i = 0; i < MSM_TAILS; i++) ctx->tails[i].active = false;
     for (MsmLane &ln : ctx->lanes) { if (ln.st) { (void)hipStreamSynchronize(ln.st); if (ln.st_sort != ln.st) (void)hipStreamSynchronize(ln.st_sort); } ln.last_sort_scalars = nullptr; }

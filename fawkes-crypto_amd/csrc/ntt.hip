@@ -61,17 +61,26 @@ struct PassArgs {
     const Fr *post_lo, *post_hi;
 };
 
-static __device__ __forceinline__ void lds_put(uint4 *p0, uint4 *p1, uint32_t e, const Fr &v) {
+// The passes compute in the lazily reduced form FrL ([0, 2r): no conditional subtraction behind a product, field.hpp); what
+// they read from memory (data, tables) is canonical, hence valid, and what they store is made canonical again.
+// (FL = Fr itself: the canonical form, FK_NTT_LAZY=0.)
+template <class FL> static __device__ __forceinline__ FL ldl_(const Fr &x) { FL r; for (int i = 0; i < 8; i++) r.v[i] = x.v[i]; return r; }
+static __device__ __forceinline__ Fr canon(const Fr &x) { return x; }
+template <class FL>
+static __device__ __forceinline__ void lds_put(uint4 *p0, uint4 *p1, uint32_t e, const FL &v) {
     p0[e] = make_uint4(v.v[0], v.v[1], v.v[2], v.v[3]);
     p1[e] = make_uint4(v.v[4], v.v[5], v.v[6], v.v[7]);
 }
-static __device__ __forceinline__ Fr lds_get(const uint4 *p0, const uint4 *p1, uint32_t e) {
+template <class FL>
+static __device__ __forceinline__ FL lds_get(const uint4 *p0, const uint4 *p1, uint32_t e) {
     uint4 a = p0[e], b = p1[e];
-    Fr v; v.v[0] = a.x; v.v[1] = a.y; v.v[2] = a.z; v.v[3] = a.w; v.v[4] = b.x; v.v[5] = b.y; v.v[6] = b.z; v.v[7] = b.w;
+    FL v; v.v[0] = a.x; v.v[1] = a.y; v.v[2] = a.z; v.v[3] = a.w; v.v[4] = b.x; v.v[5] = b.y; v.v[6] = b.z; v.v[7] = b.w;
     return v;
 }
 
+template <class FL>
 __global__ __launch_bounds__(NTT_MAX_THREADS) void ntt_pass_kernel(PassArgs a) {
+    auto ldl = [](const Fr *p, uint64_t i) { return ldl_<FL>(p[i]); };
     const uint32_t NTT_THREADS = blockDim.x;
     extern __shared__ uint4 lds[];
     const uint32_t R = 1u << a.deg, C = 1u << a.logC, tile = R << a.logC;
@@ -83,11 +92,11 @@ __global__ __launch_bounds__(NTT_MAX_THREADS) void ntt_pass_kernel(PassArgs a) {
     const uint32_t Lmask = (1u << a.L) - 1;
 
     // Every lane handles two elements / butterflies per step (e and e + NTT_THREADS) so that the field products can
-    // be issued as dual chains (Fr::mul2: two interleaved accumulator chains per wave, the same instruction count).
+    // be issued as dual chains (FL::mul2: two interleaved accumulator chains per wave, the same instruction count).
     // tile is a multiple of 2 * NTT_THREADS except for tiny transforms, where the second element is masked off.
 
     // ---- load tile (rows r, columns c), fused pre-op and inter-pass twiddle
-    const Fr one = Fr::one();
+    
     for (uint32_t e0 = tid; e0 < tile; e0 += 2 * NTT_THREADS) {
         const uint32_t e1 = e0 + NTT_THREADS;
         const bool has1 = e1 < tile;
@@ -95,27 +104,27 @@ __global__ __launch_bounds__(NTT_MAX_THREADS) void ntt_pass_kernel(PassArgs a) {
         const uint32_t c0 = e0 & (C - 1), r0 = e0 >> a.logC, c1 = ee1 & (C - 1), r1 = ee1 >> a.logC;
         const uint64_t i0 = i_base + c0, i1 = i_base + c1;
         const uint64_t idx0 = i0 + (uint64_t)r0 * t, idx1 = i1 + (uint64_t)r1 * t;
-        Fr v0 = a.x[idx0], v1 = a.x[idx1];
+        FL v0 = ldl(a.x, idx0), v1 = ldl(a.x, idx1);
         if (a.pre_mode == PRE_ABC) {
-            Fr p0, p1;
-            Fr::mul2(v0, a.xb[idx0], v1, a.xb[idx1], p0, p1);
-            Fr::sub2(p0, a.xc[idx0], p1, a.xc[idx1], v0, v1);
+            FL p0, p1;
+            FL::mul2(v0, ldl(a.xb, idx0), v1, ldl(a.xb, idx1), p0, p1);
+            FL::sub2(p0, ldl(a.xc, idx0), p1, ldl(a.xc, idx1), v0, v1);
         } else if (a.pre_mode == PRE_AB) {
-            Fr::mul2(v0, a.xb[idx0], v1, a.xb[idx1], v0, v1);
+            FL::mul2(v0, ldl(a.xb, idx0), v1, ldl(a.xb, idx1), v0, v1);
         } else if (a.pre_mode == PRE_TABLE) {
-            Fr s0, s1;
-            Fr::mul2(a.pre_lo[idx0 & Lmask], a.pre_hi[idx0 >> a.L], a.pre_lo[idx1 & Lmask], a.pre_hi[idx1 >> a.L], s0, s1);
-            Fr::mul2(v0, s0, v1, s1, v0, v1);
+            FL s0, s1;
+            FL::mul2(ldl(a.pre_lo, idx0 & Lmask), ldl(a.pre_hi, idx0 >> a.L), ldl(a.pre_lo, idx1 & Lmask), ldl(a.pre_hi, idx1 >> a.L), s0, s1);
+            FL::mul2(v0, s0, v1, s1, v0, v1);
         }
         if (a.lgp) {
             const uint64_t y0 = (i0 & pmask) * r0, y1 = (i1 & pmask) * r1;
             if (a.tw_full) {
-                Fr::mul2(v0, a.tw_full[y0], v1, a.tw_full[y1], v0, v1);
+                FL::mul2(v0, ldl(a.tw_full, y0), v1, ldl(a.tw_full, y1), v0, v1);
             } else {
                 const uint64_t x0 = y0 << (a.log_n - a.lgp - a.deg), x1 = y1 << (a.log_n - a.lgp - a.deg);
-                Fr w0, w1;
-                Fr::mul2(a.tw_lo[x0 & Lmask], a.tw_hi[x0 >> a.L], a.tw_lo[x1 & Lmask], a.tw_hi[x1 >> a.L], w0, w1);
-                Fr::mul2(v0, w0, v1, w1, v0, v1);
+                FL w0, w1;
+                FL::mul2(ldl(a.tw_lo, x0 & Lmask), ldl(a.tw_hi, x0 >> a.L), ldl(a.tw_lo, x1 & Lmask), ldl(a.tw_hi, x1 >> a.L), w0, w1);
+                FL::mul2(v0, w0, v1, w1, v0, v1);
             }
         }
         lds_put(p0, p1, e0, v0);
@@ -135,21 +144,21 @@ __global__ __launch_bounds__(NTT_MAX_THREADS) void ntt_pass_kernel(PassArgs a) {
             const uint32_t d = ii & (bq - 1);
             const uint32_t row = ((ii - d) << 2) + d;                 // bits `bit` and `bq` of the row are zero
             const uint32_t e0 = (row << a.logC) + c, e1 = e0 + (bq << a.logC), e2 = e0 + (bit << a.logC), e3 = e2 + (bq << a.logC);
-            Fr x0 = lds_get(p0, p1, e0), x1 = lds_get(p0, p1, e1), x2 = lds_get(p0, p1, e2), x3 = lds_get(p0, p1, e3);
-            Fr s0, d0, s1, d1, y0, y1;
-            Fr::addsub2(x0, x2, x0, x2, s0, d0);
-            Fr::addsub2(x1, x3, x1, x3, s1, d1);
-            Fr::addsub2(s0, s1, s0, s1, y0, y1);
+            FL x0 = lds_get<FL>(p0, p1, e0), x1 = lds_get<FL>(p0, p1, e1), x2 = lds_get<FL>(p0, p1, e2), x3 = lds_get<FL>(p0, p1, e3);
+            FL s0, d0, s1, d1, y0, y1;
+            FL::addsub2(x0, x2, x0, x2, s0, d0);
+            FL::addsub2(x1, x3, x1, x3, s1, d1);
+            FL::addsub2(s0, s1, s0, s1, y0, y1);
             if (bq == 1) {                                            // d = 0: T1 = T3 = 1, T2 = the fourth root
-                d1 = Fr::mul(d1, a.pq[(1u << rnd) << a.pq_shift]);
+                d1 = FL::mul(d1, ldl(a.pq, (1u << rnd) << a.pq_shift));
             } else {
-                Fr::mul2(d0, a.pq[(d << rnd) << a.pq_shift], d1, a.pq[((d + bq) << rnd) << a.pq_shift], d0, d1);
+                FL::mul2(d0, ldl(a.pq, (d << rnd) << a.pq_shift), d1, ldl(a.pq, ((d + bq) << rnd) << a.pq_shift), d0, d1);
             }
-            Fr y2, y3;
-            Fr::addsub2(d0, d1, d0, d1, y2, y3);
+            FL y2, y3;
+            FL::addsub2(d0, d1, d0, d1, y2, y3);
             if (bq != 1) {
-                const Fr t3 = a.pq[(d << (rnd + 1)) << a.pq_shift];
-                Fr::mul2(y1, t3, y3, t3, y1, y3);
+                const FL t3 = ldl(a.pq, (d << (rnd + 1)) << a.pq_shift);
+                FL::mul2(y1, t3, y3, t3, y1, y3);
             }
             lds_put(p0, p1, e0, y0);
             lds_put(p0, p1, e1, y1);
@@ -163,8 +172,8 @@ __global__ __launch_bounds__(NTT_MAX_THREADS) void ntt_pass_kernel(PassArgs a) {
         for (uint32_t bf = tid; bf < nbf; bf += NTT_THREADS) {
             const uint32_t c = bf & (C - 1), ii = bf >> a.logC;
             const uint32_t e0 = ((ii << 1) << a.logC) + c, e1 = e0 + C;
-            Fr u = lds_get(p0, p1, e0), w = lds_get(p0, p1, e1), sm, df;
-            Fr::addsub2(u, w, u, w, sm, df);
+            FL u = lds_get<FL>(p0, p1, e0), w = lds_get<FL>(p0, p1, e1), sm, df;
+            FL::addsub2(u, w, u, w, sm, df);
             lds_put(p0, p1, e0, sm);
             lds_put(p0, p1, e1, df);
         }
@@ -180,21 +189,20 @@ __global__ __launch_bounds__(NTT_MAX_THREADS) void ntt_pass_kernel(PassArgs a) {
         if (a.lgp == 0) { rr0 = e0 & (R - 1); c0 = e0 >> a.deg; rr1 = e1 & (R - 1); c1 = e1 >> a.deg; }      // first pass: runs of R outputs
         else { c0 = e0 & (C - 1); rr0 = e0 >> a.logC; c1 = e1 & (C - 1); rr1 = e1 >> a.logC; }            // later passes: runs of C outputs
         const uint32_t q0 = a.deg ? (__brev(rr0) >> (32 - a.deg)) : 0, q1 = a.deg ? (__brev(rr1) >> (32 - a.deg)) : 0;
-        Fr v0 = lds_get(p0, p1, (q0 << a.logC) + c0), v1 = lds_get(p0, p1, (q1 << a.logC) + c1);
+        FL v0 = lds_get<FL>(p0, p1, (q0 << a.logC) + c0), v1 = lds_get<FL>(p0, p1, (q1 << a.logC) + c1);
         const uint64_t i0 = i_base + c0, i1 = i_base + c1;
         const uint64_t k0 = i0 & pmask, k1 = i1 & pmask;
         const uint64_t o0 = ((i0 - k0) << a.deg) + k0 + ((uint64_t)rr0 << a.lgp), o1 = ((i1 - k1) << a.deg) + k1 + ((uint64_t)rr1 << a.lgp);
-        if (a.post_mode == POST_CONST) Fr::mul2(v0, a.post_const, v1, a.post_const, v0, v1);
+        if (a.post_mode == POST_CONST) { const FL pc = ldl_<FL>(a.post_const); FL::mul2(v0, pc, v1, pc, v0, v1); }
         else if (a.post_mode == POST_TABLE || a.post_mode == POST_TABLE_SUB) {
-            Fr s0, s1;
-            Fr::mul2(a.post_lo[o0 & Lmask], a.post_hi[o0 >> a.L], a.post_lo[o1 & Lmask], a.post_hi[o1 >> a.L], s0, s1);
-            Fr::mul2(v0, s0, v1, s1, v0, v1);
-            if (a.post_mode == POST_TABLE_SUB) Fr::sub2(v0, a.xc[o0], v1, a.xc[o1], v0, v1);
+            FL s0, s1;
+            FL::mul2(ldl(a.post_lo, o0 & Lmask), ldl(a.post_hi, o0 >> a.L), ldl(a.post_lo, o1 & Lmask), ldl(a.post_hi, o1 >> a.L), s0, s1);
+            FL::mul2(v0, s0, v1, s1, v0, v1);
+            if (a.post_mode == POST_TABLE_SUB) FL::sub2(v0, ldl(a.xc, o0), v1, ldl(a.xc, o1), v0, v1);
         }
-        a.y[o0] = v0;
-        if (has1) a.y[o1] = v1;
+        a.y[o0] = canon(v0);
+        if (has1) a.y[o1] = canon(v1);
     }
-    (void)one;
 }
 
 __global__ void fr_mul_batch_kernel(const Fr *a, const Fr *b, Fr *o, size_t n) {
@@ -359,13 +367,16 @@ static int ntt_exec(fk_ctx *ctx, NttDomain *d, const NttOp &op, const Fr *in, Fr
         if (op.post) { a.post_lo = op.post->lo; a.post_hi = op.post->hi; }
         const uint64_t nblk = ((uint64_t)1 << (d->log_n - deg)) >> logC;
         const size_t lds_bytes = (size_t)2 * sizeof(uint4) << (deg + logC);
-        FK_HIP(ctx, hipFuncSetAttribute((const void *)ntt_pass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        static int t_lazy = -1;     // FK_NTT_LAZY=0: butterflies in the canonical form (the round-1 kernel)
+        if (t_lazy < 0) { const char *e = getenv("FK_NTT_LAZY"); t_lazy = e ? atoi(e) : 1; }
+        void (*kern)(PassArgs) = t_lazy ? ntt_pass_kernel<FrL> : ntt_pass_kernel<Fr>;
+        FK_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         FK_TRY(stats_begin(ctx, ctx->ev_ntt, (uint64_t)1 << d->log_n));
         // one lane per two butterflies (the kernel issues the field products of a pair as dual chains)
         uint32_t threads = 1u << (deg + logC > 1 ? deg + logC - 2 : 0);
         if (threads < 64) threads = 64;
         if (threads > ctx->ntt_threads) threads = ctx->ntt_threads;
-        hipLaunchKernelGGL(ntt_pass_kernel, dim3((unsigned)nblk), dim3(threads), lds_bytes, ctx->stream, a);
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(threads), lds_bytes, ctx->stream, a);
         FK_HIP(ctx, hipGetLastError());
         FK_TRY(stats_end(ctx, ctx->ev_ntt));
         src = dst;

@@ -310,6 +310,15 @@ int fk_key_synthetic(fk_ctx *ctx, uint64_t m, uint32_t num_input, uint32_t num_a
 // running there -- or its all-to-all phases on several GPUs -- overlaps with their memory-bound sorts and their
 // latency-bound tails.  B1 and B2 come first so that the long G2 tail is covered by L and A.  `witness_end` collects
 // them (and an H multiplication the caller has begun, if any) into the FK_MSM_RESULT_BYTES record.
+// The sorts-first schedule of prove_msms_dev: on for domains of 2^25 and more (below that the phases are short and the
+// queue-everything schedule with three lanes is ahead: 2^24 69.6 vs 73.0 ms, 64 transactions 18.2 vs 19.5, 256 transactions
+// equal; profiles/r02_sorts_first_probe.log).  FK_PROVE_SORTS_FIRST=0 / 1 forces it off / on.
+static bool sorts_first(const fk_key *key) {
+    static int t = -2;
+    if (t == -2) { const char *e = getenv("FK_PROVE_SORTS_FIRST"); t = e ? atoi(e) : -1; }
+    return t >= 0 ? t != 0 : key->m >= (1ull << 25);
+}
+
 static int witness_begin(fk_ctx *ctx, const fk_key *key, const Fr *d_z, const uint8_t *d_a_aux, const uint8_t *d_b_in,
                          const uint8_t *d_b_aux, hipEvent_t z_ready) {
     if (!key || !d_z) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "prove: null argument");
@@ -323,7 +332,8 @@ static int witness_begin(fk_ctx *ctx, const fk_key *key, const Fr *d_z, const ui
     // 211.2 ms (profiles/r02_lanes_probe.log; one lane, no overlap at all: 227.3).  Since a multiplication is queued without
     // a host round trip (msm.hip) the picture at the top end changed: at 2^25 two lanes are 1 % ahead of three (195.1 vs
     // 197.5 ms, one lane 207.2), below that three still win by 1.5-5 % (profiles/r02_async_msm_ab_probe.log).
-    ctx->lanes_in_use = key->m >= (1ull << 25) ? 2 : MSM_LANES;
+    // In the sorts-first schedule (prove_msms_dev) every multiplication has a lane of its own.
+    ctx->lanes_in_use = sorts_first(key) ? MSM_LANES : (key->m >= (1ull << 25) ? 2 : 3);
     FK_HIP(ctx, hipSetDevice(ctx->device));
     if (!ctx->aux) {
         FK_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
@@ -415,7 +425,7 @@ static int prove_msms_dev(fk_ctx *ctx, const fk_key *key, Fr *d_a, Fr *d_b, Fr *
     Fr *d_h = ctx->hbuf.as<Fr>();
     uint64_t m = 0;
     ctx->lane_next = 0;     // same lane for the same multiplication in every proof: lane buffers keep their sizes
-    ctx->lanes_in_use = key->m >= (1ull << 25) ? 2 : MSM_LANES;      // measured, see fk_prove_msms_z_begin_dev
+    ctx->lanes_in_use = sorts_first(key) ? MSM_LANES : (key->m >= (1ull << 25) ? 2 : 3);      // measured, see witness_begin
     // The witness multiplications depend on z only: they are begun right behind the QUEUED quotient, so that their sorts (and what
     // fits of their accumulations) fill the transforms' gaps: 214.5 -> 206.9 ms per proof on the 1024-transaction system
     // (profiles/r02_cusplit_witness_first_probe.log), and at every smaller size measured -- synthetic 2^20 13.4 -> 11.1 ms,
@@ -426,15 +436,45 @@ static int prove_msms_dev(fk_ctx *ctx, const fk_key *key, Fr *d_a, Fr *d_b, Fr *
     const bool wfirst = t_wfirst != 0;
     if (!ctx->ev_main) FK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_main, hipEventDisableTiming));
     if (!ctx->ev_z) FK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_z, hipEventDisableTiming));
-    FK_HIP(ctx, hipEventRecord(ctx->ev_z, ctx->stream));           // z (and a, b, c) are complete here
-    FK_TRY(quotient_dev(ctx, d_a, d_b, d_c, n, d_h, &m));          // queued on the main stream, not waited for
+    // z is complete here -- or, for a resident constraint system, it already was before a, b, c were evaluated from it
+    // (fk_prove_r1cs_dev): the witness multiplications then start together with that evaluation instead of behind it
+    if (!ctx->ev_z_recorded) FK_HIP(ctx, hipEventRecord(ctx->ev_z, ctx->stream));
+    ctx->ev_z_recorded = false;
+    // Sorts first (the kernel timeline of a proof, tools/trace_gantt.py, is what this follows): a sort's workgroups (1024
+    // lanes, > 100 KB of LDS) make no headway underneath the transforms (two 64 KB workgroups per compute unit) nor underneath
+    // an accumulation (the whole register file) -- a 1.5 ms scatter pass took 30 ms there and the accumulations behind it
+    // started when the quotient was done.  So the witness multiplications are queued FIRST, each on a lane of its own, their
+    // sorts run beside the evaluation of a, b, c (latency-bound gathers), and the quotient's first kernel waits for the
+    // sorts: from then on transforms and accumulations -- all VALU-bound -- share the GPU without anything crawling, and H
+    // (its own lane) sorts as soon as the quotient is done.
+    const bool gate = wfirst && sorts_first(key);
+    static int t_accgate = -1;      // FK_PROVE_ACC_AFTER_NTT (default 1): the witness accumulations wait for the quotient, see below
+    if (t_accgate < 0) { const char *e = getenv("FK_PROVE_ACC_AFTER_NTT"); t_accgate = e ? atoi(e) : 1; }
+    if (gate) {
+        ctx->defer_back = t_accgate != 0;
+        const int rcw = witness_begin(ctx, key, d_z, d_a_aux, d_b_in, d_b_aux, ctx->ev_z);
+        ctx->defer_back = false;
+        if (rcw != FK_OK) { msm_abandon(ctx); return rcw; }
+        for (MsmLane &ln : ctx->lanes)
+            if (ln.ev_sorted_valid) { FK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ln.ev_sorted, 0)); ln.ev_sorted_valid = false; }
+    }
+    const int rcq = quotient_dev(ctx, d_a, d_b, d_c, n, d_h, &m);          // queued on the main stream, not waited for
+    if (rcq != FK_OK) { if (gate) msm_abandon(ctx); return rcq; }
     const double t1 = now_ms();
     if (wfirst) {
         FK_HIP(ctx, hipEventRecord(ctx->ev_main, ctx->stream));
-        const int rcw = witness_begin(ctx, key, d_z, d_a_aux, d_b_in, d_b_aux, ctx->ev_z);
-        if (rcw != FK_OK) { msm_abandon(ctx); return rcw; }
+        // ... and the transforms make no headway underneath the accumulations either (one pass took 55 ms there): the
+        // witness accumulations are queued behind the quotient.  H's sort then has the whole of them to crawl underneath
+        // and a clear run beside their latency-bound tails.
+        if (gate) { const int rcd = msm_run_deferred(ctx, ctx->ev_main); if (rcd != FK_OK) { msm_abandon(ctx); return rcd; } }
+        if (!gate) {
+            const int rcw = witness_begin(ctx, key, d_z, d_a_aux, d_b_in, d_b_aux, ctx->ev_z);
+            if (rcw != FK_OK) { msm_abandon(ctx); return rcw; }
+        }
         int t_h0 = -1;
+        ctx->sort_under = gate;
         const int rch = msm_g1_begin(ctx, key->d_h, d_h + key->h_lo, key->h_hi - key->h_lo, &t_h0, ctx->ev_main, &key->pre_h);
+        ctx->sort_under = false;
         if (rch != FK_OK) { msm_abandon(ctx); return rch; }
         const double t2w = now_ms();
         FK_TRY(witness_end(ctx, out, t_h0));

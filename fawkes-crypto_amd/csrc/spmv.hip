@@ -387,10 +387,21 @@ int fk_prove_r1cs_dev(fk_ctx *ctx, const fk_key *key, const fk_r1cs_dev *r, cons
     FK_HIP(ctx, hipSetDevice(ctx->device));
     const size_t mb = key->m * sizeof(Fr);
     FK_HIP(ctx, ctx->stage_a.reserve(mb)); FK_HIP(ctx, ctx->stage_b.reserve(mb)); FK_HIP(ctx, ctx->stage_c.reserve(mb));
-    FK_TRY(fk_r1cs_eval_dev(ctx, r, d_z, ctx->stage_a.p, ctx->stage_b.p, ctx->stage_c.p));
+    // z is complete at this point of the main stream: the witness multiplications wait for THIS, not for the evaluation of a, b, c
+    // (11.6 ms at 2^25 during which nothing else ran; FK_PROVE_Z_EARLY=0 restores that)
+    static int t_zearly = -1;
+    if (t_zearly < 0) { const char *e = getenv("FK_PROVE_Z_EARLY"); t_zearly = e ? atoi(e) : 1; }
+    if (t_zearly) {
+        if (!ctx->ev_z) FK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_z, hipEventDisableTiming));
+        FK_HIP(ctx, hipEventRecord(ctx->ev_z, ctx->stream));
+        ctx->ev_z_recorded = true;
+    }
+    const int rce = fk_r1cs_eval_dev(ctx, r, d_z, ctx->stage_a.p, ctx->stage_b.p, ctx->stage_c.p);
+    if (rce != FK_OK) { ctx->ev_z_recorded = false; return rce; }
     ctx->qidx = &r->qidx;      // the queries' index lists are known: no per-proof density compaction
     const int rc = fk_prove_dev(ctx, key, ctx->stage_a.p, ctx->stage_b.p, ctx->stage_c.p, rows, d_z, r->d_a_aux, r->d_b_in, r->d_b_aux, rr, ss, out_proof, tm);
     ctx->qidx = nullptr;
+    ctx->ev_z_recorded = false;
     return rc;
 }
 
