@@ -794,6 +794,10 @@ class Context:
             u = C.c_uint64()
             self._ck(self.lib.fk_stats_get(self.handle, C.c_int(which), None, None, C.byref(u)))
             out[name]['adds'] = u.value
+        for which, name in ((5, 'acc_g1'), (6, 'acc_g2')):     # union of the launches' intervals (launches side by side)
+            ms = C.c_double()
+            self._ck(self.lib.fk_stats_get(self.handle, C.c_int(which), C.byref(ms), None, None))
+            out[name]['union_ms'] = ms.value
         return out
 
     def calibrate(self):

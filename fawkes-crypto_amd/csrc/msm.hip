@@ -1053,6 +1053,9 @@ static int lane_init(fk_ctx *ctx, MsmLane &ln) {
     }
     FK_HIP(ctx, hipEventCreateWithFlags(&ln.ev_in, hipEventDisableTiming));
     FK_HIP(ctx, hipEventCreateWithFlags(&ln.ev_sorted, hipEventDisableTiming));
+    FK_HIP(ctx, hipEventCreateWithFlags(&ln.ev_front, hipEventDisableTiming));
+    FK_HIP(ctx, hipEventCreateWithFlags(&ln.ev_accd, hipEventDisableTiming));
+    FK_HIP(ctx, hipEventCreateWithFlags(&ln.ev_tail, hipEventDisableTiming));
     return FK_OK;
 }
 
@@ -1250,11 +1253,22 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
     *tail_out = ti;
     // the back of the multiplication: queued now, or by msm_run_deferred (ctx->defer_back)
     MsmLane *lnp = &ln; MsmTail *tlp = &tl;
+    const hipStream_t st_lane = st;
     auto back = [=]() -> int {
     MsmLane &ln = *lnp; MsmTail &tl = *tlp;
     // bound late: a multiplication begun on this lane in between (B2 after B1) may have GROWN the bucket buffer, i.e. moved it
     Xyzz<F> *buckets = ln.buckets.as<Xyzz<F>>();
     std::vector<EventPair> &evv = (sizeof(F) == sizeof(Fq)) ? ctx->ev_acc : ctx->ev_acc2;
+    // the stream the accumulation runs on: the lane's, or the shared one (fk_ctx::acc_serial) -- then lane -> acc_st before it
+    // and acc_st -> lane behind it, and it also waits for the lane's previous tail (B2 after B1 share the bucket buffer)
+    hipStream_t st = st_lane;
+    if (ctx->acc_serial) {
+        if (!ctx->acc_st) FK_HIP(ctx, hipStreamCreateWithFlags(&ctx->acc_st, hipStreamNonBlocking));
+        st = ctx->acc_st;
+        FK_HIP(ctx, hipEventRecord(ln.ev_front, st_lane));
+        FK_HIP(ctx, hipStreamWaitEvent(st, ln.ev_front, 0));
+        if (ln.ev_tail_valid) FK_HIP(ctx, hipStreamWaitEvent(st, ln.ev_tail, 0));
+    }
     FK_TRY(stats_begin(ctx, evv, (uint64_t)n, st));
     // FK_MSM_LIMB29=1: G1 accumulator on 9 x 29-bit limbs (field29.hpp).  Measured and NOT the default: the product alone is
     // 155 against 134 G/s, but the mixed addition around it (re-slicing two coordinates per point, signed carry chains for the
@@ -1291,6 +1305,11 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
     if (!ctx->ev_acc_done) FK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_acc_done, hipEventDisableTiming));
     FK_HIP(ctx, hipEventRecord(ctx->ev_acc_done, st)); ctx->ev_acc_done_valid = true;
     FK_DBG_ST(ctx, st, "msm_accumulate");
+    if (st != st_lane) {
+        FK_HIP(ctx, hipEventRecord(ln.ev_accd, st));
+        FK_HIP(ctx, hipStreamWaitEvent(st_lane, ln.ev_accd, 0));
+        st = st_lane;       // the tail runs on the lane
+    }
     {   // oversized buckets: fixed grids looping over the device-built tables (they leave at once when there is nothing to do)
         if (l29) hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_overflow_kernel<F, FC, M29>), dim3(2048), dim3(64), 0, st,
                                     d_bases, d_lev, sorted, n, starts, totals, p.B, dyn, d_tasks, ln.partials.as<Xyzz<FC>>());
@@ -1312,6 +1331,7 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
     FK_HIP(ctx, hipMemcpyAsync((char *)tl.h_wp + wp_bytes + 8, &dyn->error, 4, hipMemcpyDeviceToHost, st));
     FK_HIP(ctx, hipEventRecord(tl.done, st));
     if (split) { FK_HIP(ctx, hipEventRecord(ln.ev_lane_done, st)); ln.ev_lane_done_valid = true; }
+    FK_HIP(ctx, hipEventRecord(ln.ev_tail, st)); ln.ev_tail_valid = true;
     FK_DBG_ST(ctx, st, "msm_bucket_reduce");
     return FK_OK;
     };
@@ -1322,6 +1342,10 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
 // queues the deferred backs in the order their multiplications were begun (the lane streams first wait for `after`, if given)
 int msm_run_deferred(fk_ctx *ctx, hipEvent_t after) {
     if (after) for (MsmLane &ln : ctx->lanes) if (ln.st) FK_HIP(ctx, hipStreamWaitEvent(ln.st, after, 0));
+    if (after && ctx->acc_serial) {
+        if (!ctx->acc_st) FK_HIP(ctx, hipStreamCreateWithFlags(&ctx->acc_st, hipStreamNonBlocking));
+        FK_HIP(ctx, hipStreamWaitEvent(ctx->acc_st, after, 0));
+    }
     std::vector<std::function<int()>> todo;
     todo.swap(ctx->deferred);
     for (auto &f : todo) FK_TRY(f());
@@ -1362,13 +1386,15 @@ int msm_sync(fk_ctx *ctx) {
 
 void msm_abandon(fk_ctx *ctx) {
     ctx->wit_active = false;
-    ctx->defer_back = false; ctx->deferred.clear();
+    ctx->defer_back = false; ctx->deferred.clear(); ctx->acc_serial = false;
+    if (ctx->acc_st) (void)hipStreamSynchronize(ctx->acc_st);
     if (ctx->aux) (void)hipStreamSynchronize(ctx->aux);
     for (int i = 0; i < MSM_TAILS; i++) ctx->tails[i].active = false;
     for (MsmLane &ln : ctx->lanes) { if (ln.st) { (void)hipStreamSynchronize(ln.st); if (ln.st_sort != ln.st) (void)hipStreamSynchronize(ln.st_sort); } ln.last_sort_scalars = nullptr; }
 }
 
 void msm_release(fk_ctx *ctx) {
+    if (ctx->acc_st) { (void)hipStreamSynchronize(ctx->acc_st); (void)hipStreamDestroy(ctx->acc_st); ctx->acc_st = nullptr; }
     if (ctx->aux) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamDestroy(ctx->aux); ctx->aux = nullptr; }
     if (ctx->ev_aux) { (void)hipEventDestroy(ctx->ev_aux); ctx->ev_aux = nullptr; }
     if (ctx->ev_main) { (void)hipEventDestroy(ctx->ev_main); ctx->ev_main = nullptr; }
@@ -1381,6 +1407,9 @@ void msm_release(fk_ctx *ctx) {
             b->release();
         if (ln.h_stage) (void)hipHostFree(ln.h_stage);
         if (ln.ev_in) (void)hipEventDestroy(ln.ev_in);
+        if (ln.ev_front) (void)hipEventDestroy(ln.ev_front);
+        if (ln.ev_accd) (void)hipEventDestroy(ln.ev_accd);
+        if (ln.ev_tail) (void)hipEventDestroy(ln.ev_tail);
         if (ln.ev_sorted) (void)hipEventDestroy(ln.ev_sorted);
         if (ln.ev_lane_done) (void)hipEventDestroy(ln.ev_lane_done);
         if (ln.st_sort && ln.st_sort != ln.st) { (void)hipStreamSynchronize(ln.st_sort); (void)hipStreamDestroy(ln.st_sort); }

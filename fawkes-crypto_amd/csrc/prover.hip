@@ -466,6 +466,12 @@ static int prove_msms_dev(fk_ctx *ctx, const fk_key *key, Fr *d_a, Fr *d_b, Fr *
         // ... and the transforms make no headway underneath the accumulations either (one pass took 55 ms there): the
         // witness accumulations are queued behind the quotient.  H's sort then has the whole of them to crawl underneath
         // and a clear run beside their latency-bound tails.
+        // The accumulations of B1, L and A then run side by side on their lanes (they fill each other's last waves).  One after
+        // the other on a stream of their own, each tail underneath the next accumulation (FK_PROVE_ACC_SERIAL=1), was measured
+        // slower: 192.3 - 195.5 against 185.8 - 188.5 ms (profiles/r02_sorts_first_probe.log).
+        static int t_accser = -1;
+        if (t_accser < 0) { const char *e = getenv("FK_PROVE_ACC_SERIAL"); t_accser = e ? atoi(e) : 0; }
+        ctx->acc_serial = gate && t_accser != 0;
         if (gate) { const int rcd = msm_run_deferred(ctx, ctx->ev_main); if (rcd != FK_OK) { msm_abandon(ctx); return rcd; } }
         if (!gate) {
             const int rcw = witness_begin(ctx, key, d_z, d_a_aux, d_b_in, d_b_aux, ctx->ev_z);
@@ -475,6 +481,7 @@ static int prove_msms_dev(fk_ctx *ctx, const fk_key *key, Fr *d_a, Fr *d_b, Fr *
         ctx->sort_under = gate;
         const int rch = msm_g1_begin(ctx, key->d_h, d_h + key->h_lo, key->h_hi - key->h_lo, &t_h0, ctx->ev_main, &key->pre_h);
         ctx->sort_under = false;
+        ctx->acc_serial = false;
         if (rch != FK_OK) { msm_abandon(ctx); return rch; }
         const double t2w = now_ms();
         FK_TRY(witness_end(ctx, out, t_h0));
@@ -869,13 +876,32 @@ int fk_stats_reset(fk_ctx *ctx) {
 }
 int fk_stats_get(fk_ctx *ctx, int which, double *ms, uint64_t *launches, uint64_t *units) {
     if (!ctx) return FK_ERR_BAD_ARG;
-    if (which < 0 || which > 4) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "stats: which must be 0 / 3 (G1 accumulate), 1 / 4 (G2 accumulate) or 2 (NTT pass)");
+    if (which < 0 || which > 6) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "stats: which must be 0 / 3 / 5 (G1 accumulate), 1 / 4 / 6 (G2 accumulate) or 2 (NTT pass)");
     FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     FK_TRY(msm_sync(ctx));
-    std::vector<EventPair> &v = (which == 0 || which == 3) ? ctx->ev_acc : ((which == 1 || which == 4) ? ctx->ev_acc2 : ctx->ev_ntt);
+    std::vector<EventPair> &v = (which == 0 || which == 3 || which == 5) ? ctx->ev_acc : ((which == 1 || which == 4 || which == 6) ? ctx->ev_acc2 : ctx->ev_ntt);
     double t = 0; uint64_t u = 0;
-    for (auto &ep : v) { float x = 0; FK_HIP(ctx, hipEventElapsedTime(&x, ep.a, ep.b)); t += x; u += ep.units; }
-    if (which >= 3) u = ctx->acc_adds[which - 3];
+    if (which >= 5) {
+        // launches of one kernel that run side by side (the sorts-first schedule: B1, L, A) each span the whole phase: the time
+        // the KERNEL took is the union of the launches' intervals, not their sum
+        std::vector<std::pair<double, double>> iv;
+        for (auto &ep : v) {
+            float s = 0, e = 0;
+            FK_HIP(ctx, hipEventElapsedTime(&s, v[0].a, ep.a)); FK_HIP(ctx, hipEventElapsedTime(&e, v[0].a, ep.b));
+            iv.emplace_back((double)s, (double)e); u += ep.units;
+        }
+        std::sort(iv.begin(), iv.end());
+        double cs = 0, ce = 0; bool open = false;
+        for (auto &x : iv) {
+            if (!open) { cs = x.first; ce = x.second; open = true; }
+            else if (x.first <= ce) ce = std::max(ce, x.second);
+            else { t += ce - cs; cs = x.first; ce = x.second; }
+        }
+        if (open) t += ce - cs;
+    } else {
+        for (auto &ep : v) { float x = 0; FK_HIP(ctx, hipEventElapsedTime(&x, ep.a, ep.b)); t += x; u += ep.units; }
+    }
+    if (which == 3 || which == 4) u = ctx->acc_adds[which - 3];
     if (ms) *ms = t;
     if (launches) *launches = v.size();
     if (units) *units = u;

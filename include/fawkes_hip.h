@@ -377,7 +377,9 @@ int fk_verify_batch_dev(fk_ctx *ctx, const uint8_t *vk, size_t vk_len, const uin
  * launches.  which: 0 = msm_accumulate_kernel<Fq> (G1 bucket accumulation; units = points per launch),
  * 1 = msm_accumulate_kernel<Fq2> (G2), 2 = ntt_pass_kernel (units = elements per pass); 3 / 4 = the same kernels as 0 / 1
  * with units = the mixed point additions they performed (the work unit of the VALU roofline: 10 modular products each
- * in G1), counted on the device from the sorted bucket sizes. */
+ * in G1), counted on the device from the sorted bucket sizes; 5 / 6 = the same kernels as 0 / 1 with ms = the UNION of the
+ * launches' intervals (launches of one kernel that run side by side on different lanes each span the whole phase: the union
+ * is the time the kernel took, the sum counts it once per launch). */
 int fk_stats_reset(fk_ctx *ctx);
 /* Live calibration of the VALU ceilings the measurement quotes (a few milliseconds): out[0] = v_mad_u64_u32 lane-operations
  * per second (the 32 x 32 -> 64-bit multiply-accumulate every Montgomery product is made of), out[1] = Montgomery products
