@@ -40,12 +40,11 @@ struct MsmLane {
     hipStream_t st = nullptr;
     hipStream_t st_sort = nullptr;  // FK_MSM_CU_SPLIT: digits / sort / size ordering on a CU subset of their own (else == st)
     hipEvent_t ev_in = nullptr;     // main stream -> lane: the scalars are ready
-    hipEvent_t ev_front = nullptr, ev_accd = nullptr, ev_tail = nullptr;   // serialised accumulations (fk_ctx::acc_serial): lane -> accumulate stream -> lane; the lane's latest tail is done
-    bool ev_tail_valid = false;
     hipEvent_t ev_sorted = nullptr, ev_lane_done = nullptr;   // the lane's latest sort is complete (sort stream -> lane stream; the prover gates the quotient on it); lane stream -> next sort on this lane
     bool ev_sorted_valid = false;
     bool ev_lane_done_valid = false;
     DevBuf digits, sorted, totals, starts, perm, overlist, tasktab, partials, s2_cnt1, s2_seg, s2_cnt2, s2_tmp_idx, s2_tmp_lo, buckets;
+    DevBuf buckets2;     // the buckets of a multiplication that reuses this lane's sort (B2 after B1): its accumulation is queued right behind B1's, before B1's tail has read `buckets`
     void *h_stage = nullptr;        // pinned host staging: counters read back, oversized-bucket list, task tables
     size_t h_cap = 0;
     const void *last_sort_scalars = nullptr; size_t last_sort_n = 0; unsigned last_sort_c = 0; bool last_merged = false;   // what `sorted` currently holds
@@ -103,12 +102,8 @@ struct fk_ctx {
     // size ordering) and leaves the rest (accumulation, oversized buckets, reduction, download) here, to be queued by
     // msm_run_deferred once the caller has put the quotient between the two
     bool sort_under = false;        // the next multiplication's sort runs underneath accumulations (H in the sorts-first schedule): experiment switches in msm.hip
-    // Accumulations one after the other on a stream of their own (acc_st), every multiplication's tail (oversized buckets,
-    // reduction, download) on its lane underneath the NEXT accumulation: set by the prover in the sorts-first schedule
-    bool acc_serial = false;
-    hipStream_t acc_st = nullptr;
     bool defer_back = false;
-    std::vector<std::function<int()>> deferred;
+    std::vector<std::function<int()>> deferred, deferred_tails;     // accumulations; tails
     bool ev_z_recorded = false;     // fk_prove_r1cs_dev recorded ev_z BEFORE the constraint-system evaluation (z is complete there)
     hipEvent_t ev_acc_done = nullptr; bool ev_acc_done_valid = false;   // behind the most recent bucket accumulation (any lane)
     bool wit_active = false;

@@ -1053,9 +1053,6 @@ static int lane_init(fk_ctx *ctx, MsmLane &ln) {
     }
     FK_HIP(ctx, hipEventCreateWithFlags(&ln.ev_in, hipEventDisableTiming));
     FK_HIP(ctx, hipEventCreateWithFlags(&ln.ev_sorted, hipEventDisableTiming));
-    FK_HIP(ctx, hipEventCreateWithFlags(&ln.ev_front, hipEventDisableTiming));
-    FK_HIP(ctx, hipEventCreateWithFlags(&ln.ev_accd, hipEventDisableTiming));
-    FK_HIP(ctx, hipEventCreateWithFlags(&ln.ev_tail, hipEventDisableTiming));
     return FK_OK;
 }
 
@@ -1129,7 +1126,7 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
     struct Need { DevBuf *b; size_t bytes; };
     const Need needs[] = {
         {&ln.digits, (size_t)p.W * n * 4}, {&ln.sorted, (size_t)p.W * n * 4}, {&ln.totals, WB * 4}, {&ln.starts, WB * 4},
-        {&ln.perm, WB * 4 + SIZE_BINS * 4}, {&ln.overlist, OVER_MAX * sizeof(OverEntry) + sizeof(MsmDyn) + 64}, {&ln.buckets, WB * sizeof(Xyzz<F>)},
+        {&ln.perm, WB * 4 + SIZE_BINS * 4}, {&ln.overlist, OVER_MAX * sizeof(OverEntry) + sizeof(MsmDyn) + 64}, {have_sort ? &ln.buckets2 : &ln.buckets, WB * sizeof(Xyzz<F>)},
         {&ln.tasktab, max_tasks * sizeof(Task) + OVER_MAX * sizeof(OverBucket) + 64}, {&ln.partials, max_tasks * sizeof(Xyzz<F>)},
         {&ln.s2_cnt1, (size_t)p.W * p.nchunks * p.nhi * 4}, {&ln.s2_seg, ((size_t)nseg * 4 + 2) * 4}, {&ln.s2_cnt2, max_tiles * p.nlo * 4},
         {&ln.s2_tmp_idx, (size_t)p.W * n * 4}, {&ln.s2_tmp_lo, (size_t)p.W * n * 2}};
@@ -1251,25 +1248,10 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
     if (split) FK_HIP(ctx, hipStreamWaitEvent(st, ln.ev_sorted, 0));
     tl.active = true; tl.cb = p.cb; tl.wide = p.wide; tl.W = WR; tl.nblk = p.nblk;     // merged: one "window" of weight 1
     *tail_out = ti;
-    // the back of the multiplication: queued now, or by msm_run_deferred (ctx->defer_back)
+    // The back of the multiplication in two pieces -- the accumulation, and the tail (oversized buckets, reduction, download) --
+    // queued now, or by msm_run_deferred (ctx->defer_back): all accumulations first, then all tails, so that on the B pair's lane
+    // the G2 accumulation follows the G1 one at once and both tails come behind (B2 has a bucket buffer of its own for that).
     MsmLane *lnp = &ln; MsmTail *tlp = &tl;
-    const hipStream_t st_lane = st;
-    auto back = [=]() -> int {
-    MsmLane &ln = *lnp; MsmTail &tl = *tlp;
-    // bound late: a multiplication begun on this lane in between (B2 after B1) may have GROWN the bucket buffer, i.e. moved it
-    Xyzz<F> *buckets = ln.buckets.as<Xyzz<F>>();
-    std::vector<EventPair> &evv = (sizeof(F) == sizeof(Fq)) ? ctx->ev_acc : ctx->ev_acc2;
-    // the stream the accumulation runs on: the lane's, or the shared one (fk_ctx::acc_serial) -- then lane -> acc_st before it
-    // and acc_st -> lane behind it, and it also waits for the lane's previous tail (B2 after B1 share the bucket buffer)
-    hipStream_t st = st_lane;
-    if (ctx->acc_serial) {
-        if (!ctx->acc_st) FK_HIP(ctx, hipStreamCreateWithFlags(&ctx->acc_st, hipStreamNonBlocking));
-        st = ctx->acc_st;
-        FK_HIP(ctx, hipEventRecord(ln.ev_front, st_lane));
-        FK_HIP(ctx, hipStreamWaitEvent(st, ln.ev_front, 0));
-        if (ln.ev_tail_valid) FK_HIP(ctx, hipStreamWaitEvent(st, ln.ev_tail, 0));
-    }
-    FK_TRY(stats_begin(ctx, evv, (uint64_t)n, st));
     // FK_MSM_LIMB29=1: G1 accumulator on 9 x 29-bit limbs (field29.hpp).  Measured and NOT the default: the product alone is
     // 155 against 134 G/s, but the mixed addition around it (re-slicing two coordinates per point, signed carry chains for the
     // five differences, 20 % more multiplier operations at an eighth of the simple-ALU rate) comes out at 11.9 against 12.1 G
@@ -1285,32 +1267,38 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
     const bool lazy = t_lazy != 0;
     constexpr int MINW_ = IS_G1 ? 4 : 2;
     constexpr int M29 = IS_G1 ? 1 : 0;
-    if (merged) {
-        if (l29) hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_merged_kernel<F, (IS_G1 ? 3 : 2), M29>), dim3((p.B + 255) / 256), dim3(256), 0, st, d_bases, d_lev, sorted, n,
+    // bound late (inside the pieces): a multiplication begun on this lane in between may have GROWN a buffer, i.e. moved it
+    auto bucket_buf = [=]() -> Xyzz<F> * { return (have_sort ? lnp->buckets2 : lnp->buckets).template as<Xyzz<F>>(); };
+    auto back_acc = [=]() -> int {
+        Xyzz<F> *buckets = bucket_buf();
+        std::vector<EventPair> &evv = (sizeof(F) == sizeof(Fq)) ? ctx->ev_acc : ctx->ev_acc2;
+        FK_TRY(stats_begin(ctx, evv, (uint64_t)n, st));
+        if (merged) {
+            if (l29) hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_merged_kernel<F, (IS_G1 ? 3 : 2), M29>), dim3((p.B + 255) / 256), dim3(256), 0, st, d_bases, d_lev, sorted, n,
+                                        starts, totals, p.B, p.W, dyn, perm, perm + p.B, buckets);
+            else if (lazy) hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_merged_kernel<F, MINW_, 2>), dim3((p.B + 255) / 256), dim3(256), 0, st, d_bases, d_lev, sorted, n,
+                                              starts, totals, p.B, p.W, dyn, perm, perm + p.B, buckets);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_merged_kernel<F, MINW_, 0>), dim3((p.B + 255) / 256), dim3(256), 0, st, d_bases, d_lev, sorted, n,
                                     starts, totals, p.B, p.W, dyn, perm, perm + p.B, buckets);
-        else if (lazy) hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_merged_kernel<F, MINW_, 2>), dim3((p.B + 255) / 256), dim3(256), 0, st, d_bases, d_lev, sorted, n,
-                                          starts, totals, p.B, p.W, dyn, perm, perm + p.B, buckets);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_merged_kernel<F, MINW_, 0>), dim3((p.B + 255) / 256), dim3(256), 0, st, d_bases, d_lev, sorted, n,
-                                starts, totals, p.B, p.W, dyn, perm, perm + p.B, buckets);
-    } else {
-        if (l29) hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_kernel<F, (IS_G1 ? 3 : 2), M29>), dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, d_bases, sorted, n,
+        } else {
+            if (l29) hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_kernel<F, (IS_G1 ? 3 : 2), M29>), dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, d_bases, sorted, n,
+                                        starts, totals, p.B, p.W, dyn, perm, buckets);
+            else if (lazy) hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_kernel<F, MINW_, 2>), dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, d_bases, sorted, n,
+                                              starts, totals, p.B, p.W, dyn, perm, buckets);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_kernel<F, MINW_, 0>), dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, d_bases, sorted, n,
                                     starts, totals, p.B, p.W, dyn, perm, buckets);
-        else if (lazy) hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_kernel<F, MINW_, 2>), dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, d_bases, sorted, n,
-                                          starts, totals, p.B, p.W, dyn, perm, buckets);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_kernel<F, MINW_, 0>), dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, d_bases, sorted, n,
-                                starts, totals, p.B, p.W, dyn, perm, buckets);
-    }
-    FK_HIP(ctx, hipGetLastError());
-    FK_TRY(stats_end(ctx, evv, st));
-    if (!ctx->ev_acc_done) FK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_acc_done, hipEventDisableTiming));
-    FK_HIP(ctx, hipEventRecord(ctx->ev_acc_done, st)); ctx->ev_acc_done_valid = true;
-    FK_DBG_ST(ctx, st, "msm_accumulate");
-    if (st != st_lane) {
-        FK_HIP(ctx, hipEventRecord(ln.ev_accd, st));
-        FK_HIP(ctx, hipStreamWaitEvent(st_lane, ln.ev_accd, 0));
-        st = st_lane;       // the tail runs on the lane
-    }
-    {   // oversized buckets: fixed grids looping over the device-built tables (they leave at once when there is nothing to do)
+        }
+        FK_HIP(ctx, hipGetLastError());
+        FK_TRY(stats_end(ctx, evv, st));
+        if (!ctx->ev_acc_done) FK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_acc_done, hipEventDisableTiming));
+        FK_HIP(ctx, hipEventRecord(ctx->ev_acc_done, st)); ctx->ev_acc_done_valid = true;
+        FK_DBG_ST(ctx, st, "msm_accumulate");
+        return FK_OK;
+    };
+    auto back_tail = [=]() -> int {
+        MsmLane &ln = *lnp; MsmTail &tl = *tlp;
+        Xyzz<F> *buckets = bucket_buf();
+        // oversized buckets: fixed grids looping over the device-built tables (they leave at once when there is nothing to do)
         if (l29) hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_overflow_kernel<F, FC, M29>), dim3(2048), dim3(64), 0, st,
                                     d_bases, d_lev, sorted, n, starts, totals, p.B, dyn, d_tasks, ln.partials.as<Xyzz<FC>>());
         else if (lazy) hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_overflow_kernel<F, FC, 2>), dim3(2048), dim3(64), 0, st,
@@ -1322,33 +1310,30 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
         hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_overflow_fold_kernel<F>), dim3(256), dim3(256), 0, st, d_obs, dyn, ln.partials.as<Xyzz<F>>(), buckets);
         FK_HIP(ctx, hipGetLastError());
         FK_DBG_ST(ctx, st, "msm_overflow_fold");
-    }
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_bucket_reduce_kernel<F>), dim3(p.nblk, WR), dim3(256), 0, st,
-                       buckets, p.B, p.L, p.T, p.nblk, winparts);
-    FK_HIP(ctx, hipGetLastError());
-    FK_HIP(ctx, hipMemcpyAsync(tl.h_wp, winparts, wp_bytes, hipMemcpyDeviceToHost, st));
-    FK_HIP(ctx, hipMemcpyAsync((char *)tl.h_wp + wp_bytes, d_adds, 8, hipMemcpyDeviceToHost, st));
-    FK_HIP(ctx, hipMemcpyAsync((char *)tl.h_wp + wp_bytes + 8, &dyn->error, 4, hipMemcpyDeviceToHost, st));
-    FK_HIP(ctx, hipEventRecord(tl.done, st));
-    if (split) { FK_HIP(ctx, hipEventRecord(ln.ev_lane_done, st)); ln.ev_lane_done_valid = true; }
-    FK_HIP(ctx, hipEventRecord(ln.ev_tail, st)); ln.ev_tail_valid = true;
-    FK_DBG_ST(ctx, st, "msm_bucket_reduce");
-    return FK_OK;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_bucket_reduce_kernel<F>), dim3(p.nblk, WR), dim3(256), 0, st,
+                           buckets, p.B, p.L, p.T, p.nblk, winparts);
+        FK_HIP(ctx, hipGetLastError());
+        FK_HIP(ctx, hipMemcpyAsync(tl.h_wp, winparts, wp_bytes, hipMemcpyDeviceToHost, st));
+        FK_HIP(ctx, hipMemcpyAsync((char *)tl.h_wp + wp_bytes, d_adds, 8, hipMemcpyDeviceToHost, st));
+        FK_HIP(ctx, hipMemcpyAsync((char *)tl.h_wp + wp_bytes + 8, &dyn->error, 4, hipMemcpyDeviceToHost, st));
+        FK_HIP(ctx, hipEventRecord(tl.done, st));
+        if (split) { FK_HIP(ctx, hipEventRecord(ln.ev_lane_done, st)); ln.ev_lane_done_valid = true; }
+        FK_DBG_ST(ctx, st, "msm_bucket_reduce");
+        return FK_OK;
     };
-    if (ctx->defer_back) { ctx->deferred.push_back(back); return FK_OK; }
-    return back();
+    if (ctx->defer_back) { ctx->deferred.push_back(back_acc); ctx->deferred_tails.push_back(back_tail); return FK_OK; }
+    FK_TRY(back_acc());
+    return back_tail();
 }
 
-// queues the deferred backs in the order their multiplications were begun (the lane streams first wait for `after`, if given)
+// queues the deferred pieces in the order their multiplications were begun -- all accumulations, then all tails (the lane
+// streams first wait for `after`, if given)
 int msm_run_deferred(fk_ctx *ctx, hipEvent_t after) {
     if (after) for (MsmLane &ln : ctx->lanes) if (ln.st) FK_HIP(ctx, hipStreamWaitEvent(ln.st, after, 0));
-    if (after && ctx->acc_serial) {
-        if (!ctx->acc_st) FK_HIP(ctx, hipStreamCreateWithFlags(&ctx->acc_st, hipStreamNonBlocking));
-        FK_HIP(ctx, hipStreamWaitEvent(ctx->acc_st, after, 0));
-    }
-    std::vector<std::function<int()>> todo;
-    todo.swap(ctx->deferred);
-    for (auto &f : todo) FK_TRY(f());
+    std::vector<std::function<int()>> accs, tails;
+    accs.swap(ctx->deferred); tails.swap(ctx->deferred_tails);
+    for (auto &f : accs) FK_TRY(f());
+    for (auto &f : tails) FK_TRY(f());
     return FK_OK;
 }
 
@@ -1386,15 +1371,13 @@ int msm_sync(fk_ctx *ctx) {
 
 void msm_abandon(fk_ctx *ctx) {
     ctx->wit_active = false;
-    ctx->defer_back = false; ctx->deferred.clear(); ctx->acc_serial = false;
-    if (ctx->acc_st) (void)hipStreamSynchronize(ctx->acc_st);
+    ctx->defer_back = false; ctx->deferred.clear(); ctx->deferred_tails.clear();
     if (ctx->aux) (void)hipStreamSynchronize(ctx->aux);
     for (int i = 0; i < MSM_TAILS; i++) ctx->tails[i].active = false;
     for (MsmLane &ln : ctx->lanes) { if (ln.st) { (void)hipStreamSynchronize(ln.st); if (ln.st_sort != ln.st) (void)hipStreamSynchronize(ln.st_sort); } ln.last_sort_scalars = nullptr; }
 }
 
 void msm_release(fk_ctx *ctx) {
-    if (ctx->acc_st) { (void)hipStreamSynchronize(ctx->acc_st); (void)hipStreamDestroy(ctx->acc_st); ctx->acc_st = nullptr; }
     if (ctx->aux) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamDestroy(ctx->aux); ctx->aux = nullptr; }
     if (ctx->ev_aux) { (void)hipEventDestroy(ctx->ev_aux); ctx->ev_aux = nullptr; }
     if (ctx->ev_main) { (void)hipEventDestroy(ctx->ev_main); ctx->ev_main = nullptr; }
@@ -1403,13 +1386,10 @@ void msm_release(fk_ctx *ctx) {
     for (MsmLane &ln : ctx->lanes) {
         if (ln.st) (void)hipStreamSynchronize(ln.st);
         for (DevBuf *b : {&ln.digits, &ln.sorted, &ln.totals, &ln.starts, &ln.perm, &ln.overlist, &ln.tasktab, &ln.partials, &ln.s2_cnt1, &ln.s2_seg,
-                          &ln.s2_cnt2, &ln.s2_tmp_idx, &ln.s2_tmp_lo, &ln.buckets})
+                          &ln.s2_cnt2, &ln.s2_tmp_idx, &ln.s2_tmp_lo, &ln.buckets, &ln.buckets2})
             b->release();
         if (ln.h_stage) (void)hipHostFree(ln.h_stage);
         if (ln.ev_in) (void)hipEventDestroy(ln.ev_in);
-        if (ln.ev_front) (void)hipEventDestroy(ln.ev_front);
-        if (ln.ev_accd) (void)hipEventDestroy(ln.ev_accd);
-        if (ln.ev_tail) (void)hipEventDestroy(ln.ev_tail);
         if (ln.ev_sorted) (void)hipEventDestroy(ln.ev_sorted);
         if (ln.ev_lane_done) (void)hipEventDestroy(ln.ev_lane_done);
         if (ln.st_sort && ln.st_sort != ln.st) { (void)hipStreamSynchronize(ln.st_sort); (void)hipStreamDestroy(ln.st_sort); }

@@ -466,12 +466,9 @@ static int prove_msms_dev(fk_ctx *ctx, const fk_key *key, Fr *d_a, Fr *d_b, Fr *
         // ... and the transforms make no headway underneath the accumulations either (one pass took 55 ms there): the
         // witness accumulations are queued behind the quotient.  H's sort then has the whole of them to crawl underneath
         // and a clear run beside their latency-bound tails.
-        // The accumulations of B1, L and A then run side by side on their lanes (they fill each other's last waves).  One after
-        // the other on a stream of their own, each tail underneath the next accumulation (FK_PROVE_ACC_SERIAL=1), was measured
-        // slower: 192.3 - 195.5 against 185.8 - 188.5 ms (profiles/r02_sorts_first_probe.log).
-        static int t_accser = -1;
-        if (t_accser < 0) { const char *e = getenv("FK_PROVE_ACC_SERIAL"); t_accser = e ? atoi(e) : 0; }
-        ctx->acc_serial = gate && t_accser != 0;
+        // The accumulations of B1, L and A then run side by side on their lanes (they fill each other's last waves; one after
+        // the other on a stream of their own was measured slower: 192.3 - 195.5 against 185.8 - 188.5 ms,
+        // profiles/r02_sorts_first_probe.log), B2's right behind B1's, all tails behind the accumulations of their lane.
         if (gate) { const int rcd = msm_run_deferred(ctx, ctx->ev_main); if (rcd != FK_OK) { msm_abandon(ctx); return rcd; } }
         if (!gate) {
             const int rcw = witness_begin(ctx, key, d_z, d_a_aux, d_b_in, d_b_aux, ctx->ev_z);
@@ -481,7 +478,6 @@ static int prove_msms_dev(fk_ctx *ctx, const fk_key *key, Fr *d_a, Fr *d_b, Fr *
         ctx->sort_under = gate;
         const int rch = msm_g1_begin(ctx, key->d_h, d_h + key->h_lo, key->h_hi - key->h_lo, &t_h0, ctx->ev_main, &key->pre_h);
         ctx->sort_under = false;
-        ctx->acc_serial = false;
         if (rch != FK_OK) { msm_abandon(ctx); return rch; }
         const double t2w = now_ms();
         FK_TRY(witness_end(ctx, out, t_h0));
