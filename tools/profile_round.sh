@@ -15,7 +15,7 @@ rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU 
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/gcal -o g -- tools/mulbench/gathercal > $O/gathercal.log 2>&1
 # the kernel trace itself is tens of MB: keep the statistics, compute the busy fraction first
 python3 tools/trace_busy.py $O/kt > $O/kt_busy.txt 2>&1; cat $O/kt_busy.txt
-python3 tools/trace_union.py $O/kt 5 > $O/kt_union.txt 2>&1; python3 tools/trace_gantt.py $O/kt 0.25 > $O/kt_gantt.txt 2>&1
+python3 tools/trace_union.py $O/kt 11 > $O/kt_union.txt 2>&1; python3 tools/trace_gantt.py $O/kt 0.25 > $O/kt_gantt.txt 2>&1
 find $O -name "*kernel_trace.csv" -delete
 find $O -name "*.csv" -size +20M -delete
 ls -la $O | head -40
