@@ -53,7 +53,9 @@ class FkError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, 'libfawkes_hip.so')
+    # FK_LIB_VARIANT=<suffix>: an experimental build of the same sources (tools/ab_probe.sh compares builds on one GPU box)
+    v = os.environ.get('FK_LIB_VARIANT', '')
+    return os.path.join(_HERE, 'libfawkes_hip%s.so' % (('_' + v) if v else ''))
 
 
 def build_library(jobs=3):

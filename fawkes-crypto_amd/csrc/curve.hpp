@@ -70,7 +70,7 @@ struct alignas(16) Xyzz {
     // the same for a q known not to be the point at infinity
     FK_HD void add_mixed_nz(const Affine<F> &q) {
         if (is_inf()) { x = q.x; y = q.y; zz = F::one(); zzz = F::one(); return; }
-        // the ten multiplications form five independent pairs -> five dual-chain products (F::mul2)
+        // the ten multiplications form five independent pairs -> four dual-chain products (F::mul2) and one fused difference of two (F::mulsub)
         F u2, s2;
         F::mul2(q.x, zz, q.y, zzz, u2, s2);
         F p, r;
@@ -86,9 +86,7 @@ struct alignas(16) Xyzz {
         F q2, t1;
         F::addsub2(q_, q_, rr, ppp, q2, t1);         // q2 = 2 q, t1 = rr - ppp
         F x3 = F::sub(t1, q2);
-        F t, yppp;
-        F::mul2(r, F::sub(q_, x3), y, ppp, t, yppp);
-        y = F::sub(t, yppp);
+        y = F::mulsub(r, F::sub(q_, x3), y, ppp);      // r (q - x3) - y ppp: one reduction in G1 on the device (field.hpp)
         x = x3;
         F::mul2(zz, pp, zzz, ppp, zz, zzz);
     }

@@ -192,6 +192,38 @@ struct alignas(16) Fp {
         r1 = mul(a, b); r2 = mul(c, d);
     }
 
+    // q - b (b <= q): the negative of b as a product operand (Fq2T::mul) -- not a reduced value when b is 0
+    static FK_HD Fp negq(const Fp &b) {
+        Fp r; uint32_t br = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { const uint64_t t = (uint64_t)P::q(i) - b.v[i] - br; r.v[i] = (uint32_t)t; br = (uint32_t)(t >> 63); }
+        return r;
+    }
+    // (a0 + a1 u)(b0 + b1 u), u^2 = -1, with ONE Montgomery reduction per component (device, inlined flavour): r0 = a0 b0 - a1 b1,
+    // r1 = a0 b1 + a1 b0.  The sum of two products is below 2 q^2, its reduction below 1.26 q (lazy: q = 2p) or 1.38 q (q = p),
+    // one conditional subtraction of q brings it back under q.
+    static constexpr bool HAS_FQ2MUL =
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(FK_FQ2_KARATSUBA)
+        INL;
+#else
+        false;
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+    static __device__ __forceinline__ void fq2mul(const Fp &a0, const Fp &a1, const Fp &b0, const Fp &b1, Fp &r0, Fp &r1) {
+        fq2mul_body_asm(a0, a1, b0, b1, negq(b1), r0, r1);
+    }
+#endif
+
+    // a b - c d.  Device, inlined flavour: ONE Montgomery reduction for the sum a b + (q - c) d (mulsum_body_asm), i.e. a
+    // reduction, a subtraction and their carry handling less than two products and a difference.
+    static FK_HD Fp mulsub(const Fp &a, const Fp &b, const Fp &c, const Fp &d) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(FK_NO_MULSUM)
+        if constexpr (INL) return mulsum_body_asm(a, b, negq(c), d);
+#endif
+        Fp x, y; mul2(a, b, c, d, x, y);
+        return sub(x, y);
+    }
+
     // CIOS Montgomery product a * b * 2^-256 mod p.
     static FK_HD Fp mul_body(const Fp &a, const Fp &b) {
         uint32_t t[8];
@@ -297,7 +329,10 @@ struct alignas(16) Fq2T {
     static FK_HD void add2(const Fq2 &a, const Fq2 &b, const Fq2 &c, const Fq2 &d, Fq2 &r1, Fq2 &r2) { const Fq2 t = add(a, b); r2 = add(c, d); r1 = t; }
     static FK_HD void sub2(const Fq2 &a, const Fq2 &b, const Fq2 &c, const Fq2 &d, Fq2 &r1, Fq2 &r2) { const Fq2 t = sub(a, b); r2 = sub(c, d); r1 = t; }
     static FK_HD void addsub2(const Fq2 &a, const Fq2 &b, const Fq2 &c, const Fq2 &d, Fq2 &r1, Fq2 &r2) { const Fq2 t = add(a, b); r2 = sub(c, d); r1 = t; }
-    static FK_HD Fq2 mul(const Fq2 &a, const Fq2 &b) {  // Karatsuba, 3 base multiplications
+    static FK_HD Fq2 mul(const Fq2 &a, const Fq2 &b) {  // Karatsuba, 3 base multiplications -- or the fused schoolbook form
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (Fq::HAS_FQ2MUL) { Fq2 r; Fq::fq2mul(a.c0, a.c1, b.c0, b.c1, r.c0, r.c1); return r; }
+#endif
         Fq aa, bb, sa, sb;
         Fq::mul2(a.c0, b.c0, a.c1, b.c1, aa, bb);
         Fq::add2(a.c0, a.c1, b.c0, b.c1, sa, sb);
@@ -313,6 +348,7 @@ struct alignas(16) Fq2T {
         r2 = mul(c, d);
         r1 = t;
     }
+    static FK_HD Fq2 mulsub(const Fq2 &a, const Fq2 &b, const Fq2 &c, const Fq2 &d) { return sub(mul(a, b), mul(c, d)); }
     static FK_HD Fq2 sqr(const Fq2 &a) {  // (c0+c1)(c0-c1), 2 c0 c1
         Fq s, d, m, n;
         Fq::addsub2(a.c0, a.c1, a.c0, a.c1, s, d);

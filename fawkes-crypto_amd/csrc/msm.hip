@@ -46,7 +46,10 @@ struct MsmPlan {
     uint32_t L, T, nblk;     // bucket-reduce: buckets per lane, lanes per window, blocks per window
     uint32_t LB, nhi, nlo;   // low bits of the bucket index, number of high / low bins
 };
-static constexpr uint32_t S2_TILE = 16384;     // entries per staged sort tile
+#ifndef FK_S2_TILE
+#define FK_S2_TILE 16384
+#endif
+static constexpr uint32_t S2_TILE = FK_S2_TILE;     // entries per staged sort tile (8192: two second-pass workgroups per compute unit -- measured)
 static constexpr uint32_t S2_EPT = S2_TILE / 1024;      // entries per lane (1024-lane workgroups)
 
 // Windows are sized from n.  Sizing them from the number of non-trivial scalars (0 and 1 never reach the ordinary
@@ -102,7 +105,10 @@ static MsmPlan make_plan(size_t n, unsigned forced_c, bool merged = false) {
     if (t_redl > 0 && (uint32_t)t_redl <= p.B) p.L = (uint32_t)t_redl;
     p.T = p.B / p.L;
     p.nblk = (p.T + 255) / 256;
-    p.LB = (c - 1) < 10 ? (c - 1) : 10;
+    // low bits sorted by the SECOND pass (its bins; the first pass splits by the bits above them).  FK_MSM_LB = 10 .. 12.
+    static int t_lb = -1;
+    if (t_lb < 0) { const char *e = getenv("FK_MSM_LB"); t_lb = e ? atoi(e) : 10; if (t_lb < 10 || t_lb > 12) t_lb = 10; }
+    p.LB = (c - 1) < (uint32_t)t_lb ? (c - 1) : (uint32_t)t_lb;
     p.nlo = 1u << p.LB;
     p.nhi = p.B >> p.LB;
     return p;
@@ -417,19 +423,25 @@ __global__ __launch_bounds__(256) void msm_over_list_kernel(const uint32_t *tota
 // Second-pass scatter with LDS staging: entries of the tile are ranked per low bin (LDS counters), placed in bin order in
 // an LDS staging buffer and then written out so that consecutive lanes store consecutive addresses of one bucket run
 // (64-byte runs on average) instead of one 4-byte store per lane to an arbitrary line.
+template <uint32_t MAXLO>      // low bins the LDS tables are sized for (1024, 2048, 4096)
 __global__ __launch_bounds__(1024) void s2_scatter2_kernel(const uint32_t *tmp_idx, const uint16_t *tmp_lo, size_t n, uint32_t nhi, uint32_t nlo, uint32_t B,
                                                             const uint32_t *tile_start, uint32_t nseg, const uint32_t *seg_start, const uint32_t *seg_size,
                                                             const uint32_t *cnt2, const uint32_t *starts, uint32_t *sorted) {
-    __shared__ uint32_t lcnt[1024];          // per-bin count, then exclusive offset inside the tile
+    constexpr uint32_t BPL = MAXLO / 1024;   // bins per lane
+    __shared__ uint32_t lcnt[MAXLO];         // per-bin count, then exclusive offset inside the tile
     __shared__ uint32_t wsum[16];
-    __shared__ uint32_t gbase[1024];         // global position (window-relative) of this tile's first entry of the bin
+    __shared__ uint32_t gbase[MAXLO];        // global position (window-relative) of this tile's first entry of the bin
     __shared__ uint32_t stage_idx[S2_TILE];
     __shared__ uint16_t stage_lo[S2_TILE];
     const uint32_t tile = blockIdx.x, tid = threadIdx.x;
     if (tile >= tile_start[nseg]) return;        // see s2_hist2_kernel
     const uint32_t sgm = s2_find_segment(tile_start, nseg, tile), w = sgm / nhi, h = sgm % nhi, t = tile - tile_start[sgm];
-    lcnt[tid] = 0;
-    gbase[tid] = tid < nlo ? starts[(size_t)w * B + (size_t)h * nlo + tid] + cnt2[(size_t)tile * nlo + tid] : 0;
+#pragma unroll
+    for (uint32_t i = 0; i < BPL; i++) {
+        const uint32_t b = tid + i * 1024;
+        lcnt[b] = 0;
+        gbase[b] = b < nlo ? starts[(size_t)w * B + (size_t)h * nlo + b] + cnt2[(size_t)tile * nlo + b] : 0;
+    }
     __syncthreads();
     const uint32_t size = seg_size[sgm], lo = t * S2_TILE, cnt = (lo + S2_TILE < size ? lo + S2_TILE : size) - lo;
     const size_t base = (size_t)w * n + seg_start[sgm] + lo;
@@ -440,11 +452,14 @@ __global__ __launch_bounds__(1024) void s2_scatter2_kernel(const uint32_t *tmp_i
         if (k < cnt) { e_idx[j] = tmp_idx[base + k]; e_lo[j] = tmp_lo[base + k]; e_rank[j] = atomicAdd(&lcnt[e_lo[j]], 1u); }
     }
     __syncthreads();
-    // exclusive scan of the 1024 bin counts
-    const uint32_t mine = lcnt[tid];
+    // exclusive scan of the bin counts: BPL consecutive bins per lane
+    uint32_t c[BPL], mine = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < BPL; i++) { c[i] = lcnt[tid * BPL + i]; mine += c[i]; }
     uint32_t all_;
-    const uint32_t excl = block_excl_scan_1024(mine, wsum, &all_);
-    lcnt[tid] = excl;
+    uint32_t excl = block_excl_scan_1024(mine, wsum, &all_);
+#pragma unroll
+    for (uint32_t i = 0; i < BPL; i++) { lcnt[tid * BPL + i] = excl; excl += c[i]; }
     __syncthreads();
 #pragma unroll
     for (uint32_t j = 0; j < S2_EPT; j++) {
@@ -1175,7 +1190,7 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
         }
         static int t_under1 = -1, t_under2 = -1;      // FK_MSM_UNDER_NT1 / _NT2: the same choice for a sort that runs underneath accumulations (ctx->sort_under)
         if (t_under1 < 0) { const char *e = getenv("FK_MSM_UNDER_NT1"); t_under1 = e ? atoi(e) : t_nt1; e = getenv("FK_MSM_UNDER_NT2"); t_under2 = e ? atoi(e) : t_nt2; }
-        const int nt1 = ctx->sort_under ? t_under1 : t_nt1, nt2 = ctx->sort_under ? t_under2 : t_nt2;
+        const int nt1 = ctx->sort_under ? t_under1 : t_nt1, nt2 = p.nlo > 1024 ? 0 : (ctx->sort_under ? t_under2 : t_nt2);     // the two-atomic second pass is built for <= 1024 bins
         if (nt1 == 256)
             hipLaunchKernelGGL(s2_scatter1_n256_kernel, dim3(p.nchunks, p.W), dim3(256), 0, ss, digits, n, p.chunk, p.nchunks, p.LB, p.nhi, cnt1, seg_start, tmp_idx, tmp_lo);
         else if (nt1 == 512)
@@ -1202,8 +1217,11 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
         else if (nt2 == 1024)
             hipLaunchKernelGGL(s2_scatter2_n1024_kernel, dim3(n_tiles), dim3(1024), 0, ss, tmp_idx, tmp_lo, n, p.nhi, p.nlo, p.B, tile_start, nseg, seg_start, seg_size, cnt2, starts, sorted);
         else
-            hipLaunchKernelGGL(s2_scatter2_kernel, dim3(n_tiles), dim3(1024), 0, ss, tmp_idx, tmp_lo, n, p.nhi, p.nlo, p.B, tile_start, nseg, seg_start,
-                               seg_size, cnt2, starts, sorted);
+        {
+            if (p.nlo <= 1024) hipLaunchKernelGGL(s2_scatter2_kernel<1024>, dim3(n_tiles), dim3(1024), 0, ss, tmp_idx, tmp_lo, n, p.nhi, p.nlo, p.B, tile_start, nseg, seg_start, seg_size, cnt2, starts, sorted);
+            else if (p.nlo <= 2048) hipLaunchKernelGGL(s2_scatter2_kernel<2048>, dim3(n_tiles), dim3(1024), 0, ss, tmp_idx, tmp_lo, n, p.nhi, p.nlo, p.B, tile_start, nseg, seg_start, seg_size, cnt2, starts, sorted);
+            else hipLaunchKernelGGL(s2_scatter2_kernel<4096>, dim3(n_tiles), dim3(1024), 0, ss, tmp_idx, tmp_lo, n, p.nhi, p.nlo, p.B, tile_start, nseg, seg_start, seg_size, cnt2, starts, sorted);
+        }
         FK_HIP(ctx, hipGetLastError());
         FK_DBG_ST(ctx, ss, "msm_sort_pass2");
         ln.last_sort_scalars = (const void *)d_scalars; ln.last_sort_n = n; ln.last_sort_c = p.c; ln.last_merged = merged;

@@ -84,14 +84,14 @@ def gen_dual(o, op1, op2):
     o.append('    }')
 
 
-def gen_red2(o):
-    """two conditional subtractions of p at once (the tail of a dual Montgomery product: x, y < 2p)"""
-    o.append('    static __device__ __forceinline__ void red2(const Fp &x, const Fp &y, Fp &r1, Fp &r2) {')
+def gen_red2(o, name='red2', mod='p'):
+    """two conditional subtractions of p at once (the tail of a dual Montgomery product: x, y < 2p); red2q: of q"""
+    o.append('    static __device__ __forceinline__ void %s(const Fp &x, const Fp &y, Fp &r1, Fp &r2) {' % name)
     o.append('        uint32_t t1[8], t2[8]; uint64_t w1, w2; Fp u, v;')
     for k in range(8):
         cs = ', '.join('"%s"(%s)' % ('=&s' if k == 0 else '+s', n) for n in ('w1', 'w2'))
         body = '\\n\\t'.join([prim('S', k, '%0', '%2', '%4', '%6'), prim('S', k, '%1', '%3', '%5', '%6'), 's_nop 0'])
-        o.append('        asm("%s" : "=&v"(t1[%d]), "=&v"(t2[%d]), %s : "v"(x.v[%d]), "v"(y.v[%d]), "v"(P::p(%d)));' % (body, k, k, cs, k, k, k))
+        o.append('        asm("%s" : "=&v"(t1[%d]), "=&v"(t2[%d]), %s : "v"(x.v[%d]), "v"(y.v[%d]), "v"(P::%s(%d)));' % (body, k, k, cs, k, k, mod, k))
     first = True
     for src, t, res, w in (('x', 't1', 'u', 'w1'), ('y', 't2', 'v', 'w2')):
         for half in range(2):
@@ -102,6 +102,24 @@ def gen_red2(o):
             ins = ', '.join('"v"(%s.v[%d]), "v"(%s[%d])' % (src, k, t, k) for k in ks)
             o.append('        asm("%s" : %s : %s, "s"(%s));' % ('\\n\\t'.join(lines), outs, ins, w))
     o.append('        r1 = u; r2 = v;')
+    o.append('    }')
+
+
+def gen_red1q(o):
+    """one conditional subtraction of q (the tail of a*b + c*d with one reduction)"""
+    o.append('    static __device__ __forceinline__ Fp red1q(const Fp &x) {')
+    o.append('        uint32_t t[8]; uint64_t w; Fp r;')
+    for k in range(8):
+        cs = '"%s"(w)' % ('=&s' if k == 0 else '+s')
+        body = '\\n\\t'.join([prim('S', k, '%0', '%1', '%2', '%3'), 's_nop 0', 's_nop 0'])
+        o.append('        asm("%s" : "=&v"(t[%d]), %s : "v"(x.v[%d]), "v"(P::q(%d)));' % (body, k, cs, k, k))
+    for half in range(2):
+        ks = range(4 * half, 4 * half + 4)
+        lines = (['s_nop 0'] if half == 0 else []) + ['v_cndmask_b32_e64 %%%d, %%%d, %%%d, %%12' % (i, 5 + 2 * i, 4 + 2 * i) for i in range(4)]
+        outs = ', '.join('"=&v"(r.v[%d])' % k for k in ks)
+        ins = ', '.join('"v"(x.v[%d]), "v"(t[%d])' % (k, k) for k in ks)
+        o.append('        asm("%s" : %s : %s, "s"(w));' % ('\\n\\t'.join(lines), outs, ins))
+    o.append('        return r;')
     o.append('    }')
 
 
@@ -140,6 +158,8 @@ def main():
     gen_dual(o, 'S', 'S')
     gen_dual(o, 'A', 'S')
     gen_red2(o)
+    gen_red2(o, 'red2q', 'q')
+    gen_red1q(o)
     text = '\n'.join(o) + '\n'
     n, bad = check(text)
     if bad or n == 0:

@@ -160,6 +160,60 @@ def gen_mul2(o):
     o.append('    }')
 
 
+def gen_mulsum(o):
+    """a*b + c*d with ONE Montgomery reduction (single chain): every column holds the products of both terms."""
+    o.append('// a*b + c*d with one Montgomery reduction: Y3 = R (Q - X3) - Y1 PPP of the mixed addition (c = -Y1); see tools/gen_mont_mul.py')
+    o.append('    static __device__ __forceinline__ Fp mulsum_body_asm(const Fp &a, const Fp &b, const Fp &c, const Fp &d) {')
+    o.append('        uint64_t lo = 0; uint32_t hi; uint64_t c0, c1, c2;')
+    o.append('        uint32_t m0, m1, m2, m3, m4, m5, m6, m7;')
+    o.append('        Fp r;')
+    for k, ab, mp in columns():
+        o.append('        // column %d' % k)
+        if mp:
+            o.append(stmt1([('m%d' % i, 'P::p(%d)' % j) for i, j in mp], 'vs', first=True))
+        if ab:
+            o.append(stmt1([('a.v[%d]' % i, 'b.v[%d]' % j) for i, j in ab], 'vv', first=not mp))
+            o.append(stmt1([('c.v[%d]' % i, 'd.v[%d]' % j) for i, j in ab], 'vv'))
+        if k < 8:
+            o.append('        m%d = (uint32_t)lo * P::INV;' % k)
+            o.append(stmt1([('m%d' % k, 'P::p(0)')], 'vs'))
+        else:
+            o.append('        r.v[%d] = (uint32_t)lo;' % (k - 8))
+        if mp or ab:
+            o.append('        lo = (lo >> 32) | ((uint64_t)hi << 32);')
+    o.append('        return red1q(r);      // a sum of two products: below 2.6 q before this, below q after it')
+    o.append('    }')
+
+
+def gen_fq2mul(o):
+    """Fq2 product by the schoolbook rule with ONE Montgomery reduction per component: r0 = a0*b0 + a1*nb1 (nb1 = -b1),
+    r1 = a0*b1 + a1*b0 -- two column accumulators interleaved like mul2, each column holding the products of both terms.
+    400 multiply-accumulates like Karatsuba's three products (408), but none of its five additions / subtractions."""
+    o.append('// Fq2 product, schoolbook with one reduction per component (the caller passes nb1 = -b1): see tools/gen_mont_mul.py')
+    o.append('    static __device__ __forceinline__ void fq2mul_body_asm(const Fp &a0, const Fp &a1, const Fp &b0, const Fp &b1, const Fp &nb1, Fp &r0, Fp &r1) {')
+    o.append('        uint64_t lo = 0, lo2 = 0; uint32_t hi, hi2; uint64_t a0_, a1_, b0_, b1_;'.replace('a0_, a1_, b0_, b1_', 'ca0, ca1, cb0, cb1'))
+    o.append('        uint32_t m0, m1, m2, m3, m4, m5, m6, m7, n0, n1, n2, n3, n4, n5, n6, n7;')
+    o.append('        Fp x, y;')
+    for k, ab, mp in columns():
+        o.append('        // column %d' % k)
+        if mp:
+            o.append(stmt2([('m%d' % i, 'P::p(%d)' % j) for i, j in mp], [('n%d' % i, 'P::p(%d)' % j) for i, j in mp], 'vs', first=True).replace('(a0)', '(ca0)').replace('(a1)', '(ca1)').replace('(b0)', '(cb0)').replace('(b1)', '(cb1)'))
+        pa = [('a0.v[%d]' % i, 'b0.v[%d]' % j) for i, j in ab] + [('a1.v[%d]' % i, 'nb1.v[%d]' % j) for i, j in ab]
+        pb = [('a0.v[%d]' % i, 'b1.v[%d]' % j) for i, j in ab] + [('a1.v[%d]' % i, 'b0.v[%d]' % j) for i, j in ab]
+        for lo_ in range(0, len(pa), 5):
+            st = stmt2(pa[lo_:lo_ + 5], pb[lo_:lo_ + 5], 'vv', first=(not mp and lo_ == 0))
+            o.append(st.replace('"=&s"(a0)', '"=&s"(ca0)').replace('"=&s"(a1)', '"=&s"(ca1)').replace('"=&s"(b0)', '"=&s"(cb0)').replace('"=&s"(b1)', '"=&s"(cb1)'))
+        if k < 8:
+            o.append('        m%d = (uint32_t)lo * P::INV; n%d = (uint32_t)lo2 * P::INV;' % (k, k))
+            o.append(stmt2([('m%d' % k, 'P::p(0)')], [('n%d' % k, 'P::p(0)')], 'vs').replace('(a0)', '(ca0)').replace('(a1)', '(ca1)').replace('(b0)', '(cb0)').replace('(b1)', '(cb1)'))
+        else:
+            o.append('        x.v[%d] = (uint32_t)lo; y.v[%d] = (uint32_t)lo2;' % (k - 8, k - 8))
+        if mp or ab:
+            o.append('        lo = (lo >> 32) | ((uint64_t)hi << 32); lo2 = (lo2 >> 32) | ((uint64_t)hi2 << 32);')
+    o.append('        red2q(x, y, r0, r1);      // a sum of two products: below 2.6 q before this, below q after it')
+    o.append('    }')
+
+
 def check(text):
     """Static check of the hazard rule on the generated text: inside every asm string, a v_addc that reads carry
     operand %k must sit >= 2 instructions after the last instruction that wrote %k."""
@@ -189,6 +243,8 @@ def main():
          '// schedule and the SGPR-carry hazard rule it obeys).']
     gen_mul(o)
     gen_mul2(o)
+    gen_mulsum(o)
+    gen_fq2mul(o)
     text = '\n'.join(o) + '\n'
     n, bad = check(text)
     if bad:
