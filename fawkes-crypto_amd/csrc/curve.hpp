@@ -80,7 +80,7 @@ struct alignas(16) Xyzz {
             return;
         }
         F pp, rr;
-        F::mul2(p, p, r, r, pp, rr);
+        F::sqr2(p, r, pp, rr);
         F ppp, q_;
         F::mul2(p, pp, x, pp, ppp, q_);
         F q2, t1;

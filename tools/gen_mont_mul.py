@@ -160,6 +160,36 @@ def gen_mul2(o):
     o.append('    }')
 
 
+def gen_sqr2(o):
+    """Two squarings at once (r1 = a^2, r2 = c^2): every cross product a_i a_j, i < j, is taken once against a doubled limb --
+    36 multiply-accumulates per square instead of 64.  The doubled limb is d_j = (a_j << 1) | (a_(j-1) >> 31) for j > i + 1
+    and e_j = a_j << 1 for j = i + 1: the bit that a_i's doubling carries into limb i + 1 belongs to the pairs of a_i itself
+    and must not be counted (sum over j > i of the doubled limbs = 2 * (a's limbs above i) exactly)."""
+    o.append('// Two squarings (the caller passes the doubled limbs ad / ae, cd / ce): cross products once; see tools/gen_mont_mul.py')
+    o.append('    static __device__ __forceinline__ void sqr2_body_asm(const Fp &a, const Fp &ad, const Fp &ae, const Fp &c, const Fp &cd, const Fp &ce, Fp &r1, Fp &r2) {')
+    o.append('        uint64_t lo = 0, lo2 = 0; uint32_t hi, hi2; uint64_t a0, a1, b0, b1;')
+    o.append('        uint32_t m0, m1, m2, m3, m4, m5, m6, m7, n0, n1, n2, n3, n4, n5, n6, n7;')
+    o.append('        Fp x, y;')
+    for k, ab, mp in columns():
+        o.append('        // column %d' % k)
+        if mp:
+            o.append(stmt2([('m%d' % i, 'P::p(%d)' % j) for i, j in mp], [('n%d' % i, 'P::p(%d)' % j) for i, j in mp], 'vs', first=True))
+        sq = [(i, j) for i, j in ab if i <= j]
+        pa = [('a.v[%d]' % i, ('a.v[%d]' if i == j else ('ae.v[%d]' if j == i + 1 else 'ad.v[%d]')) % j) for i, j in sq]
+        pb = [('c.v[%d]' % i, ('c.v[%d]' if i == j else ('ce.v[%d]' if j == i + 1 else 'cd.v[%d]')) % j) for i, j in sq]
+        for lo_ in range(0, len(pa), 5):
+            o.append(stmt2(pa[lo_:lo_ + 5], pb[lo_:lo_ + 5], 'vv', first=(not mp and lo_ == 0)))
+        if k < 8:
+            o.append('        m%d = (uint32_t)lo * P::INV; n%d = (uint32_t)lo2 * P::INV;' % (k, k))
+            o.append(stmt2([('m%d' % k, 'P::p(0)')], [('n%d' % k, 'P::p(0)')], 'vs'))
+        else:
+            o.append('        x.v[%d] = (uint32_t)lo; y.v[%d] = (uint32_t)lo2;' % (k - 8, k - 8))
+        if mp or ab:
+            o.append('        lo = (lo >> 32) | ((uint64_t)hi << 32); lo2 = (lo2 >> 32) | ((uint64_t)hi2 << 32);')
+    o.append('        fin2(x, y, r1, r2);')
+    o.append('    }')
+
+
 def gen_mulsum(o):
     """a*b + c*d with ONE Montgomery reduction (single chain): every column holds the products of both terms."""
     o.append('// a*b + c*d with one Montgomery reduction: Y3 = R (Q - X3) - Y1 PPP of the mixed addition (c = -Y1); see tools/gen_mont_mul.py')
@@ -243,6 +273,7 @@ def main():
          '// schedule and the SGPR-carry hazard rule it obeys).']
     gen_mul(o)
     gen_mul2(o)
+    gen_sqr2(o)
     gen_mulsum(o)
     gen_fq2mul(o)
     text = '\n'.join(o) + '\n'
