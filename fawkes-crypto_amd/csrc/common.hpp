@@ -104,7 +104,8 @@ struct fk_ctx {
     bool sort_under = false;        // the next multiplication's sort runs underneath accumulations (H in the sorts-first schedule): experiment switches in msm.hip
     bool defer_back = false;
     std::vector<std::function<int()>> deferred, deferred_tails;     // accumulations; tails
-    bool ev_z_recorded = false;     // fk_prove_r1cs_dev recorded ev_z BEFORE the constraint-system evaluation (z is complete there)
+    bool ev_z_recorded = false;
+    bool wit_early = false;         // fk_prove_r1cs_dev has begun the witness multiplications already (prove_witness_early)     // fk_prove_r1cs_dev recorded ev_z BEFORE the constraint-system evaluation (z is complete there)
     hipEvent_t ev_acc_done = nullptr; bool ev_acc_done_valid = false;   // behind the most recent bucket accumulation (any lane)
     bool wit_active = false;
     const fk::QueryIdx *qidx = nullptr;   // set by the resident-constraint-system entry points for the duration of a call
@@ -239,7 +240,10 @@ int key_precompute(fk_ctx *ctx, fk_key *key);
 void key_pre_free(fk_key *key);
 int msm_g2_end(fk_ctx *ctx, int tail, G2Xyzz *out);
 void msm_abandon(fk_ctx *ctx);
-int msm_run_deferred(fk_ctx *ctx, hipEvent_t after);      // see fk_ctx::defer_back
+int msm_run_deferred(fk_ctx *ctx, hipEvent_t after);
+// sorts-first schedule, resident constraint system: begins the witness multiplications (waiting for ctx->ev_z) and makes the main
+// stream wait for their sorts -- called BEFORE the evaluation of a, b, c is queued.  Returns 1 if it did, 0 if the schedule is off.
+int prove_witness_early(fk_ctx *ctx, const fk_key *key, const void *d_z, const void *d_a_aux, const void *d_b_in, const void *d_b_aux);      // see fk_ctx::defer_back
 void msm_release(fk_ctx *ctx);
 int msm_sync(fk_ctx *ctx);
 // reuse_sort: the scalars are the ones of the immediately preceding MSM call on this context (same pointer

@@ -382,6 +382,29 @@ static int witness_begin(fk_ctx *ctx, const fk_key *key, const Fr *d_z, const ui
     return FK_OK;
 }
 
+static bool spmv_after_sorts() {
+    static int t = -1;
+    if (t < 0) { const char *e = getenv("FK_PROVE_SPMV_AFTER_SORTS"); t = e ? atoi(e) : 0; }      // measured slower, see fk_prove_r1cs_dev
+    return t != 0;
+}
+extern "C++" {
+namespace fk {
+int prove_witness_early(fk_ctx *ctx, const fk_key *key, const void *d_z, const void *d_a_aux, const void *d_b_in, const void *d_b_aux) {
+    if (!sorts_first(key) || !spmv_after_sorts()) return 0;
+    static int t_wfirst = -1;
+    if (t_wfirst < 0) { const char *e = getenv("FK_PROVE_WITNESS_FIRST"); t_wfirst = e ? atoi(e) : -2; }
+    if (t_wfirst == 0) return 0;
+    ctx->lane_next = 0;
+    const int rc = witness_begin(ctx, key, (const Fr *)d_z, (const uint8_t *)d_a_aux, (const uint8_t *)d_b_in, (const uint8_t *)d_b_aux, ctx->ev_z);
+    if (rc != FK_OK) { msm_abandon(ctx); return -rc; }
+    for (MsmLane &ln : ctx->lanes)
+        if (ln.ev_sorted_valid) { if (hipStreamWaitEvent(ctx->stream, ln.ev_sorted, 0) != hipSuccess) { msm_abandon(ctx); return -FK_ERR_HIP; } ln.ev_sorted_valid = false; }
+    ctx->wit_early = true;
+    return 1;
+}
+}  // namespace fk
+}  // extern "C++"
+
 static int witness_end(fk_ctx *ctx, uint8_t out[FK_MSM_RESULT_BYTES], int tail_h = -1) {
     if (!ctx->wit_active) { msm_abandon(ctx); FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "prove: no witness multiplications in flight"); }
     ctx->wit_active = false;
@@ -447,7 +470,11 @@ static int prove_msms_dev(fk_ctx *ctx, const fk_key *key, Fr *d_a, Fr *d_b, Fr *
     // sorts run beside the evaluation of a, b, c (latency-bound gathers), and the quotient's first kernel waits for the
     // sorts: from then on transforms and accumulations -- all VALU-bound -- share the GPU without anything crawling, and H
     // (its own lane) sorts as soon as the quotient is done.
-    const bool gate = wfirst && sorts_first(key);
+    // (resident constraint system: fk_prove_r1cs_dev has queued the witness multiplications already, their sorts in front of
+    // the evaluation of a, b, c and their accumulations beside it -- prove_witness_early)
+    const bool early = ctx->wit_early;
+    ctx->wit_early = false;
+    const bool gate = wfirst && sorts_first(key) && !early;
     static int t_accgate = -1;      // FK_PROVE_ACC_AFTER_NTT (default 1): the witness accumulations wait for the quotient, see below
     if (t_accgate < 0) { const char *e = getenv("FK_PROVE_ACC_AFTER_NTT"); t_accgate = e ? atoi(e) : 1; }
     if (gate) {
@@ -470,12 +497,12 @@ static int prove_msms_dev(fk_ctx *ctx, const fk_key *key, Fr *d_a, Fr *d_b, Fr *
         // the other on a stream of their own was measured slower: 192.3 - 195.5 against 185.8 - 188.5 ms,
         // profiles/r02_sorts_first_probe.log), B2's right behind B1's, all tails behind the accumulations of their lane.
         if (gate) { const int rcd = msm_run_deferred(ctx, ctx->ev_main); if (rcd != FK_OK) { msm_abandon(ctx); return rcd; } }
-        if (!gate) {
+        if (!gate && !early) {
             const int rcw = witness_begin(ctx, key, d_z, d_a_aux, d_b_in, d_b_aux, ctx->ev_z);
             if (rcw != FK_OK) { msm_abandon(ctx); return rcw; }
         }
         int t_h0 = -1;
-        ctx->sort_under = gate;
+        ctx->sort_under = gate || early;
         const int rch = msm_g1_begin(ctx, key->d_h, d_h + key->h_lo, key->h_hi - key->h_lo, &t_h0, ctx->ev_main, &key->pre_h);
         ctx->sort_under = false;
         if (rch != FK_OK) { msm_abandon(ctx); return rch; }

@@ -396,9 +396,17 @@ int fk_prove_r1cs_dev(fk_ctx *ctx, const fk_key *key, const fk_r1cs_dev *r, cons
         FK_HIP(ctx, hipEventRecord(ctx->ev_z, ctx->stream));
         ctx->ev_z_recorded = true;
     }
-    const int rce = fk_r1cs_eval_dev(ctx, r, d_z, ctx->stage_a.p, ctx->stage_b.p, ctx->stage_c.p);
-    if (rce != FK_OK) { ctx->ev_z_recorded = false; return rce; }
+    // Experiment (FK_PROVE_SPMV_AFTER_SORTS=1, off): the witness multiplications queued HERE, the evaluation of a, b, c behind
+    // their sorts (which then run alone) and underneath their accumulations -- its workgroups (256 lanes, 93 registers, no LDS)
+    // fit where an accumulate workgroup has left.  They do not get those places: the evaluation took 47.6 ms there instead of
+    // 12 and ended with the accumulations; 178.1 - 179.2 against 174.8 - 175.1 ms (profiles/r02_sorts_first_probe.log).
     ctx->qidx = &r->qidx;      // the queries' index lists are known: no per-proof density compaction
+    if (t_zearly) {
+        const int we = prove_witness_early(ctx, key, d_z, r->d_a_aux, r->d_b_in, r->d_b_aux);
+        if (we < 0) { ctx->qidx = nullptr; ctx->ev_z_recorded = false; return -we; }
+    }
+    const int rce = fk_r1cs_eval_dev(ctx, r, d_z, ctx->stage_a.p, ctx->stage_b.p, ctx->stage_c.p);
+    if (rce != FK_OK) { if (ctx->wit_early) { msm_abandon(ctx); ctx->wit_early = false; } ctx->qidx = nullptr; ctx->ev_z_recorded = false; return rce; }
     const int rc = fk_prove_dev(ctx, key, ctx->stage_a.p, ctx->stage_b.p, ctx->stage_c.p, rows, d_z, r->d_a_aux, r->d_b_in, r->d_b_aux, rr, ss, out_proof, tm);
     ctx->qidx = nullptr;
     ctx->ev_z_recorded = false;
