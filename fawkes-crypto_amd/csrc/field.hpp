@@ -232,6 +232,16 @@ struct alignas(16) Fp {
         mul2(a, a, c, c, r1, r2);
     }
 
+    // a0 b0 + a1 b1 + a2 b2 + a3 b3, canonical operands.  Device, inlined flavour: one Montgomery reduction for the four products.
+    static FK_HD Fp dot4(const Fp &a0, const Fp &b0, const Fp &a1, const Fp &b1, const Fp &a2, const Fp &b2, const Fp &a3, const Fp &b3) {
+        static_assert(!P::LAZY, "dot4: the bound holds for canonical operands");
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(FK_NO_DOT4)
+        if constexpr (INL) return dot4_body_asm(a0, b0, a1, b1, a2, b2, a3, b3);
+#endif
+        Fp x, y, u, v; mul2(a0, b0, a1, b1, x, y); mul2(a2, b2, a3, b3, u, v);
+        return add(add(x, y), add(u, v));
+    }
+
     // a b - c d.  Device, inlined flavour: ONE Montgomery reduction for the sum a b + (q - c) d (mulsum_body_asm), i.e. a
     // reduction, a subtraction and their carry handling less than two products and a difference.
     static FK_HD Fp mulsub(const Fp &a, const Fp &b, const Fp &c, const Fp &d) {

@@ -127,6 +127,13 @@ __global__ __launch_bounds__(256) void spmv_binned_kernel(SpmvArgs a, BinArgs b,
     auto var = [&](uint32_t cv) -> uint32_t { if (TILED && cv) cv += cv < td.base_input ? in_off : aux_off; return cv; };
     Fr acc = Fr::zero();
     if (lg) {
+        // four terms per step with ONE Montgomery reduction (Fp::dot4: 328 multiply-accumulates instead of 544) ...
+        for (; k + 3 * (uint64_t)G < e; k += 4 * G) {
+            const uint32_t c0 = var(col[k]), c1 = var(col[k + G]), c2 = var(col[k + 2 * G]), c3 = var(col[k + 3 * G]);
+            const uint32_t i0 = cidx[k], i1 = cidx[k + G], i2 = cidx[k + 2 * G], i3 = cidx[k + 3 * G];
+            acc = Fr::add(acc, Fr::dot4(z[c0], table[i0], z[c1], table[i1], z[c2], table[i2], z[c3], table[i3]));
+        }
+        // ... then two
         Fr acc1 = Fr::zero();
         for (; k + G < e; k += 2 * G) {        // table[0] is ONE: multiplying by it returns the (reduced) value itself
             const uint32_t c0 = var(col[k]), c1 = var(col[k + G]), i0 = cidx[k], i1 = cidx[k + G];

@@ -215,6 +215,32 @@ def gen_mulsum(o):
     o.append('    }')
 
 
+def gen_dot4(o):
+    """a0*b0 + a1*b1 + a2*b2 + a3*b3 with ONE Montgomery reduction (single chain; canonical operands: the sum of four products
+    is below 4 p^2, its reduction below 1.76 p, one conditional subtraction makes it canonical)."""
+    o.append('// a0*b0 + a1*b1 + a2*b2 + a3*b3 with one Montgomery reduction (rows of the constraint-system evaluation); canonical operands only')
+    o.append('    static __device__ __forceinline__ Fp dot4_body_asm(const Fp &a0, const Fp &b0, const Fp &a1, const Fp &b1, const Fp &a2, const Fp &b2, const Fp &a3, const Fp &b3) {')
+    o.append('        uint64_t lo = 0; uint32_t hi; uint64_t c0, c1, c2;')
+    o.append('        uint32_t m0, m1, m2, m3, m4, m5, m6, m7;')
+    o.append('        Fp r;')
+    for k, ab, mp in columns():
+        o.append('        // column %d' % k)
+        if mp:
+            o.append(stmt1([('m%d' % i, 'P::p(%d)' % j) for i, j in mp], 'vs', first=True))
+        if ab:
+            for t in range(4):
+                o.append(stmt1([('a%d.v[%d]' % (t, i), 'b%d.v[%d]' % (t, j)) for i, j in ab], 'vv', first=(not mp and t == 0)))
+        if k < 8:
+            o.append('        m%d = (uint32_t)lo * P::INV;' % k)
+            o.append(stmt1([('m%d' % k, 'P::p(0)')], 'vs'))
+        else:
+            o.append('        r.v[%d] = (uint32_t)lo;' % (k - 8))
+        if mp or ab:
+            o.append('        lo = (lo >> 32) | ((uint64_t)hi << 32);')
+    o.append('        return red1q(r);')
+    o.append('    }')
+
+
 def gen_fq2mul(o):
     """Fq2 product by the schoolbook rule with ONE Montgomery reduction per component: r0 = a0*b0 + a1*nb1 (nb1 = -b1),
     r1 = a0*b1 + a1*b0 -- two column accumulators interleaved like mul2, each column holding the products of both terms.
@@ -275,6 +301,7 @@ def main():
     gen_mul2(o)
     gen_sqr2(o)
     gen_mulsum(o)
+    gen_dot4(o)
     gen_fq2mul(o)
     text = '\n'.join(o) + '\n'
     n, bad = check(text)
