@@ -115,9 +115,13 @@ struct fk_ctx {
     hipStream_t copy_st = nullptr;
     struct WitSlot {
         fk::DevBuf buf; hipEvent_t ready = nullptr; bool pending = false;        // pending: a submitted proof waits in this slot
+        // deferred: the upload has not been queued yet -- the proof that runs first queues it behind its memory-bound front
+        // (upload_deferred), so that the copy runs underneath transforms and accumulations instead of beside sorts
+        bool deferred = false; const void *host_z = nullptr; size_t host_bytes = 0;
         const fk_key *key = nullptr; const struct fk_r1cs_dev *r1cs = nullptr; uint64_t r[4], s[4];
     } wslot[2];
     int wslot_next = 0;
+    hipEvent_t ev_upload_gate = nullptr;
     // NTT / prover scratch
     fk::DevBuf ntt_s1, ntt_s2, ntt_io, hbuf, sc_a, sc_b, scan_tmp, stage_a, stage_b, stage_c, stage_z, stage_d;
     // stats
@@ -241,6 +245,7 @@ void key_pre_free(fk_key *key);
 int msm_g2_end(fk_ctx *ctx, int tail, G2Xyzz *out);
 void msm_abandon(fk_ctx *ctx);
 int msm_run_deferred(fk_ctx *ctx, hipEvent_t after);
+int upload_deferred(fk_ctx *ctx, bool gate_on_main);      // queues the witness uploads fk_prove_r1cs_submit left for later
 // sorts-first schedule, resident constraint system: begins the witness multiplications (waiting for ctx->ev_z) and makes the main
 // stream wait for their sorts -- called BEFORE the evaluation of a, b, c is queued.  Returns 1 if it did, 0 if the schedule is off.
 int prove_witness_early(fk_ctx *ctx, const fk_key *key, const void *d_z, const void *d_a_aux, const void *d_b_in, const void *d_b_aux);      // see fk_ctx::defer_back

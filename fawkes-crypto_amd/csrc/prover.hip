@@ -184,6 +184,29 @@ int fk_witness_ptr(fk_ctx *ctx, int slot, void **dptr) {
     return FK_OK;
 }
 
+}  // extern "C"
+namespace fk {
+// The uploads fk_prove_r1cs_submit deferred: queued on the copy stream, behind the current position of the main stream if
+// gate_on_main (the prover calls this when its memory-bound front -- sorts, evaluation of a, b, c -- is queued and the
+// VALU-bound part begins).
+int upload_deferred(fk_ctx *ctx, bool gate_on_main) {
+    for (int s = 0; s < 2; s++) {
+        fk_ctx::WitSlot &w = ctx->wslot[s];
+        if (!w.deferred) continue;
+        w.deferred = false;
+        if (gate_on_main) {
+            if (!ctx->copy_st) FK_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_st, hipStreamNonBlocking));
+            if (!ctx->ev_upload_gate) FK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_upload_gate, hipEventDisableTiming));
+            FK_HIP(ctx, hipEventRecord(ctx->ev_upload_gate, ctx->stream));
+            FK_HIP(ctx, hipStreamWaitEvent(ctx->copy_st, ctx->ev_upload_gate, 0));
+        }
+        FK_TRY(fk_witness_upload_async(ctx, s, w.host_z, w.host_bytes));
+    }
+    return FK_OK;
+}
+}  // namespace fk
+extern "C" {
+
 // ------------------------------------------------------------------------------------------ key
 static int key_alloc_slices(fk_ctx *ctx, fk_key *k, double zlo, double zhi) {
     FK_TRY(key_plan_slices(ctx, k, zlo, zhi));
@@ -316,7 +339,7 @@ int fk_key_synthetic(fk_ctx *ctx, uint64_t m, uint32_t num_input, uint32_t num_a
 static bool sorts_first(const fk_key *key) {
     static int t = -2;
     if (t == -2) { const char *e = getenv("FK_PROVE_SORTS_FIRST"); t = e ? atoi(e) : -1; }
-    return t >= 0 ? t != 0 : key->m >= (1ull << 25);
+    return t >= 0 ? t != 0 : key->h_hi - key->h_lo >= (1ull << 25) - 1;       // by this context's share of H: a rank of a multi-GPU job holds 1/N
 }
 
 static int witness_begin(fk_ctx *ctx, const fk_key *key, const Fr *d_z, const uint8_t *d_a_aux, const uint8_t *d_b_in,
@@ -333,7 +356,7 @@ static int witness_begin(fk_ctx *ctx, const fk_key *key, const Fr *d_z, const ui
     // a host round trip (msm.hip) the picture at the top end changed: at 2^25 two lanes are 1 % ahead of three (195.1 vs
     // 197.5 ms, one lane 207.2), below that three still win by 1.5-5 % (profiles/r02_async_msm_ab_probe.log).
     // In the sorts-first schedule (prove_msms_dev) every multiplication has a lane of its own.
-    ctx->lanes_in_use = sorts_first(key) ? MSM_LANES : (key->m >= (1ull << 25) ? 2 : 3);
+    ctx->lanes_in_use = sorts_first(key) ? MSM_LANES : 3;
     FK_HIP(ctx, hipSetDevice(ctx->device));
     if (!ctx->aux) {
         FK_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
@@ -448,7 +471,7 @@ static int prove_msms_dev(fk_ctx *ctx, const fk_key *key, Fr *d_a, Fr *d_b, Fr *
     Fr *d_h = ctx->hbuf.as<Fr>();
     uint64_t m = 0;
     ctx->lane_next = 0;     // same lane for the same multiplication in every proof: lane buffers keep their sizes
-    ctx->lanes_in_use = sorts_first(key) ? MSM_LANES : (key->m >= (1ull << 25) ? 2 : 3);      // measured, see witness_begin
+    ctx->lanes_in_use = sorts_first(key) ? MSM_LANES : 3;      // measured, see witness_begin
     // The witness multiplications depend on z only: they are begun right behind the QUEUED quotient, so that their sorts (and what
     // fits of their accumulations) fill the transforms' gaps: 214.5 -> 206.9 ms per proof on the 1024-transaction system
     // (profiles/r02_cusplit_witness_first_probe.log), and at every smaller size measured -- synthetic 2^20 13.4 -> 11.1 ms,
@@ -485,6 +508,7 @@ static int prove_msms_dev(fk_ctx *ctx, const fk_key *key, Fr *d_a, Fr *d_b, Fr *
         for (MsmLane &ln : ctx->lanes)
             if (ln.ev_sorted_valid) { FK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ln.ev_sorted, 0)); ln.ev_sorted_valid = false; }
     }
+    { const int rcu = upload_deferred(ctx, true); if (rcu != FK_OK) { if (gate || early) msm_abandon(ctx); return rcu; } }      // the next proof's witness: underneath what follows
     const int rcq = quotient_dev(ctx, d_a, d_b, d_c, n, d_h, &m);          // queued on the main stream, not waited for
     if (rcq != FK_OK) { if (gate) msm_abandon(ctx); return rcq; }
     const double t1 = now_ms();

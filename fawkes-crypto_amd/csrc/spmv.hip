@@ -462,8 +462,17 @@ int fk_prove_r1cs_submit(fk_ctx *ctx, const fk_key *key, const fk_r1cs_dev *r, c
     if (!key || !r || !z || !rr || !ss || !ticket) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "prove: null argument");
     const int slot = ctx->wslot_next;
     if (ctx->wslot[slot].pending) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "prove: two proofs are already submitted (call fk_prove_r1cs_wait first)");
-    FK_TRY(fk_witness_upload_async(ctx, slot, z, ((size_t)r->num_input + r->num_aux) * sizeof(Fr)));
     fk_ctx::WitSlot &w = ctx->wslot[slot];
+    const size_t zb = ((size_t)r->num_input + r->num_aux) * sizeof(Fr);
+    // With another proof submitted ahead of this one, the upload is left to THAT proof's run: it queues the copy behind its
+    // memory-bound front (sorts, evaluation of a, b, c), so that the transfer runs underneath transforms and accumulations.
+    // Started here it ran beside the sorts: +14 ms per proof on the synthetic 2^25 shape (1 GiB witness), +0.8 ms on the
+    // 1024-transaction system (profiles/r02_sorts_first_probe.log).  FK_UPLOAD_DEFER=0: start it here.  The host buffer must
+    // stay valid until fk_prove_r1cs_wait(ticket) returns either way.
+    static int t_defer = -1;
+    if (t_defer < 0) { const char *e = getenv("FK_UPLOAD_DEFER"); t_defer = e ? atoi(e) : 1; }
+    if (t_defer && ctx->wslot[slot ^ 1].pending && zb <= w.buf.cap && w.ready) { w.deferred = true; w.host_z = z; w.host_bytes = zb; }
+    else { w.deferred = false; FK_TRY(fk_witness_upload_async(ctx, slot, z, zb)); }
     w.pending = true; w.key = key; w.r1cs = r;
     memcpy(w.r, rr, 32); memcpy(w.s, ss, 32);
     ctx->wslot_next = slot ^ 1;
@@ -475,6 +484,7 @@ int fk_prove_r1cs_wait(fk_ctx *ctx, int ticket, uint8_t out_proof[FK_PROOF_BYTES
     if (ticket < 0 || ticket > 1 || !ctx->wslot[ticket].pending) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "prove: no submitted proof with ticket %d", ticket);
     fk_ctx::WitSlot &w = ctx->wslot[ticket];
     w.pending = false;
+    if (w.deferred) { w.deferred = false; FK_TRY(fk_witness_upload_async(ctx, ticket, w.host_z, w.host_bytes)); }      // nobody ran in between
     void *d_z = nullptr;
     FK_TRY(fk_witness_ptr(ctx, ticket, &d_z));
     return fk_prove_r1cs_dev(ctx, w.key, w.r1cs, d_z, w.r, w.s, out_proof, tm);
