@@ -295,7 +295,9 @@ int fk_prove_r1cs_dev(fk_ctx *ctx, const fk_key *key, const fk_r1cs_dev *r1cs, c
  * (prover.rs:69-76: the circuit closure fills WitnessCS, then prover.rs:80 consumes it), so a proving loop hands over
  * (num_input + num_aux) * 32 bytes per proof -- 1 GiB at 2^25 variables.  _submit starts the host-to-device copy into one
  * of two witness slots on a copy stream and returns at once; _wait computes the proof of that ticket.  With
- * submit(k+1) issued before wait(k) the upload of the next witness runs underneath the current proof.  At most two
+ * submit(k+1) issued before wait(k) the upload of the next witness runs underneath the current proof (with a ticket already
+ * outstanding the copy is queued by THAT proof's run, behind its memory-bound front, so that it overlaps with transforms and
+ * accumulations rather than with sorts).  At most two
  * tickets are outstanding; z must stay valid until the matching _wait returns and should be pinned memory
  * (fk_host_alloc) -- pageable memory works but is staged by the runtime and does not overlap. */
 int fk_prove_r1cs_submit(fk_ctx *ctx, const fk_key *key, const fk_r1cs_dev *r1cs, const uint64_t *z,
