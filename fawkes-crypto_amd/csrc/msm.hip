@@ -47,10 +47,15 @@ struct MsmPlan {
     uint32_t LB, nhi, nlo;   // low bits of the bucket index, number of high / low bins
 };
 #ifndef FK_S2_TILE
-#define FK_S2_TILE 16384
+#define FK_S2_TILE 8192
 #endif
-static constexpr uint32_t S2_TILE = FK_S2_TILE;     // entries per staged sort tile (8192: two second-pass workgroups per compute unit -- measured)
+// entries per tile of the SECOND sort pass.  8192: two to three workgroups of its scatter kernel per compute unit (56 KB of LDS
+// each) overlap each other's load and barrier waits -- the kernel's waves are parked 70 % of the time; 175.9 -> 174.6 ms per
+// proof against 16384, 4096 is slower again (profiles/r02_sorts_first_probe.log).  The first pass keeps 16384 (S1_TILE).
+static constexpr uint32_t S2_TILE = FK_S2_TILE;
 static constexpr uint32_t S2_EPT = S2_TILE / 1024;      // entries per lane (1024-lane workgroups)
+static constexpr uint32_t S1_TILE = 16384;               // sub-tile of the FIRST pass (internal to its scatter kernels)
+static constexpr uint32_t S1_EPT = S1_TILE / 1024;
 
 // Windows are sized from n.  Sizing them from the number of non-trivial scalars (0 and 1 never reach the ordinary
 // buckets) was measured slower on the witness MSMs: fewer windows win even at bucket loads of ~6 once lanes are
@@ -284,9 +289,9 @@ __global__ __launch_bounds__(1024) void s2_scatter1_kernel(const uint32_t *digit
     __shared__ uint32_t lcnt[S2_MAX_HI];        // entries of the sub-tile in the bin
     __shared__ uint32_t lexc[S2_MAX_HI];        // exclusive offsets inside the sub-tile
     __shared__ uint32_t part[16];
-    __shared__ uint32_t stage_idx[S2_TILE];
-    __shared__ uint16_t stage_lo[S2_TILE];
-    __shared__ uint16_t stage_bin[S2_TILE];
+    __shared__ uint32_t stage_idx[S1_TILE];
+    __shared__ uint16_t stage_lo[S1_TILE];
+    __shared__ uint16_t stage_bin[S1_TILE];
     const uint32_t ch = blockIdx.x, w = blockIdx.y, tid = threadIdx.x;
     const uint32_t *cnt = cnt1 + ((size_t)w * nchunks + ch) * nhi;
     for (uint32_t b = tid; b < S2_MAX_HI; b += 1024) cursor[b] = b < nhi ? seg_start[(size_t)w * nhi + b] + cnt[b] : 0;
@@ -295,13 +300,13 @@ __global__ __launch_bounds__(1024) void s2_scatter1_kernel(const uint32_t *digit
     const uint32_t lomask = (1u << LB) - 1;
     uint32_t *oidx = tmp_idx + (size_t)w * n;
     uint16_t *olo = tmp_lo + (size_t)w * n;
-    for (size_t sub = c_lo; sub < c_hi; sub += S2_TILE) {
-        const uint32_t cntt = (uint32_t)(c_hi - sub < S2_TILE ? c_hi - sub : S2_TILE);
+    for (size_t sub = c_lo; sub < c_hi; sub += S1_TILE) {
+        const uint32_t cntt = (uint32_t)(c_hi - sub < S1_TILE ? c_hi - sub : S1_TILE);
         lcnt[tid] = 0; lcnt[tid + 1024] = 0;
         __syncthreads();
-        uint32_t e_idx[S2_EPT], e_bin[S2_EPT], e_lo[S2_EPT], e_rank[S2_EPT];
+        uint32_t e_idx[S1_EPT], e_bin[S1_EPT], e_lo[S1_EPT], e_rank[S1_EPT];
 #pragma unroll
-        for (uint32_t j = 0; j < S2_EPT; j++) {
+        for (uint32_t j = 0; j < S1_EPT; j++) {
             const uint32_t k = tid + j * 1024;
             e_bin[j] = 0xffffffffu;
             if (k < cntt) {
@@ -321,7 +326,7 @@ __global__ __launch_bounds__(1024) void s2_scatter1_kernel(const uint32_t *digit
         lexc[2 * tid] = ex; lexc[2 * tid + 1] = ex + c0;
         __syncthreads();
 #pragma unroll
-        for (uint32_t j = 0; j < S2_EPT; j++) {
+        for (uint32_t j = 0; j < S1_EPT; j++) {
             if (e_bin[j] != 0xffffffffu) { const uint32_t q = lexc[e_bin[j]] + e_rank[j]; stage_idx[q] = e_idx[j]; stage_lo[q] = (uint16_t)e_lo[j]; stage_bin[q] = (uint16_t)e_bin[j]; }
         }
         __syncthreads();
@@ -503,13 +508,19 @@ static __device__ __forceinline__ void s2_scatter1n_body(const uint32_t *digits,
                                                            uint32_t nhi, const uint32_t *cnt1, const uint32_t *seg_start, uint32_t *tmp_idx,
                                                            uint16_t *tmp_lo) {
     constexpr uint32_t BPL = S2_MAX_HI / NT;        // bins per lane
+    constexpr uint32_t EPT = S1_TILE / NT;          // entries per lane and sub-tile
+#ifdef FK_S1_NO_PREFETCH
+    constexpr bool PREFETCH = false;
+#else
+    constexpr bool PREFETCH = EPT <= 16;            // the sub-tile's digits live in registers and the NEXT sub-tile's are loaded while this one is written out
+#endif
     __shared__ uint32_t cursor[S2_MAX_HI];
     __shared__ uint32_t lcnt[S2_MAX_HI];
     __shared__ uint32_t lexc[S2_MAX_HI];        // exclusive offsets inside the sub-tile; advanced to the bins' ends by the placing phase
     __shared__ uint32_t part[16];
-    __shared__ uint32_t stage_idx[S2_TILE];
-    __shared__ uint16_t stage_lo[S2_TILE];
-    __shared__ uint16_t stage_bin[S2_TILE];
+    __shared__ uint32_t stage_idx[S1_TILE];
+    __shared__ uint16_t stage_lo[S1_TILE];
+    __shared__ uint16_t stage_bin[S1_TILE];
     const uint32_t ch = blockIdx.x, w = blockIdx.y, tid = threadIdx.x;
     const uint32_t *cnt = cnt1 + ((size_t)w * nchunks + ch) * nhi;
     for (uint32_t b = tid; b < S2_MAX_HI; b += NT) cursor[b] = b < nhi ? seg_start[(size_t)w * nhi + b] + cnt[b] : 0;
@@ -518,15 +529,26 @@ static __device__ __forceinline__ void s2_scatter1n_body(const uint32_t *digits,
     const uint32_t lomask = (1u << LB) - 1;
     uint32_t *oidx = tmp_idx + (size_t)w * n;
     uint16_t *olo = tmp_lo + (size_t)w * n;
-    for (size_t sub = c_lo; sub < c_hi; sub += S2_TILE) {
-        const uint32_t cntt = (uint32_t)(c_hi - sub < S2_TILE ? c_hi - sub : S2_TILE);
+    uint32_t d[PREFETCH ? EPT : 1], dn[PREFETCH ? EPT : 1];
+    if (PREFETCH && c_lo < c_hi) {
+        const uint32_t cnt0 = (uint32_t)(c_hi - c_lo < S1_TILE ? c_hi - c_lo : S1_TILE);
+#pragma unroll
+        for (uint32_t j = 0; j < EPT; j++) { const uint32_t k = tid + j * NT; d[j] = k < cnt0 ? dg[c_lo + k] : 0; }
+    }
+    for (size_t sub = c_lo; sub < c_hi; sub += S1_TILE) {
+        const uint32_t cntt = (uint32_t)(c_hi - sub < S1_TILE ? c_hi - sub : S1_TILE);
         const uint32_t *src = dg + sub;
         for (uint32_t b = tid; b < S2_MAX_HI; b += NT) lcnt[b] = 0;
         __syncthreads();
+        if (PREFETCH) {
+#pragma unroll
+            for (uint32_t j = 0; j < EPT; j++) { const uint32_t bkt = d[j] & 0x7fffffffu; if (bkt) atomicAdd(&lcnt[(bkt - 1) >> LB], 1u); }     // (a digit past the end was loaded as 0)
+        } else {
 #pragma unroll 8
-        for (uint32_t k = tid; k < cntt; k += NT) {
-            const uint32_t bkt = src[k] & 0x7fffffffu;
-            if (bkt) atomicAdd(&lcnt[(bkt - 1) >> LB], 1u);
+            for (uint32_t k = tid; k < cntt; k += NT) {
+                const uint32_t bkt = src[k] & 0x7fffffffu;
+                if (bkt) atomicAdd(&lcnt[(bkt - 1) >> LB], 1u);
+            }
         }
         __syncthreads();
         uint32_t c[BPL], mine = 0;
@@ -537,12 +559,28 @@ static __device__ __forceinline__ void s2_scatter1n_body(const uint32_t *digits,
 #pragma unroll
         for (uint32_t i = 0; i < BPL; i++) { lexc[tid * BPL + i] = ex; ex += c[i]; }
         __syncthreads();
+        if (PREFETCH) {
+#pragma unroll
+            for (uint32_t j = 0; j < EPT; j++) {
+                const uint32_t bkt = d[j] & 0x7fffffffu;
+                if (bkt) {
+                    const uint32_t bin = (bkt - 1) >> LB, q = atomicAdd(&lexc[bin], 1u);
+                    stage_idx[q] = (uint32_t)(sub + tid + j * NT) | (d[j] & 0x80000000u); stage_lo[q] = (uint16_t)((bkt - 1) & lomask); stage_bin[q] = (uint16_t)bin;
+                }
+            }
+            // the next sub-tile's digits: in flight while this one is written out
+            const size_t nxt = sub + S1_TILE;
+            const uint32_t cntn = nxt < c_hi ? (uint32_t)(c_hi - nxt < S1_TILE ? c_hi - nxt : S1_TILE) : 0;
+#pragma unroll
+            for (uint32_t j = 0; j < EPT; j++) { const uint32_t k = tid + j * NT; dn[j] = k < cntn ? dg[nxt + k] : 0; }
+        } else {
 #pragma unroll 8
-        for (uint32_t k = tid; k < cntt; k += NT) {
-            const uint32_t d = src[k], bkt = d & 0x7fffffffu;
-            if (bkt) {
-                const uint32_t bin = (bkt - 1) >> LB, q = atomicAdd(&lexc[bin], 1u);
-                stage_idx[q] = (uint32_t)(sub + k) | (d & 0x80000000u); stage_lo[q] = (uint16_t)((bkt - 1) & lomask); stage_bin[q] = (uint16_t)bin;
+            for (uint32_t k = tid; k < cntt; k += NT) {
+                const uint32_t dd = src[k], bkt = dd & 0x7fffffffu;
+                if (bkt) {
+                    const uint32_t bin = (bkt - 1) >> LB, q = atomicAdd(&lexc[bin], 1u);
+                    stage_idx[q] = (uint32_t)(sub + k) | (dd & 0x80000000u); stage_lo[q] = (uint16_t)((bkt - 1) & lomask); stage_bin[q] = (uint16_t)bin;
+                }
             }
         }
         __syncthreads();
@@ -555,6 +593,10 @@ static __device__ __forceinline__ void s2_scatter1n_body(const uint32_t *digits,
         }
         __syncthreads();
         for (uint32_t b = tid; b < S2_MAX_HI; b += NT) cursor[b] += lcnt[b];
+        if (PREFETCH) {
+#pragma unroll
+            for (uint32_t j = 0; j < EPT; j++) d[j] = dn[j];
+        }
         __syncthreads();
     }
 }
