@@ -54,8 +54,19 @@ struct MsmPlan {
 // proof against 16384, 4096 is slower again (profiles/r02_sorts_first_probe.log).  The first pass keeps 16384 (S1_TILE).
 static constexpr uint32_t S2_TILE = FK_S2_TILE;
 static constexpr uint32_t S2_EPT = S2_TILE / 1024;      // entries per lane (1024-lane workgroups)
-static constexpr uint32_t S1_TILE = 16384;               // sub-tile of the FIRST pass (internal to its scatter kernels)
-static constexpr uint32_t S1_EPT = S1_TILE / 1024;
+// Sub-tile of the FIRST pass (internal to its scatter kernel) and the number of high bins its LDS tables hold.  8192 entries and
+// 1024 bins (the second pass then takes 11 low bits of a 21-bit bucket index): 76 KB of LDS, TWO workgroups per compute unit --
+// the kernel's waves are parked 79 % of the time (loads, barriers), a second workgroup fills that: 173.9 -> 171.3 ms per proof
+// against 16384 entries / 2048 bins (one workgroup per compute unit); 4096 entries (three per unit) 172.5
+// (profiles/r02_sorts_first_probe.log).
+#ifndef FK_S1_TILE
+#define FK_S1_TILE 8192
+#endif
+static constexpr uint32_t S1_TILE = FK_S1_TILE;
+#ifndef FK_S2_MAX_HI
+#define FK_S2_MAX_HI 1024
+#endif
+static constexpr uint32_t S2_MAX_HI = FK_S2_MAX_HI;     // high bins of the first pass (make_plan gives the second pass the remaining low bits)
 
 // Windows are sized from n.  Sizing them from the number of non-trivial scalars (0 and 1 never reach the ordinary
 // buckets) was measured slower on the witness MSMs: fewer windows win even at bucket loads of ~6 once lanes are
@@ -114,6 +125,7 @@ static MsmPlan make_plan(size_t n, unsigned forced_c, bool merged = false) {
     static int t_lb = -1;
     if (t_lb < 0) { const char *e = getenv("FK_MSM_LB"); t_lb = e ? atoi(e) : 10; if (t_lb < 10 || t_lb > 12) t_lb = 10; }
     p.LB = (c - 1) < (uint32_t)t_lb ? (c - 1) : (uint32_t)t_lb;
+    while ((p.B >> p.LB) > S2_MAX_HI) p.LB++;          // the first pass's LDS tables hold S2_MAX_HI bins
     p.nlo = 1u << p.LB;
     p.nhi = p.B >> p.LB;
     return p;
@@ -278,70 +290,9 @@ __global__ __launch_bounds__(1024) void s2_tile_prefix_kernel(const uint32_t *se
     if (t == 1023) tile_start[nseg] = part[1023];
 }
 
-// First-pass scatter, LDS-staged like the second one: the chunk is walked in sub-tiles of S2_TILE entries; each sub-tile
-// is ranked per high bin, laid out in bin order in LDS and written as contiguous runs (idx: 4 B, low bits: 2 B per
-// entry) behind the workgroup's per-bin cursors.
-static constexpr uint32_t S2_MAX_HI = 2048;             // c <= 22  ->  at most 2^11 high bins
-__global__ __launch_bounds__(1024) void s2_scatter1_kernel(const uint32_t *digits, size_t n, size_t chunk, uint32_t nchunks, uint32_t LB,
-                                                            uint32_t nhi, const uint32_t *cnt1, const uint32_t *seg_start, uint32_t *tmp_idx,
-                                                            uint16_t *tmp_lo) {
-    __shared__ uint32_t cursor[S2_MAX_HI];      // next free slot of the bin (window-relative)
-    __shared__ uint32_t lcnt[S2_MAX_HI];        // entries of the sub-tile in the bin
-    __shared__ uint32_t lexc[S2_MAX_HI];        // exclusive offsets inside the sub-tile
-    __shared__ uint32_t part[16];
-    __shared__ uint32_t stage_idx[S1_TILE];
-    __shared__ uint16_t stage_lo[S1_TILE];
-    __shared__ uint16_t stage_bin[S1_TILE];
-    const uint32_t ch = blockIdx.x, w = blockIdx.y, tid = threadIdx.x;
-    const uint32_t *cnt = cnt1 + ((size_t)w * nchunks + ch) * nhi;
-    for (uint32_t b = tid; b < S2_MAX_HI; b += 1024) cursor[b] = b < nhi ? seg_start[(size_t)w * nhi + b] + cnt[b] : 0;
-    const size_t c_lo = (size_t)ch * chunk, c_hi = c_lo + chunk < n ? c_lo + chunk : n;
-    const uint32_t *dg = digits + (size_t)w * n;
-    const uint32_t lomask = (1u << LB) - 1;
-    uint32_t *oidx = tmp_idx + (size_t)w * n;
-    uint16_t *olo = tmp_lo + (size_t)w * n;
-    for (size_t sub = c_lo; sub < c_hi; sub += S1_TILE) {
-        const uint32_t cntt = (uint32_t)(c_hi - sub < S1_TILE ? c_hi - sub : S1_TILE);
-        lcnt[tid] = 0; lcnt[tid + 1024] = 0;
-        __syncthreads();
-        uint32_t e_idx[S1_EPT], e_bin[S1_EPT], e_lo[S1_EPT], e_rank[S1_EPT];
-#pragma unroll
-        for (uint32_t j = 0; j < S1_EPT; j++) {
-            const uint32_t k = tid + j * 1024;
-            e_bin[j] = 0xffffffffu;
-            if (k < cntt) {
-                const uint32_t d = dg[sub + k], bkt = d & 0x7fffffffu;
-                if (bkt) {
-                    e_idx[j] = (uint32_t)(sub + k) | (d & 0x80000000u);
-                    e_bin[j] = (bkt - 1) >> LB; e_lo[j] = (bkt - 1) & lomask;
-                    e_rank[j] = atomicAdd(&lcnt[e_bin[j]], 1u);
-                }
-            }
-        }
-        __syncthreads();
-        // exclusive scan over the (<= 2048) bins: two bins per lane
-        const uint32_t c0 = lcnt[2 * tid], c1 = lcnt[2 * tid + 1];
-        uint32_t total;
-        const uint32_t ex = block_excl_scan_1024(c0 + c1, part, &total);
-        lexc[2 * tid] = ex; lexc[2 * tid + 1] = ex + c0;
-        __syncthreads();
-#pragma unroll
-        for (uint32_t j = 0; j < S1_EPT; j++) {
-            if (e_bin[j] != 0xffffffffu) { const uint32_t q = lexc[e_bin[j]] + e_rank[j]; stage_idx[q] = e_idx[j]; stage_lo[q] = (uint16_t)e_lo[j]; stage_bin[q] = (uint16_t)e_bin[j]; }
-        }
-        __syncthreads();
-        for (uint32_t q = tid; q < total; q += 1024) {
-            const uint32_t bn = stage_bin[q];            // (a binary search over lexc cost 11 LDS reads per entry here)
-            const uint32_t dst = cursor[bn] + (q - lexc[bn]);
-            oidx[dst] = stage_idx[q];
-            olo[dst] = stage_lo[q];
-        }
-        __syncthreads();
-        cursor[tid] += lcnt[tid]; cursor[tid + 1024] += lcnt[tid + 1024];
-        __syncthreads();
-    }
-}
-
+// First-pass scatter, LDS-staged like the second one: the chunk is walked in sub-tiles of S1_TILE entries; each sub-tile is
+// counted per high bin, laid out in bin order in LDS and written as contiguous runs (idx: 4 B, low bits: 2 B per entry) behind
+// the workgroup's per-bin cursors -- s2_scatter1n_body below (round 1's register-ranked form needed 128 registers and spilled).
 // which segment does tile `t` belong to (tile_start is non-decreasing; empty segments own no tile)
 static __device__ __forceinline__ uint32_t s2_find_segment(const uint32_t *tile_start, uint32_t nseg, uint32_t t) {
     uint32_t lo = 0, hi = nseg;          // invariant: tile_start[lo] <= t < tile_start[hi]
@@ -1223,8 +1174,8 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
         hipLaunchKernelGGL(s2_hist1_kernel, dim3(p.nchunks, p.W), dim3(SORT_THREADS), p.nhi * 4, ss, digits, n, p.chunk, p.nchunks, p.LB, p.nhi, cnt1);
         hipLaunchKernelGGL(s2_prefix1_kernel, dim3(p.W), dim3(1024), p.nhi * 4, ss, cnt1, p.nchunks, p.nhi, seg_size, seg_start, seg_tiles);
         hipLaunchKernelGGL(s2_tile_prefix_kernel, dim3(1), dim3(1024), 0, ss, seg_tiles, nseg, tile_start);
-        // lanes per scatter workgroup, per pass: 0 = the wide register-ranked forms (1024 lanes), 256 / 512 / 1024 = the
-        // two-atomic forms (FK_MSM_SORT_NT1, FK_MSM_SORT_NT2)
+        // lanes per scatter workgroup, per pass (FK_MSM_SORT_NT1: 256 / 512 / 1024, all two-atomic forms; FK_MSM_SORT_NT2: 0 = the
+        // register-ranked 1024-lane form, 256 / 512 / 1024 = two-atomic forms)
         static int t_nt1 = -1, t_nt2 = -1;
         if (t_nt1 < 0) {
             const char *e = getenv("FK_MSM_SORT_NT1"); t_nt1 = e ? atoi(e) : 1024;
@@ -1237,11 +1188,8 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
             hipLaunchKernelGGL(s2_scatter1_n256_kernel, dim3(p.nchunks, p.W), dim3(256), 0, ss, digits, n, p.chunk, p.nchunks, p.LB, p.nhi, cnt1, seg_start, tmp_idx, tmp_lo);
         else if (nt1 == 512)
             hipLaunchKernelGGL(s2_scatter1_n512_kernel, dim3(p.nchunks, p.W), dim3(512), 0, ss, digits, n, p.chunk, p.nchunks, p.LB, p.nhi, cnt1, seg_start, tmp_idx, tmp_lo);
-        else if (nt1 == 1024)
-            hipLaunchKernelGGL(s2_scatter1_n1024_kernel, dim3(p.nchunks, p.W), dim3(1024), 0, ss, digits, n, p.chunk, p.nchunks, p.LB, p.nhi, cnt1, seg_start, tmp_idx, tmp_lo);
         else
-            hipLaunchKernelGGL(s2_scatter1_kernel, dim3(p.nchunks, p.W), dim3(1024), 0, ss, digits, n, p.chunk, p.nchunks, p.LB, p.nhi, cnt1,
-                               seg_start, tmp_idx, tmp_lo);
+            hipLaunchKernelGGL(s2_scatter1_n1024_kernel, dim3(p.nchunks, p.W), dim3(1024), 0, ss, digits, n, p.chunk, p.nchunks, p.LB, p.nhi, cnt1, seg_start, tmp_idx, tmp_lo);
         FK_HIP(ctx, hipGetLastError());
         FK_DBG_ST(ctx, ss, "msm_sort_pass1");
         // The second pass is launched over the host's BOUND on the tile count (every segment's last tile may be partial:
