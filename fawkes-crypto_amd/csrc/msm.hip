@@ -316,8 +316,11 @@ __global__ __launch_bounds__(256) void s2_hist2_kernel(const uint16_t *tmp_lo, s
 }
 
 // one WAVE per high-bin segment (a 1024-lane workgroup per segment spent its time being launched: 24 576 of them per
-// multiplication at 2^25, 1.9 ms): lane l owns the low bins l, l + 64, ...; per 64-bin chunk a prefix over the segment's tiles,
-// then a wave scan for the bucket starts.  Also bucket totals and the size histogram above the planned cap (msm_cap_kernel).
+// multiplication at 2^25, 1.9 ms): lane l owns the low bins l, l + 64, ... (up to 64 of them, in registers); per tile all of a
+// lane's counters are loaded at once (independent loads) and replaced by the running prefix over the segment's tiles; then a
+// wave scan per 64-bin chunk gives the bucket starts.  Also bucket totals and the size histogram above the planned cap
+// (msm_cap_kernel).
+static constexpr uint32_t P2_MAX = 32;      // low bins per lane and wave: nlo <= 2048 per wave pass (larger nlo: two passes over the tiles)
 __global__ __launch_bounds__(256) void s2_prefix2_kernel(uint32_t *cnt2, uint32_t nseg, uint32_t nhi, uint32_t nlo, uint32_t B, const uint32_t *tile_start,
                                                           const uint32_t *seg_start, uint32_t cap0, uint32_t *totals, uint32_t *starts, MsmDyn *dyn) {
     __shared__ uint32_t sh_hist[16];
@@ -327,28 +330,38 @@ __global__ __launch_bounds__(256) void s2_prefix2_kernel(uint32_t *cnt2, uint32_
     if (sgm < nseg) {
         const uint32_t w = sgm / nhi, h = sgm % nhi, t0 = tile_start[sgm], t1 = tile_start[sgm + 1];
         uint32_t carry = seg_start[sgm];
-        for (uint32_t b0 = 0; b0 < nlo; b0 += 64) {
-            const uint32_t b = b0 + lane;
-            uint32_t run = 0;
-            if (b < nlo) {
-                for (uint32_t t = t0; t < t1; t++) {
-                    uint32_t *p = cnt2 + (size_t)t * nlo + b;
-                    const uint32_t v = *p; *p = run; run += v;
-                }
-            }
-            uint32_t incl = run;
+        for (uint32_t b0 = 0; b0 < nlo; b0 += 64 * P2_MAX) {          // P2_MAX 64-bin chunks at a time
+            const uint32_t per = (nlo - b0 + 63) / 64 < P2_MAX ? (nlo - b0 + 63) / 64 : P2_MAX;
+            uint32_t run[P2_MAX];
 #pragma unroll
-            for (int off = 1; off < 64; off <<= 1) { const uint32_t x = (uint32_t)__shfl_up((int)incl, off, 64); if (lane >= (uint32_t)off) incl += x; }
-            if (b < nlo) {
-                const size_t g = (size_t)w * B + (size_t)h * nlo + b;
-                totals[g] = run;
-                starts[g] = carry + incl - run;
-                if (run > cap0) {        // how far over the statistical cap: class k = the largest k with run > cap0 << k (msm_cap_kernel)
-                    const uint32_t k = 31u - (uint32_t)__clz((run - 1) / cap0);
-                    atomicAdd(&sh_hist[k < 15 ? k : 15], 1u);
+            for (uint32_t i = 0; i < P2_MAX; i++) run[i] = 0;
+            for (uint32_t t = t0; t < t1; t++) {
+                uint32_t *row = cnt2 + (size_t)t * nlo + b0;
+                uint32_t v[P2_MAX];
+#pragma unroll
+                for (uint32_t i = 0; i < P2_MAX; i++) { const uint32_t b = i * 64 + lane; v[i] = (i < per && b0 + b < nlo) ? row[b] : 0; }
+#pragma unroll
+                for (uint32_t i = 0; i < P2_MAX; i++) { const uint32_t b = i * 64 + lane; if (i < per && b0 + b < nlo) row[b] = run[i]; run[i] += v[i]; }
+            }
+#pragma unroll
+            for (uint32_t i = 0; i < P2_MAX; i++) {
+                if (i < per) {          // uniform over the wave
+                    const uint32_t b = b0 + i * 64 + lane;
+                    uint32_t incl = run[i];
+#pragma unroll
+                    for (int off = 1; off < 64; off <<= 1) { const uint32_t x = (uint32_t)__shfl_up((int)incl, off, 64); if (lane >= (uint32_t)off) incl += x; }
+                    if (b < nlo) {
+                        const size_t g = (size_t)w * B + (size_t)h * nlo + b;
+                        totals[g] = run[i];
+                        starts[g] = carry + incl - run[i];
+                        if (run[i] > cap0) {        // how far over the statistical cap: class k = the largest k with run > cap0 << k (msm_cap_kernel)
+                            const uint32_t k = 31u - (uint32_t)__clz((run[i] - 1) / cap0);
+                            atomicAdd(&sh_hist[k < 15 ? k : 15], 1u);
+                        }
+                    }
+                    carry += (uint32_t)__shfl((int)incl, 63, 64);
                 }
             }
-            carry += (uint32_t)__shfl((int)incl, 63, 64);
         }
     }
     __syncthreads();
