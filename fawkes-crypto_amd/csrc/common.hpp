@@ -44,6 +44,7 @@ struct MsmLane {
     bool ev_sorted_valid = false;
     bool ev_lane_done_valid = false;
     DevBuf digits, sorted, totals, starts, perm, overlist, tasktab, partials, s2_cnt1, s2_seg, s2_cnt2, s2_tmp_idx, s2_tmp_lo, buckets;
+    DevBuf redbuf;       // hierarchical bucket reduction: the levels' entries, ping-pong
     DevBuf buckets2;     // the buckets of a multiplication that reuses this lane's sort (B2 after B1): its accumulation is queued right behind B1's, before B1's tail has read `buckets`
     void *h_stage = nullptr;        // pinned host staging: counters read back, oversized-bucket list, task tables
     size_t h_cap = 0;
@@ -55,6 +56,7 @@ struct MsmLane {
 struct MsmTail {
     bool active = false;
     uint32_t cb = 0, wide = 0, W = 0, nblk = 0;     // window widths (msm.hip: MsmPlan), windows, partial sums per window
+    uint32_t hier = 0;              // hierarchical reduction: plain components P1..P_hier per window (0: nblk partial sums)
     hipEvent_t done = nullptr;
     void *h_wp = nullptr;           // pinned host copy of the window partial sums
     size_t h_cap = 0;

@@ -1031,6 +1031,58 @@ __global__ __launch_bounds__(256) void msm_bucket_reduce_kernel(const Xyzz<F> *b
     if (threadIdx.x == 0) winparts[(size_t)w * nblk + blockIdx.x] = acc;
 }
 
+// Hierarchical form: no lane walks more than 8 buckets and nothing is multiplied by its offset on the device.
+// With slot s = 8 t + j (lane t, j < 8) and t = 64 v + l (wave v, lane l) and so on,
+//     sum_s (s + 1) S_s = P1 + 8 (P2 + 64 (P3 + 64 (P4 + ...)))
+// where P1 = sum over lanes of the local sums with weights 1..8, and P(k+1) = sum over the level-k waves of sum_l l T_l, T_l
+// being the lane totals of that level: a weighted sum over the 64 lanes of a wave is the sum of the suffix sums 1..63
+// (shuffles).  Level 1 writes (p1, p2, T) per wave; every further level sums the plain components and adds one weighted
+// component, 64 entries per wave, until one entry is left; the host does the Horner step (3 + 6 + 6 ... doublings).  The serial
+// chain is 16 + 18 additions at level 1 and 6 (NP + 2) per further level instead of 128 + ~30 + 8 -- but 1.6x the additions in
+// total, which is why it is an experiment switch and not the default (see msm_begin).
+template <class F>
+static __device__ __forceinline__ Xyzz<F> wave_suffix_scan(Xyzz<F> v) {       // lane l: sum over lanes m >= l
+    const uint32_t lane = threadIdx.x & 63;
+#pragma unroll 1
+    for (int off = 1; off < 64; off <<= 1) {
+        Xyzz<F> o = shfl_down_obj(v, off);
+        if (lane + off < 64) v.add(o);
+    }
+    return v;
+}
+template <class F>
+__global__ __launch_bounds__(256) void msm_reduce_l1_kernel(const Xyzz<F> *buckets, uint32_t B, uint32_t n_out, Xyzz<F> *out) {
+    const uint32_t w = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;       // B / 8 lanes per window
+    const Xyzz<F> *bk = buckets + (size_t)w * B + (size_t)t * 8;
+    Xyzz<F> run = Xyzz<F>::inf(), acc = Xyzz<F>::inf();
+    for (uint32_t j = 8; j-- > 0;) { run.add(bk[j]); acc.add(run); }     // acc = sum (j + 1) S_j, run = sum S_j
+    wave_reduce(acc);                                                      // lane 0: p1
+    const Xyzz<F> suf = wave_suffix_scan(run);
+    Xyzz<F> wsum = lane ? suf : Xyzz<F>::inf();
+    wave_reduce(wsum);                                                     // lane 0: sum_l l T_l
+    if (lane == 0) {
+        Xyzz<F> *o = out + ((size_t)w * n_out + (t >> 6)) * 3;
+        o[0] = acc; o[1] = wsum; o[2] = suf;
+    }
+}
+// entries of NP plain components + the total, 64 per wave -> entries of NP + 1 plain components + the total
+template <class F>
+__global__ __launch_bounds__(256) void msm_reduce_lk_kernel(const Xyzz<F> *in, uint32_t n_in, uint32_t NP, uint32_t n_out, Xyzz<F> *out) {
+    const uint32_t w = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
+    if ((e & ~63u) >= n_in) return;          // whole wave beyond the end
+    const Xyzz<F> *ie = in + ((size_t)w * n_in + e) * (NP + 1);
+    Xyzz<F> *o = out + ((size_t)w * n_out + (e >> 6)) * (NP + 2);
+    for (uint32_t k = 0; k < NP; k++) {
+        Xyzz<F> v = e < n_in ? ie[k] : Xyzz<F>::inf();
+        wave_reduce(v);
+        if (lane == 0) o[k] = v;
+    }
+    const Xyzz<F> suf = wave_suffix_scan(e < n_in ? ie[NP] : Xyzz<F>::inf());
+    Xyzz<F> wsum = lane ? suf : Xyzz<F>::inf();
+    wave_reduce(wsum);
+    if (lane == 0) { o[NP] = wsum; o[NP + 1] = suf; }
+}
+
 // ------------------------------------------------------------------------------------------ host driver
 #define FK_DBG_ST(ctx, st, name)                                                                  \
     do {                                                                                          \
@@ -1138,7 +1190,17 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
     if (split && !have_sort && ln.ev_lane_done_valid) FK_HIP(ctx, hipStreamWaitEvent(ss, ln.ev_lane_done, 0));
     const size_t WB = (size_t)p.W * p.B;
     const uint32_t WR = merged ? 1 : p.W;      // bucket sets to reduce
-    const size_t wp_bytes = (size_t)WR * p.nblk * sizeof(Xyzz<F>);
+    // bucket reduction: FK_MSM_RED_HIER=1 selects the hierarchical form (msm_reduce_l1 / _lk kernels) from 2048 buckets on.
+    // Measured and NOT the default: its serial chain is 2.5x shorter, but the wave-level steps (18 shuffle additions per lane
+    // and level) make it 1.6x the additions of the flat form, and a tail's work is added to the accumulation it runs underneath:
+    // 171.5 -> 178.3 ms per proof at 2^25, 10.1 -> 13.2 at 2^20 (profiles/r02_sorts_first_probe.log).
+    static int t_hier = -1;
+    if (t_hier < 0) { const char *e = getenv("FK_MSM_RED_HIER"); t_hier = e ? atoi(e) : 0; }
+    const bool hier = t_hier != 0 && p.B >= 2048;
+    uint32_t hier_np = 0; const uint32_t hier_n1 = p.B / 512;     // plain components of the final entry; entries after level 1
+    if (hier) { hier_np = 2; for (uint32_t nn = hier_n1; nn > 1; nn = (nn + 63) / 64) hier_np++; }
+    const size_t wp_bytes = (size_t)WR * (hier ? hier_np + 1 : p.nblk) * sizeof(Xyzz<F>);
+    const size_t red_half = hier ? (size_t)WR * hier_n1 * 3 * sizeof(Xyzz<F>) : 0;
     // oversized buckets: at most OVER_MAX are tabled; their segment tasks are bounded by max(2048, W n / SEG_MAX) + one per bucket
     const size_t max_tasks = std::max<size_t>(2048, (size_t)p.W * n / SEG_MAX) + OVER_MAX + 64;
     // Growing a buffer frees the old one: everything queued on this lane must be finished first.
@@ -1150,7 +1212,7 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
         {&ln.perm, WB * 4 + SIZE_BINS * 4}, {&ln.overlist, OVER_MAX * sizeof(OverEntry) + sizeof(MsmDyn) + 64}, {have_sort ? &ln.buckets2 : &ln.buckets, WB * sizeof(Xyzz<F>)},
         {&ln.tasktab, max_tasks * sizeof(Task) + OVER_MAX * sizeof(OverBucket) + 64}, {&ln.partials, max_tasks * sizeof(Xyzz<F>)},
         {&ln.s2_cnt1, (size_t)p.W * p.nchunks * p.nhi * 4}, {&ln.s2_seg, ((size_t)nseg * 4 + 2) * 4}, {&ln.s2_cnt2, max_tiles * p.nlo * 4},
-        {&ln.s2_tmp_idx, (size_t)p.W * n * 4}, {&ln.s2_tmp_lo, (size_t)p.W * n * 2}};
+        {&ln.s2_tmp_idx, (size_t)p.W * n * 4}, {&ln.s2_tmp_lo, (size_t)p.W * n * 2}, {&ln.redbuf, 2 * red_half + 64}};
     bool grow = false;
     for (const Need &nd : needs) grow = grow || nd.bytes > nd.b->cap;
     if (grow) {
@@ -1267,7 +1329,7 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
     // ---- from here on nothing waits for the host
     if (!have_sort) { FK_HIP(ctx, hipEventRecord(ln.ev_sorted, ss)); ln.ev_sorted_valid = true; }
     if (split) FK_HIP(ctx, hipStreamWaitEvent(st, ln.ev_sorted, 0));
-    tl.active = true; tl.cb = p.cb; tl.wide = p.wide; tl.W = WR; tl.nblk = p.nblk;     // merged: one "window" of weight 1
+    tl.active = true; tl.cb = p.cb; tl.wide = p.wide; tl.W = WR; tl.nblk = hier ? hier_np + 1 : p.nblk; tl.hier = hier_np;     // merged: one "window" of weight 1
     *tail_out = ti;
     // The back of the multiplication in two pieces -- the accumulation, and the tail (oversized buckets, reduction, download) --
     // queued now, or by msm_run_deferred (ctx->defer_back): all accumulations first, then all tails, so that on the B pair's lane
@@ -1331,10 +1393,23 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
         hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_overflow_fold_kernel<F>), dim3(256), dim3(256), 0, st, d_obs, dyn, ln.partials.as<Xyzz<F>>(), buckets);
         FK_HIP(ctx, hipGetLastError());
         FK_DBG_ST(ctx, st, "msm_overflow_fold");
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_bucket_reduce_kernel<F>), dim3(p.nblk, WR), dim3(256), 0, st,
-                           buckets, p.B, p.L, p.T, p.nblk, winparts);
+        const Xyzz<F> *wp_src = winparts;
+        if (hier) {
+            Xyzz<F> *bufa = (Xyzz<F> *)ln.redbuf.p, *bufb = (Xyzz<F> *)((char *)ln.redbuf.p + red_half);
+            uint32_t nn = hier_n1, np = 2;
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_reduce_l1_kernel<F>), dim3(p.B / 8 / 256, WR), dim3(256), 0, st, buckets, p.B, nn, bufa);
+            while (nn > 1) {
+                const uint32_t no = (nn + 63) / 64;
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_reduce_lk_kernel<F>), dim3((nn + 255) / 256, WR), dim3(256), 0, st, bufa, nn, np, no, bufb);
+                std::swap(bufa, bufb); nn = no; np++;
+            }
+            wp_src = bufa;          // WR entries of np plain components + the total
+        } else {
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_bucket_reduce_kernel<F>), dim3(p.nblk, WR), dim3(256), 0, st,
+                               buckets, p.B, p.L, p.T, p.nblk, winparts);
+        }
         FK_HIP(ctx, hipGetLastError());
-        FK_HIP(ctx, hipMemcpyAsync(tl.h_wp, winparts, wp_bytes, hipMemcpyDeviceToHost, st));
+        FK_HIP(ctx, hipMemcpyAsync(tl.h_wp, wp_src, wp_bytes, hipMemcpyDeviceToHost, st));
         FK_HIP(ctx, hipMemcpyAsync((char *)tl.h_wp + wp_bytes, d_adds, 8, hipMemcpyDeviceToHost, st));
         FK_HIP(ctx, hipMemcpyAsync((char *)tl.h_wp + wp_bytes + 8, &dyn->error, 4, hipMemcpyDeviceToHost, st));
         FK_HIP(ctx, hipEventRecord(tl.done, st));
@@ -1377,6 +1452,15 @@ static int msm_end(fk_ctx *ctx, int tail, Xyzz<F> *out) {
     for (uint32_t w = tl.W; w-- > 0;) {
         const uint32_t cw = tl.cb + (w < tl.wide ? 1 : 0);       // acc holds the windows above w, relative to w's top bit
         for (uint32_t k = 0; k < cw; k++) acc = Xyzz<F>::dbl(acc);
+        if (tl.hier) {       // hierarchical reduction: P1 + 8 (P2 + 64 (P3 + ...)); the entry's last point (the bucket total) is not needed
+            const Xyzz<F> *P = wp + (size_t)w * tl.nblk;
+            Xyzz<F> r = P[tl.hier - 1];
+            for (uint32_t k = tl.hier - 1; k-- > 0;) {
+                for (uint32_t d = 0; d < (k == 0 ? 3u : 6u); d++) r = Xyzz<F>::dbl(r);
+                r.add(P[k]);
+            }
+            acc.add(r);
+        } else
         for (uint32_t b = 0; b < tl.nblk; b++) acc.add(wp[(size_t)w * tl.nblk + b]);
     }
     *out = acc;
@@ -1408,7 +1492,7 @@ void msm_release(fk_ctx *ctx) {
     for (MsmLane &ln : ctx->lanes) {
         if (ln.st) (void)hipStreamSynchronize(ln.st);
         for (DevBuf *b : {&ln.digits, &ln.sorted, &ln.totals, &ln.starts, &ln.perm, &ln.overlist, &ln.tasktab, &ln.partials, &ln.s2_cnt1, &ln.s2_seg,
-                          &ln.s2_cnt2, &ln.s2_tmp_idx, &ln.s2_tmp_lo, &ln.buckets, &ln.buckets2})
+                          &ln.s2_cnt2, &ln.s2_tmp_idx, &ln.s2_tmp_lo, &ln.buckets, &ln.buckets2, &ln.redbuf})
             b->release();
         if (ln.h_stage) (void)hipHostFree(ln.h_stage);
         if (ln.ev_in) (void)hipEventDestroy(ln.ev_in);
