@@ -830,14 +830,15 @@ __global__ __launch_bounds__(256, MINW) void msm_accumulate_merged_kernel(const 
 }
 // mt[b] = sum over the windows of min(totals[w][b], cap): the merged bucket's length, for the size ordering
 __global__ __launch_bounds__(256) void msm_merge_totals_kernel(const uint32_t *totals, uint32_t B, uint32_t W, const MsmDyn *dyn, uint32_t *mt, unsigned long long *adds) {
-    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
     const uint32_t cap = dyn->cap;
-    uint32_t s = 0;
-    if (b < B) {
+    unsigned long long mine = 0;       // mixed additions of this lane's buckets (a bucket's first entry is a copy)
+    for (uint32_t b = blockIdx.x * 256 + threadIdx.x; b < B; b += gridDim.x * 256) {       // grid-stride: ONE atomic per wave at the end (8192 atomics on one address cost 0.4 ms per launch)
+        uint32_t s = 0;
         for (uint32_t w = 0; w < W; w++) { const uint32_t v = totals[(size_t)w * B + b]; s += v < cap ? v : cap; }
         mt[b] = s;
+        mine += s ? s - 1 : 0;
     }
-    const unsigned long long all = wave_sum_u64(s ? s - 1 : 0);      // mixed additions of this bucket (the first entry is a copy)
+    const unsigned long long all = wave_sum_u64(mine);
     if ((threadIdx.x & 63) == 0 && all) atomicAdd(adds, all);
 }
 // level w+1 = 2^bits * level w, affine in, affine out.  NB (4 for G1, 2 for G2: registers) points per lane share one
@@ -1306,7 +1307,7 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
         FK_HIP(ctx, hipMemsetAsync(size_bins, 0, SIZE_BINS * 4, ss));
         if (merged) {     // one bucket set: order its B buckets by their length over all windows (perm[0, B); lengths kept behind it)
             uint32_t *mt = perm + p.B;
-            hipLaunchKernelGGL(msm_merge_totals_kernel, dim3((p.B + 255) / 256), dim3(256), 0, ss, totals, p.B, p.W, dyn, mt, d_adds);
+            hipLaunchKernelGGL(msm_merge_totals_kernel, dim3(std::min<uint32_t>((p.B + 255) / 256, 1024)), dim3(256), 0, ss, totals, p.B, p.W, dyn, mt, d_adds);
             hipLaunchKernelGGL(msm_size_hist_kernel, dim3((unsigned)std::min<size_t>((p.B + 255) / 256, 1024)), dim3(256), 0, ss, mt, (size_t)p.B, dyn, p.W, size_bins, (unsigned long long *)nullptr);
             hipLaunchKernelGGL(msm_size_scan_kernel, dim3(1), dim3(SIZE_BINS), 0, ss, size_bins);
             hipLaunchKernelGGL(msm_size_scatter_kernel, dim3((unsigned)((p.B + 1023) / 1024)), dim3(1024), 0, ss, mt, (size_t)p.B, dyn, p.W, size_bins, perm);
