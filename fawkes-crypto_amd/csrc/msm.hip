@@ -1161,6 +1161,13 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
         if (pm.cb == pre->cb && pm.wide == pre->wide && pm.W == pre->W) { p = pm; merged = true; }
     }
     const Affine<F> *d_lev = merged ? (const Affine<F> *)pre->lev : nullptr;
+    // G2: shorter lanes in the bucket reduction (FK_MSM_RED_L_G2, experiment): its serial chain is what a proof ends on (a G2
+    // addition is 3.3 G1 ones) -- measured: 64 (the plan's) 170.4, 32 170.8, 16 172.6 ms per proof; off
+    if (!std::is_same<F, Fq>::value) {
+        static int t_l2 = -1;
+        if (t_l2 < 0) { const char *e = getenv("FK_MSM_RED_L_G2"); t_l2 = e ? atoi(e) : 0; }
+        if (t_l2 > 0 && p.L > (uint32_t)t_l2 && (uint32_t)t_l2 <= p.B) { p.L = (uint32_t)t_l2; p.T = p.B / p.L; p.nblk = (p.T + 255) / 256; }
+    }
     // lane: the next one in turn, unless this call reuses the previous call's sort (B2 after B1).  With three lanes the
     // multiplication after the G2 one does not queue behind its long overflow / reduction tail (at 2^22 that tail was 5.4 ms
     // during which nothing else ran: 31 % of the proof).
@@ -1418,7 +1425,17 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
         FK_DBG_ST(ctx, st, "msm_bucket_reduce");
         return FK_OK;
     };
-    if (ctx->defer_back) { ctx->deferred.push_back(back_acc); ctx->deferred_tails.push_back(back_tail); return FK_OK; }
+    if (ctx->defer_back) {
+        // FK_PROVE_G2_FIRST (default 1): a multiplication that reuses the lane's sort (B2, the G2 one) accumulates BEFORE the sort's
+        // owner (B1): its long latency-bound tail then falls into the window after the witness accumulations in which only H's
+        // sort runs, instead of starving underneath H's accumulation and ending the proof
+        static int t_g2first = -1;
+        if (t_g2first < 0) { const char *e = getenv("FK_PROVE_G2_FIRST"); t_g2first = e ? atoi(e) : 1; }
+        if (have_sort && t_g2first && !ctx->deferred.empty()) ctx->deferred.insert(ctx->deferred.end() - 1, back_acc);
+        else ctx->deferred.push_back(back_acc);
+        ctx->deferred_tails.push_back(back_tail);
+        return FK_OK;
+    }
     FK_TRY(back_acc());
     return back_tail();
 }
