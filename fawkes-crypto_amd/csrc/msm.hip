@@ -1426,11 +1426,12 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
         return FK_OK;
     };
     if (ctx->defer_back) {
-        // FK_PROVE_G2_FIRST (default 1): a multiplication that reuses the lane's sort (B2, the G2 one) accumulates BEFORE the sort's
-        // owner (B1): its long latency-bound tail then falls into the window after the witness accumulations in which only H's
-        // sort runs, instead of starving underneath H's accumulation and ending the proof
+        // FK_PROVE_G2_FIRST=1 (experiment): a multiplication that reuses the lane's sort (B2, the G2 one) accumulates BEFORE the sort's
+        // owner (B1), beside L and A, so that its long latency-bound tail might fall into the window in which only H's sort runs
+        // instead of starving underneath H's accumulation.  It does not fit there either (6.6 ms against 4): 170.0 against 170.5 ms,
+        // and the G1 kernel's time is then shared with the G2 kernel's.  Off.
         static int t_g2first = -1;
-        if (t_g2first < 0) { const char *e = getenv("FK_PROVE_G2_FIRST"); t_g2first = e ? atoi(e) : 1; }
+        if (t_g2first < 0) { const char *e = getenv("FK_PROVE_G2_FIRST"); t_g2first = e ? atoi(e) : 0; }
         if (have_sort && t_g2first && !ctx->deferred.empty()) ctx->deferred.insert(ctx->deferred.end() - 1, back_acc);
         else ctx->deferred.push_back(back_acc);
         ctx->deferred_tails.push_back(back_tail);
