@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void spmv_binned_kernel(SpmvArgs a, BinArgs b,
             const uint32_t c0 = var(col[k]), c1 = var(col[k + G]), c2 = var(col[k + 2 * G]), c3 = var(col[k + 3 * G]);
             const uint32_t i0 = cidx[k], i1 = cidx[k + G], i2 = cidx[k + 2 * G], i3 = cidx[k + 3 * G];
             acc = Fr::add(acc, Fr::dot4(z[c0], table[i0], z[c1], table[i1], z[c2], table[i2], z[c3], table[i3]));
-        }
+        }       // (loading the NEXT step's indices ahead of this step's products was measured: 169.8 against 168.8 ms per proof)
         // ... then two
         Fr acc1 = Fr::zero();
         for (; k + G < e; k += 2 * G) {        // table[0] is ONE: multiplying by it returns the (reduced) value itself
