@@ -520,6 +520,25 @@ static int prove_msms_dev(fk_ctx *ctx, const fk_key *key, Fr *d_a, Fr *d_b, Fr *
         // The accumulations of B1, L and A then run side by side on their lanes (they fill each other's last waves; one after
         // the other on a stream of their own was measured slower: 192.3 - 195.5 against 185.8 - 188.5 ms,
         // profiles/r02_sorts_first_probe.log), B2's right behind B1's, all tails behind the accumulations of their lane.
+        // FK_PROVE_H_SORT_FIRST=1 (experiment): H's sort right behind the quotient, ALONE, and every accumulation behind it
+        // (instead of H's sort crawling underneath the witness accumulations and finishing once they are over)
+        static int t_hfirst = -1;
+        if (t_hfirst < 0) { const char *e = getenv("FK_PROVE_H_SORT_FIRST"); t_hfirst = e ? atoi(e) : 0; }
+        if (gate && t_hfirst) {
+            int t_h1 = -1;
+            ctx->defer_back = true;
+            const int rch = msm_g1_begin(ctx, key->d_h, d_h + key->h_lo, key->h_hi - key->h_lo, &t_h1, ctx->ev_main, &key->pre_h);
+            ctx->defer_back = false;
+            if (rch != FK_OK) { msm_abandon(ctx); return rch; }
+            MsmLane &lh = ctx->lanes[ctx->lane_prev];
+            const int rcd = msm_run_deferred(ctx, lh.ev_sorted_valid ? lh.ev_sorted : ctx->ev_main);
+            lh.ev_sorted_valid = false;
+            if (rcd != FK_OK) { msm_abandon(ctx); return rcd; }
+            const double t2w = now_ms();
+            FK_TRY(witness_end(ctx, out, t_h1));
+            if (tm) { tm->ntt_ms = t1 - t0; tm->msm_l_ms = t2w - t1; tm->msm_h_ms = now_ms() - t2w; tm->total_ms = now_ms() - t0; }
+            return FK_OK;
+        }
         if (gate) { const int rcd = msm_run_deferred(ctx, ctx->ev_main); if (rcd != FK_OK) { msm_abandon(ctx); return rcd; } }
         if (!gate && !early) {
             const int rcw = witness_begin(ctx, key, d_z, d_a_aux, d_b_in, d_b_aux, ctx->ev_z);

@@ -21,7 +21,7 @@ SWITCHES = [
     {'FK_MSM_PRE_MIN_LOG2': '8', 'FK_PROVE_SORTS_FIRST': '1', 'FK_MSM_H_PRIO': '1', 'FK_MSM_UNDER_NT1': '512', 'FK_MSM_UNDER_NT2': '512'},
     {'FK_MSM_LANES': '1'}, {'FK_MSM_LANES': '2'}, {'FK_MSM_LIMB29': '1'}, {'FK_MSM_CU_SPLIT': '1'}, {'FK_MSM_SORT_ALONE': '1'},
     {'FK_MSM_PRECOMP': '0'}, {'FK_MSM_RED_HIER': '1'}, {'FK_MSM_RED_HIER': '1', 'FK_MSM_PRE_MIN_LOG2': '8'}, {'FK_UPLOAD_DEFER': '0'},
-    {'FK_PROVE_SORTS_FIRST': '1', 'FK_PROVE_G2_FIRST': '1'}, {'FK_MSM_RED_L_G2': '16'},
+    {'FK_PROVE_SORTS_FIRST': '1', 'FK_PROVE_G2_FIRST': '1'}, {'FK_MSM_RED_L_G2': '16'}, {'FK_PROVE_SORTS_FIRST': '1', 'FK_PROVE_H_SORT_FIRST': '1'},
 ]
 
 
