@@ -21,7 +21,10 @@
 namespace fk {
 
 static constexpr uint32_t NTT_MAXDEG = 9;       // R <= 512
-static constexpr uint32_t NTT_TILE_LOG = 11;    // R*C <= 2048 elements = 64 KiB of LDS
+#ifndef FK_NTT_TILE_LOG
+#define FK_NTT_TILE_LOG 10
+#endif
+static constexpr uint32_t NTT_TILE_LOG = FK_NTT_TILE_LOG;    // R*C <= 1024 elements = 32 KiB of LDS: four workgroups per compute unit (2048 elements / two: 169.4 -> 168.1 ms per proof; 4096 / one: 171.2; profiles/r02_sorts_first_probe.log)
 static constexpr uint32_t NTT_MAX_THREADS = 1024;
 
 enum { PRE_NONE = 0, PRE_TABLE = 1, PRE_ABC = 2, PRE_AB = 3 };
