@@ -1032,6 +1032,18 @@ __global__ __launch_bounds__(256) void msm_bucket_reduce_kernel(const Xyzz<F> *b
     if (threadIdx.x == 0) winparts[(size_t)w * nblk + blockIdx.x] = acc;
 }
 
+// The nblk partial sums of a window folded into one point on the device: the host used to add them (128 per multiplication,
+// 1.2 ms per proof of host arithmetic AFTER the last kernel -- the GPU idle gap between consecutive proofs).
+template <class F>
+__global__ __launch_bounds__(256) void msm_fold_partials_kernel(const Xyzz<F> *winparts, uint32_t nblk, Xyzz<F> *out) {
+    __shared__ Xyzz<F> sh[4];
+    const uint32_t w = blockIdx.x;
+    Xyzz<F> acc = Xyzz<F>::inf();
+    for (uint32_t b = threadIdx.x; b < nblk; b += 256) acc.add(winparts[(size_t)w * nblk + b]);
+    block_reduce_256(acc, sh);
+    if (threadIdx.x == 0) out[w] = acc;
+}
+
 // Hierarchical form: no lane walks more than 8 buckets and nothing is multiplied by its offset on the device.
 // With slot s = 8 t + j (lane t, j < 8) and t = 64 v + l (wave v, lane l) and so on,
 //     sum_s (s + 1) S_s = P1 + 8 (P2 + 64 (P3 + 64 (P4 + ...)))
@@ -1207,7 +1219,8 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
     const bool hier = t_hier != 0 && p.B >= 2048;
     uint32_t hier_np = 0; const uint32_t hier_n1 = p.B / 512;     // plain components of the final entry; entries after level 1
     if (hier) { hier_np = 2; for (uint32_t nn = hier_n1; nn > 1; nn = (nn + 63) / 64) hier_np++; }
-    const size_t wp_bytes = (size_t)WR * (hier ? hier_np + 1 : p.nblk) * sizeof(Xyzz<F>);
+    const size_t wp_bytes = (size_t)WR * (hier ? hier_np + 1 : 1) * sizeof(Xyzz<F>);        // flat form: ONE point per window (folded on the device)
+    const size_t wp_dev_bytes = hier ? wp_bytes : (size_t)WR * (p.nblk + 1) * sizeof(Xyzz<F>);     // ... behind the nblk partial sums of every window
     const size_t red_half = hier ? (size_t)WR * hier_n1 * 3 * sizeof(Xyzz<F>) : 0;
     // oversized buckets: at most OVER_MAX are tabled; their segment tasks are bounded by max(2048, W n / SEG_MAX) + one per bucket
     const size_t max_tasks = std::max<size_t>(2048, (size_t)p.W * n / SEG_MAX) + OVER_MAX + 64;
@@ -1229,7 +1242,7 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
         for (const Need &nd : needs) FK_HIP(ctx, nd.b->reserve(nd.bytes));
         if (!have_sort) ln.last_sort_scalars = nullptr;
     }
-    FK_HIP(ctx, tl.d_wp.reserve(wp_bytes));
+    FK_HIP(ctx, tl.d_wp.reserve(wp_dev_bytes));
     if (wp_bytes + 16 > tl.h_cap) {         // + the additions counter and the error word
         if (tl.h_wp) { FK_HIP(ctx, hipHostFree(tl.h_wp)); tl.h_wp = nullptr; tl.h_cap = 0; }
         FK_HIP(ctx, hipHostMalloc(&tl.h_wp, wp_bytes + (wp_bytes >> 2) + 16, hipHostMallocDefault));
@@ -1337,7 +1350,7 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
     // ---- from here on nothing waits for the host
     if (!have_sort) { FK_HIP(ctx, hipEventRecord(ln.ev_sorted, ss)); ln.ev_sorted_valid = true; }
     if (split) FK_HIP(ctx, hipStreamWaitEvent(st, ln.ev_sorted, 0));
-    tl.active = true; tl.cb = p.cb; tl.wide = p.wide; tl.W = WR; tl.nblk = hier ? hier_np + 1 : p.nblk; tl.hier = hier_np;     // merged: one "window" of weight 1
+    tl.active = true; tl.cb = p.cb; tl.wide = p.wide; tl.W = WR; tl.nblk = hier ? hier_np + 1 : 1; tl.hier = hier_np;     // merged: one "window" of weight 1
     *tail_out = ti;
     // The back of the multiplication in two pieces -- the accumulation, and the tail (oversized buckets, reduction, download) --
     // queued now, or by msm_run_deferred (ctx->defer_back): all accumulations first, then all tails, so that on the B pair's lane
@@ -1415,6 +1428,9 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
         } else {
             hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_bucket_reduce_kernel<F>), dim3(p.nblk, WR), dim3(256), 0, st,
                                buckets, p.B, p.L, p.T, p.nblk, winparts);
+            Xyzz<F> *folded = winparts + (size_t)WR * p.nblk;
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_fold_partials_kernel<F>), dim3(WR), dim3(256), 0, st, winparts, p.nblk, folded);
+            wp_src = folded;
         }
         FK_HIP(ctx, hipGetLastError());
         FK_HIP(ctx, hipMemcpyAsync(tl.h_wp, wp_src, wp_bytes, hipMemcpyDeviceToHost, st));
