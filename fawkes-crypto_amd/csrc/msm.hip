@@ -5,25 +5,27 @@
 // /root/reference/fawkes-crypto/src/backend/bellman_groth16/prover.rs:80).  Any correct MSM yields the
 // same group element, so the result is bit-identical to bellman's after `into_affine`.
 //
-// MI355X pipeline (no MFMA -- 256-bit modular integer work).  A multiplication is queued completely on one of
-// MSM_LANES lanes (stream + private scratch); consecutive multiplications use different lanes, so the latency-bound
-// steps 4-5 of one run underneath steps 1-3 of the next (msm_*_begin / msm_*_end):
+// MI355X pipeline (no MFMA -- 256-bit modular integer work).  A multiplication is queued on one of MSM_LANES lanes (stream +
+// private scratch); consecutive multiplications use different lanes, so the latency-bound steps 4-5 of one run underneath
+// steps 1-3 of the next (msm_*_begin / msm_*_end).  Its front (steps 1-2b), its accumulation (3) and its tail (4-5) can be
+// queued separately (fk_ctx::defer_back, msm_run_deferred): the prover's sorts-first schedule puts the quotient between the
+// witness multiplications' fronts and their accumulations (prover.hip).
 //   1. msm_digits      scalars leave Montgomery form (bellman's `into_repr`) and are cut into W signed digits; the 255
 //                      bits are split evenly into windows of cb or cb + 1 bits (no short top window).
-//   2. bucket sort     two-pass radix sort on the bucket index (high bits, then the low 10 bits inside each
-//                      segment): LDS histograms and cursors, every tile ranked and staged in LDS and written as
-//                      contiguous runs.  No global atomics, so skewed witness scalars (many 0/1) cost nothing extra.
+//   2. bucket sort     two-pass radix sort on the bucket index (up to 1024 high bins, then the low 10-11 bits inside each
+//                      segment): LDS histograms and cursors, every tile counted, laid out in bin order in LDS and written
+//                      as contiguous runs; 8192-entry tiles, two workgroups per compute unit in both passes.  No global atomics, so skewed witness scalars (many 0/1) cost nothing extra.
 //                      The second pass is launched over the host's upper bound on the tile count; the cap of a bucket-lane,
 //                      the list of oversized buckets and their segment tasks are worked out by small kernels into a
 //                      device-side record (MsmDyn) the later kernels read -- the host never waits inside a multiplication.
 //   2b. size order     buckets are counting-sorted by length so the 64 lanes of a wave run equally long.
-//   3. msm_accumulate  one lane per bucket walks its run with XYZZ mixed additions (8M+2S), gathering
-//                      64-byte affine bases; buckets above `cap` = mean + 6 sigma + 8 entries hand the excess to
+//   3. msm_accumulate  one lane per bucket walks its run with XYZZ mixed additions (6 products, a dual squaring and one
+//                      fused difference of two products, lazily reduced: field.hpp), gathering 64-byte affine bases; buckets above `cap` = mean + 6 sigma + 8 entries hand the excess to
 //   4. msm_overflow    one wave per segment (sized so that all oversized entries give ~2 waves per SIMD), reduced with
 //                      wavefront shuffles; then 256 lanes per oversized bucket fold the partials.
 //   5. msm_bucket_reduce  sum_b b*S_b per window: each lane runs the running-sum trick over L buckets,
-//                      adds its offset multiple by double-and-add, then wave64 shuffle + LDS reduction; the window
-//                      sums are copied to pinned host memory.
+//                      adds its offset multiple by double-and-add, then wave64 shuffle + LDS reduction; a last small
+//                      kernel folds the workgroups' partial sums, the window sums are copied to pinned host memory.
 //   6. host            W window sums are Horner-combined (cw doublings each) -- microseconds.
 #include "common.hpp"
 #include "field29.hpp"
