@@ -312,7 +312,13 @@ __global__ __launch_bounds__(256) void s2_hist2_kernel(const uint16_t *tmp_lo, s
     __syncthreads();
     const uint32_t size = seg_size[sgm], lo = t * S2_TILE, hi = lo + S2_TILE < size ? lo + S2_TILE : size;
     const uint16_t *src = tmp_lo + (size_t)w * n + seg_start[sgm];
-    for (uint32_t k = lo + threadIdx.x; k < hi; k += 256) atomicAdd(&hist[src[k]], 1u);
+    for (uint32_t k = lo + threadIdx.x; k < hi; k += 256 * 8) {        // eight independent loads in flight per lane
+        uint32_t v[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; u++) { const uint32_t kk = k + u * 256; v[u] = kk < hi ? src[kk] : 0xffffffffu; }
+#pragma unroll
+        for (uint32_t u = 0; u < 8; u++) if (v[u] != 0xffffffffu) atomicAdd(&hist[v[u]], 1u);
+    }
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < nlo; b += 256) cnt2[(size_t)tile * nlo + b] = hist[b];
 }
