@@ -299,6 +299,35 @@ def pairing_check(vk_full, z_inputs, proof):
     return True
 
 
+def self_launch(n_gpus):
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nproc-per-node N bench.py <same
+    arguments>` as a child process (one rank per GPU, rendezvous on 127.0.0.1 at a free port), pass its output through and
+    print rank 0's JSON line once more as the LAST line of our stdout.  Returns the child's exit code."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n_gpus), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC: what RCCL needs on this driver
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True, bufsize=1)
+    line = None
+    for ln in proc.stdout:
+        if ln.startswith('{"metric"'):
+            line = ln.rstrip('\n')
+        else:
+            sys.stdout.write(ln)
+    rc = proc.wait()
+    sys.stdout.flush()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        rc = 1
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -315,12 +344,14 @@ def main():
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend ('nccl' = RCCL; 'gloo' only for single-GPU dry runs of the N>1 code path with FK_BENCH_SAME_DEVICE=1)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves, as fresh child processes, BEFORE this process has
+        # made any GPU call (it never does), and relay rank 0's JSON line as our own last line of stdout
+        raise SystemExit(self_launch(args.gpus))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('bench.py --gpus %d must be launched with torch.distributed.run (one process per GPU)' % args.gpus)
         raise SystemExit('--gpus %d != WORLD_SIZE %d' % (args.gpus, world))
 
     import torch

@@ -38,7 +38,11 @@ EXPORTED_SYMBOLS = [
     'fk_dq_gather_dev', 'fk_dq_local_dev', 'fk_dq_cross_dev', 'fk_dq_cross_sub_dev',
     'fk_setup', 'fk_setup_tiled', 'fk_r1cs_load_tiled', 'fk_key_download', 'fk_key_load_bellman', 'fk_key_vk', 'fk_key_counts', 'fk_key_precomputed',
     'fk_gates_decode', 'fk_gates_free', 'fk_gates_info', 'fk_gates_export', 'fk_r1cs_load_gates',
-    'fk_r1cs_load', 'fk_r1cs_free', 'fk_r1cs_info', 'fk_r1cs_density_ptrs', 'fk_r1cs_eval_dev', 'fk_prove_r1cs', 'fk_prove_r1cs_dev',
+    'fk_r1cs_load', 'fk_r1cs_free', 'fk_r1cs_info', 'fk_r1cs_density_ptrs', 'fk_r1cs_eval_dev', 'fk_r1cs_eval_slice_dev', 'fk_prove_r1cs', 'fk_prove_r1cs_dev',
+    'fk_init_devices', 'fk_multi_free', 'fk_multi_last_error', 'fk_multi_size', 'fk_multi_ctx', 'fk_multi_sync',
+    'fk_multi_key_load', 'fk_multi_key_load_bellman', 'fk_multi_setup', 'fk_multi_setup_tiled', 'fk_multi_key_free', 'fk_multi_key_shard',
+    'fk_multi_r1cs_load', 'fk_multi_r1cs_load_tiled', 'fk_multi_r1cs_load_gates', 'fk_multi_r1cs_free', 'fk_multi_r1cs_replica',
+    'fk_multi_prove_r1cs', 'fk_multi_prove_r1cs_submit', 'fk_multi_prove_r1cs_wait',
 ]
 
 _ERR = {1: 'FK_ERR_BAD_ARG', 2: 'FK_ERR_DOMAIN_TOO_LARGE (bellman: PolynomialDegreeTooLarge)',
@@ -108,6 +112,20 @@ def load_library():
         lib.fk_key_free.restype = None
         lib.fk_gates_free.argtypes = [C.c_void_p]
         lib.fk_gates_free.restype = None
+        lib.fk_multi_last_error.restype = C.c_char_p
+        lib.fk_multi_last_error.argtypes = [C.c_void_p]
+        lib.fk_multi_free.argtypes = [C.c_void_p]
+        lib.fk_multi_free.restype = None
+        lib.fk_multi_key_free.argtypes = [C.c_void_p, C.c_void_p]
+        lib.fk_multi_key_free.restype = None
+        lib.fk_multi_r1cs_free.argtypes = [C.c_void_p, C.c_void_p]
+        lib.fk_multi_r1cs_free.restype = None
+        lib.fk_multi_ctx.restype = C.c_void_p
+        lib.fk_multi_ctx.argtypes = [C.c_void_p, C.c_int]
+        lib.fk_multi_key_shard.restype = C.c_void_p
+        lib.fk_multi_key_shard.argtypes = [C.c_void_p, C.c_int]
+        lib.fk_multi_r1cs_replica.restype = C.c_void_p
+        lib.fk_multi_r1cs_replica.argtypes = [C.c_void_p, C.c_int]
         _LIB = lib
     return _LIB
 
@@ -440,18 +458,23 @@ class HostVk:
 class Context:
     """One GPU (one process per GPU for multi-GPU runs).  Raises FkError if no GPU is usable."""
 
-    def __init__(self, device_id=0):
+    def __init__(self, device_id=0, _borrowed=None):
         self.lib = load_library()
+        self.device_id = device_id
+        self._owned = _borrowed is None
+        if _borrowed is not None:           # a rank's context of a MultiContext: owned by the fk_multi
+            self.handle = C.c_void_p(_borrowed)
+            return
         h = C.c_void_p()
         rc = self.lib.fk_init(C.c_int(device_id), C.byref(h))
         if rc != 0:
             raise FkError(rc, 'fk_init(device %d) failed -- no usable MI355X/HIP device; there is no CPU fallback' % device_id)
         self.handle = h
-        self.device_id = device_id
 
     def close(self):
         if getattr(self, 'handle', None):
-            self.lib.fk_free(self.handle)
+            if self._owned:
+                self.lib.fk_free(self.handle)
             self.handle = None
 
     def __del__(self):
@@ -764,6 +787,11 @@ class Context:
     def r1cs_eval_dev(self, dr, d_z, d_a, d_b, d_c):
         self._ck(self.lib.fk_r1cs_eval_dev(self.handle, dr.handle, C.c_void_p(d_z), C.c_void_p(d_a), C.c_void_p(d_b), C.c_void_p(d_c)))
 
+    def r1cs_eval_slice_dev(self, dr, d_z, log_m, rank, log_w, d_a, d_b, d_c):
+        """fk_r1cs_eval_slice_dev: the cyclic row slice of rank `rank` of 2^log_w (2^(log_m - log_w) elements per array)"""
+        self._ck(self.lib.fk_r1cs_eval_slice_dev(self.handle, dr.handle, C.c_void_p(d_z), C.c_uint32(log_m), C.c_uint32(rank), C.c_uint32(log_w),
+                                                 C.c_void_p(d_a), C.c_void_p(d_b), C.c_void_p(d_c)))
+
     def prove_witness(self, key, dr, z, r, s, want_timings=False):
         """fk_prove_r1cs: z (host, (num_input+num_aux, 4) uint64 Montgomery) -> 256-byte proof."""
         z, r, s = _fr(z), _fr(r, 1), _fr(s, 1)
@@ -810,6 +838,154 @@ class Context:
 
     def dev_copy(self, dst, src, nbytes):
         self._ck(self.lib.fk_dev_copy(self.handle, C.c_void_p(dst), C.c_void_p(src), C.c_size_t(nbytes)))
+
+
+class _MultiHandle:
+    """a key / constraint system loaded through a MultiContext (one shard / replica per GPU)"""
+
+    def __init__(self, multi, handle, free_fn):
+        self.multi, self.handle, self._free = multi, handle, free_fn
+
+    def free(self):
+        if self.handle is not None and self.multi.handle:
+            self._free(self.multi.handle, self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class MultiContext:
+    """N GPUs of one node behind ONE call (fk_init_devices / fk_multi_*, csrc/multi.hip): one process, a library context and a
+    worker thread per GPU, exchanges inside the library.  `device_ids` may repeat (ranks sharing a GPU: one-GPU test boxes).
+    The reference's `prove` (prover.rs:63-90) is one call; so is `prove_witness` here, whatever N is."""
+
+    def __init__(self, device_ids):
+        self.lib = load_library()
+        ids = (C.c_int * len(device_ids))(*[int(d) for d in device_ids])
+        h = C.c_void_p()
+        rc = self.lib.fk_init_devices(C.c_int(len(device_ids)), ids, C.byref(h))
+        if rc != 0:
+            raise FkError(rc, 'fk_init_devices(%s) failed -- no usable MI355X/HIP device; there is no CPU fallback' % list(device_ids))
+        self.handle = h
+        self.device_ids = list(device_ids)
+        self._tickets = {}
+
+    @property
+    def size(self):
+        return int(self.lib.fk_multi_size(self.handle))
+
+    def close(self):
+        if getattr(self, 'handle', None):
+            self.lib.fk_multi_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != 0:
+            msg = self.lib.fk_multi_last_error(self.handle)
+            raise FkError(rc, msg.decode() if msg else '')
+
+    def ctx(self, rank):
+        """rank's single-GPU Context (borrowed: statistics, calibration, pinned host buffers)"""
+        p = self.lib.fk_multi_ctx(self.handle, C.c_int(rank))
+        if not p:
+            raise IndexError(rank)
+        return Context(self.device_ids[rank], _borrowed=p)
+
+    def sync(self):
+        self._ck(self.lib.fk_multi_sync(self.handle))
+
+    def load_key(self, params):
+        d = params.desc(0, 1, Z_EQUAL_SPLIT)
+        h = C.c_void_p()
+        self._ck(self.lib.fk_multi_key_load(self.handle, C.byref(d), C.byref(h)))
+        return _MultiHandle(self, h, self.lib.fk_multi_key_free)
+
+    def load_key_bellman(self, data, flags=FK_KEY_CHECKED):
+        buf = np.frombuffer(bytes(data), np.uint8)
+        h = C.c_void_p()
+        gamma = np.zeros(128, np.uint8)
+        n_ic = C.c_uint32()
+        cap = 1 << 16
+        ic = np.zeros((cap, 64), np.uint8)
+        self._ck(self.lib.fk_multi_key_load_bellman(self.handle, _vp(buf), C.c_size_t(buf.size), C.c_uint32(flags), C.byref(h), _vp(gamma), _vp(ic),
+                                                    C.c_uint32(cap), C.byref(n_ic)))
+        return _MultiHandle(self, h, self.lib.fk_multi_key_free), gamma, ic[:min(n_ic.value, cap)].copy()
+
+    def setup(self, r1cs, tau, alpha, beta, gamma, delta, copies=None):
+        """fk_multi_setup / fk_multi_setup_tiled: rank g derives only shard g.  Returns (key, vk dict) like Context.setup."""
+        h = C.c_void_p()
+        vk = np.zeros(6 * 128, np.uint8)
+        tau, alpha, beta, gamma, delta = _fr(tau, 1), _fr(alpha, 1), _fr(beta, 1), _fr(gamma, 1), _fr(delta, 1)
+        tox = (_vp(tau), _vp(alpha), _vp(beta), _vp(gamma), _vp(delta))
+        if copies is None:
+            ic = np.zeros((r1cs.num_input, 64), np.uint8)
+            self._ck(self.lib.fk_multi_setup(self.handle, C.byref(r1cs.struct), *tox, C.byref(h), _vp(vk), _vp(ic)))
+        else:
+            ic = np.zeros((1 + int(copies) * (r1cs.num_input - 1), 64), np.uint8)
+            self._ck(self.lib.fk_multi_setup_tiled(self.handle, C.byref(r1cs.struct), C.c_uint32(int(copies)), *tox, C.byref(h), _vp(vk), _vp(ic)))
+        names = (('alpha_g1', 64), ('beta_g1', 64), ('beta_g2', 128), ('gamma_g2', 128), ('delta_g1', 64), ('delta_g2', 128))
+        out = {n: vk[i * 128:i * 128 + w].copy() for i, (n, w) in enumerate(names)}
+        out['ic'] = ic
+        return _MultiHandle(self, h, self.lib.fk_multi_key_free), out
+
+    def key_shard(self, key, rank):
+        """rank's shard as a (borrowed) DeviceKey: counts(), shard_info(), precomputed()"""
+        dk = DeviceKey(self.ctx(rank), C.c_void_p(self.lib.fk_multi_key_shard(key.handle, C.c_int(rank))), rank, self.size)
+        dk.free = lambda: None
+        return dk
+
+    def load_r1cs(self, r1cs, copies=None):
+        h = C.c_void_p()
+        if copies is None:
+            self._ck(self.lib.fk_multi_r1cs_load(self.handle, C.byref(r1cs.struct), C.byref(h)))
+        else:
+            self._ck(self.lib.fk_multi_r1cs_load_tiled(self.handle, C.byref(r1cs.struct), C.c_uint32(int(copies)), C.byref(h)))
+        return _MultiHandle(self, h, self.lib.fk_multi_r1cs_free)
+
+    def load_gates(self, gates):
+        h = C.c_void_p()
+        self._ck(self.lib.fk_multi_r1cs_load_gates(self.handle, gates.handle, C.byref(h)))
+        return _MultiHandle(self, h, self.lib.fk_multi_r1cs_free)
+
+    def r1cs_replica(self, dr, rank):
+        d = DeviceR1cs(self.ctx(rank), C.c_void_p(self.lib.fk_multi_r1cs_replica(dr.handle, C.c_int(rank))))
+        d.free = lambda: None
+        return d
+
+    def prove_witness(self, key, dr, z, r, s, want_timings=False):
+        """fk_multi_prove_r1cs: z (host, (num_input + num_aux, 4) uint64 Montgomery) -> 256-byte proof, on all GPUs"""
+        z, r, s = _fr(z), _fr(r, 1), _fr(s, 1)
+        out = np.zeros(FK_PROOF_BYTES, np.uint8)
+        tm = Timings()
+        self._ck(self.lib.fk_multi_prove_r1cs(self.handle, key.handle, dr.handle, _vp(z), _vp(r), _vp(s), _vp(out), C.byref(tm)))
+        return (out, tm.as_dict()) if want_timings else out
+
+    def prove_witness_submit(self, key, dr, z, r, s):
+        assert z.dtype == np.uint64 and z.flags['C_CONTIGUOUS']
+        r, s = _fr(r, 1), _fr(s, 1)
+        t = C.c_int(-1)
+        self._ck(self.lib.fk_multi_prove_r1cs_submit(self.handle, key.handle, dr.handle, _vp(z), _vp(r), _vp(s), C.byref(t)))
+        self._tickets[t.value] = (z, r, s, key, dr)
+        return t.value
+
+    def prove_witness_wait(self, ticket, want_timings=False):
+        out = np.zeros(FK_PROOF_BYTES, np.uint8)
+        tm = Timings()
+        try:
+            self._ck(self.lib.fk_multi_prove_r1cs_wait(self.handle, C.c_int(ticket), _vp(out), C.byref(tm)))
+        finally:
+            self._tickets.pop(ticket, None)
+        return (out, tm.as_dict()) if want_timings else out
 
 
 def synthesize(r1cs, z, ctx=None):

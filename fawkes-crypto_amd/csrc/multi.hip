@@ -1,0 +1,536 @@
+// Multi-GPU prover behind the C ABI: ONE call proves on N GPUs of one node (include/fawkes_hip.h: fk_init_devices, fk_multi_*).
+//
+// The reference's entry point is one call -- `prove(params, pub, sec, circuit)`
+// (/root/reference/fawkes-crypto/src/backend/bellman_groth16/prover.rs:63-90) -- so the sharded form is one call as well: a
+// host that binds this library (the Rust shim, shim/src/lib.rs) needs no process group, no launcher and no collective
+// library of its own.  One process, one library context and one worker thread per GPU.  What shards:
+//   * every key array: rank g keeps 1/N of h, l, a, b_g1, b_g2 (and derives the fixed-base levels of its slices);
+//   * the evaluation of a, b, c: rank g evaluates only the rows t = g (mod N) -- the cyclic slice its part of the quotient
+//     starts from (fk_r1cs_eval_slice_dev);
+//   * the quotient: every m-point transform is cut once between the ranks (ntt.hip, dq_*), one all-to-all per transform, seven
+//     per proof; rank g ends with the block of h whose bases it holds;
+//   * the five multi-scalar multiplications: rank g sums its slices; the 384-byte partial results are folded on the host.
+// The all-to-all is done here, by the library: every rank PULLS its chunks out of its peers' buffers with
+// hipMemcpyPeerAsync -- device-to-device DMA over xGMI -- on an exchange stream of its own, ordered against the producers
+// and consumers with HIP events (the host threads only tell each other that an event has been recorded).  The exchange of
+// polynomial k runs while the rank-local transform of polynomial k + 1 does, like the RCCL form in parallel.py.
+// Device ids may repeat (several ranks on one GPU: how a one-GPU box tests this path; copies are then device-local).
+#include "r1cs.hpp"
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <chrono>
+#include <string.h>
+#include <stdlib.h>
+
+using namespace fk;
+
+struct fk_multi_key { std::vector<fk_key *> shard; };
+struct fk_multi_r1cs { std::vector<fk_r1cs_dev *> rep; };
+
+namespace fk {
+
+static constexpr int MX_EXCHANGES = 7;       // per proof: three ifft halves, two coset halves, icoset half, block-cyclic -> blocks
+
+struct MultiWorker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::function<int()> job;
+    bool has_job = false, quit = false, done = true;
+    int rc = FK_OK;
+};
+
+struct MultiRank {
+    hipStream_t xs = nullptr;                           // exchange stream: the pulls of this rank
+    hipEvent_t ev_ready[MX_EXCHANGES] = {nullptr};      // main stream: the source buffer of exchange e is complete
+    hipEvent_t ev_done[MX_EXCHANGES] = {nullptr};       // exchange stream: this rank's chunks of exchange e have arrived
+    std::atomic<uint64_t> posted{0};                    // sequence number of the latest ev_ready this rank has recorded
+    DevBuf send[3], recv[3];
+    uint64_t buf_elems = 0;
+    uint8_t part[FK_MSM_RESULT_BYTES];
+};
+
+}  // namespace fk
+
+struct fk_multi {
+    int n = 0;
+    uint32_t log_w = 0;
+    bool pow2 = false;
+    std::vector<int> dev;
+    std::vector<fk_ctx *> ctx;
+    std::deque<MultiWorker> workers;
+    std::deque<MultiRank> ranks;
+    std::string err;
+    std::atomic<int> abort{0};
+    uint64_t seq = 0;                                   // exchanges begun so far (same on every rank: they run the same schedule)
+    bool host_event_wait = false;                       // FK_MULTI_HOST_EVENTS=1: wait for a peer's event on the host instead of in the stream
+    // barrier of the rank threads
+    std::mutex bmu;
+    std::condition_variable bcv;
+    int bcount = 0;
+    uint64_t bgen = 0;
+    // pipelined proofs (submit / wait)
+    struct Pending { bool active = false; const fk_multi_key *key = nullptr; const fk_multi_r1cs *r1cs = nullptr; uint64_t r[4], s[4]; } pending[2];
+    int ticket_next = 0;
+};
+
+namespace fk {
+
+static void worker_main(fk_multi *M, int rank) {
+    MultiWorker &w = M->workers[rank];
+    (void)hipSetDevice(M->dev[rank]);
+    for (;;) {
+        std::function<int()> job;
+        {
+            std::unique_lock<std::mutex> lk(w.mu);
+            w.cv.wait(lk, [&] { return w.has_job || w.quit; });
+            if (w.quit) return;
+            job.swap(w.job);
+            w.has_job = false;
+        }
+        int rc = FK_ERR_HIP;
+        try { rc = job(); } catch (const std::bad_alloc &) { rc = FK_ERR_OOM; } catch (...) { rc = FK_ERR_HIP; }
+        if (rc != FK_OK) { M->abort.store(1); std::lock_guard<std::mutex> bl(M->bmu); M->bcv.notify_all(); }
+        {
+            std::lock_guard<std::mutex> lk(w.mu);
+            w.rc = rc; w.done = true;
+        }
+        w.cv.notify_all();
+    }
+}
+
+// runs fn(rank) on every rank's worker thread (serial = one rank after the other: ranks that share a GPU, host-memory-heavy
+// loaders) and returns the first failure, with that rank's error text
+static int run_all(fk_multi *M, const std::function<int(int)> &fn, bool serial = false) {
+    M->abort.store(0);
+    { std::lock_guard<std::mutex> bl(M->bmu); M->bcount = 0; }
+    auto start = [&](int r) {
+        MultiWorker &w = M->workers[r];
+        std::lock_guard<std::mutex> lk(w.mu);
+        w.job = [&fn, r] { return fn(r); };
+        w.has_job = true; w.done = false; w.rc = FK_OK;
+        w.cv.notify_all();
+    };
+    auto finish = [&](int r) {
+        MultiWorker &w = M->workers[r];
+        std::unique_lock<std::mutex> lk(w.mu);
+        w.cv.wait(lk, [&] { return w.done; });
+        return w.rc;
+    };
+    int rc = FK_OK, bad = -1;
+    if (serial) {
+        for (int r = 0; r < M->n && rc == FK_OK; r++) { start(r); rc = finish(r); if (rc != FK_OK) bad = r; }
+    } else {
+        for (int r = 0; r < M->n; r++) start(r);
+        for (int r = 0; r < M->n; r++) { const int x = finish(r); if (x != FK_OK && rc == FK_OK) { rc = x; bad = r; } }
+    }
+    if (rc != FK_OK) {
+        // the rank that failed first may be one that only gave up because another one had (abort): prefer a rank with a message
+        for (int r = 0; r < M->n; r++) if (M->workers[r].rc != FK_OK && !M->ctx[r]->err.empty() && M->ctx[r]->err.find("aborted") == std::string::npos) { bad = r; rc = M->workers[r].rc; break; }
+        char b[64]; snprintf(b, sizeof b, "rank %d (device %d): ", bad, bad >= 0 ? M->dev[bad] : -1);
+        M->err = std::string(b) + (bad >= 0 ? M->ctx[bad]->err : std::string());
+    }
+    return rc;
+}
+
+static int barrier(fk_multi *M, fk_ctx *ctx) {
+    std::unique_lock<std::mutex> lk(M->bmu);
+    const uint64_t gen = M->bgen;
+    if (++M->bcount == M->n) { M->bcount = 0; M->bgen++; M->bcv.notify_all(); return FK_OK; }
+    M->bcv.wait(lk, [&] { return M->bgen != gen || M->abort.load(); });
+    if (M->bgen == gen) { M->bcount--; FK_SET_ERR(ctx, FK_ERR_HIP, "aborted: another rank failed"); }
+    return FK_OK;
+}
+
+// ---- the all-to-all.  chunk p of this rank's dst <- chunk `rank` of rank p's src (what all_to_all_single does), `bytes` per chunk.
+// begin: records "src is ready" on the main stream, then queues the pulls on the exchange stream behind every peer's event;
+// end: the main stream waits for the pulls.  bufsel / k name the buffers (0 = send[k], 1 = recv[k]) so that a rank can find
+// its peers' addresses.
+static int xchg_begin(fk_multi *M, int rank, int e, int dst_sel, int src_sel, int k, size_t chunk_bytes, uint64_t seq) {
+    fk_ctx *ctx = M->ctx[rank];
+    MultiRank &me = M->ranks[rank];
+    FK_HIP(ctx, hipEventRecord(me.ev_ready[e], ctx->stream));
+    me.posted.store(seq, std::memory_order_release);
+    uint8_t *dst = (uint8_t *)(dst_sel ? me.recv[k].p : me.send[k].p);
+    for (int i = 0; i < M->n; i++) {
+        const int p = (rank + i) % M->n;             // start with the own chunk, then walk the peers in a rotated order (spreads the links)
+        MultiRank &peer = M->ranks[p];
+        while (peer.posted.load(std::memory_order_acquire) < seq) {
+            if (M->abort.load()) FK_SET_ERR(ctx, FK_ERR_HIP, "aborted: another rank failed");
+            std::this_thread::yield();
+        }
+        if (M->host_event_wait) FK_HIP(ctx, hipEventSynchronize(peer.ev_ready[e]));
+        else FK_HIP(ctx, hipStreamWaitEvent(me.xs, peer.ev_ready[e], 0));
+        const uint8_t *src = (const uint8_t *)(src_sel ? peer.recv[k].p : peer.send[k].p) + (size_t)rank * chunk_bytes;
+        if (M->dev[p] == M->dev[rank]) FK_HIP(ctx, hipMemcpyAsync(dst + (size_t)p * chunk_bytes, src, chunk_bytes, hipMemcpyDeviceToDevice, me.xs));
+        else FK_HIP(ctx, hipMemcpyPeerAsync(dst + (size_t)p * chunk_bytes, M->dev[rank], src, M->dev[p], chunk_bytes, me.xs));
+    }
+    FK_HIP(ctx, hipEventRecord(me.ev_done[e], me.xs));
+    return FK_OK;
+}
+static int xchg_end(fk_multi *M, int rank, int e) {
+    fk_ctx *ctx = M->ctx[rank];
+    FK_HIP(ctx, hipStreamWaitEvent(ctx->stream, M->ranks[rank].ev_done[e], 0));
+    return FK_OK;
+}
+
+// h = (A*B - C)/Z over the ranks; the cyclic slices of a, b, c are in send[0..2] (L = m / W elements each).  The order of
+// calls is parallel.py's quotient_distributed (six transforms: c is subtracted in coefficient space); returns with this rank's
+// block h[rank * L, (rank + 1) * L) queued into send[0].
+static int quotient_multi(fk_multi *M, int rank, uint32_t log_m, uint64_t seq0) {
+    fk_ctx *ctx = M->ctx[rank];
+    MultiRank &me = M->ranks[rank];
+    const uint32_t lw = M->log_w;
+    const size_t chunk = (sizeof(Fr) << (log_m - lw)) >> lw;
+    Fr *send[3], *recv[3];
+    for (int k = 0; k < 3; k++) { send[k] = me.send[k].as<Fr>(); recv[k] = me.recv[k].as<Fr>(); }
+    for (int k = 0; k < 3; k++) {                           // ifft, first half; its exchange starts at once
+        FK_TRY(dq_local(ctx, send[k], nullptr, nullptr, log_m, rank, lw, 0));
+        FK_TRY(xchg_begin(M, rank, k, 1, 0, k, chunk, seq0 + k + 1));
+    }
+    for (int k = 0; k < 2; k++) {                           // a, b: ifft second half, coset shift, coset_fft first half
+        FK_TRY(xchg_end(M, rank, k));
+        FK_TRY(dq_cross(ctx, recv[k], log_m, rank, lw, 0));
+        FK_TRY(xchg_begin(M, rank, 3 + k, 0, 1, k, chunk, seq0 + 4 + k));
+    }
+    FK_TRY(xchg_end(M, rank, 2));
+    FK_TRY(dq_cross(ctx, recv[2], log_m, rank, lw, 2));     // c: ifft second half * 1 / (m Z(g)); block-cyclic coefficients stay in recv[2]
+    for (int k = 1; k >= 0; k--) {                          // coset_fft, second half (b first: a is multiplied in place next)
+        FK_TRY(xchg_end(M, rank, 3 + k));
+        FK_TRY(dq_local(ctx, send[k], nullptr, nullptr, log_m, rank, lw, 1));
+    }
+    FK_TRY(dq_local(ctx, send[0], send[1], nullptr, log_m, rank, lw, 3));      // a*b, icoset_fft first half
+    FK_TRY(xchg_begin(M, rank, 5, 1, 0, 0, chunk, seq0 + 6));
+    FK_TRY(xchg_end(M, rank, 5));
+    FK_TRY(dq_cross(ctx, recv[0], log_m, rank, lw, 1, recv[2]));               // icoset_fft second half, / Z(g), - c's coefficients
+    FK_TRY(xchg_begin(M, rank, 6, 0, 1, 0, chunk, seq0 + 7));                  // block-cyclic -> blocks (the key's h sharding)
+    FK_TRY(xchg_end(M, rank, 6));
+    return FK_OK;
+}
+
+static bool overlap_witness(const fk_multi *M) {
+    // the witness multiplications do not need the quotient: begun first, they fill the GPU during the exchanges.  On one GPU
+    // the overlap measured neutral to slower; from four ranks on the per-rank transforms are short next to seven exchanges.
+    const char *e = getenv("FK_OVERLAP_WITNESS");
+    if (e && e[0]) return e[0] != '0';
+    return M->n >= 4;
+}
+
+// one rank's share of a proof; the witness is in this rank's slot `slot`
+static int prove_rank(fk_multi *M, int rank, const fk_multi_key *K, const fk_multi_r1cs *R, int slot, const uint64_t r_[4], const uint64_t s_[4],
+                      uint8_t out[FK_PROOF_BYTES], fk_timings *tm, uint64_t seq0) {
+    fk_ctx *ctx = M->ctx[rank];
+    MultiRank &me = M->ranks[rank];
+    const fk_key *key = K->shard[rank];
+    const fk_r1cs_dev *rs = R->rep[rank];
+    FK_HIP(ctx, hipSetDevice(ctx->device));
+    void *d_z = nullptr;
+    FK_TRY(fk_witness_ptr(ctx, slot, &d_z));
+    if (rs->num_input != key->num_input || rs->num_aux != key->num_aux) FK_SET_ERR(ctx, FK_ERR_KEY_MISMATCH, "prove: constraint system and key disagree on the variable counts");
+    const uint64_t rows = rs->num_gates + rs->num_input;
+    if (rows > key->m || (key->m > 1 && rows <= key->m / 2)) FK_SET_ERR(ctx, FK_ERR_KEY_MISMATCH, "prove: %llu rows do not match key domain %llu",
+                                                                     (unsigned long long)rows, (unsigned long long)key->m);
+    if (M->n == 1) return fk_prove_r1cs_dev(ctx, key, rs, d_z, r_, s_, out, tm);       // nothing to cut: the single-GPU prover
+    const uint32_t log_m = ceil_log2_u64(key->m);
+    uint8_t *part = me.part;
+    if (M->pow2 && log_m >= 2 * M->log_w) {
+        const uint64_t L = key->m >> M->log_w;
+        if (me.buf_elems < L) {
+            FK_HIP(ctx, hipStreamSynchronize(ctx->stream)); FK_HIP(ctx, hipStreamSynchronize(me.xs));
+            FK_TRY(barrier(M, ctx));              // nobody may still be pulling from the buffers that are about to move
+            for (int k = 0; k < 3; k++) { FK_HIP(ctx, me.send[k].reserve(L * sizeof(Fr))); FK_HIP(ctx, me.recv[k].reserve(L * sizeof(Fr))); }
+            me.buf_elems = L;
+            FK_TRY(barrier(M, ctx));
+        }
+        const bool ov = overlap_witness(M);
+        if (ov) FK_TRY(fk_prove_msms_z_begin_r1cs_dev(ctx, key, rs, d_z));
+        int rc = fk_r1cs_eval_slice_dev(ctx, rs, d_z, log_m, rank, M->log_w, me.send[0].p, me.send[1].p, me.send[2].p);
+        if (rc == FK_OK) rc = quotient_multi(M, rank, log_m, seq0);
+        if (rc != FK_OK) { if (ov) msm_abandon(ctx); return rc; }
+        if (ov) FK_TRY(fk_prove_msms_finish_dev(ctx, key, me.send[0].p, part));
+        else FK_TRY(fk_prove_msms_hz_r1cs_dev(ctx, key, rs, me.send[0].p, d_z, part));
+    } else {
+        // a rank count that is not a power of two (or a domain too small to cut): every rank computes the whole quotient and
+        // its slices of the five multiplications -- no exchange before the fold
+        const size_t mb = key->m * sizeof(Fr);
+        FK_HIP(ctx, ctx->stage_a.reserve(mb)); FK_HIP(ctx, ctx->stage_b.reserve(mb)); FK_HIP(ctx, ctx->stage_c.reserve(mb));
+        FK_TRY(fk_r1cs_eval_dev(ctx, rs, d_z, ctx->stage_a.p, ctx->stage_b.p, ctx->stage_c.p));
+        ctx->qidx = &rs->qidx;
+        const int rc = fk_prove_msms_dev(ctx, key, ctx->stage_a.p, ctx->stage_b.p, ctx->stage_c.p, rows, d_z, rs->d_a_aux, rs->d_b_in, rs->d_b_aux, part, nullptr);
+        ctx->qidx = nullptr;
+        FK_TRY(rc);
+    }
+    // "all-reduce of the partial sums": there is no elliptic-curve reduction operator to hand to a collective, so the N 384-byte
+    // records meet in host memory (they are host results already: the window sums are folded on the host) and rank 0 folds them
+    FK_TRY(barrier(M, ctx));
+    if (rank == 0) {
+        std::vector<uint8_t> parts((size_t)M->n * FK_MSM_RESULT_BYTES);
+        for (int g = 0; g < M->n; g++) memcpy(parts.data() + (size_t)g * FK_MSM_RESULT_BYTES, M->ranks[g].part, FK_MSM_RESULT_BYTES);
+        FK_TRY(fk_prove_assemble(ctx, key, parts.data(), (uint32_t)M->n, r_, s_, out));
+    }
+    (void)tm;
+    return FK_OK;
+}
+
+static int multi_check(fk_multi *M, const fk_multi_key *K, const fk_multi_r1cs *R) {
+    if (!K || !R || (int)K->shard.size() != M->n || (int)R->rep.size() != M->n) { M->err = "prove: key / constraint system were not loaded through this fk_multi"; return FK_ERR_BAD_ARG; }
+    return FK_OK;
+}
+
+}  // namespace fk
+
+extern "C" {
+
+int fk_init_devices(int n_devices, const int *device_ids, fk_multi **out) {
+    if (!out) return FK_ERR_BAD_ARG;
+    *out = nullptr;
+    if (n_devices < 1 || n_devices > 64 || !device_ids) return FK_ERR_BAD_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return FK_ERR_HIP;       // no GPU: fail loudly, no CPU fallback
+    for (int i = 0; i < n_devices; i++) if (device_ids[i] < 0 || device_ids[i] >= ndev) return FK_ERR_BAD_ARG;
+    fk_multi *M = new fk_multi();
+    M->n = n_devices;
+    M->dev.assign(device_ids, device_ids + n_devices);
+    M->pow2 = (n_devices & (n_devices - 1)) == 0 && n_devices <= 8;
+    while ((1 << M->log_w) < n_devices) M->log_w++;
+    { const char *e = getenv("FK_MULTI_HOST_EVENTS"); M->host_event_wait = e && e[0] && e[0] != '0'; }
+    int rc = FK_OK;
+    for (int i = 0; i < n_devices && rc == FK_OK; i++) {
+        fk_ctx *c = nullptr;
+        rc = fk_init(device_ids[i], &c);
+        if (rc == FK_OK) M->ctx.push_back(c);
+    }
+    // direct access between every pair of distinct devices (xGMI); "already enabled" is fine, a refusal leaves the copies staged by the runtime
+    for (int i = 0; i < n_devices && rc == FK_OK; i++)
+        for (int j = 0; j < n_devices; j++) {
+            if (device_ids[i] == device_ids[j]) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, device_ids[i], device_ids[j]) == hipSuccess && can) {
+                (void)hipSetDevice(device_ids[i]);
+                (void)hipDeviceEnablePeerAccess(device_ids[j], 0);
+                (void)hipGetLastError();
+            }
+        }
+    for (int i = 0; i < n_devices && rc == FK_OK; i++) {
+        M->ranks.emplace_back();
+        MultiRank &rk = M->ranks.back();
+        if (hipSetDevice(device_ids[i]) != hipSuccess || hipStreamCreateWithFlags(&rk.xs, hipStreamNonBlocking) != hipSuccess) { rc = FK_ERR_HIP; break; }
+        for (int e = 0; e < MX_EXCHANGES; e++)
+            if (hipEventCreateWithFlags(&rk.ev_ready[e], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&rk.ev_done[e], hipEventDisableTiming) != hipSuccess) rc = FK_ERR_HIP;
+    }
+    if (rc != FK_OK) {
+        for (fk_ctx *c : M->ctx) fk_free(c);
+        delete M;
+        return rc;
+    }
+    for (int i = 0; i < n_devices; i++) M->workers.emplace_back();
+    for (int i = 0; i < n_devices; i++) M->workers[i].th = std::thread(worker_main, M, i);
+    *out = M;
+    return FK_OK;
+}
+
+void fk_multi_free(fk_multi *M) {
+    if (!M) return;
+    for (auto &w : M->workers) {
+        { std::lock_guard<std::mutex> lk(w.mu); w.quit = true; }
+        w.cv.notify_all();
+        if (w.th.joinable()) w.th.join();
+    }
+    for (int i = 0; i < M->n; i++) {
+        MultiRank &rk = M->ranks[i];
+        (void)hipSetDevice(M->dev[i]);
+        (void)hipStreamSynchronize(M->ctx[i]->stream);
+        if (rk.xs) { (void)hipStreamSynchronize(rk.xs); (void)hipStreamDestroy(rk.xs); }
+        for (int e = 0; e < MX_EXCHANGES; e++) { if (rk.ev_ready[e]) (void)hipEventDestroy(rk.ev_ready[e]); if (rk.ev_done[e]) (void)hipEventDestroy(rk.ev_done[e]); }
+        for (int k = 0; k < 3; k++) { rk.send[k].release(); rk.recv[k].release(); }
+    }
+    for (fk_ctx *c : M->ctx) fk_free(c);
+    delete M;
+}
+
+const char *fk_multi_last_error(const fk_multi *M) { return M ? M->err.c_str() : "null multi-GPU context"; }
+int fk_multi_size(const fk_multi *M) { return M ? M->n : 0; }
+fk_ctx *fk_multi_ctx(fk_multi *M, int rank) { return (M && rank >= 0 && rank < M->n) ? M->ctx[rank] : nullptr; }
+
+static bool shares_device(const fk_multi *M) {
+    for (int i = 0; i < M->n; i++) for (int j = i + 1; j < M->n; j++) if (M->dev[i] == M->dev[j]) return true;
+    return false;
+}
+
+// ---------------------------------------------------------------- keys: shard g of N on rank g
+int fk_multi_key_load(fk_multi *M, const fk_key_desc *desc, fk_multi_key **out) {
+    if (!M || !out) return FK_ERR_BAD_ARG;
+    *out = nullptr;
+    if (!desc) { M->err = "key: null descriptor"; return FK_ERR_BAD_ARG; }
+    fk_multi_key *K = new fk_multi_key();
+    K->shard.assign(M->n, nullptr);
+    const int rc = run_all(M, [&](int r) {
+        fk_key_desc d = *desc;
+        d.shard_index = (uint32_t)r; d.shard_count = (uint32_t)M->n; d.z_frac_lo = FK_Z_EQUAL_SPLIT; d.z_frac_hi = 0;
+        return fk_key_load(M->ctx[r], &d, &K->shard[r]);
+    }, shares_device(M));
+    if (rc != FK_OK) { fk_multi_key_free(M, K); return rc; }
+    *out = K;
+    return FK_OK;
+}
+
+int fk_multi_key_load_bellman(fk_multi *M, const uint8_t *buf, size_t len, uint32_t flags, fk_multi_key **out, uint8_t *gamma_g2_out,
+                              uint8_t *ic_out, uint32_t ic_cap, uint32_t *n_ic) {
+    if (!M || !out) return FK_ERR_BAD_ARG;
+    *out = nullptr;
+    fk_multi_key *K = new fk_multi_key();
+    K->shard.assign(M->n, nullptr);
+    const int rc = run_all(M, [&](int r) {
+        uint32_t nic = 0;
+        const int x = fk_key_load_bellman(M->ctx[r], buf, len, flags, (uint32_t)r, (uint32_t)M->n, FK_Z_EQUAL_SPLIT, 0, &K->shard[r],
+                                          r == 0 ? gamma_g2_out : nullptr, r == 0 ? ic_out : nullptr, r == 0 ? ic_cap : 0, &nic);
+        if (r == 0 && n_ic) *n_ic = nic;
+        return x;
+    }, shares_device(M));
+    if (rc != FK_OK) { fk_multi_key_free(M, K); return rc; }
+    *out = K;
+    return FK_OK;
+}
+
+static int multi_setup(fk_multi *M, const fk_r1cs *cs, uint32_t copies, const uint64_t tau[4], const uint64_t alpha[4], const uint64_t beta[4],
+                       const uint64_t gamma[4], const uint64_t delta[4], fk_multi_key **out, uint8_t vk_out[6 * 128], uint8_t *ic_out) {
+    if (!M || !out) return FK_ERR_BAD_ARG;
+    *out = nullptr;
+    if (!cs || !vk_out || !ic_out) { M->err = "setup: null argument"; return FK_ERR_BAD_ARG; }
+    fk_multi_key *K = new fk_multi_key();
+    K->shard.assign(M->n, nullptr);
+    const size_t n_ic = copies ? 1 + (size_t)copies * (cs->num_input - 1) : cs->num_input;
+    const int rc = run_all(M, [&](int r) {
+        // every rank derives ONLY its shard of the five arrays (setup.hip); the verifying key comes out of each derivation, rank 0's is returned
+        std::vector<uint8_t> vk_tmp, ic_tmp;
+        uint8_t *vk = vk_out, *ic = ic_out;
+        if (r != 0) { vk_tmp.resize(6 * 128); ic_tmp.resize(n_ic * 64 + 64); vk = vk_tmp.data(); ic = ic_tmp.data(); }
+        if (copies) return fk_setup_tiled(M->ctx[r], cs, copies, tau, alpha, beta, gamma, delta, (uint32_t)r, (uint32_t)M->n, FK_Z_EQUAL_SPLIT, 0, &K->shard[r], vk, ic);
+        return fk_setup(M->ctx[r], cs, tau, alpha, beta, gamma, delta, (uint32_t)r, (uint32_t)M->n, FK_Z_EQUAL_SPLIT, 0, &K->shard[r], vk, ic);
+    }, shares_device(M));
+    if (rc != FK_OK) { fk_multi_key_free(M, K); return rc; }
+    *out = K;
+    return FK_OK;
+}
+int fk_multi_setup(fk_multi *M, const fk_r1cs *cs, const uint64_t tau[4], const uint64_t alpha[4], const uint64_t beta[4], const uint64_t gamma[4],
+                   const uint64_t delta[4], fk_multi_key **out, uint8_t vk_out[6 * 128], uint8_t *ic_out) {
+    return multi_setup(M, cs, 0, tau, alpha, beta, gamma, delta, out, vk_out, ic_out);
+}
+int fk_multi_setup_tiled(fk_multi *M, const fk_r1cs *instance, uint32_t copies, const uint64_t tau[4], const uint64_t alpha[4], const uint64_t beta[4],
+                         const uint64_t gamma[4], const uint64_t delta[4], fk_multi_key **out, uint8_t vk_out[6 * 128], uint8_t *ic_out) {
+    if (M && !copies) { M->err = "setup: copies must be at least 1"; return FK_ERR_BAD_ARG; }
+    return multi_setup(M, instance, copies, tau, alpha, beta, gamma, delta, out, vk_out, ic_out);
+}
+
+void fk_multi_key_free(fk_multi *M, fk_multi_key *K) {
+    if (!K) return;
+    for (size_t r = 0; r < K->shard.size(); r++) if (K->shard[r]) fk_key_free(M && r < M->ctx.size() ? M->ctx[r] : nullptr, K->shard[r]);
+    delete K;
+}
+const fk_key *fk_multi_key_shard(const fk_multi_key *K, int rank) { return (K && rank >= 0 && rank < (int)K->shard.size()) ? K->shard[rank] : nullptr; }
+
+// ---------------------------------------------------------------- constraint system: one replica per GPU
+static int multi_r1cs(fk_multi *M, fk_multi_r1cs **out, const std::function<int(int, fk_r1cs_dev **)> &load) {
+    if (!M || !out) return FK_ERR_BAD_ARG;
+    *out = nullptr;
+    fk_multi_r1cs *R = new fk_multi_r1cs();
+    R->rep.assign(M->n, nullptr);
+    const int rc = run_all(M, [&](int r) { return load(r, &R->rep[r]); }, true);      // one after the other: each load builds host-side tables
+    if (rc != FK_OK) { fk_multi_r1cs_free(M, R); return rc; }
+    *out = R;
+    return FK_OK;
+}
+int fk_multi_r1cs_load(fk_multi *M, const fk_r1cs *cs, fk_multi_r1cs **out) {
+    return multi_r1cs(M, out, [&](int r, fk_r1cs_dev **o) { return fk_r1cs_load(M->ctx[r], cs, o); });
+}
+int fk_multi_r1cs_load_tiled(fk_multi *M, const fk_r1cs *instance, uint32_t copies, fk_multi_r1cs **out) {
+    return multi_r1cs(M, out, [&](int r, fk_r1cs_dev **o) { return fk_r1cs_load_tiled(M->ctx[r], instance, copies, o); });
+}
+int fk_multi_r1cs_load_gates(fk_multi *M, const fk_gates *gates, fk_multi_r1cs **out) {
+    return multi_r1cs(M, out, [&](int r, fk_r1cs_dev **o) { return fk_r1cs_load_gates(M->ctx[r], gates, o); });
+}
+void fk_multi_r1cs_free(fk_multi *M, fk_multi_r1cs *R) {
+    if (!R) return;
+    for (size_t r = 0; r < R->rep.size(); r++) if (R->rep[r]) fk_r1cs_free(M && r < M->ctx.size() ? M->ctx[r] : nullptr, R->rep[r]);
+    delete R;
+}
+const fk_r1cs_dev *fk_multi_r1cs_replica(const fk_multi_r1cs *R, int rank) { return (R && rank >= 0 && rank < (int)R->rep.size()) ? R->rep[rank] : nullptr; }
+
+// ---------------------------------------------------------------- the prover: witness in (host memory) -> 256-byte proof out
+// Every rank uploads the witness over its own PCIe link into one of its two slots (the evaluation of a, b, c reads all of z
+// for a cyclic row slice, and the L / A / B slices are gathered from it).
+static int multi_upload(fk_multi *M, int slot, const uint64_t *z, size_t bytes) {
+    for (int r = 0; r < M->n; r++) {
+        const int rc = fk_witness_upload_async(M->ctx[r], slot, z, bytes);
+        if (rc != FK_OK) { char b[48]; snprintf(b, sizeof b, "rank %d: ", r); M->err = std::string(b) + M->ctx[r]->err; return rc; }
+    }
+    return FK_OK;
+}
+
+static int multi_prove_slot(fk_multi *M, const fk_multi_key *K, const fk_multi_r1cs *R, int slot, const uint64_t r_[4], const uint64_t s_[4],
+                            uint8_t out[FK_PROOF_BYTES], fk_timings *tm) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const uint64_t seq0 = M->seq;
+    M->seq += MX_EXCHANGES;
+    if (tm) memset(tm, 0, sizeof *tm);
+    const int rc = run_all(M, [&](int r) { return prove_rank(M, r, K, R, slot, r_, s_, out, tm, seq0); });
+    if (rc != FK_OK) {
+        // leave every rank in a state from which the next call can start: nothing queued, no multiplication outstanding
+        for (int r = 0; r < M->n; r++) { (void)hipSetDevice(M->dev[r]); msm_abandon(M->ctx[r]); M->ctx[r]->qidx = nullptr; (void)hipStreamSynchronize(M->ctx[r]->stream); (void)hipStreamSynchronize(M->ranks[r].xs); }
+        for (auto &rk : M->ranks) rk.posted.store(M->seq);
+        return rc;
+    }
+    if (tm) tm->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return FK_OK;
+}
+
+int fk_multi_prove_r1cs(fk_multi *M, const fk_multi_key *K, const fk_multi_r1cs *R, const uint64_t *z, const uint64_t r_[4], const uint64_t s_[4],
+                        uint8_t out[FK_PROOF_BYTES], fk_timings *tm) {
+    if (!M) return FK_ERR_BAD_ARG;
+    if (!z || !r_ || !s_ || !out) { M->err = "prove: null argument"; return FK_ERR_BAD_ARG; }
+    if (M->pending[0].active || M->pending[1].active) { M->err = "prove: submitted proofs are outstanding (call fk_multi_prove_r1cs_wait first)"; return FK_ERR_BAD_ARG; }
+    FK_TRY(multi_check(M, K, R));
+    const size_t zb = ((size_t)R->rep[0]->num_input + R->rep[0]->num_aux) * sizeof(Fr);
+    FK_TRY(multi_upload(M, 0, z, zb));
+    return multi_prove_slot(M, K, R, 0, r_, s_, out, tm);
+}
+
+int fk_multi_prove_r1cs_submit(fk_multi *M, const fk_multi_key *K, const fk_multi_r1cs *R, const uint64_t *z, const uint64_t r_[4], const uint64_t s_[4], int *ticket) {
+    if (!M) return FK_ERR_BAD_ARG;
+    if (!z || !r_ || !s_ || !ticket) { M->err = "prove: null argument"; return FK_ERR_BAD_ARG; }
+    FK_TRY(multi_check(M, K, R));
+    const int slot = M->ticket_next;
+    if (M->pending[slot].active) { M->err = "prove: two proofs are already submitted (call fk_multi_prove_r1cs_wait first)"; return FK_ERR_BAD_ARG; }
+    const size_t zb = ((size_t)R->rep[0]->num_input + R->rep[0]->num_aux) * sizeof(Fr);
+    FK_TRY(multi_upload(M, slot, z, zb));
+    fk_multi::Pending &p = M->pending[slot];
+    p.active = true; p.key = K; p.r1cs = R; memcpy(p.r, r_, 32); memcpy(p.s, s_, 32);
+    M->ticket_next = slot ^ 1;
+    *ticket = slot;
+    return FK_OK;
+}
+
+int fk_multi_prove_r1cs_wait(fk_multi *M, int ticket, uint8_t out[FK_PROOF_BYTES], fk_timings *tm) {
+    if (!M) return FK_ERR_BAD_ARG;
+    if (ticket < 0 || ticket > 1 || !M->pending[ticket].active || !out) { M->err = "prove: no submitted proof with this ticket"; return FK_ERR_BAD_ARG; }
+    fk_multi::Pending &p = M->pending[ticket];
+    p.active = false;
+    return multi_prove_slot(M, p.key, p.r1cs, ticket, p.r, p.s, out, tm);
+}
+
+// waits for everything queued on every rank
+int fk_multi_sync(fk_multi *M) {
+    if (!M) return FK_ERR_BAD_ARG;
+    for (int r = 0; r < M->n; r++) {
+        const int rc = fk_sync(M->ctx[r]);
+        if (rc != FK_OK) { M->err = M->ctx[r]->err; return rc; }
+        (void)hipStreamSynchronize(M->ranks[r].xs);
+    }
+    return FK_OK;
+}
+
+}  // extern "C"

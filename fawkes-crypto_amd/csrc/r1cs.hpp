@@ -1,0 +1,52 @@
+// The device-resident constraint system (spmv.hip builds and evaluates it; multi.hip keeps one replica per GPU).
+#pragma once
+#include "common.hpp"
+#include <mutex>
+
+namespace fk {
+// launch plan of spmv_binned_kernel: up to 3 length classes for each of the 3 matrices
+struct BinArgs {
+    uint32_t nseg = 0, mask = 0;            // mask: bit k = matrix k is binned
+    uint32_t first_block[10] = {0}, lg[9] = {0}, mtx[9] = {0}, n_rows[9] = {0}, list_off[9] = {0};
+    const uint32_t *rowlist[3] = {nullptr, nullptr, nullptr};
+};
+// Cyclic row slices (multi-GPU: rank g of W = 2^log_w evaluates only the rows t = g (mod W), the slice the distributed
+// quotient starts from).  The length-class lists are kept a second time per log_w with every class grouped by row mod W
+// (inside a group still longest first), so that a rank's rows of a class are one contiguous run per copy; which residue a
+// copy needs depends on the copy (row t = copy * base_gates + row), with period P = W / gcd(base_gates, W) copies.
+struct SliceLists {
+    uint32_t *d_list[3] = {nullptr, nullptr, nullptr};    // per matrix, same length and class boundaries as rowlist
+    uint32_t cnt[9][8] = {{0}}, offs[9][8] = {{0}};       // per segment: rows of each residue / their first position in the class
+    bool built = false;
+};
+struct SliceArgs {
+    uint32_t log_w = 0, rank = 0, P = 1;
+    uint32_t rho[8] = {0};                 // residue copy q*P + p needs
+    uint32_t T[9] = {0};                   // groups of one period of copies, per segment
+    uint32_t cnt[9][8] = {{0}}, offs[9][8] = {{0}};
+};
+}  // namespace fk
+
+struct fk_r1cs_dev {
+    uint32_t num_input = 0, num_aux = 0;
+    uint64_t num_gates = 0;
+    uint64_t *ptr[3] = {nullptr, nullptr, nullptr};
+    uint32_t *col[3] = {nullptr, nullptr, nullptr};
+    uint32_t *cidx[3] = {nullptr, nullptr, nullptr};
+    fk::Fr *table = nullptr;
+    uint64_t n_table = 0, nnz[3] = {0, 0, 0};
+    uint8_t *d_a_aux = nullptr, *d_b_in = nullptr, *d_b_aux = nullptr;
+    uint64_t n_a_aux = 0, n_b_in = 0, n_b_aux = 0;   // popcounts
+    uint32_t *d_idx_a = nullptr, *d_idx_b = nullptr; // variables of the A / B query in query order
+    fk::QueryIdx qidx;
+    // tiled system (fk_r1cs_load_tiled): the CSR above is ONE instance (base_gates rows, base_input / base_aux variables)
+    // and stands for `copies` of it; num_input / num_aux / num_gates / nnz are the totals
+    uint32_t copies = 1, base_input = 0, base_aux = 0, base_gates = 0;
+    // matrices with long rows: the (instance's) rows in classes by length, sorted by length inside a class (see spmv_binned_kernel)
+    uint32_t *rowlist[3] = {nullptr, nullptr, nullptr};
+    fk::BinArgs bins;
+    // host copies of the class lists and the per-log_w residue-grouped variants, built on first use (fk_r1cs_eval_slice_dev)
+    std::vector<uint32_t> h_rowlist[3];
+    mutable fk::SliceLists slices[4];
+    mutable std::mutex slice_mu;
+};

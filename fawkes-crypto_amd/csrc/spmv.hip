@@ -19,34 +19,7 @@
 #include <unordered_map>
 #include <string>
 
-namespace fk {
-// launch plan of spmv_binned_kernel: up to 3 length classes for each of the 3 matrices
-struct BinArgs {
-    uint32_t nseg = 0, mask = 0;            // mask: bit k = matrix k is binned
-    uint32_t first_block[10] = {0}, lg[9] = {0}, mtx[9] = {0}, n_rows[9] = {0}, list_off[9] = {0};
-    const uint32_t *rowlist[3] = {nullptr, nullptr, nullptr};
-};
-}  // namespace fk
-
-struct fk_r1cs_dev {
-    uint32_t num_input = 0, num_aux = 0;
-    uint64_t num_gates = 0;
-    uint64_t *ptr[3] = {nullptr, nullptr, nullptr};
-    uint32_t *col[3] = {nullptr, nullptr, nullptr};
-    uint32_t *cidx[3] = {nullptr, nullptr, nullptr};
-    fk::Fr *table = nullptr;
-    uint64_t n_table = 0, nnz[3] = {0, 0, 0};
-    uint8_t *d_a_aux = nullptr, *d_b_in = nullptr, *d_b_aux = nullptr;
-    uint64_t n_a_aux = 0, n_b_in = 0, n_b_aux = 0;   // popcounts
-    uint32_t *d_idx_a = nullptr, *d_idx_b = nullptr; // variables of the A / B query in query order
-    fk::QueryIdx qidx;
-    // tiled system (fk_r1cs_load_tiled): the CSR above is ONE instance (base_gates rows, base_input / base_aux variables)
-    // and stands for `copies` of it; num_input / num_aux / num_gates / nnz are the totals
-    uint32_t copies = 1, base_input = 0, base_aux = 0, base_gates = 0;
-    // matrices with long rows: the (instance's) rows in classes by length, sorted by length inside a class (see spmv_binned_kernel)
-    uint32_t *rowlist[3] = {nullptr, nullptr, nullptr};
-    fk::BinArgs bins;
-};
+#include "r1cs.hpp"
 
 namespace fk {
 
@@ -66,12 +39,14 @@ struct SpmvArgs {
 // layout of a circuit that allocates the same gadget `copies` times), so a 4096-signature batch costs the memory of one.
 struct TileDims { uint32_t base_gates, base_input, base_aux; };
 // binned: bit k set = matrix k's gate rows belong to spmv_binned_kernel; this kernel then only writes the rows behind them
-template <bool TILED>
+// SLICED: lane group tl evaluates row t = rank + W * tl and writes out[tl] (the cyclic slice of rank `rank` of W = 2^log_w)
+template <bool TILED, bool SLICED>
 __global__ __launch_bounds__(256) void spmv_kernel(SpmvArgs a, const Fr *table, const Fr *z, uint64_t num_gates, uint32_t num_input, uint32_t lg0, uint32_t lg1,
-                                                   uint32_t lg2, TileDims td, uint32_t binned) {
+                                                   uint32_t lg2, TileDims td, uint32_t binned, uint32_t log_w, uint32_t rank) {
     const uint32_t mtx = blockIdx.y;
     const uint32_t lg = mtx == 0 ? lg0 : (mtx == 1 ? lg1 : lg2);
-    const uint64_t t = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> lg;
+    const uint64_t tl = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> lg;
+    const uint64_t t = SLICED ? rank + (tl << log_w) : tl;
     const uint32_t sub = threadIdx.x & ((1u << lg) - 1);
     const uint64_t rows = num_gates + num_input;
     if (t >= rows) return;                   // the lanes of a row group leave together (256 is a multiple of G)
@@ -99,7 +74,7 @@ __global__ __launch_bounds__(256) void spmv_kernel(SpmvArgs a, const Fr *table, 
         for (int i = 0; i < 8; i++) o.v[i] = (uint32_t)__shfl_down((int)acc.v[i], off, 64);
         acc = Fr::add(acc, o);
     }
-    if (sub == 0) a.out[mtx][t] = acc;
+    if (sub == 0) a.out[mtx][tl] = acc;
 }
 
 // Circuits built from Poseidon are bimodal: three quarters of the eddsa verifier's rows hold ONE term, the rest 128-512 (the
@@ -108,16 +83,29 @@ __global__ __launch_bounds__(256) void spmv_kernel(SpmvArgs a, const Fr *table, 
 // their own group size (1, 4 or 16 lanes per row) and sorted by length inside a class, so that the rows sharing a wave
 // have (nearly) the same length; long rows take two terms per step through the dual-chain multiplier.  Segment s of the
 // launch is one (matrix, class); a tiled system walks its copies in the outer order, so a copy's z stays in cache.
-template <bool TILED>
-__global__ __launch_bounds__(256) void spmv_binned_kernel(SpmvArgs a, BinArgs b, const Fr *table, const Fr *z, uint32_t num_input, TileDims td, uint32_t copies) {
+// SLICED (b.rowlist = the residue-grouped lists, b.first_block = this rank's plan): group index -> (copy, position in the
+// residue group that copy needs); the row's result goes to out[(copy * base_gates + row) >> log_w].
+template <bool TILED, bool SLICED>
+__global__ __launch_bounds__(256) void spmv_binned_kernel(SpmvArgs a, BinArgs b, const Fr *table, const Fr *z, uint32_t num_input, TileDims td, uint32_t copies, SliceArgs sl) {
     uint32_t s = 0;
     while (s + 1 < b.nseg && blockIdx.x >= b.first_block[s + 1]) s++;
     const uint32_t lg = b.lg[s], mtx = b.mtx[s], nr = b.n_rows[s];
     const uint64_t gidx = (uint64_t)(blockIdx.x - b.first_block[s]) * (256u >> lg) + (threadIdx.x >> lg);
     const uint32_t sub = threadIdx.x & ((1u << lg) - 1);
-    if (gidx >= (uint64_t)nr * copies) return;
     uint32_t copy = 0, li = (uint32_t)gidx;
-    if (TILED) { copy = (uint32_t)(gidx / nr); li = (uint32_t)(gidx - (uint64_t)copy * nr); }
+    if (SLICED) {
+        const uint32_t T = sl.T[s];
+        const uint64_t q = gidx / T;
+        uint32_t rem = (uint32_t)(gidx - q * T), pp = 0;
+        while (pp + 1 < sl.P && rem >= sl.cnt[s][sl.rho[pp]]) { rem -= sl.cnt[s][sl.rho[pp]]; pp++; }
+        const uint64_t cp = q * sl.P + pp;
+        if (cp >= copies || rem >= sl.cnt[s][sl.rho[pp]]) return;
+        copy = (uint32_t)cp;
+        li = sl.offs[s][sl.rho[pp]] + rem;
+    } else {
+        if (gidx >= (uint64_t)nr * copies) return;
+        if (TILED) { copy = (uint32_t)(gidx / nr); li = (uint32_t)(gidx - (uint64_t)copy * nr); }
+    }
     const uint32_t row = b.rowlist[mtx][b.list_off[s] + li];
     const uint32_t in_off = copy * (td.base_input - 1), aux_off = num_input + copy * td.base_aux - td.base_input;
     const uint64_t *ptr = a.ptr[mtx]; const uint32_t *col = a.col[mtx]; const uint32_t *cidx = a.cidx[mtx];
@@ -155,7 +143,7 @@ __global__ __launch_bounds__(256) void spmv_binned_kernel(SpmvArgs a, BinArgs b,
         for (int i = 0; i < 8; i++) o.v[i] = (uint32_t)__shfl_down((int)acc.v[i], off, 64);
         acc = Fr::add(acc, o);
     }
-    if (sub == 0) a.out[mtx][(uint64_t)copy * td.base_gates + row] = acc;
+    if (sub == 0) a.out[mtx][((uint64_t)copy * td.base_gates + row) >> (SLICED ? sl.log_w : 0)] = acc;
 }
 
 }  // namespace fk
@@ -169,6 +157,7 @@ void fk_r1cs_free(fk_ctx *ctx, fk_r1cs_dev *r) {
     if (ctx) (void)hipSetDevice(ctx->device);
     for (int k = 0; k < 3; k++) { if (r->ptr[k]) (void)hipFree(r->ptr[k]); if (r->col[k]) (void)hipFree(r->col[k]); if (r->cidx[k]) (void)hipFree(r->cidx[k]); if (r->rowlist[k]) (void)hipFree(r->rowlist[k]); }
     for (void *p : {(void *)r->table, (void *)r->d_a_aux, (void *)r->d_b_in, (void *)r->d_b_aux, (void *)r->d_idx_a, (void *)r->d_idx_b}) if (p) (void)hipFree(p);
+    for (auto &sl : r->slices) for (uint32_t *p : sl.d_list) if (p) (void)hipFree(p);
     delete r;
 }
 
@@ -262,6 +251,7 @@ static int r1cs_load_impl(fk_ctx *ctx, const fk_r1cs *cs, uint32_t copies, fk_r1
             const uint32_t n16 = cnt[CAP - 32], n4 = cnt[CAP - 4] - n16, n1 = ng - n16 - n4;     // cnt[i] is now the END of key CAP - i
             if (hipMalloc((void **)&r->rowlist[k], (size_t)ng * 4) != hipSuccess) { ctx->err = "r1cs: device allocation failed"; return fail(FK_ERR_OOM); }
             if (hipMemcpy(r->rowlist[k], list.data(), (size_t)ng * 4, hipMemcpyHostToDevice) != hipSuccess) rc = FK_ERR_HIP;
+            r->h_rowlist[k] = list;
             BinArgs &b = r->bins;
             b.rowlist[k] = r->rowlist[k]; b.mask |= 1u << k;
             const uint32_t cls_n[3] = {n16, n4, n1}, cls_lg[3] = {4, 2, 0};
@@ -344,15 +334,50 @@ int fk_r1cs_info(const fk_r1cs_dev *r, uint64_t out[8]) {
     return FK_OK;
 }
 
-// a, b, c: device arrays with room for next_pow2(rows) elements each (fk_prove_dev's contract); rows written.
-int fk_r1cs_eval_dev(fk_ctx *ctx, const fk_r1cs_dev *r, const void *d_z, void *d_a, void *d_b, void *d_c) {
-    if (!ctx) return FK_ERR_BAD_ARG;
-    if (!r || !d_z || !d_a || !d_b || !d_c) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "r1cs eval: null argument");
+}  // extern "C"
+namespace fk {
+// The per-log_w residue-grouped class lists of a constraint system with binned matrices (see SliceLists), built on first use.
+static int slice_lists(fk_ctx *ctx, const fk_r1cs_dev *r, uint32_t log_w, const SliceLists **out) {
+    std::lock_guard<std::mutex> lock(r->slice_mu);
+    SliceLists &sl = r->slices[log_w];
+    if (!sl.built) {
+        const uint32_t W = 1u << log_w;
+        for (int k = 0; k < 3; k++) {
+            if (!((r->bins.mask >> k) & 1)) continue;
+            const std::vector<uint32_t> &src = r->h_rowlist[k];
+            std::vector<uint32_t> dst(src.size());
+            for (uint32_t s = 0; s < r->bins.nseg; s++) {
+                if (r->bins.mtx[s] != (uint32_t)k) continue;
+                const uint32_t off = r->bins.list_off[s], nr = r->bins.n_rows[s];
+                uint32_t c[8] = {0};
+                for (uint32_t i = 0; i < nr; i++) c[src[off + i] & (W - 1)]++;
+                uint32_t pos[8], acc = 0;
+                for (uint32_t q = 0; q < W; q++) { sl.cnt[s][q] = c[q]; sl.offs[s][q] = acc; pos[q] = acc; acc += c[q]; }
+                for (uint32_t i = 0; i < nr; i++) { const uint32_t row = src[off + i]; dst[off + pos[row & (W - 1)]++] = row; }   // stable: longest first inside a group
+            }
+            FK_HIP(ctx, hipMalloc((void **)&sl.d_list[k], dst.size() * 4 + 4));
+            if (!dst.empty()) FK_HIP(ctx, hipMemcpy(sl.d_list[k], dst.data(), dst.size() * 4, hipMemcpyHostToDevice));
+        }
+        sl.built = true;
+    }
+    *out = &sl;
+    return FK_OK;
+}
+
+// a, b, c <- the rows t = rank (mod 2^log_w) of A z, B z, C z, densely: out[j] = row rank + j * 2^log_w (sliced), or all rows
+// (not sliced: rank = log_w = 0).  n_out: elements the caller's arrays hold; those behind the last row are zeroed when sliced.
+int r1cs_eval_impl(fk_ctx *ctx, const fk_r1cs_dev *r, const void *d_z, void *d_a, void *d_b, void *d_c, bool sliced, uint32_t rank, uint32_t log_w, uint64_t n_out) {
     FK_HIP(ctx, hipSetDevice(ctx->device));
     SpmvArgs a;
     for (int k = 0; k < 3; k++) { a.ptr[k] = r->ptr[k]; a.col[k] = r->col[k]; a.cidx[k] = r->cidx[k]; }
     a.out[0] = (Fr *)d_a; a.out[1] = (Fr *)d_b; a.out[2] = (Fr *)d_c;
     const uint64_t rows = r->num_gates + r->num_input;
+    const uint64_t W = (uint64_t)1 << log_w;
+    const uint64_t my_rows = sliced ? (rows > rank ? (rows - rank + W - 1) / W : 0) : rows;      // row groups this launch evaluates
+    if (sliced) {
+        if (my_rows > n_out) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "r1cs eval: the slice holds %llu rows, the arrays %llu", (unsigned long long)my_rows, (unsigned long long)n_out);
+        if (n_out > my_rows) for (int k = 0; k < 3; k++) FK_HIP(ctx, hipMemsetAsync(a.out[k] + my_rows, 0, (n_out - my_rows) * sizeof(Fr), ctx->stream));
+    }
     // lanes per row: half of the matrix's mean row length, rounded down to a power of two (1 .. 64); measured on the eddsa batch: 16 / 8 / 4 / 2 / 1 terms per lane -> 1.51 / 1.27 / 1.16 / 1.02 / 0.97 ms
     uint32_t lg[3], lgmax = 0;
     static int t_div = -1;
@@ -363,23 +388,76 @@ int fk_r1cs_eval_dev(fk_ctx *ctx, const fk_r1cs_dev *r, const void *d_z, void *d
         while (!((r->bins.mask >> k) & 1) && lg[k] < 6 && ((uint64_t)t_div << lg[k]) <= mean) lg[k]++;
         if (lg[k] > lgmax) lgmax = lg[k];
     }
-    const uint64_t lanes = rows << lgmax;
+    const uint64_t lanes = my_rows << lgmax;
     const TileDims td{r->base_gates, r->base_input, r->base_aux};
     const uint32_t binned = r->bins.mask;
-    if (r->copies > 1)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_kernel<true>), dim3((unsigned)((lanes + 255) / 256), 3), dim3(256), 0, ctx->stream, a, r->table, (const Fr *)d_z, r->num_gates,
-                           r->num_input, lg[0], lg[1], lg[2], td, binned);
-    else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_kernel<false>), dim3((unsigned)((lanes + 255) / 256), 3), dim3(256), 0, ctx->stream, a, r->table, (const Fr *)d_z, r->num_gates,
-                           r->num_input, lg[0], lg[1], lg[2], td, binned);
+    const dim3 grid((unsigned)((lanes + 255) / 256), 3), block(256);
+    const bool tiled = r->copies > 1;
+    if (lanes) {
+#define FK_SPMV_LAUNCH(T_, S_) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_kernel<T_, S_>), grid, block, 0, ctx->stream, a, r->table, (const Fr *)d_z, r->num_gates, \
+                                                  r->num_input, lg[0], lg[1], lg[2], td, binned, log_w, rank)
+        if (tiled) { if (sliced) FK_SPMV_LAUNCH(true, true); else FK_SPMV_LAUNCH(true, false); }
+        else { if (sliced) FK_SPMV_LAUNCH(false, true); else FK_SPMV_LAUNCH(false, false); }
+#undef FK_SPMV_LAUNCH
+    }
     if (binned) {
-        const unsigned blocks = r->bins.first_block[r->bins.nseg];
-        if (r->copies > 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_binned_kernel<true>), dim3(blocks), dim3(256), 0, ctx->stream, a, r->bins, r->table, (const Fr *)d_z, r->num_input, td, r->copies);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_binned_kernel<false>), dim3(blocks), dim3(256), 0, ctx->stream, a, r->bins, r->table, (const Fr *)d_z, r->num_input, td, r->copies);
+        BinArgs b = r->bins;
+        SliceArgs sa;
+        if (sliced) {
+            // this rank's plan: copy c needs the rows = rank - c * base_gates (mod W); the residues repeat every P copies
+            const SliceLists *sl = nullptr;
+            FK_TRY(slice_lists(ctx, r, log_w, &sl));
+            sa.log_w = log_w; sa.rank = rank;
+            const uint32_t g = (uint32_t)(r->base_gates & (W - 1));
+            uint32_t P = 1;
+            while ((uint32_t)((uint64_t)P * g) & (W - 1)) P++;
+            sa.P = P;
+            for (uint32_t p_ = 0; p_ < P; p_++) sa.rho[p_] = (uint32_t)((rank + W * P - ((uint64_t)p_ * g & (W - 1))) & (W - 1));
+            b.first_block[0] = 0;
+            for (uint32_t s = 0; s < b.nseg; s++) {
+                memcpy(sa.cnt[s], sl->cnt[s], sizeof sa.cnt[s]); memcpy(sa.offs[s], sl->offs[s], sizeof sa.offs[s]);
+                uint64_t T = 0, part = 0;
+                const uint32_t tail = r->copies % P;
+                for (uint32_t p_ = 0; p_ < P; p_++) { T += sa.cnt[s][sa.rho[p_]]; if (p_ < tail) part += sa.cnt[s][sa.rho[p_]]; }
+                sa.T[s] = (uint32_t)T;
+                const uint64_t groups = (uint64_t)(r->copies / P) * T + part, per = 256u >> b.lg[s], blocks = (groups + per - 1) / per;
+                if (b.first_block[s] + blocks > 0x7fffffffull) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "r1cs: system too large for the binned product");
+                b.first_block[s + 1] = b.first_block[s] + (uint32_t)blocks;
+            }
+            for (int k = 0; k < 3; k++) b.rowlist[k] = sl->d_list[k];
+        }
+        const unsigned blocks = b.first_block[b.nseg];
+        if (blocks) {
+#define FK_SPMVB_LAUNCH(T_, S_) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_binned_kernel<T_, S_>), dim3(blocks), dim3(256), 0, ctx->stream, a, b, r->table, (const Fr *)d_z, \
+                                                   r->num_input, td, r->copies, sa)
+            if (tiled) { if (sliced) FK_SPMVB_LAUNCH(true, true); else FK_SPMVB_LAUNCH(true, false); }
+            else { if (sliced) FK_SPMVB_LAUNCH(false, true); else FK_SPMVB_LAUNCH(false, false); }
+#undef FK_SPMVB_LAUNCH
+        }
     }
     FK_HIP(ctx, hipGetLastError());
     FK_DBG(ctx, "spmv");
     return FK_OK;
+}
+}  // namespace fk
+extern "C" {
+
+// a, b, c: device arrays with room for next_pow2(rows) elements each (fk_prove_dev's contract); rows written.
+int fk_r1cs_eval_dev(fk_ctx *ctx, const fk_r1cs_dev *r, const void *d_z, void *d_a, void *d_b, void *d_c) {
+    if (!ctx) return FK_ERR_BAD_ARG;
+    if (!r || !d_z || !d_a || !d_b || !d_c) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "r1cs eval: null argument");
+    return r1cs_eval_impl(ctx, r, d_z, d_a, d_b, d_c, false, 0, 0, 0);
+}
+
+// Multi-GPU form: only the cyclic slice rank `rank` of 2^log_w ranks needs -- local[j] = row (rank + j * 2^log_w) of A z, B z,
+// C z, zero behind the last row: exactly what fk_dq_gather_dev would cut out of the full vectors, at 1 / 2^log_w of the work and
+// without the three m-element vectors.  Arrays of 2^(log_m - log_w) elements.
+int fk_r1cs_eval_slice_dev(fk_ctx *ctx, const fk_r1cs_dev *r, const void *d_z, uint32_t log_m, uint32_t rank, uint32_t log_w, void *d_a, void *d_b, void *d_c) {
+    if (!ctx) return FK_ERR_BAD_ARG;
+    if (!r || !d_z || !d_a || !d_b || !d_c) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "r1cs eval: null argument");
+    if (log_w > 3 || (rank >> log_w) || log_m < log_w || log_m >= FK_FR_S) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "r1cs eval: bad slice (rank %u of 2^%u, domain 2^%u)", rank, log_w, log_m);
+    if (r->num_gates + r->num_input > ((uint64_t)1 << log_m)) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "r1cs eval: the system has more rows than the domain 2^%u", log_m);
+    return r1cs_eval_impl(ctx, r, d_z, d_a, d_b, d_c, true, rank, log_w, (uint64_t)1 << (log_m - log_w));
 }
 
 // witness in -> proof out: SpMV, quotient, MSMs, assembly.  z: device pointer (num_input + num_aux elements).

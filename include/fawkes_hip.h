@@ -281,6 +281,11 @@ int fk_r1cs_info(const fk_r1cs_dev *r1cs, uint64_t out[8]);
 int fk_r1cs_density_ptrs(const fk_r1cs_dev *r1cs, const void *out[3]);
 /* a, b, c <- A z, B z, C z on the device (arrays sized for next_pow2(rows) elements, `rows` written) */
 int fk_r1cs_eval_dev(fk_ctx *ctx, const fk_r1cs_dev *r1cs, const void *d_z, void *d_a, void *d_b, void *d_c);
+/* the cyclic row slice one of 2^log_w ranks needs: local[j] = row (rank + j * 2^log_w) of A z, B z, C z, zero behind the last
+ * row -- what fk_dq_gather_dev cuts out of the full vectors, at 1 / 2^log_w of the work and without the three m-element
+ * vectors.  d_a, d_b, d_c: 2^(log_m - log_w) elements each. */
+int fk_r1cs_eval_slice_dev(fk_ctx *ctx, const fk_r1cs_dev *r1cs, const void *d_z, uint32_t log_m, uint32_t rank, uint32_t log_w,
+                           void *d_a, void *d_b, void *d_c);
 int fk_prove_r1cs(fk_ctx *ctx, const fk_key *key, const fk_r1cs_dev *r1cs, const uint64_t *z,
                   const uint64_t r[4], const uint64_t s[4], uint8_t out_proof[FK_PROOF_BYTES], fk_timings *timings);
 /* multi-GPU counterpart of fk_prove_msms_hz_dev for a resident constraint system (its A / B query index lists replace
@@ -362,6 +367,56 @@ int fk_key_load_bellman(fk_ctx *ctx, const uint8_t *buf, size_t len, uint32_t fl
 int fk_key_vk(const fk_key *key, uint8_t out[3 * 64 + 2 * 128]);
 /* out[8] = m, num_input, num_aux, n_h, n_l, n_a, n_b, shard_count */
 int fk_key_counts(const fk_key *key, uint64_t out[8]);
+
+/* ---------------------------------------------------------------- multi-GPU prover: one call, N GPUs of one node
+ * `fk_init(int n_devices, const int *device_ids)`.  The reference's entry is ONE call --
+ * `prove(params, pub, sec, circuit)` (prover.rs:63-90) -- and so is the sharded form: one process, one library context and
+ * one worker thread per GPU, every exchange inside the library (csrc/multi.hip).  Rank g (= position in device_ids) keeps
+ * shard g of every key array, evaluates the rows t = g (mod N) of a, b, c, computes 1/N of the quotient (every transform is
+ * cut once between the ranks; its all-to-all is device-to-device DMA over xGMI -- hipMemcpyPeerAsync pulls on an exchange
+ * stream per rank, ordered with HIP events against the kernels on both sides, seven per proof) and 1/N of each of the five
+ * multi-scalar multiplications; the N 384-byte partial results are folded on the host ("all-reduce of the partial sums":
+ * no collective library has an elliptic-curve reduction operator).  N = 1, 2, 4, 8 use this schedule; any other N up to 64
+ * shards the multiplications only (every rank computes the whole quotient).  Device ids may repeat: several ranks then share
+ * a GPU (how a one-GPU box tests the path).  The proof bytes do not depend on N.
+ * An fk_multi is not thread-safe (one call at a time); keys and constraint systems loaded through it belong to it.
+ * FK_OVERLAP_WITNESS=1 / 0: begin the witness multiplications before the quotient (default from 4 ranks on);
+ * FK_MULTI_HOST_EVENTS=1: wait for a peer GPU's event on the host instead of in the stream (diagnosis). */
+typedef struct fk_multi fk_multi;
+typedef struct fk_multi_key fk_multi_key;
+typedef struct fk_multi_r1cs fk_multi_r1cs;
+int fk_init_devices(int n_devices, const int *device_ids, fk_multi **out);
+void fk_multi_free(fk_multi *multi);
+const char *fk_multi_last_error(const fk_multi *multi);
+int fk_multi_size(const fk_multi *multi);
+/* rank `rank`'s single-GPU context (statistics, calibration, building blocks); owned by the fk_multi */
+fk_ctx *fk_multi_ctx(fk_multi *multi, int rank);
+int fk_multi_sync(fk_multi *multi);
+/* the key loaders of the single-GPU interface, shard g of N on rank g (desc->shard_index / shard_count / z_frac_* are ignored) */
+int fk_multi_key_load(fk_multi *multi, const fk_key_desc *desc, fk_multi_key **out);
+int fk_multi_key_load_bellman(fk_multi *multi, const uint8_t *buf, size_t len, uint32_t flags, fk_multi_key **out, uint8_t *gamma_g2_out,
+                              uint8_t *ic_out, uint32_t ic_cap, uint32_t *n_ic);
+int fk_multi_setup(fk_multi *multi, const fk_r1cs *cs, const uint64_t tau[4], const uint64_t alpha[4], const uint64_t beta[4],
+                   const uint64_t gamma[4], const uint64_t delta[4], fk_multi_key **out, uint8_t vk_out[6 * 128], uint8_t *ic_out);
+int fk_multi_setup_tiled(fk_multi *multi, const fk_r1cs *instance, uint32_t copies, const uint64_t tau[4], const uint64_t alpha[4],
+                         const uint64_t beta[4], const uint64_t gamma[4], const uint64_t delta[4], fk_multi_key **out,
+                         uint8_t vk_out[6 * 128], uint8_t *ic_out);
+void fk_multi_key_free(fk_multi *multi, fk_multi_key *key);
+const fk_key *fk_multi_key_shard(const fk_multi_key *key, int rank);
+/* the resident constraint system, one replica per GPU */
+int fk_multi_r1cs_load(fk_multi *multi, const fk_r1cs *cs, fk_multi_r1cs **out);
+int fk_multi_r1cs_load_tiled(fk_multi *multi, const fk_r1cs *instance, uint32_t copies, fk_multi_r1cs **out);
+int fk_multi_r1cs_load_gates(fk_multi *multi, const fk_gates *gates, fk_multi_r1cs **out);
+void fk_multi_r1cs_free(fk_multi *multi, fk_multi_r1cs *r1cs);
+const fk_r1cs_dev *fk_multi_r1cs_replica(const fk_multi_r1cs *r1cs, int rank);
+/* witness in (host memory; every GPU uploads it over its own PCIe link) -> proof out: the multi-GPU fk_prove_r1cs, and its
+ * two-slot pipelined form (the upload of proof k+1 runs underneath proof k; z must stay valid until the matching _wait
+ * returns and should be pinned -- fk_host_alloc on fk_multi_ctx(multi, 0)) */
+int fk_multi_prove_r1cs(fk_multi *multi, const fk_multi_key *key, const fk_multi_r1cs *r1cs, const uint64_t *z, const uint64_t r[4],
+                        const uint64_t s[4], uint8_t out_proof[FK_PROOF_BYTES], fk_timings *timings);
+int fk_multi_prove_r1cs_submit(fk_multi *multi, const fk_multi_key *key, const fk_multi_r1cs *r1cs, const uint64_t *z,
+                               const uint64_t r[4], const uint64_t s[4], int *ticket);
+int fk_multi_prove_r1cs_wait(fk_multi *multi, int ticket, uint8_t out_proof[FK_PROOF_BYTES], fk_timings *timings);
 
 /* ---------------------------------------------------------------- verifier
  * `verifier::verify(vk, proof, inputs)` (verifier.rs:75-81 -> bellman's verify_proof).  vk: fawkes' Borsh `VK`

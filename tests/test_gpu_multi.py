@@ -1,0 +1,178 @@
+"""The multi-GPU prover behind the C ABI (fk_init_devices / fk_multi_*, csrc/multi.hip): ONE call proves on N ranks, every
+exchange inside the library.  A one-GPU box passes the same device id N times (the ranks then share the GPU and the
+all-to-all copies are device-local); the proof bytes must not depend on N and must equal the oracle's.
+Also here: the cyclic row slices of the constraint-system evaluation (fk_r1cs_eval_slice_dev) against the full evaluation."""
+import numpy as np
+import pytest
+
+import bn254_ref as ref
+import fixtures as fx
+from helpers import params_from_oracle_key, r1cs_product, TOXIC
+from test_gpu_r1cs import _ragged_system
+
+pytestmark = pytest.mark.gpu
+
+
+def _eval_full_and_slices(ctx, dr, z, rows, log_m):
+    m = 1 << log_m
+    d = [ctx.dev_alloc(m * 32) for _ in range(3)]
+    d_z = ctx.dev_alloc(z.nbytes)
+    try:
+        ctx.upload(d_z, z)
+        for p in d:
+            ctx.upload(p, np.zeros(m * 4, np.uint64))
+        ctx.r1cs_eval_dev(dr, d_z, *d)
+        full = [ctx.download(p, m * 32, np.uint64).reshape(-1, 4) for p in d]
+        for f in full:
+            assert not f[rows:].any()
+        for log_w in (0, 1, 2, 3):
+            W, L = 1 << log_w, m >> log_w
+            for rank in range(W):
+                for p in d:
+                    ctx.upload(p, np.full(L * 4, 0xdeadbeefdeadbeef, np.uint64))
+                ctx.r1cs_eval_slice_dev(dr, d_z, log_m, rank, log_w, *d)
+                for k in range(3):
+                    got = ctx.download(d[k], L * 32, np.uint64).reshape(-1, 4)
+                    assert np.array_equal(got, full[k][rank::W]), (log_w, rank, k)
+        return full
+    finally:
+        for p in d + [d_z]:
+            ctx.dev_free(p)
+
+
+@pytest.mark.parametrize('lens', [[0, 1, 1, 1, 2, 3, 4, 5, 31, 32, 33, 100, 257, 512], [1, 1, 2], [40, 41, 1500]])
+@pytest.mark.parametrize('copies,gates', [(1, 700), (5, 700), (7, 333), (4, 252)])
+def test_eval_slice_matches_full_evaluation(ctx, oracle, lens, copies, gates):
+    """every cyclic slice (W = 1, 2, 4, 8, every rank) of a system with short rows only, with the Poseidon-like mix of row
+    lengths (length-class kernel) and with very long rows; untiled and tiled, with gate counts of every residue mod 8 (which
+    residue class a copy needs depends on copy * gates mod W)"""
+    base = _ragged_system(len(lens) * 100 + copies, lens, gates, 3, 300)
+    csr = fx.tile_r1cs(base, copies) if copies > 1 else base
+    nv, rows = csr.num_input + csr.num_aux, csr.num_gates + csr.num_input
+    rnd = np.random.default_rng(copies)
+    z = fx.co.limbs_arr([int(x) % ref.R for x in rnd.integers(0, 2**63, nv).astype(object) * (2**190 + 12345)])
+    want = oracle.synthesize(csr, z)
+    log_m = max(rows - 1, 1).bit_length()
+    loads = [lambda: ctx.load_r1cs(r1cs_product(csr))]
+    if copies > 1:
+        loads.append(lambda: ctx.load_r1cs(r1cs_product(base), copies=copies))
+    for load in loads:
+        dr = load()
+        try:
+            full = _eval_full_and_slices(ctx, dr, z, rows, log_m)
+            for k in range(3):
+                assert np.array_equal(full[k][:rows], want[k])
+        finally:
+            dr.free()
+
+
+def test_eval_slice_argument_checks(ctx):
+    import fawkes_crypto_amd as fk
+    base = _ragged_system(5, [1, 2], 100, 2, 50)
+    dr = ctx.load_r1cs(r1cs_product(base))
+    d = ctx.dev_alloc(1 << 14)
+    try:
+        with pytest.raises(fk.FkError):
+            ctx.r1cs_eval_slice_dev(dr, d, 7, 2, 1, d, d, d)        # rank 2 of 2
+        with pytest.raises(fk.FkError):
+            ctx.r1cs_eval_slice_dev(dr, d, 7, 0, 4, d, d, d)        # 16 ranks
+        with pytest.raises(fk.FkError):
+            ctx.r1cs_eval_slice_dev(dr, d, 6, 0, 1, d, d, d)        # 102 rows do not fit 2^6
+    finally:
+        ctx.dev_free(d)
+        dr.free()
+
+
+def _toy(oracle, seed, gates, nin, naux):
+    cs, z_in, z_aux = ref.random_r1cs(seed, gates, nin, naux)
+    csr = fx.r1cs_to_csr(cs)
+    okey = oracle.setup(csr, **TOXIC)
+    z = fx.witness_mont(z_in, z_aux)
+    r, s = fx.mont_fr(0x1111 + seed), fx.mont_fr(0x2222 + seed)
+    aa = oracle.synthesize(csr, z)
+    want = oracle.prove(okey, *aa[:3], z, *aa[3:], r, s)
+    return csr, okey, z, z_in, r, s, want
+
+
+@pytest.mark.parametrize('world', [1, 2, 3, 4, 8])
+def test_multi_prove_one_call_matches_oracle(ctx, oracle, world):
+    """fk_multi_prove_r1cs on `world` ranks (sharing this GPU): key shards derived by fk_multi_setup, one constraint-system replica
+    per rank, witness from host memory -- the oracle's bytes, whatever the rank count; also through fk_multi_key_load (host key
+    arrays) and the two-slot submit / wait form"""
+    import fawkes_crypto_amd as fk
+    csr, okey, z, z_in, r, s, want = _toy(oracle, 5150 + world, 1500, 3, 1600)
+    r1cs = r1cs_product(csr)
+    tox = {k: fx.mont_fr(v) for k, v in TOXIC.items()}
+    mc = fk.MultiContext([0] * world)
+    try:
+        assert mc.size == world
+        key, vk = mc.setup(r1cs, **tox)
+        dr = mc.load_r1cs(r1cs)
+        for g in range(world):
+            info = mc.key_shard(key, g).shard_info()
+            assert info['h'] == fk.api.h_shard_range((1 << 11) - 1, g, world)
+        got = mc.prove_witness(key, dr, z, r, s)
+        assert got.tobytes() == want.tobytes()
+        assert ref.verify(fx.key_to_py(okey), z_in[1:], ref.proof_from_borsh(got.tobytes()))
+        # the verifying key of the sharded derivation is the oracle's
+        assert np.array_equal(vk['ic'], np.array(okey.ic)) and vk['alpha_g1'].tobytes() == np.array(okey.alpha_g1).tobytes()
+        # pipelined: two witnesses in flight, a different one second
+        z2 = z.copy()
+        t0 = mc.prove_witness_submit(key, dr, z, r, s)
+        t1 = mc.prove_witness_submit(key, dr, z2, s, r)
+        with pytest.raises(fk.FkError):
+            mc.prove_witness_submit(key, dr, z, r, s)               # a third one does not fit
+        assert mc.prove_witness_wait(t0).tobytes() == want.tobytes()
+        p1 = mc.prove_witness_wait(t1)
+        assert p1.tobytes() != want.tobytes() and ref.verify(fx.key_to_py(okey), z_in[1:], ref.proof_from_borsh(p1.tobytes()))
+        key.free()
+        # the same through host key arrays (fk_key_load on every rank, shard g of `world`)
+        key2 = mc.load_key(params_from_oracle_key(okey, r1cs))
+        assert mc.prove_witness(key2, dr, z, r, s).tobytes() == want.tobytes()
+        key2.free(); dr.free()
+    finally:
+        mc.close()
+
+
+def test_multi_prove_long_rows_tiled_and_errors(ctx, oracle):
+    """a tiled system with the Poseidon-like mix of row lengths (the length-class kernel's slices), 4 ranks; a key that does not
+    belong to the system is refused with the rank's message and the next proof still works"""
+    import fawkes_crypto_amd as fk
+    copies = 6
+    base = _ragged_system(99, [0, 1, 1, 1, 2, 3, 4, 5, 31, 32, 33, 100, 257], 250, 3, 120)
+    csr = fx.tile_r1cs(base, copies)
+    nv = csr.num_input + csr.num_aux
+    rnd = np.random.default_rng(3)
+    z = fx.co.limbs_arr([int(x) % ref.R for x in rnd.integers(0, 2**63, nv).astype(object) * (2**190 + 12345)])
+    z[0] = fx.mont_fr(1)
+    tox = {k: fx.mont_fr(v) for k, v in TOXIC.items()}
+    r, s = fx.mont_fr(77), fx.mont_fr(88)
+    # single-GPU proof of the explicitly replicated system = the reference point (itself oracle-checked in test_gpu_tiled.py)
+    k1, _ = ctx.setup(r1cs_product(base), copies=copies, **tox)
+    d1 = ctx.load_r1cs(r1cs_product(base), copies=copies)
+    want = ctx.prove_witness(k1, d1, z, r, s)
+    okey = oracle.setup(csr, **TOXIC)
+    aa = oracle.synthesize(csr, z)
+    assert oracle.prove(okey, *aa[:3], z, *aa[3:], r, s).tobytes() == want.tobytes()
+    k1.free(); d1.free()
+    mc = fk.MultiContext([0, 0, 0, 0])
+    try:
+        key, _ = mc.setup(r1cs_product(base), copies=copies, **tox)
+        dr = mc.load_r1cs(r1cs_product(base), copies=copies)
+        assert mc.prove_witness(key, dr, z, r, s).tobytes() == want.tobytes()
+        other = mc.load_r1cs(r1cs_product(_ragged_system(98, [1, 2], 250, 3, 121)), copies=copies)
+        with pytest.raises(fk.FkError) as e:
+            mc.prove_witness(key, other, z[:-1], r, s)
+        assert e.value.code == 6 and 'rank' in str(e.value)
+        assert mc.prove_witness(key, dr, z, r, s).tobytes() == want.tobytes()
+        other.free(); key.free(); dr.free()
+    finally:
+        mc.close()
+
+
+def test_multi_init_argument_checks():
+    import fawkes_crypto_amd as fk
+    with pytest.raises(fk.FkError):
+        fk.MultiContext([])
+    with pytest.raises(fk.FkError):
+        fk.MultiContext([0, 99])
