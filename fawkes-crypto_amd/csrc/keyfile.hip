@@ -178,9 +178,13 @@ int fk_key_load_bellman(fk_ctx *ctx, const uint8_t *buf, size_t len, uint32_t fl
             std::vector<G1Affine> o1(n1);
             if (hipMemcpy(d_in1, g1buf.data(), g1buf.size(), hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d_in2, g2buf.data(), g2buf.size(), hipMemcpyHostToDevice) != hipSuccess) rc = FK_ERR_HIP;
             else {
-                // the verifying key never holds the identity (bellman's VerifyingKey::read rejects it), whatever the flags say
-                hipLaunchKernelGGL(convert_g1_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, ctx->stream, d_in1, n1, (Affine<FqC> *)d_o1, flags | FK_KEY_NO_INFINITY, d_bad);
-                hipLaunchKernelGGL(convert_g2_kernel, dim3(1), dim3(128), 0, ctx->stream, d_in2, (size_t)3, (Affine<Fq2C> *)d_o2, flags | FK_KEY_NO_INFINITY, d_bad);
+                // bellman's VerifyingKey::read (restated from upstream, not verifiable here) decodes alpha, beta, gamma, delta and ic
+                // with the CHECKED `into_affine` whatever Parameters::read's `checked` says, and refuses the identity among the ic
+                // points only
+                hipLaunchKernelGGL(convert_g1_kernel, dim3(1), dim3(256), 0, ctx->stream, d_in1, (size_t)3, (Affine<FqC> *)d_o1, (uint32_t)FK_KEY_CHECKED, d_bad);
+                hipLaunchKernelGGL(convert_g1_kernel, dim3((unsigned)((cnt[0] + 255) / 256)), dim3(256), 0, ctx->stream, d_in1 + 3 * 64, (size_t)cnt[0], (Affine<FqC> *)(d_o1 + 3),
+                                   (uint32_t)(FK_KEY_CHECKED | FK_KEY_NO_INFINITY), d_bad);
+                hipLaunchKernelGGL(convert_g2_kernel, dim3(1), dim3(128), 0, ctx->stream, d_in2, (size_t)3, (Affine<Fq2C> *)d_o2, (uint32_t)FK_KEY_CHECKED, d_bad);
                 if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipMemcpy(o1.data(), d_o1, n1 * 64, hipMemcpyDeviceToHost) != hipSuccess ||
                     hipMemcpy(vk2, d_o2, 3 * 128, hipMemcpyDeviceToHost) != hipSuccess) rc = FK_ERR_HIP;
                 else { vk1[0] = o1[0]; vk1[1] = o1[1]; vk1[2] = o1[2]; for (uint32_t i = 0; i < cnt[0]; i++) ic[i] = o1[3 + i]; }

@@ -218,11 +218,12 @@ def torch_all_to_all(ctx, group=None):
     return a2a
 
 
-def quotient_distributed(ctx, rank, world, d_full, n, log_m, send, recv, a2a):
+def quotient_distributed(ctx, rank, world, d_full, n, log_m, send, recv, a2a, slices_in_send=False):
     """h = (A*B - C)/Z over `world` ranks.  d_full: device pointers of the three row-evaluation vectors a, b, c (n valid
-    rows; every rank holds them -- the SpMV is ~1 % of a proof).  send, recv: 3 + 3 buffers of (m/world)*32 bytes with
-    .data_ptr() (torch uint8 device tensors); a2a(dst_list, src_list): the exchange.  Returns the buffer that holds
-    this rank's block h[rank*m/world, (rank+1)*m/world) (Montgomery, 32 B per coefficient).
+    rows) from which this rank's cyclic slices are cut -- or, with slices_in_send, None: send[0..2] already hold the slices
+    (fk_r1cs_eval_slice_dev: a rank of a resident constraint system evaluates only its own rows).  send, recv: 3 + 3 buffers of
+    (m/world)*32 bytes with .data_ptr() (torch uint8 device tensors); a2a(dst_list, src_list): the exchange.  Returns the buffer
+    that holds this rank's block h[rank*m/world, (rank+1)*m/world) (Montgomery, 32 B per coefficient).
 
     The three polynomials are independent until the pointwise step, so when the exchange has a split form (a2a.begin /
     a2a.end: torch_all_to_all over RCCL) they are pipelined: polynomial k's all-to-all is on the links while polynomial
@@ -237,7 +238,8 @@ def quotient_distributed(ctx, rank, world, d_full, n, log_m, send, recv, a2a):
     # SIX transforms (csrc/ntt.hip: quotient_dev): c is subtracted in coefficient space, so it needs the inverse transform only
     h1 = []
     for k in range(3):                                   # ifft, first half; its exchange starts at once
-        ctx.dq_gather_dev(d_full[k], n, log_m, rank, lw, p(send[k]))
+        if not slices_in_send:
+            ctx.dq_gather_dev(d_full[k], n, log_m, rank, lw, p(send[k]))
         ctx.dq_local_dev(p(send[k]), log_m, rank, lw, 0)
         h1.append(begin(recv[k:k + 1], send[k:k + 1]))
     h2 = [None, None]
@@ -259,12 +261,21 @@ def quotient_distributed(ctx, rank, world, d_full, n, log_m, send, recv, a2a):
 
 def prove_distributed_dev(ctx, key, rank, world, d_full, n, log_m, d_z, d_a_aux, d_b_in, d_b_aux, r, s, send, recv,
                           group=None, device=None, eval_fn=None, a2a=None, device_r1cs=None):
-    """One proof over `world` GPUs with the quotient AND the five MSMs cut 1/world each.  key: this rank's equal shard
-    (shard_index = rank, shard_count = world, no z fractions).  eval_fn(): fills d_full (device SpMV)."""
-    if eval_fn is not None:
-        eval_fn()
+    """One proof over `world` GPUs with the evaluation of a, b, c, the quotient AND the five MSMs cut 1/world each.  key: this
+    rank's equal shard (shard_index = rank, shard_count = world, no z fractions).  With a resident constraint system
+    (device_r1cs) the rank evaluates only its cyclic row slice, straight into send[0..2] (d_full / eval_fn unused: no
+    m-element vectors on a rank); otherwise eval_fn() fills d_full and the slices are cut out of it."""
+    sliced = device_r1cs is not None and os.environ.get('FK_DIST_SLICED_EVAL', '1') != '0'
     if a2a is None:
         a2a = torch_all_to_all(ctx, group)
+
+    def quotient():
+        if sliced:
+            ctx.r1cs_eval_slice_dev(device_r1cs, d_z, log_m, rank, log2_world(world), *[t.data_ptr() for t in send])
+        elif eval_fn is not None:
+            eval_fn()
+        return quotient_distributed(ctx, rank, world, d_full, n, log_m, send, recv, a2a, slices_in_send=sliced)
+
     # The witness MSMs do not need the quotient, so they can be begun first and fill the GPU during the quotient's
     # all-to-all phases.  On ONE GPU the overlap measured neutral at 2^25 and 10 % slower at 2^20 / 2^22 (both sides are
     # VALU-bound and there is nothing to wait for); from 4 ranks on the per-rank transforms are short next to the eight
@@ -275,10 +286,10 @@ def prove_distributed_dev(ctx, key, rank, world, d_full, n, log_m, d_z, d_a_aux,
             ctx.prove_msms_z_begin_r1cs_dev(key, device_r1cs, d_z)
         else:
             ctx.prove_msms_z_begin_dev(key, d_z, d_a_aux, d_b_in, d_b_aux)
-        h_blk = quotient_distributed(ctx, rank, world, d_full, n, log_m, send, recv, a2a)
+        h_blk = quotient()
         part = ctx.prove_msms_finish_dev(key, h_blk.data_ptr())
     else:
-        h_blk = quotient_distributed(ctx, rank, world, d_full, n, log_m, send, recv, a2a)
+        h_blk = quotient()
         if device_r1cs is not None:      # resident constraint system: its query index lists replace the density compaction
             part = ctx.prove_msms_hz_r1cs_dev(key, device_r1cs, h_blk.data_ptr(), d_z)
         else:

@@ -188,17 +188,23 @@ def load_parameters(ctx, data, shard_index=0, shard_count=1, z_frac=(-1.0, -1.0)
     c = key.counts()
     blob = hdr['gates_blob']
     raw = blob.startswith(RAW_MAGIC)
+    gates = dr = None
     try:
         gates = api.Gates(blob[len(RAW_MAGIC):] if raw else blob, api.FK_GATES_RAW if raw else api.FK_GATES_BROTLI, hdr['num_gates'],
                           c['num_input'], c['num_aux'], ctx=ctx)
+        dr = gates.load(ctx)
+        hdr.update(gamma_g2=gamma_g2, ic=ic, gates_info=gates.info())
+        if want_host_r1cs:
+            hdr['r1cs'] = gates.to_r1cs()
     except Exception:
+        # nothing stays behind in HBM when the circuit half of the file is bad (a 2^25 key is several GB)
+        if dr is not None:
+            dr.free()
         key.free()
         raise
-    dr = gates.load(ctx)
-    hdr.update(gamma_g2=gamma_g2, ic=ic, gates_info=gates.info())
-    if want_host_r1cs:
-        hdr['r1cs'] = gates.to_r1cs()
-    gates.free()
+    finally:
+        if gates is not None:
+            gates.free()
     return key, dr, hdr
 
 

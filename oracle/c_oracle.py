@@ -212,6 +212,18 @@ def synthesize(cs, z):
     return a, b, c, a_aux, b_in, b_aux
 
 
+def synthesize_tiled(inst, copies, z):
+    """synthesize() of fixtures.tile_r1cs(inst, copies) without materialising it (orc_synthesize_tiled)."""
+    z = np.ascontiguousarray(z, np.uint64)
+    nin, naux = 1 + copies * (inst.num_input - 1), copies * inst.num_aux
+    n = copies * inst.num_gates + nin
+    assert z.shape == (nin + naux, 4)
+    a = np.zeros((n, 4), np.uint64); b = np.zeros((n, 4), np.uint64); c = np.zeros((n, 4), np.uint64)
+    a_aux = np.zeros(naux, np.uint8); b_in = np.zeros(nin, np.uint8); b_aux = np.zeros(naux, np.uint8)
+    lib().orc_synthesize_tiled(C.byref(inst.struct), C.c_uint32(copies), _p(z), _p(a), _p(b), _p(c), _p(a_aux), _p(b_in), _p(b_aux))
+    return a, b, c, a_aux, b_in, b_aux
+
+
 class Key:
     """Owns an orc_key; exposes numpy views of the key arrays."""
 

@@ -522,6 +522,47 @@ void orc_synthesize(const orc_r1cs *cs, const uint64_t *z, uint64_t *a, uint64_t
     }
 }
 
+/* The same evaluation for a batch circuit given as ONE instance + a copy count (the system fixtures.tile_r1cs writes out
+ * explicitly: rows of copy j are [j*G, (j+1)*G); variables ONE, copy 0's inputs, copy 1's inputs, ..., copy 0's aux, ...),
+ * without materialising copies x nnz terms -- what lets the CPU baseline run at the benchmark's full size (9.6e8 terms).
+ * Same order of additions per row as orc_synthesize on the replicated system, hence the same field elements. */
+static void eval_lc_tiled(fe *out, const uint64_t *ptr, const uint32_t *col, const uint64_t *val, uint64_t row, const fe *z,
+                          uint32_t base_input, uint32_t in_off, uint32_t aux_off, uint32_t num_input, uint8_t *din, uint8_t *daux) {
+    fe acc; memset(&acc, 0, sizeof acc);
+    for (uint64_t k = ptr[row]; k < ptr[row + 1]; k++) {
+        uint32_t v = col[k];
+        if (v) v += v < base_input ? in_off : aux_off;
+        if (v < num_input) { if (din) din[v] = 1; } else { if (daux) daux[v - num_input] = 1; }
+        fe t = z[v];
+        const fe *cf = (const fe *)(val + 4 * k);
+        if (!fe_eq(cf, &FR.r)) fe_mul(&FR, &t, &t, cf);
+        fe_add(&FR, &acc, &acc, &t);
+    }
+    *out = acc;
+}
+
+void orc_synthesize_tiled(const orc_r1cs *inst, uint32_t copies, const uint64_t *z, uint64_t *a, uint64_t *b, uint64_t *c,
+                          uint8_t *a_aux, uint8_t *b_input, uint8_t *b_aux) {
+    orc_init();
+    const uint32_t num_input = 1 + copies * (inst->num_input - 1), num_aux = copies * inst->num_aux;
+    const uint64_t G = inst->num_gates;
+    memset(a_aux, 0, num_aux); memset(b_input, 0, num_input); memset(b_aux, 0, num_aux);
+    const fe *Z = (const fe *)z;
+    for (uint32_t j = 0; j < copies; j++) {
+        const uint32_t in_off = j * (inst->num_input - 1), aux_off = num_input + j * inst->num_aux - inst->num_input;
+        for (uint64_t g = 0; g < G; g++) {
+            const uint64_t t = (uint64_t)j * G + g;
+            eval_lc_tiled((fe *)(a + 4 * t), inst->a_ptr, inst->a_col, inst->a_val, g, Z, inst->num_input, in_off, aux_off, num_input, NULL, a_aux);
+            eval_lc_tiled((fe *)(b + 4 * t), inst->b_ptr, inst->b_col, inst->b_val, g, Z, inst->num_input, in_off, aux_off, num_input, b_input, b_aux);
+            eval_lc_tiled((fe *)(c + 4 * t), inst->c_ptr, inst->c_col, inst->c_val, g, Z, inst->num_input, in_off, aux_off, num_input, NULL, NULL);
+        }
+    }
+    for (uint32_t i = 0; i < num_input; i++) {   /* input_i * 0 = 0 */
+        uint64_t row = (uint64_t)copies * G + i;
+        memcpy(a + 4 * row, Z + i, 32); memset(b + 4 * row, 0, 32); memset(c + 4 * row, 0, 32);
+    }
+}
+
 /* ------------------------------------------------------------------ key material */
 typedef struct {
     uint64_t m; uint32_t num_input, num_aux;

@@ -188,3 +188,91 @@ def test_key_file_roundtrip_and_prove(ctx, oracle):
     rejected(setb(B2, enc))
     bad = bytearray(bell); bad[B2:B2 + 128] = enc
     ctx.load_key_bellman(bytes(bad), flags=0)[0].free()
+
+
+def test_bitvec_packing_is_bit_vec_0_6(oracle):
+    """`BitVec::to_bytes` / `from_bytes` (mod.rs:155,169) pack the FIRST bit into the HIGH-order bit of byte 0.  The cases are the
+    documentation examples of the bit-vec crate (0.6), i.e. facts that do not come from this repository: a self round trip
+    cannot tell MSB-first from LSB-first, these can -- including lengths that are not a multiple of 8."""
+    from fawkes_crypto_amd import params_io as pio
+    # to_bytes: BitVec::from_elem(3, true) with bit 1 cleared -> [0b10100000]
+    assert pio.bits_to_bytes([True, False, True]) == bytes([0b10100000])
+    # to_bytes: BitVec::from_elem(9, false) with bits 2 and 8 set -> [0b00100000, 0b10000000]
+    bits9 = [False] * 9
+    bits9[2] = bits9[8] = True
+    assert pio.bits_to_bytes(bits9) == bytes([0b00100000, 0b10000000])
+    # from_bytes(&[0b10100000, 0b00010010]) == [t f t f f f f f  f f f t f f t f]
+    want = [True, False, True, False, False, False, False, False, False, False, False, True, False, False, True, False]
+    assert pio.bytes_to_bits(bytes([0b10100000, 0b00010010]), 16) == want
+    assert pio.bytes_to_bits(bytes([0b10100000, 0b00010010]), 12) == want[:12]        # mod.rs:170: truncate to the stored bit length
+    with pytest.raises(ValueError):
+        pio.bytes_to_bits(bytes([0xff]), 9)                                            # mod.rs:165-167: inconsistent length
+    # the fawkes wrapper around it, byte for byte (mod.rs:150-157): u32 LE gate count | Borsh Vec<u8> | u32 LE bit length | Borsh Vec<u8>
+    data = pio.write_parameters(7, b'\xaa\xbb', bits9, b'TAIL')
+    assert data == bytes.fromhex('07000000' '02000000' 'aabb' '09000000' '02000000' '2080') + b'TAIL'
+    hdr = pio.read_parameters(data)
+    assert hdr['num_gates'] == 7 and hdr['gates_blob'] == b'\xaa\xbb' and hdr['const_tracker'] == bits9 and hdr['bellman'] == b'TAIL'
+
+
+@pytest.mark.gpu
+def test_handmade_bellman_key_bytes(ctx):
+    """A `Parameters::write` image assembled BY HAND from the upstream format description (SURVEY Appendix B.2) -- not by
+    params_io.encode_bellman_parameters -- and loaded through fk_key_load_bellman: big-endian coordinates, G2 as
+    x.c1 | x.c0 | y.c1 | y.c0 (for the generator that is literally the EIP-197 hex of it), `u32` BIG-endian counts, the 0x40
+    infinity byte, the 0x80 compression bit.  Expected device bytes come from the big-int reference (Montgomery LE)."""
+    import fawkes_crypto_amd as fk
+    be = lambda v: v.to_bytes(32, 'big')
+    G1x, G1y = 1, 2
+    D = (1368015179489954701390400359078579693043519447331113978918064868415326638035,
+         9918110051302171585080402603319702774565515993150576347155970296011118125764)          # 2 * G1, public constant
+    g1 = lambda P: be(P[0]) + be(P[1])
+    G2HEX = ('198e9393920d483a7260bfb731fb5d25f1aa493335a9e71297e485b7aef312c2' '1800deef121f1e76426a00665e5c4479674322d4f75edadd46debd5cd992f6ed'
+             '090689d0585ff075ec9e99ad690c3395bc4b313370b38ef355acdadcd122975b' '12c85ea5db8c6deb4aab71808dcb408fe3d1e7690c43d37b4ce6cc0166fa7daa')
+    g2gen = bytes.fromhex(G2HEX)
+    assert ref.G2_GEN == ((int(G2HEX[64:128], 16), int(G2HEX[0:64], 16)), (int(G2HEX[192:256], 16), int(G2HEX[128:192], 16)))
+    P3, P5 = ref.G1.mul(ref.G1_GEN, 3), ref.G1.mul(ref.G1_GEN, 5)
+    Q2 = ref.G2.mul(ref.G2_GEN, 2)
+    g2 = lambda P: be(P[0][1]) + be(P[0][0]) + be(P[1][1]) + be(P[1][0])
+    INF1, INF2 = b'\x40' + bytes(63), b'\x40' + bytes(127)
+    u32be = lambda v: v.to_bytes(4, 'big')
+    vk = g1((G1x, G1y)) + g1(D) + g2gen + g2(Q2) + g1(P3) + g2gen           # alpha_g1 beta_g1 beta_g2 gamma_g2 delta_g1 delta_g2
+    ic = [(G1x, G1y), D]
+    h = [D, P3, P5]                                                        # m - 1 = 3 points: domain 4
+    l = [P5, None]                                                         # num_aux = 2, the second one the identity
+    a = [(G1x, G1y), D, P3]
+    b1 = [P3, None]
+    b2 = [Q2, None]
+    enc1 = lambda pts: u32be(len(pts)) + b''.join(INF1 if P is None else g1(P) for P in pts)
+    enc2 = lambda pts: u32be(len(pts)) + b''.join(INF2 if P is None else g2(P) for P in pts)
+    data = vk + enc1(ic) + enc1(h) + enc1(l) + enc1(a) + enc1(b1) + enc2(b2)
+    assert len(data) == 576 + 4 + 128 + 4 + 192 + 4 + 128 + 4 + 192 + 4 + 128 + 4 + 256
+    raw1 = lambda pts: b''.join(ref.g1_raw_le(P) for P in pts)
+    raw2 = lambda pts: b''.join(ref.g2_raw_le(P) for P in pts)
+    for flags in (0, fk.api.FK_KEY_CHECKED):
+        dk, gamma, icv = ctx.load_key_bellman(data, flags=flags)
+        c = dk.counts()
+        assert (c['m'], c['num_input'], c['num_aux'], c['n_a'], c['n_b']) == (4, 2, 2, 3, 2)
+        assert dk.download('h').tobytes() == raw1(h) and dk.download('l').tobytes() == raw1(l) and dk.download('a').tobytes() == raw1(a)
+        assert dk.download('b_g1').tobytes() == raw1(b1) and dk.download('b_g2').tobytes() == raw2(b2)
+        v = dk.vk()
+        assert v['alpha_g1'].tobytes() == ref.g1_raw_le((G1x, G1y)) and v['beta_g1'].tobytes() == ref.g1_raw_le(D) and v['delta_g1'].tobytes() == ref.g1_raw_le(P3)
+        assert v['beta_g2'].tobytes() == ref.g2_raw_le(ref.G2_GEN) and v['delta_g2'].tobytes() == ref.g2_raw_le(ref.G2_GEN)
+        assert gamma.tobytes() == ref.g2_raw_le(Q2) and icv.tobytes() == raw1(ic)
+        dk.free()
+
+    def rejected(mutated, flags=0):
+        with pytest.raises(fk.FkError) as e:
+            ctx.load_key_bellman(bytes(mutated), flags=flags)
+        assert e.value.code == 7, e.value
+
+    rejected(data, flags=fk.api.FK_KEY_NO_INFINITY)                          # l[1], b_g1[1], b_g2[1] are the identity
+    H0 = 576 + 4 + 128 + 4
+    bad = bytearray(data); bad[H0] |= 0x80; rejected(bad)                    # compression bit on an uncompressed point
+    bad = bytearray(data); bad[H0 + 64 + 128 + 4 + 64 + 9] = 1; rejected(bad)                # l[1]: infinity byte with a non-zero rest
+    bad = bytearray(data); bad[576:580] = (2).to_bytes(4, 'little'); rejected(bad)           # a little-endian count reads as 2^25 points: truncated
+    # the identity among the ic points is refused whatever the flags; inside alpha .. delta it is an encoding like any other
+    bad = bytearray(data); bad[580:644] = INF1; rejected(bad)
+    bad = bytearray(data); bad[64:128] = INF1                                # beta_g1
+    ctx.load_key_bellman(bytes(bad), flags=0)[0].free()
+    # the verifying key is always decoded with the curve check (VerifyingKey::read uses into_affine), `checked` or not
+    bad = bytearray(data); bad[63] ^= 1; rejected(bad, flags=0)
