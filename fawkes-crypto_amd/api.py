@@ -38,7 +38,7 @@ EXPORTED_SYMBOLS = [
     'fk_dq_gather_dev', 'fk_dq_local_dev', 'fk_dq_cross_dev', 'fk_dq_cross_sub_dev',
     'fk_setup', 'fk_setup_tiled', 'fk_r1cs_load_tiled', 'fk_key_download', 'fk_key_load_bellman', 'fk_key_vk', 'fk_key_counts', 'fk_key_precomputed',
     'fk_gates_decode', 'fk_gates_free', 'fk_gates_info', 'fk_gates_export', 'fk_r1cs_load_gates',
-    'fk_r1cs_load', 'fk_r1cs_free', 'fk_r1cs_info', 'fk_r1cs_density_ptrs', 'fk_r1cs_eval_dev', 'fk_r1cs_eval_slice_dev', 'fk_prove_r1cs', 'fk_prove_r1cs_dev',
+    'fk_r1cs_load', 'fk_r1cs_load_coded', 'fk_r1cs_free', 'fk_r1cs_info', 'fk_r1cs_density_ptrs', 'fk_r1cs_eval_dev', 'fk_r1cs_eval_slice_dev', 'fk_prove_r1cs', 'fk_prove_r1cs_dev',
     'fk_init_devices', 'fk_multi_free', 'fk_multi_last_error', 'fk_multi_size', 'fk_multi_ctx', 'fk_multi_sync',
     'fk_multi_key_load', 'fk_multi_key_load_bellman', 'fk_multi_setup', 'fk_multi_setup_tiled', 'fk_multi_key_free', 'fk_multi_key_shard',
     'fk_multi_r1cs_load', 'fk_multi_r1cs_load_tiled', 'fk_multi_r1cs_load_gates', 'fk_multi_r1cs_free', 'fk_multi_r1cs_replica',
@@ -784,6 +784,24 @@ class Context:
             self._ck(self.lib.fk_r1cs_load_tiled(self.handle, C.byref(r1cs.struct), C.c_uint32(int(copies)), C.byref(h)))
         return DeviceR1cs(self, h)
 
+    def load_r1cs_coded(self, num_input, num_aux, mats, table):
+        """fk_r1cs_load_coded: mats = three (ptr u64, col u32, cidx u32) triples, cidx indexing `table` ((n, 4) uint64 Montgomery,
+        table[0] = ONE).  8 bytes per term: how a system with 10^9 explicit terms is loaded."""
+        keep = []
+        st = R1csStruct()
+        st.num_input, st.num_aux, st.num_gates = num_input, num_aux, len(mats[0][0]) - 1
+        cidx = []
+        for nm, (ptr, col, ci) in zip('abc', mats):
+            ptr = np.ascontiguousarray(ptr, np.uint64); col = np.ascontiguousarray(col, np.uint32); ci = np.ascontiguousarray(ci, np.uint32)
+            assert len(col) == len(ci) == int(ptr[-1])
+            keep += [ptr, col, ci]
+            setattr(st, nm + '_ptr', ptr.ctypes.data); setattr(st, nm + '_col', col.ctypes.data if len(col) else None); setattr(st, nm + '_val', None)
+            cidx.append(ci)
+        table = _fr(table)
+        h = C.c_void_p()
+        self._ck(self.lib.fk_r1cs_load_coded(self.handle, C.byref(st), _vp(cidx[0]), _vp(cidx[1]), _vp(cidx[2]), _vp(table), C.c_uint64(len(table)), C.byref(h)))
+        return DeviceR1cs(self, h)
+
     def r1cs_eval_dev(self, dr, d_z, d_a, d_b, d_c):
         self._ck(self.lib.fk_r1cs_eval_dev(self.handle, dr.handle, C.c_void_p(d_z), C.c_void_p(d_a), C.c_void_p(d_b), C.c_void_p(d_c)))
 
@@ -1071,7 +1089,8 @@ def verify_batch(ctx, vk_borsh, inputs, proofs):
     proofs (count, 256) uint8.  Returns a bool array."""
     vkb = np.frombuffer(bytes(vk_borsh), np.uint8)
     pr = np.ascontiguousarray(proofs, np.uint8).reshape(-1, FK_PROOF_BYTES)
-    inp = np.ascontiguousarray(inputs, np.uint64).reshape(pr.shape[0], -1, 4)
+    inp = np.ascontiguousarray(inputs, np.uint64)
+    inp = inp.reshape(pr.shape[0], -1, 4) if inp.size else np.zeros((pr.shape[0], 0, 4), np.uint64)     # a key without public inputs
     out = np.zeros(pr.shape[0], np.uint8)
     ctx._ck(ctx.lib.fk_verify_batch_dev(ctx.handle, _vp(vkb), C.c_size_t(vkb.size), _vp(inp), C.c_uint32(inp.shape[1]), _vp(pr),
                                         C.c_uint32(pr.shape[0]), _vp(out)))

@@ -320,6 +320,19 @@ int r1cs_load_coded(fk_ctx *ctx, uint32_t num_input, uint32_t num_aux, uint64_t 
 extern "C" {
 int fk_r1cs_load_tiled(fk_ctx *ctx, const fk_r1cs *instance, uint32_t copies, fk_r1cs_dev **out) { return r1cs_load_impl(ctx, instance, copies, out); }
 
+// the same system with its coefficients already dictionary-coded by the caller: *_val of `cs` are ignored, cidx[k][i] indexes
+// `table` (n_table Montgomery values, table[0] = ONE).  8 bytes per term on the host side as well -- how a system of 10^9
+// explicit terms is handed over (32-byte values per term would be 30 GB of host memory).
+int fk_r1cs_load_coded(fk_ctx *ctx, const fk_r1cs *cs, const uint32_t *a_cidx, const uint32_t *b_cidx, const uint32_t *c_cidx, const uint64_t *table,
+                       uint64_t n_table, fk_r1cs_dev **out) {
+    if (!ctx) return FK_ERR_BAD_ARG;
+    if (!cs || !table || !n_table || !out) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "r1cs: null argument");
+    const uint32_t *cidx[3] = {a_cidx, b_cidx, c_cidx};
+    const uint64_t *ptrs[3] = {cs->a_ptr, cs->b_ptr, cs->c_ptr};
+    for (int k = 0; k < 3; k++) if (ptrs[k] && ptrs[k][cs->num_gates] && !cidx[k]) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "r1cs: null coefficient index array");
+    return r1cs_load_impl(ctx, cs, 1, out, cidx, (const Fr *)table, n_table);
+}
+
 int fk_r1cs_density_ptrs(const fk_r1cs_dev *r, const void *out[3]) {
     if (!r || !out) return FK_ERR_BAD_ARG;
     out[0] = r->d_a_aux; out[1] = r->d_b_in; out[2] = r->d_b_aux;

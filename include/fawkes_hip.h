@@ -274,6 +274,10 @@ int fk_r1cs_load(fk_ctx *ctx, const fk_r1cs *cs, fk_r1cs_dev **out);
  * materialising copies x nnz terms (2.2e9 for that batch): the kernel maps a copy's variables by arithmetic.  The
  * result is indistinguishable from fk_r1cs_load of the explicitly replicated system (tests/test_gpu_tiled.py). */
 int fk_r1cs_load_tiled(fk_ctx *ctx, const fk_r1cs *instance, uint32_t copies, fk_r1cs_dev **out);
+/* the same with the coefficients already dictionary-coded by the caller (cs->*_val ignored): x_cidx[i] indexes `table`
+ * (n_table Montgomery values, table[0] must be ONE) -- 8 bytes per term on the host side too, for systems of 10^9 terms */
+int fk_r1cs_load_coded(fk_ctx *ctx, const fk_r1cs *cs, const uint32_t *a_cidx, const uint32_t *b_cidx, const uint32_t *c_cidx,
+                       const uint64_t *table, uint64_t n_table, fk_r1cs_dev **out);
 void fk_r1cs_free(fk_ctx *ctx, fk_r1cs_dev *r1cs);
 /* out[8] = rows, nnz(A), nnz(B), nnz(C), distinct coefficients, points the a query needs, points the b query needs, 0 */
 int fk_r1cs_info(const fk_r1cs_dev *r1cs, uint64_t out[8]);

@@ -136,3 +136,20 @@ def test_assemble_matches_oracle(oracle):
     part1[:64] = minus_five_g
     out2 = api.assemble(host_key.handle, np.stack([part0, part1]), fx.mont_fr(r), fx.mont_fr(s))
     assert out2.tobytes().hex() == g['proof']
+
+
+def test_bench_materialised_rollup_system_is_the_tiled_one():
+    """bench.py's `untiled` leg writes the 1024-transaction system out term by term; at a small copy count the arrays must be the
+    ones fixtures.tile_r1cs (the oracle-side definition of a tiled system) produces"""
+    import numpy as np
+    import bench
+    import c_oracle as co
+    import fixtures as fx
+    inst, _ = bench.load_rollup_instance()
+    copies = 3
+    n_in, n_aux, mats, table = bench.materialise_rollup(copies)
+    one = co.R1csC(inst.num_input, inst.num_aux, *[co.Csr(p_, c_, v_) for p_, c_, v_ in inst.mats])
+    big = fx.tile_r1cs(one, copies)
+    assert (n_in, n_aux) == (big.num_input, big.num_aux)
+    for (ptr, col, cidx), m in zip(mats, (big.A, big.B, big.C)):
+        assert np.array_equal(ptr, m.ptr) and np.array_equal(col, m.col) and np.array_equal(table[cidx], m.val)

@@ -106,5 +106,5 @@ def test_pairing_check_on_the_gpu(ctx):
     import fawkes_crypto_amd as fk
     for case in K['pairing']:
         vk, proof = _as_groth16_instance(pairs(case['in']))
-        acc = fk.api.verify_batch(ctx, fk.api.vk_to_borsh(vk), np.zeros((3, 0, 4), np.uint64), [proof] * 3)
+        acc = fk.api.verify_batch(ctx, fk.api.vk_to_borsh(vk), np.zeros((3, 0, 4), np.uint64), np.frombuffer(proof * 3, np.uint8))
         assert list(acc) == [bool(case['expect'])] * 3, case['name']

@@ -171,3 +171,21 @@ def test_threaded_prover_same_bytes(oracle):
     want = oracle.prove(key, a, b, c, z, aa, bi, ba, r, s)
     for t in (2, 3, 8, 64):
         assert oracle.prove(key, a, b, c, z, aa, bi, ba, r, s, threads=t).tobytes() == want.tobytes(), t
+
+
+def test_synthesize_tiled_equals_replicated_system(oracle):
+    """orc_synthesize_tiled (what lets the CPU baseline run at the benchmark's full size) = orc_synthesize of the explicitly
+    replicated system: a, b, c and the three density maps, for gate counts of different residues"""
+    import numpy as np
+    import fixtures as fx
+    from test_gpu_r1cs import _ragged_system
+    for copies, gates in ((1, 50), (3, 41), (6, 64)):
+        base = _ragged_system(7 + copies, [0, 1, 1, 2, 5, 33], gates, 3, 40)
+        big = fx.tile_r1cs(base, copies)
+        nv = big.num_input + big.num_aux
+        rnd = np.random.default_rng(copies)
+        z = fx.co.limbs_arr([int(x) % R for x in rnd.integers(0, 2**63, nv).astype(object) * (2**190 + 12345)])
+        want = oracle.synthesize(big, z)
+        got = oracle.synthesize_tiled(base, copies, z)
+        for w, g in zip(want, got):
+            assert np.array_equal(w, g)
