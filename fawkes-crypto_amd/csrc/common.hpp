@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <map>
 #include <string>
 #include <vector>
@@ -38,13 +39,10 @@ struct EventPair { hipEvent_t a, b; uint64_t units; };
 // multiplication k run underneath the VALU-bound bucket accumulation of the other lane (msm.hip).
 struct MsmLane {
     hipStream_t st = nullptr;
-    hipStream_t st_sort = nullptr;  // FK_MSM_CU_SPLIT: digits / sort / size ordering on a CU subset of their own (else == st)
     hipEvent_t ev_in = nullptr;     // main stream -> lane: the scalars are ready
-    hipEvent_t ev_sorted = nullptr, ev_lane_done = nullptr;   // the lane's latest sort is complete (sort stream -> lane stream; the prover gates the quotient on it); lane stream -> next sort on this lane
+    hipEvent_t ev_sorted = nullptr;   // the lane's latest sort is complete (the prover gates the quotient on it)
     bool ev_sorted_valid = false;
-    bool ev_lane_done_valid = false;
     DevBuf digits, sorted, totals, starts, perm, overlist, tasktab, partials, s2_cnt1, s2_seg, s2_cnt2, s2_tmp_idx, s2_tmp_lo, buckets;
-    DevBuf redbuf;       // hierarchical bucket reduction: the levels' entries, ping-pong
     DevBuf buckets2;     // the buckets of a multiplication that reuses this lane's sort (B2 after B1): its accumulation is queued right behind B1's, before B1's tail has read `buckets`
     void *h_stage = nullptr;        // pinned host staging: counters read back, oversized-bucket list, task tables
     size_t h_cap = 0;
@@ -56,7 +54,6 @@ struct MsmLane {
 struct MsmTail {
     bool active = false;
     uint32_t cb = 0, wide = 0, W = 0, nblk = 0;     // window widths (msm.hip: MsmPlan), windows, partial sums per window
-    uint32_t hier = 0;              // hierarchical reduction: plain components P1..P_hier per window (0: nblk partial sums)
     hipEvent_t done = nullptr;
     void *h_wp = nullptr;           // pinned host copy of the window partial sums
     size_t h_cap = 0;
@@ -103,11 +100,9 @@ struct fk_ctx {
     // sorts-first schedule (prover.hip): with defer_back set, msm_begin queues only the front of a multiplication (digits, sort,
     // size ordering) and leaves the rest (accumulation, oversized buckets, reduction, download) here, to be queued by
     // msm_run_deferred once the caller has put the quotient between the two
-    bool sort_under = false;        // the next multiplication's sort runs underneath accumulations (H in the sorts-first schedule): experiment switches in msm.hip
     bool defer_back = false;
     std::vector<std::function<int()>> deferred, deferred_tails;     // accumulations; tails
     bool ev_z_recorded = false;
-    bool wit_early = false;         // fk_prove_r1cs_dev has begun the witness multiplications already (prove_witness_early)     // fk_prove_r1cs_dev recorded ev_z BEFORE the constraint-system evaluation (z is complete there)
     hipEvent_t ev_acc_done = nullptr; bool ev_acc_done_valid = false;   // behind the most recent bucket accumulation (any lane)
     bool wit_active = false;
     const fk::QueryIdx *qidx = nullptr;   // set by the resident-constraint-system entry points for the duration of a call
@@ -180,6 +175,20 @@ struct fk_key {
 
 namespace fk {
 
+// Tuning knobs.  A release build compiles the measured default in; `make EXP=1` (-DFK_EXPERIMENTS, libfawkes_hip_exp.so, loaded
+// with FK_LIB_VARIANT=exp) reads them from the environment for same-box A/B runs.  The run-time switches of a release build
+// are few and documented in DESIGN.md: FK_DEBUG, FK_MSM_PRECOMP, FK_MSM_PRE_MIN_LOG2, FK_PROVE_SORTS_FIRST, FK_SPMV_BIN_MIN,
+// FK_OVERLAP_WITNESS, FK_MULTI_HOST_EVENTS.
+static inline int tune(const char *name, int dflt) {
+#ifdef FK_EXPERIMENTS
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+#else
+    (void)name;
+    return dflt;
+#endif
+}
+
 static inline uint32_t ceil_log2_u64(uint64_t n) { uint32_t k = 0; while (((uint64_t)1 << k) < n) k++; return k; }
 
 // The h bases are sharded in blocks of the evaluation domain (m = n_h + 1 slots, the last one clipped): shard g holds
@@ -248,9 +257,6 @@ int msm_g2_end(fk_ctx *ctx, int tail, G2Xyzz *out);
 void msm_abandon(fk_ctx *ctx);
 int msm_run_deferred(fk_ctx *ctx, hipEvent_t after);
 int upload_deferred(fk_ctx *ctx, bool gate_on_main);      // queues the witness uploads fk_prove_r1cs_submit left for later
-// sorts-first schedule, resident constraint system: begins the witness multiplications (waiting for ctx->ev_z) and makes the main
-// stream wait for their sorts -- called BEFORE the evaluation of a, b, c is queued.  Returns 1 if it did, 0 if the schedule is off.
-int prove_witness_early(fk_ctx *ctx, const fk_key *key, const void *d_z, const void *d_a_aux, const void *d_b_in, const void *d_b_aux);      // see fk_ctx::defer_back
 void msm_release(fk_ctx *ctx);
 int msm_sync(fk_ctx *ctx);
 // reuse_sort: the scalars are the ones of the immediately preceding MSM call on this context (same pointer

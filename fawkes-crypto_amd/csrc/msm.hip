@@ -28,7 +28,6 @@
 //                      kernel folds the workgroups' partial sums, the window sums are copied to pinned host memory.
 //   6. host            W window sums are Horner-combined (cw doublings each) -- microseconds.
 #include "common.hpp"
-#include "field29.hpp"
 #include <algorithm>
 #include <string.h>
 #include <type_traits>
@@ -74,7 +73,7 @@ static constexpr uint32_t S2_MAX_HI = FK_S2_MAX_HI;     // high bins of the firs
 // buckets) was measured slower on the witness MSMs: fewer windows win even at bucket loads of ~6 once lanes are
 // size-ordered (G2 accumulate 22.6 ms at c = 20 vs 26.2 ms at c = 16 for 16.7M scalars of which 3.3M are dense).
 // merged: the bases carry precomputed levels (KeyPre), all windows share ONE bucket set -- the reduction costs a W-th, so the
-// windows can be wider (FK_MSM_PRE_DC, default +2 bits, up to the sort's limit of 22)
+// windows can be wider (FK_MSM_PRE_DC: +3 bits, up to the sort's limit of 22)
 static MsmPlan make_plan(size_t n, unsigned forced_c, bool merged = false) {
     MsmPlan p{};
     p.n = n;
@@ -82,14 +81,8 @@ static MsmPlan make_plan(size_t n, unsigned forced_c, bool merged = false) {
     uint32_t lg = 0; while (((size_t)1 << (lg + 1)) <= nd + nd / 2) lg++;     // log2 rounded (2^25 - 1 counts as 2^25)
     // large MSMs: bucket loads of ~64 are enough now that lanes are size-ordered, so c grows with n (fewer digits
     // per scalar: 13 at c = 20 instead of 16)
-    static int t_small = -1, t_delta = -1, t_sig = -1, t_pre_dc = 3;
-    if (t_small < 0) {   // tuning knobs (environment, read once)
-        const char *e;
-        t_small = (e = getenv("FK_MSM_C_SMALL")) ? atoi(e) : 17;
-        t_delta = (e = getenv("FK_MSM_C_DELTA")) ? atoi(e) : 5;
-        t_sig = (e = getenv("FK_MSM_CAP_SIGMA")) ? atoi(e) : 6;
-        t_pre_dc = (e = getenv("FK_MSM_PRE_DC")) ? atoi(e) : 3;
-    }
+    // tuning knobs: compile-time constants in a release build, read from the environment in an -DFK_EXPERIMENTS build (common.hpp: tune)
+    static const int t_small = tune("FK_MSM_C_SMALL", 17), t_delta = tune("FK_MSM_C_DELTA", 5), t_sig = tune("FK_MSM_CAP_SIGMA", 6), t_pre_dc = tune("FK_MSM_PRE_DC", 3);
     uint32_t c = forced_c ? forced_c : (lg >= 22 ? lg - t_delta : (lg >= 18 ? (uint32_t)t_small : (lg >= 6 ? lg - 2 : 4)));
     if (merged && !forced_c) c = (uint32_t)std::max(2, (int)c + t_pre_dc);
     if (c < 2) c = 2;
@@ -117,15 +110,13 @@ static MsmPlan make_plan(size_t n, unsigned forced_c, bool merged = false) {
     p.cap_top = p.cap;
     // bucket reduction: buckets per lane (<= 64).  L = 8 everywhere below 2^18 buckets (shorter serial chains) was measured
     // neutral-to-worse: the reduction already runs underneath the next multiplication.  FK_MSM_RED_L overrides (tuning).
-    static int t_redl = -1;
-    if (t_redl < 0) { const char *e = getenv("FK_MSM_RED_L"); t_redl = e ? atoi(e) : 0; }
+    static const int t_redl = tune("FK_MSM_RED_L", 0);
     p.L = p.B >= (1u << 18) ? 64 : (p.B >= (1u << 17) ? p.B / 2048 : (p.B >= 8192 ? p.B / 4096 : 1));      // 2^16 buckets: 16 per lane (32: 2^20 13.0 -> 12.0 ms per proof, 8: 15.4); 2^17: 64 (32: 2^23 44.1 -> 45.1)
     if (t_redl > 0 && (uint32_t)t_redl <= p.B) p.L = (uint32_t)t_redl;
     p.T = p.B / p.L;
     p.nblk = (p.T + 255) / 256;
     // low bits sorted by the SECOND pass (its bins; the first pass splits by the bits above them).  FK_MSM_LB = 10 .. 12.
-    static int t_lb = -1;
-    if (t_lb < 0) { const char *e = getenv("FK_MSM_LB"); t_lb = e ? atoi(e) : 10; if (t_lb < 10 || t_lb > 12) t_lb = 10; }
+    static const int t_lb = std::min(12, std::max(10, tune("FK_MSM_LB", 10)));
     p.LB = (c - 1) < (uint32_t)t_lb ? (c - 1) : (uint32_t)t_lb;
     while ((p.B >> p.LB) > S2_MAX_HI) p.LB++;          // the first pass's LDS tables hold S2_MAX_HI bins
     p.nlo = 1u << p.LB;
@@ -451,13 +442,10 @@ __global__ __launch_bounds__(1024) void s2_scatter2_kernel(const uint32_t *tmp_i
     }
 }
 
-// The scatter kernels again, shaped to fit where ONE accumulate workgroup has left (256 lanes = one wave per SIMD, <= 120
-// registers; or 512 lanes at <= 60): the 1024-lane forms above need 128 / 70 registers x 4 waves per SIMD, i.e. a compute unit
-// that the accumulation (4 waves per SIMD at 115 registers -- the whole register file) has drained completely, and every
-// drained unit is VALU time lost.  A lane now owns S2_TILE / NT entries and keeps nothing about them between the phases: the
-// counting phase only counts, the placing phase reads the entries a second time (the tile was read a moment ago: L2) and draws
-// each one's slot from a per-bin LDS cursor.  Same output as the wide forms up to the order inside a bucket (both rank with
-// LDS atomics).
+// First-pass scatter (two-atomic form): a lane owns S1_TILE / NT entries and keeps nothing about them between the phases -- the
+// counting phase only counts, the placing phase draws each entry's slot from a per-bin LDS cursor (round 1's register-ranked
+// form needed 128 registers and spilled).  256- and 512-lane shapes of both scatter kernels ("thin" workgroups that fit where one
+// accumulate workgroup has left) were built and measured in rounds 1 and 2: slower alone and no better underneath -- removed.
 template <uint32_t NT>
 static __device__ __forceinline__ uint32_t block_excl_scan_nt(uint32_t v, uint32_t *wsum, uint32_t *total) {
     constexpr uint32_t NW = NT / 64;
@@ -573,63 +561,9 @@ static __device__ __forceinline__ void s2_scatter1n_body(const uint32_t *digits,
     }
 }
 
-template <uint32_t NT>
-static __device__ __forceinline__ void s2_scatter2n_body(const uint32_t *tmp_idx, const uint16_t *tmp_lo, size_t n, uint32_t nhi, uint32_t nlo, uint32_t B,
-                                                           const uint32_t *tile_start, uint32_t nseg, const uint32_t *seg_start, const uint32_t *seg_size,
-                                                           const uint32_t *cnt2, const uint32_t *starts, uint32_t *sorted) {
-    constexpr uint32_t BPL = 1024 / NT;
-    __shared__ uint32_t lcnt[1024];          // per-bin count
-    __shared__ uint32_t lexc[1024];          // exclusive offset inside the tile, advanced to the bin's end by the placing phase
-    __shared__ uint32_t wsum[16];
-    __shared__ uint32_t gbase[1024];
-    __shared__ uint32_t stage_idx[S2_TILE];
-    __shared__ uint16_t stage_lo[S2_TILE];
-    const uint32_t tile = blockIdx.x, tid = threadIdx.x;
-    if (tile >= tile_start[nseg]) return;
-    const uint32_t sgm = s2_find_segment(tile_start, nseg, tile), w = sgm / nhi, h = sgm % nhi, t = tile - tile_start[sgm];
-    for (uint32_t b = tid; b < 1024; b += NT) {
-        lcnt[b] = 0;
-        gbase[b] = b < nlo ? starts[(size_t)w * B + (size_t)h * nlo + b] + cnt2[(size_t)tile * nlo + b] : 0;
-    }
-    __syncthreads();
-    const uint32_t size = seg_size[sgm], lo = t * S2_TILE, cnt = (lo + S2_TILE < size ? lo + S2_TILE : size) - lo;
-    const uint16_t *src_lo = tmp_lo + (size_t)w * n + seg_start[sgm] + lo;
-    const uint32_t *src_idx = tmp_idx + (size_t)w * n + seg_start[sgm] + lo;
-#pragma unroll 8
-    for (uint32_t k = tid; k < cnt; k += NT) atomicAdd(&lcnt[src_lo[k]], 1u);
-    __syncthreads();
-    uint32_t c[BPL], mine = 0;
-#pragma unroll
-    for (uint32_t i = 0; i < BPL; i++) { c[i] = lcnt[tid * BPL + i]; mine += c[i]; }
-    uint32_t all_;
-    uint32_t ex = block_excl_scan_nt<NT>(mine, wsum, &all_);
-#pragma unroll
-    for (uint32_t i = 0; i < BPL; i++) { lexc[tid * BPL + i] = ex; ex += c[i]; }
-    __syncthreads();
-#pragma unroll 8
-    for (uint32_t k = tid; k < cnt; k += NT) {
-        const uint32_t e_lo = src_lo[k], q = atomicAdd(&lexc[e_lo], 1u);
-        stage_idx[q] = src_idx[k]; stage_lo[q] = (uint16_t)e_lo;
-    }
-    __syncthreads();
-    uint32_t *out = sorted + (size_t)w * n;
-#pragma unroll 1
-    for (uint32_t q = tid; q < cnt; q += NT) {
-        const uint32_t b = stage_lo[q];
-        out[gbase[b] + (q - (lexc[b] - lcnt[b]))] = stage_idx[q];
-    }
-}
-
 #define S2N_ARGS1 const uint32_t *digits, size_t n, size_t chunk, uint32_t nchunks, uint32_t LB, uint32_t nhi, const uint32_t *cnt1, const uint32_t *seg_start, uint32_t *tmp_idx, uint16_t *tmp_lo
 #define S2N_PASS1 digits, n, chunk, nchunks, LB, nhi, cnt1, seg_start, tmp_idx, tmp_lo
-#define S2N_ARGS2 const uint32_t *tmp_idx, const uint16_t *tmp_lo, size_t n, uint32_t nhi, uint32_t nlo, uint32_t B, const uint32_t *tile_start, uint32_t nseg, const uint32_t *seg_start, const uint32_t *seg_size, const uint32_t *cnt2, const uint32_t *starts, uint32_t *sorted
-#define S2N_PASS2 tmp_idx, tmp_lo, n, nhi, nlo, B, tile_start, nseg, seg_start, seg_size, cnt2, starts, sorted
-__global__ __launch_bounds__(256) void s2_scatter1_n256_kernel(S2N_ARGS1) { s2_scatter1n_body<256>(S2N_PASS1); }
-__global__ __launch_bounds__(512) void s2_scatter1_n512_kernel(S2N_ARGS1) { s2_scatter1n_body<512>(S2N_PASS1); }
 __global__ __launch_bounds__(1024) void s2_scatter1_n1024_kernel(S2N_ARGS1) { s2_scatter1n_body<1024>(S2N_PASS1); }
-__global__ __launch_bounds__(256) void s2_scatter2_n256_kernel(S2N_ARGS2) { s2_scatter2n_body<256>(S2N_PASS2); }
-__global__ __launch_bounds__(512) void s2_scatter2_n512_kernel(S2N_ARGS2) { s2_scatter2n_body<512>(S2N_PASS2); }
-__global__ __launch_bounds__(1024) void s2_scatter2_n1024_kernel(S2N_ARGS2) { s2_scatter2n_body<1024>(S2N_PASS2); }
 
 // ------------------------------------------------------------------------------------------ bucket -> lane assignment
 // A wave runs as long as its longest bucket, so lanes are handed buckets of (nearly) equal length: buckets are
@@ -737,19 +671,14 @@ static __device__ __forceinline__ void block_reduce_256(Xyzz<F> &acc, Xyzz<F> *s
 }
 
 // ------------------------------------------------------------------------------------------ bucket accumulation
-// The per-lane walk of a bucket.  G1 with L29: the accumulator lives on 9 x 29-bit limbs (field29.hpp: no carry-out per
-// multiply-accumulate, no conditional subtractions); points are re-sliced on load, the bucket on store.  Otherwise the 8 x 32
-// XYZZ accumulator of curve.hpp.
+// The per-lane walk of a bucket: the 8 x 32-bit XYZZ accumulator of curve.hpp.  (A 9 x 29-bit-limb accumulator -- no carry-out
+// per multiply-accumulate, no conditional subtractions -- was built in round 2, bit-exact and NOT faster in place: 234 against
+// 216 ms per proof; DESIGN.md section 3.3.  Removed in round 3.)
 #if defined(__HIP_DEVICE_COMPILE__)
 template <class F, int MODE> struct Walker {       // MODE 0
     Xyzz<F> acc = Xyzz<F>::inf();
     __device__ __forceinline__ void add(const Affine<F> &p, bool neg) { acc.add_mixed(affine_neg_if(p, neg)); }
     __device__ __forceinline__ Xyzz<F> result() const { return acc; }
-};
-template <> struct Walker<Fq, 1> {
-    Xyzz29 acc = Xyzz29::inf();
-    __device__ __forceinline__ void add(const G1Affine &p, bool neg) { acc.add_mixed(p, neg); }
-    __device__ __forceinline__ G1Xyzz result() const { return acc.to_resident(); }
 };
 // MODE 2: the accumulator's coordinates live in [0, 2p) (field.hpp, LAZY): no conditional subtraction behind any of the ten
 // products of a mixed addition; the bucket is made canonical when it is stored.  A loaded point is canonical, hence valid.
@@ -1052,58 +981,6 @@ __global__ __launch_bounds__(256) void msm_fold_partials_kernel(const Xyzz<F> *w
     if (threadIdx.x == 0) out[w] = acc;
 }
 
-// Hierarchical form: no lane walks more than 8 buckets and nothing is multiplied by its offset on the device.
-// With slot s = 8 t + j (lane t, j < 8) and t = 64 v + l (wave v, lane l) and so on,
-//     sum_s (s + 1) S_s = P1 + 8 (P2 + 64 (P3 + 64 (P4 + ...)))
-// where P1 = sum over lanes of the local sums with weights 1..8, and P(k+1) = sum over the level-k waves of sum_l l T_l, T_l
-// being the lane totals of that level: a weighted sum over the 64 lanes of a wave is the sum of the suffix sums 1..63
-// (shuffles).  Level 1 writes (p1, p2, T) per wave; every further level sums the plain components and adds one weighted
-// component, 64 entries per wave, until one entry is left; the host does the Horner step (3 + 6 + 6 ... doublings).  The serial
-// chain is 16 + 18 additions at level 1 and 6 (NP + 2) per further level instead of 128 + ~30 + 8 -- but 1.6x the additions in
-// total, which is why it is an experiment switch and not the default (see msm_begin).
-template <class F>
-static __device__ __forceinline__ Xyzz<F> wave_suffix_scan(Xyzz<F> v) {       // lane l: sum over lanes m >= l
-    const uint32_t lane = threadIdx.x & 63;
-#pragma unroll 1
-    for (int off = 1; off < 64; off <<= 1) {
-        Xyzz<F> o = shfl_down_obj(v, off);
-        if (lane + off < 64) v.add(o);
-    }
-    return v;
-}
-template <class F>
-__global__ __launch_bounds__(256) void msm_reduce_l1_kernel(const Xyzz<F> *buckets, uint32_t B, uint32_t n_out, Xyzz<F> *out) {
-    const uint32_t w = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;       // B / 8 lanes per window
-    const Xyzz<F> *bk = buckets + (size_t)w * B + (size_t)t * 8;
-    Xyzz<F> run = Xyzz<F>::inf(), acc = Xyzz<F>::inf();
-    for (uint32_t j = 8; j-- > 0;) { run.add(bk[j]); acc.add(run); }     // acc = sum (j + 1) S_j, run = sum S_j
-    wave_reduce(acc);                                                      // lane 0: p1
-    const Xyzz<F> suf = wave_suffix_scan(run);
-    Xyzz<F> wsum = lane ? suf : Xyzz<F>::inf();
-    wave_reduce(wsum);                                                     // lane 0: sum_l l T_l
-    if (lane == 0) {
-        Xyzz<F> *o = out + ((size_t)w * n_out + (t >> 6)) * 3;
-        o[0] = acc; o[1] = wsum; o[2] = suf;
-    }
-}
-// entries of NP plain components + the total, 64 per wave -> entries of NP + 1 plain components + the total
-template <class F>
-__global__ __launch_bounds__(256) void msm_reduce_lk_kernel(const Xyzz<F> *in, uint32_t n_in, uint32_t NP, uint32_t n_out, Xyzz<F> *out) {
-    const uint32_t w = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
-    if ((e & ~63u) >= n_in) return;          // whole wave beyond the end
-    const Xyzz<F> *ie = in + ((size_t)w * n_in + e) * (NP + 1);
-    Xyzz<F> *o = out + ((size_t)w * n_out + (e >> 6)) * (NP + 2);
-    for (uint32_t k = 0; k < NP; k++) {
-        Xyzz<F> v = e < n_in ? ie[k] : Xyzz<F>::inf();
-        wave_reduce(v);
-        if (lane == 0) o[k] = v;
-    }
-    const Xyzz<F> suf = wave_suffix_scan(e < n_in ? ie[NP] : Xyzz<F>::inf());
-    Xyzz<F> wsum = lane ? suf : Xyzz<F>::inf();
-    wave_reduce(wsum);
-    if (lane == 0) { o[NP] = wsum; o[NP + 1] = suf; }
-}
-
 // ------------------------------------------------------------------------------------------ host driver
 #define FK_DBG_ST(ctx, st, name)                                                                  \
     do {                                                                                          \
@@ -1114,37 +991,9 @@ __global__ __launch_bounds__(256) void msm_reduce_lk_kernel(const Xyzz<F> *in, u
         }                                                                                         \
     } while (0)
 
-// FK_MSM_CU_SPLIT=k (1..4, experiment): of every 8 compute units k run only the memory-bound front of a multiplication
-// (digits, sort, size ordering: a stream with that CU mask), the other 8 - k only its accumulation and tail.  Without it a sort
-// workgroup (1024 lanes, > 100 KB of LDS) and the accumulation's workgroups evict each other from whole CUs.
-static int cu_split() {
-    static int k = -1;
-    if (k < 0) { const char *e = getenv("FK_MSM_CU_SPLIT"); k = e ? atoi(e) : 0; if (k < 0 || k > 4) k = 0; }
-    return k;
-}
 static int lane_init(fk_ctx *ctx, MsmLane &ln) {
     if (ln.st) return FK_OK;
-    const int k = cu_split();
-    if (k) {
-        int ncu = 0;
-        FK_HIP(ctx, hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device));
-        const uint32_t words = (uint32_t)((ncu + 31) / 32);
-        std::vector<uint32_t> m_sort(words, 0), m_acc(words, 0);
-        for (int i = 0; i < ncu; i++) { if ((i & 7) < k) m_sort[i >> 5] |= 1u << (i & 31); else m_acc[i >> 5] |= 1u << (i & 31); }
-        FK_HIP(ctx, hipExtStreamCreateWithCUMask(&ln.st, words, m_acc.data()));
-        FK_HIP(ctx, hipExtStreamCreateWithCUMask(&ln.st_sort, words, m_sort.data()));
-        FK_HIP(ctx, hipEventCreateWithFlags(&ln.ev_lane_done, hipEventDisableTiming));
-    } else {
-        // FK_MSM_H_PRIO=1 (experiment): the last lane -- H's in the sorts-first schedule -- gets a high-priority stream
-        static int t_hprio = -1;
-        if (t_hprio < 0) { const char *e = getenv("FK_MSM_H_PRIO"); t_hprio = e ? atoi(e) : 0; }
-        if (t_hprio && &ln == &ctx->lanes[MSM_LANES - 1]) {
-            int lo_ = 0, hi_ = 0;
-            FK_HIP(ctx, hipDeviceGetStreamPriorityRange(&lo_, &hi_));
-            FK_HIP(ctx, hipStreamCreateWithPriority(&ln.st, hipStreamNonBlocking, hi_));
-        } else FK_HIP(ctx, hipStreamCreateWithFlags(&ln.st, hipStreamNonBlocking));
-        ln.st_sort = ln.st;
-    }
+    FK_HIP(ctx, hipStreamCreateWithFlags(&ln.st, hipStreamNonBlocking));
     FK_HIP(ctx, hipEventCreateWithFlags(&ln.ev_in, hipEventDisableTiming));
     FK_HIP(ctx, hipEventCreateWithFlags(&ln.ev_sorted, hipEventDisableTiming));
     return FK_OK;
@@ -1181,13 +1030,6 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
         if (pm.cb == pre->cb && pm.wide == pre->wide && pm.W == pre->W) { p = pm; merged = true; }
     }
     const Affine<F> *d_lev = merged ? (const Affine<F> *)pre->lev : nullptr;
-    // G2: shorter lanes in the bucket reduction (FK_MSM_RED_L_G2, experiment): its serial chain is what a proof ends on (a G2
-    // addition is 3.3 G1 ones) -- measured: 64 (the plan's) 170.4, 32 170.8, 16 172.6 ms per proof; off
-    if (!std::is_same<F, Fq>::value) {
-        static int t_l2 = -1;
-        if (t_l2 < 0) { const char *e = getenv("FK_MSM_RED_L_G2"); t_l2 = e ? atoi(e) : 0; }
-        if (t_l2 > 0 && p.L > (uint32_t)t_l2 && (uint32_t)t_l2 <= p.B) { p.L = (uint32_t)t_l2; p.T = p.B / p.L; p.nblk = (p.T + 255) / 256; }
-    }
     // lane: the next one in turn, unless this call reuses the previous call's sort (B2 after B1).  With three lanes the
     // multiplication after the G2 one does not queue behind its long overflow / reduction tail (at 2^22 that tail was 5.4 ms
     // during which nothing else ran: 31 % of the proof).
@@ -1196,40 +1038,26 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
     const int li = have_sort ? ctx->lane_prev : ctx->lane_next;
     MsmLane &ln = ctx->lanes[li];
     FK_TRY(lane_init(ctx, ln));
-    static int t_lanes = -1, t_serial_sort = -1;      // experiments: FK_MSM_LANES = 1..3 overrides the lane count; FK_MSM_SORT_ALONE=1 see below
-    if (t_lanes < 0) { const char *e = getenv("FK_MSM_LANES"); t_lanes = e ? atoi(e) : 0; e = getenv("FK_MSM_SORT_ALONE"); t_serial_sort = e ? atoi(e) : 0; }
-    const int n_lanes = (t_lanes >= 1 && t_lanes <= MSM_LANES) ? t_lanes : (ctx->lanes_in_use >= 2 && ctx->lanes_in_use <= MSM_LANES ? ctx->lanes_in_use : MSM_LANES);
+    // FK_MSM_LANES (experiment builds): fewer lanes -- never while pieces are deferred (sorts-first schedule): its deferred
+    // accumulations and tails hold pointers into their lane's buffers, so every multiplication needs a lane of its own there
+    static const int t_lanes = tune("FK_MSM_LANES", 0);
+    const int n_lanes = (t_lanes >= 1 && t_lanes <= MSM_LANES && !ctx->defer_back && ctx->deferred.empty())
+                            ? t_lanes : (ctx->lanes_in_use >= 2 && ctx->lanes_in_use <= MSM_LANES ? ctx->lanes_in_use : MSM_LANES);
     ctx->lane_prev = li; ctx->lane_next = (li + 1) % n_lanes;
     hipStream_t st = ln.st;
-    const bool split = ln.st_sort != ln.st;
-    hipStream_t ss = ln.st_sort;              // the front of the multiplication (== st unless FK_MSM_CU_SPLIT)
-    // FK_MSM_SORT_ALONE=1: this multiplication's digits / sort do not start before the previous multiplication's accumulation
-    // has finished (they then run at full memory speed instead of crawling underneath it); its latency-bound tail still overlaps
-    if (t_serial_sort == 1 && !have_sort && ctx->ev_acc_done_valid) FK_HIP(ctx, hipStreamWaitEvent(ss, ctx->ev_acc_done, 0));
-    if (ready) {
-        FK_HIP(ctx, hipStreamWaitEvent(ss, ready, 0));
-        if (split) FK_HIP(ctx, hipStreamWaitEvent(st, ready, 0));
-    } else {
+    hipStream_t ss = st;                      // the front of the multiplication runs on the lane's stream as well
+    if (ready) FK_HIP(ctx, hipStreamWaitEvent(ss, ready, 0));
+    else {
         FK_HIP(ctx, hipEventRecord(ln.ev_in, ctx->stream));        // scalars / bases produced on the main stream
         FK_HIP(ctx, hipStreamWaitEvent(ss, ln.ev_in, 0));
-        if (split) FK_HIP(ctx, hipStreamWaitEvent(st, ln.ev_in, 0));
     }
-    // the lane's sort buffers are read by its previous multiplication's accumulation / overflow kernels
-    if (split && !have_sort && ln.ev_lane_done_valid) FK_HIP(ctx, hipStreamWaitEvent(ss, ln.ev_lane_done, 0));
     const size_t WB = (size_t)p.W * p.B;
     const uint32_t WR = merged ? 1 : p.W;      // bucket sets to reduce
-    // bucket reduction: FK_MSM_RED_HIER=1 selects the hierarchical form (msm_reduce_l1 / _lk kernels) from 2048 buckets on.
-    // Measured and NOT the default: its serial chain is 2.5x shorter, but the wave-level steps (18 shuffle additions per lane
-    // and level) make it 1.6x the additions of the flat form, and a tail's work is added to the accumulation it runs underneath:
-    // 171.5 -> 178.3 ms per proof at 2^25, 10.1 -> 13.2 at 2^20 (profiles/r02_sorts_first_probe.log).
-    static int t_hier = -1;
-    if (t_hier < 0) { const char *e = getenv("FK_MSM_RED_HIER"); t_hier = e ? atoi(e) : 0; }
-    const bool hier = t_hier != 0 && p.B >= 2048;
-    uint32_t hier_np = 0; const uint32_t hier_n1 = p.B / 512;     // plain components of the final entry; entries after level 1
-    if (hier) { hier_np = 2; for (uint32_t nn = hier_n1; nn > 1; nn = (nn + 63) / 64) hier_np++; }
-    const size_t wp_bytes = (size_t)WR * (hier ? hier_np + 1 : 1) * sizeof(Xyzz<F>);        // flat form: ONE point per window (folded on the device)
-    const size_t wp_dev_bytes = hier ? wp_bytes : (size_t)WR * (p.nblk + 1) * sizeof(Xyzz<F>);     // ... behind the nblk partial sums of every window
-    const size_t red_half = hier ? (size_t)WR * hier_n1 * 3 * sizeof(Xyzz<F>) : 0;
+    // bucket reduction: the flat form (up to 64 buckets per lane, then a double-and-add by the lane's offset).  A hierarchical form
+    // (8 buckets per lane, wave-level suffix sums) was built in round 2: a 2.5x shorter serial chain, 1.6x the additions, slower
+    // everywhere (171.5 -> 178.3 ms per proof at 2^25) -- removed in round 3.
+    const size_t wp_bytes = (size_t)WR * sizeof(Xyzz<F>);                      // ONE point per bucket set (folded on the device)
+    const size_t wp_dev_bytes = (size_t)WR * (p.nblk + 1) * sizeof(Xyzz<F>);  // ... behind the nblk partial sums of every set
     // oversized buckets: at most OVER_MAX are tabled; their segment tasks are bounded by max(2048, W n / SEG_MAX) + one per bucket
     const size_t max_tasks = std::max<size_t>(2048, (size_t)p.W * n / SEG_MAX) + OVER_MAX + 64;
     // Growing a buffer frees the old one: everything queued on this lane must be finished first.
@@ -1241,12 +1069,11 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
         {&ln.perm, WB * 4 + SIZE_BINS * 4}, {&ln.overlist, OVER_MAX * sizeof(OverEntry) + sizeof(MsmDyn) + 64}, {have_sort ? &ln.buckets2 : &ln.buckets, WB * sizeof(Xyzz<F>)},
         {&ln.tasktab, max_tasks * sizeof(Task) + OVER_MAX * sizeof(OverBucket) + 64}, {&ln.partials, max_tasks * sizeof(Xyzz<F>)},
         {&ln.s2_cnt1, (size_t)p.W * p.nchunks * p.nhi * 4}, {&ln.s2_seg, ((size_t)nseg * 4 + 2) * 4}, {&ln.s2_cnt2, max_tiles * p.nlo * 4},
-        {&ln.s2_tmp_idx, (size_t)p.W * n * 4}, {&ln.s2_tmp_lo, (size_t)p.W * n * 2}, {&ln.redbuf, 2 * red_half + 64}};
+        {&ln.s2_tmp_idx, (size_t)p.W * n * 4}, {&ln.s2_tmp_lo, (size_t)p.W * n * 2}};
     bool grow = false;
     for (const Need &nd : needs) grow = grow || nd.bytes > nd.b->cap;
     if (grow) {
         FK_HIP(ctx, hipStreamSynchronize(st));
-        if (split) FK_HIP(ctx, hipStreamSynchronize(ss));
         for (const Need &nd : needs) FK_HIP(ctx, nd.b->reserve(nd.bytes));
         if (!have_sort) ln.last_sort_scalars = nullptr;
     }
@@ -1278,22 +1105,7 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
         hipLaunchKernelGGL(s2_hist1_kernel, dim3(p.nchunks, p.W), dim3(SORT_THREADS), p.nhi * 4, ss, digits, n, p.chunk, p.nchunks, p.LB, p.nhi, cnt1);
         hipLaunchKernelGGL(s2_prefix1_kernel, dim3(p.W), dim3(1024), p.nhi * 4, ss, cnt1, p.nchunks, p.nhi, seg_size, seg_start, seg_tiles);
         hipLaunchKernelGGL(s2_tile_prefix_kernel, dim3(1), dim3(1024), 0, ss, seg_tiles, nseg, tile_start);
-        // lanes per scatter workgroup, per pass (FK_MSM_SORT_NT1: 256 / 512 / 1024, all two-atomic forms; FK_MSM_SORT_NT2: 0 = the
-        // register-ranked 1024-lane form, 256 / 512 / 1024 = two-atomic forms)
-        static int t_nt1 = -1, t_nt2 = -1;
-        if (t_nt1 < 0) {
-            const char *e = getenv("FK_MSM_SORT_NT1"); t_nt1 = e ? atoi(e) : 1024;
-            e = getenv("FK_MSM_SORT_NT2"); t_nt2 = e ? atoi(e) : 0;
-        }
-        static int t_under1 = -1, t_under2 = -1;      // FK_MSM_UNDER_NT1 / _NT2: the same choice for a sort that runs underneath accumulations (ctx->sort_under)
-        if (t_under1 < 0) { const char *e = getenv("FK_MSM_UNDER_NT1"); t_under1 = e ? atoi(e) : t_nt1; e = getenv("FK_MSM_UNDER_NT2"); t_under2 = e ? atoi(e) : t_nt2; }
-        const int nt1 = ctx->sort_under ? t_under1 : t_nt1, nt2 = p.nlo > 1024 ? 0 : (ctx->sort_under ? t_under2 : t_nt2);     // the two-atomic second pass is built for <= 1024 bins
-        if (nt1 == 256)
-            hipLaunchKernelGGL(s2_scatter1_n256_kernel, dim3(p.nchunks, p.W), dim3(256), 0, ss, digits, n, p.chunk, p.nchunks, p.LB, p.nhi, cnt1, seg_start, tmp_idx, tmp_lo);
-        else if (nt1 == 512)
-            hipLaunchKernelGGL(s2_scatter1_n512_kernel, dim3(p.nchunks, p.W), dim3(512), 0, ss, digits, n, p.chunk, p.nchunks, p.LB, p.nhi, cnt1, seg_start, tmp_idx, tmp_lo);
-        else
-            hipLaunchKernelGGL(s2_scatter1_n1024_kernel, dim3(p.nchunks, p.W), dim3(1024), 0, ss, digits, n, p.chunk, p.nchunks, p.LB, p.nhi, cnt1, seg_start, tmp_idx, tmp_lo);
+        hipLaunchKernelGGL(s2_scatter1_n1024_kernel, dim3(p.nchunks, p.W), dim3(1024), 0, ss, digits, n, p.chunk, p.nchunks, p.LB, p.nhi, cnt1, seg_start, tmp_idx, tmp_lo);
         FK_HIP(ctx, hipGetLastError());
         FK_DBG_ST(ctx, ss, "msm_sort_pass1");
         // The second pass is launched over the host's BOUND on the tile count (every segment's last tile may be partial:
@@ -1304,13 +1116,6 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
             hipLaunchKernelGGL(s2_hist2_kernel, dim3(n_tiles), dim3(256), p.nlo * 4, ss, tmp_lo, n, p.nhi, p.nlo, tile_start, nseg, seg_start, seg_size, cnt2);
         }
         hipLaunchKernelGGL(s2_prefix2_kernel, dim3((nseg + 3) / 4), dim3(256), 0, ss, cnt2, nseg, p.nhi, p.nlo, p.B, tile_start, seg_start, p.cap ? p.cap : 1u, totals, starts, dyn);
-        if (nt2 == 256)
-            hipLaunchKernelGGL(s2_scatter2_n256_kernel, dim3(n_tiles), dim3(256), 0, ss, tmp_idx, tmp_lo, n, p.nhi, p.nlo, p.B, tile_start, nseg, seg_start, seg_size, cnt2, starts, sorted);
-        else if (nt2 == 512)
-            hipLaunchKernelGGL(s2_scatter2_n512_kernel, dim3(n_tiles), dim3(512), 0, ss, tmp_idx, tmp_lo, n, p.nhi, p.nlo, p.B, tile_start, nseg, seg_start, seg_size, cnt2, starts, sorted);
-        else if (nt2 == 1024)
-            hipLaunchKernelGGL(s2_scatter2_n1024_kernel, dim3(n_tiles), dim3(1024), 0, ss, tmp_idx, tmp_lo, n, p.nhi, p.nlo, p.B, tile_start, nseg, seg_start, seg_size, cnt2, starts, sorted);
-        else
         {
             if (p.nlo <= 1024) hipLaunchKernelGGL(s2_scatter2_kernel<1024>, dim3(n_tiles), dim3(1024), 0, ss, tmp_idx, tmp_lo, n, p.nhi, p.nlo, p.B, tile_start, nseg, seg_start, seg_size, cnt2, starts, sorted);
             else if (p.nlo <= 2048) hipLaunchKernelGGL(s2_scatter2_kernel<2048>, dim3(n_tiles), dim3(1024), 0, ss, tmp_idx, tmp_lo, n, p.nhi, p.nlo, p.B, tile_start, nseg, seg_start, seg_size, cnt2, starts, sorted);
@@ -1323,8 +1128,7 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
     // oversized buckets (skewed scalars), size ordering: all on the device (MsmDyn) -- nothing below waits for the host.  With a
     // reused sort (B2 after B1) the lane's state and tables are still valid.
     if (!have_sort) {
-        static int t_many = -1;
-        if (t_many < 0) { const char *e = getenv("FK_MSM_OVER_MANY"); t_many = e ? atoi(e) : 2048; }
+        static const int t_many = tune("FK_MSM_OVER_MANY", 2048);
         // "few": every oversized bucket costs a wave per segment plus a 256-lane fold workgroup -- with 4e5 of them, what round 1's
         // WB / 64 allowed at 2^25, the overflow + fold kernels took 70 ms of a proof whose witness held each value 341 times
         const uint32_t many = (uint32_t)std::min<size_t>(std::max<size_t>((size_t)t_many, WB / 8192), OVER_MAX - 64);
@@ -1357,28 +1161,17 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
 
     // ---- from here on nothing waits for the host
     if (!have_sort) { FK_HIP(ctx, hipEventRecord(ln.ev_sorted, ss)); ln.ev_sorted_valid = true; }
-    if (split) FK_HIP(ctx, hipStreamWaitEvent(st, ln.ev_sorted, 0));
-    tl.active = true; tl.cb = p.cb; tl.wide = p.wide; tl.W = WR; tl.nblk = hier ? hier_np + 1 : 1; tl.hier = hier_np;     // merged: one "window" of weight 1
+    tl.active = true; tl.cb = p.cb; tl.wide = p.wide; tl.W = WR; tl.nblk = 1;     // merged: one "window" of weight 1
     *tail_out = ti;
     // The back of the multiplication in two pieces -- the accumulation, and the tail (oversized buckets, reduction, download) --
     // queued now, or by msm_run_deferred (ctx->defer_back): all accumulations first, then all tails, so that on the B pair's lane
     // the G2 accumulation follows the G1 one at once and both tails come behind (B2 has a bucket buffer of its own for that).
     MsmLane *lnp = &ln; MsmTail *tlp = &tl;
-    // FK_MSM_LIMB29=1: G1 accumulator on 9 x 29-bit limbs (field29.hpp).  Measured and NOT the default: the product alone is
-    // 155 against 134 G/s, but the mixed addition around it (re-slicing two coordinates per point, signed carry chains for the
-    // five differences, 20 % more multiplier operations at an eighth of the simple-ALU rate) comes out at 11.9 against 12.1 G
-    // additions/s in registers (tools/mulbench/addbench.hip) and 234 against 216 ms per proof in place
-    // (profiles/r02_limb29_in_situ.log).
-    static int t_l29 = -1;
-    if (t_l29 < 0) { const char *e = getenv("FK_MSM_LIMB29"); t_l29 = e ? atoi(e) : 0; }
     // FK_MSM_LAZY (default 1): accumulators in the lazily reduced form [0, 2p) (Walker<F, 2>); 0 = canonical after every product
-    static int t_lazy = -1;
-    if (t_lazy < 0) { const char *e = getenv("FK_MSM_LAZY"); t_lazy = e ? atoi(e) : 1; }
+    static const int t_lazy = tune("FK_MSM_LAZY", 1);
     constexpr bool IS_G1 = std::is_same<F, Fq>::value;
-    const bool l29 = IS_G1 && t_l29 != 0;
     const bool lazy = t_lazy != 0;
     constexpr int MINW_ = IS_G1 ? 4 : 2;
-    constexpr int M29 = IS_G1 ? 1 : 0;
     // bound late (inside the pieces): a multiplication begun on this lane in between may have GROWN a buffer, i.e. moved it
     auto bucket_buf = [=]() -> Xyzz<F> * { return (have_sort ? lnp->buckets2 : lnp->buckets).template as<Xyzz<F>>(); };
     auto back_acc = [=]() -> int {
@@ -1386,16 +1179,12 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
         std::vector<EventPair> &evv = (sizeof(F) == sizeof(Fq)) ? ctx->ev_acc : ctx->ev_acc2;
         FK_TRY(stats_begin(ctx, evv, (uint64_t)n, st));
         if (merged) {
-            if (l29) hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_merged_kernel<F, (IS_G1 ? 3 : 2), M29>), dim3((p.B + 255) / 256), dim3(256), 0, st, d_bases, d_lev, sorted, n,
-                                        starts, totals, p.B, p.W, dyn, perm, perm + p.B, buckets);
-            else if (lazy) hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_merged_kernel<F, MINW_, 2>), dim3((p.B + 255) / 256), dim3(256), 0, st, d_bases, d_lev, sorted, n,
+            if (lazy) hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_merged_kernel<F, MINW_, 2>), dim3((p.B + 255) / 256), dim3(256), 0, st, d_bases, d_lev, sorted, n,
                                               starts, totals, p.B, p.W, dyn, perm, perm + p.B, buckets);
             else hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_merged_kernel<F, MINW_, 0>), dim3((p.B + 255) / 256), dim3(256), 0, st, d_bases, d_lev, sorted, n,
                                     starts, totals, p.B, p.W, dyn, perm, perm + p.B, buckets);
         } else {
-            if (l29) hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_kernel<F, (IS_G1 ? 3 : 2), M29>), dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, d_bases, sorted, n,
-                                        starts, totals, p.B, p.W, dyn, perm, buckets);
-            else if (lazy) hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_kernel<F, MINW_, 2>), dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, d_bases, sorted, n,
+            if (lazy) hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_kernel<F, MINW_, 2>), dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, d_bases, sorted, n,
                                               starts, totals, p.B, p.W, dyn, perm, buckets);
             else hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_accumulate_kernel<F, MINW_, 0>), dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, d_bases, sorted, n,
                                     starts, totals, p.B, p.W, dyn, perm, buckets);
@@ -1411,9 +1200,7 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
         MsmLane &ln = *lnp; MsmTail &tl = *tlp;
         Xyzz<F> *buckets = bucket_buf();
         // oversized buckets: fixed grids looping over the device-built tables (they leave at once when there is nothing to do)
-        if (l29) hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_overflow_kernel<F, FC, M29>), dim3(2048), dim3(64), 0, st,
-                                    d_bases, d_lev, sorted, n, starts, totals, p.B, dyn, d_tasks, ln.partials.as<Xyzz<FC>>());
-        else if (lazy) hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_overflow_kernel<F, FC, 2>), dim3(2048), dim3(64), 0, st,
+        if (lazy) hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_overflow_kernel<F, FC, 2>), dim3(2048), dim3(64), 0, st,
                                           d_bases, d_lev, sorted, n, starts, totals, p.B, dyn, d_tasks, ln.partials.as<Xyzz<FC>>());
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_overflow_kernel<F, FC, 0>), dim3(2048), dim3(64), 0, st,
                                 d_bases, d_lev, sorted, n, starts, totals, p.B, dyn, d_tasks, ln.partials.as<Xyzz<FC>>());
@@ -1423,17 +1210,7 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
         FK_HIP(ctx, hipGetLastError());
         FK_DBG_ST(ctx, st, "msm_overflow_fold");
         const Xyzz<F> *wp_src = winparts;
-        if (hier) {
-            Xyzz<F> *bufa = (Xyzz<F> *)ln.redbuf.p, *bufb = (Xyzz<F> *)((char *)ln.redbuf.p + red_half);
-            uint32_t nn = hier_n1, np = 2;
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_reduce_l1_kernel<F>), dim3(p.B / 8 / 256, WR), dim3(256), 0, st, buckets, p.B, nn, bufa);
-            while (nn > 1) {
-                const uint32_t no = (nn + 63) / 64;
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_reduce_lk_kernel<F>), dim3((nn + 255) / 256, WR), dim3(256), 0, st, bufa, nn, np, no, bufb);
-                std::swap(bufa, bufb); nn = no; np++;
-            }
-            wp_src = bufa;          // WR entries of np plain components + the total
-        } else {
+        {
             hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_bucket_reduce_kernel<F>), dim3(p.nblk, WR), dim3(256), 0, st,
                                buckets, p.B, p.L, p.T, p.nblk, winparts);
             Xyzz<F> *folded = winparts + (size_t)WR * p.nblk;
@@ -1445,19 +1222,11 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
         FK_HIP(ctx, hipMemcpyAsync((char *)tl.h_wp + wp_bytes, d_adds, 8, hipMemcpyDeviceToHost, st));
         FK_HIP(ctx, hipMemcpyAsync((char *)tl.h_wp + wp_bytes + 8, &dyn->error, 4, hipMemcpyDeviceToHost, st));
         FK_HIP(ctx, hipEventRecord(tl.done, st));
-        if (split) { FK_HIP(ctx, hipEventRecord(ln.ev_lane_done, st)); ln.ev_lane_done_valid = true; }
         FK_DBG_ST(ctx, st, "msm_bucket_reduce");
         return FK_OK;
     };
     if (ctx->defer_back) {
-        // FK_PROVE_G2_FIRST=1 (experiment): a multiplication that reuses the lane's sort (B2, the G2 one) accumulates BEFORE the sort's
-        // owner (B1), beside L and A, so that its long latency-bound tail might fall into the window in which only H's sort runs
-        // instead of starving underneath H's accumulation.  It does not fit there either (6.6 ms against 4): 170.0 against 170.5 ms,
-        // and the G1 kernel's time is then shared with the G2 kernel's.  Off.
-        static int t_g2first = -1;
-        if (t_g2first < 0) { const char *e = getenv("FK_PROVE_G2_FIRST"); t_g2first = e ? atoi(e) : 0; }
-        if (have_sort && t_g2first && !ctx->deferred.empty()) ctx->deferred.insert(ctx->deferred.end() - 1, back_acc);
-        else ctx->deferred.push_back(back_acc);
+        ctx->deferred.push_back(back_acc);
         ctx->deferred_tails.push_back(back_tail);
         return FK_OK;
     }
@@ -1495,15 +1264,6 @@ static int msm_end(fk_ctx *ctx, int tail, Xyzz<F> *out) {
     for (uint32_t w = tl.W; w-- > 0;) {
         const uint32_t cw = tl.cb + (w < tl.wide ? 1 : 0);       // acc holds the windows above w, relative to w's top bit
         for (uint32_t k = 0; k < cw; k++) acc = Xyzz<F>::dbl(acc);
-        if (tl.hier) {       // hierarchical reduction: P1 + 8 (P2 + 64 (P3 + ...)); the entry's last point (the bucket total) is not needed
-            const Xyzz<F> *P = wp + (size_t)w * tl.nblk;
-            Xyzz<F> r = P[tl.hier - 1];
-            for (uint32_t k = tl.hier - 1; k-- > 0;) {
-                for (uint32_t d = 0; d < (k == 0 ? 3u : 6u); d++) r = Xyzz<F>::dbl(r);
-                r.add(P[k]);
-            }
-            acc.add(r);
-        } else
         for (uint32_t b = 0; b < tl.nblk; b++) acc.add(wp[(size_t)w * tl.nblk + b]);
     }
     *out = acc;
@@ -1513,7 +1273,7 @@ static int msm_end(fk_ctx *ctx, int tail, Xyzz<F> *out) {
 
 int msm_sync(fk_ctx *ctx) {
     if (ctx->aux) FK_HIP(ctx, hipStreamSynchronize(ctx->aux));
-    for (MsmLane &ln : ctx->lanes) if (ln.st) { FK_HIP(ctx, hipStreamSynchronize(ln.st)); if (ln.st_sort != ln.st) FK_HIP(ctx, hipStreamSynchronize(ln.st_sort)); }
+    for (MsmLane &ln : ctx->lanes) if (ln.st) FK_HIP(ctx, hipStreamSynchronize(ln.st));
     return FK_OK;
 }
 
@@ -1522,7 +1282,7 @@ void msm_abandon(fk_ctx *ctx) {
     ctx->defer_back = false; ctx->deferred.clear(); ctx->deferred_tails.clear();
     if (ctx->aux) (void)hipStreamSynchronize(ctx->aux);
     for (int i = 0; i < MSM_TAILS; i++) ctx->tails[i].active = false;
-    for (MsmLane &ln : ctx->lanes) { if (ln.st) { (void)hipStreamSynchronize(ln.st); if (ln.st_sort != ln.st) (void)hipStreamSynchronize(ln.st_sort); } ln.last_sort_scalars = nullptr; }
+    for (MsmLane &ln : ctx->lanes) { if (ln.st) (void)hipStreamSynchronize(ln.st); ln.last_sort_scalars = nullptr; }
 }
 
 void msm_release(fk_ctx *ctx) {
@@ -1535,13 +1295,11 @@ void msm_release(fk_ctx *ctx) {
     for (MsmLane &ln : ctx->lanes) {
         if (ln.st) (void)hipStreamSynchronize(ln.st);
         for (DevBuf *b : {&ln.digits, &ln.sorted, &ln.totals, &ln.starts, &ln.perm, &ln.overlist, &ln.tasktab, &ln.partials, &ln.s2_cnt1, &ln.s2_seg,
-                          &ln.s2_cnt2, &ln.s2_tmp_idx, &ln.s2_tmp_lo, &ln.buckets, &ln.buckets2, &ln.redbuf})
+                          &ln.s2_cnt2, &ln.s2_tmp_idx, &ln.s2_tmp_lo, &ln.buckets, &ln.buckets2})
             b->release();
         if (ln.h_stage) (void)hipHostFree(ln.h_stage);
         if (ln.ev_in) (void)hipEventDestroy(ln.ev_in);
         if (ln.ev_sorted) (void)hipEventDestroy(ln.ev_sorted);
-        if (ln.ev_lane_done) (void)hipEventDestroy(ln.ev_lane_done);
-        if (ln.st_sort && ln.st_sort != ln.st) { (void)hipStreamSynchronize(ln.st_sort); (void)hipStreamDestroy(ln.st_sort); }
         if (ln.st) (void)hipStreamDestroy(ln.st);
         ln = MsmLane();
     }
@@ -1579,8 +1337,9 @@ int msm_g2_dev(fk_ctx *ctx, const G2Affine *d_bases, const Fr *d_scalars, size_t
 }
 
 // ------------------------------------------------------------------------------------------ fixed-base precomputation of a key
+// name: the key array (for the message); require: FK_MSM_PRECOMP=require -- fail instead of falling back when HBM is short
 template <class F>
-static int precompute_levels(fk_ctx *ctx, const Affine<F> *d_bases, size_t n, KeyPre *out) {
+static int precompute_levels(fk_ctx *ctx, const Affine<F> *d_bases, size_t n, KeyPre *out, const char *name, bool require) {
     *out = KeyPre();
     // Arrays below 2^24 points (rounded as the window rule rounds) keep the ordinary path: measured per proof with / without
     // levels -- 2^20: 15.5 / 13.1 ms, 2^22: 29.9 / 25.8, 2^23: 45.7 / 44.1, 2^24: 79.0 / 80.6, 2^25: 139.5 / 148.2.  (Read per call:
@@ -1594,9 +1353,19 @@ static int precompute_levels(fk_ctx *ctx, const Affine<F> *d_bases, size_t n, Ke
     size_t fr = 0, tot = 0;
     FK_HIP(ctx, hipMemGetInfo(&fr, &tot));
     // leave room for the lanes' scratch (about 0.6 KB per scalar of the largest multiplication), the NTT tables and the caller
-    if (bytes + (size_t)n * 640 * MSM_LANES + ((size_t)8 << 30) > fr) return FK_OK;
     void *lev = nullptr;
-    if (hipMalloc(&lev, bytes) != hipSuccess) { (void)hipGetLastError(); return FK_OK; }
+    const bool fits = bytes + (size_t)n * 640 * MSM_LANES + ((size_t)8 << 30) <= fr;
+    if (!fits || hipMalloc(&lev, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        // Not an error by default -- the array keeps the ordinary W-bucket-set path (same bytes, ~7-10 % slower at 2^25) -- but never
+        // silent: the text stays in fk_last_error (a second key or another process on the GPU is the usual cause).
+        char msg[320];
+        snprintf(msg, sizeof msg, "key: fixed-base levels of %s (%zu points, %.1f GiB) do not fit into the %.1f GiB of free HBM", name, n,
+                 (double)bytes / (double)(1ull << 30), (double)fr / (double)(1ull << 30));
+        if (require) { ctx->err = std::string(msg) + " and FK_MSM_PRECOMP=require"; return FK_ERR_OOM; }
+        ctx->err += (ctx->err.empty() ? "warning: " : "; ") + std::string(msg) + " -- that array takes the slower W-bucket-set path";
+        return FK_OK;
+    }
     const Affine<F> *prev = d_bases;
     for (uint32_t w = 1; w < p.W; w++) {
         Affine<F> *cur = (Affine<F> *)lev + (size_t)(w - 1) * n;
@@ -1614,17 +1383,21 @@ void key_pre_free(fk_key *k) {
     for (KeyPre *p : {&k->pre_h, &k->pre_l, &k->pre_a, &k->pre_b1, &k->pre_b2}) { if (p->lev) (void)hipFree(p->lev); *p = KeyPre(); }
 }
 
+// FK_MSM_PRECOMP: unset / 1 = derive the levels that fit (a skipped array leaves a warning in fk_last_error), 0 = none,
+// require = fail with FK_ERR_OOM instead of degrading.
 int key_precompute(fk_ctx *ctx, fk_key *k) {
     const char *e = getenv("FK_MSM_PRECOMP");
-    const int on = e ? atoi(e) : 1;
+    const bool require = e && !strcmp(e, "require");
+    const int on = e && !require ? atoi(e) : 1;
     key_pre_free(k);
+    ctx->err.clear();
     if (!on) return FK_OK;
-    // the long G1 accumulations first: if HBM runs short the later arrays simply stay on the ordinary path
-    if (k->d_h) FK_TRY(precompute_levels<Fq>(ctx, k->d_h, k->h_hi - k->h_lo, &k->pre_h));
-    if (k->d_l) FK_TRY(precompute_levels<Fq>(ctx, k->d_l, k->l_hi - k->l_lo, &k->pre_l));
-    if (k->d_b2) FK_TRY(precompute_levels<Fq2>(ctx, k->d_b2, k->b_hi - k->b_lo, &k->pre_b2));
-    if (k->d_b1 && (k->pre_b2.lev || !k->d_b2)) FK_TRY(precompute_levels<Fq>(ctx, k->d_b1, k->b_hi - k->b_lo, &k->pre_b1));   // B1 and B2 share one sort: same plan or none
-    if (k->d_a) FK_TRY(precompute_levels<Fq>(ctx, k->d_a, k->a_hi - k->a_lo, &k->pre_a));
+    // the long G1 accumulations first: if HBM runs short the later arrays stay on the ordinary path
+    if (k->d_h) FK_TRY(precompute_levels<Fq>(ctx, k->d_h, k->h_hi - k->h_lo, &k->pre_h, "h", require));
+    if (k->d_l) FK_TRY(precompute_levels<Fq>(ctx, k->d_l, k->l_hi - k->l_lo, &k->pre_l, "l", require));
+    if (k->d_b2) FK_TRY(precompute_levels<Fq2>(ctx, k->d_b2, k->b_hi - k->b_lo, &k->pre_b2, "b_g2", require));
+    if (k->d_b1 && (k->pre_b2.lev || !k->d_b2)) FK_TRY(precompute_levels<Fq>(ctx, k->d_b1, k->b_hi - k->b_lo, &k->pre_b1, "b_g1", require));   // B1 and B2 share one sort: same plan or none
+    if (k->d_a) FK_TRY(precompute_levels<Fq>(ctx, k->d_a, k->a_hi - k->a_lo, &k->pre_a, "a", require));
     return FK_OK;
 }
 

@@ -292,8 +292,7 @@ static int get_domain(fk_ctx *ctx, uint32_t log_n, NttDomain **out) {
     // single-level twiddles for every pass but the first (sizes 2^(lgp + deg): the last one is the whole domain, 32 B per
     // point and direction).  FK_NTT_FULL_TW=0 disables them; they are skipped when they would not fit comfortably.
     {
-        const char *e = getenv("FK_NTT_FULL_TW");
-        const bool want = !(e && e[0] == '0');
+        const bool want = tune("FK_NTT_FULL_TW", 1) != 0;
         size_t free_b = 0, total_b = 0;
         (void)hipMemGetInfo(&free_b, &total_b);
         uint64_t need = 0;
@@ -370,8 +369,7 @@ static int ntt_exec(fk_ctx *ctx, NttDomain *d, const NttOp &op, const Fr *in, Fr
         if (op.post) { a.post_lo = op.post->lo; a.post_hi = op.post->hi; }
         const uint64_t nblk = ((uint64_t)1 << (d->log_n - deg)) >> logC;
         const size_t lds_bytes = (size_t)2 * sizeof(uint4) << (deg + logC);
-        static int t_lazy = -1;     // FK_NTT_LAZY=0: butterflies in the canonical form (the round-1 kernel)
-        if (t_lazy < 0) { const char *e = getenv("FK_NTT_LAZY"); t_lazy = e ? atoi(e) : 1; }
+        static const int t_lazy = tune("FK_NTT_LAZY", 1);     // 0: butterflies in the canonical form (the round-1 kernel)
         void (*kern)(PassArgs) = t_lazy ? ntt_pass_kernel<FrL> : ntt_pass_kernel<Fr>;
         FK_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         FK_TRY(stats_begin(ctx, ctx->ev_ntt, (uint64_t)1 << d->log_n));

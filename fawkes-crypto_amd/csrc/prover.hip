@@ -69,7 +69,7 @@ int fk_init(int device_id, fk_ctx **out) {
     fk_ctx *ctx = new fk_ctx();
     ctx->device = device_id;
     { const char *d = getenv("FK_DEBUG"); ctx->debug = d && d[0] && d[0] != '0'; }
-    { const char *t = getenv("FK_NTT_THREADS"); if (t) { int v = atoi(t); if (v == 64 || v == 128 || v == 256 || v == 512 || v == 1024) ctx->ntt_threads = (unsigned)v; } }
+    { const int v = tune("FK_NTT_THREADS", 512); if (v == 64 || v == 128 || v == 256 || v == 512 || v == 1024) ctx->ntt_threads = (unsigned)v; }
     if (hipStreamCreate(&ctx->stream) != hipSuccess) { delete ctx; return FK_ERR_HIP; }
     *out = ctx;
     return FK_OK;
@@ -405,29 +405,6 @@ static int witness_begin(fk_ctx *ctx, const fk_key *key, const Fr *d_z, const ui
     return FK_OK;
 }
 
-static bool spmv_after_sorts() {
-    static int t = -1;
-    if (t < 0) { const char *e = getenv("FK_PROVE_SPMV_AFTER_SORTS"); t = e ? atoi(e) : 0; }      // measured slower, see fk_prove_r1cs_dev
-    return t != 0;
-}
-extern "C++" {
-namespace fk {
-int prove_witness_early(fk_ctx *ctx, const fk_key *key, const void *d_z, const void *d_a_aux, const void *d_b_in, const void *d_b_aux) {
-    if (!sorts_first(key) || !spmv_after_sorts()) return 0;
-    static int t_wfirst = -1;
-    if (t_wfirst < 0) { const char *e = getenv("FK_PROVE_WITNESS_FIRST"); t_wfirst = e ? atoi(e) : -2; }
-    if (t_wfirst == 0) return 0;
-    ctx->lane_next = 0;
-    const int rc = witness_begin(ctx, key, (const Fr *)d_z, (const uint8_t *)d_a_aux, (const uint8_t *)d_b_in, (const uint8_t *)d_b_aux, ctx->ev_z);
-    if (rc != FK_OK) { msm_abandon(ctx); return -rc; }
-    for (MsmLane &ln : ctx->lanes)
-        if (ln.ev_sorted_valid) { if (hipStreamWaitEvent(ctx->stream, ln.ev_sorted, 0) != hipSuccess) { msm_abandon(ctx); return -FK_ERR_HIP; } ln.ev_sorted_valid = false; }
-    ctx->wit_early = true;
-    return 1;
-}
-}  // namespace fk
-}  // extern "C++"
-
 static int witness_end(fk_ctx *ctx, uint8_t out[FK_MSM_RESULT_BYTES], int tail_h = -1) {
     if (!ctx->wit_active) { msm_abandon(ctx); FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "prove: no witness multiplications in flight"); }
     ctx->wit_active = false;
@@ -477,8 +454,7 @@ static int prove_msms_dev(fk_ctx *ctx, const fk_key *key, Fr *d_a, Fr *d_b, Fr *
     // (profiles/r02_cusplit_witness_first_probe.log), and at every smaller size measured -- synthetic 2^20 13.4 -> 11.1 ms,
     // 2^22 26.2 -> 23.7, 2^24 80.4 -> 78.0; 64 transactions 21.0 -> 19.1 (profiles/r02_witness_first_by_size.log).  (Round 1
     // measured an earlier form of this overlap as a loss below 2^24.)  FK_PROVE_WITNESS_FIRST=0 puts the quotient first again.
-    static int t_wfirst = -1;
-    if (t_wfirst < 0) { const char *e = getenv("FK_PROVE_WITNESS_FIRST"); t_wfirst = e ? atoi(e) : -2; }
+    static const int t_wfirst = tune("FK_PROVE_WITNESS_FIRST", 1);
     const bool wfirst = t_wfirst != 0;
     if (!ctx->ev_main) FK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_main, hipEventDisableTiming));
     if (!ctx->ev_z) FK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_z, hipEventDisableTiming));
@@ -493,13 +469,10 @@ static int prove_msms_dev(fk_ctx *ctx, const fk_key *key, Fr *d_a, Fr *d_b, Fr *
     // sorts run beside the evaluation of a, b, c (latency-bound gathers), and the quotient's first kernel waits for the
     // sorts: from then on transforms and accumulations -- all VALU-bound -- share the GPU without anything crawling, and H
     // (its own lane) sorts as soon as the quotient is done.
-    // (resident constraint system: fk_prove_r1cs_dev has queued the witness multiplications already, their sorts in front of
-    // the evaluation of a, b, c and their accumulations beside it -- prove_witness_early)
-    const bool early = ctx->wit_early;
-    ctx->wit_early = false;
-    const bool gate = wfirst && sorts_first(key) && !early;
-    static int t_accgate = -1;      // FK_PROVE_ACC_AFTER_NTT (default 1): the witness accumulations wait for the quotient, see below
-    if (t_accgate < 0) { const char *e = getenv("FK_PROVE_ACC_AFTER_NTT"); t_accgate = e ? atoi(e) : 1; }
+    // (An experiment of round 2 queued the evaluation of a, b, c BEHIND the sorts and underneath the accumulations: it took 47.6 ms
+    // there instead of 12 -- removed.)
+    const bool gate = wfirst && sorts_first(key);
+    static const int t_accgate = tune("FK_PROVE_ACC_AFTER_NTT", 1);      // the witness accumulations wait for the quotient, see below
     if (gate) {
         ctx->defer_back = t_accgate != 0;
         const int rcw = witness_begin(ctx, key, d_z, d_a_aux, d_b_in, d_b_aux, ctx->ev_z);
@@ -508,7 +481,7 @@ static int prove_msms_dev(fk_ctx *ctx, const fk_key *key, Fr *d_a, Fr *d_b, Fr *
         for (MsmLane &ln : ctx->lanes)
             if (ln.ev_sorted_valid) { FK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ln.ev_sorted, 0)); ln.ev_sorted_valid = false; }
     }
-    { const int rcu = upload_deferred(ctx, true); if (rcu != FK_OK) { if (gate || early) msm_abandon(ctx); return rcu; } }      // the next proof's witness: underneath what follows
+    { const int rcu = upload_deferred(ctx, true); if (rcu != FK_OK) { if (gate) msm_abandon(ctx); return rcu; } }      // the next proof's witness: underneath what follows
     const int rcq = quotient_dev(ctx, d_a, d_b, d_c, n, d_h, &m);          // queued on the main stream, not waited for
     if (rcq != FK_OK) { if (gate) msm_abandon(ctx); return rcq; }
     const double t1 = now_ms();
@@ -520,34 +493,14 @@ static int prove_msms_dev(fk_ctx *ctx, const fk_key *key, Fr *d_a, Fr *d_b, Fr *
         // The accumulations of B1, L and A then run side by side on their lanes (they fill each other's last waves; one after
         // the other on a stream of their own was measured slower: 192.3 - 195.5 against 185.8 - 188.5 ms,
         // profiles/r02_sorts_first_probe.log), B2's right behind B1's, all tails behind the accumulations of their lane.
-        // FK_PROVE_H_SORT_FIRST=1 (experiment): H's sort right behind the quotient, ALONE, and every accumulation behind it
-        // (instead of H's sort crawling underneath the witness accumulations and finishing once they are over)
-        static int t_hfirst = -1;
-        if (t_hfirst < 0) { const char *e = getenv("FK_PROVE_H_SORT_FIRST"); t_hfirst = e ? atoi(e) : 0; }
-        if (gate && t_hfirst) {
-            int t_h1 = -1;
-            ctx->defer_back = true;
-            const int rch = msm_g1_begin(ctx, key->d_h, d_h + key->h_lo, key->h_hi - key->h_lo, &t_h1, ctx->ev_main, &key->pre_h);
-            ctx->defer_back = false;
-            if (rch != FK_OK) { msm_abandon(ctx); return rch; }
-            MsmLane &lh = ctx->lanes[ctx->lane_prev];
-            const int rcd = msm_run_deferred(ctx, lh.ev_sorted_valid ? lh.ev_sorted : ctx->ev_main);
-            lh.ev_sorted_valid = false;
-            if (rcd != FK_OK) { msm_abandon(ctx); return rcd; }
-            const double t2w = now_ms();
-            FK_TRY(witness_end(ctx, out, t_h1));
-            if (tm) { tm->ntt_ms = t1 - t0; tm->msm_l_ms = t2w - t1; tm->msm_h_ms = now_ms() - t2w; tm->total_ms = now_ms() - t0; }
-            return FK_OK;
-        }
+        // (H's sort right behind the quotient, ALONE, with every accumulation behind it was measured too: slower by 3-10 ms.)
         if (gate) { const int rcd = msm_run_deferred(ctx, ctx->ev_main); if (rcd != FK_OK) { msm_abandon(ctx); return rcd; } }
-        if (!gate && !early) {
+        if (!gate) {
             const int rcw = witness_begin(ctx, key, d_z, d_a_aux, d_b_in, d_b_aux, ctx->ev_z);
             if (rcw != FK_OK) { msm_abandon(ctx); return rcw; }
         }
         int t_h0 = -1;
-        ctx->sort_under = gate || early;
         const int rch = msm_g1_begin(ctx, key->d_h, d_h + key->h_lo, key->h_hi - key->h_lo, &t_h0, ctx->ev_main, &key->pre_h);
-        ctx->sort_under = false;
         if (rch != FK_OK) { msm_abandon(ctx); return rch; }
         const double t2w = now_ms();
         FK_TRY(witness_end(ctx, out, t_h0));

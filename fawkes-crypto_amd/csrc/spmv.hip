@@ -16,6 +16,7 @@
 // Kernel: one lane per (matrix, row); HBM-bound gather of z (32 B per term).
 #include "common.hpp"
 #include <string.h>
+#include <algorithm>
 #include <unordered_map>
 #include <string>
 
@@ -202,7 +203,7 @@ static int r1cs_load_impl(fk_ctx *ctx, const fk_r1cs *cs, uint32_t copies, fk_r1
     std::vector<uint8_t> a_aux(cs->num_aux ? cs->num_aux : 1, 0), b_in(cs->num_input, 0), b_aux(cs->num_aux ? cs->num_aux : 1, 0);
     int rc = FK_OK;
     auto fail = [&](int code) { fk_r1cs_free(ctx, r); return code; };
-    uint64_t bin_min = 8;          // rows this long make a matrix binned; FK_SPMV_BIN_MIN=0 turns the binned product off
+    uint64_t bin_min = 8;          // rows this long make a matrix binned; FK_SPMV_BIN_MIN=0 turns the binned product off (a run-time switch: the tests run both kernels)
     if (const char *e = getenv("FK_SPMV_BIN_MIN")) { bin_min = strtoull(e, nullptr, 10); if (!bin_min) bin_min = ~0ull; }
     for (int k = 0; k < 3 && rc == FK_OK; k++) {
         const uint64_t nnz = ptrs[k][cs->num_gates];
@@ -393,8 +394,7 @@ int r1cs_eval_impl(fk_ctx *ctx, const fk_r1cs_dev *r, const void *d_z, void *d_a
     }
     // lanes per row: half of the matrix's mean row length, rounded down to a power of two (1 .. 64); measured on the eddsa batch: 16 / 8 / 4 / 2 / 1 terms per lane -> 1.51 / 1.27 / 1.16 / 1.02 / 0.97 ms
     uint32_t lg[3], lgmax = 0;
-    static int t_div = -1;
-    if (t_div < 0) { const char *e = getenv("FK_SPMV_TERMS_PER_LANE"); t_div = e ? atoi(e) : 2; if (t_div < 1) t_div = 1; }
+    static const int t_div = std::max(1, tune("FK_SPMV_TERMS_PER_LANE", 2));
     for (int k = 0; k < 3; k++) {
         const uint64_t mean = r->num_gates ? r->nnz[k] / r->num_gates : 0;
         lg[k] = 0;
@@ -487,24 +487,15 @@ int fk_prove_r1cs_dev(fk_ctx *ctx, const fk_key *key, const fk_r1cs_dev *r, cons
     FK_HIP(ctx, ctx->stage_a.reserve(mb)); FK_HIP(ctx, ctx->stage_b.reserve(mb)); FK_HIP(ctx, ctx->stage_c.reserve(mb));
     // z is complete at this point of the main stream: the witness multiplications wait for THIS, not for the evaluation of a, b, c
     // (11.6 ms at 2^25 during which nothing else ran; FK_PROVE_Z_EARLY=0 restores that)
-    static int t_zearly = -1;
-    if (t_zearly < 0) { const char *e = getenv("FK_PROVE_Z_EARLY"); t_zearly = e ? atoi(e) : 1; }
+    static const int t_zearly = tune("FK_PROVE_Z_EARLY", 1);
     if (t_zearly) {
         if (!ctx->ev_z) FK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_z, hipEventDisableTiming));
         FK_HIP(ctx, hipEventRecord(ctx->ev_z, ctx->stream));
         ctx->ev_z_recorded = true;
     }
-    // Experiment (FK_PROVE_SPMV_AFTER_SORTS=1, off): the witness multiplications queued HERE, the evaluation of a, b, c behind
-    // their sorts (which then run alone) and underneath their accumulations -- its workgroups (256 lanes, 93 registers, no LDS)
-    // fit where an accumulate workgroup has left.  They do not get those places: the evaluation took 47.6 ms there instead of
-    // 12 and ended with the accumulations; 178.1 - 179.2 against 174.8 - 175.1 ms (profiles/r02_sorts_first_probe.log).
     ctx->qidx = &r->qidx;      // the queries' index lists are known: no per-proof density compaction
-    if (t_zearly) {
-        const int we = prove_witness_early(ctx, key, d_z, r->d_a_aux, r->d_b_in, r->d_b_aux);
-        if (we < 0) { ctx->qidx = nullptr; ctx->ev_z_recorded = false; return -we; }
-    }
     const int rce = fk_r1cs_eval_dev(ctx, r, d_z, ctx->stage_a.p, ctx->stage_b.p, ctx->stage_c.p);
-    if (rce != FK_OK) { if (ctx->wit_early) { msm_abandon(ctx); ctx->wit_early = false; } ctx->qidx = nullptr; ctx->ev_z_recorded = false; return rce; }
+    if (rce != FK_OK) { ctx->qidx = nullptr; ctx->ev_z_recorded = false; return rce; }
     const int rc = fk_prove_dev(ctx, key, ctx->stage_a.p, ctx->stage_b.p, ctx->stage_c.p, rows, d_z, r->d_a_aux, r->d_b_in, r->d_b_aux, rr, ss, out_proof, tm);
     ctx->qidx = nullptr;
     ctx->ev_z_recorded = false;
@@ -560,8 +551,7 @@ int fk_prove_r1cs_submit(fk_ctx *ctx, const fk_key *key, const fk_r1cs_dev *r, c
     // Started here it ran beside the sorts: +14 ms per proof on the synthetic 2^25 shape (1 GiB witness), +0.8 ms on the
     // 1024-transaction system (profiles/r02_sorts_first_probe.log).  FK_UPLOAD_DEFER=0: start it here.  The host buffer must
     // stay valid until fk_prove_r1cs_wait(ticket) returns either way.
-    static int t_defer = -1;
-    if (t_defer < 0) { const char *e = getenv("FK_UPLOAD_DEFER"); t_defer = e ? atoi(e) : 1; }
+    static const int t_defer = tune("FK_UPLOAD_DEFER", 1);
     if (t_defer && ctx->wslot[slot ^ 1].pending && zb <= w.buf.cap && w.ready) { w.deferred = true; w.host_z = z; w.host_bytes = zb; }
     else { w.deferred = false; FK_TRY(fk_witness_upload_async(ctx, slot, z, zb)); }
     w.pending = true; w.key = key; w.r1cs = r;

@@ -7,6 +7,9 @@ use std::os::raw::{c_char, c_int, c_void};
 #[repr(C)] pub struct fk_key { _p: [u8; 0] }
 #[repr(C)] pub struct fk_r1cs_dev { _p: [u8; 0] }
 #[repr(C)] pub struct fk_gates { _p: [u8; 0] }
+#[repr(C)] pub struct fk_multi { _p: [u8; 0] }
+#[repr(C)] pub struct fk_multi_key { _p: [u8; 0] }
+#[repr(C)] pub struct fk_multi_r1cs { _p: [u8; 0] }
 
 pub const FK_OK: c_int = 0;
 pub const FK_PROOF_BYTES: usize = 256;
@@ -49,4 +52,19 @@ extern "C" {
     pub fn fk_prove_r1cs_submit(ctx: *mut fk_ctx, key: *const fk_key, r1cs: *const fk_r1cs_dev, z: *const u64,
                                 r: *const u64, s: *const u64, ticket: *mut c_int) -> c_int;
     pub fn fk_prove_r1cs_wait(ctx: *mut fk_ctx, ticket: c_int, out_proof: *mut u8, timings: *mut c_void) -> c_int;
+
+    // ---- N GPUs of one node behind one call (one process, a worker thread per GPU, exchanges inside the library).
+    // fk_init_devices(1, [d]) is the single-GPU prover; the proof bytes do not depend on N.
+    pub fn fk_init_devices(n_devices: c_int, device_ids: *const c_int, out: *mut *mut fk_multi) -> c_int;
+    pub fn fk_multi_free(multi: *mut fk_multi);
+    pub fn fk_multi_last_error(multi: *const fk_multi) -> *const c_char;
+    pub fn fk_multi_key_load(multi: *mut fk_multi, desc: *const fk_key_desc, out: *mut *mut fk_multi_key) -> c_int;
+    pub fn fk_multi_key_free(multi: *mut fk_multi, key: *mut fk_multi_key);
+    pub fn fk_multi_r1cs_load_gates(multi: *mut fk_multi, gates: *const fk_gates, out: *mut *mut fk_multi_r1cs) -> c_int;
+    pub fn fk_multi_r1cs_free(multi: *mut fk_multi, r1cs: *mut fk_multi_r1cs);
+    pub fn fk_multi_prove_r1cs(multi: *mut fk_multi, key: *const fk_multi_key, r1cs: *const fk_multi_r1cs, z: *const u64,
+                               r: *const u64, s: *const u64, out_proof: *mut u8, timings: *mut c_void) -> c_int;
+    pub fn fk_multi_prove_r1cs_submit(multi: *mut fk_multi, key: *const fk_multi_key, r1cs: *const fk_multi_r1cs, z: *const u64,
+                                      r: *const u64, s: *const u64, ticket: *mut c_int) -> c_int;
+    pub fn fk_multi_prove_r1cs_wait(multi: *mut fk_multi, ticket: c_int, out_proof: *mut u8, timings: *mut c_void) -> c_int;
 }

@@ -23,17 +23,20 @@ use fawkes_crypto::ff_uint::Num;
 
 use bellman::pairing::{CurveAffine, RawEncodable};
 
-/// A proving key and its constraint system resident in the HBM of one MI355X: built once per `Parameters`.
+/// A proving key and its constraint system resident in the HBM of one or several MI355X of one node: built once per
+/// `Parameters`.  With N devices every GPU keeps 1/N of each key array and a replica of the constraint system; a proof is
+/// still ONE call (`fk_multi_prove_r1cs`): the library shards the evaluation of a, b, c, the quotient and the five
+/// multi-scalar multiplications and moves the data between the GPUs itself (csrc/multi.hip).
 pub struct HipProver {
-    ctx: *mut ffi::fk_ctx,
-    key: *mut ffi::fk_key,
-    r1cs: *mut ffi::fk_r1cs_dev,
+    multi: *mut ffi::fk_multi,
+    key: *mut ffi::fk_multi_key,
+    r1cs: *mut ffi::fk_multi_r1cs,
 }
 
 unsafe impl Send for HipProver {}
 
-fn last_error(ctx: *const ffi::fk_ctx) -> String {
-    unsafe { CStr::from_ptr(ffi::fk_last_error(ctx)).to_string_lossy().into_owned() }
+fn last_error(multi: *const ffi::fk_multi) -> String {
+    unsafe { CStr::from_ptr(ffi::fk_multi_last_error(multi)).to_string_lossy().into_owned() }
 }
 
 /// `into_raw_uncompressed_le` per point (the call group.rs:59,97 already uses), the identity as zeros (group.rs:55)
@@ -49,7 +52,9 @@ fn raw_points<G: CurveAffine + RawEncodable>(v: &[G], width: usize) -> Vec<u8> {
 impl HipProver {
     /// Uploads `params.0` (bellman's key) and decodes `params.2` (the brotli gate blob, setup.rs:25-32) into the resident
     /// constraint system -- ONCE, instead of once per proof (cs.rs:243-245).
-    pub fn new<E: Engine>(device_id: i32, params: &Parameters<E>) -> Self {
+    /// `device_ids`: the GPUs to prove on (`&[0]` = one GPU; 1, 2, 4 or 8 of them shard the quotient as well as the
+    /// multiplications).
+    pub fn new<E: Engine>(device_ids: &[i32], params: &Parameters<E>) -> Self {
         let bp = &params.0;
         let num_input = bp.vk.ic.len() as u32;                     // includes the constant ONE (cs.rs:111)
         let num_aux = bp.l.len() as u32;
@@ -68,16 +73,19 @@ impl HipProver {
             shard_index: 0, shard_count: 1, z_frac_lo: ffi::FK_Z_EQUAL_SPLIT, z_frac_hi: ffi::FK_Z_EQUAL_SPLIT,
         };
         unsafe {
-            let (mut ctx, mut key, mut gates, mut r1cs) = (ptr::null_mut(), ptr::null_mut(), ptr::null_mut(), ptr::null_mut());
-            assert!(ffi::fk_init(device_id, &mut ctx) == ffi::FK_OK, "fk_init: no usable MI355X (there is no CPU fallback)");
-            let rc = ffi::fk_key_load(ctx, &desc, &mut key);
-            assert!(rc == ffi::FK_OK, "fk_key_load: {}", last_error(ctx));
-            let rc = ffi::fk_gates_decode(ctx, params.2.as_ptr(), params.2.len(), ffi::FK_GATES_BROTLI, params.1, num_input, num_aux, &mut gates);
-            assert!(rc == ffi::FK_OK, "fk_gates_decode: {}", last_error(ctx));
-            let rc = ffi::fk_r1cs_load_gates(ctx, gates, &mut r1cs);
+            let (mut multi, mut key, mut gates, mut r1cs) = (ptr::null_mut(), ptr::null_mut(), ptr::null_mut(), ptr::null_mut());
+            let rc = ffi::fk_init_devices(device_ids.len() as i32, device_ids.as_ptr(), &mut multi);
+            assert!(rc == ffi::FK_OK, "fk_init_devices: no usable MI355X (there is no CPU fallback)");
+            // shard g of every key array goes to device_ids[g] (desc.shard_* are ignored by the multi-GPU loader)
+            let rc = ffi::fk_multi_key_load(multi, &desc, &mut key);
+            assert!(rc == ffi::FK_OK, "fk_multi_key_load: {}", last_error(multi));
+            // the gate blob is decoded once on the host (ctx = NULL), then uploaded to every GPU
+            let rc = ffi::fk_gates_decode(ptr::null_mut(), params.2.as_ptr(), params.2.len(), ffi::FK_GATES_BROTLI, params.1, num_input, num_aux, &mut gates);
+            assert!(rc == ffi::FK_OK, "fk_gates_decode failed ({}): malformed gate blob", rc);
+            let rc = ffi::fk_multi_r1cs_load_gates(multi, gates, &mut r1cs);
             ffi::fk_gates_free(gates);
-            assert!(rc == ffi::FK_OK, "fk_r1cs_load_gates: {}", last_error(ctx));
-            HipProver { ctx, key, r1cs }
+            assert!(rc == ffi::FK_OK, "fk_multi_r1cs_load_gates: {}", last_error(multi));
+            HipProver { multi, key, r1cs }
         }
     }
 
@@ -86,18 +94,18 @@ impl HipProver {
     fn prove_bytes<Fr: fawkes_crypto::ff_uint::PrimeField>(&self, z: &[Num<Fr>], r: &Num<Fr>, s: &Num<Fr>) -> [u8; ffi::FK_PROOF_BYTES] {
         let mut out = [0u8; ffi::FK_PROOF_BYTES];
         let rc = unsafe {
-            ffi::fk_prove_r1cs(self.ctx, self.key, self.r1cs, z.as_ptr() as *const u64, r as *const _ as *const u64,
-                               s as *const _ as *const u64, out.as_mut_ptr(), ptr::null_mut())
+            ffi::fk_multi_prove_r1cs(self.multi, self.key, self.r1cs, z.as_ptr() as *const u64, r as *const _ as *const u64,
+                                     s as *const _ as *const u64, out.as_mut_ptr(), ptr::null_mut())
         };
         // the reference `.unwrap()`s bellman's SynthesisError at prover.rs:80: a non-zero status panics here as well
-        assert!(rc == ffi::FK_OK, "fk_prove_r1cs ({}): {}", rc, last_error(self.ctx));
+        assert!(rc == ffi::FK_OK, "fk_multi_prove_r1cs ({}): {}", rc, last_error(self.multi));
         out
     }
 }
 
 impl Drop for HipProver {
     fn drop(&mut self) {
-        unsafe { ffi::fk_r1cs_free(self.ctx, self.r1cs); ffi::fk_key_free(self.ctx, self.key); ffi::fk_free(self.ctx); }
+        unsafe { ffi::fk_multi_r1cs_free(self.multi, self.r1cs); ffi::fk_multi_key_free(self.multi, self.key); ffi::fk_multi_free(self.multi); }
     }
 }
 

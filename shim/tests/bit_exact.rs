@@ -28,7 +28,7 @@ fn circuit<C: CS>(public: CNum<C>, secret: (CNum<C>, CMerkleProof<C, 32>)) {
 #[test]
 fn hip_proof_bytes_equal_bellman_create_proof() {
     let params = setup::<Bn256, _, _, _>(circuit);
-    let hip = HipProver::new(0, &params);
+    let hip = HipProver::new(&[0], &params);
 
     let mut rng = thread_rng();
     let poseidon_params = PoseidonParams::<Fr>::new(3, 8, 53);
@@ -46,7 +46,7 @@ fn hip_proof_bytes_equal_bellman_create_proof() {
     let ref rcs = params.get_witness_rcs();
     let signal_pub = <CNum<WitnessCS<Fr>> as Signal<_>>::alloc(rcs, Some(&root));
     signal_pub.inputize();
-    let signal_sec = <(CNum<WitnessCS<Fr>>, CMerkleProof<WitnessCS<Fr>, 32>) as Signal<_>>::alloc(rcs, Some(&(leaf, proof)));
+    let signal_sec = <(CNum<WitnessCS<Fr>>, CMerkleProof<WitnessCS<Fr>, 32>) as Signal<_>>::alloc(rcs, Some(&(leaf, proof.clone())));
     circuit(signal_pub, signal_sec);
     let bcs = BellmanCS::<Bn256, WitnessCS<Fr>>::new(rcs.clone());
     let want = Proof::<Bn256>::from_bellman(
@@ -55,5 +55,10 @@ fn hip_proof_bytes_equal_bellman_create_proof() {
             fawkes_crypto::backend::bellman_groth16::num_to_bellman_fp(s)).unwrap());
 
     assert_eq!(got.try_to_vec().unwrap(), want.try_to_vec().unwrap(), "GPU proof bytes differ from bellman's");
+
+    // the sharded form of the same call: two ranks (the same GPU named twice works on a one-GPU machine; [0, 1] on a node)
+    let hip2 = HipProver::new(&[0, 0], &params);
+    let (_, got2) = prove_hip_with_rs(&params, &hip2, &root, &(leaf, proof.clone()), circuit, r, s);
+    assert_eq!(got2.try_to_vec().unwrap(), want.try_to_vec().unwrap(), "2-rank GPU proof bytes differ from bellman's");
     assert!(verifier::verify(&params.get_vk(), &got, &inputs), "Verifier result should be true");   // tests/bellman_groth16.rs:45-46
 }

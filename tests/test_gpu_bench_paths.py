@@ -12,10 +12,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(extra_env, *args):
+def _run(extra_env, *args, gpus=1):
     env = dict(os.environ, **extra_env)
-    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1', *args],
-                         env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(gpus), '--steps', '2', '--warmup', '1', *args],
+                         env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1, out.stdout[-2000:]
@@ -41,6 +41,29 @@ def test_bench_default_workload_small():
     _check_line(j)
     assert 'rollup-style transactions' in j['config']['workload'] and j['config']['num_input'] == 1 + 6 * 2
     assert j['config']['witness_bytes_per_proof'] == (j['config']['num_input'] + j['config']['num_aux']) * 32
+    # the CPU baseline is MEASURED at the benchmarked size when it fits the budget (here it does) and its proof equals the GPU's
+    assert j['cpu_baseline']['measured_at_full_size'] is True and 'MEASURED AT FULL SIZE' in j['cpu_baseline']['sample']
+    # the same system with every term explicit (no tiling shortcut), and the multiplications / transforms timed alone
+    assert j['untiled']['matrix_terms_resident'] == sum(j['config']['nnz']) and j['untiled']['device_resident_ms_per_step'] > 0
+    st = j['standalone']
+    assert st['msm_g1_2p20']['scalar_muls_per_sec'] > 1e7 and st['msm_g2_2p20']['scalar_muls_per_sec'] > 1e6 and st['ntt_2p20']['algorithmic_GBps'] > 1
+    assert j['kernel_ms_per_step']['ntt_sec8d_GBps'] > 0
+
+
+def test_bench_plain_command_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher and no WORLD_SIZE in the environment: bench.py starts the two ranks itself
+    (fresh child processes, before it has touched the GPU) and relays rank 0's line.  Both ranks share this box's one GPU
+    (FK_BENCH_SAME_DEVICE=1, gloo).  The line also carries the one-call form of the same proof (fk_multi_prove_r1cs)."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['FK_BENCH_SAME_DEVICE'] = '1'
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--steps', '2', '--warmup', '1', '--copies', '9'],
+                         env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
+    last = out.stdout.strip().splitlines()[-1]
+    j = json.loads(last)
+    assert j['n_gpus'] == 2 and j['value'] > 0 and j['proof_verified_by_pairing_check'] is True
+    assert j['single_process_multi_gpu']['ranks'] == 2 and j['single_process_multi_gpu']['ms_per_step'] > 0
+    assert j['replica_proofs_per_sec'] > 0
 
 
 def test_bench_synthetic_workload_small():

@@ -1,7 +1,7 @@
 """BASELINE.json's two large configurations at their FULL sizes on one GPU, where no CPU oracle can follow: the checks are
 the Groth16 pairing equation (oracle/bn254_ref.py verifier -- an independent big-int implementation), a negative control
 (one witness element changed: the proof must be rejected), and byte equality between independent routes to the same
-proof (single GPU vs 8 thread-ranks with sharded keys and the distributed quotient).
+proof (single GPU vs ONE fk_multi_prove_r1cs call on 8 ranks with sharded keys and the distributed quotient).
 
   configs[4]  2^27-row synthetic R1CS with the G2 MSM included -- the largest domain bellman accepts;
               proved once with FK_MSM_PRECOMP=0 (the W-bucket-set path for all five multiplications at the largest index
@@ -10,13 +10,10 @@ proof (single GPU vs 8 thread-ranks with sharded keys and the distributed quotie
   configs[3]  2^25 rollup-style R1CS, 1024-transaction shape: 1024 tiled rollup transactions (19.7 M gates, 9.6e8 matrix
               terms), the workload bench.py reports.
 """
-import threading
-
 import numpy as np
 import pytest
 
 import bn254_ref as ref
-from test_gpu_dist_quotient import DevBuf, HostExchange, run_ranks
 
 pytestmark = pytest.mark.gpu
 
@@ -73,14 +70,12 @@ def test_config4_2p27_rows_with_g2_pairing_checked(ctx):
         dr.free(); key.free()
 
 
-def test_config3_2p25_rollup1024_single_gpu_and_8_thread_ranks(ctx):
+def test_config3_2p25_rollup1024_single_gpu_and_one_call_on_8_ranks(ctx):
     """the 1024-transaction system: single-GPU proof pairing-checked against its 2048 public roots, then reproduced byte for
-    byte by 8 ranks (threads with their own library contexts on this GPU): key shards from fk_setup_tiled (each rank derives
-    only its shard), every rank evaluates the resident constraint system, distributed quotient over log_w = 3 with the
-    all-to-all emulated through host memory, 1/8 of each of the five MSMs, fold of the eight 384-byte records."""
+    byte by ONE fk_multi_prove_r1cs call on 8 ranks (this box's GPU named eight times: a library context and a worker thread
+    per rank, all-to-all and fold inside the library)."""
     import bench
     import fawkes_crypto_amd as fk
-    from fawkes_crypto_amd import parallel
     copies, world = 1024, 8
     inst, zs = bench.load_rollup_instance()
     z = bench.tile_witness(zs, inst.num_input, copies)
@@ -112,34 +107,27 @@ def test_config3_2p25_rollup1024_single_gpu_and_8_thread_ranks(ctx):
     ctx.host_free(zp)
     key.free()                                  # 140 GiB of key + levels make room for the eight shards' scratch
 
-    L = (1 << log_m) // world
-    ex = HostExchange(world)
-    parts = [None] * world
-    bar = threading.Barrier(world)
-    one_at_a_time = threading.Lock()
-    dens = dr.density_ptrs()
-
-    def rank_fn(c_, rank):
-        with one_at_a_time:                     # the shard derivations run one after the other (host memory, setup scratch)
-            sk, _ = c_.setup(inst, copies=copies, shard_index=rank, shard_count=world, **tox)
-        assert sk.shard_info()['h'] == (rank * L, min((rank + 1) * L, (1 << log_m) - 1))
-        full = [DevBuf(c_, (1 << log_m) * 32) for _ in range(3)]
-        send = [DevBuf(c_, L * 32) for _ in range(3)]
-        recv = [DevBuf(c_, L * 32) for _ in range(3)]
-        # the resident constraint system and the witness are read-only device memory shared by all contexts of the process
-        c_.r1cs_eval_dev(dr, d_z, *[f.data_ptr() for f in full])
-        blk = parallel.quotient_distributed(c_, rank, world, [f.data_ptr() for f in full], n, log_m, send, recv, ex.a2a_for(c_, rank))
-        parts[rank] = c_.prove_msms_hz_r1cs_dev(sk, dr, blk.data_ptr(), d_z)
-        bar.wait()
-        proof = c_.prove_assemble(sk, np.stack(parts), r, s)
-        for x in full + send + recv:
-            x.free()
-        sk.free()
-        return proof.tobytes()
-
+    ctx.dev_free(d_z); dr.free()
+    # ---- the same proof from ONE call on 8 ranks: fk_init_devices with this box's GPU named eight times, shard keys from
+    # fk_multi_setup_tiled (each rank derives only its shard), one constraint-system replica per rank, every rank evaluates only
+    # its rows t = g (mod 8), distributed quotient with the all-to-all inside the library, 1/8 of each multiplication
+    mc = fk.MultiContext([0] * world)
     try:
-        got = run_ranks(world, rank_fn)
-        assert all(g == want.tobytes() for g in got)
+        mkey, mvk = mc.setup(inst, copies=copies, **tox)
+        L = (1 << log_m) // world
+        for g in range(world):
+            assert mc.key_shard(mkey, g).shard_info()['h'] == (g * L, min((g + 1) * L, (1 << log_m) - 1))
+        assert all(np.array_equal(mvk[k], vk[k]) for k in vk)
+        mdr = mc.load_r1cs(inst, copies=copies)
+        got, tm = mc.prove_witness(mkey, mdr, z, r, s, want_timings=True)
+        assert got.tobytes() == want.tobytes()
+        # ... and pipelined from pinned host memory, twice
+        zp = mc.ctx(0).host_alloc(z.shape)
+        zp[:] = z
+        t0 = mc.prove_witness_submit(mkey, mdr, zp, r, s)
+        t1 = mc.prove_witness_submit(mkey, mdr, zp, r, s)
+        assert mc.prove_witness_wait(t0).tobytes() == want.tobytes() and mc.prove_witness_wait(t1).tobytes() == want.tobytes()
+        mc.ctx(0).host_free(zp)
+        mkey.free(); mdr.free()
     finally:
-        ctx.dev_free(d_z)
-        dr.free()
+        mc.close()

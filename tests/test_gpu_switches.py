@@ -1,7 +1,8 @@
-"""Every tuning / schedule switch of the library must leave the proof bytes unchanged: the alternative code paths (canonical
-instead of lazily reduced arithmetic, the scatter kernel shapes, the schedules, lane counts, fixed-base levels at small sizes)
-are run on a small tiled system in subprocesses -- the switches are read once per process -- and compared with the default
-path, which tests/test_gpu_tiled.py pins against the oracle."""
+"""The run-time switches a release build keeps ("Environment switches") must leave the proof bytes unchanged: both
+schedules, the fixed-base levels at a small size (FK_MSM_PRE_MIN_LOG2), levels off / required, the single-class SpMV -- run on
+a small tiled system in subprocesses (the switches are read per process) and compared with the default path, which
+tests/test_gpu_tiled.py pins against the oracle.  The tuning knobs measured slower in rounds 1-2 are compile-time constants
+now (`make EXP=1` builds the variant that reads them); the code paths measured slower were removed."""
 import os
 import subprocess
 import sys
@@ -11,24 +12,16 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SWITCHES = [
-    {'FK_MSM_LAZY': '0'}, {'FK_NTT_LAZY': '0'},
-    {'FK_PROVE_SORTS_FIRST': '1'}, {'FK_PROVE_SORTS_FIRST': '1', 'FK_PROVE_ACC_AFTER_NTT': '0'},
-    {'FK_PROVE_SORTS_FIRST': '1', 'FK_PROVE_SPMV_AFTER_SORTS': '1'}, {'FK_PROVE_SORTS_FIRST': '0'},
-    {'FK_PROVE_Z_EARLY': '0'}, {'FK_PROVE_WITNESS_FIRST': '0'},
-    {'FK_MSM_SORT_NT1': '0'}, {'FK_MSM_SORT_NT1': '256', 'FK_MSM_SORT_NT2': '256'}, {'FK_MSM_SORT_NT1': '512', 'FK_MSM_SORT_NT2': '1024'},
-    {'FK_MSM_LB': '12'}, {'FK_MSM_LB': '11', 'FK_MSM_C_SMALL': '20'},
-    {'FK_MSM_PRE_MIN_LOG2': '8'}, {'FK_MSM_PRE_MIN_LOG2': '8', 'FK_PROVE_SORTS_FIRST': '1'},
-    {'FK_MSM_PRE_MIN_LOG2': '8', 'FK_PROVE_SORTS_FIRST': '1', 'FK_MSM_H_PRIO': '1', 'FK_MSM_UNDER_NT1': '512', 'FK_MSM_UNDER_NT2': '512'},
-    {'FK_MSM_LANES': '1'}, {'FK_MSM_LANES': '2'}, {'FK_MSM_LIMB29': '1'}, {'FK_MSM_CU_SPLIT': '1'}, {'FK_MSM_SORT_ALONE': '1'},
-    {'FK_MSM_PRECOMP': '0'}, {'FK_MSM_RED_HIER': '1'}, {'FK_MSM_RED_HIER': '1', 'FK_MSM_PRE_MIN_LOG2': '8'}, {'FK_UPLOAD_DEFER': '0'},
-    {'FK_PROVE_SORTS_FIRST': '1', 'FK_PROVE_G2_FIRST': '1'}, {'FK_MSM_RED_L_G2': '16'}, {'FK_PROVE_SORTS_FIRST': '1', 'FK_PROVE_H_SORT_FIRST': '1'},
+    {'FK_PROVE_SORTS_FIRST': '1'}, {'FK_PROVE_SORTS_FIRST': '0'},
+    {'FK_MSM_PRE_MIN_LOG2': '8'}, {'FK_MSM_PRE_MIN_LOG2': '8', 'FK_PROVE_SORTS_FIRST': '1'}, {'FK_MSM_PRE_MIN_LOG2': '8', 'FK_MSM_PRECOMP': 'require'},
+    {'FK_MSM_PRECOMP': '0'}, {'FK_SPMV_BIN_MIN': '0'}, {'FK_DEBUG': '1'},
 ]
 
 
 def _child(env):
     e = dict(os.environ)
     for k in list(e):
-        if k.startswith(('FK_MSM_', 'FK_NTT_', 'FK_PROVE_')): del e[k]
+        if k.startswith(('FK_MSM_', 'FK_NTT_', 'FK_PROVE_', 'FK_SPMV_', 'FK_DEBUG')): del e[k]
     e.update(env)
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', '_switch_child.py')], env=e, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, (env, out.stderr[-2000:])
