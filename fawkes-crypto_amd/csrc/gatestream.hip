@@ -14,6 +14,9 @@
 // this image and on the GPU box -- bound at run time with dlopen: the format's 122 KB static dictionary makes a private
 // decoder pointless.  Without the library FK_GATES_BROTLI fails loudly with FK_ERR_UNSUPPORTED; FK_GATES_RAW needs nothing.
 #include "common.hpp"
+#include <new>
+#include <stdexcept>
+#include <algorithm>
 #include <dlfcn.h>
 #include <string.h>
 #include <string>
@@ -62,7 +65,8 @@ struct GateParser {
         g->table.push_back(one);
         uint8_t c1[32] = {1};
         dict.emplace(std::string((const char *)c1, 32), 0u);
-        for (int k = 0; k < 3; k++) { g->ptr[k].reserve(g->num_gates + 1); g->ptr[k].push_back(0); }
+        // num_gates comes straight from a file header: reserve what a plausible stream needs, let push_back grow beyond it
+        for (int k = 0; k < 3; k++) { g->ptr[k].reserve(std::min<uint64_t>(g->num_gates, (uint64_t)1 << 24) + 1); g->ptr[k].push_back(0); }
     }
     bool done() const { return gate == g->num_gates; }
 
@@ -132,10 +136,14 @@ static int gates_decode(fk_ctx *ctx, const uint8_t *blob, size_t len, int format
     *out = nullptr;
     if (num_input == 0) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "gates: num_input must include the constant ONE");
     if ((uint64_t)num_input + num_aux > 0xffffffffull) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "gates: too many variables");
-    fk_gates *g = new fk_gates();
+    // every gate is at least three 4-byte counts: a header that promises more gates than the stream can hold is malformed
+    if (format == FK_GATES_RAW && (uint64_t)num_gates * 12 > len) FK_SET_ERR(ctx, FK_ERR_FORMAT, "gates: %u gates cannot fit into %zu bytes", num_gates, len);
+    // owns the half-built system and the decoder state on every way out, exceptions (std::bad_alloc) included
+    struct Guard { fk_gates *g = nullptr; void *st = nullptr; const BrotliApi *br = nullptr; ~Guard() { if (st && br) br->destroy(st); delete g; } } guard;
+    fk_gates *g = guard.g = new fk_gates();
     g->num_input = num_input; g->num_aux = num_aux; g->num_gates = num_gates;
     GateParser ps(g);
-    auto fail = [&](int code, const std::string &msg) { ctx->err = "gates: " + msg; delete g; return code; };
+    auto fail = [&](int code, const std::string &msg) { ctx->err = "gates: " + msg; return code; };
     if (format == FK_GATES_RAW) {
         if (!ps.feed(blob, len)) return fail(FK_ERR_FORMAT, ps.err);
     } else if (format == FK_GATES_BROTLI) {
@@ -143,23 +151,23 @@ static int gates_decode(fk_ctx *ctx, const uint8_t *blob, size_t len, int format
         if (!br.ok) return fail(FK_ERR_UNSUPPORTED, "libbrotlidec.so.1 not found (needed for a brotli gate blob)");
         void *st = br.create(nullptr, nullptr, nullptr);
         if (!st) return fail(FK_ERR_OOM, "brotli decoder allocation failed");
+        guard.st = st; guard.br = &br;
         std::vector<uint8_t> buf((size_t)4 << 20);
         size_t avail_in = len; const uint8_t *next_in = blob;
         int res;
         do {
             size_t avail_out = buf.size(); uint8_t *next_out = buf.data();
             res = br.stream(st, &avail_in, &next_in, &avail_out, &next_out, nullptr);     // 0 error, 1 done, 2 needs input, 3 needs output
-            if (res == 0) { br.destroy(st); return fail(FK_ERR_FORMAT, "corrupt brotli stream"); }
-            if (!ps.feed(buf.data(), buf.size() - avail_out)) { br.destroy(st); return fail(FK_ERR_FORMAT, ps.err); }
-            if (res == 2 && avail_in == 0) { br.destroy(st); return fail(FK_ERR_FORMAT, "brotli stream truncated"); }
+            if (res == 0) return fail(FK_ERR_FORMAT, "corrupt brotli stream");
+            if (!ps.feed(buf.data(), buf.size() - avail_out)) return fail(FK_ERR_FORMAT, ps.err);
+            if (res == 2 && avail_in == 0) return fail(FK_ERR_FORMAT, "brotli stream truncated");
         } while (res != 1);
-        br.destroy(st);
     } else {
-        delete g;
         FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "gates: unknown blob format %d", format);
     }
     if (ps.n_carry || !ps.done()) return fail(FK_ERR_FORMAT, "gate stream truncated (fewer than num_gates gates)");
     *out = g;
+    guard.g = nullptr;
     return FK_OK;
 }
 
@@ -172,7 +180,11 @@ extern "C" {
 int fk_gates_decode(fk_ctx *ctx, const uint8_t *blob, size_t len, int format, uint32_t num_gates, uint32_t num_input, uint32_t num_aux, fk_gates **out) {
     fk_ctx local;                  // host-only routine: usable without a GPU context
     if (!ctx) ctx = &local;
-    return gates_decode(ctx, blob, len, format, num_gates, num_input, num_aux, out);
+    // a tiny brotli blob can inflate to anything: running out of host memory is a status code, never an exception that leaves
+    // an extern "C" function (std::terminate would take the ctypes / Rust host down)
+    try { return gates_decode(ctx, blob, len, format, num_gates, num_input, num_aux, out); }
+    catch (const std::bad_alloc &) { if (out) *out = nullptr; ctx->err = "gates: out of host memory while decoding the gate stream"; return FK_ERR_OOM; }
+    catch (const std::length_error &) { if (out) *out = nullptr; ctx->err = "gates: the gate stream is larger than this host can hold"; return FK_ERR_OOM; }
 }
 
 void fk_gates_free(fk_gates *g) { delete g; }
@@ -205,5 +217,6 @@ extern "C" int fk_r1cs_load_gates(fk_ctx *ctx, const fk_gates *g, fk_r1cs_dev **
     const uint64_t *ptr[3] = {g->ptr[0].data(), g->ptr[1].data(), g->ptr[2].data()};
     const uint32_t *col[3] = {g->col[0].data(), g->col[1].data(), g->col[2].data()};
     const uint32_t *cidx[3] = {g->cidx[0].data(), g->cidx[1].data(), g->cidx[2].data()};
-    return r1cs_load_coded(ctx, g->num_input, g->num_aux, g->num_gates, ptr, col, cidx, g->table.data(), g->table.size(), out);
+    try { return r1cs_load_coded(ctx, g->num_input, g->num_aux, g->num_gates, ptr, col, cidx, g->table.data(), g->table.size(), out); }
+    catch (const std::bad_alloc &) { *out = nullptr; ctx->err = "r1cs: out of host memory"; return FK_ERR_OOM; }
 }

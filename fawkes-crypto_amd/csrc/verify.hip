@@ -51,6 +51,21 @@ static FK_HD int verify_one(const uint8_t *vk, uint32_t n_ic, const FrT *inputs,
     const Affine<Fq> A = g1_from_borsh<Fq>(proof, &ok), C = g1_from_borsh<Fq>(proof + 192, &ok);
     const Affine<Fq2T<Fq>> B = g2_from_borsh<Fq>(proof + 64, &ok);
     if (!ok) return -1;
+    // The reference decodes the proof unchecked (from_raw_uncompressed_le, group.rs:59-66), so on honest inputs nothing differs;
+    // but the Miller loop below assumes B has prime order r (it never meets R = +-Q then) and an off-curve or wrong-subgroup point
+    // would make accept / reject unspecified.  Such proofs are REJECTED here: A, C on y^2 = x^3 + 3 (cofactor 1), B on the twist
+    // and r * B = identity -- one scalar multiplication per proof, not a hot path.
+    {
+        const uint32_t bw[8] = FK_G1_B, b0[8] = FK_G2_B0, b1[8] = FK_G2_B1, rw[8] = FK_R_CANON;
+        auto cst = [](const uint32_t (&w)[8]) { Fq t; for (int i = 0; i < 8; i++) t.v[i] = w[i]; return t; };
+        auto on_g1 = [&](const Affine<Fq> &P) { return P.is_inf() || Fq::sqr(P.y) == Fq::add(Fq::mul(Fq::sqr(P.x), P.x), cst(bw)); };
+        using F2 = Fq2T<Fq>;
+        if (!on_g1(A) || !on_g1(C)) return 0;
+        if (!B.is_inf()) {
+            if (F2::sqr(B.y) != F2::add(F2::mul(F2::sqr(B.x), B.x), F2{cst(b0), cst(b1)})) return 0;
+            if (!Xyzz<F2>::mul_scalar(Xyzz<F2>::from_affine(B), rw).is_inf()) return 0;
+        }
+    }
     return groth16_check<Fq>(A, B, C, alpha, beta, gamma, delta, acc.to_affine()) ? 1 : 0;
 }
 

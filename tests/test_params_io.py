@@ -276,3 +276,15 @@ def test_handmade_bellman_key_bytes(ctx):
     ctx.load_key_bellman(bytes(bad), flags=0)[0].free()
     # the verifying key is always decoded with the curve check (VerifyingKey::read uses into_affine), `checked` or not
     bad = bytearray(data); bad[63] ^= 1; rejected(bad, flags=0)
+
+
+def test_gate_decoder_refuses_a_forged_gate_count():
+    """`num_gates` comes from the file header: a count the stream cannot hold is InvalidData at once (no 3 x 32 GiB reservation,
+    no exception leaving the C ABI)"""
+    import fawkes_crypto_amd as fk
+    from fawkes_crypto_amd import api
+    stream = b'\x00' * 12 * 5                                  # five gates of three empty linear combinations
+    api.Gates(stream, api.FK_GATES_RAW, 5, 1, 0).free()
+    with pytest.raises(fk.FkError) as e:
+        api.Gates(stream, api.FK_GATES_RAW, 0xffffffff, 1, 0)
+    assert e.value.code == 7

@@ -106,3 +106,42 @@ def test_batch_verifier_on_the_gpu(ctx, oracle):
     got = api.verify_batch(ctx, vkb, inputs, proofs)
     assert np.array_equal(got, want)
     assert all(api.verify(vkb, inputs[i], proofs[i].tobytes()) == bool(want[i]) for i in (0, 1, 3, 4))
+
+
+def test_host_verifier_rejects_points_outside_the_groups(oracle):
+    """proof points that are canonical field elements but not group elements -- A or C off the curve, B on the twist but outside
+    the order-r subgroup -- are rejected outright (the pairing loop assumes prime-order points); honest proofs are unaffected"""
+    from fawkes_crypto_amd import api
+    key, z, z_in, proof = _instance(oracle, 9, 40, 2, 45)
+    vkb = api.vk_to_borsh(_vk_of(key))
+    inputs = z[1:2]
+    assert api.verify(vkb, inputs, proof.tobytes()) is True
+    A, B, C = ref.proof_from_borsh(proof.tobytes())
+    assert api.verify(vkb, inputs, ref.proof_borsh((A[0], (A[1] + 1) % ref.Q), B, C)) is False        # A off the curve
+    assert api.verify(vkb, inputs, ref.proof_borsh(A, B, (C[0], (C[1] + 1) % ref.Q))) is False        # C off the curve
+    # a point ON the twist that is not in the order-r subgroup (the twist's cofactor is large: almost every curve point)
+    F2, b2 = ref.F2, ref.G2.b
+
+    def fq_sqrt(v):
+        y = pow(v, (ref.Q + 1) // 4, ref.Q)
+        return y if y * y % ref.Q == v % ref.Q else None
+
+    def fq2_sqrt(a0, a1):
+        alpha = fq_sqrt((a0 * a0 + a1 * a1) % ref.Q)
+        if alpha is None:
+            return None
+        for d in ((a0 + alpha) * pow(2, -1, ref.Q) % ref.Q, (a0 - alpha) * pow(2, -1, ref.Q) % ref.Q):
+            x0 = fq_sqrt(d)
+            if x0:
+                return x0, a1 * pow(2 * x0, -1, ref.Q) % ref.Q
+        return None
+    x = (11, 3)
+    while True:
+        rhs = F2.add(F2.mul(F2.sqr(x), x), b2)
+        y = fq2_sqrt(*rhs)
+        if y is not None and F2.sqr(y) == rhs:
+            break
+        x = (x[0] + 1, x[1])
+    assert ref.G2.on_curve((x, y)) and ref.G2.mul((x, y), ref.R) is not None
+    assert api.verify(vkb, inputs, ref.proof_borsh(A, (x, y), C)) is False
+    assert api.verify(vkb, inputs, ref.proof_borsh(A, (B[0], (B[1][0], (B[1][1] + 1) % ref.Q)), C)) is False   # B off the twist
