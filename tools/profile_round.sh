@@ -3,11 +3,11 @@
 # Usage: bash tools/profile_round.sh [tag]      -> gpurun_out/<tag>/
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-TAG=${1:-r02}; O=gpurun_out/$TAG; mkdir -p $O
-B="bench.py --steps 1 --warmup 0 --no-cpu-baseline"
+TAG=${1:-r03}; O=gpurun_out/$TAG; mkdir -p $O
+B="bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-untiled --no-standalone"
 python3 -m pytest tests -m gpu -q --durations=10 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log; tail -4 $O/pytest_gpu.log
 python3 bench.py --steps 10 --warmup 3 > $O/bench.log 2>&1; tail -c 1500 $O/bench.log; echo
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o k -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline > $O/kt.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o k -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-untiled --no-standalone > $O/kt.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -o f -- python3 $B > $O/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -o w -- python3 $B > $O/write.log 2>&1
 rocprofv3 --pmc VALUBusy VALUUtilization MemUnitBusy --output-format csv -d $O/derived -o d -- python3 $B > $O/derived.log 2>&1

@@ -1,7 +1,9 @@
-# Standalone cost of every kernel of a proof (GPU box): one lane, quotient first -- nothing overlaps -- under rocprofv3 --kernel-trace --stats
+# Standalone cost of every kernel of a proof (GPU box): one lane, quotient first -- nothing overlaps -- under rocprofv3 --kernel-trace --stats.
+# The knobs it sets are tuning knobs: they exist in the experiment build only (make -C fawkes-crypto_amd/csrc EXP=1 -> libfawkes_hip_exp.so).
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"; O=gpurun_out/serial; mkdir -p $O
-FK_MSM_PRE_DC=${PRE_DC:-2} FK_MSM_LANES=1 FK_PROVE_WITNESS_FIRST=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o k -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline > $O/kt.log 2>&1
+export FK_LIB_VARIANT=exp FK_MSM_PRE_DC=${PRE_DC:-3} FK_MSM_LANES=1 FK_PROVE_WITNESS_FIRST=0 FK_PROVE_SORTS_FIRST=0
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o k -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-untiled --no-standalone > $O/kt.log 2>&1
 grep '^{' $O/kt.log | python3 -c "
 import json,sys
 for l in sys.stdin:
