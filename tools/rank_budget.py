@@ -1,0 +1,109 @@
+#!/usr/bin/env python3
+"""Per-rank compute budget of the N-GPU prover, measured on ONE GPU: for W = 1, 2, 4, 8 the share of rank 0 of W -- its key
+shard, its cyclic row slice, its 1/W of every transform, its slices of the five multiplications -- runs ALONE on the device
+through the same C-ABI pieces the multi-GPU schedules issue (fk_r1cs_eval_slice_dev, fk_dq_*, fk_prove_msms_hz_r1cs_dev), with
+the all-to-all replaced by a device-local copy of the same size.  What a rank's GPU has to do per proof is therefore measured;
+what it has to wait for -- the xGMI exchanges -- is link arithmetic (printed beside it), since a one-GPU box has no links.
+
+    python tools/rank_budget.py [--copies 1024] [--ranks 1,2,4,8]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+
+import bench  # noqa: E402  (workload helpers only)
+import fawkes_crypto_amd as fk  # noqa: E402
+from fawkes_crypto_amd import parallel  # noqa: E402
+
+XGMI_GBPS_PER_LINK_PER_DIRECTION = 64.0      # 128 GB/s bidirectional per link (MI355X_MICROARCH.md: 7 links x ~153 GB/s peak); ~64 GB/s one way in practice
+
+
+class Buf:
+    def __init__(self, ctx, nbytes):
+        self.ctx, self.nbytes, self.ptr = ctx, nbytes, ctx.dev_alloc(nbytes)
+
+    def data_ptr(self):
+        return self.ptr
+
+    def free(self):
+        self.ctx.dev_free(self.ptr)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--copies', type=int, default=1024)
+    ap.add_argument('--ranks', default='1,2,4,8')
+    ap.add_argument('--reps', type=int, default=3)
+    args = ap.parse_args()
+    ctx = fk.Context(0)
+    r1cs, zs = bench.load_rollup_instance()
+    copies = args.copies
+    num_input = 1 + copies * (r1cs.num_input - 1)
+    n = copies * r1cs.num_gates + num_input
+    log_m = max(n - 1, 1).bit_length()
+    m = 1 << log_m
+    z = bench.tile_witness(zs, r1cs.num_input, copies)
+    d_z = ctx.dev_alloc(z.nbytes)
+    ctx.upload(d_z, z)
+    dr = ctx.load_r1cs(r1cs, copies=copies)
+    tox = {k: bench.mont(v) for k, v in bench.TOXIC.items()}
+    out = {'workload': '%d rollup-style transactions, domain 2^%d' % (copies, log_m), 'ranks': {}}
+    for W in [int(x) for x in args.ranks.split(',')]:
+        lw = parallel.log2_world(W)
+        L = m >> lw
+        key, _ = ctx.setup(r1cs, copies=copies, shard_index=0, shard_count=W, **tox)
+        send = [Buf(ctx, L * 32) for _ in range(3)]
+        recv = [Buf(ctx, L * 32) for _ in range(3)]
+
+        def a2a(dst, src):          # the same bytes moved, device-locally (the exchange itself is not what is measured here)
+            for d_, s_ in zip(dst, src):
+                ctx.dev_copy(d_.data_ptr(), s_.data_ptr(), s_.nbytes)
+
+        def timed(fn):
+            fn(); ctx.sync()
+            t0 = time.perf_counter()
+            for _ in range(args.reps):
+                fn()
+            ctx.sync()
+            return (time.perf_counter() - t0) / args.reps * 1e3
+
+        def ev():
+            ctx.r1cs_eval_slice_dev(dr, d_z, log_m, 0, lw, *[b.data_ptr() for b in send])
+
+        def quot():
+            return parallel.quotient_distributed(ctx, 0, W, None, n, log_m, send, recv, a2a, slices_in_send=True)
+
+        def msms():
+            return ctx.prove_msms_hz_r1cs_dev(key, dr, send[0].data_ptr(), d_z)
+
+        def whole():
+            ev(); blk = quot()
+            return ctx.prove_msms_hz_r1cs_dev(key, dr, blk.data_ptr(), d_z)
+
+        t_ev = timed(ev)
+        ev(); t_q = timed(quot)
+        t_m = timed(msms)
+        t_all = timed(whole)
+        # exchanges: 7 per proof, each rank sends (W - 1) / W of its L * 32 bytes, one chunk per peer, every peer on a link of its own
+        chunk = L * 32 // W
+        t_x = 7 * (chunk / (XGMI_GBPS_PER_LINK_PER_DIRECTION * 1e9)) * 1e3 if W > 1 else 0.0
+        out['ranks'][str(W)] = {'eval_slice_ms': t_ev, 'quotient_compute_ms': t_q, 'msms_ms': t_m, 'whole_share_ms': t_all,
+                                'witness_upload_bytes_per_rank': int(z.nbytes), 'exchange_bytes_per_rank_per_proof': 7 * chunk * (W - 1),
+                                'exchange_ms_by_link_arithmetic': t_x,
+                                'levels': key.precomputed(), 'h_points': key.shard_info()['h'][1] - key.shard_info()['h'][0]}
+        print('W = %d: eval %.2f ms, quotient %.2f ms, MSMs %.2f ms, whole share %.2f ms; exchanges %.2f ms by link arithmetic' % (W, t_ev, t_q, t_m, t_all, t_x),
+              flush=True)
+        for b in send + recv:
+            b.free()
+        key.free()
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()
