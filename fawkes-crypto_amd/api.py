@@ -39,7 +39,7 @@ EXPORTED_SYMBOLS = [
     'fk_setup', 'fk_setup_tiled', 'fk_r1cs_load_tiled', 'fk_key_download', 'fk_key_load_bellman', 'fk_key_vk', 'fk_key_counts', 'fk_key_precomputed',
     'fk_gates_decode', 'fk_gates_free', 'fk_gates_info', 'fk_gates_export', 'fk_r1cs_load_gates',
     'fk_r1cs_load', 'fk_r1cs_load_coded', 'fk_r1cs_free', 'fk_r1cs_info', 'fk_r1cs_density_ptrs', 'fk_r1cs_eval_dev', 'fk_r1cs_eval_slice_dev', 'fk_prove_r1cs', 'fk_prove_r1cs_dev',
-    'fk_init_devices', 'fk_multi_free', 'fk_multi_last_error', 'fk_multi_size', 'fk_multi_ctx', 'fk_multi_sync',
+    'fk_init_devices', 'fk_multi_free', 'fk_multi_last_error', 'fk_multi_size', 'fk_multi_transport', 'fk_multi_ctx', 'fk_multi_sync',
     'fk_multi_key_load', 'fk_multi_key_load_bellman', 'fk_multi_setup', 'fk_multi_setup_tiled', 'fk_multi_key_free', 'fk_multi_key_shard',
     'fk_multi_r1cs_load', 'fk_multi_r1cs_load_tiled', 'fk_multi_r1cs_load_gates', 'fk_multi_r1cs_free', 'fk_multi_r1cs_replica',
     'fk_multi_prove_r1cs', 'fk_multi_prove_r1cs_submit', 'fk_multi_prove_r1cs_wait',
@@ -120,6 +120,8 @@ def load_library():
         lib.fk_multi_key_free.restype = None
         lib.fk_multi_r1cs_free.argtypes = [C.c_void_p, C.c_void_p]
         lib.fk_multi_r1cs_free.restype = None
+        lib.fk_multi_transport.restype = C.c_char_p
+        lib.fk_multi_transport.argtypes = [C.c_void_p]
         lib.fk_multi_ctx.restype = C.c_void_p
         lib.fk_multi_ctx.argtypes = [C.c_void_p, C.c_int]
         lib.fk_multi_key_shard.restype = C.c_void_p
@@ -895,6 +897,16 @@ class MultiContext:
     @property
     def size(self):
         return int(self.lib.fk_multi_size(self.handle))
+
+    @property
+    def transport(self):
+        """'peer-dma' (hipMemcpyPeerAsync pulls) or 'rccl' (FK_MULTI_TRANSPORT=rccl)"""
+        return self.lib.fk_multi_transport(self.handle).decode()
+
+    def note(self):
+        """text left by fk_init_devices / the last call (e.g. why RCCL was not used)"""
+        msg = self.lib.fk_multi_last_error(self.handle)
+        return msg.decode() if msg else ''
 
     def close(self):
         if getattr(self, 'handle', None):

@@ -15,6 +15,12 @@
 // and consumers with HIP events (the host threads only tell each other that an event has been recorded).  The exchange of
 // polynomial k runs while the rank-local transform of polynomial k + 1 does, like the RCCL form in parallel.py.
 // Device ids may repeat (several ranks on one GPU: how a one-GPU box tests this path; copies are then device-local).
+//
+// FK_MULTI_TRANSPORT=rccl selects the other transport for the same seven exchanges: RCCL (bound with dlopen: librccl.so.1) --
+// one communicator per rank from ncclCommInitAll, every exchange a group of ncclSend / ncclRecv on the rank's exchange stream.
+// The ordering against the kernels is the same pair of events; the ranks' rendezvous is RCCL's.  Distinct devices only (a
+// communicator cannot name a GPU twice); anything that keeps RCCL from starting falls back to the peer copies with a note in
+// fk_multi_last_error.  Default: peer copies -- the one transport a one-GPU box can execute with more than one rank.
 #include "r1cs.hpp"
 #include <atomic>
 #include <condition_variable>
@@ -25,6 +31,7 @@
 #include <chrono>
 #include <string.h>
 #include <stdlib.h>
+#include <dlfcn.h>
 
 using namespace fk;
 
@@ -34,6 +41,34 @@ struct fk_multi_r1cs { std::vector<fk_r1cs_dev *> rep; };
 namespace fk {
 
 static constexpr int MX_EXCHANGES = 7;       // per proof: three ifft halves, two coset halves, icoset half, block-cyclic -> blocks
+
+// librccl, bound at run time like libbrotlidec: the library has no link-time dependency on it
+struct RcclApi {
+    typedef void *comm_t;
+    int (*CommInitAll)(comm_t *, int, const int *) = nullptr;
+    int (*CommDestroy)(comm_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void *, size_t, int, int, comm_t, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, comm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    bool ok = false;
+    RcclApi() {
+        void *h = nullptr;
+        for (const char *nm : {"librccl.so.1", "librccl.so"}) if ((h = dlopen(nm, RTLD_NOW | RTLD_LOCAL))) break;
+        if (!h) return;
+        CommInitAll = (decltype(CommInitAll))dlsym(h, "ncclCommInitAll");
+        CommDestroy = (decltype(CommDestroy))dlsym(h, "ncclCommDestroy");
+        GroupStart = (decltype(GroupStart))dlsym(h, "ncclGroupStart");
+        GroupEnd = (decltype(GroupEnd))dlsym(h, "ncclGroupEnd");
+        Send = (decltype(Send))dlsym(h, "ncclSend");
+        Recv = (decltype(Recv))dlsym(h, "ncclRecv");
+        GetErrorString = (decltype(GetErrorString))dlsym(h, "ncclGetErrorString");
+        ok = CommInitAll && CommDestroy && GroupStart && GroupEnd && Send && Recv;
+    }
+};
+static const RcclApi &rccl_api() { static RcclApi a; return a; }
+static constexpr int NCCL_UINT8 = 1;        // ncclUint8 (rccl.h)
 
 struct MultiWorker {
     std::thread th;
@@ -68,6 +103,8 @@ struct fk_multi {
     std::atomic<int> abort{0};
     uint64_t seq = 0;                                   // exchanges begun so far (same on every rank: they run the same schedule)
     bool host_event_wait = false;                       // FK_MULTI_HOST_EVENTS=1: wait for a peer's event on the host instead of in the stream
+    bool force_exchange = false;                        // FK_MULTI_FORCE_EXCHANGE=1: run the distributed schedule (exchanges with itself) even with ONE rank -- test aid
+    std::vector<void *> comms;                          // FK_MULTI_TRANSPORT=rccl: one RCCL communicator per rank (empty: peer copies)
     // barrier of the rank threads
     std::mutex bmu;
     std::condition_variable bcv;
@@ -156,6 +193,23 @@ static int xchg_begin(fk_multi *M, int rank, int e, int dst_sel, int src_sel, in
     FK_HIP(ctx, hipEventRecord(me.ev_ready[e], ctx->stream));
     me.posted.store(seq, std::memory_order_release);
     uint8_t *dst = (uint8_t *)(dst_sel ? me.recv[k].p : me.send[k].p);
+    if (!M->comms.empty()) {
+        // RCCL: this rank's sends read its own source (ready behind ev_ready), its receives write its own destination (free: its
+        // last consumer is earlier on the main stream, hence behind ev_ready too); the rendezvous with the peers is RCCL's
+        const RcclApi &nc = rccl_api();
+        const uint8_t *src = (const uint8_t *)(src_sel ? me.recv[k].p : me.send[k].p);
+        FK_HIP(ctx, hipStreamWaitEvent(me.xs, me.ev_ready[e], 0));
+        int rc = nc.GroupStart();
+        for (int p = 0; p < M->n && rc == 0; p++) {
+            rc = nc.Send(src + (size_t)p * chunk_bytes, chunk_bytes, NCCL_UINT8, p, M->comms[rank], me.xs);
+            if (rc == 0) rc = nc.Recv(dst + (size_t)p * chunk_bytes, chunk_bytes, NCCL_UINT8, p, M->comms[rank], me.xs);
+        }
+        const int rce = nc.GroupEnd();
+        if (rc == 0) rc = rce;
+        if (rc != 0) FK_SET_ERR(ctx, FK_ERR_HIP, "RCCL all-to-all failed: %s", nc.GetErrorString ? nc.GetErrorString(rc) : "?");
+        FK_HIP(ctx, hipEventRecord(me.ev_done[e], me.xs));
+        return FK_OK;
+    }
     for (int i = 0; i < M->n; i++) {
         const int p = (rank + i) % M->n;             // start with the own chunk, then walk the peers in a rotated order (spreads the links)
         MultiRank &peer = M->ranks[p];
@@ -234,7 +288,7 @@ static int prove_rank(fk_multi *M, int rank, const fk_multi_key *K, const fk_mul
     const uint64_t rows = rs->num_gates + rs->num_input;
     if (rows > key->m || (key->m > 1 && rows <= key->m / 2)) FK_SET_ERR(ctx, FK_ERR_KEY_MISMATCH, "prove: %llu rows do not match key domain %llu",
                                                                      (unsigned long long)rows, (unsigned long long)key->m);
-    if (M->n == 1) return fk_prove_r1cs_dev(ctx, key, rs, d_z, r_, s_, out, tm);       // nothing to cut: the single-GPU prover
+    if (M->n == 1 && !M->force_exchange) return fk_prove_r1cs_dev(ctx, key, rs, d_z, r_, s_, out, tm);       // nothing to cut: the single-GPU prover
     const uint32_t log_m = ceil_log2_u64(key->m);
     uint8_t *part = me.part;
     if (M->pow2 && log_m >= 2 * M->log_w) {
@@ -298,6 +352,7 @@ int fk_init_devices(int n_devices, const int *device_ids, fk_multi **out) {
     M->pow2 = (n_devices & (n_devices - 1)) == 0 && n_devices <= 8;
     while ((1 << M->log_w) < n_devices) M->log_w++;
     { const char *e = getenv("FK_MULTI_HOST_EVENTS"); M->host_event_wait = e && e[0] && e[0] != '0'; }
+    { const char *e = getenv("FK_MULTI_FORCE_EXCHANGE"); M->force_exchange = e && e[0] && e[0] != '0'; }
     int rc = FK_OK;
     for (int i = 0; i < n_devices && rc == FK_OK; i++) {
         fk_ctx *c = nullptr;
@@ -327,6 +382,21 @@ int fk_init_devices(int n_devices, const int *device_ids, fk_multi **out) {
         delete M;
         return rc;
     }
+    {   // FK_MULTI_TRANSPORT=rccl: communicators for the exchanges (distinct devices only); any obstacle leaves the peer copies in place
+        const char *e = getenv("FK_MULTI_TRANSPORT");
+        if (e && !strcmp(e, "rccl") && M->pow2) {
+            bool distinct = true;
+            for (int i = 0; i < n_devices; i++) for (int j = i + 1; j < n_devices; j++) distinct = distinct && device_ids[i] != device_ids[j];
+            const RcclApi &nc = rccl_api();
+            if (!nc.ok) M->err = "note: FK_MULTI_TRANSPORT=rccl but librccl.so.1 could not be bound -- peer copies are used";
+            else if (!distinct) M->err = "note: FK_MULTI_TRANSPORT=rccl needs distinct devices -- peer copies are used";
+            else {
+                M->comms.assign(n_devices, nullptr);
+                const int rcn = nc.CommInitAll(M->comms.data(), n_devices, device_ids);
+                if (rcn != 0) { M->comms.clear(); M->err = std::string("note: ncclCommInitAll failed (") + (nc.GetErrorString ? nc.GetErrorString(rcn) : "?") + ") -- peer copies are used"; }
+            }
+        }
+    }
     for (int i = 0; i < n_devices; i++) M->workers.emplace_back();
     for (int i = 0; i < n_devices; i++) M->workers[i].th = std::thread(worker_main, M, i);
     *out = M;
@@ -348,9 +418,13 @@ void fk_multi_free(fk_multi *M) {
         for (int e = 0; e < MX_EXCHANGES; e++) { if (rk.ev_ready[e]) (void)hipEventDestroy(rk.ev_ready[e]); if (rk.ev_done[e]) (void)hipEventDestroy(rk.ev_done[e]); }
         for (int k = 0; k < 3; k++) { rk.send[k].release(); rk.recv[k].release(); }
     }
+    for (void *c : M->comms) if (c) (void)rccl_api().CommDestroy(c);
     for (fk_ctx *c : M->ctx) fk_free(c);
     delete M;
 }
+
+// which transport the exchanges use: "rccl" or "peer-dma"
+const char *fk_multi_transport(const fk_multi *M) { return (M && !M->comms.empty()) ? "rccl" : "peer-dma"; }
 
 const char *fk_multi_last_error(const fk_multi *M) { return M ? M->err.c_str() : "null multi-GPU context"; }
 int fk_multi_size(const fk_multi *M) { return M ? M->n : 0; }

@@ -385,7 +385,10 @@ int fk_key_counts(const fk_key *key, uint64_t out[8]);
  * a GPU (how a one-GPU box tests the path).  The proof bytes do not depend on N.
  * An fk_multi is not thread-safe (one call at a time); keys and constraint systems loaded through it belong to it.
  * FK_OVERLAP_WITNESS=1 / 0: begin the witness multiplications before the quotient (default from 4 ranks on);
- * FK_MULTI_HOST_EVENTS=1: wait for a peer GPU's event on the host instead of in the stream (diagnosis). */
+ * FK_MULTI_HOST_EVENTS=1: wait for a peer GPU's event on the host instead of in the stream (diagnosis);
+ * FK_MULTI_TRANSPORT=rccl: the seven exchanges as grouped ncclSend / ncclRecv over one RCCL communicator per rank (librccl.so.1
+ * bound with dlopen; distinct devices only; falls back to the peer copies with a note in fk_multi_last_error);
+ * FK_MULTI_FORCE_EXCHANGE=1: run the distributed schedule even with one rank (test aid). */
 typedef struct fk_multi fk_multi;
 typedef struct fk_multi_key fk_multi_key;
 typedef struct fk_multi_r1cs fk_multi_r1cs;
@@ -393,6 +396,8 @@ int fk_init_devices(int n_devices, const int *device_ids, fk_multi **out);
 void fk_multi_free(fk_multi *multi);
 const char *fk_multi_last_error(const fk_multi *multi);
 int fk_multi_size(const fk_multi *multi);
+/* "peer-dma" (hipMemcpyPeerAsync pulls, the default) or "rccl" */
+const char *fk_multi_transport(const fk_multi *multi);
 /* rank `rank`'s single-GPU context (statistics, calibration, building blocks); owned by the fk_multi */
 fk_ctx *fk_multi_ctx(fk_multi *multi, int rank);
 int fk_multi_sync(fk_multi *multi);

@@ -176,3 +176,33 @@ def test_multi_init_argument_checks():
         fk.MultiContext([])
     with pytest.raises(fk.FkError):
         fk.MultiContext([0, 99])
+
+
+@pytest.mark.parametrize('transport', ['peer-dma', 'rccl'])
+def test_one_rank_runs_the_exchanges_over_both_transports(ctx, oracle, monkeypatch, transport):
+    """FK_MULTI_FORCE_EXCHANGE=1: a single rank runs the distributed schedule -- seven exchanges with itself -- once with the
+    peer copies and once over a real RCCL communicator (FK_MULTI_TRANSPORT=rccl: librccl bound with dlopen, ncclCommInitAll,
+    grouped ncclSend / ncclRecv on the exchange stream).  What a one-GPU box can execute of the RCCL transport; same bytes."""
+    import fawkes_crypto_amd as fk
+    csr, okey, z, z_in, r, s, want = _toy(oracle, 6200, 1500, 3, 1600)
+    monkeypatch.setenv('FK_MULTI_FORCE_EXCHANGE', '1')
+    if transport == 'rccl':
+        monkeypatch.setenv('FK_MULTI_TRANSPORT', 'rccl')
+    mc = fk.MultiContext([0])
+    try:
+        assert mc.transport == transport, mc.note()
+        tox = {k: fx.mont_fr(v) for k, v in TOXIC.items()}
+        key, _ = mc.setup(r1cs_product(csr), **tox)
+        dr = mc.load_r1cs(r1cs_product(csr))
+        for _ in range(2):
+            assert mc.prove_witness(key, dr, z, r, s).tobytes() == want.tobytes()
+        key.free(); dr.free()
+    finally:
+        mc.close()
+    # two ranks on ONE device cannot share a communicator: the library says so and keeps the peer copies
+    if transport == 'rccl':
+        mc = fk.MultiContext([0, 0])
+        try:
+            assert mc.transport == 'peer-dma' and 'distinct devices' in mc.note()
+        finally:
+            mc.close()
