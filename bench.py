@@ -21,15 +21,22 @@ The key is a VALID key (fk_setup*, fixed toxic waste), so the proof produced in 
 with the Groth16 pairing equation.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py --gpus N --steps K --warmup W          (starts its own N ranks: torch.distributed.run as a child process)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-N > 1: one process per GPU, strong scaling of a single proof: every rank holds 1/N of each key array (MSM sharded
-by points) and computes 1/N of the quotient -- the transforms are cut across the ranks with one all-to-all
-(RCCL over xGMI) each -- then ONE all-gather of 384 bytes per rank exchanges the partial MSM sums and the proof is
-folded locally (fawkes-crypto_amd/parallel.py: prove_distributed_dev).  With 2 ranks, or a rank count that is not a
-power of two, rank 0 computes the quotient while the other ranks start on the witness MSMs, and h slices travel point
-to point (prove_balanced_dev); FK_DIST_QUOTIENT=1 / 0 forces either schedule.
+N > 1: one process per GPU, strong scaling of a single proof: every rank holds 1/N of each key array (MSM sharded by points),
+evaluates only the rows t = rank (mod N) of a, b, c and computes 1/N of the quotient -- the transforms are cut across the
+ranks with one all-to-all (RCCL over xGMI) each -- then ONE all-gather of 384 bytes per rank exchanges the partial MSM sums and
+the proof is folded locally (fawkes-crypto_amd/parallel.py: prove_distributed_dev).  With 2 ranks, or a rank count that is not a
+power of two, rank 0 computes the quotient while the other ranks start on the witness MSMs, and h slices travel point to point
+(prove_balanced_dev); FK_DIST_QUOTIENT=1 / 0 forces either schedule.  The line of an N-rank run also carries the one-call form
+of the same proof (`single_process_multi_gpu`: fk_init_devices + fk_multi_prove_r1cs, one process driving all GPUs, exchanges
+inside the library) and the throughput mode (`replica_proofs_per_sec`).
+
+Beside `value` (N = 1): `cpu_baseline` MEASURED at the benchmarked size when the projection from a sample fits --cpu-full-budget
+(the C oracle proves the same 2^25 system; its bytes must equal the GPU's), `standalone` (G1 / G2 MSM and Fr NTT timed alone,
+SURVEY 8(d) units), `untiled` (the same circuit with every matrix term explicit in HBM, fk_r1cs_load_coded).
 
 The CPU oracle (oracle/) appears here only in the `cpu_baseline` leg: the timed CPU baseline (one thread = the
 reference's configured worker, and all host cores = bellman's multicore split), a live parity check of that same

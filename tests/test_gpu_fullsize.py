@@ -131,3 +131,15 @@ def test_config3_2p25_rollup1024_single_gpu_and_one_call_on_8_ranks(ctx):
         mkey.free(); mdr.free()
     finally:
         mc.close()
+    # ... and on 2 ranks: half-size shards -- the h shard (2^24 points) keeps its fixed-base levels, the l / a / b shards take the
+    # W-bucket-set path: the two accumulation forms side by side in one proof
+    mc = fk.MultiContext([0, 0])
+    try:
+        mkey, _ = mc.setup(inst, copies=copies, **tox)
+        pre = mc.key_shard(mkey, 1).precomputed()
+        assert pre['h'] > 0 and pre['l'] == 0
+        mdr = mc.load_r1cs(inst, copies=copies)
+        assert mc.prove_witness(mkey, mdr, z, r, s).tobytes() == want.tobytes()
+        mkey.free(); mdr.free()
+    finally:
+        mc.close()
