@@ -33,6 +33,8 @@ def test_no_gpu_fails_loudly():
         pytest.skip('a GPU is visible')
     with pytest.raises(fk.FkError):
         fk.Context(0)
+    with pytest.raises(fk.FkError):          # ... nor the multi-GPU one
+        fk.MultiContext([0, 1])
 
 
 def test_proof_borsh_roundtrip_and_points():

@@ -206,3 +206,26 @@ def test_one_rank_runs_the_exchanges_over_both_transports(ctx, oracle, monkeypat
             assert mc.transport == 'peer-dma' and 'distinct devices' in mc.note()
         finally:
             mc.close()
+
+
+def test_multi_context_grows_and_survives_changing_systems(ctx, oracle):
+    """one MultiContext, three constraint systems of growing domain one after the other (the exchange buffers of every rank are
+    re-allocated between proofs: nobody may still be pulling from them), then the small one again; oracle bytes every time"""
+    import fawkes_crypto_amd as fk
+    mc = fk.MultiContext([0, 0, 0, 0])
+    tox = {k: fx.mont_fr(v) for k, v in TOXIC.items()}
+    try:
+        cases = [_toy(oracle, 7000 + i, g, 3, g + 40) for i, g in enumerate((300, 2500, 9000))]
+        loaded = []
+        for csr, okey, z, z_in, r, s, want in cases:
+            key, _ = mc.setup(r1cs_product(csr), **tox)
+            dr = mc.load_r1cs(r1cs_product(csr))
+            loaded.append((key, dr))
+            assert mc.prove_witness(key, dr, z, r, s).tobytes() == want.tobytes()
+        for (key, dr), (csr, okey, z, z_in, r, s, want) in zip(loaded, cases):      # all keys resident at once, any order
+            t = mc.prove_witness_submit(key, dr, z, r, s)
+            assert mc.prove_witness_wait(t).tobytes() == want.tobytes()
+        for key, dr in loaded:
+            key.free(); dr.free()
+    finally:
+        mc.close()
