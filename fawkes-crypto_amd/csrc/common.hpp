@@ -59,7 +59,7 @@ struct MsmTail {
     size_t h_cap = 0;
     DevBuf d_wp;
 };
-static constexpr int MSM_TAILS = 8;
+static constexpr int MSM_TAILS = 12;     // five per proof; a second proof's four witness multiplications may be begun before the first one's are collected (early front)
 static constexpr int MSM_LANES = 4;   // B pair, L, A and H each on a lane of their own in the sorts-first schedule (prover.hip)
 
 // Which variables feed the A and the B query, as index lists (they are structural: a resident constraint system
@@ -105,6 +105,13 @@ struct fk_ctx {
     bool ev_z_recorded = false;
     hipEvent_t ev_acc_done = nullptr; bool ev_acc_done_valid = false;   // behind the most recent bucket accumulation (any lane)
     bool wit_active = false;
+    // Early front (pipelined proofs, sorts-first schedule): while proof k's last kernels run -- latency-bound tails that leave the GPU
+    // mostly idle -- the memory-bound front of proof k+1 (evaluation of a, b, c and the witness sorts) is already queued behind
+    // proof k's last accumulation.  before_block: called by the prover when everything of proof k is queued, before it blocks on
+    // the results; early: what that front left for proof k+1's run to pick up.
+    std::function<int()> before_block;
+    bool gather_on_main = false;
+    struct EarlyFront { bool done = false; int tails[4] = {-1, -1, -1, -1}; const fk_key *key = nullptr; const struct fk_r1cs_dev *r1cs = nullptr; const void *d_z = nullptr; } early;
     const fk::QueryIdx *qidx = nullptr;   // set by the resident-constraint-system entry points for the duration of a call
     int wit_tail[4] = {-1, -1, -1, -1}; // B1, B2, L, A
     // witness hand-over from host memory (fk_witness_upload_async / fk_prove_r1cs_submit): two device slots filled on a copy
@@ -257,6 +264,8 @@ int msm_g2_end(fk_ctx *ctx, int tail, G2Xyzz *out);
 void msm_abandon(fk_ctx *ctx);
 int msm_run_deferred(fk_ctx *ctx, hipEvent_t after);
 int upload_deferred(fk_ctx *ctx, bool gate_on_main);      // queues the witness uploads fk_prove_r1cs_submit left for later
+int early_witness_begin(fk_ctx *ctx, const fk_key *key, const void *d_z, const void *d_a_aux, const void *d_b_in, const void *d_b_aux, int tails_out[4]);   // prover.hip
+bool early_front_applies(const fk_key *key);
 void msm_release(fk_ctx *ctx);
 int msm_sync(fk_ctx *ctx);
 // reuse_sort: the scalars are the ones of the immediately preceding MSM call on this context (same pointer

@@ -1279,6 +1279,7 @@ int msm_sync(fk_ctx *ctx) {
 
 void msm_abandon(fk_ctx *ctx) {
     ctx->wit_active = false;
+    ctx->early.done = false;
     ctx->defer_back = false; ctx->deferred.clear(); ctx->deferred_tails.clear();
     if (ctx->aux) (void)hipStreamSynchronize(ctx->aux);
     for (int i = 0; i < MSM_TAILS; i++) ctx->tails[i].active = false;

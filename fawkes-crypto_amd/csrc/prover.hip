@@ -365,8 +365,11 @@ static int witness_begin(fk_ctx *ctx, const fk_key *key, const Fr *d_z, const ui
     const uint32_t v_in = key->num_input, v_aux = key->num_aux;
     for (int i = 0; i < 4; i++) ctx->wit_tail[i] = -1;
     auto body = [&]() -> int {
-        hipStream_t ax = ctx->aux;
-        if (z_ready) FK_HIP(ctx, hipStreamWaitEvent(ax, z_ready, 0));
+        // the gathers of the A / B query scalars: on the auxiliary stream -- or, for an early front (the previous proof's tails are
+        // still running and HIP maps more streams than there are hardware queues: the auxiliary stream was seen waiting behind the
+        // G2 tail of the B pair's lane), on the main stream, which has nothing queued but the evaluation that follows
+        hipStream_t ax = ctx->gather_on_main ? ctx->stream : ctx->aux;
+        if (z_ready && !ctx->gather_on_main) FK_HIP(ctx, hipStreamWaitEvent(ax, z_ready, 0));
         // B query: inputs and aux variables that occur in some B-side LC;  A query: all inputs, then the aux variables
         // that occur in some A-side LC
         FK_HIP(ctx, ctx->sc_b.reserve(((size_t)v_in + v_aux) * sizeof(Fr)));
@@ -395,7 +398,7 @@ static int witness_begin(fk_ctx *ctx, const fk_key *key, const Fr *d_z, const ui
         FK_HIP(ctx, hipEventRecord(ctx->ev_aux, ax));
         FK_TRY(msm_g1_begin(ctx, key->d_b1, sb + key->b_lo, key->b_hi - key->b_lo, &ctx->wit_tail[0], ctx->ev_aux, &key->pre_b1));
         FK_TRY(msm_g2_begin(ctx, key->d_b2, sb + key->b_lo, key->b_hi - key->b_lo, /*reuse_sort=*/true, &ctx->wit_tail[1], ctx->ev_aux, &key->pre_b2));   // same scalars as B1
-        FK_TRY(msm_g1_begin(ctx, key->d_l, d_z + v_in + key->l_lo, key->l_hi - key->l_lo, &ctx->wit_tail[2], ctx->ev_aux, &key->pre_l));
+        FK_TRY(msm_g1_begin(ctx, key->d_l, d_z + v_in + key->l_lo, key->l_hi - key->l_lo, &ctx->wit_tail[2], z_ready ? z_ready : ctx->ev_aux, &key->pre_l));   // L reads z itself: it need not wait for the gathers
         FK_TRY(msm_g1_begin(ctx, key->d_a, sa + key->a_lo, key->a_hi - key->a_lo, &ctx->wit_tail[3], ctx->ev_aux, &key->pre_a));
         return FK_OK;
     };
@@ -405,15 +408,43 @@ static int witness_begin(fk_ctx *ctx, const fk_key *key, const Fr *d_z, const ui
     return FK_OK;
 }
 
-static int witness_end(fk_ctx *ctx, uint8_t out[FK_MSM_RESULT_BYTES], int tail_h = -1) {
-    if (!ctx->wit_active) { msm_abandon(ctx); FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "prove: no witness multiplications in flight"); }
-    ctx->wit_active = false;
+extern "C++" {
+namespace fk {
+// The witness half of an early front (spmv.hip: early_front): L, A, B1, B2 of the NEXT proof begun with their accumulations and
+// tails deferred, exactly as prove_msms_dev's sorts-first path would begin them.  Returns 0 when the schedule does not apply.
+int early_witness_begin(fk_ctx *ctx, const fk_key *key, const void *d_z, const void *d_a_aux, const void *d_b_in, const void *d_b_aux, int tails_out[4]) {
+    if (!early_front_applies(key)) return 0;
+    ctx->defer_back = true;
+    ctx->gather_on_main = true;
+    const int rc = witness_begin(ctx, key, (const Fr *)d_z, (const uint8_t *)d_a_aux, (const uint8_t *)d_b_in, (const uint8_t *)d_b_aux, ctx->ev_z);
+    ctx->gather_on_main = false;
+    ctx->defer_back = false;
+    if (rc != FK_OK) return -rc;
+    memcpy(tails_out, ctx->wit_tail, 4 * sizeof(int));
+    return 1;
+}
+bool early_front_applies(const fk_key *key) {
+    static const int t_wfirst = tune("FK_PROVE_WITNESS_FIRST", 1), t_accgate = tune("FK_PROVE_ACC_AFTER_NTT", 1), t_early = tune("FK_PROVE_EARLY_FRONT", 1);
+    return t_early && t_wfirst && t_accgate && key && sorts_first(key);
+}
+}  // namespace fk
+}  // extern "C++"
+
+// tails: the four witness multiplications to collect (B1, B2, L, A) when they are no longer the context's current ones -- the
+// next proof's may have been begun already (early front); default: the context's
+static int witness_end(fk_ctx *ctx, uint8_t out[FK_MSM_RESULT_BYTES], int tail_h = -1, const int *tails = nullptr) {
+    if (!tails) {
+        if (!ctx->wit_active) { msm_abandon(ctx); FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "prove: no witness multiplications in flight"); }
+        ctx->wit_active = false;
+        tails = ctx->wit_tail;
+    }
+    const int tw[4] = {tails[0], tails[1], tails[2], tails[3]};
     G1Xyzz H = G1Xyzz::inf(), L, A, B1; G2Xyzz B2;
     auto body = [&]() -> int {
-        FK_TRY(msm_g1_end(ctx, ctx->wit_tail[0], &B1));
-        FK_TRY(msm_g2_end(ctx, ctx->wit_tail[1], &B2));
-        FK_TRY(msm_g1_end(ctx, ctx->wit_tail[2], &L));
-        FK_TRY(msm_g1_end(ctx, ctx->wit_tail[3], &A));
+        FK_TRY(msm_g1_end(ctx, tw[0], &B1));
+        FK_TRY(msm_g2_end(ctx, tw[1], &B2));
+        FK_TRY(msm_g1_end(ctx, tw[2], &L));
+        FK_TRY(msm_g1_end(ctx, tw[3], &A));
         if (tail_h >= 0) FK_TRY(msm_g1_end(ctx, tail_h, &H));
         return FK_OK;
     };
@@ -447,7 +478,11 @@ static int prove_msms_dev(fk_ctx *ctx, const fk_key *key, Fr *d_a, Fr *d_b, Fr *
     FK_HIP(ctx, ctx->hbuf.reserve(key->m * sizeof(Fr)));
     Fr *d_h = ctx->hbuf.as<Fr>();
     uint64_t m = 0;
-    ctx->lane_next = 0;     // same lane for the same multiplication in every proof: lane buffers keep their sizes
+    // early front: this proof's witness multiplications were begun (and a, b, c evaluated) while the previous proof's tails ran
+    const bool early = ctx->early.done && ctx->early.key == key && ctx->early.d_z == (const void *)d_z;
+    if (ctx->early.done && !early) { msm_abandon(ctx); FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "prove: an early front of another proof is outstanding"); }
+    ctx->early.done = false;
+    if (!early) ctx->lane_next = 0;     // same lane for the same multiplication in every proof: lane buffers keep their sizes
     ctx->lanes_in_use = sorts_first(key) ? MSM_LANES : 3;      // measured, see witness_begin
     // The witness multiplications depend on z only: they are begun right behind the QUEUED quotient, so that their sorts (and what
     // fits of their accumulations) fill the transforms' gaps: 214.5 -> 206.9 ms per proof on the 1024-transaction system
@@ -473,11 +508,17 @@ static int prove_msms_dev(fk_ctx *ctx, const fk_key *key, Fr *d_a, Fr *d_b, Fr *
     // there instead of 12 -- removed.)
     const bool gate = wfirst && sorts_first(key);
     static const int t_accgate = tune("FK_PROVE_ACC_AFTER_NTT", 1);      // the witness accumulations wait for the quotient, see below
+    if (early && !gate) { msm_abandon(ctx); FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "prove: early front without the sorts-first schedule"); }
     if (gate) {
-        ctx->defer_back = t_accgate != 0;
-        const int rcw = witness_begin(ctx, key, d_z, d_a_aux, d_b_in, d_b_aux, ctx->ev_z);
-        ctx->defer_back = false;
-        if (rcw != FK_OK) { msm_abandon(ctx); return rcw; }
+        if (early) {
+            memcpy(ctx->wit_tail, ctx->early.tails, sizeof ctx->wit_tail);      // begun by early_front (deferred pieces included)
+            ctx->wit_active = true;
+        } else {
+            ctx->defer_back = t_accgate != 0;
+            const int rcw = witness_begin(ctx, key, d_z, d_a_aux, d_b_in, d_b_aux, ctx->ev_z);
+            ctx->defer_back = false;
+            if (rcw != FK_OK) { msm_abandon(ctx); return rcw; }
+        }
         for (MsmLane &ln : ctx->lanes)
             if (ln.ev_sorted_valid) { FK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ln.ev_sorted, 0)); ln.ev_sorted_valid = false; }
     }
@@ -503,7 +544,19 @@ static int prove_msms_dev(fk_ctx *ctx, const fk_key *key, Fr *d_a, Fr *d_b, Fr *
         const int rch = msm_g1_begin(ctx, key->d_h, d_h + key->h_lo, key->h_hi - key->h_lo, &t_h0, ctx->ev_main, &key->pre_h);
         if (rch != FK_OK) { msm_abandon(ctx); return rch; }
         const double t2w = now_ms();
-        FK_TRY(witness_end(ctx, out, t_h0));
+        // Everything of this proof is queued.  Before blocking on its results: the front of the NEXT proof, if the caller has one
+        // waiting (fk_prove_r1cs_wait) -- its witness multiplications become the context's current ones, so this proof's are
+        // collected by their handles.
+        if (gate && ctx->before_block) {
+            int mine[4];
+            memcpy(mine, ctx->wit_tail, sizeof mine);
+            ctx->wit_active = false;
+            std::function<int()> hook;
+            hook.swap(ctx->before_block);
+            const int rce = hook();
+            if (rce != FK_OK) { msm_abandon(ctx); return rce; }
+            FK_TRY(witness_end(ctx, out, t_h0, mine));
+        } else FK_TRY(witness_end(ctx, out, t_h0));
         if (tm) { tm->ntt_ms = t1 - t0; tm->msm_l_ms = t2w - t1; tm->msm_h_ms = now_ms() - t2w; tm->total_ms = now_ms() - t0; }
         return FK_OK;
     }

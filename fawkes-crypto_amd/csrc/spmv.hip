@@ -484,6 +484,17 @@ int fk_prove_r1cs_dev(fk_ctx *ctx, const fk_key *key, const fk_r1cs_dev *r, cons
                                                                      (unsigned long long)rows, (unsigned long long)key->m);
     FK_HIP(ctx, hipSetDevice(ctx->device));
     const size_t mb = key->m * sizeof(Fr);
+    if (ctx->early.done && ctx->early.key == key && ctx->early.r1cs == r && ctx->early.d_z == d_z) {
+        // the front of this proof -- ev_z, the evaluation of a, b, c into the stage buffers, the witness multiplications' sorts --
+        // was queued while the previous proof's tails ran (early_front below): go on with the quotient
+        ctx->qidx = &r->qidx;
+        ctx->ev_z_recorded = true;
+        const int rc = fk_prove_dev(ctx, key, ctx->stage_a.p, ctx->stage_b.p, ctx->stage_c.p, rows, d_z, r->d_a_aux, r->d_b_in, r->d_b_aux, rr, ss, out_proof, tm);
+        ctx->qidx = nullptr;
+        ctx->ev_z_recorded = false;
+        return rc;
+    }
+    if (ctx->early.done) { msm_abandon(ctx); FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "prove: an early front of another proof is outstanding"); }
     FK_HIP(ctx, ctx->stage_a.reserve(mb)); FK_HIP(ctx, ctx->stage_b.reserve(mb)); FK_HIP(ctx, ctx->stage_c.reserve(mb));
     // z is complete at this point of the main stream: the witness multiplications wait for THIS, not for the evaluation of a, b, c
     // (11.6 ms at 2^25 during which nothing else ran; FK_PROVE_Z_EARLY=0 restores that)
@@ -560,6 +571,39 @@ int fk_prove_r1cs_submit(fk_ctx *ctx, const fk_key *key, const fk_r1cs_dev *r, c
     *ticket = slot;
     return FK_OK;
 }
+}  // extern "C"
+namespace fk {
+// Early front of the proof waiting in witness slot `slot` (pipelined proofs at sizes that run the sorts-first schedule): called by
+// the prover when everything of the CURRENT proof is queued.  The current proof ends on latency-bound tails -- G2's bucket
+// reduction behind H's accumulation: ~7 ms at 2^25 during which the GPU is mostly idle -- and the next proof begins with
+// memory-bound work that needs nothing from it: the evaluation of a, b, c and the witness multiplications' sorts.  They are queued
+// here behind the current proof's LAST ACCUMULATION (underneath an accumulation they would only take its time, csrc/prover.hip),
+// so they fill that idle stretch and the host's turnaround between two proofs.
+static int early_front(fk_ctx *ctx, int slot) {
+    fk_ctx::WitSlot &w = ctx->wslot[slot];
+    const fk_key *key = w.key; const fk_r1cs_dev *r = w.r1cs;
+    if (w.deferred) { w.deferred = false; FK_TRY(fk_witness_upload_async(ctx, slot, w.host_z, w.host_bytes)); }
+    void *d_z = nullptr;
+    FK_TRY(fk_witness_ptr(ctx, slot, &d_z));               // the main stream waits for the slot's upload
+    if (ctx->ev_acc_done_valid) FK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_acc_done, 0));      // ... and for the current proof's last accumulation (H's)
+    const size_t mb = key->m * sizeof(Fr);
+    if (mb > ctx->stage_a.cap || mb > ctx->stage_b.cap || mb > ctx->stage_c.cap) return FK_OK;       // never grow buffers the current proof may still read: no early front
+    if (!ctx->ev_z) FK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_z, hipEventDisableTiming));
+    FK_HIP(ctx, hipEventRecord(ctx->ev_z, ctx->stream));
+    ctx->qidx = &r->qidx;
+    int tails[4];
+    const int wb = early_witness_begin(ctx, key, d_z, r->d_a_aux, r->d_b_in, r->d_b_aux, tails);
+    if (wb < 0) { ctx->qidx = nullptr; return -wb; }
+    if (wb == 0) { ctx->qidx = nullptr; return FK_OK; }     // (the schedule does not apply: nothing was queued but the waits)
+    const int rce = fk_r1cs_eval_dev(ctx, r, d_z, ctx->stage_a.p, ctx->stage_b.p, ctx->stage_c.p);
+    ctx->qidx = nullptr;
+    if (rce != FK_OK) return rce;
+    ctx->early.done = true; ctx->early.key = key; ctx->early.r1cs = r; ctx->early.d_z = d_z;
+    memcpy(ctx->early.tails, tails, sizeof tails);
+    return FK_OK;
+}
+}  // namespace fk
+extern "C" {
 int fk_prove_r1cs_wait(fk_ctx *ctx, int ticket, uint8_t out_proof[FK_PROOF_BYTES], fk_timings *tm) {
     if (!ctx) return FK_ERR_BAD_ARG;
     if (ticket < 0 || ticket > 1 || !ctx->wslot[ticket].pending) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "prove: no submitted proof with ticket %d", ticket);
@@ -567,8 +611,19 @@ int fk_prove_r1cs_wait(fk_ctx *ctx, int ticket, uint8_t out_proof[FK_PROOF_BYTES
     w.pending = false;
     if (w.deferred) { w.deferred = false; FK_TRY(fk_witness_upload_async(ctx, ticket, w.host_z, w.host_bytes)); }      // nobody ran in between
     void *d_z = nullptr;
-    FK_TRY(fk_witness_ptr(ctx, ticket, &d_z));
-    return fk_prove_r1cs_dev(ctx, w.key, w.r1cs, d_z, w.r, w.s, out_proof, tm);
+    const bool early = ctx->early.done && ctx->early.key == w.key && ctx->early.r1cs == w.r1cs && ctx->early.d_z == ctx->wslot[ticket].buf.p;
+    if (early) d_z = ctx->wslot[ticket].buf.p;            // its front is queued already (the main stream waited for the upload there)
+    else FK_TRY(fk_witness_ptr(ctx, ticket, &d_z));
+    // the other slot holds the NEXT proof of the same key and system: its front goes behind this proof's last accumulation
+    const fk_ctx::WitSlot &o = ctx->wslot[ticket ^ 1];
+    ctx->before_block = nullptr;
+    if (o.pending && o.key == w.key && o.r1cs == w.r1cs && early_front_applies(w.key)) {
+        const int other = ticket ^ 1;
+        ctx->before_block = [ctx, other]() { return early_front(ctx, other); };
+    }
+    const int rc = fk_prove_r1cs_dev(ctx, w.key, w.r1cs, d_z, w.r, w.s, out_proof, tm);
+    ctx->before_block = nullptr;
+    return rc;
 }
 
 }  // extern "C"
