@@ -308,7 +308,11 @@ int fk_prove_r1cs_dev(fk_ctx *ctx, const fk_key *key, const fk_r1cs_dev *r1cs, c
  * outstanding the copy is queued by THAT proof's run, behind its memory-bound front, so that it overlaps with transforms and
  * accumulations rather than with sorts).  At most two
  * tickets are outstanding; z must stay valid until the matching _wait returns and should be pinned memory
- * (fk_host_alloc) -- pageable memory works but is staged by the runtime and does not overlap. */
+ * (fk_host_alloc) -- pageable memory works but is staged by the runtime and does not overlap.
+ * With a second ticket of the same key and system outstanding, _wait(k) also queues the FRONT of proof k+1 -- the evaluation of
+ * a, b, c and the witness multiplications' sorts -- behind proof k's last accumulation, where proof k only has latency-bound
+ * tails left (sizes that run the sorts-first schedule, 2^25 and up: "early front", csrc/spmv.hip); _wait(k+1) picks it up.
+ * Between a _submit and its _wait only _submit / _wait may be called on the context. */
 int fk_prove_r1cs_submit(fk_ctx *ctx, const fk_key *key, const fk_r1cs_dev *r1cs, const uint64_t *z,
                          const uint64_t r[4], const uint64_t s[4], int *ticket);
 int fk_prove_r1cs_wait(fk_ctx *ctx, int ticket, uint8_t out_proof[FK_PROOF_BYTES], fk_timings *timings);
