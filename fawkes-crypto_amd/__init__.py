@@ -13,6 +13,7 @@ There is NO CPU fallback: if libfawkes_hip.so is missing or no GPU is visible, `
 from .api import (  # noqa: F401
     FkError, Context, MultiContext, Parameters, Proof, G1Point, G2Point, R1cs, prove, prove_with_rs, lib_path, load_library,
     FK_MSM_RESULT_BYTES, FK_PROOF_BYTES, EXPORTED_SYMBOLS, build_library,
+    verify, verify_batch, vk_to_borsh, synthesize, sample_fr,
 )
 from . import parallel  # noqa: F401
 from . import params_io  # noqa: F401

@@ -867,8 +867,8 @@ class _MultiHandle:
         self.multi, self.handle, self._free = multi, handle, free_fn
 
     def free(self):
-        if self.handle is not None and self.multi.handle:
-            self._free(self.multi.handle, self.handle)
+        if self.handle is not None:
+            self._free(self.multi.handle or None, self.handle)      # a closed MultiContext: the device memory is released all the same
         self.handle = None
 
     def __del__(self):
@@ -1098,7 +1098,8 @@ def verify(vk_borsh, inputs, proof, ctx=None):
 
 def verify_batch(ctx, vk_borsh, inputs, proofs):
     """fk_verify_batch_dev: `count` proofs of one key on the GPU, one lane per proof.  inputs (count, n_inputs, 4) uint64,
-    proofs (count, 256) uint8.  Returns a bool array."""
+    proofs (count, 256) uint8.  Returns a bool array; a proof that does not even decode (coordinate >= q) is False like any other
+    bad proof, it does not fail the batch (the single-proof `verify` raises FK_ERR_FORMAT for it, as upstream's Borsh reader would)."""
     vkb = np.frombuffer(bytes(vk_borsh), np.uint8)
     pr = np.ascontiguousarray(proofs, np.uint8).reshape(-1, FK_PROOF_BYTES)
     inp = np.ascontiguousarray(inputs, np.uint64)

@@ -127,9 +127,17 @@ int fk_verify_batch_dev(fk_ctx *ctx, const uint8_t *vk, size_t vk_len, const uin
     std::vector<int8_t> res(count);
     FK_HIP(ctx, hipMemcpyAsync(res.data(), d_out, count, hipMemcpyDeviceToHost, ctx->stream));
     FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // A proof that does not decode (a coordinate >= q: upstream fails in `Proof`'s Borsh reader, before verify is reached) is
+    // that proof's rejection, not the batch's failure -- one bad submission must not hide the verdicts on the others.
+    uint32_t n_bad = 0, first_bad = 0;
     for (uint32_t i = 0; i < count; i++) {
-        if (res[i] < 0) FK_SET_ERR(ctx, FK_ERR_FORMAT, "verify: proof %u holds a coordinate that is not a canonical field element", i);
-        accept[i] = (uint8_t)res[i];
+        if (res[i] < 0 && !n_bad++) first_bad = i;
+        accept[i] = res[i] > 0 ? 1 : 0;
+    }
+    if (n_bad) {
+        char buf[160];
+        snprintf(buf, sizeof buf, "note: %u of %u proofs hold a coordinate that is not a canonical field element (first: proof %u) -- rejected", n_bad, count, first_bad);
+        ctx->err = buf;
     }
     return FK_OK;
 }

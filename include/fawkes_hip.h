@@ -437,7 +437,9 @@ int fk_multi_prove_r1cs_wait(fk_multi *multi, int ticket, uint8_t out_proof[FK_P
  * proof: the 256-byte Borsh `Proof`; inputs: n_inputs Montgomery Fr, the public inputs without the leading ONE.
  * *accept = 1 / 0.  n_inputs + 1 != #ic is FK_ERR_KEY_MISMATCH (bellman: MalformedVerifyingKey), a non-canonical
  * coordinate FK_ERR_FORMAT.  fk_verify runs on the host (ctx may be NULL, ~25 ms); fk_verify_batch_dev checks `count`
- * proofs of the same key on the GPU, one lane per proof (inputs: count x n_inputs, proofs: count x 256 B, host memory). */
+ * proofs of the same key on the GPU, one lane per proof (inputs: count x n_inputs, proofs: count x 256 B, host memory);
+ * accept[i] = 1 / 0, and a proof with a non-canonical coordinate is REJECTED (0) like any other bad proof -- the call
+ * still returns FK_OK with the verdicts on the rest (fk_last_error then holds a note naming the first such proof). */
 int fk_verify(fk_ctx *ctx, const uint8_t *vk, size_t vk_len, const uint64_t *inputs, uint32_t n_inputs,
               const uint8_t proof[FK_PROOF_BYTES], int *accept);
 int fk_verify_batch_dev(fk_ctx *ctx, const uint8_t *vk, size_t vk_len, const uint64_t *inputs, uint32_t n_inputs,

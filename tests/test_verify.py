@@ -106,6 +106,14 @@ def test_batch_verifier_on_the_gpu(ctx, oracle):
     got = api.verify_batch(ctx, vkb, inputs, proofs)
     assert np.array_equal(got, want)
     assert all(api.verify(vkb, inputs[i], proofs[i].tobytes()) == bool(want[i]) for i in (0, 1, 3, 4))
+    # a proof that does not decode -- a coordinate >= q, found by tools/fuzz_parity.py -- is rejected as one proof of the batch;
+    # the verdicts on the others stand (the single-proof entry point refuses it as malformed, like upstream's Borsh reader)
+    proofs[7, 0:32] = 0xff
+    want[7] = False
+    assert np.array_equal(api.verify_batch(ctx, vkb, inputs, proofs), want)
+    with pytest.raises(api.FkError) as e:
+        api.verify(vkb, inputs[7], proofs[7].tobytes(), ctx)
+    assert 'FORMAT' in str(e.value)
 
 
 def test_host_verifier_rejects_points_outside_the_groups(oracle):
