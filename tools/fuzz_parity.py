@@ -333,6 +333,46 @@ def case_tiled(ctx, rnd, stats):
     return cs.num_gates
 
 
+def case_corrupt(ctx, rnd, stats):
+    """a damaged Parameters file: truncated, bytes flipped (in the counts, the points, the gate blob), regions swapped.  The loader
+    must refuse it or -- when the damage leaves a decodable file -- load it; it must never crash, hang or leak the device"""
+    from fawkes_crypto_amd import params_io
+    while True:
+        cs, z, _ = rand_system(rnd)
+        if cs.num_gates <= 400:
+            break
+    key = co.setup(cs, **{k: rnd.randrange(1, R) for k in ('tau', 'alpha', 'beta', 'gamma', 'delta')})
+    arrays = dict(alpha_g1=key.alpha_g1, beta_g1=key.beta_g1, beta_g2=key.beta_g2, gamma_g2=key.gamma_g2, delta_g1=key.delta_g1,
+                  delta_g2=key.delta_g2, ic=np.array(key.ic), h=np.array(key.h), l=np.array(key.l), a=np.array(key.a),
+                  b_g1=np.array(key.b_g1), b_g2=np.array(key.b_g2))
+    good = params_io.store_parameters(arrays, r1cs_product(cs), const_tracker_bits=[True, False])
+    for _ in range(12):
+        data = bytearray(good)
+        k = rnd.random()
+        if k < 0.25:
+            data = data[:rnd.randrange(0, len(data))]
+        elif k < 0.7:
+            for _ in range(rnd.choice([1, 1, 2, 8])):
+                data[rnd.randrange(len(data))] ^= 1 << rnd.randrange(8)
+        elif k < 0.85:
+            i = rnd.randrange(len(data)); data[i:i + 4] = rnd.getrandbits(32).to_bytes(4, 'big')      # a forged count, most likely
+        else:
+            i, j = sorted(rnd.randrange(len(data)) for _ in range(2)); data = data[:i] + data[j:] + data[i:j]
+        try:
+            dk, dr, _ = params_io.load_parameters(ctx, bytes(data), checked=rnd.random() < 0.8, disallow_points_at_infinity=rnd.random() < 0.3)
+            stats['corrupt_loaded'] = stats.get('corrupt_loaded', 0) + 1
+            try:
+                if dk.counts()['num_input'] + dk.counts()['num_aux'] == len(z):
+                    ctx.prove_witness(dk, dr, z, fx.mont_fr(3), fx.mont_fr(4))      # whatever it proves, it returns
+            except fk.FkError:
+                pass
+            dr.free(); dk.free()
+        except (fk.FkError, ValueError, AssertionError, IndexError, OverflowError, MemoryError) as e:      # refused: by the library or by the host-side reader
+            stats['corrupt_refused'] = stats.get('corrupt_refused', 0) + 1
+            stats.setdefault('corrupt_kinds', set()).add(type(e).__name__)
+    return 12
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--seconds', type=float, default=600)
@@ -340,7 +380,7 @@ def main():
     args = ap.parse_args()
     co.build(); co.lib()
     ctx = fk.Context(0)
-    kinds = [('msm_g1', 3), ('msm_g2', 2), ('ntt', 2), ('quotient', 2), ('prove', 6), ('tiled', 2)]
+    kinds = [('msm_g1', 3), ('msm_g2', 2), ('ntt', 2), ('quotient', 2), ('prove', 6), ('tiled', 2), ('corrupt', 1)]
     bag = [k for k, w in kinds for _ in range(w)]
     counts, units, fails, stats = {}, {}, [], STATS
     t0 = time.time()
@@ -355,6 +395,7 @@ def main():
             elif kind == 'ntt': u = case_ntt(ctx, rnd)
             elif kind == 'quotient': u = case_quotient(ctx, rnd)
             elif kind == 'tiled': u = case_tiled(ctx, rnd, stats)
+            elif kind == 'corrupt': u = case_corrupt(ctx, rnd, stats)
             else: u = case_prove(ctx, rnd, stats)
             counts[kind] = counts.get(kind, 0) + 1
             units[kind] = units.get(kind, 0) + u
