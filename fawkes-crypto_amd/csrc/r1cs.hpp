@@ -45,6 +45,9 @@ struct fk_r1cs_dev {
     // matrices with long rows: the (instance's) rows in classes by length, sorted by length inside a class (see spmv_binned_kernel)
     uint32_t *rowlist[3] = {nullptr, nullptr, nullptr};
     fk::BinArgs bins;
+    // batch circuits of >= 64 copies: the rows of middling length that spmv_tiled_wave_kernel takes (matrix << 30 | row, circuit
+    // order) and where they sit in rowlist (sorted by length: [wave_from, wave_to) of each matrix)
+    uint32_t *d_wavelist = nullptr, n_wavelist = 0, wave_from[3] = {0, 0, 0}, wave_to[3] = {0, 0, 0};
     // host copies of the class lists and the per-log_w residue-grouped variants, built on first use (fk_r1cs_eval_slice_dev)
     std::vector<uint32_t> h_rowlist[3];
     mutable fk::SliceLists slices[4];

@@ -147,6 +147,48 @@ __global__ __launch_bounds__(256) void spmv_binned_kernel(SpmvArgs a, BinArgs b,
     if (sub == 0) a.out[mtx][((uint64_t)copy * td.base_gates + row) >> (SLICED ? sl.log_w : 0)] = acc;
 }
 
+// Batch circuits (TILED), rows of middling length the other way round: one WAVE per (instance row, block of 64 copies) -- lane l
+// evaluates the row for copy 64 * cb + l.  Every lane of a wave then walks the SAME row: the trip count, the column and
+// coefficient indices and the coefficients are wave-uniform (scalar loads, one copy in SGPRs), no lane is padding (a 33-term
+// row shared by 16 lanes keeps them busy 33 / 48 of the time), there are no partial sums to fold, and four terms at a time
+// share one Montgomery reduction.  What differs per lane is the copy's offset into z.  Measured on the benchmark's system
+// (tools/spmv_rollup_probe.py, profiles/r03_spmv_rollup_probe.log): rows of 4 .. 31 terms 2.16 -> 1.78 ms, 32 .. 63 terms
+// 4.58 -> 2.83 ms; rows of 64 terms and more are faster in the lane-group form (their 16 lanes read neighbouring variables of
+// ONE copy; here 64 lanes read 64 copies' -- 3.72 -> 4.80 ms), single-term rows too, so those stay with spmv_binned_kernel.
+// wavelist: the rows (matrix in the top two bits) in circuit order, so that what runs at one time reads a window of the
+// same 64 copies' variables; copy block outermost.
+__global__ __launch_bounds__(256) void spmv_tiled_wave_kernel(SpmvArgs a, const Fr *table, const Fr *z, uint32_t num_input, TileDims td, uint32_t copies,
+                                                              const uint32_t *wavelist, uint32_t n_list, uint32_t n_waves) {
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    if (wave >= n_waves) return;
+    const uint32_t cb = wave / n_list, ent = wavelist[wave - cb * n_list], mtx = ent >> 30, row = ent & 0x3fffffffu;
+    const uint32_t c_raw = cb * 64 + lane;
+    const bool active = c_raw < copies;
+    const uint32_t copy = active ? c_raw : copies - 1;
+    const uint32_t in_off = copy * (td.base_input - 1), aux_off = num_input + copy * td.base_aux - td.base_input;
+    const uint64_t *ptr = a.ptr[mtx]; const uint32_t *col = a.col[mtx]; const uint32_t *cidx = a.cidx[mtx];
+    auto var = [&](uint32_t cv) -> uint32_t { if (cv) cv += cv < td.base_input ? in_off : aux_off; return cv; };
+    uint64_t k = ptr[row];
+    const uint64_t e = ptr[row + 1];
+    Fr acc = Fr::zero();
+    for (; k + 3 < e; k += 4)
+        acc = Fr::add(acc, Fr::dot4(z[var(col[k])], table[cidx[k]], z[var(col[k + 1])], table[cidx[k + 1]], z[var(col[k + 2])], table[cidx[k + 2]],
+                                    z[var(col[k + 3])], table[cidx[k + 3]]));
+    if (k + 1 < e) {
+        Fr p0, p1;
+        Fr::mul2(z[var(col[k])], table[cidx[k]], z[var(col[k + 1])], table[cidx[k + 1]], p0, p1);
+        acc = Fr::add(acc, Fr::add(p0, p1));
+        k += 2;
+    }
+    if (k < e) {
+        Fr v = z[var(col[k])];
+        const uint32_t ci = cidx[k];
+        if (ci) v = Fr::mul(v, table[ci]);       // index 0 is ONE: bellman's eval skips that product, and so does every lane here
+        acc = Fr::add(acc, v);
+    }
+    if (active) a.out[mtx][(uint64_t)copy * td.base_gates + row] = acc;
+}
+
 }  // namespace fk
 
 using namespace fk;
@@ -159,6 +201,7 @@ void fk_r1cs_free(fk_ctx *ctx, fk_r1cs_dev *r) {
     for (int k = 0; k < 3; k++) { if (r->ptr[k]) (void)hipFree(r->ptr[k]); if (r->col[k]) (void)hipFree(r->col[k]); if (r->cidx[k]) (void)hipFree(r->cidx[k]); if (r->rowlist[k]) (void)hipFree(r->rowlist[k]); }
     for (void *p : {(void *)r->table, (void *)r->d_a_aux, (void *)r->d_b_in, (void *)r->d_b_aux, (void *)r->d_idx_a, (void *)r->d_idx_b}) if (p) (void)hipFree(p);
     for (auto &sl : r->slices) for (uint32_t *p : sl.d_list) if (p) (void)hipFree(p);
+    if (r->d_wavelist) (void)hipFree(r->d_wavelist);
     delete r;
 }
 
@@ -203,6 +246,10 @@ static int r1cs_load_impl(fk_ctx *ctx, const fk_r1cs *cs, uint32_t copies, fk_r1
     std::vector<uint8_t> a_aux(cs->num_aux ? cs->num_aux : 1, 0), b_in(cs->num_input, 0), b_aux(cs->num_aux ? cs->num_aux : 1, 0);
     int rc = FK_OK;
     auto fail = [&](int code) { fk_r1cs_free(ctx, r); return code; };
+    // rows of [wave_lo, wave_hi) terms of a batch of >= wave_copies copies go to spmv_tiled_wave_kernel (see there); the lower bound
+    // is the boundary of the one-lane class, the upper one lies in the 16-lane class (>= 32 terms)
+    static const uint32_t wave_copies = (uint32_t)tune("FK_SPMV_WAVE_MIN_COPIES", 64), wave_lo = 4,
+                          wave_hi = (uint32_t)std::min(1024, std::max(32, tune("FK_SPMV_WAVE_HI", 64)));
     uint64_t bin_min = 8;          // rows this long make a matrix binned; FK_SPMV_BIN_MIN=0 turns the binned product off (a run-time switch: the tests run both kernels)
     if (const char *e = getenv("FK_SPMV_BIN_MIN")) { bin_min = strtoull(e, nullptr, 10); if (!bin_min) bin_min = ~0ull; }
     for (int k = 0; k < 3 && rc == FK_OK; k++) {
@@ -250,6 +297,7 @@ static int r1cs_load_impl(fk_ctx *ctx, const fk_r1cs *cs, uint32_t copies, fk_r1
             for (uint32_t i = 0; i <= CAP; i++) cnt[i + 1] += cnt[i];
             for (uint32_t g = 0; g < ng; g++) list[cnt[CAP - key(g)]++] = g;
             const uint32_t n16 = cnt[CAP - 32], n4 = cnt[CAP - 4] - n16, n1 = ng - n16 - n4;     // cnt[i] is now the END of key CAP - i
+            r->wave_from[k] = cnt[CAP - wave_hi]; r->wave_to[k] = cnt[CAP - wave_lo];             // rows of wave_lo <= length < wave_hi
             if (hipMalloc((void **)&r->rowlist[k], (size_t)ng * 4) != hipSuccess) { ctx->err = "r1cs: device allocation failed"; return fail(FK_ERR_OOM); }
             if (hipMemcpy(r->rowlist[k], list.data(), (size_t)ng * 4, hipMemcpyHostToDevice) != hipSuccess) rc = FK_ERR_HIP;
             r->h_rowlist[k] = list;
@@ -270,6 +318,19 @@ static int r1cs_load_impl(fk_ctx *ctx, const fk_r1cs *cs, uint32_t copies, fk_r1
         }
     }
     if (rc != FK_OK) { ctx->err = "r1cs: upload failed"; return fail(rc); }
+    if (copies > 1 && wave_copies && copies >= wave_copies && r->bins.mask && cs->num_gates < ((uint64_t)1 << 30)) {
+        std::vector<uint32_t> wl;
+        for (uint64_t g = 0; g < cs->num_gates; g++)
+            for (uint32_t k = 0; k < 3; k++) {
+                const uint64_t l = ptrs[k][g + 1] - ptrs[k][g];
+                if (((r->bins.mask >> k) & 1) && l >= wave_lo && l < wave_hi) wl.push_back(k << 30 | (uint32_t)g);
+            }
+        if (!wl.empty() && (uint64_t)((copies + 63) / 64) * wl.size() < 0xfffffff0ull) {
+            if (hipMalloc((void **)&r->d_wavelist, wl.size() * 4) != hipSuccess) { ctx->err = "r1cs: device allocation failed"; return fail(FK_ERR_OOM); }
+            if (hipMemcpy(r->d_wavelist, wl.data(), wl.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { ctx->err = "r1cs: upload failed"; return fail(FK_ERR_HIP); }
+            r->n_wavelist = (uint32_t)wl.size();
+        }
+    }
     if (copies > 1) {      // density maps of the whole batch: every copy repeats the instance's pattern, ONE is shared
         auto rep = [&](std::vector<uint8_t> &f, size_t skip, size_t per) {
             std::vector<uint8_t> o(skip + per * copies + (skip + per * copies == 0));
@@ -438,6 +499,22 @@ int r1cs_eval_impl(fk_ctx *ctx, const fk_r1cs_dev *r, const void *d_z, void *d_a
                 b.first_block[s + 1] = b.first_block[s] + (uint32_t)blocks;
             }
             for (int k = 0; k < 3; k++) b.rowlist[k] = sl->d_list[k];
+        }
+        if (tiled && !sliced && r->n_wavelist) {
+            // rows of wave_lo .. wave_hi - 1 terms go to spmv_tiled_wave_kernel: they are rowlist[wave_from, wave_to) of their matrix
+            // (the lists are sorted by length, longest first), i.e. the tail of the 16-lane class and the whole 4-lane class
+            b.first_block[0] = 0;
+            for (uint32_t s = 0; s < b.nseg; s++) {
+                const uint32_t k = b.mtx[s], s0 = b.list_off[s], s1 = s0 + b.n_rows[s], w0 = r->wave_from[k], w1 = r->wave_to[k];
+                uint32_t lo = s0, hi = s1;
+                if (w0 <= s0) lo = std::min(std::max(s0, w1), s1); else hi = std::min(s1, w0);      // (load keeps the wave range from lying strictly inside a class)
+                b.list_off[s] = lo; b.n_rows[s] = hi - lo;
+                const uint64_t groups = (uint64_t)b.n_rows[s] * r->copies, per = 256u >> b.lg[s];
+                b.first_block[s + 1] = b.first_block[s] + (uint32_t)((groups + per - 1) / per);
+            }
+            const uint64_t n_waves = (uint64_t)((r->copies + 63) / 64) * r->n_wavelist;
+            hipLaunchKernelGGL(spmv_tiled_wave_kernel, dim3((unsigned)((n_waves + 3) / 4)), dim3(256), 0, ctx->stream, a, r->table, (const Fr *)d_z, r->num_input, td,
+                               r->copies, r->d_wavelist, r->n_wavelist, (uint32_t)n_waves);
         }
         const unsigned blocks = b.first_block[b.nseg];
         if (blocks) {

@@ -127,3 +127,44 @@ def test_spmv_long_rows_vs_oracle(ctx, oracle, monkeypatch, lens, copies):
     finally:
         for p in d + [d_z]:
             ctx.dev_free(p)
+
+
+@pytest.mark.parametrize('copies,gates', [(64, 90), (65, 211), (130, 64), (257, 33)])
+def test_spmv_wave_form_of_batch_circuits(ctx, oracle, copies, gates):
+    """batch circuits of 64 copies and more: rows of 4 .. 63 terms are evaluated one wave per (row, 64 copies)
+    (spmv_tiled_wave_kernel), the others by the length-class kernel -- every boundary length, copy counts that do not fill the
+    last wave, against the oracle's evaluation of the explicitly replicated system; the slices a multi-GPU rank evaluates
+    (which keep the length-class form) agree with it too"""
+    lens = [0, 1, 2, 3, 4, 5, 7, 8, 9, 31, 32, 33, 62, 63, 64, 65, 127, 128, 300]
+    base = _ragged_system(copies * 7 + gates, lens, gates, 3, 150)
+    csr = fx.tile_r1cs(base, copies)
+    nv, rows = csr.num_input + csr.num_aux, csr.num_gates + csr.num_input
+    rnd = np.random.default_rng(copies)
+    z = fx.co.limbs_arr([int(x) % ref.R for x in rnd.integers(0, 2**63, nv).astype(object) * (2**190 + 12345)])
+    want = oracle.synthesize_tiled(base, copies, z)
+    ref_full = oracle.synthesize(csr, z)
+    for k in range(3):
+        assert np.array_equal(want[k], ref_full[k])
+    log_m = max(rows - 1, 1).bit_length()
+    m = 1 << log_m
+    d = [ctx.dev_alloc(m * 32) for _ in range(3)]
+    d_z = ctx.dev_alloc(z.nbytes)
+    ctx.upload(d_z, z)
+    dr = ctx.load_r1cs(r1cs_product(base), copies=copies)
+    try:
+        for p in d:
+            ctx.upload(p, np.full(m * 4, 0xdeadbeefdeadbeef, np.uint64))
+        ctx.r1cs_eval_dev(dr, d_z, *d)
+        for k in range(3):
+            assert np.array_equal(ctx.download(d[k], rows * 32, np.uint64).reshape(-1, 4), want[k]), k
+        for log_w, rank in ((1, 1), (2, 3)):
+            W, L = 1 << log_w, m >> log_w
+            ctx.r1cs_eval_slice_dev(dr, d_z, log_m, rank, log_w, *d)
+            for k in range(3):
+                got = ctx.download(d[k], L * 32, np.uint64).reshape(-1, 4)
+                full = np.zeros((m, 4), np.uint64); full[:rows] = want[k]
+                assert np.array_equal(got, full[rank::W]), (log_w, rank, k)
+    finally:
+        dr.free()
+        for p in d + [d_z]:
+            ctx.dev_free(p)

@@ -279,7 +279,10 @@ def case_tiled(ctx, rnd, stats):
         base, _, _ = rand_system(rnd)
         if base.num_gates <= 1500:
             break
-    copies = rnd.choice([1, 2, 3, 5, 8, rnd.randrange(2, 40)])
+    copies = rnd.choice([1, 2, 3, 5, 8, rnd.randrange(2, 40), rnd.randrange(64, 200)])       # 64 and more: the wave form of the evaluation
+    if copies >= 64:
+        while base.num_gates > 200:
+            base, _, _ = rand_system(rnd)
     cs = fx.tile_r1cs(base, copies)
     nv = cs.num_input + cs.num_aux
     z = mont_arr([1] + [scalar(rnd) for _ in range(nv - 1)])
