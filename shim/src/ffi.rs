@@ -67,4 +67,11 @@ extern "C" {
     pub fn fk_multi_prove_r1cs_submit(multi: *mut fk_multi, key: *const fk_multi_key, r1cs: *const fk_multi_r1cs, z: *const u64,
                                       r: *const u64, s: *const u64, ticket: *mut c_int) -> c_int;
     pub fn fk_multi_prove_r1cs_wait(multi: *mut fk_multi, ticket: c_int, out_proof: *mut u8, timings: *mut c_void) -> c_int;
+
+    // verifier (verifier.rs:75-81): vk = fawkes' Borsh `VK`, inputs = Montgomery Fr without the leading ONE, proof = Borsh `Proof`.
+    // fk_verify is host code (ctx may be null); the batch form judges `count` proofs of one key on the GPU, accept[i] = 1 / 0
+    // (a proof that does not decode is that proof's rejection, the call still returns 0).
+    pub fn fk_verify(ctx: *mut fk_ctx, vk: *const u8, vk_len: usize, inputs: *const u64, n_inputs: u32, proof: *const u8, accept: *mut c_int) -> c_int;
+    pub fn fk_verify_batch_dev(ctx: *mut fk_ctx, vk: *const u8, vk_len: usize, inputs: *const u64, n_inputs: u32, proofs: *const u8,
+                               count: u32, accept: *mut u8) -> c_int;
 }
