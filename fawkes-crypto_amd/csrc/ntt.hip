@@ -32,6 +32,7 @@ enum { POST_NONE = 0, POST_CONST = 1, POST_TABLE = 2, POST_TABLE_SUB = 3 };     
 
 struct ScaleTable {          // value(i) = lo[i & (2^L - 1)] * hi[i >> L]
     Fr *lo = nullptr, *hi = nullptr;
+    Fr *full = nullptr;      // the products themselves (the quotient's two post-scale tables, memory permitting): one product per element instead of two
 };
 
 struct NttDomain {
@@ -61,7 +62,7 @@ struct PassArgs {
     const Fr *pre_lo, *pre_hi;
     int post_mode;
     Fr post_const;
-    const Fr *post_lo, *post_hi;
+    const Fr *post_lo, *post_hi, *post_full;
 };
 
 // The passes compute in the lazily reduced form FrL ([0, 2r): no conditional subtraction behind a product, field.hpp); what
@@ -198,9 +199,12 @@ __global__ __launch_bounds__(NTT_MAX_THREADS) void ntt_pass_kernel(PassArgs a) {
         const uint64_t o0 = ((i0 - k0) << a.deg) + k0 + ((uint64_t)rr0 << a.lgp), o1 = ((i1 - k1) << a.deg) + k1 + ((uint64_t)rr1 << a.lgp);
         if (a.post_mode == POST_CONST) { const FL pc = ldl_<FL>(a.post_const); FL::mul2(v0, pc, v1, pc, v0, v1); }
         else if (a.post_mode == POST_TABLE || a.post_mode == POST_TABLE_SUB) {
-            FL s0, s1;
-            FL::mul2(ldl(a.post_lo, o0 & Lmask), ldl(a.post_hi, o0 >> a.L), ldl(a.post_lo, o1 & Lmask), ldl(a.post_hi, o1 >> a.L), s0, s1);
-            FL::mul2(v0, s0, v1, s1, v0, v1);
+            if (a.post_full) FL::mul2(v0, ldl(a.post_full, o0), v1, ldl(a.post_full, o1), v0, v1);
+            else {
+                FL s0, s1;
+                FL::mul2(ldl(a.post_lo, o0 & Lmask), ldl(a.post_hi, o0 >> a.L), ldl(a.post_lo, o1 & Lmask), ldl(a.post_hi, o1 >> a.L), s0, s1);
+                FL::mul2(v0, s0, v1, s1, v0, v1);
+            }
             if (a.post_mode == POST_TABLE_SUB) FL::sub2(v0, ldl(a.xc, o0), v1, ldl(a.xc, o1), v0, v1);
         }
         a.y[o0] = canon(v0);
@@ -322,6 +326,24 @@ static int get_domain(fk_ctx *ctx, uint32_t log_n, NttDomain **out) {
     if (rc == FK_OK) rc = make_scale_table(ctx, d, ginv, d->minv, &d->t_ginv_minv);
     if (rc == FK_OK) rc = make_scale_table(ctx, d, g, d->minv, &d->t_g_minv);
     if (rc == FK_OK) rc = make_scale_table(ctx, d, ginv, Fr::mul(d->minv, d->zinv), &d->t_ginv_minv_zinv);
+    // the quotient's two post-scale tables also in single-level form (2 x 32 B per point): their passes then spend one product per
+    // element on the scale instead of two (3 of the ~83 products per point of a quotient)
+    if (rc == FK_OK && tune("FK_NTT_FULL_SCALE", 1)) {
+        size_t free_b = 0, total_b = 0;
+        (void)hipMemGetInfo(&free_b, &total_b);
+        const uint64_t cnt = (uint64_t)1 << log_n;
+        if (2 * cnt * sizeof(Fr) < free_b / 8) {
+            for (ScaleTable *t : {&d->t_g_minv, &d->t_ginv_minv_zinv}) {
+                void *p = nullptr;
+                if (hipMalloc(&p, cnt * sizeof(Fr)) != hipSuccess) { rc = FK_ERR_OOM; break; }
+                d->allocs.push_back(p);
+                hipLaunchKernelGGL(tw_full_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream, t->lo, t->hi, d->L, 0u, cnt, (Fr *)p);
+                if (hipGetLastError() != hipSuccess) { rc = FK_ERR_HIP; break; }
+                t->full = (Fr *)p;
+            }
+            if (rc == FK_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = FK_ERR_HIP;
+        }
+    }
     if (rc != FK_OK) { for (void *p : d->allocs) (void)hipFree(p); delete d; return rc; }
     ctx->domains[log_n] = d;
     *out = d;
@@ -366,7 +388,8 @@ static int ntt_exec(fk_ctx *ctx, NttDomain *d, const NttOp &op, const Fr *in, Fr
         if (op.pre) { a.pre_lo = op.pre->lo; a.pre_hi = op.pre->hi; }
         a.post_mode = (i == P - 1) ? op.post_mode : POST_NONE;
         a.post_const = op.post_const;
-        if (op.post) { a.post_lo = op.post->lo; a.post_hi = op.post->hi; }
+        a.post_full = nullptr;
+        if (op.post) { a.post_lo = op.post->lo; a.post_hi = op.post->hi; a.post_full = op.post->full; }
         const uint64_t nblk = ((uint64_t)1 << (d->log_n - deg)) >> logC;
         const size_t lds_bytes = (size_t)2 * sizeof(uint4) << (deg + logC);
         static const int t_lazy = tune("FK_NTT_LAZY", 1);     // 0: butterflies in the canonical form (the round-1 kernel)
