@@ -15,9 +15,9 @@ def short(n):
     n = n.replace('Fp<FqParams, true>', 'Fq').replace('Fq2T<Fq >', 'Fq2').replace('Fp<FqParams, false>', 'FqC').replace('Fp<FrParams, true>', 'Fr').replace('Fp<FrLazyParams, true>', 'FrL')
     return n[:48]
 # proofs start with the SpMV kernel
-starts = [i for i, r in enumerate(rows) if 'spmv_binned' in r[2] or 'spmv_kernel' in r[2]]
-# the last proof: from the last spmv_binned launch to the end
-i0 = [i for i in starts if 'spmv_binned' in rows[i][2]][-1]
+# the last proof: from the last launch of the evaluation's first kernel (spmv_kernel: the input rows and the short matrices; the wave
+# and length-class kernels follow it) to the end
+i0 = [i for i, r in enumerate(rows) if 'spmv_kernel' in r[2]][-1]
 sel = rows[i0:]
 t0 = sel[0][0]
 merged = []
