@@ -297,6 +297,29 @@ static int r1cs_load_impl(fk_ctx *ctx, const fk_r1cs *cs, uint32_t copies, fk_r1
             for (uint32_t i = 0; i <= CAP; i++) cnt[i + 1] += cnt[i];
             for (uint32_t g = 0; g < ng; g++) list[cnt[CAP - key(g)]++] = g;
             const uint32_t n16 = cnt[CAP - 32], n4 = cnt[CAP - 4] - n16, n1 = ng - n16 - n4;     // cnt[i] is now the END of key CAP - i
+            // A large flat system (a circuit as it comes out of a Parameters file): sorting a class by length over the WHOLE system
+            // puts rows from everywhere in the circuit side by side -- every wave then gathers z from all over the witness and
+            // streams its matrix entries from all over the CSR.  Sort by length inside blocks of consecutive rows instead: the rows
+            // that share a wave still have (nearly) the same length, and what runs at one time reads one window of the circuit
+            // (the benchmark's system with every term explicit: evaluation 15.2 -> see profiles/r03_spmv_rollup_probe.log).
+            static const uint32_t block_rows = (uint32_t)std::max(0, tune("FK_SPMV_BLOCK_ROWS", 4096));
+            if (copies == 1 && block_rows && ng >= 16 * block_rows) {
+                const uint32_t cls_lo[3] = {32, 4, 0};              // class c holds the rows of cls_lo[c] <= length < cls_lo[c - 1]
+                uint32_t pos[3] = {0, n16, n16 + n4};
+                std::vector<uint32_t> bc(CAP + 2);
+                std::vector<uint32_t> tmp(block_rows);
+                for (uint32_t g0 = 0; g0 < ng; g0 += block_rows) {
+                    const uint32_t g1 = std::min(ng, g0 + block_rows);
+                    std::fill(bc.begin(), bc.end(), 0u);
+                    for (uint32_t g = g0; g < g1; g++) bc[CAP - key(g) + 1]++;
+                    for (uint32_t i = 0; i <= CAP; i++) bc[i + 1] += bc[i];
+                    for (uint32_t g = g0; g < g1; g++) tmp[bc[CAP - key(g)]++] = g;           // the block's rows, longest first (stable)
+                    for (uint32_t i = 0; i < g1 - g0; i++) {
+                        const uint32_t l = key(tmp[i]), c = l >= cls_lo[0] ? 0 : (l >= cls_lo[1] ? 1 : 2);
+                        list[pos[c]++] = tmp[i];
+                    }
+                }
+            }
             r->wave_from[k] = cnt[CAP - wave_hi]; r->wave_to[k] = cnt[CAP - wave_lo];             // rows of wave_lo <= length < wave_hi
             if (hipMalloc((void **)&r->rowlist[k], (size_t)ng * 4) != hipSuccess) { ctx->err = "r1cs: device allocation failed"; return fail(FK_ERR_OOM); }
             if (hipMemcpy(r->rowlist[k], list.data(), (size_t)ng * 4, hipMemcpyHostToDevice) != hipSuccess) rc = FK_ERR_HIP;

@@ -168,3 +168,35 @@ def test_spmv_wave_form_of_batch_circuits(ctx, oracle, copies, gates):
         dr.free()
         for p in d + [d_z]:
             ctx.dev_free(p)
+
+
+def test_spmv_large_flat_system_block_ordering(ctx, oracle):
+    """a flat system of more than 16 x 4096 rows with long rows: its length classes are ordered by length inside blocks of
+    consecutive rows (locality), not over the whole system -- same a, b, c as the oracle, whole and as multi-GPU slices"""
+    lens = [0, 1, 1, 1, 2, 3, 4, 9, 31, 32, 33, 70, 200]
+    base = _ragged_system(4242, lens, 70001, 3, 50000)
+    nv, rows = base.num_input + base.num_aux, base.num_gates + base.num_input
+    rnd = np.random.default_rng(11)
+    z = fx.co.limbs_arr([int(x) % ref.R for x in rnd.integers(0, 2**63, nv).astype(object) * (2**190 + 12345)])
+    want = oracle.synthesize(base, z)
+    log_m = max(rows - 1, 1).bit_length()
+    m = 1 << log_m
+    d = [ctx.dev_alloc(m * 32) for _ in range(3)]
+    d_z = ctx.dev_alloc(z.nbytes)
+    ctx.upload(d_z, z)
+    dr = ctx.load_r1cs(r1cs_product(base))
+    try:
+        ctx.r1cs_eval_dev(dr, d_z, *d)
+        for k in range(3):
+            assert np.array_equal(ctx.download(d[k], rows * 32, np.uint64).reshape(-1, 4), want[k]), k
+        for log_w, rank in ((1, 0), (3, 5)):
+            W, L = 1 << log_w, m >> log_w
+            ctx.r1cs_eval_slice_dev(dr, d_z, log_m, rank, log_w, *d)
+            for k in range(3):
+                got = ctx.download(d[k], L * 32, np.uint64).reshape(-1, 4)
+                full = np.zeros((m, 4), np.uint64); full[:rows] = want[k]
+                assert np.array_equal(got, full[rank::W]), (log_w, rank, k)
+    finally:
+        dr.free()
+        for p in d + [d_z]:
+            ctx.dev_free(p)

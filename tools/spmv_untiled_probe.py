@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Evaluation of a, b, c of the benchmark's system with every term explicit in HBM (no tiling shortcut: what a circuit loaded
+from a Parameters file looks like), alone on the GPU: 10 repetitions; beside it the tiled form (GPU box)."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+
+import bench  # noqa: E402
+import fawkes_crypto_amd as fk  # noqa: E402
+
+COPIES = int(os.environ.get('COPIES', 1024))
+ctx = fk.Context(0)
+r1cs, zs = bench.load_rollup_instance()
+z = bench.tile_witness(zs, r1cs.num_input, COPIES)
+d_z = ctx.dev_alloc(z.nbytes); ctx.upload(d_z, z)
+rows = COPIES * r1cs.num_gates + 1 + COPIES * (r1cs.num_input - 1)
+m = 1 << max(rows - 1, 1).bit_length()
+d = [ctx.dev_alloc(m * 32) for _ in range(3)]
+e = [ctx.dev_alloc(m * 32) for _ in range(3)]
+
+
+def timed(dr, out):
+    ctx.r1cs_eval_dev(dr, d_z, *out); ctx.sync()
+    t = time.perf_counter()
+    for _ in range(10):
+        ctx.r1cs_eval_dev(dr, d_z, *out)
+    ctx.sync()
+    return (time.perf_counter() - t) / 10
+
+
+dt = ctx.load_r1cs(r1cs, copies=COPIES)
+t_t = timed(dt, d)
+nnz = sum(dt.info()['nnz'])
+print('tiled    %.3f ms  %.1f G terms/s' % (t_t * 1e3, nnz / t_t / 1e9), flush=True)
+t0 = time.perf_counter()
+u_in, u_aux, u_mats, u_table = bench.materialise_rollup(COPIES)
+du = ctx.load_r1cs_coded(u_in, u_aux, u_mats, u_table)
+print('untiled system built and loaded in %.1f s' % (time.perf_counter() - t0), flush=True)
+t_u = timed(du, e)
+print('untiled  %.3f ms  %.1f G terms/s' % (t_u * 1e3, nnz / t_u / 1e9), flush=True)
+same = all(np.array_equal(ctx.download(d[k], rows * 32, np.uint64), ctx.download(e[k], rows * 32, np.uint64)) for k in range(3))
+print('same a, b, c:', same)
