@@ -4,10 +4,11 @@
 #include <mutex>
 
 namespace fk {
-// launch plan of spmv_binned_kernel: up to 3 length classes for each of the 3 matrices
+// launch plan of spmv_binned_kernel: up to SPMV_CLASSES length classes for each of the 3 matrices
+static constexpr int SPMV_CLASSES = 5, SPMV_SEGS = 3 * SPMV_CLASSES;
 struct BinArgs {
     uint32_t nseg = 0, mask = 0;            // mask: bit k = matrix k is binned
-    uint32_t first_block[10] = {0}, lg[9] = {0}, mtx[9] = {0}, n_rows[9] = {0}, list_off[9] = {0};
+    uint32_t first_block[SPMV_SEGS + 1] = {0}, lg[SPMV_SEGS] = {0}, mtx[SPMV_SEGS] = {0}, n_rows[SPMV_SEGS] = {0}, list_off[SPMV_SEGS] = {0};
     const uint32_t *rowlist[3] = {nullptr, nullptr, nullptr};
 };
 // Cyclic row slices (multi-GPU: rank g of W = 2^log_w evaluates only the rows t = g (mod W), the slice the distributed
@@ -16,14 +17,14 @@ struct BinArgs {
 // copy needs depends on the copy (row t = copy * base_gates + row), with period P = W / gcd(base_gates, W) copies.
 struct SliceLists {
     uint32_t *d_list[3] = {nullptr, nullptr, nullptr};    // per matrix, same length and class boundaries as rowlist
-    uint32_t cnt[9][8] = {{0}}, offs[9][8] = {{0}};       // per segment: rows of each residue / their first position in the class
+    uint32_t cnt[SPMV_SEGS][8] = {{0}}, offs[SPMV_SEGS][8] = {{0}};       // per segment: rows of each residue / their first position in the class
     bool built = false;
 };
 struct SliceArgs {
     uint32_t log_w = 0, rank = 0, P = 1;
     uint32_t rho[8] = {0};                 // residue copy q*P + p needs
-    uint32_t T[9] = {0};                   // groups of one period of copies, per segment
-    uint32_t cnt[9][8] = {{0}}, offs[9][8] = {{0}};
+    uint32_t T[SPMV_SEGS] = {0};           // groups of one period of copies, per segment
+    uint32_t cnt[SPMV_SEGS][8] = {{0}}, offs[SPMV_SEGS][8] = {{0}};
 };
 }  // namespace fk
 

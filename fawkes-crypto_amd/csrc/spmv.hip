@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void spmv_kernel(SpmvArgs a, const Fr *table, 
 // Circuits built from Poseidon are bimodal: three quarters of the eddsa verifier's rows hold ONE term, the rest 128-512 (the
 // MDS mixing is kept as lazily expanded linear combinations).  A wave runs as long as its longest row, so one lane-group
 // size for a whole matrix wastes most lanes either way.  Here the rows of a matrix are split by length into classes with
-// their own group size (1, 4 or 16 lanes per row) and sorted by length inside a class, so that the rows sharing a wave
+// their own group size (1, 2, 4, 8 or 16 lanes per row: a lane gets 4 .. 7 terms) and sorted by length inside a class, so that the rows sharing a wave
 // have (nearly) the same length; long rows take two terms per step through the dual-chain multiplier.  Segment s of the
 // launch is one (matrix, class); a tiled system walks its copies in the outer order, so a copy's z stays in cache.
 // SLICED (b.rowlist = the residue-grouped lists, b.first_block = this rank's plan): group index -> (copy, position in the
@@ -115,14 +115,13 @@ __global__ __launch_bounds__(256) void spmv_binned_kernel(SpmvArgs a, BinArgs b,
     const uint32_t G = 1u << lg;
     auto var = [&](uint32_t cv) -> uint32_t { if (TILED && cv) cv += cv < td.base_input ? in_off : aux_off; return cv; };
     Fr acc = Fr::zero();
-    if (lg) {
-        // four terms per step with ONE Montgomery reduction (Fp::dot4: 328 multiply-accumulates instead of 544) ...
-        for (; k + 3 * (uint64_t)G < e; k += 4 * G) {
-            const uint32_t c0 = var(col[k]), c1 = var(col[k + G]), c2 = var(col[k + 2 * G]), c3 = var(col[k + 3 * G]);
-            const uint32_t i0 = cidx[k], i1 = cidx[k + G], i2 = cidx[k + 2 * G], i3 = cidx[k + 3 * G];
-            acc = Fr::add(acc, Fr::dot4(z[c0], table[i0], z[c1], table[i1], z[c2], table[i2], z[c3], table[i3]));
-        }       // (loading the NEXT step's indices ahead of this step's products was measured: 169.8 against 168.8 ms per proof)
-        // ... then two
+    // four terms per step with ONE Montgomery reduction (Fp::dot4: 328 multiply-accumulates instead of 544) ...
+    for (; k + 3 * (uint64_t)G < e; k += 4 * G) {
+        const uint32_t c0 = var(col[k]), c1 = var(col[k + G]), c2 = var(col[k + 2 * G]), c3 = var(col[k + 3 * G]);
+        const uint32_t i0 = cidx[k], i1 = cidx[k + G], i2 = cidx[k + 2 * G], i3 = cidx[k + 3 * G];
+        acc = Fr::add(acc, Fr::dot4(z[c0], table[i0], z[c1], table[i1], z[c2], table[i2], z[c3], table[i3]));
+    }           // (loading the NEXT step's indices ahead of this step's products was measured: 169.8 against 168.8 ms per proof)
+    if (lg) {   // ... then two (one lane per row: the last terms one by one, ONE coefficients skipped)
         Fr acc1 = Fr::zero();
         for (; k + G < e; k += 2 * G) {        // table[0] is ONE: multiplying by it returns the (reduced) value itself
             const uint32_t c0 = var(col[k]), c1 = var(col[k + G]), i0 = cidx[k], i1 = cidx[k + G];
@@ -286,7 +285,7 @@ static int r1cs_load_impl(fk_ctx *ctx, const fk_r1cs *cs, uint32_t copies, fk_r1
         if (hipMemcpy(r->ptr[k], ptrs[k], (cs->num_gates + 1) * 8, hipMemcpyHostToDevice) != hipSuccess) rc = FK_ERR_HIP;
         if (nnz && hipMemcpy(r->col[k], cols[k], nnz * 4, hipMemcpyHostToDevice) != hipSuccess) rc = FK_ERR_HIP;
         if (nnz && hipMemcpy(r->cidx[k], cidx.data(), nnz * 4, hipMemcpyHostToDevice) != hipSuccess) rc = FK_ERR_HIP;
-        // length classes (spmv_binned_kernel) when the matrix has long rows: < 4 terms -> 1 lane, < 32 -> 4 lanes, else 16
+        // length classes (spmv_binned_kernel) when the matrix has long rows
         uint64_t maxlen = 0;
         for (uint64_t g = 0; g < cs->num_gates; g++) if (ptrs[k][g + 1] - ptrs[k][g] > maxlen) maxlen = ptrs[k][g + 1] - ptrs[k][g];
         if (maxlen >= bin_min && cs->num_gates && cs->num_gates < 0xffffffffull && rc == FK_OK) {
@@ -296,7 +295,14 @@ static int r1cs_load_impl(fk_ctx *ctx, const fk_r1cs *cs, uint32_t copies, fk_r1
             for (uint32_t g = 0; g < ng; g++) cnt[CAP - key(g) + 1]++;
             for (uint32_t i = 0; i <= CAP; i++) cnt[i + 1] += cnt[i];
             for (uint32_t g = 0; g < ng; g++) list[cnt[CAP - key(g)]++] = g;
-            const uint32_t n16 = cnt[CAP - 32], n4 = cnt[CAP - 4] - n16, n1 = ng - n16 - n4;     // cnt[i] is now the END of key CAP - i
+            // classes: 16 lanes per row from 64 terms, 8 from 32, 4 from 16, 2 from 8, one lane below -- a lane then has 4 .. 7 terms
+            // (one or two four-term steps with a shared reduction) in every class but the last; cnt[i] is now the END of key CAP - i
+            const uint32_t cls_lo[SPMV_CLASSES] = {64, 32, 16, 8, 0}, cls_lg[SPMV_CLASSES] = {4, 3, 2, 1, 0};
+            uint32_t cls_n[SPMV_CLASSES], cls_start[SPMV_CLASSES];
+            for (int c = 0; c < SPMV_CLASSES; c++) {
+                cls_start[c] = c ? cnt[CAP - cls_lo[c - 1]] : 0;
+                cls_n[c] = (cls_lo[c] ? cnt[CAP - cls_lo[c]] : ng) - cls_start[c];
+            }
             // A large flat system (a circuit as it comes out of a Parameters file): sorting a class by length over the WHOLE system
             // puts rows from everywhere in the circuit side by side -- every wave then gathers z from all over the witness and
             // streams its matrix entries from all over the CSR.  Sort by length inside blocks of consecutive rows instead: the rows
@@ -304,8 +310,8 @@ static int r1cs_load_impl(fk_ctx *ctx, const fk_r1cs *cs, uint32_t copies, fk_r1
             // (the benchmark's system with every term explicit: evaluation 15.2 -> see profiles/r03_spmv_rollup_probe.log).
             static const uint32_t block_rows = (uint32_t)std::max(0, tune("FK_SPMV_BLOCK_ROWS", 4096));
             if (copies == 1 && block_rows && ng >= 16 * block_rows) {
-                const uint32_t cls_lo[3] = {32, 4, 0};              // class c holds the rows of cls_lo[c] <= length < cls_lo[c - 1]
-                uint32_t pos[3] = {0, n16, n16 + n4};
+                uint32_t pos[SPMV_CLASSES];                            // class c holds the rows of cls_lo[c] <= length < cls_lo[c - 1]
+                for (int c = 0; c < SPMV_CLASSES; c++) pos[c] = cls_start[c];
                 std::vector<uint32_t> bc(CAP + 2);
                 std::vector<uint32_t> tmp(block_rows);
                 for (uint32_t g0 = 0; g0 < ng; g0 += block_rows) {
@@ -315,7 +321,9 @@ static int r1cs_load_impl(fk_ctx *ctx, const fk_r1cs *cs, uint32_t copies, fk_r1
                     for (uint32_t i = 0; i <= CAP; i++) bc[i + 1] += bc[i];
                     for (uint32_t g = g0; g < g1; g++) tmp[bc[CAP - key(g)]++] = g;           // the block's rows, longest first (stable)
                     for (uint32_t i = 0; i < g1 - g0; i++) {
-                        const uint32_t l = key(tmp[i]), c = l >= cls_lo[0] ? 0 : (l >= cls_lo[1] ? 1 : 2);
+                        const uint32_t l = key(tmp[i]);
+                        int c = 0;
+                        while (l < cls_lo[c]) c++;
                         list[pos[c]++] = tmp[i];
                     }
                 }
@@ -326,9 +334,8 @@ static int r1cs_load_impl(fk_ctx *ctx, const fk_r1cs *cs, uint32_t copies, fk_r1
             r->h_rowlist[k] = list;
             BinArgs &b = r->bins;
             b.rowlist[k] = r->rowlist[k]; b.mask |= 1u << k;
-            const uint32_t cls_n[3] = {n16, n4, n1}, cls_lg[3] = {4, 2, 0};
             uint32_t off = 0;
-            for (int c = 0; c < 3; c++) {
+            for (int c = 0; c < SPMV_CLASSES; c++) {
                 if (cls_n[c]) {
                     const uint64_t groups = (uint64_t)cls_n[c] * copies, per = 256u >> cls_lg[c], blocks = (groups + per - 1) / per;
                     if (b.first_block[b.nseg] + blocks > 0x7fffffffull) { ctx->err = "r1cs: system too large for the binned product"; return fail(FK_ERR_BAD_ARG); }
