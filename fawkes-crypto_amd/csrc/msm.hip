@@ -1241,10 +1241,6 @@ int msm_run_deferred(fk_ctx *ctx, hipEvent_t after) {
     std::vector<std::function<int()>> accs, tails;
     accs.swap(ctx->deferred); tails.swap(ctx->deferred_tails);
     for (auto &f : accs) FK_TRY(f());
-    // FK_MSM_TAILS_REVERSED (experiment): on the B pair's lane the G2 tail in front of B1's (it crawls underneath H's accumulation
-    // for as long as it is given; B1's 128-register waves find room sooner)
-    static const int t_rev = tune("FK_MSM_TAILS_REVERSED", 0);
-    if (t_rev) std::reverse(tails.begin(), tails.end());
     for (auto &f : tails) FK_TRY(f());
     return FK_OK;
 }
