@@ -129,7 +129,7 @@ def test_spmv_long_rows_vs_oracle(ctx, oracle, monkeypatch, lens, copies):
             ctx.dev_free(p)
 
 
-@pytest.mark.parametrize('copies,gates', [(64, 90), (65, 211), (130, 64), (257, 33)])
+@pytest.mark.parametrize('copies,gates', [(64, 90), (65, 211), (130, 64), (257, 33), (1024, 17), (1000, 9), (1088, 5)])
 def test_spmv_wave_form_of_batch_circuits(ctx, oracle, copies, gates):
     """batch circuits of 64 copies and more: rows of 4 .. 63 terms are evaluated one wave per (row, 64 copies)
     (spmv_tiled_wave_kernel), the others by the length-class kernel -- every boundary length, copy counts that do not fill the
