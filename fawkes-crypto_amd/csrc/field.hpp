@@ -212,6 +212,11 @@ struct alignas(16) Fp {
     static __device__ __forceinline__ void fq2mul(const Fp &a0, const Fp &a1, const Fp &b0, const Fp &b1, Fp &r0, Fp &r1) {
         fq2mul_body_asm(a0, a1, b0, b1, negq(b1), r0, r1);
     }
+    // (a0 + a1 u)(b0 + b1 u) - (c0 + c1 u)(d0 + d1 u), one reduction per component: 656 multiply-accumulates instead of 800
+    static __device__ __forceinline__ void fq2mulsub(const Fp &a0, const Fp &a1, const Fp &b0, const Fp &b1, const Fp &c0, const Fp &c1, const Fp &d0, const Fp &d1,
+                                                     Fp &r0, Fp &r1) {
+        fq2mulsub_body_asm(a0, a1, b0, b1, negq(b1), c0, c1, d1, negq(d0), negq(d1), r0, r1);
+    }
 #endif
 
     // r1 = a^2, r2 = c^2.  Device, inlined flavour: the cross products a_i a_j (i < j) are taken once, against a doubled limb
@@ -376,7 +381,12 @@ struct alignas(16) Fq2T {
         r2 = mul(c, d);
         r1 = t;
     }
-    static FK_HD Fq2 mulsub(const Fq2 &a, const Fq2 &b, const Fq2 &c, const Fq2 &d) { return sub(mul(a, b), mul(c, d)); }
+    static FK_HD Fq2 mulsub(const Fq2 &a, const Fq2 &b, const Fq2 &c, const Fq2 &d) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(FK_NO_FQ2MULSUB)
+        if constexpr (Fq::HAS_FQ2MUL) { Fq2 r; Fq::fq2mulsub(a.c0, a.c1, b.c0, b.c1, c.c0, c.c1, d.c0, d.c1, r.c0, r.c1); return r; }
+#endif
+        return sub(mul(a, b), mul(c, d));
+    }
     static FK_HD void sqr2(const Fq2 &a, const Fq2 &c, Fq2 &r1, Fq2 &r2) { const Fq2 t = sqr(a); r2 = sqr(c); r1 = t; }
     static FK_HD Fq2 sqr(const Fq2 &a) {  // (c0+c1)(c0-c1), 2 c0 c1
         Fq s, d, m, n;

@@ -270,6 +270,42 @@ def gen_fq2mul(o):
     o.append('    }')
 
 
+def gen_fq2mulsub(o):
+    """Fq2: a*b - c*d with ONE Montgomery reduction per component (Y3 = R (Q - X3) - Y1 PPP of the G2 mixed addition):
+    r0 = a0*b0 + a1*nb1 + c0*nd0 + c1*d1,  r1 = a0*b1 + a1*b0 + c0*nd1 + c1*nd0   (n. = the negative as a product operand, q - .)
+    -- 8 x 64 + 2 x 72 = 656 multiply-accumulates instead of two fq2mul (800).  A sum of four products is below 4 q^2, its
+    reduction below 2.02 q (lazy, q = 2p) or 1.76 q (q = p): two conditional subtractions of q."""
+    o.append('// Fq2: a*b - c*d, one reduction per component (the caller passes the negatives nb1, nd0, nd1): see tools/gen_mont_mul.py')
+    o.append('    static __device__ __forceinline__ void fq2mulsub_body_asm(const Fp &a0, const Fp &a1, const Fp &b0, const Fp &b1, const Fp &nb1, const Fp &c0, const Fp &c1,'
+             ' const Fp &d1, const Fp &nd0, const Fp &nd1, Fp &r0, Fp &r1) {')
+    o.append('        uint64_t lo = 0, lo2 = 0; uint32_t hi, hi2; uint64_t ca0, ca1, cb0, cb1;')
+    o.append('        uint32_t m0, m1, m2, m3, m4, m5, m6, m7, n0, n1, n2, n3, n4, n5, n6, n7;')
+    o.append('        Fp x, y;')
+    ren = lambda st: st.replace('(a0)', '(ca0)').replace('(a1)', '(ca1)').replace('(b0)', '(cb0)').replace('(b1)', '(cb1)')
+    for k, ab, mp in columns():
+        o.append('        // column %d' % k)
+        if mp:
+            o.append(ren(stmt2([('m%d' % i, 'P::p(%d)' % j) for i, j in mp], [('n%d' % i, 'P::p(%d)' % j) for i, j in mp], 'vs', first=True)))
+        pa, pb = [], []
+        for (xa, ya), (xb, yb) in ((('a0', 'b0'), ('a0', 'b1')), (('a1', 'nb1'), ('a1', 'b0')), (('c0', 'nd0'), ('c0', 'nd1')), (('c1', 'd1'), ('c1', 'nd0'))):
+            pa += [('%s.v[%d]' % (xa, i), '%s.v[%d]' % (ya, j)) for i, j in ab]
+            pb += [('%s.v[%d]' % (xb, i), '%s.v[%d]' % (yb, j)) for i, j in ab]
+        for lo_ in range(0, len(pa), 5):
+            st = stmt2(pa[lo_:lo_ + 5], pb[lo_:lo_ + 5], 'vv', first=(not mp and lo_ == 0))
+            o.append(st.replace('"=&s"(a0)', '"=&s"(ca0)').replace('"=&s"(a1)', '"=&s"(ca1)').replace('"=&s"(b0)', '"=&s"(cb0)').replace('"=&s"(b1)', '"=&s"(cb1)'))
+        if k < 8:
+            o.append('        m%d = (uint32_t)lo * P::INV; n%d = (uint32_t)lo2 * P::INV;' % (k, k))
+            o.append(ren(stmt2([('m%d' % k, 'P::p(0)')], [('n%d' % k, 'P::p(0)')], 'vs')))
+        else:
+            o.append('        x.v[%d] = (uint32_t)lo; y.v[%d] = (uint32_t)lo2;' % (k - 8, k - 8))
+        if mp or ab:
+            o.append('        lo = (lo >> 32) | ((uint64_t)hi << 32); lo2 = (lo2 >> 32) | ((uint64_t)hi2 << 32);')
+    o.append('        Fp s, t;')
+    o.append('        red2q(x, y, s, t);        // a sum of four products: below 2.02 q before this ...')
+    o.append('        red2q(s, t, r0, r1);      // ... below 1.02 q here, below q after it')
+    o.append('    }')
+
+
 def check(text):
     """Static check of the hazard rule on the generated text: inside every asm string, a v_addc that reads carry
     operand %k must sit >= 2 instructions after the last instruction that wrote %k."""
@@ -303,6 +339,7 @@ def main():
     gen_mulsum(o)
     gen_dot4(o)
     gen_fq2mul(o)
+    gen_fq2mulsub(o)
     text = '\n'.join(o) + '\n'
     n, bad = check(text)
     if bad:
