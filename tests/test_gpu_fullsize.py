@@ -105,6 +105,21 @@ def test_config3_2p25_rollup1024_single_gpu_and_one_call_on_8_ranks(ctx):
     t1 = ctx.prove_witness_submit(key, dr, zp, r, s)
     assert ctx.prove_witness_wait(t0).tobytes() == want.tobytes() and ctx.prove_witness_wait(t1).tobytes() == want.tobytes()
     ctx.host_free(zp)
+    # the multiplications as separate calls: quotient -> fk_prove_msm_h_dev (H on its own over the resident levels), the four witness
+    # multiplications by fk_prove_msms_z_dev, folded on the host = same bytes
+    m = 1 << log_m
+    d_abc = [ctx.dev_alloc(m * 32) for _ in range(3)]
+    d_h = ctx.dev_alloc(m * 32)
+    try:
+        ctx.r1cs_eval_dev(dr, d_z, *d_abc)
+        ctx.quotient_h_dev(d_abc[0], d_abc[1], d_abc[2], n, d_h)
+        part = ctx.prove_msms_z_dev(key, d_z, *dr.density_ptrs())
+        assert part[:64].tobytes() == bytes(64)
+        part[:64] = ctx.prove_msm_h_dev(key, d_h)
+        assert ctx.prove_assemble(key, np.stack([part]), r, s).tobytes() == want.tobytes()
+    finally:
+        for p_ in d_abc + [d_h]:
+            ctx.dev_free(p_)
     key.free()                                  # 140 GiB of key + levels make room for the eight shards' scratch
 
     ctx.dev_free(d_z); dr.free()
