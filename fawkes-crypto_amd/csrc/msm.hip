@@ -564,29 +564,6 @@ static __device__ __forceinline__ void s2_scatter1n_body(const uint32_t *digits,
 #define S2N_ARGS1 const uint32_t *digits, size_t n, size_t chunk, uint32_t nchunks, uint32_t LB, uint32_t nhi, const uint32_t *cnt1, const uint32_t *seg_start, uint32_t *tmp_idx, uint16_t *tmp_lo
 #define S2N_PASS1 digits, n, chunk, nchunks, LB, nhi, cnt1, seg_start, tmp_idx, tmp_lo
 __global__ __launch_bounds__(1024) void s2_scatter1_n1024_kernel(S2N_ARGS1) { s2_scatter1n_body<1024>(S2N_PASS1); }
-// Experiment (FK_S1_DIRECT): no staging, no barriers -- every entry draws its slot from the bin's LDS cursor and is written straight to
-// its place.  The order inside a bin is then arbitrary, which the group law does not mind; the writes are 4 + 2 bytes each.
-__global__ __launch_bounds__(1024) void s2_scatter1_direct_kernel(S2N_ARGS1) {
-    __shared__ uint32_t cursor[S2_MAX_HI];
-    const uint32_t ch = blockIdx.x, w = blockIdx.y, tid = threadIdx.x;
-    const uint32_t *cnt = cnt1 + ((size_t)w * nchunks + ch) * nhi;
-    for (uint32_t b = tid; b < S2_MAX_HI; b += 1024) cursor[b] = b < nhi ? seg_start[(size_t)w * nhi + b] + cnt[b] : 0;
-    __syncthreads();
-    const size_t c_lo = (size_t)ch * chunk, c_hi = c_lo + chunk < n ? c_lo + chunk : n;
-    const uint32_t *dg = digits + (size_t)w * n;
-    const uint32_t lomask = (1u << LB) - 1;
-    uint32_t *oidx = tmp_idx + (size_t)w * n;
-    uint16_t *olo = tmp_lo + (size_t)w * n;
-#pragma unroll 4
-    for (size_t k = c_lo + tid; k < c_hi; k += 1024) {
-        const uint32_t dd = dg[k], bkt = dd & 0x7fffffffu;
-        if (bkt) {
-            const uint32_t pos = atomicAdd(&cursor[(bkt - 1) >> LB], 1u);
-            oidx[pos] = (uint32_t)k | (dd & 0x80000000u);
-            olo[pos] = (uint16_t)((bkt - 1) & lomask);
-        }
-    }
-}
 
 // ------------------------------------------------------------------------------------------ bucket -> lane assignment
 // A wave runs as long as its longest bucket, so lanes are handed buckets of (nearly) equal length: buckets are
@@ -1128,9 +1105,7 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
         hipLaunchKernelGGL(s2_hist1_kernel, dim3(p.nchunks, p.W), dim3(SORT_THREADS), p.nhi * 4, ss, digits, n, p.chunk, p.nchunks, p.LB, p.nhi, cnt1);
         hipLaunchKernelGGL(s2_prefix1_kernel, dim3(p.W), dim3(1024), p.nhi * 4, ss, cnt1, p.nchunks, p.nhi, seg_size, seg_start, seg_tiles);
         hipLaunchKernelGGL(s2_tile_prefix_kernel, dim3(1), dim3(1024), 0, ss, seg_tiles, nseg, tile_start);
-        static const int t_direct = tune("FK_S1_DIRECT", 0);
-        if (t_direct) hipLaunchKernelGGL(s2_scatter1_direct_kernel, dim3(p.nchunks, p.W), dim3(1024), 0, ss, digits, n, p.chunk, p.nchunks, p.LB, p.nhi, cnt1, seg_start, tmp_idx, tmp_lo);
-        else hipLaunchKernelGGL(s2_scatter1_n1024_kernel, dim3(p.nchunks, p.W), dim3(1024), 0, ss, digits, n, p.chunk, p.nchunks, p.LB, p.nhi, cnt1, seg_start, tmp_idx, tmp_lo);
+        hipLaunchKernelGGL(s2_scatter1_n1024_kernel, dim3(p.nchunks, p.W), dim3(1024), 0, ss, digits, n, p.chunk, p.nchunks, p.LB, p.nhi, cnt1, seg_start, tmp_idx, tmp_lo);
         FK_HIP(ctx, hipGetLastError());
         FK_DBG_ST(ctx, ss, "msm_sort_pass1");
         // The second pass is launched over the host's BOUND on the tile count (every segment's last tile may be partial:
