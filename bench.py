@@ -11,10 +11,13 @@ handed over per proof from pinned host memory through the two-slot pipeline of t
 the upload of proof k+1 runs underneath proof k), so K steps contain K uploads and K proofs.  The same proof with the
 witness already resident in HBM is reported beside it (`device_resident_ms_per_step`).
 
-Default workload (`--workload rollup1024`): BASELINE configs[3]'s "1024-tx shape" with real gadgets -- 1024 rollup-style
-transactions (two depth-32 poseidon merkle proofs + one eddsa-poseidon signature each, 19 270 gates and 942 k matrix
-terms per transaction) as ONE R1CS of 19.7 M gates / 9.6e8 matrix terms through fk_setup_tiled / fk_r1cs_load_tiled.  The
-transaction comes from the committed data fixture tests/golden/rollup_tx_instance.npz (made by
+Default workload (`--workload rollup1024 --copies 1741`): BASELINE configs[3]'s "1024-tx shape" with real gadgets, sized so
+that it FILLS the 2^25 domain the metric names (rows = 2^25) -- 1741 rollup-style transactions (two
+depth-32 poseidon merkle proofs + one eddsa-poseidon signature each, 19 270 gates and 942 k matrix terms per transaction) as
+ONE R1CS of 33 552 553 rows (99.99 % of 2^25) / 1.64e9 matrix terms through fk_setup_tiled / fk_r1cs_load_tiled.  (Rounds 2-3
+benchmarked 1024 of them: 19.7 M rows, the same domain 59 % filled -- kept as the `secondary_1024_transactions` leg; the
+`reference_published` leg is 1853 transactions = 35.7 M rows on the 2^26 domain, the size of the reference's one published
+figure, README.md:54-56.)  The transaction comes from the committed data fixture tests/golden/rollup_tx_instance.npz (made by
 tests/golden/make_rollup_tx_fixture.py; the circuit builder itself is oracle-side and is NOT imported here).
 `--workload synthetic` is the round-1 shape (1-2 term rows, m = 2^LOG2 exactly; `--lc-terms` for longer combinations).
 The key is a VALID key (fk_setup*, fixed toxic waste), so the proof produced in the timed region is checked afterwards
@@ -244,49 +247,147 @@ def materialise_rollup(copies, path=None):
     return n_in, copies * b_aux, mats, np.ascontiguousarray(d['table'])
 
 
-def standalone_legs(ctx, key, m):
-    """BASELINE configs[1] and the metric's second half as figures of their own: the G1 / G2 multi-scalar multiplication and the
-    Fr transform timed ALONE on this GPU (inputs resident, dense uniform scalars), in SURVEY section 8(d)'s units."""
-    out = {}
+def _spread(samples_s):
+    """min / median / max of per-repetition times, in ms"""
+    ts = sorted(samples_s)
+    k = len(ts)
+    med = ts[k // 2] if k & 1 else 0.5 * (ts[k // 2 - 1] + ts[k // 2])
+    return {'min': ts[0] * 1e3, 'median': med * 1e3, 'max': ts[-1] * 1e3, 'reps': k}
 
-    def timed(fn, reps):
-        fn()
-        ctx.sync()
-        t0 = time.perf_counter()
-        for _ in range(reps):
+
+def standalone_legs(ctx, key, m, reps=10):
+    """BASELINE configs[1] and the metric's second half ("MSM scalar-muls/sec") as figures of their own: the G1 / G2 multi-scalar
+    multiplication and the Fr transform timed ALONE on this GPU (inputs resident), in SURVEY section 8(d)'s units.  Every figure is
+    `reps` (>= 10) separately timed repetitions after two untimed ones -- min / median / max of the host's wall clock around a
+    synchronised call, and beside it the same repetitions by HIP events on the library's stream (`hip_event_ms`) -- so that a slow
+    outlier shows as an outlier and not as the figure.  Rates are quoted on the MEDIAN.  Scalar distributions: BASELINE.md config 2
+    (a) uniform mod r and (b) witness-like (half in {0, 1}: fk_gen_scalars_dev kind 1)."""
+    import torch
+    out = {}
+    st = torch.cuda.ExternalStream(ctx.stream_handle())
+
+    def timed(fn, n_reps=reps):
+        for _ in range(2):
             fn()
         ctx.sync()
-        return (time.perf_counter() - t0) / reps
+        wall, evs = [], []
+        for _ in range(n_reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ctx.sync()
+            t0 = time.perf_counter()
+            e0.record(st)
+            fn()
+            e1.record(st)
+            ctx.sync()
+            wall.append(time.perf_counter() - t0)
+            e1.synchronize()
+            evs.append(e0.elapsed_time(e1) * 1e-3)
+        return _spread(wall), _spread(evs)
 
+    def entry(wall, ev, n, bytes_per, path, **kw):
+        t = wall['median'] * 1e-3
+        d = {'ms': wall['median'], 'wall_ms': wall, 'hip_event_ms': ev, 'scalar_muls_per_sec': n / t, 'algorithmic_GBps': bytes_per * n / t / 1e9, 'path': path}
+        d.update(kw)
+        return d
+
+    kinds = ((0, 'uniform'), (1, 'witness_like'))
     for log_n in (20,):
         n = 1 << log_n
         d_b1, d_b2, d_s = ctx.dev_alloc(n * 64), ctx.dev_alloc(n * 128), ctx.dev_alloc(n * 32)
-        ctx.gen_points_g1_dev(d_b1, n, 11); ctx.gen_points_g2_dev(d_b2, n, 12); ctx.gen_scalars_dev(d_s, n, 13, 0)
-        t1 = timed(lambda: ctx.msm_g1_dev(d_b1, d_s, n), 10)
-        t2 = timed(lambda: ctx.msm_g2_dev(d_b2, d_s, n), 5)
-        out['msm_g1_2p%d' % log_n] = {'ms': t1 * 1e3, 'scalar_muls_per_sec': n / t1, 'algorithmic_GBps': 96 * n / t1 / 1e9, 'path': 'fk_msm_g1_dev (bases as plain device memory)'}
-        out['msm_g2_2p%d' % log_n] = {'ms': t2 * 1e3, 'scalar_muls_per_sec': n / t2, 'algorithmic_GBps': 160 * n / t2 / 1e9, 'path': 'fk_msm_g2_dev'}
+        ctx.gen_points_g1_dev(d_b1, n, 11); ctx.gen_points_g2_dev(d_b2, n, 12)
+        for kind, kname in kinds:
+            ctx.gen_scalars_dev(d_s, n, 13 + kind, kind)
+            sfx = '' if kind == 0 else '_' + kname
+            w, e = timed(lambda: ctx.msm_g1_dev(d_b1, d_s, n))
+            out['msm_g1_2p%d%s' % (log_n, sfx)] = entry(w, e, n, 96, 'fk_msm_g1_dev (bases as plain device memory)', scalars=kname)
+            w, e = timed(lambda: ctx.msm_g2_dev(d_b2, d_s, n))
+            out['msm_g2_2p%d%s' % (log_n, sfx)] = entry(w, e, n, 160, 'fk_msm_g2_dev', scalars=kname)
         for p_ in (d_b1, d_b2, d_s):
             ctx.dev_free(p_)
-    # the key's h array (m - 1 bases, resident, with its fixed-base levels when the key holds them): the product's path at this size
-    info = key.shard_info()
-    n_h = info['h'][1] - info['h'][0]
-    d_s = ctx.dev_alloc(max(n_h, 1) * 32)
-    ctx.gen_scalars_dev(d_s, n_h, 17, 0)
-    t = timed(lambda: ctx.prove_msm_h_dev(key, d_s), 3)
-    out['msm_g1_2p%d_key_bases' % (int(m).bit_length() - 1)] = {
-        'ms': t * 1e3, 'points': n_h, 'scalar_muls_per_sec': n_h / t, 'algorithmic_GBps': 96 * n_h / t / 1e9,
-        'path': 'fk_prove_msm_h_dev over the resident h array (fixed-base levels: %d)' % key.precomputed()['h']}
-    ctx.dev_free(d_s)
-    for log_n in sorted({20, int(m).bit_length() - 1}):
+    # the key's own arrays (resident, with their fixed-base levels when the key holds them): the product's path at this size
+    info, pre = key.shard_info(), key.precomputed()
+    log_m = int(m).bit_length() - 1
+    for arr, cnt_key, bytes_per, tag in (('h', 'h', 96, 'msm_g1_2p%d_key_bases' % log_m), ('l', 'l', 96, 'msm_g1_key_l'), ('b_g2', 'b', 160, 'msm_g2_key_b_g2')):
+        n_pts = info[cnt_key][1] - info[cnt_key][0]
+        if n_pts <= 0:
+            continue
+        d_s = ctx.dev_alloc(n_pts * 32)
+        for kind, kname in kinds:
+            if arr == 'h' and kind == 1:
+                continue                  # h's scalars are quotient coefficients: dense by nature
+            ctx.gen_scalars_dev(d_s, n_pts, 17 + kind, kind)
+            w, e = timed(lambda: ctx.prove_msm_array_dev(key, arr, d_s))
+            out[tag + ('' if kind == 0 else '_' + kname)] = entry(
+                w, e, n_pts, bytes_per, 'fk_prove_msm_array_dev over the resident %s array (fixed-base levels: %d)' % (arr, pre[arr]), points=n_pts, scalars=kname)
+        ctx.dev_free(d_s)
+    for log_n in sorted({20, log_m}):
         n = 1 << log_n
         d = ctx.dev_alloc(n * 32)
         ctx.gen_scalars_dev(d, n, 19, 0)
-        t = timed(lambda: ctx.ntt_dev(d, log_n), 10 if log_n <= 22 else 4)
-        out['ntt_2p%d' % log_n] = {'ms': t * 1e3, 'algorithmic_GBps': 64 * n / t / 1e9,
-                                   'GBps_is': 'SURVEY 8(d): 64 B per element per transform (one ideal pass), forward transform in place'}
+        w, e = timed(lambda: ctx.ntt_dev(d, log_n))
+        t = e['median'] * 1e-3
+        out['ntt_2p%d' % log_n] = {'ms': e['median'], 'wall_ms': w, 'hip_event_ms': e, 'algorithmic_GBps': 64 * n / t / 1e9,
+                                   'GBps_is': 'SURVEY 8(d): 64 B per element per transform (one ideal pass), forward transform in place; quoted on the HIP-event median'}
         ctx.dev_free(d)
     return out
+
+
+def other_size_leg(ctx, inst, zs, copies, tox, r, s, steps, check=True):
+    """The same prover on the same circuit family at another transaction count (its own key and resident system; the main key must
+    have been freed): host-witness pipeline `ms_per_step` exactly as `value` is measured, the device-resident latency beside it,
+    which key arrays kept their fixed-base levels, and the proof pairing-checked against the system's public inputs."""
+    num_input, num_aux = 1 + copies * (inst.num_input - 1), copies * inst.num_aux
+    n = copies * inst.num_gates + num_input
+    log_m = max(n - 1, 1).bit_length()
+    nv = num_input + num_aux
+    t0 = time.perf_counter()
+    z_pin = [ctx.host_alloc((nv, 4)) for _ in range(2)]
+    tile_witness(zs, inst.num_input, copies, out=z_pin[0])
+    # the second slot holds a DIFFERENT witness (the transactions dealt to the copies in another order): two distinct proofs
+    # alternate in the two-slot pipeline, each checked
+    tile_witness(zs[::-1], inst.num_input, copies, out=z_pin[1])
+    dr = ctx.load_r1cs(inst, copies=copies)
+    key, vk = ctx.setup(inst, copies=copies, **tox)
+    prep = time.perf_counter() - t0
+    try:
+        tk = ctx.prove_witness_submit(key, dr, z_pin[0], r, s)
+        proofs = [None, None]
+        for i in range(2):                # warm-up: both slots once
+            nxt = ctx.prove_witness_submit(key, dr, z_pin[(i + 1) & 1], r, s)
+            proofs[i & 1] = ctx.prove_witness_wait(tk).tobytes(); tk = nxt
+        ctx.sync()
+        t1 = time.perf_counter()
+        for i in range(2, 2 + steps):
+            nxt = ctx.prove_witness_submit(key, dr, z_pin[(i + 1) & 1], r, s)
+            p_ = ctx.prove_witness_wait(tk).tobytes(); tk = nxt
+            if p_ != proofs[i & 1]:
+                raise AssertionError('bench: pipelined proofs of the %d-transaction system differ between steps' % copies)
+        ctx.sync()
+        ms = (time.perf_counter() - t1) / steps * 1e3
+        ctx.prove_witness_wait(tk)
+        d_z = ctx.dev_alloc(nv * 32)
+        ctx.upload(d_z, z_pin[0])
+        ctx.prove_witness_dev(key, dr, d_z, r, s)
+        ctx.sync()
+        t1 = time.perf_counter()
+        for _ in range(max(2, min(steps, 5))):
+            p_dev = ctx.prove_witness_dev(key, dr, d_z, r, s)
+        dev_ms = (time.perf_counter() - t1) / max(2, min(steps, 5)) * 1e3
+        ctx.dev_free(d_z)
+        if p_dev.tobytes() != proofs[0]:
+            raise AssertionError('bench: device-resident proof of the %d-transaction system differs from the pipelined one' % copies)
+        out = {'transactions': copies, 'rows': n, 'log2_domain': log_m, 'domain_fill': n / float(1 << log_m), 'num_aux': num_aux,
+               'matrix_terms': int(sum(dr.info()['nnz'])), 'ms_per_step': ms, 'proofs_per_sec': 1e3 / ms, 'steps': steps,
+               'device_resident_ms_per_step': dev_ms, 'msm_fixed_base_levels': key.precomputed(), 'prep_seconds': prep,
+               'witness_bytes_per_proof': nv * 32}
+        if check:
+            out['proof_verified_by_pairing_check'] = bool(pairing_check(vk, z_pin[0][1:num_input].copy(), proofs[0]) and
+                                                          pairing_check(vk, z_pin[1][1:num_input].copy(), proofs[1]))
+        return out
+    finally:
+        key.free(); dr.free()
+        for zp in z_pin:
+            ctx.host_free(zp)
 
 
 def single_process_leg(fk, n_ranks, same_device, r1cs, copies, z_pin, tox, r, s, want, steps):
@@ -298,20 +399,21 @@ def single_process_leg(fk, n_ranks, same_device, r1cs, copies, z_pin, tox, r, s,
         key, _ = mc.setup(r1cs, copies=copies, **tox)
         dr = mc.load_r1cs(r1cs, copies=copies)
         prep = time.perf_counter() - t0
-        tk = mc.prove_witness_submit(key, dr, z_pin[0], r, s)
-        for i in range(1):       # warm-up
-            nxt = mc.prove_witness_submit(key, dr, z_pin[(i + 1) & 1], r, s)
-            p = mc.prove_witness_wait(tk); tk = nxt
+        tk, slot = mc.prove_witness_submit(key, dr, z_pin[0], r, s), 0
         mc.sync()
-        t1 = time.perf_counter()
-        for i in range(steps):
-            nxt = mc.prove_witness_submit(key, dr, z_pin[i & 1], r, s)
+        t1 = None
+        for i in range(1 + steps):       # one warm-up step, then `steps` timed ones; the two slots hold different witnesses
+            if i == 1:
+                mc.sync()
+                t1 = time.perf_counter()
+            nxt = mc.prove_witness_submit(key, dr, z_pin[slot ^ 1], r, s)
             p = mc.prove_witness_wait(tk); tk = nxt
+            if want[slot] is not None and p.tobytes() != want[slot]:
+                raise AssertionError('single-process multi-GPU proof differs from the benchmarked proof')
+            slot ^= 1
         mc.sync()
         ms = (time.perf_counter() - t1) / steps * 1e3
         mc.prove_witness_wait(tk)
-        if p.tobytes() != want:
-            raise AssertionError('single-process multi-GPU proof differs from the benchmarked proof')
         key.free(); dr.free()
         return {'ms_per_step': ms, 'proofs_per_sec': 1e3 / ms, 'ranks': n_ranks, 'steps': steps, 'prep_seconds': prep,
                 'is': 'fk_multi_prove_r1cs (ONE call on %d GPUs, in-library peer-DMA all-to-all), same proof bytes' % n_ranks}
@@ -430,6 +532,36 @@ def pairing_check(vk_full, z_inputs, proof):
     return True
 
 
+def pmc_traffic(args, log_m, rows, world, acc, acc_s, achieved):
+    """HBM traffic of the dominant kernel from the newest committed PMC pass taken on THIS workload (same workload name, domain and
+    row count): bytes per (scalar, base) pair of that pass x this run's pairs / this run's kernel time.  Returns (GB/s or None,
+    source, error).  A figure that cannot be right -- below the algorithmic bytes, more than 30x above them, or beyond what HBM can
+    deliver (6.3 TB/s measured, /opt/skills/guides/MI355X_MICROARCH.md) -- is reported as null with the reason (a summary
+    divided by the wrong proof count once put 7.2 TB/s here)."""
+    if world != 1 or acc_s <= 0:
+        return None, None, None
+    prof = os.path.join(ROOT, 'profiles')
+    for cand in sorted((f for f in os.listdir(prof) if f.endswith('.json') and 'pmc_traffic' in f), reverse=True):
+        try:
+            pmc = json.load(open(os.path.join(prof, cand)))
+            if pmc.get('workload', 'synthetic') != args.workload or pmc['log2n'] != log_m or pmc.get('rows', rows) != rows:
+                continue
+            dkk = pmc['dominant_kernel']
+            per_pt = (dkk['fetch_bytes_per_proof_raw'] * dkk.get('fetch_correction', 1.0) + dkk['write_bytes_per_proof']) / dkk['points_per_proof']
+            traffic = per_pt * acc['units'] / acc_s / 1e9
+            src = ('rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/%s (%d proofs in the pass, counted from its dispatches; bytes per point '
+                   'from that pass x this run\'s points; FETCH_SIZE x %.2f, the factor calibrated for 64-byte gathers)'
+                   % (cand, dkk.get('proofs_in_the_pass', 1), dkk.get('fetch_correction', 1.0)))
+            ratio = traffic / achieved if achieved > 0 else 0.0
+            if not (1.0 <= ratio <= 30.0) or traffic > 6300.0:
+                return None, src, ('implausible: %.0f GB/s = %.1f x the algorithmic bytes (accepted: 1 .. 30 x and <= 6300 GB/s); the PMC summary '
+                                   'is mis-normalised or from another configuration' % (traffic, ratio))
+            return traffic, src, None
+        except Exception:
+            continue
+    return None, None, 'no committed PMC traffic pass for this workload / domain / row count under profiles/'
+
+
 def self_launch(n_gpus):
     """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nproc-per-node N bench.py <same
     arguments>` as a child process (one rank per GPU, rendezvous on 127.0.0.1 at a free port), pass its output through and
@@ -465,7 +597,9 @@ def main():
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--workload', choices=('rollup1024', 'synthetic'), default='rollup1024')
-    ap.add_argument('--copies', type=int, default=1024, help='rollup1024: transactions in the one R1CS (1024 -> 19.7 M gates, domain 2^25)')
+    ap.add_argument('--copies', type=int, default=1741,
+                    help='rollup1024: transactions in the one R1CS (1741 -> 33 552 553 rows = 99.99 %% of the 2^25 domain, BASELINE config 4: "rows = 2^25"; '
+                         '1024 -> 19.7 M rows, the same domain 59 %% filled: rounds 2-3)')
     ap.add_argument('--lc-terms', type=int, default=0, help='synthetic: operands per side of every product gate (default: the 1-2 term shape)')
     ap.add_argument('--log2n', type=int, default=25, help='synthetic: log2 of the row count handed to the prover')
     ap.add_argument('--cpu-log2n', type=int, default=20, help='synthetic: size of the CPU-baseline sample instance')
@@ -475,7 +609,13 @@ def main():
     ap.add_argument('--no-single-process', action='store_true', help='N > 1: skip the fk_multi_prove_r1cs leg (one process driving all GPUs)')
     ap.add_argument('--no-untiled', action='store_true', help='rollup1024, N = 1: skip the leg with the 9.6e8-term system materialised (no tiling shortcut)')
     ap.add_argument('--no-standalone', action='store_true', help='N = 1: skip the standalone MSM / NTT figures')
-    ap.add_argument('--cpu-full-budget', type=float, default=420.0,
+    ap.add_argument('--no-other-sizes', action='store_true',
+                    help='rollup1024, N = 1: skip the legs at other transaction counts (--secondary-copies, --reference-copies)')
+    ap.add_argument('--secondary-copies', type=int, default=1024, help='rollup1024, N = 1: the 1024-transaction system of rounds 2-3 (59 %% of the domain) as a secondary leg')
+    ap.add_argument('--reference-copies', type=int, default=1853,
+                    help='rollup1024, N = 1: transactions of the `reference_published` leg (1853 -> 35 711 017 rows >= the 35 695 616 constraints of the '
+                         'reference\'s one published figure, README.md:54-56; domain 2^26)')
+    ap.add_argument('--cpu-full-budget', type=float, default=600.0,
                     help='seconds the FULL-SIZE all-cores CPU baseline run may take by projection from the sample (else the scaled sample is reported)')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend ('nccl' = RCCL; 'gloo' only for single-GPU dry runs of the N>1 code path with FK_BENCH_SAME_DEVICE=1)")
     args = ap.parse_args()
@@ -531,11 +671,16 @@ def main():
     z_pin = [ctx.host_alloc((nv, 4)) for _ in range(2)]
     if copies is not None:
         tile_witness(zs, r1cs.num_input, copies, out=z_pin[0])
+        # the second slot holds a DIFFERENT witness (the same transactions dealt to the copies in reverse order, so other values in
+        # every position): two distinct proofs alternate through the two-slot pipeline and each is checked -- a slot mix-up or a stale
+        # staging buffer in the pipelined front cannot pass as "same bytes" 
+        tile_witness(zs[::-1], r1cs.num_input, copies, out=z_pin[1])
     else:
         z_pin[0][:] = z
         del z
-    z_pin[1][:] = z_pin[0]
-    z_inputs = z_pin[0][1:num_input].copy()
+        z_pin[1][:] = z_pin[0]
+    z_inputs = [z_pin[0][1:num_input].copy(), z_pin[1][1:num_input].copy()]
+    two_witnesses = not np.array_equal(z_pin[0], z_pin[1])
     zeros = int((~z_pin[0].any(axis=1)).sum()); ones = int((z_pin[0] == mont(1)).all(axis=1).sum())
     dr = ctx.load_r1cs(r1cs, copies=copies)
     info = dr.info()
@@ -622,8 +767,12 @@ def main():
     elapsed = time.perf_counter() - t0
     stats = ctx.stats()
     drain()
-    if len(set(proofs)) != 1 or proofs[0] == bytes(256):
+    # proof k comes from slot k & 1; with two distinct witnesses the two slots give two proofs, each the same at every step
+    want = [proofs[0], proofs[1] if len(proofs) > 1 else None]
+    if any(pf != want[k & 1] for k, pf in enumerate(proofs)) or proofs[0] == bytes(256):
         raise AssertionError('bench: proofs differ between steps (non-deterministic result)')
+    if two_witnesses and want[1] is not None and want[1] == want[0]:
+        raise AssertionError('bench: two different witnesses gave the same proof bytes')
     if multi:
         import torch.distributed as dist
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == 'nccl' else 'cpu')
@@ -641,8 +790,17 @@ def main():
         for _ in range(dev_steps):
             p_dev = ctx.prove_witness_dev(key, dr, d_z0, r, s)
         dev_ms = (time.perf_counter() - t1) / dev_steps * 1e3
-        if p_dev.tobytes() != proofs[-1]:
+        if p_dev.tobytes() != want[0]:
             raise AssertionError('bench: device-resident proof differs from the host-witness proof')
+        # latency: ONE proof at a time from the witness in (pinned) host memory, upload inside the call, nothing overlapped
+        lats = []
+        for k in range(dev_steps):
+            t1 = time.perf_counter()
+            p_lat = ctx.prove_witness(key, dr, z_pin[k & 1], r, s)
+            lats.append(time.perf_counter() - t1)
+            if want[k & 1] is not None and p_lat.tobytes() != want[k & 1]:
+                raise AssertionError('bench: one-at-a-time proof differs from the pipelined proof')
+        lat_ms = sorted(lats)[len(lats) // 2] * 1e3
     else:
         barrier()
         t1 = time.perf_counter()
@@ -650,7 +808,7 @@ def main():
             p_dev = prove_multi(d_z0)
         barrier()
         dev_ms = (time.perf_counter() - t1) / dev_steps * 1e3
-        if p_dev.tobytes() != proofs[-1]:
+        if p_dev.tobytes() != want[0]:
             raise AssertionError('bench: device-resident proof differs from the host-witness proof')
 
     # ---- not `value`: the SAME circuit with every one of its 9.6e8 terms explicit in HBM (no tiling shortcut: what a circuit that is
@@ -670,7 +828,7 @@ def main():
         for _ in range(dev_steps):
             p_u = ctx.prove_witness_dev(key, dr_u, d_z0, r, s)
         u_ms = (time.perf_counter() - t1) / dev_steps * 1e3
-        if p_u.tobytes() != proofs[-1]:
+        if p_u.tobytes() != want[0]:
             raise AssertionError('bench: the proof from the materialised system differs from the tiled one')
         ui = dr_u.info()
         untiled = {'device_resident_ms_per_step': u_ms, 'tiled_device_resident_ms_per_step': dev_ms, 'matrix_terms_resident': int(sum(ui['nnz'])),
@@ -700,7 +858,7 @@ def main():
         barrier()
         rep_t = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev if args.backend == 'nccl' else 'cpu')
         dist.all_reduce(rep_t, op=dist.ReduceOp.MAX)
-        if p_rep.tobytes() != proofs[-1]:
+        if p_rep.tobytes() != want[(dev_steps - 1) & 1] and want[(dev_steps - 1) & 1] is not None:
             raise AssertionError('bench: replica proof differs from the distributed proof')
         replica = world * (dev_steps + 1) / float(rep_t.item())
     ctx.dev_free(d_z0)
@@ -721,11 +879,12 @@ def main():
         barrier()
         if rank == 0:
             try:
-                single_proc = single_process_leg(fk, world, same_dev, r1cs, copies, z_pin, tox, r, s, proofs[-1], dev_steps)
+                single_proc = single_process_leg(fk, world, same_dev, r1cs, copies, z_pin, tox, r, s, want, dev_steps)
             except Exception as e:     # noqa: BLE001 -- reported, the rank-per-GPU result above stands
                 single_proc = {'error': '%s: %s' % (type(e).__name__, e)}
         dist.barrier(group=hostgrp)
 
+    out = None
     if rank == 0:
         sec_per_step = elapsed / args.steps
         msm_units = (m - 1) + num_aux + n_a + 2 * n_b       # scalar-muls per proof: H, L, A, B1 (G1) and B2 (G2)
@@ -736,32 +895,21 @@ def main():
         acc_s = acc.get('union_ms', acc['ms']) * 1e-3
         # dominant kernel: G1 bucket accumulation; achieved = algorithmic bytes / its HIP-event time
         achieved = (acc['units'] * G1_BYTES_PER_SCALAR_MUL) / acc_s / 1e9 if acc_s > 0 else 0.0
-        traffic, traffic_src = None, None
-        for cand in sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('.json') and 'pmc_traffic' in f)[::-1]:
-            try:   # HBM traffic of the dominant kernel from the newest committed PMC pass taken on this workload
-                pmc = json.load(open(os.path.join(ROOT, 'profiles', cand)))
-                if pmc.get('workload', 'synthetic') == args.workload and pmc['log2n'] == log_m and world == 1 and acc_s > 0:
-                    dkk = pmc['dominant_kernel']
-                    per_pt = (dkk['fetch_bytes_per_proof_raw'] * dkk.get('fetch_correction', 1.0) + dkk['write_bytes_per_proof']) / dkk['points_per_proof']
-                    traffic = per_pt * acc['units'] / acc_s / 1e9
-                    traffic_src = ('rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/%s (bytes per point from that pass x this run\'s '
-                                   'points; FETCH_SIZE x %.2f, the factor calibrated for 64-byte gathers)' % (cand, dkk.get('fetch_correction', 1.0)))
-                    break
-            except Exception:
-                continue
+        traffic, traffic_src, traffic_err = pmc_traffic(args, log_m, n, world, acc, acc_s, achieved)
         cal = ctx.calibrate()
         modmul = acc['adds'] * MODMUL_PER_G1_MIXED_ADD
         valu_peak = cal['mad_lane_ops_per_s'] / MUL_PIPE_OPS_PER_MODMUL
         merged = bool(pre_levels.get('h'))
         kname = '%s<Fq> (G1 bucket accumulation)' % ('msm_accumulate_merged_kernel' if merged else 'msm_accumulate_kernel')
+        fill = n / float(m)
         if args.workload == 'rollup1024':
             wl = ('%d rollup-style transactions (two depth-32 poseidon merkle proofs + one eddsa-poseidon signature each; a composition of the '
-                  'reference\'s gadgets, tests/golden/rollup_tx_instance.npz) as ONE R1CS through fk_setup_tiled / fk_r1cs_load_tiled, domain 2^%d '
-                  '(BASELINE configs[3] shape)' % (copies, log_m))
+                  'reference\'s gadgets, tests/golden/rollup_tx_instance.npz) as ONE R1CS through fk_setup_tiled / fk_r1cs_load_tiled: %d rows '
+                  '= %.2f %% of the 2^%d domain (BASELINE configs[3] shape; BASELINE.md config 4: rows = 2^25)' % (copies, n, 100.0 * fill, log_m))
         else:
             wl = 'synthetic satisfiable R1CS, 2^%d rows, 1-2 term rows%s' % (log_m, ' / %d-term product gates' % args.lc_terms if args.lc_terms > 1 else '')
         out = {
-            'metric': 'Groth16 proofs/sec (BN254, 2^%d constraints)' % log_m,
+            'metric': 'Groth16 proofs/sec + MSM scalar-muls/sec, BN254, 2^%d constraints (%d rows = %.2f %% of the 2^%d domain)' % (log_m, n, 100.0 * fill, log_m),
             'value': args.steps / elapsed,
             'unit': 'proofs/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -771,20 +919,25 @@ def main():
             'vs_baseline': None,
             'dtype': 'u32',
             'data': 'synthetic',
-            'config': {'workload': wl + '; per step: witness from pinned HOST memory (two-slot pipeline) -> device SpMV + quotient (6 NTTs) + G1 MSMs '
-                                      'H/L/A/B1 + G2 MSM B2 + assembly; constraint system and valid key resident in HBM',
-                       'log2_constraints': log_m, 'rows': n, 'num_input': num_input, 'num_aux': num_aux,
+            'config': {'workload': wl + '; per step: witness from pinned HOST memory (two-slot pipeline, two distinct witnesses alternating) -> device '
+                                      'SpMV + quotient (6 NTTs) + G1 MSMs H/L/A/B1 + G2 MSM B2 + assembly; constraint system and valid key resident in HBM',
+                       'log2_domain': log_m, 'rows': n, 'domain_fill': fill, 'num_input': num_input, 'num_aux': num_aux,
                        'nnz': list(info['nnz']), 'witness_bytes_per_proof': nv * 32,
                        'distinct_transactions': (len(zs) if copies is not None else None),
+                       'distinct_witnesses_in_the_pipeline': 2 if two_witnesses else 1,
                        'a_query_points': n_a, 'b_query_points': n_b,
+                       'msm_points': {'h': m - 1, 'l': num_aux, 'a': n_a, 'b_g1': n_b, 'b_g2': n_b},
                        'msm_fixed_base_levels': pre_levels,
                        'witness': '%.1f%% zeros, %.1f%% ones, rest dense 254-bit' % (100.0 * zeros / nv, 100.0 * ones / nv),
                        'parallelism': 'msm-shard%d%s' % (world, '' if not multi else
                                                          '+distributed-quotient (7 all-to-all per proof)' if dist_q else '+balanced-quotient')},
             'msm_scalar_muls_per_sec': msm_units / sec_per_step,
             'msm_scalar_muls_per_sec_counts': 'every (scalar, base) pair of the five multiplications, trivial scalars (0 and 1) included, divided by the '
-                                              'WHOLE proof time; the multiplications timed alone are under `standalone`',
+                                              'WHOLE proof time; the multiplications timed alone (min / median / max of >= 10 repetitions) are under `standalone`',
             'device_resident_ms_per_step': dev_ms,
+            'latency_ms_per_proof': None if multi else lat_ms,
+            'latency_ms_per_proof_is': 'ONE proof at a time from the witness in pinned host memory: upload (fk_prove_r1cs, nothing overlapped) + proof; '
+                                       '`ms_per_step` is the pipelined rate, `device_resident_ms_per_step` the same without the upload',
             'roofline': {
                 'bound': 'hbm', 'kernel': kname,
                 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
@@ -823,11 +976,14 @@ def main():
             },
             'prep_seconds': prep_s,
         }
+        if traffic_err:
+            out['roofline']['traffic_error'] = traffic_err
         if replica is not None:
             out['replica_proofs_per_sec'] = replica
             out['replica_proofs_per_sec_is'] = 'throughput mode: every GPU holds the whole key and proves its own witnesses (host-witness pipeline), no collective'
         if not args.no_cpu_baseline:
-            out['proof_verified_by_pairing_check'] = pairing_check(vk, z_inputs, proofs[-1])
+            out['proof_verified_by_pairing_check'] = bool(pairing_check(vk, z_inputs[0], want[0]) and
+                                                          (want[1] is None or pairing_check(vk, z_inputs[1], want[1])))
         if untiled is not None:
             out['untiled'] = untiled
         if standalone is not None:
@@ -835,7 +991,7 @@ def main():
         if single_proc is not None:
             out['single_process_multi_gpu'] = single_proc
         if not multi and not args.no_cpu_baseline:
-            full = (key, vk, z_pin[0], r, s, proofs[-1]) if copies is not None else None
+            full = (key, vk, z_pin[0], r, s, want[0]) if copies is not None else None
             cb = cpu_baseline_leg(ctx, fk, args, full=full)
             best = cb['best_threads']
             scaled = lambda th: (cb['synth_s'] + cb['prove_s'][th]) * cb['scale']
@@ -843,9 +999,9 @@ def main():
                 f_ = cb['full']
                 secs = f_['synth_s'] + f_['prove_s']
                 sample = ('MEASURED AT FULL SIZE: oracle/groth16_oracle.c (bellman\'s algorithm restated; %d threads = bellman\'s multicore split: parallel_fft + '
-                          'one task per multiexp region; synthesis serial as in the reference) on the benchmarked system itself -- %s, domain 2^%d: synthesis '
-                          '%.1f s + proof %.1f s; its 256 proof bytes equal the GPU\'s.  Thread count chosen on a 32-transaction sample (2^%d): %s'
-                          % (best, '%d rollup-style transactions as one R1CS' % args.copies, f_['log2_m'], f_['synth_s'], f_['prove_s'], cb['log2_m'],
+                          'one task per multiexp region; synthesis serial as in the reference) on the benchmarked system itself -- %s, %d rows, domain 2^%d: synthesis '
+                          '%.1f s + proof %.1f s; its 256 proof bytes equal the GPU\'s.  Thread count chosen on a %d-transaction sample (2^%d): %s'
+                          % (best, '%d rollup-style transactions as one R1CS' % args.copies, n, f_['log2_m'], f_['synth_s'], f_['prove_s'], args.cpu_copies, cb['log2_m'],
                              ', '.join('%d thr %.2f s' % (th, t) for th, t in sorted(cb['prove_s'].items()))))
             else:
                 secs = scaled(best)
@@ -860,9 +1016,29 @@ def main():
                                   'sample_seconds': cb['synth_s'] + cb['prove_s'][1],
                                   'note': 'the worker fawkes-crypto configures (SURVEY fact 3): the sample on one thread, scaled linearly by %g (extrapolated)' % cb['scale']},
             }
-        line = json.dumps(out)
-    else:
-        line = None
+
+    # ---- not `value`: the same prover at other transaction counts (N = 1): the 1024-transaction system of rounds 2-3, and a system of at
+    # least the reference's published size (35 695 616 constraints, README.md:54-56: 628 s on an i9-9900K) on the 2^26 domain
+    if rank == 0 and not multi and copies is not None and not args.no_other_sizes:
+        key.free(); key = None
+        dr.free(); dr = None
+        for zp in z_pin:
+            ctx.host_free(zp)
+        z_pin = []
+        for tag, cp in (('secondary_1024_transactions', args.secondary_copies), ('reference_published', args.reference_copies)):
+            if cp <= 0 or cp == copies:
+                continue
+            try:
+                leg = other_size_leg(ctx, r1cs, zs, cp, tox, r, s, max(3, min(args.steps, 6)), check=not args.no_cpu_baseline)
+            except Exception as e:     # noqa: BLE001 -- reported; the headline above stands
+                leg = {'error': '%s: %s' % (type(e).__name__, e)}
+            if tag == 'reference_published':
+                leg['reference'] = ('the reference\'s one published figure: rollup, 1024 txs, 35 695 616 constraints, 628 s on an i9-9900K '
+                                    '(/root/reference/README.md:54-56; thread count and bellman features not stated).  This leg: a rollup-STYLE system '
+                                    'of at least that many rows (the reference\'s own rollup circuit is not in its repository), same domain 2^26')
+                leg['reference_seconds_per_proof'] = 628.0
+            out[tag] = leg
+    line = json.dumps(out) if out is not None else None
 
     for zp in z_pin:
         ctx.host_free(zp)

@@ -28,7 +28,7 @@ EXPORTED_SYMBOLS = [
     'fk_dev_alloc', 'fk_dev_free', 'fk_upload', 'fk_download', 'fk_dev_copy', 'fk_sync', 'fk_stream',
     'fk_host_alloc', 'fk_host_free', 'fk_witness_upload_async', 'fk_witness_ptr', 'fk_prove_r1cs_submit', 'fk_prove_r1cs_wait',
     'fk_key_load', 'fk_key_synthetic', 'fk_key_shard_info', 'fk_key_host_vk', 'fk_key_free',
-    'fk_prove', 'fk_prove_dev', 'fk_prove_msms', 'fk_prove_msms_dev', 'fk_prove_msms_z_dev', 'fk_prove_msm_h_dev', 'fk_prove_msms_hz_dev',
+    'fk_prove', 'fk_prove_dev', 'fk_prove_msms', 'fk_prove_msms_dev', 'fk_prove_msms_z_dev', 'fk_prove_msm_h_dev', 'fk_prove_msm_array_dev', 'fk_prove_msms_hz_dev',
     'fk_prove_msms_z_begin_dev', 'fk_prove_msms_finish_dev', 'fk_prove_msms_hz_r1cs_dev', 'fk_prove_msms_z_begin_r1cs_dev',
     'fk_prove_assemble',
     'fk_fr_mul_batch', 'fk_ntt', 'fk_ntt_dev', 'fk_quotient_h', 'fk_quotient_h_dev',
@@ -354,7 +354,14 @@ class DeviceR1cs:
         if rc != 0:
             raise FkError(rc, 'fk_r1cs_info')
         v = list(out)
-        return dict(rows=v[0], nnz=(v[1], v[2], v[3]), distinct_coefficients=v[4], n_a=v[5], n_b=v[6])
+        return dict(rows=v[0], nnz=(v[1], v[2], v[3]), distinct_coefficients=v[4], n_a=v[5], n_b=v[6], num_vars=v[7])
+
+    def check_witness(self, z):
+        """the prove calls read (num_input + num_aux) * 32 bytes from the caller's witness: refuse a vector of another length HERE
+        (the C ABI cannot know the size of the buffer behind a pointer)"""
+        nv = self.info()['num_vars']
+        if z.size != nv * 4:
+            raise FkError(6, 'witness holds %d field elements, the constraint system has %d variables' % (z.size // 4, nv))
 
     def density_ptrs(self):
         """device pointers (a_aux, b_input, b_aux) of the structural density maps"""
@@ -546,6 +553,7 @@ class Context:
     def prove_witness_submit(self, key, dr, z, r, s):
         """fk_prove_r1cs_submit -> ticket.  z, r, s are kept referenced until prove_witness_wait(ticket)."""
         assert z.dtype == np.uint64 and z.flags['C_CONTIGUOUS']
+        dr.check_witness(z)
         r, s = _fr(r, 1), _fr(s, 1)
         t = C.c_int(-1)
         self._ck(self.lib.fk_prove_r1cs_submit(self.handle, key.handle, dr.handle, _vp(z), _vp(r), _vp(s), C.byref(t)))
@@ -733,6 +741,15 @@ class Context:
         self._ck(self.lib.fk_prove_msm_h_dev(self.handle, key.handle, C.c_void_p(d_h_slice), _vp(out)))
         return out
 
+    ARRAYS = {'h': 0, 'l': 1, 'a': 2, 'b_g1': 3, 'b_g2': 4}
+
+    def prove_msm_array_dev(self, key, which, d_scalars):
+        """fk_prove_msm_array_dev: ONE multiplication over the key's resident array `which` ('h', 'l', 'a', 'b_g1', 'b_g2'; with its
+        fixed-base levels when held), one scalar per point of the key's slice; raw affine result (64 B, 128 B for 'b_g2')"""
+        out = np.zeros(128 if which == 'b_g2' else 64, np.uint8)
+        self._ck(self.lib.fk_prove_msm_array_dev(self.handle, key.handle, C.c_int(self.ARRAYS[which]), C.c_void_p(d_scalars), _vp(out)))
+        return out
+
     def prove_dev(self, key, d_a, d_b, d_c, n, d_z, d_a_aux, d_b_in, d_b_aux, r, s, want_timings=False):
         out = np.zeros(FK_PROOF_BYTES, np.uint8)
         tm = Timings()
@@ -815,6 +832,7 @@ class Context:
     def prove_witness(self, key, dr, z, r, s, want_timings=False):
         """fk_prove_r1cs: z (host, (num_input+num_aux, 4) uint64 Montgomery) -> 256-byte proof."""
         z, r, s = _fr(z), _fr(r, 1), _fr(s, 1)
+        dr.check_witness(z)
         out = np.zeros(FK_PROOF_BYTES, np.uint8)
         tm = Timings()
         self._ck(self.lib.fk_prove_r1cs(self.handle, key.handle, dr.handle, _vp(z), _vp(r), _vp(s), _vp(out), C.byref(tm)))
@@ -995,6 +1013,7 @@ class MultiContext:
     def prove_witness(self, key, dr, z, r, s, want_timings=False):
         """fk_multi_prove_r1cs: z (host, (num_input + num_aux, 4) uint64 Montgomery) -> 256-byte proof, on all GPUs"""
         z, r, s = _fr(z), _fr(r, 1), _fr(s, 1)
+        self.r1cs_replica(dr, 0).check_witness(z)
         out = np.zeros(FK_PROOF_BYTES, np.uint8)
         tm = Timings()
         self._ck(self.lib.fk_multi_prove_r1cs(self.handle, key.handle, dr.handle, _vp(z), _vp(r), _vp(s), _vp(out), C.byref(tm)))
@@ -1002,6 +1021,7 @@ class MultiContext:
 
     def prove_witness_submit(self, key, dr, z, r, s):
         assert z.dtype == np.uint64 and z.flags['C_CONTIGUOUS']
+        self.r1cs_replica(dr, 0).check_witness(z)
         r, s = _fr(r, 1), _fr(s, 1)
         t = C.c_int(-1)
         self._ck(self.lib.fk_multi_prove_r1cs_submit(self.handle, key.handle, dr.handle, _vp(z), _vp(r), _vp(s), C.byref(t)))

@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void calib_mul_kernel(Fq *out, int iters) {
 
 using namespace fk;
 
-extern "C" int fk_calibrate(fk_ctx *ctx, double out[2]) {
+extern "C" int fk_calibrate(fk_ctx *ctx, double out[2]) { return fk_guard(ctx, [&]() -> int {
     if (!ctx || !out) return FK_ERR_BAD_ARG;
     FK_HIP(ctx, hipSetDevice(ctx->device));
     const unsigned blocks = 256 * 8, threads = 256;
@@ -64,4 +64,4 @@ extern "C" int fk_calibrate(fk_ctx *ctx, double out[2]) {
     out[0] = (double)n * it_mad * 64 / t_mad;         // v_mad_u64_u32 lane-operations per second
     out[1] = (double)n * it_mul * 4 / t_mul;          // Montgomery products per second, production multiplier in isolation
     return FK_OK;
-}
+}); }

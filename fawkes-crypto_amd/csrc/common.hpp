@@ -6,6 +6,8 @@
 #include <stdlib.h>
 #include <map>
 #include <string>
+#include <new>
+#include <stdexcept>
 #include <vector>
 #include <functional>
 #include "../../include/fawkes_hip.h"
@@ -179,6 +181,21 @@ struct fk_key {
     } while (0)
 
 #define FK_TRY(expr) do { int _rc = (expr); if (_rc != FK_OK) return _rc; } while (0)
+
+// Every extern "C" entry that can allocate on the host (std::vector / std::string / std::function behind almost all of them) runs
+// its body through this guard: a C++ exception must never leave an extern "C" function -- std::terminate would take the Rust or
+// ctypes host down, where the reference's `prove` at worst panics ("Errors": status codes, never aborts).  Out of host
+// memory is FK_ERR_OOM like out of device memory; anything else FK_ERR_HIP with what() as the message.  `c` is the fk_ctx / fk_multi
+// that carries the error string (may be null: code only).
+template <class C, class F>
+static inline int fk_guard(C *c, F &&body) noexcept {
+    auto note = [&](const char *msg) noexcept { if (c) { try { c->err = msg; } catch (...) {} } };
+    try { return body(); }
+    catch (const std::bad_alloc &) { note("out of host memory"); return FK_ERR_OOM; }
+    catch (const std::length_error &) { note("out of host memory (a container larger than this host can hold)"); return FK_ERR_OOM; }
+    catch (const std::exception &e) { note(e.what()); return FK_ERR_HIP; }
+    catch (...) { note("unknown C++ exception"); return FK_ERR_HIP; }
+}
 
 namespace fk {
 

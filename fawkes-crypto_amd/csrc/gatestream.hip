@@ -177,7 +177,7 @@ using namespace fk;
 
 extern "C" {
 
-int fk_gates_decode(fk_ctx *ctx, const uint8_t *blob, size_t len, int format, uint32_t num_gates, uint32_t num_input, uint32_t num_aux, fk_gates **out) {
+int fk_gates_decode(fk_ctx *ctx, const uint8_t *blob, size_t len, int format, uint32_t num_gates, uint32_t num_input, uint32_t num_aux, fk_gates **out) { return fk_guard(ctx, [&]() -> int {
     fk_ctx local;                  // host-only routine: usable without a GPU context
     if (!ctx) ctx = &local;
     // a tiny brotli blob can inflate to anything: running out of host memory is a status code, never an exception that leaves
@@ -185,7 +185,7 @@ int fk_gates_decode(fk_ctx *ctx, const uint8_t *blob, size_t len, int format, ui
     try { return gates_decode(ctx, blob, len, format, num_gates, num_input, num_aux, out); }
     catch (const std::bad_alloc &) { if (out) *out = nullptr; ctx->err = "gates: out of host memory while decoding the gate stream"; return FK_ERR_OOM; }
     catch (const std::length_error &) { if (out) *out = nullptr; ctx->err = "gates: the gate stream is larger than this host can hold"; return FK_ERR_OOM; }
-}
+}); }
 
 void fk_gates_free(fk_gates *g) { delete g; }
 

@@ -108,7 +108,7 @@ extern "C" {
 // buf/len: bellman `Parameters::write` bytes.  ic_out (may be NULL): receives up to ic_cap raw 64-byte points;
 // *n_ic gets the count; gamma_g2_out (may be NULL): 128 bytes raw.  shard arguments as in fk_key_desc.
 int fk_key_load_bellman(fk_ctx *ctx, const uint8_t *buf, size_t len, uint32_t flags, uint32_t shard_index, uint32_t shard_count, double z_frac_lo,
-                        double z_frac_hi, fk_key **out, uint8_t *gamma_g2_out, uint8_t *ic_out, uint32_t ic_cap, uint32_t *n_ic) {
+                        double z_frac_hi, fk_key **out, uint8_t *gamma_g2_out, uint8_t *ic_out, uint32_t ic_cap, uint32_t *n_ic) { return fk_guard(ctx, [&]() -> int {
     if (!ctx) return FK_ERR_BAD_ARG;
     if (!buf || !out) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "key file: null argument");
     if (flags & ~(uint32_t)(FK_KEY_CHECKED | FK_KEY_NO_INFINITY)) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "key file: unknown flags 0x%x", flags);
@@ -211,7 +211,7 @@ int fk_key_load_bellman(fk_ctx *ctx, const uint8_t *buf, size_t len, uint32_t fl
     if ((rc = key_precompute(ctx, k)) != FK_OK) { fk_key_free(ctx, k); return rc; }
     *out = k;
     return FK_OK;
-}
+}); }
 
 // vk points of a key as raw Montgomery LE: alpha_g1, beta_g1, delta_g1 (64 B each) then beta_g2, delta_g2 (128 B each)
 int fk_key_vk(const fk_key *key, uint8_t out[3 * 64 + 2 * 128]) {

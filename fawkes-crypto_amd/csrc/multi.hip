@@ -144,6 +144,9 @@ static void worker_main(fk_multi *M, int rank) {
 // loaders) and returns the first failure, with that rank's error text
 static int run_all(fk_multi *M, const std::function<int(int)> &fn, bool serial = false) {
     M->abort.store(0);
+    // a rank that is never started in this call (serial mode stops at the first failure) must not be read below with the code of
+    // an earlier call: only ranks that fail in THIS call carry a code other than FK_OK
+    for (int r = 0; r < M->n; r++) { std::lock_guard<std::mutex> lk(M->workers[r].mu); M->workers[r].rc = FK_OK; }
     { std::lock_guard<std::mutex> bl(M->bmu); M->bcount = 0; }
     auto start = [&](int r) {
         MultiWorker &w = M->workers[r];
@@ -297,8 +300,11 @@ static int prove_rank(fk_multi *M, int rank, const fk_multi_key *K, const fk_mul
             FK_HIP(ctx, hipStreamSynchronize(ctx->stream)); FK_HIP(ctx, hipStreamSynchronize(me.xs));
             FK_TRY(barrier(M, ctx));              // nobody may still be pulling from the buffers that are about to move
             for (int k = 0; k < 3; k++) { FK_HIP(ctx, me.send[k].reserve(L * sizeof(Fr))); FK_HIP(ctx, me.recv[k].reserve(L * sizeof(Fr))); }
-            me.buf_elems = L;
+            // the new size counts only once EVERY rank has its buffers: a rank whose reserve() failed leaves before this
+            // barrier, the others wake up in it with the abort -- nobody has recorded L, so the next call finds all ranks in this
+            // branch together again (a rank that had already noted L would skip it and wait for an exchange that never comes)
             FK_TRY(barrier(M, ctx));
+            me.buf_elems = L;
         }
         const bool ov = overlap_witness(M);
         if (ov) FK_TRY(fk_prove_msms_z_begin_r1cs_dev(ctx, key, rs, d_z));
@@ -332,6 +338,12 @@ static int prove_rank(fk_multi *M, int rank, const fk_multi_key *K, const fk_mul
 
 static int multi_check(fk_multi *M, const fk_multi_key *K, const fk_multi_r1cs *R) {
     if (!K || !R || (int)K->shard.size() != M->n || (int)R->rep.size() != M->n) { M->err = "prove: key / constraint system were not loaded through this fk_multi"; return FK_ERR_BAD_ARG; }
+    // before anything is read from the caller's witness buffer: its length is taken from the constraint system, so a system that
+    // does not belong to the key must be refused HERE, not after (num_input + num_aux) * 32 bytes of `z` have been uploaded
+    for (int g = 0; g < M->n; g++)
+        if (!K->shard[g] || !R->rep[g] || K->shard[g]->num_input != R->rep[g]->num_input || K->shard[g]->num_aux != R->rep[g]->num_aux) {
+            M->err = "prove: constraint system and key disagree on the variable counts"; return FK_ERR_KEY_MISMATCH;
+        }
     return FK_OK;
 }
 
@@ -436,7 +448,7 @@ static bool shares_device(const fk_multi *M) {
 }
 
 // ---------------------------------------------------------------- keys: shard g of N on rank g
-int fk_multi_key_load(fk_multi *M, const fk_key_desc *desc, fk_multi_key **out) {
+int fk_multi_key_load(fk_multi *M, const fk_key_desc *desc, fk_multi_key **out) { return fk_guard(M, [&]() -> int {
     if (!M || !out) return FK_ERR_BAD_ARG;
     *out = nullptr;
     if (!desc) { M->err = "key: null descriptor"; return FK_ERR_BAD_ARG; }
@@ -450,10 +462,10 @@ int fk_multi_key_load(fk_multi *M, const fk_key_desc *desc, fk_multi_key **out) 
     if (rc != FK_OK) { fk_multi_key_free(M, K); return rc; }
     *out = K;
     return FK_OK;
-}
+}); }
 
 int fk_multi_key_load_bellman(fk_multi *M, const uint8_t *buf, size_t len, uint32_t flags, fk_multi_key **out, uint8_t *gamma_g2_out,
-                              uint8_t *ic_out, uint32_t ic_cap, uint32_t *n_ic) {
+                              uint8_t *ic_out, uint32_t ic_cap, uint32_t *n_ic) { return fk_guard(M, [&]() -> int {
     if (!M || !out) return FK_ERR_BAD_ARG;
     *out = nullptr;
     fk_multi_key *K = new fk_multi_key();
@@ -468,7 +480,7 @@ int fk_multi_key_load_bellman(fk_multi *M, const uint8_t *buf, size_t len, uint3
     if (rc != FK_OK) { fk_multi_key_free(M, K); return rc; }
     *out = K;
     return FK_OK;
-}
+}); }
 
 static int multi_setup(fk_multi *M, const fk_r1cs *cs, uint32_t copies, const uint64_t tau[4], const uint64_t alpha[4], const uint64_t beta[4],
                        const uint64_t gamma[4], const uint64_t delta[4], fk_multi_key **out, uint8_t vk_out[6 * 128], uint8_t *ic_out) {
@@ -491,14 +503,14 @@ static int multi_setup(fk_multi *M, const fk_r1cs *cs, uint32_t copies, const ui
     return FK_OK;
 }
 int fk_multi_setup(fk_multi *M, const fk_r1cs *cs, const uint64_t tau[4], const uint64_t alpha[4], const uint64_t beta[4], const uint64_t gamma[4],
-                   const uint64_t delta[4], fk_multi_key **out, uint8_t vk_out[6 * 128], uint8_t *ic_out) {
+                   const uint64_t delta[4], fk_multi_key **out, uint8_t vk_out[6 * 128], uint8_t *ic_out) { return fk_guard(M, [&]() -> int {
     return multi_setup(M, cs, 0, tau, alpha, beta, gamma, delta, out, vk_out, ic_out);
-}
+}); }
 int fk_multi_setup_tiled(fk_multi *M, const fk_r1cs *instance, uint32_t copies, const uint64_t tau[4], const uint64_t alpha[4], const uint64_t beta[4],
-                         const uint64_t gamma[4], const uint64_t delta[4], fk_multi_key **out, uint8_t vk_out[6 * 128], uint8_t *ic_out) {
+                         const uint64_t gamma[4], const uint64_t delta[4], fk_multi_key **out, uint8_t vk_out[6 * 128], uint8_t *ic_out) { return fk_guard(M, [&]() -> int {
     if (M && !copies) { M->err = "setup: copies must be at least 1"; return FK_ERR_BAD_ARG; }
     return multi_setup(M, instance, copies, tau, alpha, beta, gamma, delta, out, vk_out, ic_out);
-}
+}); }
 
 void fk_multi_key_free(fk_multi *M, fk_multi_key *K) {
     if (!K) return;
@@ -518,15 +530,15 @@ static int multi_r1cs(fk_multi *M, fk_multi_r1cs **out, const std::function<int(
     *out = R;
     return FK_OK;
 }
-int fk_multi_r1cs_load(fk_multi *M, const fk_r1cs *cs, fk_multi_r1cs **out) {
+int fk_multi_r1cs_load(fk_multi *M, const fk_r1cs *cs, fk_multi_r1cs **out) { return fk_guard(M, [&]() -> int {
     return multi_r1cs(M, out, [&](int r, fk_r1cs_dev **o) { return fk_r1cs_load(M->ctx[r], cs, o); });
-}
-int fk_multi_r1cs_load_tiled(fk_multi *M, const fk_r1cs *instance, uint32_t copies, fk_multi_r1cs **out) {
+}); }
+int fk_multi_r1cs_load_tiled(fk_multi *M, const fk_r1cs *instance, uint32_t copies, fk_multi_r1cs **out) { return fk_guard(M, [&]() -> int {
     return multi_r1cs(M, out, [&](int r, fk_r1cs_dev **o) { return fk_r1cs_load_tiled(M->ctx[r], instance, copies, o); });
-}
-int fk_multi_r1cs_load_gates(fk_multi *M, const fk_gates *gates, fk_multi_r1cs **out) {
+}); }
+int fk_multi_r1cs_load_gates(fk_multi *M, const fk_gates *gates, fk_multi_r1cs **out) { return fk_guard(M, [&]() -> int {
     return multi_r1cs(M, out, [&](int r, fk_r1cs_dev **o) { return fk_r1cs_load_gates(M->ctx[r], gates, o); });
-}
+}); }
 void fk_multi_r1cs_free(fk_multi *M, fk_multi_r1cs *R) {
     if (!R) return;
     for (size_t r = 0; r < R->rep.size(); r++) if (R->rep[r]) fk_r1cs_free(M && r < M->ctx.size() ? M->ctx[r] : nullptr, R->rep[r]);
@@ -563,7 +575,7 @@ static int multi_prove_slot(fk_multi *M, const fk_multi_key *K, const fk_multi_r
 }
 
 int fk_multi_prove_r1cs(fk_multi *M, const fk_multi_key *K, const fk_multi_r1cs *R, const uint64_t *z, const uint64_t r_[4], const uint64_t s_[4],
-                        uint8_t out[FK_PROOF_BYTES], fk_timings *tm) {
+                        uint8_t out[FK_PROOF_BYTES], fk_timings *tm) { return fk_guard(M, [&]() -> int {
     if (!M) return FK_ERR_BAD_ARG;
     if (!z || !r_ || !s_ || !out) { M->err = "prove: null argument"; return FK_ERR_BAD_ARG; }
     if (M->pending[0].active || M->pending[1].active) { M->err = "prove: submitted proofs are outstanding (call fk_multi_prove_r1cs_wait first)"; return FK_ERR_BAD_ARG; }
@@ -571,9 +583,9 @@ int fk_multi_prove_r1cs(fk_multi *M, const fk_multi_key *K, const fk_multi_r1cs 
     const size_t zb = ((size_t)R->rep[0]->num_input + R->rep[0]->num_aux) * sizeof(Fr);
     FK_TRY(multi_upload(M, 0, z, zb));
     return multi_prove_slot(M, K, R, 0, r_, s_, out, tm);
-}
+}); }
 
-int fk_multi_prove_r1cs_submit(fk_multi *M, const fk_multi_key *K, const fk_multi_r1cs *R, const uint64_t *z, const uint64_t r_[4], const uint64_t s_[4], int *ticket) {
+int fk_multi_prove_r1cs_submit(fk_multi *M, const fk_multi_key *K, const fk_multi_r1cs *R, const uint64_t *z, const uint64_t r_[4], const uint64_t s_[4], int *ticket) { return fk_guard(M, [&]() -> int {
     if (!M) return FK_ERR_BAD_ARG;
     if (!z || !r_ || !s_ || !ticket) { M->err = "prove: null argument"; return FK_ERR_BAD_ARG; }
     FK_TRY(multi_check(M, K, R));
@@ -586,18 +598,18 @@ int fk_multi_prove_r1cs_submit(fk_multi *M, const fk_multi_key *K, const fk_mult
     M->ticket_next = slot ^ 1;
     *ticket = slot;
     return FK_OK;
-}
+}); }
 
-int fk_multi_prove_r1cs_wait(fk_multi *M, int ticket, uint8_t out[FK_PROOF_BYTES], fk_timings *tm) {
+int fk_multi_prove_r1cs_wait(fk_multi *M, int ticket, uint8_t out[FK_PROOF_BYTES], fk_timings *tm) { return fk_guard(M, [&]() -> int {
     if (!M) return FK_ERR_BAD_ARG;
     if (ticket < 0 || ticket > 1 || !M->pending[ticket].active || !out) { M->err = "prove: no submitted proof with this ticket"; return FK_ERR_BAD_ARG; }
     fk_multi::Pending &p = M->pending[ticket];
     p.active = false;
     return multi_prove_slot(M, p.key, p.r1cs, ticket, p.r, p.s, out, tm);
-}
+}); }
 
 // waits for everything queued on every rank
-int fk_multi_sync(fk_multi *M) {
+int fk_multi_sync(fk_multi *M) { return fk_guard(M, [&]() -> int {
     if (!M) return FK_ERR_BAD_ARG;
     for (int r = 0; r < M->n; r++) {
         const int rc = fk_sync(M->ctx[r]);
@@ -605,6 +617,6 @@ int fk_multi_sync(fk_multi *M) {
         (void)hipStreamSynchronize(M->ranks[r].xs);
     }
     return FK_OK;
-}
+}); }
 
 }  // extern "C"

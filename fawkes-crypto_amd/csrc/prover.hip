@@ -95,70 +95,70 @@ void fk_free(fk_ctx *ctx) {
 
 const char *fk_last_error(const fk_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
-int fk_set_window_bits(fk_ctx *ctx, unsigned c) {
+int fk_set_window_bits(fk_ctx *ctx, unsigned c) { return fk_guard(ctx, [&]() -> int {
     if (!ctx) return FK_ERR_BAD_ARG;
     if (c != 0 && (c < 2 || c > 22)) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "window bits must be 0 or 2..22");
     ctx->window_bits = c;
     return FK_OK;
-}
+}); }
 
 // ------------------------------------------------------------------------------------------ device buffers
-int fk_dev_alloc(fk_ctx *ctx, size_t bytes, void **dptr) {
+int fk_dev_alloc(fk_ctx *ctx, size_t bytes, void **dptr) { return fk_guard(ctx, [&]() -> int {
     if (!ctx || !dptr) return FK_ERR_BAD_ARG;
     FK_HIP(ctx, hipSetDevice(ctx->device));
     FK_HIP(ctx, hipMalloc(dptr, bytes ? bytes : 16));
     return FK_OK;
-}
-int fk_dev_free(fk_ctx *ctx, void *dptr) {
+}); }
+int fk_dev_free(fk_ctx *ctx, void *dptr) { return fk_guard(ctx, [&]() -> int {
     if (!ctx) return FK_ERR_BAD_ARG;
     if (dptr) FK_HIP(ctx, hipFree(dptr));
     return FK_OK;
-}
-int fk_upload(fk_ctx *ctx, void *dptr, const void *host, size_t bytes) {
+}); }
+int fk_upload(fk_ctx *ctx, void *dptr, const void *host, size_t bytes) { return fk_guard(ctx, [&]() -> int {
     if (!ctx) return FK_ERR_BAD_ARG;
     if (bytes) FK_HIP(ctx, hipMemcpyAsync(dptr, host, bytes, hipMemcpyHostToDevice, ctx->stream));
     FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return FK_OK;
-}
-int fk_download(fk_ctx *ctx, void *host, const void *dptr, size_t bytes) {
+}); }
+int fk_download(fk_ctx *ctx, void *host, const void *dptr, size_t bytes) { return fk_guard(ctx, [&]() -> int {
     if (!ctx) return FK_ERR_BAD_ARG;
     if (bytes) FK_HIP(ctx, hipMemcpyAsync(host, dptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
     FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return FK_OK;
-}
-int fk_dev_copy(fk_ctx *ctx, void *dst, const void *src, size_t bytes) {
+}); }
+int fk_dev_copy(fk_ctx *ctx, void *dst, const void *src, size_t bytes) { return fk_guard(ctx, [&]() -> int {
     if (!ctx) return FK_ERR_BAD_ARG;
     if (bytes) FK_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     return FK_OK;
-}
+}); }
 // the HIP stream the library queues its main-path work on (quotient, SpMV, fk_dq_*): lets a host that owns other streams
 // (RCCL collectives issued by torch.distributed) order against it with events instead of host-side synchronisation
-int fk_stream(fk_ctx *ctx, void **out) {
+int fk_stream(fk_ctx *ctx, void **out) { return fk_guard(ctx, [&]() -> int {
     if (!ctx || !out) return FK_ERR_BAD_ARG;
     *out = (void *)ctx->stream;
     return FK_OK;
-}
-int fk_sync(fk_ctx *ctx) {
+}); }
+int fk_sync(fk_ctx *ctx) { return fk_guard(ctx, [&]() -> int {
     if (!ctx) return FK_ERR_BAD_ARG;
     FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return msm_sync(ctx);
-}
+}); }
 
 // ------------------------------------------------------------------------------------------ witness hand-over
 // prover.rs:69-76 produces the witness on the host for every proof.  Pinned buffers + two device slots filled on a copy
 // stream let the (num_input + num_aux) * 32-byte upload of proof k+1 run underneath proof k.
-int fk_host_alloc(fk_ctx *ctx, size_t bytes, void **hptr) {
+int fk_host_alloc(fk_ctx *ctx, size_t bytes, void **hptr) { return fk_guard(ctx, [&]() -> int {
     if (!ctx || !hptr) return FK_ERR_BAD_ARG;
     FK_HIP(ctx, hipSetDevice(ctx->device));
     FK_HIP(ctx, hipHostMalloc(hptr, bytes ? bytes : 16, hipHostMallocDefault));
     return FK_OK;
-}
-int fk_host_free(fk_ctx *ctx, void *hptr) {
+}); }
+int fk_host_free(fk_ctx *ctx, void *hptr) { return fk_guard(ctx, [&]() -> int {
     if (!ctx) return FK_ERR_BAD_ARG;
     if (hptr) FK_HIP(ctx, hipHostFree(hptr));
     return FK_OK;
-}
-int fk_witness_upload_async(fk_ctx *ctx, int slot, const void *z_host, size_t bytes) {
+}); }
+int fk_witness_upload_async(fk_ctx *ctx, int slot, const void *z_host, size_t bytes) { return fk_guard(ctx, [&]() -> int {
     if (!ctx) return FK_ERR_BAD_ARG;
     if (slot < 0 || slot > 1 || (bytes && !z_host)) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "witness upload: slot must be 0 or 1, buffer non-null");
     FK_HIP(ctx, hipSetDevice(ctx->device));
@@ -174,15 +174,15 @@ int fk_witness_upload_async(fk_ctx *ctx, int slot, const void *z_host, size_t by
     if (bytes) FK_HIP(ctx, hipMemcpyAsync(w.buf.p, z_host, bytes, hipMemcpyHostToDevice, ctx->copy_st));
     FK_HIP(ctx, hipEventRecord(w.ready, ctx->copy_st));
     return FK_OK;
-}
-int fk_witness_ptr(fk_ctx *ctx, int slot, void **dptr) {
+}); }
+int fk_witness_ptr(fk_ctx *ctx, int slot, void **dptr) { return fk_guard(ctx, [&]() -> int {
     if (!ctx || !dptr) return FK_ERR_BAD_ARG;
     if (slot < 0 || slot > 1 || !ctx->wslot[slot].ready) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "witness slot %d holds nothing", slot);
     FK_HIP(ctx, hipSetDevice(ctx->device));
     FK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->wslot[slot].ready, 0));      // stream-ordered: the host does not wait
     *dptr = ctx->wslot[slot].buf.p;
     return FK_OK;
-}
+}); }
 
 }  // extern "C"
 namespace fk {
@@ -236,7 +236,7 @@ static int key_check_shape(fk_ctx *ctx, uint64_t m, uint32_t num_input, uint64_t
     if (shard_count == 0 || shard_index >= shard_count) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "key: bad shard %u/%u", shard_index, shard_count);
     return FK_OK;
 }
-int fk_key_load(fk_ctx *ctx, const fk_key_desc *d, fk_key **out) {
+int fk_key_load(fk_ctx *ctx, const fk_key_desc *d, fk_key **out) { return fk_guard(ctx, [&]() -> int {
     if (!ctx || !d || !out) return FK_ERR_BAD_ARG;
     *out = nullptr;
     FK_HIP(ctx, hipSetDevice(ctx->device));
@@ -264,7 +264,7 @@ int fk_key_load(fk_ctx *ctx, const fk_key_desc *d, fk_key **out) {
     if (rc != FK_OK) { fk_key_free(ctx, k); return rc; }
     *out = k;
     return FK_OK;
-}
+}); }
 
 int fk_key_host_vk(const uint8_t *alpha_g1, const uint8_t *beta_g1, const uint8_t *delta_g1, const uint8_t *beta_g2,
                    const uint8_t *delta_g2, fk_key **out) {
@@ -291,7 +291,7 @@ int fk_key_shard_info(const fk_key *k, uint64_t out[8]) {
 }
 
 int fk_key_synthetic(fk_ctx *ctx, uint64_t m, uint32_t num_input, uint32_t num_aux, uint64_t n_a, uint64_t n_b,
-                     uint64_t seed, uint32_t shard_index, uint32_t shard_count, double z_frac_lo, double z_frac_hi, fk_key **out) {
+                     uint64_t seed, uint32_t shard_index, uint32_t shard_count, double z_frac_lo, double z_frac_hi, fk_key **out) { return fk_guard(ctx, [&]() -> int {
     if (!ctx || !out) return FK_ERR_BAD_ARG;
     *out = nullptr;
     FK_HIP(ctx, hipSetDevice(ctx->device));
@@ -325,7 +325,7 @@ int fk_key_synthetic(fk_ctx *ctx, uint64_t m, uint32_t num_input, uint32_t num_a
     if (rc != FK_OK) { fk_key_free(ctx, k); return rc; }
     *out = k;
     return FK_OK;
-}
+}); }
 
 // ------------------------------------------------------------------------------------------ prover
 // L, A, B1, B2 over this key's slices depend on the assignment only, not on the quotient: `witness_begin` queues them on
@@ -579,13 +579,13 @@ static int prove_msms_dev(fk_ctx *ctx, const fk_key *key, Fr *d_a, Fr *d_b, Fr *
 }
 
 int fk_prove_msms_z_dev(fk_ctx *ctx, const fk_key *key, const void *d_z, const void *d_a_aux, const void *d_b_in,
-                        const void *d_b_aux, uint8_t out[FK_MSM_RESULT_BYTES], fk_timings *tm) {
+                        const void *d_b_aux, uint8_t out[FK_MSM_RESULT_BYTES], fk_timings *tm) { return fk_guard(ctx, [&]() -> int {
     if (!ctx) return FK_ERR_BAD_ARG;
     if (tm) memset(tm, 0, sizeof *tm);
     return prove_msms_z(ctx, key, (const Fr *)d_z, (const uint8_t *)d_a_aux, (const uint8_t *)d_b_in, (const uint8_t *)d_b_aux, out, tm);
-}
+}); }
 
-int fk_prove_msm_h_dev(fk_ctx *ctx, const fk_key *key, const void *d_h_slice, uint8_t out[FK_G1_BYTES]) {
+int fk_prove_msm_h_dev(fk_ctx *ctx, const fk_key *key, const void *d_h_slice, uint8_t out[FK_G1_BYTES]) { return fk_guard(ctx, [&]() -> int {
     if (!ctx) return FK_ERR_BAD_ARG;
     if (!key || !out || (!d_h_slice && key->h_hi > key->h_lo)) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "prove: null argument");
     FK_HIP(ctx, hipSetDevice(ctx->device));
@@ -593,17 +593,38 @@ int fk_prove_msm_h_dev(fk_ctx *ctx, const fk_key *key, const void *d_h_slice, ui
     FK_TRY(msm_g1_dev(ctx, key->d_h, (const Fr *)d_h_slice, key->h_hi - key->h_lo, &H, &key->pre_h));
     g1_to_raw(out, H);
     return FK_OK;
-}
+}); }
 
-int fk_prove_msms_z_begin_dev(fk_ctx *ctx, const fk_key *key, const void *d_z, const void *d_a_aux, const void *d_b_in, const void *d_b_aux) {
+int fk_prove_msm_array_dev(fk_ctx *ctx, const fk_key *key, int which, const void *d_scalars, uint8_t *out) { return fk_guard(ctx, [&]() -> int {
+    if (!ctx) return FK_ERR_BAD_ARG;
+    if (!key || !out || which < FK_ARRAY_H || which > FK_ARRAY_B_G2) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "msm over a key array: null argument or unknown array");
+    FK_HIP(ctx, hipSetDevice(ctx->device));
+    const uint64_t n = which == FK_ARRAY_H ? key->h_hi - key->h_lo : which == FK_ARRAY_L ? key->l_hi - key->l_lo
+                     : which == FK_ARRAY_A ? key->a_hi - key->a_lo : key->b_hi - key->b_lo;
+    if (!d_scalars && n) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "msm over a key array: null scalars");
+    if (which == FK_ARRAY_B_G2) {
+        G2Xyzz R;
+        FK_TRY(msm_g2_dev(ctx, key->d_b2, (const Fr *)d_scalars, n, &R, false, &key->pre_b2));
+        g2_to_raw(out, R);
+        return FK_OK;
+    }
+    const G1Affine *bases = which == FK_ARRAY_H ? key->d_h : which == FK_ARRAY_L ? key->d_l : which == FK_ARRAY_A ? key->d_a : key->d_b1;
+    const KeyPre *pre = which == FK_ARRAY_H ? &key->pre_h : which == FK_ARRAY_L ? &key->pre_l : which == FK_ARRAY_A ? &key->pre_a : &key->pre_b1;
+    G1Xyzz R;
+    FK_TRY(msm_g1_dev(ctx, bases, (const Fr *)d_scalars, n, &R, pre));
+    g1_to_raw(out, R);
+    return FK_OK;
+}); }
+
+int fk_prove_msms_z_begin_dev(fk_ctx *ctx, const fk_key *key, const void *d_z, const void *d_a_aux, const void *d_b_in, const void *d_b_aux) { return fk_guard(ctx, [&]() -> int {
     if (!ctx) return FK_ERR_BAD_ARG;
     FK_HIP(ctx, hipSetDevice(ctx->device));
     if (!ctx->ev_main) FK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_main, hipEventDisableTiming));
     FK_HIP(ctx, hipEventRecord(ctx->ev_main, ctx->stream));
     return witness_begin(ctx, key, (const Fr *)d_z, (const uint8_t *)d_a_aux, (const uint8_t *)d_b_in, (const uint8_t *)d_b_aux, ctx->ev_main);
-}
+}); }
 
-int fk_prove_msms_finish_dev(fk_ctx *ctx, const fk_key *key, const void *d_h_slice, uint8_t out[FK_MSM_RESULT_BYTES]) {
+int fk_prove_msms_finish_dev(fk_ctx *ctx, const fk_key *key, const void *d_h_slice, uint8_t out[FK_MSM_RESULT_BYTES]) { return fk_guard(ctx, [&]() -> int {
     if (!ctx) return FK_ERR_BAD_ARG;
     if (!key || !out || (!d_h_slice && key->h_hi > key->h_lo)) { msm_abandon(ctx); FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "prove: null argument"); }
     FK_HIP(ctx, hipSetDevice(ctx->device));
@@ -611,28 +632,28 @@ int fk_prove_msms_finish_dev(fk_ctx *ctx, const fk_key *key, const void *d_h_sli
     const int rc = msm_g1_begin(ctx, key->d_h, (const Fr *)d_h_slice, key->h_hi - key->h_lo, &t_h, nullptr, &key->pre_h);
     if (rc != FK_OK) { msm_abandon(ctx); return rc; }
     return witness_end(ctx, out, t_h);
-}
+}); }
 
 int fk_prove_msms_hz_dev(fk_ctx *ctx, const fk_key *key, const void *d_h_slice, const void *d_z, const void *d_a_aux, const void *d_b_in,
-                         const void *d_b_aux, uint8_t out[FK_MSM_RESULT_BYTES], fk_timings *tm) {
+                         const void *d_b_aux, uint8_t out[FK_MSM_RESULT_BYTES], fk_timings *tm) { return fk_guard(ctx, [&]() -> int {
     if (!ctx) return FK_ERR_BAD_ARG;
     if (tm) memset(tm, 0, sizeof *tm);
     FK_TRY(fk_prove_msms_z_begin_dev(ctx, key, d_z, d_a_aux, d_b_in, d_b_aux));
     return fk_prove_msms_finish_dev(ctx, key, d_h_slice, out);
-}
+}); }
 
 int fk_prove_msms_dev(fk_ctx *ctx, const fk_key *key, void *d_a, void *d_b, void *d_c, uint64_t n, const void *d_z,
-                      const void *d_a_aux, const void *d_b_in, const void *d_b_aux, uint8_t out[FK_MSM_RESULT_BYTES], fk_timings *tm) {
+                      const void *d_a_aux, const void *d_b_in, const void *d_b_aux, uint8_t out[FK_MSM_RESULT_BYTES], fk_timings *tm) { return fk_guard(ctx, [&]() -> int {
     if (!ctx) return FK_ERR_BAD_ARG;
     if (tm) memset(tm, 0, sizeof *tm);
     return prove_msms_dev(ctx, key, (Fr *)d_a, (Fr *)d_b, (Fr *)d_c, n, (const Fr *)d_z, (const uint8_t *)d_a_aux,
                           (const uint8_t *)d_b_in, (const uint8_t *)d_b_aux, out, tm);
-}
+}); }
 
 // A = alpha + A_q + r*delta1 ; B = beta2 + B2 + s*delta2 ;
 // C = H + L + s*A_q + r*B1 + s*alpha + r*beta1 + (r s)*delta1   
 int fk_prove_assemble(fk_ctx *ctx, const fk_key *key, const uint8_t *parts, uint32_t n_parts, const uint64_t r_[4],
-                      const uint64_t s_[4], uint8_t out[FK_PROOF_BYTES]) {
+                      const uint64_t s_[4], uint8_t out[FK_PROOF_BYTES]) { return fk_guard(ctx, [&]() -> int {
     fk_ctx local;                  // host-only routine: usable without a GPU context
     if (!ctx) ctx = &local;
     if (!key || !parts || !n_parts || !r_ || !s_ || !out) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "assemble: null argument");
@@ -663,11 +684,11 @@ int fk_prove_assemble(fk_ctx *ctx, const fk_key *key, const uint8_t *parts, uint
                          Fq::from_mont(pb.y.c0), Fq::from_mont(pb.y.c1), Fq::from_mont(pc.x), Fq::from_mont(pc.y)};
     memcpy(out, words, 256);
     return FK_OK;
-}
+}); }
 
 int fk_prove_dev(fk_ctx *ctx, const fk_key *key, void *d_a, void *d_b, void *d_c, uint64_t n, const void *d_z,
                  const void *d_a_aux, const void *d_b_in, const void *d_b_aux, const uint64_t r[4], const uint64_t s[4],
-                 uint8_t out[FK_PROOF_BYTES], fk_timings *tm) {
+                 uint8_t out[FK_PROOF_BYTES], fk_timings *tm) { return fk_guard(ctx, [&]() -> int {
     if (!ctx) return FK_ERR_BAD_ARG;
     if (key && key->shard_count != 1) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "fk_prove needs an unsharded key (use fk_prove_msms + fk_prove_assemble)");
     uint8_t msms[FK_MSM_RESULT_BYTES];
@@ -676,7 +697,7 @@ int fk_prove_dev(fk_ctx *ctx, const fk_key *key, void *d_a, void *d_b, void *d_c
     FK_TRY(fk_prove_assemble(ctx, key, msms, 1, r, s, out));
     if (tm) { tm->assemble_ms = now_ms() - t0; tm->total_ms += tm->assemble_ms; }
     return FK_OK;
-}
+}); }
 
 static int stage_inputs(fk_ctx *ctx, const fk_key *key, const uint64_t *a, const uint64_t *b, const uint64_t *c, uint64_t n,
                         const uint64_t *z, const uint8_t *a_aux, const uint8_t *b_in, const uint8_t *b_aux) {
@@ -702,7 +723,7 @@ static int stage_inputs(fk_ctx *ctx, const fk_key *key, const uint64_t *a, const
 
 int fk_prove_msms(fk_ctx *ctx, const fk_key *key, const uint64_t *a, const uint64_t *b, const uint64_t *c, uint64_t n,
                   const uint64_t *z, const uint8_t *a_aux, const uint8_t *b_in, const uint8_t *b_aux,
-                  uint8_t out[FK_MSM_RESULT_BYTES], fk_timings *tm) {
+                  uint8_t out[FK_MSM_RESULT_BYTES], fk_timings *tm) { return fk_guard(ctx, [&]() -> int {
     if (!ctx) return FK_ERR_BAD_ARG;
     const double t0 = now_ms();
     FK_TRY(stage_inputs(ctx, key, a, b, c, n, z, a_aux, b_in, b_aux));
@@ -712,11 +733,11 @@ int fk_prove_msms(fk_ctx *ctx, const fk_key *key, const uint64_t *a, const uint6
                              dd + key->num_aux + key->num_input, out, tm));
     if (tm) { tm->upload_ms = up; tm->total_ms += up; }
     return FK_OK;
-}
+}); }
 
 int fk_prove(fk_ctx *ctx, const fk_key *key, const uint64_t *a, const uint64_t *b, const uint64_t *c, uint64_t n,
              const uint64_t *z, const uint8_t *a_aux, const uint8_t *b_in, const uint8_t *b_aux, const uint64_t r[4],
-             const uint64_t s[4], uint8_t out[FK_PROOF_BYTES], fk_timings *tm) {
+             const uint64_t s[4], uint8_t out[FK_PROOF_BYTES], fk_timings *tm) { return fk_guard(ctx, [&]() -> int {
     if (!ctx) return FK_ERR_BAD_ARG;
     if (key && key->shard_count != 1) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "fk_prove needs an unsharded key (use fk_prove_msms + fk_prove_assemble)");
     if (!r || !s || !out) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "prove: null argument");
@@ -726,10 +747,10 @@ int fk_prove(fk_ctx *ctx, const fk_key *key, const uint64_t *a, const uint64_t *
     FK_TRY(fk_prove_assemble(ctx, key, msms, 1, r, s, out));
     if (tm) { tm->assemble_ms = now_ms() - t0; tm->total_ms += tm->assemble_ms; }
     return FK_OK;
-}
+}); }
 
 // ------------------------------------------------------------------------------------------ building blocks
-int fk_fr_mul_batch(fk_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n) {
+int fk_fr_mul_batch(fk_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n) { return fk_guard(ctx, [&]() -> int {
     if (!ctx) return FK_ERR_BAD_ARG;
     if (n && (!a || !b || !out)) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "null argument");
     if (!n) return FK_OK;
@@ -742,16 +763,16 @@ int fk_fr_mul_batch(fk_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t 
     FK_HIP(ctx, hipMemcpyAsync(out, ctx->stage_a.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
     FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return FK_OK;
-}
+}); }
 
-int fk_ntt_dev(fk_ctx *ctx, void *d_data, uint32_t log_n, int inverse, int coset) {
+int fk_ntt_dev(fk_ctx *ctx, void *d_data, uint32_t log_n, int inverse, int coset) { return fk_guard(ctx, [&]() -> int {
     if (!ctx) return FK_ERR_BAD_ARG;
     if (!d_data) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "null argument");
     FK_HIP(ctx, hipSetDevice(ctx->device));
     return ntt_exec_simple(ctx, (Fr *)d_data, log_n, inverse != 0, coset != 0);
-}
+}); }
 
-int fk_ntt(fk_ctx *ctx, uint64_t *data, uint32_t log_n, int inverse, int coset) {
+int fk_ntt(fk_ctx *ctx, uint64_t *data, uint32_t log_n, int inverse, int coset) { return fk_guard(ctx, [&]() -> int {
     if (!ctx) return FK_ERR_BAD_ARG;
     if (!data) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "null argument");
     if (log_n >= FK_FR_S) FK_SET_ERR(ctx, FK_ERR_DOMAIN_TOO_LARGE, "evaluation domain 2^%u too large (max 2^%d)", log_n, FK_FR_S - 1);
@@ -763,47 +784,47 @@ int fk_ntt(fk_ctx *ctx, uint64_t *data, uint32_t log_n, int inverse, int coset) 
     FK_HIP(ctx, hipMemcpyAsync(data, ctx->ntt_io.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
     FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return FK_OK;
-}
+}); }
 
-int fk_quotient_h_dev(fk_ctx *ctx, void *d_a, void *d_b, void *d_c, uint64_t n, void *d_h_out) {
+int fk_quotient_h_dev(fk_ctx *ctx, void *d_a, void *d_b, void *d_c, uint64_t n, void *d_h_out) { return fk_guard(ctx, [&]() -> int {
     if (!ctx) return FK_ERR_BAD_ARG;
     if (!d_a || !d_b || !d_c || !d_h_out) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "null argument");
     FK_HIP(ctx, hipSetDevice(ctx->device));
     return quotient_dev(ctx, (Fr *)d_a, (Fr *)d_b, (Fr *)d_c, n, (Fr *)d_h_out, nullptr);
-}
+}); }
 
-int fk_dq_gather_dev(fk_ctx *ctx, const void *d_full, uint64_t n, uint32_t log_m, uint32_t rank, uint32_t log_w, void *d_local) {
+int fk_dq_gather_dev(fk_ctx *ctx, const void *d_full, uint64_t n, uint32_t log_m, uint32_t rank, uint32_t log_w, void *d_local) { return fk_guard(ctx, [&]() -> int {
     if (!ctx) return FK_ERR_BAD_ARG;
     if (!d_full || !d_local) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "null argument");
     FK_HIP(ctx, hipSetDevice(ctx->device));
     return dq_gather(ctx, (const Fr *)d_full, n, log_m, rank, log_w, (Fr *)d_local);
-}
+}); }
 
-int fk_dq_local_dev(fk_ctx *ctx, void *d_x, const void *d_xb, const void *d_xc, uint32_t log_m, uint32_t rank, uint32_t log_w, int stage) {
+int fk_dq_local_dev(fk_ctx *ctx, void *d_x, const void *d_xb, const void *d_xc, uint32_t log_m, uint32_t rank, uint32_t log_w, int stage) { return fk_guard(ctx, [&]() -> int {
     if (!ctx) return FK_ERR_BAD_ARG;
     if (!d_x) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "null argument");
     if (log_m >= FK_FR_S) FK_SET_ERR(ctx, FK_ERR_DOMAIN_TOO_LARGE, "evaluation domain 2^%u too large (max 2^%d)", log_m, FK_FR_S - 1);
     FK_HIP(ctx, hipSetDevice(ctx->device));
     return dq_local(ctx, (Fr *)d_x, (const Fr *)d_xb, (const Fr *)d_xc, log_m, rank, log_w, stage);
-}
+}); }
 
-int fk_dq_cross_dev(fk_ctx *ctx, void *d_buf, uint32_t log_m, uint32_t rank, uint32_t log_w, int mode) {
+int fk_dq_cross_dev(fk_ctx *ctx, void *d_buf, uint32_t log_m, uint32_t rank, uint32_t log_w, int mode) { return fk_guard(ctx, [&]() -> int {
     if (!ctx) return FK_ERR_BAD_ARG;
     if (!d_buf) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "null argument");
     if (log_m >= FK_FR_S) FK_SET_ERR(ctx, FK_ERR_DOMAIN_TOO_LARGE, "evaluation domain 2^%u too large (max 2^%d)", log_m, FK_FR_S - 1);
     FK_HIP(ctx, hipSetDevice(ctx->device));
     return dq_cross(ctx, (Fr *)d_buf, log_m, rank, log_w, mode);
-}
+}); }
 
-int fk_dq_cross_sub_dev(fk_ctx *ctx, void *d_buf, const void *d_sub, uint32_t log_m, uint32_t rank, uint32_t log_w) {
+int fk_dq_cross_sub_dev(fk_ctx *ctx, void *d_buf, const void *d_sub, uint32_t log_m, uint32_t rank, uint32_t log_w) { return fk_guard(ctx, [&]() -> int {
     if (!ctx) return FK_ERR_BAD_ARG;
     if (!d_buf || !d_sub) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "null argument");
     if (log_m >= FK_FR_S) FK_SET_ERR(ctx, FK_ERR_DOMAIN_TOO_LARGE, "evaluation domain 2^%u too large (max 2^%d)", log_m, FK_FR_S - 1);
     FK_HIP(ctx, hipSetDevice(ctx->device));
     return dq_cross(ctx, (Fr *)d_buf, log_m, rank, log_w, 1, (const Fr *)d_sub);
-}
+}); }
 
-int fk_quotient_h(fk_ctx *ctx, const uint64_t *a, const uint64_t *b, const uint64_t *c, uint64_t n, uint64_t *h_out) {
+int fk_quotient_h(fk_ctx *ctx, const uint64_t *a, const uint64_t *b, const uint64_t *c, uint64_t n, uint64_t *h_out) { return fk_guard(ctx, [&]() -> int {
     if (!ctx) return FK_ERR_BAD_ARG;
     if (!a || !b || !c || !h_out || !n) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "null argument");
     const uint32_t log_n = ceil_log2_u64(n);
@@ -819,9 +840,9 @@ int fk_quotient_h(fk_ctx *ctx, const uint64_t *a, const uint64_t *b, const uint6
     FK_HIP(ctx, hipMemcpyAsync(h_out, ctx->hbuf.p, mb - sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
     FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return FK_OK;
-}
+}); }
 
-int fk_msm_g1_dev(fk_ctx *ctx, const void *d_bases, const void *d_scalars, size_t n, uint8_t out[FK_G1_BYTES]) {
+int fk_msm_g1_dev(fk_ctx *ctx, const void *d_bases, const void *d_scalars, size_t n, uint8_t out[FK_G1_BYTES]) { return fk_guard(ctx, [&]() -> int {
     if (!ctx) return FK_ERR_BAD_ARG;
     if (!out || (n && (!d_bases || !d_scalars))) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "null argument");
     FK_HIP(ctx, hipSetDevice(ctx->device));
@@ -829,8 +850,8 @@ int fk_msm_g1_dev(fk_ctx *ctx, const void *d_bases, const void *d_scalars, size_
     FK_TRY(msm_g1_dev(ctx, (const G1Affine *)d_bases, (const Fr *)d_scalars, n, &r));
     g1_to_raw(out, r);
     return FK_OK;
-}
-int fk_msm_g2_dev(fk_ctx *ctx, const void *d_bases, const void *d_scalars, size_t n, uint8_t out[FK_G2_BYTES]) {
+}); }
+int fk_msm_g2_dev(fk_ctx *ctx, const void *d_bases, const void *d_scalars, size_t n, uint8_t out[FK_G2_BYTES]) { return fk_guard(ctx, [&]() -> int {
     if (!ctx) return FK_ERR_BAD_ARG;
     if (!out || (n && (!d_bases || !d_scalars))) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "null argument");
     FK_HIP(ctx, hipSetDevice(ctx->device));
@@ -838,7 +859,7 @@ int fk_msm_g2_dev(fk_ctx *ctx, const void *d_bases, const void *d_scalars, size_
     FK_TRY(msm_g2_dev(ctx, (const G2Affine *)d_bases, (const Fr *)d_scalars, n, &r));
     g2_to_raw(out, r);
     return FK_OK;
-}
+}); }
 
 static int msm_host(fk_ctx *ctx, const uint8_t *bases, const uint64_t *scalars, size_t n, size_t w, uint8_t *out) {
     if (!out || (n && (!bases || !scalars))) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "null argument");
@@ -850,36 +871,36 @@ static int msm_host(fk_ctx *ctx, const uint8_t *bases, const uint64_t *scalars, 
     }
     return w == 64 ? fk_msm_g1_dev(ctx, ctx->stage_a.p, ctx->stage_z.p, n, out) : fk_msm_g2_dev(ctx, ctx->stage_a.p, ctx->stage_z.p, n, out);
 }
-int fk_msm_g1(fk_ctx *ctx, const uint8_t *bases, const uint64_t *scalars, size_t n, uint8_t out[FK_G1_BYTES]) {
+int fk_msm_g1(fk_ctx *ctx, const uint8_t *bases, const uint64_t *scalars, size_t n, uint8_t out[FK_G1_BYTES]) { return fk_guard(ctx, [&]() -> int {
     if (!ctx) return FK_ERR_BAD_ARG;
     return msm_host(ctx, bases, scalars, n, 64, out);
-}
-int fk_msm_g2(fk_ctx *ctx, const uint8_t *bases, const uint64_t *scalars, size_t n, uint8_t out[FK_G2_BYTES]) {
+}); }
+int fk_msm_g2(fk_ctx *ctx, const uint8_t *bases, const uint64_t *scalars, size_t n, uint8_t out[FK_G2_BYTES]) { return fk_guard(ctx, [&]() -> int {
     if (!ctx) return FK_ERR_BAD_ARG;
     return msm_host(ctx, bases, scalars, n, 128, out);
-}
+}); }
 
-int fk_gen_points_g1_dev(fk_ctx *ctx, void *d_out, size_t n, uint64_t seed) {
+int fk_gen_points_g1_dev(fk_ctx *ctx, void *d_out, size_t n, uint64_t seed) { return fk_guard(ctx, [&]() -> int {
     if (!ctx) return FK_ERR_BAD_ARG;
     FK_HIP(ctx, hipSetDevice(ctx->device));
     FK_TRY(gen_points_g1(ctx, (G1Affine *)d_out, n, seed));
     FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return FK_OK;
-}
-int fk_gen_points_g2_dev(fk_ctx *ctx, void *d_out, size_t n, uint64_t seed) {
+}); }
+int fk_gen_points_g2_dev(fk_ctx *ctx, void *d_out, size_t n, uint64_t seed) { return fk_guard(ctx, [&]() -> int {
     if (!ctx) return FK_ERR_BAD_ARG;
     FK_HIP(ctx, hipSetDevice(ctx->device));
     FK_TRY(gen_points_g2(ctx, (G2Affine *)d_out, n, seed));
     FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return FK_OK;
-}
-int fk_gen_scalars_dev(fk_ctx *ctx, void *d_out, size_t n, uint64_t seed, int kind) {
+}); }
+int fk_gen_scalars_dev(fk_ctx *ctx, void *d_out, size_t n, uint64_t seed, int kind) { return fk_guard(ctx, [&]() -> int {
     if (!ctx) return FK_ERR_BAD_ARG;
     FK_HIP(ctx, hipSetDevice(ctx->device));
     FK_TRY(gen_scalars(ctx, (Fr *)d_out, n, seed, kind));
     FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return FK_OK;
-}
+}); }
 
 // ------------------------------------------------------------------------------------------ synthesis (host)
 static inline void eval_lc(Fr *out, const uint64_t *ptr, const uint32_t *col, const uint64_t *val, uint64_t row, const Fr *z,
@@ -900,7 +921,7 @@ static inline void eval_lc(Fr *out, const uint64_t *ptr, const uint32_t *col, co
 }
 
 int fk_synthesize(fk_ctx *ctx, const fk_r1cs *cs, const uint64_t *z_, uint64_t *a, uint64_t *b, uint64_t *c,
-                  uint8_t *a_aux, uint8_t *b_in, uint8_t *b_aux) {
+                  uint8_t *a_aux, uint8_t *b_in, uint8_t *b_aux) { return fk_guard(ctx, [&]() -> int {
     fk_ctx local;                  // host-only routine: usable without a GPU context
     if (!ctx) ctx = &local;
     if (!cs || !z_ || !a || !b || !c || !a_aux || !b_in || !b_aux) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "null argument");
@@ -922,7 +943,7 @@ int fk_synthesize(fk_ctx *ctx, const fk_r1cs *cs, const uint64_t *z_, uint64_t *
         memcpy(a + 4 * row, &z[i], 32); memset(b + 4 * row, 0, 32); memset(c + 4 * row, 0, 32);
     }
     return FK_OK;
-}
+}); }
 
 void fk_shard_range(uint64_t n, uint32_t index, uint32_t count, uint64_t *lo, uint64_t *hi) {
     if (!count || !lo || !hi) return;
@@ -935,7 +956,7 @@ void fk_h_shard_range(uint64_t n_h, uint32_t index, uint32_t count, uint64_t *lo
 }
 
 // ------------------------------------------------------------------------------------------ stats
-int fk_stats_reset(fk_ctx *ctx) {
+int fk_stats_reset(fk_ctx *ctx) { return fk_guard(ctx, [&]() -> int {
     if (!ctx) return FK_ERR_BAD_ARG;
     FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     FK_TRY(msm_sync(ctx));
@@ -945,8 +966,8 @@ int fk_stats_reset(fk_ctx *ctx) {
     }
     ctx->acc_adds[0] = ctx->acc_adds[1] = 0;
     return FK_OK;
-}
-int fk_stats_get(fk_ctx *ctx, int which, double *ms, uint64_t *launches, uint64_t *units) {
+}); }
+int fk_stats_get(fk_ctx *ctx, int which, double *ms, uint64_t *launches, uint64_t *units) { return fk_guard(ctx, [&]() -> int {
     if (!ctx) return FK_ERR_BAD_ARG;
     if (which < 0 || which > 6) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "stats: which must be 0 / 3 / 5 (G1 accumulate), 1 / 4 / 6 (G2 accumulate) or 2 (NTT pass)");
     FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -978,6 +999,6 @@ int fk_stats_get(fk_ctx *ctx, int which, double *ms, uint64_t *launches, uint64_
     if (launches) *launches = v.size();
     if (units) *units = u;
     return FK_OK;
-}
+}); }
 
 }  // extern "C"

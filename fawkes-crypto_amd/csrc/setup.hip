@@ -445,18 +445,18 @@ static int setup_impl(fk_ctx *ctx, const fk_r1cs *cs, uint32_t copies, const uin
 
 int fk_setup(fk_ctx *ctx, const fk_r1cs *cs, const uint64_t tau[4], const uint64_t alpha[4], const uint64_t beta[4], const uint64_t gamma[4],
              const uint64_t delta[4], uint32_t shard_index, uint32_t shard_count, double z_frac_lo, double z_frac_hi, fk_key **out_key,
-             uint8_t vk_out[6 * 128], uint8_t *ic_out) {
+             uint8_t vk_out[6 * 128], uint8_t *ic_out) { return fk_guard(ctx, [&]() -> int {
     return setup_impl(ctx, cs, 1, tau, alpha, beta, gamma, delta, shard_index, shard_count, z_frac_lo, z_frac_hi, out_key, vk_out, ic_out);
-}
+}); }
 
 int fk_setup_tiled(fk_ctx *ctx, const fk_r1cs *instance, uint32_t copies, const uint64_t tau[4], const uint64_t alpha[4], const uint64_t beta[4],
                    const uint64_t gamma[4], const uint64_t delta[4], uint32_t shard_index, uint32_t shard_count, double z_frac_lo, double z_frac_hi,
-                   fk_key **out_key, uint8_t vk_out[6 * 128], uint8_t *ic_out) {
+                   fk_key **out_key, uint8_t vk_out[6 * 128], uint8_t *ic_out) { return fk_guard(ctx, [&]() -> int {
     return setup_impl(ctx, instance, copies, tau, alpha, beta, gamma, delta, shard_index, shard_count, z_frac_lo, z_frac_hi, out_key, vk_out, ic_out);
-}
+}); }
 
 // which: 0 = h, 1 = l, 2 = a, 3 = b_g1, 4 = b_g2.  Copies this key's slice of the array to the host.
-int fk_key_download(fk_ctx *ctx, const fk_key *key, int which, void *host, size_t host_bytes) {
+int fk_key_download(fk_ctx *ctx, const fk_key *key, int which, void *host, size_t host_bytes) { return fk_guard(ctx, [&]() -> int {
     if (!ctx) return FK_ERR_BAD_ARG;
     if (!key || !host) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "key download: null argument");
     FK_HIP(ctx, hipSetDevice(ctx->device));
@@ -472,6 +472,6 @@ int fk_key_download(fk_ctx *ctx, const fk_key *key, int which, void *host, size_
     if (host_bytes < bytes) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "key download: buffer too small (%zu < %zu)", host_bytes, bytes);
     if (bytes) FK_HIP(ctx, hipMemcpy(host, src, bytes, hipMemcpyDeviceToHost));
     return FK_OK;
-}
+}); }
 
 }  // extern "C"

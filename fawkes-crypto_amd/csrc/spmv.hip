@@ -245,10 +245,16 @@ static int r1cs_load_impl(fk_ctx *ctx, const fk_r1cs *cs, uint32_t copies, fk_r1
     std::vector<uint8_t> a_aux(cs->num_aux ? cs->num_aux : 1, 0), b_in(cs->num_input, 0), b_aux(cs->num_aux ? cs->num_aux : 1, 0);
     int rc = FK_OK;
     auto fail = [&](int code) { fk_r1cs_free(ctx, r); return code; };
-    // rows of [wave_lo, wave_hi) terms of a batch of >= wave_copies copies go to spmv_tiled_wave_kernel (see there); the lower bound
-    // is the boundary of the one-lane class, the upper one lies in the 16-lane class (>= 32 terms)
-    static const uint32_t wave_copies = (uint32_t)tune("FK_SPMV_WAVE_MIN_COPIES", 64), wave_lo = 4,
-                          wave_hi = (uint32_t)std::min(1024, std::max(32, tune("FK_SPMV_WAVE_HI", 64)));
+    // rows of [wave_lo, wave_hi) terms of a batch of >= wave_copies copies go to spmv_tiled_wave_kernel (see there).  The length
+    // classes are 16 lanes per row from 64 terms, 8 from 32, 4 from 16, 2 from 8, one lane below; with [4, 64) the wave kernel takes
+    // the WHOLE 8-, 4- and 2-lane classes and the head (4 .. 7 terms) of the one-lane class.  The clipping in r1cs_eval_impl removes a
+    // prefix or a suffix of a class segment, so the range may cut only the first class (wave_hi >= 64) and the last one (wave_lo < 8):
+    // an upper bound strictly inside a middle class is snapped down to that class's boundary (experiment builds can set any value).
+    static const uint32_t wave_copies = (uint32_t)tune("FK_SPMV_WAVE_MIN_COPIES", 64), wave_lo = 4;
+    static const uint32_t wave_hi = [] {
+        const uint32_t v = (uint32_t)std::min(1024, std::max(32, tune("FK_SPMV_WAVE_HI", 64)));
+        return v >= 64 ? v : 32u;           // 32 .. 63 -> 32: the boundary between the 8-lane and the 4-lane class
+    }();
     uint64_t bin_min = 8;          // rows this long make a matrix binned; FK_SPMV_BIN_MIN=0 turns the binned product off (a run-time switch: the tests run both kernels)
     if (const char *e = getenv("FK_SPMV_BIN_MIN")) { bin_min = strtoull(e, nullptr, 10); if (!bin_min) bin_min = ~0ull; }
     for (int k = 0; k < 3 && rc == FK_OK; k++) {
@@ -398,7 +404,7 @@ static int r1cs_load_impl(fk_ctx *ctx, const fk_r1cs *cs, uint32_t copies, fk_r1
     return FK_OK;
 }
 
-int fk_r1cs_load(fk_ctx *ctx, const fk_r1cs *cs, fk_r1cs_dev **out) { return r1cs_load_impl(ctx, cs, 1, out); }
+int fk_r1cs_load(fk_ctx *ctx, const fk_r1cs *cs, fk_r1cs_dev **out) { return fk_guard(ctx, [&]() -> int { return r1cs_load_impl(ctx, cs, 1, out); }); }
 }  // extern "C"
 namespace fk {
 int r1cs_load_coded(fk_ctx *ctx, uint32_t num_input, uint32_t num_aux, uint64_t num_gates, const uint64_t *const ptr[3], const uint32_t *const col[3],
@@ -410,20 +416,20 @@ int r1cs_load_coded(fk_ctx *ctx, uint32_t num_input, uint32_t num_aux, uint64_t 
 }
 }  // namespace fk
 extern "C" {
-int fk_r1cs_load_tiled(fk_ctx *ctx, const fk_r1cs *instance, uint32_t copies, fk_r1cs_dev **out) { return r1cs_load_impl(ctx, instance, copies, out); }
+int fk_r1cs_load_tiled(fk_ctx *ctx, const fk_r1cs *instance, uint32_t copies, fk_r1cs_dev **out) { return fk_guard(ctx, [&]() -> int { return r1cs_load_impl(ctx, instance, copies, out); }); }
 
 // the same system with its coefficients already dictionary-coded by the caller: *_val of `cs` are ignored, cidx[k][i] indexes
 // `table` (n_table Montgomery values, table[0] = ONE).  8 bytes per term on the host side as well -- how a system of 10^9
 // explicit terms is handed over (32-byte values per term would be 30 GB of host memory).
 int fk_r1cs_load_coded(fk_ctx *ctx, const fk_r1cs *cs, const uint32_t *a_cidx, const uint32_t *b_cidx, const uint32_t *c_cidx, const uint64_t *table,
-                       uint64_t n_table, fk_r1cs_dev **out) {
+                       uint64_t n_table, fk_r1cs_dev **out) { return fk_guard(ctx, [&]() -> int {
     if (!ctx) return FK_ERR_BAD_ARG;
     if (!cs || !table || !n_table || !out) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "r1cs: null argument");
     const uint32_t *cidx[3] = {a_cidx, b_cidx, c_cidx};
     const uint64_t *ptrs[3] = {cs->a_ptr, cs->b_ptr, cs->c_ptr};
     for (int k = 0; k < 3; k++) if (ptrs[k] && ptrs[k][cs->num_gates] && !cidx[k]) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "r1cs: null coefficient index array");
     return r1cs_load_impl(ctx, cs, 1, out, cidx, (const Fr *)table, n_table);
-}
+}); }
 
 int fk_r1cs_density_ptrs(const fk_r1cs_dev *r, const void *out[3]) {
     if (!r || !out) return FK_ERR_BAD_ARG;
@@ -434,7 +440,7 @@ int fk_r1cs_density_ptrs(const fk_r1cs_dev *r, const void *out[3]) {
 int fk_r1cs_info(const fk_r1cs_dev *r, uint64_t out[8]) {
     if (!r || !out) return FK_ERR_BAD_ARG;
     const uint64_t v[8] = {r->num_gates + r->num_input, r->nnz[0], r->nnz[1], r->nnz[2], r->n_table,
-                           (uint64_t)r->num_input + r->n_a_aux, r->n_b_in + r->n_b_aux, 0};
+                           (uint64_t)r->num_input + r->n_a_aux, r->n_b_in + r->n_b_aux, (uint64_t)r->num_input + r->num_aux};
     memcpy(out, v, sizeof v);
     return FK_OK;
 }
@@ -532,7 +538,8 @@ int r1cs_eval_impl(fk_ctx *ctx, const fk_r1cs_dev *r, const void *d_z, void *d_a
         }
         if (tiled && !sliced && r->n_wavelist) {
             // rows of wave_lo .. wave_hi - 1 terms go to spmv_tiled_wave_kernel: they are rowlist[wave_from, wave_to) of their matrix
-            // (the lists are sorted by length, longest first), i.e. the tail of the 16-lane class and the whole 4-lane class
+            // (the lists are sorted by length, longest first), i.e. with the default [4, 64): the whole 8-, 4- and 2-lane classes and the
+            // 4 .. 7-term head of the one-lane class; with wave_hi > 64 also the tail of the 16-lane class
             b.first_block[0] = 0;
             for (uint32_t s = 0; s < b.nseg; s++) {
                 const uint32_t k = b.mtx[s], s0 = b.list_off[s], s1 = s0 + b.n_rows[s], w0 = r->wave_from[k], w1 = r->wave_to[k];
@@ -563,26 +570,26 @@ int r1cs_eval_impl(fk_ctx *ctx, const fk_r1cs_dev *r, const void *d_z, void *d_a
 extern "C" {
 
 // a, b, c: device arrays with room for next_pow2(rows) elements each (fk_prove_dev's contract); rows written.
-int fk_r1cs_eval_dev(fk_ctx *ctx, const fk_r1cs_dev *r, const void *d_z, void *d_a, void *d_b, void *d_c) {
+int fk_r1cs_eval_dev(fk_ctx *ctx, const fk_r1cs_dev *r, const void *d_z, void *d_a, void *d_b, void *d_c) { return fk_guard(ctx, [&]() -> int {
     if (!ctx) return FK_ERR_BAD_ARG;
     if (!r || !d_z || !d_a || !d_b || !d_c) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "r1cs eval: null argument");
     return r1cs_eval_impl(ctx, r, d_z, d_a, d_b, d_c, false, 0, 0, 0);
-}
+}); }
 
 // Multi-GPU form: only the cyclic slice rank `rank` of 2^log_w ranks needs -- local[j] = row (rank + j * 2^log_w) of A z, B z,
 // C z, zero behind the last row: exactly what fk_dq_gather_dev would cut out of the full vectors, at 1 / 2^log_w of the work and
 // without the three m-element vectors.  Arrays of 2^(log_m - log_w) elements.
-int fk_r1cs_eval_slice_dev(fk_ctx *ctx, const fk_r1cs_dev *r, const void *d_z, uint32_t log_m, uint32_t rank, uint32_t log_w, void *d_a, void *d_b, void *d_c) {
+int fk_r1cs_eval_slice_dev(fk_ctx *ctx, const fk_r1cs_dev *r, const void *d_z, uint32_t log_m, uint32_t rank, uint32_t log_w, void *d_a, void *d_b, void *d_c) { return fk_guard(ctx, [&]() -> int {
     if (!ctx) return FK_ERR_BAD_ARG;
     if (!r || !d_z || !d_a || !d_b || !d_c) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "r1cs eval: null argument");
     if (log_w > 3 || (rank >> log_w) || log_m < log_w || log_m >= FK_FR_S) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "r1cs eval: bad slice (rank %u of 2^%u, domain 2^%u)", rank, log_w, log_m);
     if (r->num_gates + r->num_input > ((uint64_t)1 << log_m)) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "r1cs eval: the system has more rows than the domain 2^%u", log_m);
     return r1cs_eval_impl(ctx, r, d_z, d_a, d_b, d_c, true, rank, log_w, (uint64_t)1 << (log_m - log_w));
-}
+}); }
 
 // witness in -> proof out: SpMV, quotient, MSMs, assembly.  z: device pointer (num_input + num_aux elements).
 int fk_prove_r1cs_dev(fk_ctx *ctx, const fk_key *key, const fk_r1cs_dev *r, const void *d_z, const uint64_t rr[4], const uint64_t ss[4],
-                      uint8_t out_proof[FK_PROOF_BYTES], fk_timings *tm) {
+                      uint8_t out_proof[FK_PROOF_BYTES], fk_timings *tm) { return fk_guard(ctx, [&]() -> int {
     if (!ctx) return FK_ERR_BAD_ARG;
     if (!key || !r || !d_z) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "prove: null argument");
     if (r->num_input != key->num_input || r->num_aux != key->num_aux) FK_SET_ERR(ctx, FK_ERR_KEY_MISMATCH, "prove: constraint system and key disagree on the variable counts");
@@ -618,11 +625,11 @@ int fk_prove_r1cs_dev(fk_ctx *ctx, const fk_key *key, const fk_r1cs_dev *r, cons
     ctx->qidx = nullptr;
     ctx->ev_z_recorded = false;
     return rc;
-}
+}); }
 
 // multi-GPU: all five multiplications of this key's slices for a resident constraint system (see fk_prove_msms_hz_dev)
 int fk_prove_msms_hz_r1cs_dev(fk_ctx *ctx, const fk_key *key, const fk_r1cs_dev *r, const void *d_h_slice, const void *d_z,
-                              uint8_t out[FK_MSM_RESULT_BYTES]) {
+                              uint8_t out[FK_MSM_RESULT_BYTES]) { return fk_guard(ctx, [&]() -> int {
     if (!ctx) return FK_ERR_BAD_ARG;
     if (!key || !r || !d_z) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "prove: null argument");
     if (r->num_input != key->num_input || r->num_aux != key->num_aux) FK_SET_ERR(ctx, FK_ERR_KEY_MISMATCH, "prove: constraint system and key disagree on the variable counts");
@@ -630,11 +637,11 @@ int fk_prove_msms_hz_r1cs_dev(fk_ctx *ctx, const fk_key *key, const fk_r1cs_dev 
     const int rc = fk_prove_msms_hz_dev(ctx, key, d_h_slice, d_z, r->d_a_aux, r->d_b_in, r->d_b_aux, out, nullptr);
     ctx->qidx = nullptr;
     return rc;
-}
+}); }
 
 // ... and of fk_prove_msms_z_begin_dev: the witness multiplications are queued (index-list gathers), the caller runs the
 // (distributed) quotient and finishes with fk_prove_msms_finish_dev
-int fk_prove_msms_z_begin_r1cs_dev(fk_ctx *ctx, const fk_key *key, const fk_r1cs_dev *r, const void *d_z) {
+int fk_prove_msms_z_begin_r1cs_dev(fk_ctx *ctx, const fk_key *key, const fk_r1cs_dev *r, const void *d_z) { return fk_guard(ctx, [&]() -> int {
     if (!ctx) return FK_ERR_BAD_ARG;
     if (!key || !r || !d_z) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "prove: null argument");
     if (r->num_input != key->num_input || r->num_aux != key->num_aux) FK_SET_ERR(ctx, FK_ERR_KEY_MISMATCH, "prove: constraint system and key disagree on the variable counts");
@@ -642,10 +649,10 @@ int fk_prove_msms_z_begin_r1cs_dev(fk_ctx *ctx, const fk_key *key, const fk_r1cs
     const int rc = fk_prove_msms_z_begin_dev(ctx, key, d_z, r->d_a_aux, r->d_b_in, r->d_b_aux);
     ctx->qidx = nullptr;
     return rc;
-}
+}); }
 
 int fk_prove_r1cs(fk_ctx *ctx, const fk_key *key, const fk_r1cs_dev *r, const uint64_t *z, const uint64_t rr[4], const uint64_t ss[4],
-                  uint8_t out_proof[FK_PROOF_BYTES], fk_timings *tm) {
+                  uint8_t out_proof[FK_PROOF_BYTES], fk_timings *tm) { return fk_guard(ctx, [&]() -> int {
     if (!ctx) return FK_ERR_BAD_ARG;
     if (!key || !r || !z) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "prove: null argument");
     FK_HIP(ctx, hipSetDevice(ctx->device));
@@ -653,11 +660,11 @@ int fk_prove_r1cs(fk_ctx *ctx, const fk_key *key, const fk_r1cs_dev *r, const ui
     FK_HIP(ctx, ctx->stage_z.reserve(zb));
     FK_HIP(ctx, hipMemcpyAsync(ctx->stage_z.p, z, zb, hipMemcpyHostToDevice, ctx->stream));
     return fk_prove_r1cs_dev(ctx, key, r, ctx->stage_z.p, rr, ss, out_proof, tm);
-}
+}); }
 
 // Pipelined form of fk_prove_r1cs: _submit starts the upload of the witness into one of the two slots and returns at once;
 // _wait computes that proof.  Calling submit(k+1) before wait(k) hides the upload of proof k+1 underneath proof k.
-int fk_prove_r1cs_submit(fk_ctx *ctx, const fk_key *key, const fk_r1cs_dev *r, const uint64_t *z, const uint64_t rr[4], const uint64_t ss[4], int *ticket) {
+int fk_prove_r1cs_submit(fk_ctx *ctx, const fk_key *key, const fk_r1cs_dev *r, const uint64_t *z, const uint64_t rr[4], const uint64_t ss[4], int *ticket) { return fk_guard(ctx, [&]() -> int {
     if (!ctx) return FK_ERR_BAD_ARG;
     if (!key || !r || !z || !rr || !ss || !ticket) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "prove: null argument");
     const int slot = ctx->wslot_next;
@@ -677,7 +684,7 @@ int fk_prove_r1cs_submit(fk_ctx *ctx, const fk_key *key, const fk_r1cs_dev *r, c
     ctx->wslot_next = slot ^ 1;
     *ticket = slot;
     return FK_OK;
-}
+}); }
 }  // extern "C"
 namespace fk {
 // Early front of the proof waiting in witness slot `slot` (pipelined proofs at sizes that run the sorts-first schedule): called by
@@ -711,7 +718,7 @@ static int early_front(fk_ctx *ctx, int slot) {
 }
 }  // namespace fk
 extern "C" {
-int fk_prove_r1cs_wait(fk_ctx *ctx, int ticket, uint8_t out_proof[FK_PROOF_BYTES], fk_timings *tm) {
+int fk_prove_r1cs_wait(fk_ctx *ctx, int ticket, uint8_t out_proof[FK_PROOF_BYTES], fk_timings *tm) { return fk_guard(ctx, [&]() -> int {
     if (!ctx) return FK_ERR_BAD_ARG;
     if (ticket < 0 || ticket > 1 || !ctx->wslot[ticket].pending) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "prove: no submitted proof with ticket %d", ticket);
     fk_ctx::WitSlot &w = ctx->wslot[ticket];
@@ -731,6 +738,6 @@ int fk_prove_r1cs_wait(fk_ctx *ctx, int ticket, uint8_t out_proof[FK_PROOF_BYTES
     const int rc = fk_prove_r1cs_dev(ctx, w.key, w.r1cs, d_z, w.r, w.s, out_proof, tm);
     ctx->before_block = nullptr;
     return rc;
-}
+}); }
 
 }  // extern "C"

@@ -92,7 +92,7 @@ using namespace fk;
 
 extern "C" {
 
-int fk_verify(fk_ctx *ctx, const uint8_t *vk, size_t vk_len, const uint64_t *inputs, uint32_t n_inputs, const uint8_t proof[FK_PROOF_BYTES], int *accept) {
+int fk_verify(fk_ctx *ctx, const uint8_t *vk, size_t vk_len, const uint64_t *inputs, uint32_t n_inputs, const uint8_t proof[FK_PROOF_BYTES], int *accept) { return fk_guard(ctx, [&]() -> int {
     fk_ctx local;                  // host-only routine: usable without a GPU context
     if (!ctx) ctx = &local;
     if (!proof || !accept || (n_inputs && !inputs)) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "verify: null argument");
@@ -103,10 +103,10 @@ int fk_verify(fk_ctx *ctx, const uint8_t *vk, size_t vk_len, const uint64_t *inp
     if (r < 0) FK_SET_ERR(ctx, FK_ERR_FORMAT, "verify: a coordinate is not a canonical field element");
     *accept = r;
     return FK_OK;
-}
+}); }
 
 int fk_verify_batch_dev(fk_ctx *ctx, const uint8_t *vk, size_t vk_len, const uint64_t *inputs, uint32_t n_inputs, const uint8_t *proofs, uint32_t count,
-                        uint8_t *accept) {
+                        uint8_t *accept) { return fk_guard(ctx, [&]() -> int {
     if (!ctx) return FK_ERR_BAD_ARG;
     if (!proofs || !accept || (n_inputs && !inputs)) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "verify: null argument");
     if (!count) return FK_OK;
@@ -140,6 +140,6 @@ int fk_verify_batch_dev(fk_ctx *ctx, const uint8_t *vk, size_t vk_len, const uin
         ctx->err = buf;
     }
     return FK_OK;
-}
+}); }
 
 }  // extern "C"

@@ -176,6 +176,16 @@ int fk_prove_msms_z_dev(fk_ctx *ctx, const fk_key *key, const void *d_z, const v
                         const void *d_b_input_density, const void *d_b_aux_density,
                         uint8_t out_msms[FK_MSM_RESULT_BYTES], fk_timings *timings);
 int fk_prove_msm_h_dev(fk_ctx *ctx, const fk_key *key, const void *d_h_slice, uint8_t out[FK_G1_BYTES]);
+/* ONE multiplication over one of the key's resident arrays, alone (bench / test micro entry point like fk_msm_g1, SURVEY 8(b);
+ * bellman's `multiexp(worker, (bases, 0), FullDensity, scalars)` over that array): `which` = FK_ARRAY_H / _L / _A / _B_G1 / _B_G2,
+ * d_scalars holds one Montgomery scalar per point of this key's slice of the array (counts: fk_key_shard_info), and the array's
+ * fixed-base levels are used when the key holds them.  Result raw affine: FK_G1_BYTES, FK_G2_BYTES for FK_ARRAY_B_G2. */
+#define FK_ARRAY_H 0
+#define FK_ARRAY_L 1
+#define FK_ARRAY_A 2
+#define FK_ARRAY_B_G1 3
+#define FK_ARRAY_B_G2 4
+int fk_prove_msm_array_dev(fk_ctx *ctx, const fk_key *key, int which, const void *d_scalars, uint8_t *out);
 /* Split form for schedules that compute the quotient while the witness multiplications run: _begin queues L, A, B1, B2
  * of this key's slices on the library's MSM streams (nothing is put on the main stream, so fk_quotient_h_dev / fk_dq_*
  * calls issued next overlap with them) and returns at once; _finish adds H over d_h_slice and writes the complete
@@ -279,7 +289,8 @@ int fk_r1cs_load_tiled(fk_ctx *ctx, const fk_r1cs *instance, uint32_t copies, fk
 int fk_r1cs_load_coded(fk_ctx *ctx, const fk_r1cs *cs, const uint32_t *a_cidx, const uint32_t *b_cidx, const uint32_t *c_cidx,
                        const uint64_t *table, uint64_t n_table, fk_r1cs_dev **out);
 void fk_r1cs_free(fk_ctx *ctx, fk_r1cs_dev *r1cs);
-/* out[8] = rows, nnz(A), nnz(B), nnz(C), distinct coefficients, points the a query needs, points the b query needs, 0 */
+/* out[8] = rows, nnz(A), nnz(B), nnz(C), distinct coefficients, points the a query needs, points the b query needs,
+ * variables (num_input + num_aux: the length of the witness vector the prove calls read) */
 int fk_r1cs_info(const fk_r1cs_dev *r1cs, uint64_t out[8]);
 /* device pointers of the structural density maps: a_aux[num_aux], b_input[num_input], b_aux[num_aux] */
 int fk_r1cs_density_ptrs(const fk_r1cs_dev *r1cs, const void *out[3]);

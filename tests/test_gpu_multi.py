@@ -161,9 +161,16 @@ def test_multi_prove_long_rows_tiled_and_errors(ctx, oracle):
         dr = mc.load_r1cs(r1cs_product(base), copies=copies)
         assert mc.prove_witness(key, dr, z, r, s).tobytes() == want.tobytes()
         other = mc.load_r1cs(r1cs_product(_ragged_system(98, [1, 2], 250, 3, 121)), copies=copies)
+        # a system that does not belong to the key: refused BEFORE anything is read from z (fk_multi_prove_r1cs compares the
+        # variable counts first: ADVICE r3 -- it used to upload num_vars(other) * 32 bytes from the caller's shorter buffer) ...
+        z_other = np.zeros((mc.r1cs_replica(other, 0).info()['num_vars'], 4), np.uint64)
         with pytest.raises(fk.FkError) as e:
-            mc.prove_witness(key, other, z[:-1], r, s)
-        assert e.value.code == 6 and 'rank' in str(e.value)
+            mc.prove_witness(key, other, z_other, r, s)
+        assert e.value.code == 6 and 'variable counts' in str(e.value)
+        # ... and the Python host refuses a witness of the wrong length for the system it is given
+        with pytest.raises(fk.FkError) as e:
+            mc.prove_witness(key, dr, z[:-1], r, s)
+        assert e.value.code == 6 and 'variables' in str(e.value)
         assert mc.prove_witness(key, dr, z, r, s).tobytes() == want.tobytes()
         other.free(); key.free(); dr.free()
     finally:

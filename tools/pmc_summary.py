@@ -1,7 +1,13 @@
 #!/usr/bin/env python3
 """Summarises rocprofv3 --pmc counter_collection CSVs (one directory per pass) into the JSON files under profiles/.
 
-    python tools/pmc_summary.py traffic  <fetch_dir> <write_dir> <log2n> <points_per_proof> <out.json> [proofs in the pass] [workload] [gathercal dir]
+    python tools/pmc_summary.py traffic  <fetch_dir> <write_dir> <log2n> <points_per_proof> <out.json> [proofs in the pass | auto] [workload] [gathercal dir] [rows]
+
+The number of proofs in a pass is DERIVED from the pass itself: dispatches of the G1 accumulation / 4 (H, L, A, B1 -- one launch
+each per proof), cross-checked against the dispatches of ntt_pass_kernel (6 transforms x ceil(log2n / 9) passes per proof) in
+both the FETCH and the WRITE pass.  A number given on the command line must agree with it (round 3 summarised a 5-proof pass with
+the default of 1 and put 5x the traffic into bench.py's line).
+
     python tools/pmc_summary.py valu     <sq_dir> <derived_dir> <out.json>
 
 FETCH_SIZE / WRITE_SIZE are in KB (x1024 = bytes).  FETCH_SIZE of wide coalesced streams under-reports by 2x on gfx950
@@ -52,32 +58,55 @@ def gather_correction(gcal_dir):
     return res.get('gather_kernel<4>'), res
 
 
-def traffic(fetch_dir, write_dir, log2n, points, out, proofs=1, workload='synthetic', gcal_dir=None):
+def proofs_in_pass(launches, dom, log2n, what):
+    """proofs in a pass, from its own dispatch counts"""
+    n_acc = launches[dom]
+    if n_acc % 4:
+        raise SystemExit('%s pass: %d G1-accumulate dispatches is not a multiple of 4 (H, L, A, B1 per proof)' % (what, n_acc))
+    proofs = n_acc // 4
+    ntt = sum(v for k, v in launches.items() if k.startswith('ntt_pass_kernel'))
+    per = 6 * ((log2n + 8) // 9)
+    if ntt and ntt != proofs * per:
+        raise SystemExit('%s pass: %d ntt_pass_kernel dispatches != %d proofs x %d passes (6 transforms x ceil(%d / 9))' % (what, ntt, proofs, per, log2n))
+    return proofs
+
+
+def traffic(fetch_dir, write_dir, log2n, points, out, proofs=None, workload='synthetic', gcal_dir=None, rows=None):
     fa, fl = per_kernel(load(fetch_dir))
-    wa, _ = per_kernel(load(write_dir))
+    wa, wl = per_kernel(load(write_dir))
     ks = sorted(fa, key=lambda k: -(fa[k]['FETCH_SIZE'] + wa.get(k, {}).get('WRITE_SIZE', 0)))
     per = [dict(kernel=k, launches=fl[k], FETCH_SIZE_KB=fa[k]['FETCH_SIZE'], WRITE_SIZE_KB=wa.get(k, {}).get('WRITE_SIZE', 0.0)) for k in ks[:24]]
     # the G1 accumulation: the merged form (fixed-base levels, one bucket set) when the key carries levels, else the W-set form
     dom = next(k for k in ks if k.startswith(('msm_accumulate_merged_kernel<Fp<FqParams', 'msm_accumulate_kernel<Fp<FqParams')))
     merged = dom.startswith('msm_accumulate_merged')
+    derived = proofs_in_pass(fl, dom, log2n, 'FETCH_SIZE')
+    if proofs_in_pass(wl, dom, log2n, 'WRITE_SIZE') != derived:
+        raise SystemExit('the FETCH_SIZE and WRITE_SIZE passes hold different numbers of proofs')
+    if proofs is not None and proofs != derived:
+        raise SystemExit('proofs given (%d) != proofs derived from the dispatches (%d)' % (proofs, derived))
+    proofs = derived
     corr, corr_all = gather_correction(gcal_dir)
     j = dict(
         workload=workload, fetch_size_calibration=corr_all,
         _doc='rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python3 bench.py --steps 1 --warmup 0 '
              '--no-cpu-baseline` (2^%d rows).  Counter units: KB (x1024 = bytes), summed over the launches of the whole pass (per_kernel); '
              'dominant_kernel is per proof.' % log2n,
-        log2n=log2n, per_kernel=per,
+        log2n=log2n, rows=rows, proofs_in_the_pass=proofs,
+        proofs_in_the_pass_is='derived: G1-accumulate dispatches / 4, cross-checked against ntt_pass_kernel dispatches (6 transforms x ceil(log2n / 9) passes per proof)',
+        per_kernel=per,
         dominant_kernel=dict(
             name='msm_accumulate_merged_kernel<Fq>' if merged else 'msm_accumulate_kernel<Fq>', launches_per_proof=fl[dom] // proofs, points_per_proof=points, proofs_in_the_pass=proofs,
             fetch_bytes_per_proof_raw=fa[dom]['FETCH_SIZE'] * 1024 / proofs, write_bytes_per_proof=wa[dom]['WRITE_SIZE'] * 1024 / proofs,
             fetch_correction=corr if corr else 1.0,
+            traffic_bytes_per_point=(fa[dom]['FETCH_SIZE'] * 1024 * (corr if corr else 1.0) + wa[dom]['WRITE_SIZE'] * 1024) / proofs / points,
+            traffic_over_algorithmic_bytes=(fa[dom]['FETCH_SIZE'] * 1024 * (corr if corr else 1.0) + wa[dom]['WRITE_SIZE'] * 1024) / proofs / points / 96.0,
             note='WRITE_SIZE is exact (XYZZ buckets of 128 B: W*B per launch, B in the merged form).  FETCH_SIZE is reported RAW: the guide\'s x2 gfx950 '
                  'correction is calibrated for wide coalesced streams (it holds for ntt_pass_kernel in this same pass), while this '
                  'kernel gathers 64-byte points at random 64-B-aligned addresses -- an uncalibrated width.  Expected demand: W (12-13) windows x '
                  '(64 B point + 4 B index), about 850 B per non-trivial point.  Traffic is several times the 96 B/point algorithmic bytes '
                  'because Pippenger re-gathers every base once per window; the rate stays far below HBM peak: the kernel is VALU-bound.'))
     json.dump(j, open(out, 'w'), indent=1)
-    print('wrote', out, 'dominant fetch GB', fa[dom]['FETCH_SIZE'] * 1024 / 1e9)
+    print('wrote', out, 'proofs in the pass', proofs, 'dominant fetch GB per proof', fa[dom]['FETCH_SIZE'] * 1024 / 1e9 / proofs)
 
 
 def valu(sq_dir, derived_dir, out):
@@ -104,7 +133,9 @@ def valu(sq_dir, derived_dir, out):
 
 if __name__ == '__main__':
     if sys.argv[1] == 'traffic':
-        traffic(sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), sys.argv[6], int(sys.argv[7]) if len(sys.argv) > 7 else 1,
-                sys.argv[8] if len(sys.argv) > 8 else 'synthetic', sys.argv[9] if len(sys.argv) > 9 else None)
+        traffic(sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), sys.argv[6],
+                int(sys.argv[7]) if len(sys.argv) > 7 and sys.argv[7] != 'auto' else None,
+                sys.argv[8] if len(sys.argv) > 8 else 'synthetic', sys.argv[9] if len(sys.argv) > 9 and sys.argv[9] != '-' else None,
+                int(sys.argv[10]) if len(sys.argv) > 10 else None)
     else:
         valu(sys.argv[2], sys.argv[3], sys.argv[4])
