@@ -258,7 +258,7 @@ def _spread(samples_s):
 def standalone_legs(ctx, key, m, reps=10):
     """BASELINE configs[1] and the metric's second half ("MSM scalar-muls/sec") as figures of their own: the G1 / G2 multi-scalar
     multiplication and the Fr transform timed ALONE on this GPU (inputs resident), in SURVEY section 8(d)'s units.  Every figure is
-    `reps` (>= 10) separately timed repetitions after two untimed ones -- min / median / max of the host's wall clock around a
+    `reps` (>= 10) separately timed repetitions after five untimed ones -- min / median / max of the host's wall clock around a
     synchronised call, and beside it the same repetitions by HIP events on the library's stream (`hip_event_ms`) -- so that a slow
     outlier shows as an outlier and not as the figure.  Rates are quoted on the MEDIAN.  Scalar distributions: BASELINE.md config 2
     (a) uniform mod r and (b) witness-like (half in {0, 1}: fk_gen_scalars_dev kind 1)."""
@@ -267,7 +267,11 @@ def standalone_legs(ctx, key, m, reps=10):
     st = torch.cuda.ExternalStream(ctx.stream_handle())
 
     def timed(fn, n_reps=reps):
-        for _ in range(2):
+        # FIVE untimed calls: a standalone multiplication takes the library's four MSM lanes in turn, and a lane whose scratch was
+        # sized by a smaller multiplication of the proofs before (A's, B's) frees and re-allocates several GB the first time a larger
+        # one lands on it -- 120 .. 300 ms, once per lane.  That was round 3's "4x outlier" (1 warm-up + 3 repetitions = one call per
+        # lane, three of them growing: tools/stall_probe.py, profiles/r04_stall_probe.log); five calls touch every lane.
+        for _ in range(5):
             fn()
         ctx.sync()
         wall, evs = [], []

@@ -113,6 +113,19 @@ static MsmPlan make_plan(size_t n, unsigned forced_c, bool merged = false) {
     static const int t_redl = tune("FK_MSM_RED_L", 0);
     p.L = p.B >= (1u << 18) ? 64 : (p.B >= (1u << 17) ? p.B / 2048 : (p.B >= 8192 ? p.B / 4096 : 1));      // 2^16 buckets: 16 per lane (32: 2^20 13.0 -> 12.0 ms per proof, 8: 15.4); 2^17: 64 (32: 2^23 44.1 -> 45.1)
     if (t_redl > 0 && (uint32_t)t_redl <= p.B) p.L = (uint32_t)t_redl;
+    // merged form: ONE bucket set, so the reduction is B / L lanes in all -- 2^19 buckets / 64 = 32 workgroups, a serial chain of 64 full
+    // additions each, on the tail of every multiplication.  A shorter chain costs more additions in all (every lane also multiplies
+    // its partial sum by its offset) and less time: FK_MSM_RED_L_MERGED (experiment builds), default by the round-4 sweeps below.
+    // Round-4 sweeps (profiles/r04_small_levels_sweep.log, r04_shard_levels_sweep.log, r04_red_l_sweep.log): 2^19 buckets -- L = 8 (proof of
+    // a 2^22 system 21.3 -> 20.6 ms, the share of rank 0 of 8 at 2^25 41.6 -> 39.7 ms), 2^20 buckets -- L = 16 (512 transactions 95.5 -> 89.6 ms),
+    // 2^21 buckets (the benchmark size) -- L = 64 stays (223.0 / 224.1 ms per proof against 225.6 / 226.1 at 32, 227.6 at 16, 230 at 8:
+    // there the reductions run underneath the next accumulation and only their work counts).
+    static const int t_redl_m = tune("FK_MSM_RED_L_MERGED", 0);
+    if (merged) {
+        if (p.B <= (1u << 19)) p.L = std::min<uint32_t>(p.L, 8);
+        else if (p.B <= (1u << 20)) p.L = std::min<uint32_t>(p.L, 16);
+        if (t_redl_m > 0 && (uint32_t)t_redl_m <= p.B) p.L = (uint32_t)t_redl_m;
+    }
     p.T = p.B / p.L;
     p.nblk = (p.T + 255) / 256;
     // low bits sorted by the SECOND pass (its bins; the first pass splits by the bits above them).  FK_MSM_LB = 10 .. 12.
@@ -1340,22 +1353,26 @@ int msm_g2_dev(fk_ctx *ctx, const G2Affine *d_bases, const Fr *d_scalars, size_t
 // ------------------------------------------------------------------------------------------ fixed-base precomputation of a key
 // name: the key array (for the message); require: FK_MSM_PRECOMP=require -- fail instead of falling back when HBM is short
 template <class F>
-static int precompute_levels(fk_ctx *ctx, const Affine<F> *d_bases, size_t n, KeyPre *out, const char *name, bool require) {
+static int precompute_levels(fk_ctx *ctx, const Affine<F> *d_bases, size_t n, KeyPre *out, const char *name, bool require, size_t reserve) {
     *out = KeyPre();
-    // Arrays below 2^24 points (rounded as the window rule rounds) keep the ordinary path: measured per proof with / without
-    // levels -- 2^20: 15.5 / 13.1 ms, 2^22: 29.9 / 25.8, 2^23: 45.7 / 44.1, 2^24: 79.0 / 80.6, 2^25: 139.5 / 148.2.  (Read per call:
-    // the tests lower it to run the merged path on small keys.)
+    // Arrays below 2^21 points (rounded as the window rule rounds) keep the ordinary path.  Rounds 1-3 drew the line at 2^24 (measured
+    // per proof with / without levels -- 2^20: 15.5 / 13.1 ms, 2^22: 29.9 / 25.8, 2^23: 45.7 / 44.1, 2^24: 79.0 / 80.6, 2^25: 139.5 /
+    // 148.2): the merged form lost below it because its ONE bucket set was reduced by 64 buckets per lane -- 32 workgroups for 2^19
+    // buckets, twice the time of the W-set form's reduction (profiles/r04_shard_levels_kernel_stats.log).  With the short chain of
+    // make_plan (L = 8 / 16 for small bucket sets) the levels pay from ~2^21 points on (round 4, host-witness ms per proof without /
+    // with: 2^22 synthetic 21.3 / 20.6, 2^23 37.0 / 36.3, 256 transactions 50.9 / 48.7, 512 transactions 95.5 / 89.6; 2^20: 9.8 / 10.2 --
+    // still a loss), which also keeps them on the 1/4 and 1/8 shards of a 2^25 key (section 4.4).  (Read per call: the tests lower it.)
     const char *e = getenv("FK_MSM_PRE_MIN_LOG2");
-    const int min_lg = e ? atoi(e) : 24;
+    const int min_lg = e ? atoi(e) : 21;
     if (min_lg < 6 || min_lg > 40 || n + n / 2 < ((size_t)1 << min_lg)) return FK_OK;
     const MsmPlan p = make_plan(n, ctx->window_bits, true);
     if (p.W < 2) return FK_OK;
     const size_t bytes = (size_t)(p.W - 1) * n * sizeof(Affine<F>);
     size_t fr = 0, tot = 0;
     FK_HIP(ctx, hipMemGetInfo(&fr, &tot));
-    // leave room for the lanes' scratch (about 0.6 KB per scalar of the largest multiplication), the NTT tables and the caller
+    // leave room for what a proof with this key will allocate later (`reserve`, computed once per key: key_precompute)
     void *lev = nullptr;
-    const bool fits = bytes + (size_t)n * 640 * MSM_LANES + ((size_t)8 << 30) <= fr;
+    const bool fits = bytes + reserve <= fr;
     if (!fits || hipMalloc(&lev, bytes) != hipSuccess) {
         (void)hipGetLastError();
         // Not an error by default -- the array keeps the ordinary W-bucket-set path (same bytes, ~7-10 % slower at 2^25) -- but never
@@ -1393,12 +1410,28 @@ int key_precompute(fk_ctx *ctx, fk_key *k) {
     key_pre_free(k);
     ctx->err.clear();
     if (!on) return FK_OK;
+    // What proofs with this key allocate AFTER the key is loaded, and the levels must leave free (round 4: the rule used to be 640 B x
+    // 4 lanes x the points of the array in hand -- 172 GB for the h array of a 2^26 domain, so the reference-size system of bench.py
+    // lost h's levels although everything fits):
+    //   * lane scratch, one lane per multiplication (msm_begin_t: digits, sorted, two staging arrays = 14 B per digit, W <= 13 digits
+    //     per scalar) + per lane the bucket sets, counters and task tables (3.2 GB G1 / 6.4 GB G2 at c = 22, from the plan of the
+    //     largest array);
+    //   * the quotient's vectors and tables over the domain (a, b, c, h, staging, scalar vectors, two full twiddle tables, four scale
+    //     tables): 16 vectors of m x 32 B;
+    //   * two witness slots and 8 GB for the caller (a resident constraint system, the bench's own buffers).
+    const size_t pts = (size_t)(k->h_hi - k->h_lo) + (k->l_hi - k->l_lo) + (k->a_hi - k->a_lo) + (k->b_hi - k->b_lo);
+    const size_t nv = (size_t)k->num_input + k->num_aux;
+    const size_t nmax = std::max<size_t>(std::max<size_t>(k->h_hi - k->h_lo, k->l_hi - k->l_lo), std::max<size_t>(k->a_hi - k->a_lo, k->b_hi - k->b_lo));
+    const MsmPlan pl = make_plan(nmax, ctx->window_bits, true);
+    const size_t lane_fixed = (size_t)pl.W * pl.B * (MSM_LANES * (sizeof(Xyzz<Fq>) + 16) + sizeof(Xyzz<Fq2>)) + ((size_t)1 << 30);   // bucket sets (G1 per lane, G2 once), counters, tables
+    const bool cut = k->shard_count > 1 && !(k->shard_count & (k->shard_count - 1));       // the quotient is cut between 2^k ranks only
+    const size_t reserve = pts * 14 * 13 + lane_fixed + (size_t)k->m / (cut ? k->shard_count : 1) * 32 * 16 + 2 * nv * 32 + ((size_t)8 << 30);
     // the long G1 accumulations first: if HBM runs short the later arrays stay on the ordinary path
-    if (k->d_h) FK_TRY(precompute_levels<Fq>(ctx, k->d_h, k->h_hi - k->h_lo, &k->pre_h, "h", require));
-    if (k->d_l) FK_TRY(precompute_levels<Fq>(ctx, k->d_l, k->l_hi - k->l_lo, &k->pre_l, "l", require));
-    if (k->d_b2) FK_TRY(precompute_levels<Fq2>(ctx, k->d_b2, k->b_hi - k->b_lo, &k->pre_b2, "b_g2", require));
-    if (k->d_b1 && (k->pre_b2.lev || !k->d_b2)) FK_TRY(precompute_levels<Fq>(ctx, k->d_b1, k->b_hi - k->b_lo, &k->pre_b1, "b_g1", require));   // B1 and B2 share one sort: same plan or none
-    if (k->d_a) FK_TRY(precompute_levels<Fq>(ctx, k->d_a, k->a_hi - k->a_lo, &k->pre_a, "a", require));
+    if (k->d_h) FK_TRY(precompute_levels<Fq>(ctx, k->d_h, k->h_hi - k->h_lo, &k->pre_h, "h", require, reserve));
+    if (k->d_l) FK_TRY(precompute_levels<Fq>(ctx, k->d_l, k->l_hi - k->l_lo, &k->pre_l, "l", require, reserve));
+    if (k->d_b2) FK_TRY(precompute_levels<Fq2>(ctx, k->d_b2, k->b_hi - k->b_lo, &k->pre_b2, "b_g2", require, reserve));
+    if (k->d_b1 && (k->pre_b2.lev || !k->d_b2)) FK_TRY(precompute_levels<Fq>(ctx, k->d_b1, k->b_hi - k->b_lo, &k->pre_b1, "b_g1", require, reserve));   // B1 and B2 share one sort: same plan or none
+    if (k->d_a) FK_TRY(precompute_levels<Fq>(ctx, k->d_a, k->a_hi - k->a_lo, &k->pre_a, "a", require, reserve));
     return FK_OK;
 }
 

@@ -9,8 +9,10 @@
 //! repository's test-suite through the ctypes mirror fawkes-crypto_amd/api.py.
 pub mod ffi;
 
+use std::collections::HashMap;
 use std::ffi::CStr;
 use std::ptr;
+use std::sync::{Arc, Mutex, OnceLock};
 
 use borsh::BorshDeserialize;
 use fawkes_crypto::backend::bellman_groth16::{
@@ -34,6 +36,9 @@ pub struct HipProver {
 }
 
 unsafe impl Send for HipProver {}
+// The C ABI allows one proof at a time per fk_multi (SURVEY 8(b) "Threading"): the process-wide cache below hands a prover out
+// behind a Mutex, so sharing the handle between threads is sound.
+unsafe impl Sync for HipProver {}
 
 fn last_error(multi: *const ffi::fk_multi) -> String {
     unsafe { CStr::from_ptr(ffi::fk_multi_last_error(multi)).to_string_lossy().into_owned() }
@@ -156,4 +161,79 @@ pub fn prove_hip<'a, E: Engine, Pub: Signal<WitnessCS<'a, E::Fr>>, Sec: Signal<W
     let r = <<E::BE as bellman::pairing::ff::ScalarEngine>::Fr as Field>::rand(rng);
     let s = <<E::BE as bellman::pairing::ff::ScalarEngine>::Fr as Field>::rand(rng);
     prove_hip_with_rs(params, hip, input_pub, input_sec, circuit, bellman_fp_to_num(r), bellman_fp_to_num(s))
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// `prove` with EXACTLY the reference's signature (prover.rs:63-68): call sites do not change at all.
+//
+// The resident state the GPU path needs (key shards, fixed-base levels, the decoded constraint system: seconds to build, 10^2 GB
+// at 2^25) cannot be rebuilt per call, and the reference's signature has no place to pass it -- so it lives in a process-wide
+// cache keyed by the `Parameters` the caller passes (its address plus a fingerprint of its contents) and the device list.
+// Devices: the environment variable FK_DEVICES, a comma-separated list of HIP device ids ("0", "0,1,2,3,4,5,6,7"); default "0".
+// `prove_hip(params, &hip, ..)` above stays for callers that want to own the prover (several keys, explicit lifetime, eviction).
+
+type CacheKey = (usize, u32, usize, usize, [u8; 64], Vec<i32>);
+
+fn cache() -> &'static Mutex<HashMap<CacheKey, Arc<Mutex<HipProver>>>> {
+    static CACHE: OnceLock<Mutex<HashMap<CacheKey, Arc<Mutex<HipProver>>>>> = OnceLock::new();
+    CACHE.get_or_init(|| Mutex::new(HashMap::new()))
+}
+
+/// FK_DEVICES="0,1,2,3" -> [0, 1, 2, 3]; unset or empty -> [0].  Panics on anything that is not a list of integers (a typo must
+/// not silently fall back to one GPU).
+pub fn devices_from_env() -> Vec<i32> {
+    match std::env::var("FK_DEVICES") {
+        Ok(v) if !v.trim().is_empty() => v.split(',').map(|t| t.trim().parse::<i32>().expect("FK_DEVICES: comma-separated HIP device ids")).collect(),
+        _ => vec![0],
+    }
+}
+
+fn cache_key<E: Engine>(params: &Parameters<E>, devices: &[i32]) -> CacheKey {
+    let bp = &params.0;
+    let mut tag = [0u8; 64];
+    tag.copy_from_slice(bp.vk.delta_g1.into_raw_uncompressed_le().as_ref());    // the key's delta: differs between any two setups
+    (params as *const _ as usize, params.1, bp.h.len(), bp.l.len(), tag, devices.to_vec())
+}
+
+/// The cached prover of (`params`, FK_DEVICES), built on first use.  A `Parameters` value that is dropped should be `forget`-ed:
+/// the cache cannot see a drop, and HBM is released only when the entry goes.
+pub fn resident_prover<E: Engine>(params: &Parameters<E>) -> Arc<Mutex<HipProver>> {
+    let devices = devices_from_env();
+    let key = cache_key(params, &devices);
+    let mut map = cache().lock().unwrap();
+    map.entry(key).or_insert_with(|| Arc::new(Mutex::new(HipProver::new(&devices, params)))).clone()
+}
+
+/// Drops the cached prover(s) of `params` (all device lists): frees the key shards, levels and constraint system in HBM.
+pub fn forget<E: Engine>(params: &Parameters<E>) {
+    let probe = cache_key(params, &[]);
+    cache().lock().unwrap().retain(|k, _| !(k.0 == probe.0 && k.1 == probe.1 && k.2 == probe.2 && k.3 == probe.3 && k.4 == probe.4));
+}
+
+/// `fawkes_crypto::backend::bellman_groth16::prover::prove` -- the SAME signature, argument meaning, return value and panics
+/// (prover.rs:63-90) -- with `create_random_proof` (prover.rs:80) running on the MI355X named by FK_DEVICES.
+/// Replace `use fawkes_crypto::backend::bellman_groth16::prover::prove;` by `use fawkes_crypto_hip::prove;`: nothing else changes.
+pub fn prove<'a, E: Engine, Pub: Signal<WitnessCS<'a, E::Fr>>, Sec: Signal<WitnessCS<'a, E::Fr>>, C: Fn(Pub, Sec)>(
+    params: &'a Parameters<E>,
+    input_pub: &Pub::Value,
+    input_sec: &Sec::Value,
+    circuit: C,
+) -> (Vec<Num<E::Fr>>, Proof<E>) {
+    let hip = resident_prover(params);
+    let guard = hip.lock().unwrap();
+    prove_hip(params, &guard, input_pub, input_sec, circuit)
+}
+
+/// Deterministic twin of `prove` (r, s given: bellman's `create_proof(circuit, params, r, s)`), for byte-exact comparisons.
+pub fn prove_with_rs<'a, E: Engine, Pub: Signal<WitnessCS<'a, E::Fr>>, Sec: Signal<WitnessCS<'a, E::Fr>>, C: Fn(Pub, Sec)>(
+    params: &'a Parameters<E>,
+    input_pub: &Pub::Value,
+    input_sec: &Sec::Value,
+    circuit: C,
+    r: Num<E::Fr>,
+    s: Num<E::Fr>,
+) -> (Vec<Num<E::Fr>>, Proof<E>) {
+    let hip = resident_prover(params);
+    let guard = hip.lock().unwrap();
+    prove_hip_with_rs(params, &guard, input_pub, input_sec, circuit, r, s)
 }

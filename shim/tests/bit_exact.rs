@@ -17,7 +17,7 @@ use fawkes_crypto::{
     native::poseidon::{poseidon_merkle_proof_root, MerkleProof, PoseidonParams},
     rand::{thread_rng, Rng},
 };
-use fawkes_crypto_hip::{prove_hip_with_rs, HipProver};
+use fawkes_crypto_hip::{forget, prove, prove_hip_with_rs, prove_with_rs, HipProver};
 
 fn circuit<C: CS>(public: CNum<C>, secret: (CNum<C>, CMerkleProof<C, 32>)) {
     let poseidon_params = PoseidonParams::<C::Fr>::new(3, 8, 53);
@@ -61,4 +61,13 @@ fn hip_proof_bytes_equal_bellman_create_proof() {
     let (_, got2) = prove_hip_with_rs(&params, &hip2, &root, &(leaf, proof.clone()), circuit, r, s);
     assert_eq!(got2.try_to_vec().unwrap(), want.try_to_vec().unwrap(), "2-rank GPU proof bytes differ from bellman's");
     assert!(verifier::verify(&params.get_vk(), &got, &inputs), "Verifier result should be true");   // tests/bellman_groth16.rs:45-46
+
+    // the reference's OWN signature (prover.rs:63-68): no prover argument, the resident state comes from the process-wide cache
+    // keyed by `params` and FK_DEVICES.  `prove_with_rs` is its deterministic twin; `prove` draws r, s like create_random_proof.
+    drop(hip); drop(hip2);
+    let (_, got3) = prove_with_rs(&params, &root, &(leaf, proof.clone()), circuit, r, s);
+    assert_eq!(got3.try_to_vec().unwrap(), want.try_to_vec().unwrap(), "prove_with_rs (cached prover) differs from bellman's");
+    let (inputs4, got4) = prove(&params, &root, &(leaf, proof.clone()), circuit);                   // exactly tests/bellman_groth16.rs:43
+    assert!(verifier::verify(&params.get_vk(), &got4, &inputs4), "Verifier result should be true");
+    forget(&params);
 }

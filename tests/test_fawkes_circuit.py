@@ -161,11 +161,54 @@ def test_ecc_gadget_gate_counts_match_reference_readme():
     assert cs.satisfied()
 
 
+def test_eddsa_gate_count_accounted_for_against_the_readme():
+    """README.md:47-53 against the gadget at this source revision, gate by gate.
+
+    The verifier (circuit/eddsaposeidon.rs:17-47) is 4121 gates: 20 + 20 (subgroup_decompress) + 255 (poseidon 4,8,54) + 254 (h
+    into bits) + 256 (strict comparator + assert) + 2296 (ecmul 254 bits) + 251 (s into bits) + 253 (s range check + assert) + 507
+    (fixed-base mul, 251 bits = 84 windows x 6 + 3) + 6 (add) + 3 (is_zero).  Three of the README's OWN component rows are
+    reproduced exactly by these components (255, 2296, and 513 = 85 windows x 6 + 3 for 254 bits, test above), so the restatement's
+    primitives are the README's.  The README's total is not the sum of its rows under today's gadget: 2 x 19 + 255 + 510 + 2296 + 504
+    + 507 + 6 + 3 = 4119.  What 3860 IS consistent with: the same gadget with exactly ONE of its two comparators missing --
+    without the s range check (eddsaposeidon.rs:35-36) 3868, without the strict comparator on h (bitify.rs:107-110) 3865; with the
+    README's 19-gate subgroup check (a 3-gate curve equation, which the source no longer has) 3866 / 3863.  No variant built from
+    this revision's code gives 3860 exactly: the remaining 3 .. 8 gates cannot be attributed without the revision the README was
+    measured on (the repository carries no history), and are recorded as such -- not as a restatement bug: every component that
+    the README itemises matches."""
+    rnd = random.Random(13)
+    sk, m, rho = rnd.randrange(fc.FS), rnd.randrange(ref.R), rnd.randrange(fc.FS)
+    pp, jj = fc.PoseidonParams(4, 8, 54), fc.JubJubBN256()
+    s, r_x, a_x = fc.eddsaposeidon_sign(sk, m, rho, pp, jj)
+
+    def build(**variant):
+        cs = fc.CS()
+        c_m = cs.alloc(m); cs.inputize(c_m)
+        acc = []
+        ok = fc.c_eddsaposeidon_verify(cs.alloc(s), cs.alloc(r_x), cs.alloc(a_x), c_m, pp, jj, account=acc, **variant)
+        assert ok.value == 1 and cs.satisfied()               # every variant is a satisfiable circuit that accepts the signature
+        stages = {name: acc[i][1] - acc[i - 1][1] for i, (name, _) in enumerate(acc) if i}
+        return acc[-1][1] - acc[0][1], stages
+
+    total, st = build()
+    assert total == 4121
+    assert st == {'subgroup_decompress(a)': 20, 'subgroup_decompress(r)': 20, 'poseidon(r, a, m)': 255, 'h into 254 bits': 254,
+                  'strict: h <= r - 1 comparator': 256, 'h * A (ecmul, 254 bits)': 2296, 's into 251 bits': 251, 's <= Fs - 1 comparator': 253,
+                  's * G (fixed base, 251 bits)': 507, 'hA + R': 6, 'is_zero': 3}
+    # the README's own component rows under today's structure do not add up to its total
+    assert 2 * 19 + 255 + (254 + 256) + 2296 + (251 + 253) + 507 + 6 + 3 == 4119
+    # named variants (NOT in the source): one comparator fewer brackets the README's figure, both fewer undershoots it by 248
+    assert build(range_check_s=False)[0] == 3868 and build(strict_h=False)[0] == 3865
+    assert build(range_check_s=False, strict_h=False)[0] == 3612
+    lean = build(lean_in_curve=True)
+    assert lean[1]['subgroup_decompress(a)'] == 19 and lean[0] == 4119         # README.md:47's 19 = 3 (curve) + 15 (3 doublings) + 1
+    assert build(range_check_s=False, lean_in_curve=True)[0] == 3866 and build(strict_h=False, lean_in_curve=True)[0] == 3863
+    nearest = min((abs(v - 3860), v) for v in (3868, 3865, 3866, 3863))
+    assert nearest == (3, 3863)          # closest reachable: non-strict h + 19-gate decompression; 3 gates unattributed
+
+
 def test_eddsa_circuit_shape_and_soundness_of_the_witness():
-    """One signature check.  The verifier gadget is 4121 gates at this revision of the source: 2 x 20 (subgroup_decompress)
-    + 255 (poseidon 4,8,54) + 510 (strict bit decomposition) + 2296 (ecmul) + 505 (s bits and range check) + 509
-    (fixed-base mul, 251 bits) + 6 (add) + 3 (is_zero) - the components match the README's table (255, 513, 2296); its
-    total of 3860 predates the strict decomposition's comparator (256 gates) and is not reproduced."""
+    """One signature check.  The verifier gadget is 4121 gates at this revision of the source (accounted for gate by gate against the README's 3860 in
+    test_eddsa_gate_count_accounted_for_against_the_readme above)."""
     rnd = random.Random(13)
     sk, m, rho = rnd.randrange(fc.FS), rnd.randrange(ref.R), rnd.randrange(fc.FS)
     cs, (s, r_x, a_x) = fc.eddsa_circuit(sk, m, rho)

@@ -37,9 +37,15 @@ def _check_line(j):
 
 def test_bench_default_workload_small():
     """the default workload (tiled rollup-style transactions from the committed fixture, host-witness pipeline) at 6 copies"""
-    j = _run({}, '--copies', '6', '--cpu-copies', '2')
+    j = _run({}, '--copies', '6', '--cpu-copies', '2', '--secondary-copies', '3', '--reference-copies', '7')
     _check_line(j)
     assert 'rollup-style transactions' in j['config']['workload'] and j['config']['num_input'] == 1 + 6 * 2
+    # rows and the domain are labelled as what they are (VERDICT r3: "2^25 constraints" was printed for 19.7 M rows)
+    assert j['config']['rows'] == 6 * 19270 + j['config']['num_input'] and j['config']['log2_domain'] == 17
+    assert abs(j['config']['domain_fill'] - j['config']['rows'] / 2.0 ** 17) < 1e-9 and '%d rows' % j['config']['rows'] in j['metric']
+    assert j['config']['distinct_witnesses_in_the_pipeline'] == 2 and j['latency_ms_per_proof'] >= j['device_resident_ms_per_step'] * 0.8
+    # no committed PMC pass matches a 6-transaction system: traffic is null and says why (never a number from another configuration)
+    assert j['roofline']['traffic'] is None and j['roofline']['traffic_error']
     assert j['config']['witness_bytes_per_proof'] == (j['config']['num_input'] + j['config']['num_aux']) * 32
     # the CPU baseline is MEASURED at the benchmarked size when it fits the budget (here it does) and its proof equals the GPU's
     assert j['cpu_baseline']['measured_at_full_size'] is True and 'MEASURED AT FULL SIZE' in j['cpu_baseline']['sample']
@@ -47,6 +53,15 @@ def test_bench_default_workload_small():
     assert j['untiled']['matrix_terms_resident'] == sum(j['config']['nnz']) and j['untiled']['device_resident_ms_per_step'] > 0
     st = j['standalone']
     assert st['msm_g1_2p20']['scalar_muls_per_sec'] > 1e7 and st['msm_g2_2p20']['scalar_muls_per_sec'] > 1e6 and st['ntt_2p20']['algorithmic_GBps'] > 1
+    for name in ('msm_g1_2p20', 'msm_g1_2p20_witness_like', 'msm_g2_2p20', 'msm_g1_2p17_key_bases', 'msm_g1_key_l_witness_like', 'msm_g2_key_b_g2', 'ntt_2p20'):
+        e = st[name]
+        assert e['wall_ms']['reps'] >= 10 and e['wall_ms']['min'] <= e['wall_ms']['median'] <= e['wall_ms']['max']
+        assert e['hip_event_ms']['reps'] >= 10 and 0 < e['hip_event_ms']['median'] <= e['wall_ms']['median'] * 1.05 + 0.05
+    # the legs at other transaction counts (here: tiny ones), each pairing-checked with two distinct witnesses
+    for tag, cp in (('secondary_1024_transactions', 3), ('reference_published', 7)):
+        assert j[tag]['transactions'] == cp and j[tag]['ms_per_step'] > 0 and j[tag]['proof_verified_by_pairing_check'] is True, j[tag]
+        assert j[tag]['rows'] == cp * 19270 + 1 + cp * 2
+    assert j['reference_published']['reference_seconds_per_proof'] == 628.0
     assert j['kernel_ms_per_step']['ntt_sec8d_GBps'] > 0
 
 
@@ -63,6 +78,26 @@ def test_bench_plain_command_starts_its_own_ranks():
     j = json.loads(last)
     assert j['n_gpus'] == 2 and j['value'] > 0 and j['proof_verified_by_pairing_check'] is True
     assert j['single_process_multi_gpu']['ranks'] == 2 and j['single_process_multi_gpu']['ms_per_step'] > 0
+    assert j['replica_proofs_per_sec'] > 0
+
+
+@pytest.mark.parametrize('n_ranks', [4, 8])
+def test_bench_plain_command_with_4_and_8_ranks(n_ranks):
+    """The schedules the first multi-GPU hardware run will take: `python bench.py --gpus 4` and `--gpus 8` as plain
+    commands -- the rank-per-process DISTRIBUTED QUOTIENT (the default from 4 ranks on) with 4 and 8 real processes, the replica leg and
+    the one-call leg (fk_multi_prove_r1cs on N ranks), end to end, every rank on this box's one GPU (FK_BENCH_SAME_DEVICE=1, gloo: RCCL
+    needs one device per rank).  No re-exec anywhere: the ranks are fresh children started before the parent touches the GPU."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'FK_DIST_QUOTIENT')}
+    env['FK_BENCH_SAME_DEVICE'] = '1'
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(n_ranks), '--backend', 'gloo', '--steps', '2', '--warmup', '1',
+                          '--copies', '11'], env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
+    last = out.stdout.strip().splitlines()[-1]
+    j = json.loads(last)
+    assert j['n_gpus'] == n_ranks and j['value'] > 0 and j['proof_verified_by_pairing_check'] is True
+    assert 'distributed-quotient' in j['config']['parallelism'] and j['config']['parallelism'].startswith('msm-shard%d' % n_ranks)
+    assert j['config']['distinct_witnesses_in_the_pipeline'] == 2
+    assert j['single_process_multi_gpu']['ranks'] == n_ranks and j['single_process_multi_gpu']['ms_per_step'] > 0, j['single_process_multi_gpu']
     assert j['replica_proofs_per_sec'] > 0
 
 

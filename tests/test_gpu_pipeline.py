@@ -52,6 +52,26 @@ def test_pipeline_with_distinct_witnesses(ctx):
         ctx.host_free(p)
 
 
+@pytest.mark.parametrize('sorts_first', ['1', '0'])
+def test_early_front_with_distinct_witnesses(sorts_first):
+    """the early front -- `_wait(k)` queues proof k + 1's evaluation, gathers and witness sorts out of the other
+    slot -- is on by default only from 2^25 on, where every test and the bench used to put the SAME witness into both slots.  Here it
+    is forced at a small size (FK_PROVE_SORTS_FIRST=1, read once per process -> subprocess) with five different witnesses through
+    submit / wait, plus the abandon path; FK_PROVE_SORTS_FIRST=0 runs the same sequence on the queue-everything schedule."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if not k.startswith(('FK_MSM_', 'FK_PROVE_', 'FK_SPMV_', 'FK_NTT_'))}
+    env['FK_PROVE_SORTS_FIRST'] = sorts_first
+    out = subprocess.run([sys.executable, os.path.join(root, 'tests', '_pipeline_child.py')], env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith('PIPE ok')]
+    assert len(line) == 1, out.stdout[-1000:]
+    # with the early front in use, a foreign proof between wait(A) and wait(B) must have found B's front outstanding
+    assert line[0].endswith('refused_a_foreign_proof=%s' % (sorts_first == '1')), line[0]
+
+
 def test_stats_union_of_intervals(ctx):
     cs, prod, dr, key, z = _system(ctx, 99, gates=20000, num_input=2, num_aux=15000)
     r, s = fx.mont_fr(5), fx.mont_fr(6)
