@@ -24,7 +24,7 @@ FQ_MODULUS = 2188824287183927522224640574525727508869631115729782366268903789464
 
 # every symbol include/fawkes_hip.h declares (tests check the .so exports all of them)
 EXPORTED_SYMBOLS = [
-    'fk_init', 'fk_free', 'fk_last_error', 'fk_set_window_bits',
+    'fk_init', 'fk_free', 'fk_trim', 'fk_last_error', 'fk_set_window_bits',
     'fk_dev_alloc', 'fk_dev_free', 'fk_upload', 'fk_download', 'fk_dev_copy', 'fk_sync', 'fk_stream',
     'fk_host_alloc', 'fk_host_free', 'fk_witness_upload_async', 'fk_witness_ptr', 'fk_prove_r1cs_submit', 'fk_prove_r1cs_wait',
     'fk_key_load', 'fk_key_synthetic', 'fk_key_shard_info', 'fk_key_host_vk', 'fk_key_free',
@@ -517,6 +517,10 @@ class Context:
 
     def sync(self):
         self._ck(self.lib.fk_sync(self.handle))
+
+    def trim(self):
+        """fk_trim: release the scratch grown for earlier proofs (keys and resident constraint systems stay)"""
+        self._ck(self.lib.fk_trim(self.handle))
 
     def stream_handle(self):
         """fk_stream: the library's main HIP stream as an integer (for torch.cuda.ExternalStream)"""

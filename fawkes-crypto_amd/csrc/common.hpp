@@ -24,8 +24,8 @@ struct DevBuf {
         if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
         size_t want = bytes + (bytes >> 3) + 256;
         hipError_t e = hipMalloc(&p, want);
-        if (e != hipSuccess) { e = hipMalloc(&p, bytes); want = bytes; }
-        if (e == hipSuccess) cap = want;
+        if (e != hipSuccess) { (void)hipGetLastError(); e = hipMalloc(&p, bytes); want = bytes; }      // (the failed attempt must not stay behind as the thread's "last error")
+        if (e == hipSuccess) cap = want; else { p = nullptr; (void)hipGetLastError(); }
         return e;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
@@ -93,6 +93,7 @@ struct fk_ctx {
     // MSM: two lanes used in turn, one record per outstanding multiplication
     fk::MsmLane lanes[fk::MSM_LANES];
     int lane_next = 0, lane_prev = 0;
+    int co_tenants = 1;                   // contexts of one fk_multi that share this device (ranks on one GPU: tests, rehearsals): each needs its own scratch
     int lanes_in_use = fk::MSM_LANES;   // the provers use 2 for the largest domains (measured, prover.hip)
     fk::MsmTail tails[fk::MSM_TAILS];
     fk::DevBuf misc;
@@ -166,6 +167,7 @@ struct fk_key {
             char _b[512];                                                                         \
             snprintf(_b, sizeof _b, "%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
             (ctx)->err = _b;                                                                      \
+            (void)hipGetLastError();   /* reported: do not leave it as the thread's sticky "last error" for the next call's check */ \
             return (_e == hipErrorOutOfMemory) ? FK_ERR_OOM : FK_ERR_HIP;                         \
         }                                                                                         \
     } while (0)

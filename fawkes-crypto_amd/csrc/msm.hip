@@ -1416,8 +1416,8 @@ int key_precompute(fk_ctx *ctx, fk_key *k) {
     //   * lane scratch, one lane per multiplication (msm_begin_t: digits, sorted, two staging arrays = 14 B per digit, W <= 13 digits
     //     per scalar) + per lane the bucket sets, counters and task tables (3.2 GB G1 / 6.4 GB G2 at c = 22, from the plan of the
     //     largest array);
-    //   * the quotient's vectors and tables over the domain (a, b, c, h, staging, scalar vectors, two full twiddle tables, four scale
-    //     tables): 16 vectors of m x 32 B;
+    //   * the quotient's vectors (a, b, c, h, staging, scalar vectors: 10 of m / ranks x 32 B) and tables (two full twiddle tables, four scale
+    //     tables: 6 of m x 32 B on every rank);
     //   * two witness slots and 8 GB for the caller (a resident constraint system, the bench's own buffers).
     const size_t pts = (size_t)(k->h_hi - k->h_lo) + (k->l_hi - k->l_lo) + (k->a_hi - k->a_lo) + (k->b_hi - k->b_lo);
     const size_t nv = (size_t)k->num_input + k->num_aux;
@@ -1425,7 +1425,17 @@ int key_precompute(fk_ctx *ctx, fk_key *k) {
     const MsmPlan pl = make_plan(nmax, ctx->window_bits, true);
     const size_t lane_fixed = (size_t)pl.W * pl.B * (MSM_LANES * (sizeof(Xyzz<Fq>) + 16) + sizeof(Xyzz<Fq2>)) + ((size_t)1 << 30);   // bucket sets (G1 per lane, G2 once), counters, tables
     const bool cut = k->shard_count > 1 && !(k->shard_count & (k->shard_count - 1));       // the quotient is cut between 2^k ranks only
-    const size_t reserve = pts * 14 * 13 + lane_fixed + (size_t)k->m / (cut ? k->shard_count : 1) * 32 * 16 + 2 * nv * 32 + ((size_t)8 << 30);
+    // (the twiddle and scale tables cover the whole domain on every rank; the vectors are cut)
+    const size_t need = pts * 14 * 13 + lane_fixed + (size_t)k->m * 32 * 6 + (size_t)k->m / (cut ? k->shard_count : 1) * 32 * 10 + 2 * nv * 32;
+    // ... of which this context may hold a part already (grow-only buffers of earlier, possibly larger proofs: they are reused)
+    size_t have = 0;
+    for (const MsmLane &ln : ctx->lanes)
+        for (const DevBuf *b : {&ln.digits, &ln.sorted, &ln.totals, &ln.starts, &ln.perm, &ln.overlist, &ln.tasktab, &ln.partials, &ln.s2_cnt1, &ln.s2_seg,
+                                &ln.s2_cnt2, &ln.s2_tmp_idx, &ln.s2_tmp_lo, &ln.buckets, &ln.buckets2}) have += b->cap;
+    for (const DevBuf *b : {&ctx->ntt_s1, &ctx->ntt_s2, &ctx->ntt_io, &ctx->hbuf, &ctx->sc_a, &ctx->sc_b, &ctx->stage_a, &ctx->stage_b, &ctx->stage_c, &ctx->stage_z,
+                            &ctx->stage_d, &ctx->wslot[0].buf, &ctx->wslot[1].buf}) have += b->cap;
+    // ranks of one fk_multi that share a GPU (fk_init_devices with a device named several times) each need this much again
+    const size_t reserve = (need > have ? need - have : 0) * (size_t)std::max(1, ctx->co_tenants) + ((size_t)8 << 30);
     // the long G1 accumulations first: if HBM runs short the later arrays stay on the ordinary path
     if (k->d_h) FK_TRY(precompute_levels<Fq>(ctx, k->d_h, k->h_hi - k->h_lo, &k->pre_h, "h", require, reserve));
     if (k->d_l) FK_TRY(precompute_levels<Fq>(ctx, k->d_l, k->l_hi - k->l_lo, &k->pre_l, "l", require, reserve));

@@ -371,6 +371,13 @@ int fk_init_devices(int n_devices, const int *device_ids, fk_multi **out) {
         rc = fk_init(device_ids[i], &c);
         if (rc == FK_OK) M->ctx.push_back(c);
     }
+    // ranks that share a device (a GPU named several times: tests and rehearsals) each need their own scratch on it: the key loaders'
+    // HBM planning (key_precompute) multiplies what a rank will allocate by the number of its co-tenants
+    for (size_t i = 0; i < M->ctx.size(); i++) {
+        int same = 0;
+        for (int j = 0; j < n_devices; j++) same += device_ids[j] == device_ids[i];
+        M->ctx[i]->co_tenants = same;
+    }
     // direct access between every pair of distinct devices (xGMI); "already enabled" is fine, a refusal leaves the copies staged by the runtime
     for (int i = 0; i < n_devices && rc == FK_OK; i++)
         for (int j = 0; j < n_devices; j++) {

@@ -7,6 +7,9 @@
 //   scalar vectors: h | z_aux | z_in ++ compact(z_aux, a_aux) | compact(z_in, b_in) ++ compact(z_aux, b_aux)
 //   five Pippenger MSMs (msm.hip) against the resident key slices
 //   host: XYZZ -> affine, proof assembly with r, s and the vk points (a handful of group operations)
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
 #include "common.hpp"
 #include <chrono>
 #include <string.h>
@@ -69,6 +72,23 @@ int fk_init(int device_id, fk_ctx **out) {
     fk_ctx *ctx = new fk_ctx();
     ctx->device = device_id;
     { const char *d = getenv("FK_DEBUG"); ctx->debug = d && d[0] && d[0] != '0'; }
+    if (ctx->debug || getenv("FK_BACKTRACE")) {
+        // debugging aid (FK_DEBUG=1 or FK_BACKTRACE=1): a native backtrace on SIGSEGV / SIGABRT (the Python host's faulthandler only shows Python frames; the
+        // offsets resolve against the same libfawkes_hip.so with addr2line / llvm-symbolizer)
+        static bool installed = false;
+        if (!installed) {
+            installed = true;
+            auto h = +[](int sig) {
+                void *bt[64];
+                const int n = backtrace(bt, 64);
+                const char msg[] = "[fk] fatal signal, native backtrace:\n";
+                (void)!write(2, msg, sizeof msg - 1);
+                backtrace_symbols_fd(bt, n, 2);
+                signal(sig, SIG_DFL); raise(sig);
+            };
+            signal(SIGSEGV, h); signal(SIGABRT, h);
+        }
+    }
     { const int v = tune("FK_NTT_THREADS", 512); if (v == 64 || v == 128 || v == 256 || v == 512 || v == 1024) ctx->ntt_threads = (unsigned)v; }
     if (hipStreamCreate(&ctx->stream) != hipSuccess) { delete ctx; return FK_ERR_HIP; }
     *out = ctx;
@@ -94,6 +114,28 @@ void fk_free(fk_ctx *ctx) {
 }
 
 const char *fk_last_error(const fk_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+// Releases everything the context has grown for the proofs it has run -- the MSM lanes' scratch, the transforms' tables and buffers, the
+// staging vectors, the two witness slots -- and keeps keys and resident constraint systems.  All of it is re-allocated on demand.
+// A service that moves to a larger key calls this first: the scratch of a 2^27 proof (~170 GB) would otherwise stand in the way of the
+// next key's fixed-base levels (the loader then skips the levels that do not fit, with a warning -- never silently).
+int fk_trim(fk_ctx *ctx) { return fk_guard(ctx, [&]() -> int {
+    if (!ctx) return FK_ERR_BAD_ARG;
+    FK_HIP(ctx, hipSetDevice(ctx->device));
+    for (const auto &w : ctx->wslot) if (w.pending) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "trim: a submitted proof is outstanding (call fk_prove_r1cs_wait first)");
+    if (ctx->wit_active || ctx->early.done || !ctx->deferred.empty()) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "trim: multiplications are in flight");
+    FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    FK_TRY(msm_sync(ctx));
+    if (ctx->copy_st) FK_HIP(ctx, hipStreamSynchronize(ctx->copy_st));
+    ntt_free_domains(ctx);
+    msm_release(ctx);
+    for (DevBuf *b : {&ctx->misc, &ctx->ntt_s1, &ctx->ntt_s2, &ctx->ntt_io, &ctx->hbuf, &ctx->sc_a, &ctx->sc_b, &ctx->scan_tmp, &ctx->stage_a, &ctx->stage_b,
+                      &ctx->stage_c, &ctx->stage_z, &ctx->stage_d})
+        b->release();
+    for (auto &w : ctx->wslot) { w.buf.release(); w.deferred = false; if (w.ready) { (void)hipEventDestroy(w.ready); w.ready = nullptr; } }      // "holds nothing" again
+    ctx->lane_prev = 0; ctx->lane_next = 0;
+    return FK_OK;
+}); }
 
 int fk_set_window_bits(fk_ctx *ctx, unsigned c) { return fk_guard(ctx, [&]() -> int {
     if (!ctx) return FK_ERR_BAD_ARG;

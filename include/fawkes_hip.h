@@ -66,6 +66,9 @@ int fk_init(int device_id, fk_ctx **out);
 void fk_free(fk_ctx *ctx);
 const char *fk_last_error(const fk_ctx *ctx);
 /* 0 = library default.  Pippenger window bits (2..22) used by subsequent MSMs; for tests/tuning. */
+/* Releases the scratch the context has grown for the proofs it has run (MSM lanes, transform tables, staging vectors, witness
+ * slots); keys and resident constraint systems stay.  Everything is re-allocated on demand.  Not while a proof is submitted. */
+int fk_trim(fk_ctx *ctx);
 int fk_set_window_bits(fk_ctx *ctx, unsigned c);
 
 /* ---------------------------------------------------------------- device buffers (for resident inputs) */

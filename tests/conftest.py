@@ -9,6 +9,9 @@ for p in (ROOT, os.path.join(ROOT, 'oracle'), os.path.join(ROOT, 'tests')):
         sys.path.insert(0, p)
 
 
+os.environ.setdefault('FK_BACKTRACE', '1')      # a crash inside libfawkes_hip.so prints its native backtrace (read by fk_init)
+
+
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 

@@ -86,6 +86,9 @@ def test_config3_2p25_filled_domain_single_gpu_and_one_call_on_8_ranks(ctx):
     assert 0.99 * (1 << log_m) <= n <= (1 << log_m)            # the domain is FILLED: what "2^25 constraints" means
     tox = {k: bench.mont(v) for k, v in bench.TOXIC.items()}
     r, s = bench.mont(0xA11CE), bench.mont(0xB0B)
+    # the session's context may still hold the scratch of the 2^27 proofs above (~170 GB of grow-only lane and transform buffers): a
+    # service that moves on to another key releases it first, so that this key's fixed-base levels (~120 GB) fit
+    ctx.trim()
     dr = ctx.load_r1cs(inst, copies=copies)
     assert dr.info()['rows'] == n and sum(dr.info()['nnz']) > 1.6e9
     d_z = ctx.dev_alloc(z.nbytes)
@@ -137,6 +140,7 @@ def test_config3_2p25_filled_domain_single_gpu_and_one_call_on_8_ranks(ctx):
     key.free()                                  # the key and its fixed-base levels (≈ 140 GB) make room for the eight shards' scratch
 
     ctx.dev_free(d_z); dr.free()
+    ctx.trim()                                  # ... and so does the single-GPU prover's scratch (~70 GB)
     # ---- the same proof from ONE call on 8 ranks: fk_init_devices with this box's GPU named eight times, shard keys from
     # fk_multi_setup_tiled (each rank derives only its shard), one constraint-system replica per rank, every rank evaluates only
     # its rows t = g (mod 8), distributed quotient with the all-to-all inside the library, 1/8 of each multiplication

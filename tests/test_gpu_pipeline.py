@@ -72,6 +72,29 @@ def test_early_front_with_distinct_witnesses(sorts_first):
     assert line[0].endswith('refused_a_foreign_proof=%s' % (sorts_first == '1')), line[0]
 
 
+def test_trim_releases_scratch_and_proofs_continue(ctx):
+    """fk_trim: the grow-only scratch of earlier proofs is released (keys and resident systems stay), the next proof re-allocates
+    what it needs and gives the same bytes; refused while a proof is submitted."""
+    import fawkes_crypto_amd as fk
+    cs, prod, dr, key, z = _system(ctx, 777)
+    r, s = fx.mont_fr(11), fx.mont_fr(12)
+    want = ctx.prove_witness(key, dr, z, r, s).tobytes()
+    ctx.trim()
+    assert ctx.prove_witness(key, dr, z, r, s).tobytes() == want
+    pin = ctx.host_alloc(z.shape)
+    pin[:] = z
+    t = ctx.prove_witness_submit(key, dr, pin, r, s)
+    with pytest.raises(fk.FkError) as e:
+        ctx.trim()
+    assert e.value.code == 1 and 'outstanding' in str(e.value)
+    assert ctx.prove_witness_wait(t).tobytes() == want
+    ctx.trim()
+    t = ctx.prove_witness_submit(key, dr, pin, r, s)
+    assert ctx.prove_witness_wait(t).tobytes() == want
+    ctx.host_free(pin)
+    key.free(); dr.free()
+
+
 def test_stats_union_of_intervals(ctx):
     cs, prod, dr, key, z = _system(ctx, 99, gates=20000, num_input=2, num_aux=15000)
     r, s = fx.mont_fr(5), fx.mont_fr(6)
