@@ -548,7 +548,7 @@ def pmc_traffic(args, log_m, rows, world, acc, acc_s, achieved):
     for cand in sorted((f for f in os.listdir(prof) if f.endswith('.json') and 'pmc_traffic' in f), reverse=True):
         try:
             pmc = json.load(open(os.path.join(prof, cand)))
-            if pmc.get('workload', 'synthetic') != args.workload or pmc['log2n'] != log_m or pmc.get('rows', rows) != rows:
+            if pmc.get('workload', 'synthetic') != args.workload or pmc['log2n'] != log_m or pmc.get('rows') != rows:      # (summaries without a row count: rounds 1-3, other systems)
                 continue
             dkk = pmc['dominant_kernel']
             per_pt = (dkk['fetch_bytes_per_proof_raw'] * dkk.get('fetch_correction', 1.0) + dkk['write_bytes_per_proof']) / dkk['points_per_proof']
@@ -837,8 +837,8 @@ def main():
         ui = dr_u.info()
         untiled = {'device_resident_ms_per_step': u_ms, 'tiled_device_resident_ms_per_step': dev_ms, 'matrix_terms_resident': int(sum(ui['nnz'])),
                    'matrix_bytes_resident': int(sum(ui['nnz'])) * 8 + 3 * 8 * (n + 1), 'host_build_seconds': t_build, 'load_seconds': t_load,
-                   'is': 'fk_r1cs_load_coded of the explicitly replicated 1024-transaction system (CSR with one 8-byte entry per term), same key, same '
-                         'witness, witness resident; proof bytes equal to the tiled form'}
+                   'is': 'fk_r1cs_load_coded of the explicitly replicated %d-transaction system (CSR with one 8-byte entry per term), same key, same '
+                         'witness, witness resident; proof bytes equal to the tiled form' % copies}
         dr_u.free()
     standalone = None
     if not multi and not args.no_standalone:

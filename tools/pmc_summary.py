@@ -4,8 +4,8 @@
     python tools/pmc_summary.py traffic  <fetch_dir> <write_dir> <log2n> <points_per_proof> <out.json> [proofs in the pass | auto] [workload] [gathercal dir] [rows]
 
 The number of proofs in a pass is DERIVED from the pass itself: dispatches of the G1 accumulation / 4 (H, L, A, B1 -- one launch
-each per proof), cross-checked against the dispatches of ntt_pass_kernel (6 transforms x ceil(log2n / 9) passes per proof) in
-both the FETCH and the WRITE pass.  A number given on the command line must agree with it (round 3 summarised a 5-proof pass with
+each per proof), cross-checked against the dispatches of ntt_pass_kernel (6 transforms x ceil(log2n / 9) passes per proof, plus the one or two
+transforms of the pass's key set-up) in both the FETCH and the WRITE pass.  A number given on the command line must agree with it (round 3 summarised a 5-proof pass with
 the default of 1 and put 5x the traffic into bench.py's line).
 
     python tools/pmc_summary.py valu     <sq_dir> <derived_dir> <out.json>
@@ -65,9 +65,12 @@ def proofs_in_pass(launches, dom, log2n, what):
         raise SystemExit('%s pass: %d G1-accumulate dispatches is not a multiple of 4 (H, L, A, B1 per proof)' % (what, n_acc))
     proofs = n_acc // 4
     ntt = sum(v for k, v in launches.items() if k.startswith('ntt_pass_kernel'))
-    per = 6 * ((log2n + 8) // 9)
-    if ntt and ntt != proofs * per:
-        raise SystemExit('%s pass: %d ntt_pass_kernel dispatches != %d proofs x %d passes (6 transforms x ceil(%d / 9))' % (what, ntt, proofs, per, log2n))
+    ppt = (log2n + 8) // 9                       # passes per transform
+    # 6 transforms per proof; the key set-up of the pass (fk_setup*: the Lagrange values are one inverse transform) adds one or two
+    extra = ntt - proofs * 6 * ppt
+    if ntt and (ntt % ppt or extra < 0 or extra > 2 * ppt):
+        raise SystemExit('%s pass: %d ntt_pass_kernel dispatches do not fit %d proofs x 6 transforms x %d passes (+ at most 2 set-up transforms)'
+                         % (what, ntt, proofs, ppt))
     return proofs
 
 
