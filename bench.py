@@ -846,7 +846,15 @@ def main():
 
     # ---- N > 1: throughput mode, one whole proof per GPU (replicas of the single-GPU prover; no collective in the data path)
     replica = None
-    if world > 1 and not args.no_replicas:
+    replica_skipped = None
+    if world > 1 and not args.no_replicas and os.environ.get('FK_BENCH_SAME_DEVICE') == '1':
+        # rehearsal with every rank on ONE GPU: `world` whole keys with their fixed-base levels must fit beside each other (never the
+        # case at the benchmark size; on a node every rank has a GPU of its own).  Decided from sizes every rank knows: no rank may
+        # enter the leg's collectives alone.
+        need = world * (384 * m * 13 + nv * 64 + (40 << 30))
+        if need > 0.9 * torch.cuda.get_device_properties(local_rank).total_memory:
+            replica_skipped = 'FK_BENCH_SAME_DEVICE=1: %d whole keys with their levels do not fit one GPU at this size' % world
+    if world > 1 and not args.no_replicas and replica_skipped is None:
         import torch.distributed as dist
         key.free()
         key, _ = ctx.setup(r1cs, copies=copies, **tox)           # the whole key on every GPU
@@ -982,6 +990,8 @@ def main():
         }
         if traffic_err:
             out['roofline']['traffic_error'] = traffic_err
+        if replica_skipped is not None:
+            out['replica_skipped'] = replica_skipped
         if replica is not None:
             out['replica_proofs_per_sec'] = replica
             out['replica_proofs_per_sec_is'] = 'throughput mode: every GPU holds the whole key and proves its own witnesses (host-witness pipeline), no collective'
