@@ -700,7 +700,7 @@ def main():
     fracs = parallel.plan_z_fractions(world, m, num_aux, n_a, n_b)
     tox = {k: mont(v) for k, v in TOXIC.items()}
     key, vk = ctx.setup(r1cs, shard_index=rank, shard_count=world, copies=copies,
-                        z_frac=fracs[rank] if (world > 1 and not dist_q) else fk.api.Z_EQUAL_SPLIT, **tox)
+                        z_frac=fracs[rank] if (world > 1 and not dist_q) else (fk.api.Z_WORK_SPLIT if (world > 1 and os.environ.get('FK_MULTI_SPLIT') != 'equal') else fk.api.Z_EQUAL_SPLIT), **tox)
     pre_levels = key.precomputed()        # fixed-base window levels per key array (0 = none: FK_MSM_PRECOMP=0 or HBM short)
     r, s = mont(0xA11CE), mont(0xB0B)
     d_dens = dr.density_ptrs()
@@ -851,7 +851,7 @@ def main():
         # rehearsal with every rank on ONE GPU: `world` whole keys with their fixed-base levels must fit beside each other (never the
         # case at the benchmark size; on a node every rank has a GPU of its own).  Decided from sizes every rank knows: no rank may
         # enter the leg's collectives alone.
-        need = world * (384 * m * 13 + nv * 64 + (40 << 30))
+        need = world * (384 * m * 13 + nv * 64 + m * 32 * 20 + (2 << 30))      # key + levels (worst case), witness slots, lane / quotient scratch
         if need > 0.9 * torch.cuda.get_device_properties(local_rank).total_memory:
             replica_skipped = 'FK_BENCH_SAME_DEVICE=1: %d whole keys with their levels do not fit one GPU at this size' % world
     if world > 1 and not args.no_replicas and replica_skipped is None:
@@ -941,6 +941,8 @@ def main():
                        'msm_points': {'h': m - 1, 'l': num_aux, 'a': n_a, 'b_g1': n_b, 'b_g2': n_b},
                        'msm_fixed_base_levels': pre_levels,
                        'witness': '%.1f%% zeros, %.1f%% ones, rest dense 254-bit' % (100.0 * zeros / nv, 100.0 * ones / nv),
+                       'witness_array_split': None if world == 1 else ('fractions (balanced schedule)' if not dist_q else 'equal' if os.environ.get('FK_MULTI_SPLIT') == 'equal' else
+                                                                        'by work: l | a | b_g1 | b_g2 cut into N equal pieces of work (FK_Z_WORK_SPLIT)'),
                        'parallelism': 'msm-shard%d%s' % (world, '' if not multi else
                                                          '+distributed-quotient (7 all-to-all per proof)' if dist_q else '+balanced-quotient')},
             'msm_scalar_muls_per_sec': msm_units / sec_per_step,

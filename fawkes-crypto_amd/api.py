@@ -18,6 +18,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 FK_PROOF_BYTES = 256
 Z_EQUAL_SPLIT = (-1.0, -1.0)     # FK_Z_EQUAL_SPLIT: l / a / b sliced like h; any (lo, hi) with lo >= 0 is a fraction range, (0, 0) = empty
+Z_WORK_SPLIT = (-2.0, -2.0)      # FK_Z_WORK_SPLIT: l | a | b_g1 | b_g2 cut by work (G2 = 2.8 G1): one or two large pieces per rank
 FK_MSM_RESULT_BYTES = 4 * 64 + 128
 FR_MODULUS = 21888242871839275222246405745257275088548364400416034343698204186575808495617
 FQ_MODULUS = 21888242871839275222246405745257275088696311157297823662689037894645226208583
@@ -27,7 +28,7 @@ EXPORTED_SYMBOLS = [
     'fk_init', 'fk_free', 'fk_trim', 'fk_last_error', 'fk_set_window_bits',
     'fk_dev_alloc', 'fk_dev_free', 'fk_upload', 'fk_download', 'fk_dev_copy', 'fk_sync', 'fk_stream',
     'fk_host_alloc', 'fk_host_free', 'fk_witness_upload_async', 'fk_witness_ptr', 'fk_prove_r1cs_submit', 'fk_prove_r1cs_wait',
-    'fk_key_load', 'fk_key_synthetic', 'fk_key_shard_info', 'fk_key_host_vk', 'fk_key_free',
+    'fk_key_load', 'fk_key_synthetic', 'fk_key_shard_info', 'fk_key_shard_info2', 'fk_key_host_vk', 'fk_key_free',
     'fk_prove', 'fk_prove_dev', 'fk_prove_msms', 'fk_prove_msms_dev', 'fk_prove_msms_z_dev', 'fk_prove_msm_h_dev', 'fk_prove_msm_array_dev', 'fk_prove_msms_hz_dev',
     'fk_prove_msms_z_begin_dev', 'fk_prove_msms_finish_dev', 'fk_prove_msms_hz_r1cs_dev', 'fk_prove_msms_z_begin_r1cs_dev',
     'fk_prove_assemble',
@@ -333,7 +334,12 @@ class DeviceKey:
         if rc != 0:
             raise FkError(rc, 'fk_key_shard_info')
         v = list(out)
-        return dict(h=(v[0], v[1]), l=(v[2], v[3]), a=(v[4], v[5]), b=(v[6], v[7]))
+        out2 = (C.c_uint64 * 10)()
+        rc = self.ctx.lib.fk_key_shard_info2(self.handle, out2)
+        if rc != 0:
+            raise FkError(rc, 'fk_key_shard_info2')
+        w = list(out2)
+        return dict(h=(v[0], v[1]), l=(v[2], v[3]), a=(v[4], v[5]), b=(v[6], v[7]), b_g2=(w[8], w[9]))
 
     def __del__(self):
         try:

@@ -160,7 +160,7 @@ int fk_key_load_bellman(fk_ctx *ctx, const uint8_t *buf, size_t len, uint32_t fl
     if (rc == FK_OK) rc = conv(arr[2], k->l_lo, k->l_hi, 64, (void **)&k->d_l);
     if (rc == FK_OK) rc = conv(arr[3], k->a_lo, k->a_hi, 64, (void **)&k->d_a);
     if (rc == FK_OK) rc = conv(arr[4], k->b_lo, k->b_hi, 64, (void **)&k->d_b1);
-    if (rc == FK_OK) rc = conv(arr[5], k->b_lo, k->b_hi, 128, (void **)&k->d_b2);
+    if (rc == FK_OK) rc = conv(arr[5], k->b2_lo, k->b2_hi, 128, (void **)&k->d_b2);
     // vk + ic through the same kernels
     G1Affine vk1[3]; G2Affine vk2[3];
     std::vector<G1Affine> ic(cnt[0]);

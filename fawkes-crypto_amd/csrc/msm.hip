@@ -1419,9 +1419,9 @@ int key_precompute(fk_ctx *ctx, fk_key *k) {
     //   * the quotient's vectors (a, b, c, h, staging, scalar vectors: 10 of m / ranks x 32 B) and tables (two full twiddle tables, four scale
     //     tables: 6 of m x 32 B on every rank);
     //   * two witness slots and 8 GB for the caller (a resident constraint system, the bench's own buffers).
-    const size_t pts = (size_t)(k->h_hi - k->h_lo) + (k->l_hi - k->l_lo) + (k->a_hi - k->a_lo) + (k->b_hi - k->b_lo);
+    const size_t pts = (size_t)(k->h_hi - k->h_lo) + (k->l_hi - k->l_lo) + (k->a_hi - k->a_lo) + std::max(k->b_hi - k->b_lo, k->b2_hi - k->b2_lo);
     const size_t nv = (size_t)k->num_input + k->num_aux;
-    const size_t nmax = std::max<size_t>(std::max<size_t>(k->h_hi - k->h_lo, k->l_hi - k->l_lo), std::max<size_t>(k->a_hi - k->a_lo, k->b_hi - k->b_lo));
+    const size_t nmax = std::max<size_t>(std::max<size_t>(k->h_hi - k->h_lo, k->l_hi - k->l_lo), std::max<size_t>(k->a_hi - k->a_lo, std::max(k->b_hi - k->b_lo, k->b2_hi - k->b2_lo)));
     const MsmPlan pl = make_plan(nmax, ctx->window_bits, true);
     const size_t lane_fixed = (size_t)pl.W * pl.B * (MSM_LANES * (sizeof(Xyzz<Fq>) + 16) + sizeof(Xyzz<Fq2>)) + ((size_t)1 << 30);   // bucket sets (G1 per lane, G2 once), counters, tables
     const bool cut = k->shard_count > 1 && !(k->shard_count & (k->shard_count - 1));       // the quotient is cut between 2^k ranks only
@@ -1439,8 +1439,10 @@ int key_precompute(fk_ctx *ctx, fk_key *k) {
     // the long G1 accumulations first: if HBM runs short the later arrays stay on the ordinary path
     if (k->d_h) FK_TRY(precompute_levels<Fq>(ctx, k->d_h, k->h_hi - k->h_lo, &k->pre_h, "h", require, reserve));
     if (k->d_l) FK_TRY(precompute_levels<Fq>(ctx, k->d_l, k->l_hi - k->l_lo, &k->pre_l, "l", require, reserve));
-    if (k->d_b2) FK_TRY(precompute_levels<Fq2>(ctx, k->d_b2, k->b_hi - k->b_lo, &k->pre_b2, "b_g2", require, reserve));
-    if (k->d_b1 && (k->pre_b2.lev || !k->d_b2)) FK_TRY(precompute_levels<Fq>(ctx, k->d_b1, k->b_hi - k->b_lo, &k->pre_b1, "b_g1", require, reserve));   // B1 and B2 share one sort: same plan or none
+    const bool b_shared = k->b2_lo == k->b_lo && k->b2_hi == k->b_hi;          // B1 and B2 over the same scalars share one sort: same plan or none
+    if (k->d_b2) FK_TRY(precompute_levels<Fq2>(ctx, k->d_b2, k->b2_hi - k->b2_lo, &k->pre_b2, "b_g2", require, reserve));
+    if (k->d_b1 && (!b_shared || k->pre_b2.lev || !k->d_b2)) FK_TRY(precompute_levels<Fq>(ctx, k->d_b1, k->b_hi - k->b_lo, &k->pre_b1, "b_g1", require, reserve));
+    if (b_shared && k->pre_b2.lev && !k->pre_b1.lev && k->b_hi > k->b_lo) { (void)hipFree(k->pre_b2.lev); k->pre_b2 = KeyPre(); }       // b_g1's did not fit: neither keeps them
     if (k->d_a) FK_TRY(precompute_levels<Fq>(ctx, k->d_a, k->a_hi - k->a_lo, &k->pre_a, "a", require, reserve));
     return FK_OK;
 }

@@ -336,6 +336,14 @@ static int prove_rank(fk_multi *M, int rank, const fk_multi_key *K, const fk_mul
     return FK_OK;
 }
 
+// How the witness arrays are dealt to the ranks: by WORK from two ranks on (FK_Z_WORK_SPLIT: one or two large pieces of l | a | b_g1 | b_g2
+// per rank instead of 1 / N of each -- round 4); FK_MULTI_SPLIT=equal restores the equal split of rounds 1-3.
+static double multi_split(const fk_multi *M) {
+    const char *e = getenv("FK_MULTI_SPLIT");
+    if (e && !strcmp(e, "equal")) return FK_Z_EQUAL_SPLIT;
+    return M->n >= 2 ? FK_Z_WORK_SPLIT : FK_Z_EQUAL_SPLIT;
+}
+
 static int multi_check(fk_multi *M, const fk_multi_key *K, const fk_multi_r1cs *R) {
     if (!K || !R || (int)K->shard.size() != M->n || (int)R->rep.size() != M->n) { M->err = "prove: key / constraint system were not loaded through this fk_multi"; return FK_ERR_BAD_ARG; }
     // before anything is read from the caller's witness buffer: its length is taken from the constraint system, so a system that
@@ -463,7 +471,7 @@ int fk_multi_key_load(fk_multi *M, const fk_key_desc *desc, fk_multi_key **out) 
     K->shard.assign(M->n, nullptr);
     const int rc = run_all(M, [&](int r) {
         fk_key_desc d = *desc;
-        d.shard_index = (uint32_t)r; d.shard_count = (uint32_t)M->n; d.z_frac_lo = FK_Z_EQUAL_SPLIT; d.z_frac_hi = 0;
+        d.shard_index = (uint32_t)r; d.shard_count = (uint32_t)M->n; d.z_frac_lo = multi_split(M); d.z_frac_hi = 0;
         return fk_key_load(M->ctx[r], &d, &K->shard[r]);
     }, shares_device(M));
     if (rc != FK_OK) { fk_multi_key_free(M, K); return rc; }
@@ -479,7 +487,7 @@ int fk_multi_key_load_bellman(fk_multi *M, const uint8_t *buf, size_t len, uint3
     K->shard.assign(M->n, nullptr);
     const int rc = run_all(M, [&](int r) {
         uint32_t nic = 0;
-        const int x = fk_key_load_bellman(M->ctx[r], buf, len, flags, (uint32_t)r, (uint32_t)M->n, FK_Z_EQUAL_SPLIT, 0, &K->shard[r],
+        const int x = fk_key_load_bellman(M->ctx[r], buf, len, flags, (uint32_t)r, (uint32_t)M->n, multi_split(M), 0, &K->shard[r],
                                           r == 0 ? gamma_g2_out : nullptr, r == 0 ? ic_out : nullptr, r == 0 ? ic_cap : 0, &nic);
         if (r == 0 && n_ic) *n_ic = nic;
         return x;
@@ -502,8 +510,8 @@ static int multi_setup(fk_multi *M, const fk_r1cs *cs, uint32_t copies, const ui
         std::vector<uint8_t> vk_tmp, ic_tmp;
         uint8_t *vk = vk_out, *ic = ic_out;
         if (r != 0) { vk_tmp.resize(6 * 128); ic_tmp.resize(n_ic * 64 + 64); vk = vk_tmp.data(); ic = ic_tmp.data(); }
-        if (copies) return fk_setup_tiled(M->ctx[r], cs, copies, tau, alpha, beta, gamma, delta, (uint32_t)r, (uint32_t)M->n, FK_Z_EQUAL_SPLIT, 0, &K->shard[r], vk, ic);
-        return fk_setup(M->ctx[r], cs, tau, alpha, beta, gamma, delta, (uint32_t)r, (uint32_t)M->n, FK_Z_EQUAL_SPLIT, 0, &K->shard[r], vk, ic);
+        if (copies) return fk_setup_tiled(M->ctx[r], cs, copies, tau, alpha, beta, gamma, delta, (uint32_t)r, (uint32_t)M->n, multi_split(M), 0, &K->shard[r], vk, ic);
+        return fk_setup(M->ctx[r], cs, tau, alpha, beta, gamma, delta, (uint32_t)r, (uint32_t)M->n, multi_split(M), 0, &K->shard[r], vk, ic);
     }, shares_device(M));
     if (rc != FK_OK) { fk_multi_key_free(M, K); return rc; }
     *out = K;

@@ -256,7 +256,7 @@ static int key_alloc_slices(fk_ctx *ctx, fk_key *k, double zlo, double zhi) {
     FK_HIP(ctx, hipMalloc((void **)&k->d_l, (k->l_hi - k->l_lo) * 64 + 64));
     FK_HIP(ctx, hipMalloc((void **)&k->d_a, (k->a_hi - k->a_lo) * 64 + 64));
     FK_HIP(ctx, hipMalloc((void **)&k->d_b1, (k->b_hi - k->b_lo) * 64 + 64));
-    FK_HIP(ctx, hipMalloc((void **)&k->d_b2, (k->b_hi - k->b_lo) * 128 + 128));
+    FK_HIP(ctx, hipMalloc((void **)&k->d_b2, (k->b2_hi - k->b2_lo) * 128 + 128));
     return FK_OK;
 }
 
@@ -301,7 +301,7 @@ int fk_key_load(fk_ctx *ctx, const fk_key_desc *d, fk_key **out) { return fk_gua
     if (rc == FK_OK) rc = up(k->d_l, d->l, k->l_lo, k->l_hi, 64);
     if (rc == FK_OK) rc = up(k->d_a, d->a, k->a_lo, k->a_hi, 64);
     if (rc == FK_OK) rc = up(k->d_b1, d->b_g1, k->b_lo, k->b_hi, 64);
-    if (rc == FK_OK) rc = up(k->d_b2, d->b_g2, k->b_lo, k->b_hi, 128);
+    if (rc == FK_OK) rc = up(k->d_b2, d->b_g2, k->b2_lo, k->b2_hi, 128);
     if (rc == FK_OK) rc = key_precompute(ctx, k);
     if (rc != FK_OK) { fk_key_free(ctx, k); return rc; }
     *out = k;
@@ -332,6 +332,14 @@ int fk_key_shard_info(const fk_key *k, uint64_t out[8]) {
     return FK_OK;
 }
 
+// ... and with b_g2's own slice (it differs from b_g1's in a key split by work): h, l, a, b_g1, b_g2
+int fk_key_shard_info2(const fk_key *k, uint64_t out[10]) {
+    if (!k || !out) return FK_ERR_BAD_ARG;
+    const uint64_t v[10] = {k->h_lo, k->h_hi, k->l_lo, k->l_hi, k->a_lo, k->a_hi, k->b_lo, k->b_hi, k->b2_lo, k->b2_hi};
+    memcpy(out, v, sizeof v);
+    return FK_OK;
+}
+
 int fk_key_synthetic(fk_ctx *ctx, uint64_t m, uint32_t num_input, uint32_t num_aux, uint64_t n_a, uint64_t n_b,
                      uint64_t seed, uint32_t shard_index, uint32_t shard_count, double z_frac_lo, double z_frac_hi, fk_key **out) { return fk_guard(ctx, [&]() -> int {
     if (!ctx || !out) return FK_ERR_BAD_ARG;
@@ -348,7 +356,7 @@ int fk_key_synthetic(fk_ctx *ctx, uint64_t m, uint32_t num_input, uint32_t num_a
     if (rc == FK_OK) rc = gen_points_g1(ctx, k->d_l, k->l_hi - k->l_lo, sd + 2);
     if (rc == FK_OK) rc = gen_points_g1(ctx, k->d_a, k->a_hi - k->a_lo, sd + 3);
     if (rc == FK_OK) rc = gen_points_g1(ctx, k->d_b1, k->b_hi - k->b_lo, sd + 4);
-    if (rc == FK_OK) rc = gen_points_g2(ctx, k->d_b2, k->b_hi - k->b_lo, sd + 5);
+    if (rc == FK_OK) rc = gen_points_g2(ctx, k->d_b2, k->b2_hi - k->b2_lo, sd + 5);
     // vk points: five of the generated points (same on every shard: taken from a seed-only tiny run)
     if (rc == FK_OK) {
         FK_HIP(ctx, ctx->misc.reserve(8 * 128));
@@ -425,6 +433,15 @@ static int witness_begin(fk_ctx *ctx, const fk_key *key, const Fr *d_z, const ui
             if (qi->n_a != key->n_a) FK_SET_ERR(ctx, FK_ERR_KEY_MISMATCH, "prove: a query needs %llu points, key holds %llu",
                                                 (unsigned long long)qi->n_a, (unsigned long long)key->n_a);
             FK_TRY(gather_scalars(ctx, d_z, qi->b + key->b_lo, key->b_hi - key->b_lo, sb + key->b_lo, ax));
+            if (key->b2_lo != key->b_lo || key->b2_hi != key->b_hi) {       // key split by work: b_g2's slice is its own (the part b_g1's slice does not cover)
+                const uint64_t lo = key->b2_lo, hi = key->b2_hi;
+                const uint64_t c_lo = std::max(lo, key->b_lo), c_hi = std::min(hi, key->b_hi);      // overlap with what is gathered already
+                if (c_lo >= c_hi) FK_TRY(gather_scalars(ctx, d_z, qi->b + lo, hi - lo, sb + lo, ax));
+                else {
+                    if (lo < c_lo) FK_TRY(gather_scalars(ctx, d_z, qi->b + lo, c_lo - lo, sb + lo, ax));
+                    if (c_hi < hi) FK_TRY(gather_scalars(ctx, d_z, qi->b + c_hi, hi - c_hi, sb + c_hi, ax));
+                }
+            }
             FK_TRY(gather_scalars(ctx, d_z, qi->a + key->a_lo, key->a_hi - key->a_lo, sa + key->a_lo, ax));
         } else {
             uint64_t n_b_in = 0, n_b_aux = 0, n_a_aux = 0;
@@ -439,7 +456,9 @@ static int witness_begin(fk_ctx *ctx, const fk_key *key, const Fr *d_z, const ui
         }
         FK_HIP(ctx, hipEventRecord(ctx->ev_aux, ax));
         FK_TRY(msm_g1_begin(ctx, key->d_b1, sb + key->b_lo, key->b_hi - key->b_lo, &ctx->wit_tail[0], ctx->ev_aux, &key->pre_b1));
-        FK_TRY(msm_g2_begin(ctx, key->d_b2, sb + key->b_lo, key->b_hi - key->b_lo, /*reuse_sort=*/true, &ctx->wit_tail[1], ctx->ev_aux, &key->pre_b2));   // same scalars as B1
+        // B2: the same scalars as B1 when the two slices coincide (B1's sort is reused); its own slice when the key is split by work
+        FK_TRY(msm_g2_begin(ctx, key->d_b2, sb + key->b2_lo, key->b2_hi - key->b2_lo, /*reuse_sort=*/key->b2_lo == key->b_lo && key->b2_hi == key->b_hi,
+                            &ctx->wit_tail[1], ctx->ev_aux, &key->pre_b2));
         FK_TRY(msm_g1_begin(ctx, key->d_l, d_z + v_in + key->l_lo, key->l_hi - key->l_lo, &ctx->wit_tail[2], z_ready ? z_ready : ctx->ev_aux, &key->pre_l));   // L reads z itself: it need not wait for the gathers
         FK_TRY(msm_g1_begin(ctx, key->d_a, sa + key->a_lo, key->a_hi - key->a_lo, &ctx->wit_tail[3], ctx->ev_aux, &key->pre_a));
         return FK_OK;
@@ -642,7 +661,7 @@ int fk_prove_msm_array_dev(fk_ctx *ctx, const fk_key *key, int which, const void
     if (!key || !out || which < FK_ARRAY_H || which > FK_ARRAY_B_G2) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "msm over a key array: null argument or unknown array");
     FK_HIP(ctx, hipSetDevice(ctx->device));
     const uint64_t n = which == FK_ARRAY_H ? key->h_hi - key->h_lo : which == FK_ARRAY_L ? key->l_hi - key->l_lo
-                     : which == FK_ARRAY_A ? key->a_hi - key->a_lo : key->b_hi - key->b_lo;
+                     : which == FK_ARRAY_A ? key->a_hi - key->a_lo : which == FK_ARRAY_B_G1 ? key->b_hi - key->b_lo : key->b2_hi - key->b2_lo;
     if (!d_scalars && n) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "msm over a key array: null scalars");
     if (which == FK_ARRAY_B_G2) {
         G2Xyzz R;

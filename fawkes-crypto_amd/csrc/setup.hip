@@ -412,12 +412,12 @@ static int setup_impl(fk_ctx *ctx, const fk_r1cs *cs, uint32_t copies, const uin
     if (rc != FK_OK) { fk_key_free(ctx, k); return rc; }
     k->n_a = n_a; k->n_b = n_b;
     if ((rc = key_plan_slices(ctx, k, z_frac_lo, z_frac_hi)) != FK_OK) { fk_key_free(ctx, k); return rc; }
-    const uint64_t c_h = k->h_hi - k->h_lo, c_l = k->l_hi - k->l_lo, c_a = k->a_hi - k->a_lo, c_b = k->b_hi - k->b_lo;
+    const uint64_t c_h = k->h_hi - k->h_lo, c_l = k->l_hi - k->l_lo, c_a = k->a_hi - k->a_lo, c_b = k->b_hi - k->b_lo, c_b2 = k->b2_hi - k->b2_lo;
     G1Affine *d_ic = (G1Affine *)dalloc((size_t)num_input * sizeof(G1Affine));
     if (!d_ic) return fail(FK_ERR_OOM, "setup: device allocation failed");
     if (hipMalloc((void **)&k->d_h, (c_h + 1) * sizeof(G1Affine)) != hipSuccess || hipMalloc((void **)&k->d_l, (c_l + 1) * sizeof(G1Affine)) != hipSuccess ||
         hipMalloc((void **)&k->d_a, (c_a + 1) * sizeof(G1Affine)) != hipSuccess || hipMalloc((void **)&k->d_b1, (c_b + 1) * sizeof(G1Affine)) != hipSuccess ||
-        hipMalloc((void **)&k->d_b2, (c_b + 1) * sizeof(G2Affine)) != hipSuccess) return fail(FK_ERR_OOM, "setup: device allocation failed");
+        hipMalloc((void **)&k->d_b2, (c_b2 + 1) * sizeof(G2Affine)) != hipSuccess) return fail(FK_ERR_OOM, "setup: device allocation failed");
     const unsigned fb_threads = 128;
     auto fb1 = [&](const Fr *sc, size_t n, G1Affine *o) { if (n) hipLaunchKernelGGL(HIP_KERNEL_NAME(fixed_base_kernel<Fq>), dim3((unsigned)((n + fb_threads - 1) / fb_threads)), dim3(fb_threads), 0, st, d_t1, sc, n, o); };
     fb1(d_hs + k->h_lo, c_h, k->d_h);
@@ -425,7 +425,7 @@ static int setup_impl(fk_ctx *ctx, const fk_r1cs *cs, uint32_t copies, const uin
     fb1(d_e, num_input, d_ic);                              // ic = those of the inputs
     fb1(d_sa + k->a_lo, c_a, k->d_a);
     fb1(d_sb + k->b_lo, c_b, k->d_b1);
-    if (c_b) hipLaunchKernelGGL(HIP_KERNEL_NAME(fixed_base_kernel<Fq2>), dim3((unsigned)((c_b + fb_threads - 1) / fb_threads)), dim3(fb_threads), 0, st, d_t2, d_sb + k->b_lo, (size_t)c_b, k->d_b2);
+    if (c_b2) hipLaunchKernelGGL(HIP_KERNEL_NAME(fixed_base_kernel<Fq2>), dim3((unsigned)((c_b2 + fb_threads - 1) / fb_threads)), dim3(fb_threads), 0, st, d_t2, d_sb + k->b2_lo, (size_t)c_b2, k->d_b2);
     if (hipGetLastError() != hipSuccess) return fail(FK_ERR_HIP, "setup: kernel launch failed");
     if (hipMemcpyAsync(ic_out, d_ic, (size_t)num_input * sizeof(G1Affine), hipMemcpyDeviceToHost, st) != hipSuccess) return fail(FK_ERR_HIP, "setup: copy failed");
     // vk
@@ -466,7 +466,7 @@ int fk_key_download(fk_ctx *ctx, const fk_key *key, int which, void *host, size_
         case 1: src = key->d_l; bytes = (key->l_hi - key->l_lo) * 64; break;
         case 2: src = key->d_a; bytes = (key->a_hi - key->a_lo) * 64; break;
         case 3: src = key->d_b1; bytes = (key->b_hi - key->b_lo) * 64; break;
-        case 4: src = key->d_b2; bytes = (key->b_hi - key->b_lo) * 128; break;
+        case 4: src = key->d_b2; bytes = (key->b2_hi - key->b2_lo) * 128; break;
         default: FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "key download: which must be 0..4");
     }
     if (host_bytes < bytes) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "key download: buffer too small (%zu < %zu)", host_bytes, bytes);

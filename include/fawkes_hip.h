@@ -55,6 +55,11 @@ enum {
 };
 
 #define FK_Z_EQUAL_SPLIT (-1.0)   /* z_frac_lo of every key loader: equal split by shard_index / shard_count */
+/* z_frac_lo = FK_Z_WORK_SPLIT: l, a, b_g1, b_g2 laid end to end on a line measured in work (a G2 point counts FK_G2_WORK G1 points) and
+ * the line cut into shard_count equal pieces -- a rank holds one or two LARGE pieces instead of 1 / shard_count of each array (b_g1 and
+ * b_g2 are then sliced independently: fk_key_shard_info2).  h stays in blocks of the domain.  What fk_multi_* uses from 2 ranks on. */
+#define FK_Z_WORK_SPLIT (-2.0)
+#define FK_G2_WORK 2.8
 #define FK_PROOF_BYTES 256
 #define FK_G1_BYTES 64
 #define FK_G2_BYTES 128
@@ -125,6 +130,8 @@ int fk_key_synthetic(fk_ctx *ctx, uint64_t m, uint32_t num_input, uint32_t num_a
                      double z_frac_lo, double z_frac_hi, fk_key **out);
 /* out[8] = h_lo, h_hi, l_lo, l_hi, a_lo, a_hi, b_lo, b_hi: the slices this key holds */
 int fk_key_shard_info(const fk_key *key, uint64_t out[8]);
+/* the same plus b_g2's own slice: out[10] = h, l, a, b_g1, b_g2 ([lo, hi) each) */
+int fk_key_shard_info2(const fk_key *key, uint64_t out[10]);
 /* Fixed-base precomputation.  The key arrays are fixed bases, and an MI355X has room for more than the key: every
  * loader (fk_key_load, fk_key_load_bellman, fk_setup*, fk_key_synthetic) also derives, HBM permitting, the multiples
  * 2^(offset of window w) * P of each array it holds (W - 1 further copies, W = 11..15), so that the buckets of all

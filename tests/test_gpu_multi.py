@@ -111,9 +111,32 @@ def test_multi_prove_one_call_matches_oracle(ctx, oracle, world):
         for g in range(world):
             info = mc.key_shard(key, g).shard_info()
             assert info['h'] == fk.api.h_shard_range((1 << 11) - 1, g, world)
+        # round 4: from two ranks on the witness arrays are dealt BY WORK (FK_Z_WORK_SPLIT): l | a | b_g1 | b_g2 laid end to end, a G2
+        # point counting 2.8 G1 points, cut into `world` equal pieces -- the shards must tile every array exactly and carry equal work
+        cnt = mc.key_shard(key, 0).counts()
+        infos = [mc.key_shard(key, g).shard_info() for g in range(world)]
+        for arr, n_arr in (('l', cnt['n_l']), ('a', cnt['n_a']), ('b', cnt['n_b']), ('b_g2', cnt['n_b'])):
+            assert infos[0][arr][0] == 0 and infos[-1][arr][1] == n_arr, (arr, infos)
+            assert all(infos[g][arr][1] == infos[g + 1][arr][0] for g in range(world - 1)), (arr, infos)
+        if world > 1:
+            work = [sum((i[a_][1] - i[a_][0]) * w for a_, w in (('l', 1.0), ('a', 1.0), ('b', 1.0), ('b_g2', 2.8))) for i in infos]
+            assert max(work) - min(work) <= 2 * 2.8 + 1e-6, work
+            assert any(i['b'] != i['b_g2'] for i in infos)          # b_g1 and b_g2 are sliced independently
         got = mc.prove_witness(key, dr, z, r, s)
         assert got.tobytes() == want.tobytes()
         assert ref.verify(fx.key_to_py(okey), z_in[1:], ref.proof_from_borsh(got.tobytes()))
+        if world in (2, 8):
+            # the equal split of rounds 1-3 (FK_MULTI_SPLIT=equal, read at every key load): 1 / world of each array, same bytes
+            import os
+            os.environ['FK_MULTI_SPLIT'] = 'equal'
+            try:
+                key_e, _ = mc.setup(r1cs, **tox)
+            finally:
+                del os.environ['FK_MULTI_SPLIT']
+            ie = [mc.key_shard(key_e, g).shard_info() for g in range(world)]
+            assert all(i['b'] == i['b_g2'] and i['l'] == fk.api.shard_range(cnt['n_l'], g, world) for g, i in enumerate(ie))
+            assert mc.prove_witness(key_e, dr, z, r, s).tobytes() == want.tobytes()
+            key_e.free()
         # the verifying key of the sharded derivation is the oracle's
         assert np.array_equal(vk['ic'], np.array(okey.ic)) and vk['alpha_g1'].tobytes() == np.array(okey.alpha_g1).tobytes()
         # pipelined: two witnesses in flight, a different one second

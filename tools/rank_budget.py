@@ -40,6 +40,8 @@ def main():
     ap.add_argument('--copies', type=int, default=1024)
     ap.add_argument('--ranks', default='1,2,4,8')
     ap.add_argument('--reps', type=int, default=3)
+    ap.add_argument('--split', choices=('work', 'equal'), default='work', help="how l, a, b_g1, b_g2 are dealt to the ranks (FK_Z_WORK_SPLIT / FK_Z_EQUAL_SPLIT)")
+    ap.add_argument('--all-ranks', action='store_true', help='measure every rank (default: rank 0 only; with the work split the ranks differ)')
     args = ap.parse_args()
     ctx = fk.Context(0)
     r1cs, zs = bench.load_rollup_instance()
@@ -54,10 +56,10 @@ def main():
     dr = ctx.load_r1cs(r1cs, copies=copies)
     tox = {k: bench.mont(v) for k, v in bench.TOXIC.items()}
     out = {'workload': '%d rollup-style transactions, domain 2^%d' % (copies, log_m), 'ranks': {}}
+    split = {'work': fk.api.Z_WORK_SPLIT, 'equal': fk.api.Z_EQUAL_SPLIT}[args.split]
     for W in [int(x) for x in args.ranks.split(',')]:
         lw = parallel.log2_world(W)
         L = m >> lw
-        key, _ = ctx.setup(r1cs, copies=copies, shard_index=0, shard_count=W, **tox)
         send = [Buf(ctx, L * 32) for _ in range(3)]
         recv = [Buf(ctx, L * 32) for _ in range(3)]
 
@@ -73,35 +75,46 @@ def main():
             ctx.sync()
             return (time.perf_counter() - t0) / args.reps * 1e3
 
-        def ev():
-            ctx.r1cs_eval_slice_dev(dr, d_z, log_m, 0, lw, *[b.data_ptr() for b in send])
+        # with the arrays dealt by work the ranks hold different pieces: every rank's share is measured, the slowest one counts
+        ranks = range(W) if (args.all_ranks and W > 1) else [0]
+        per_rank = []
+        for g in ranks:
+            key, _ = ctx.setup(r1cs, copies=copies, shard_index=g, shard_count=W, z_frac=split if W > 1 else fk.api.Z_EQUAL_SPLIT, **tox)
 
-        def quot():
-            return parallel.quotient_distributed(ctx, 0, W, None, n, log_m, send, recv, a2a, slices_in_send=True)
+            def ev():
+                ctx.r1cs_eval_slice_dev(dr, d_z, log_m, g, lw, *[b.data_ptr() for b in send])
 
-        def msms():
-            return ctx.prove_msms_hz_r1cs_dev(key, dr, send[0].data_ptr(), d_z)
+            def quot():
+                return parallel.quotient_distributed(ctx, g, W, None, n, log_m, send, recv, a2a, slices_in_send=True)
 
-        def whole():
-            ev(); blk = quot()
-            return ctx.prove_msms_hz_r1cs_dev(key, dr, blk.data_ptr(), d_z)
+            def msms():
+                return ctx.prove_msms_hz_r1cs_dev(key, dr, send[0].data_ptr(), d_z)
 
-        t_ev = timed(ev)
-        ev(); t_q = timed(quot)
-        t_m = timed(msms)
-        t_all = timed(whole)
+            def whole():
+                ev(); blk = quot()
+                return ctx.prove_msms_hz_r1cs_dev(key, dr, blk.data_ptr(), d_z)
+
+            t_ev = timed(ev)
+            ev(); t_q = timed(quot)
+            t_m = timed(msms)
+            t_all = timed(whole)
+            info = key.shard_info()
+            per_rank.append({'rank': g, 'eval_slice_ms': t_ev, 'quotient_compute_ms': t_q, 'msms_ms': t_m, 'whole_share_ms': t_all, 'levels': key.precomputed(),
+                             'points': {k_: v_[1] - v_[0] for k_, v_ in info.items()}})
+            key.free()
+        worst = max(per_rank, key=lambda e: e['whole_share_ms'])
         # exchanges: 7 per proof, each rank sends (W - 1) / W of its L * 32 bytes, one chunk per peer, every peer on a link of its own
         chunk = L * 32 // W
         t_x = 7 * (chunk / (XGMI_GBPS_PER_LINK_PER_DIRECTION * 1e9)) * 1e3 if W > 1 else 0.0
-        out['ranks'][str(W)] = {'eval_slice_ms': t_ev, 'quotient_compute_ms': t_q, 'msms_ms': t_m, 'whole_share_ms': t_all,
-                                'witness_upload_bytes_per_rank': int(z.nbytes), 'exchange_bytes_per_rank_per_proof': 7 * chunk * (W - 1),
-                                'exchange_ms_by_link_arithmetic': t_x,
-                                'levels': key.precomputed(), 'h_points': key.shard_info()['h'][1] - key.shard_info()['h'][0]}
-        print('W = %d: eval %.2f ms, quotient %.2f ms, MSMs %.2f ms, whole share %.2f ms; exchanges %.2f ms by link arithmetic' % (W, t_ev, t_q, t_m, t_all, t_x),
-              flush=True)
+        out['ranks'][str(W)] = dict(worst, split=args.split if W > 1 else None, per_rank=per_rank, witness_upload_bytes_per_rank=int(z.nbytes),
+                                    exchange_bytes_per_rank_per_proof=7 * chunk * (W - 1), exchange_ms_by_link_arithmetic=t_x)
+        print('W = %d (%s split): slowest rank %d: eval %.2f ms, quotient %.2f ms, MSMs %.2f ms, whole share %.2f ms; exchanges %.2f ms by link arithmetic'
+              % (W, args.split if W > 1 else '-', worst['rank'], worst['eval_slice_ms'], worst['quotient_compute_ms'], worst['msms_ms'], worst['whole_share_ms'], t_x), flush=True)
+        if len(per_rank) > 1:
+            print('        per rank (whole share ms / points l, a, b_g1, b_g2): ' + '; '.join(
+                '%d: %.1f / %s' % (e['rank'], e['whole_share_ms'], ','.join('%.1fM' % (e['points'][k_] / 1e6) for k_ in ('l', 'a', 'b', 'b_g2'))) for e in per_rank), flush=True)
         for b in send + recv:
             b.free()
-        key.free()
     print(json.dumps(out))
 
 
