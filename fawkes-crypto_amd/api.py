@@ -295,7 +295,7 @@ class DeviceKey:
         """this key's slice of one array as numpy: 'h' | 'l' | 'a' | 'b_g1' (n,64) or 'b_g2' (n,128)"""
         which = ['h', 'l', 'a', 'b_g1', 'b_g2'].index(name)
         info = self.shard_info()
-        lo, hi = info[{'h': 'h', 'l': 'l', 'a': 'a', 'b_g1': 'b', 'b_g2': 'b'}[name]]
+        lo, hi = info[{'h': 'h', 'l': 'l', 'a': 'a', 'b_g1': 'b', 'b_g2': 'b_g2'}[name]]
         w = 128 if name == 'b_g2' else 64
         out = np.zeros((max(hi - lo, 0), w), np.uint8)
         buf = out if out.size else np.zeros((1, w), np.uint8)

@@ -1,6 +1,6 @@
 """Fixed-base precomputation of the key (fk_key_precomputed; msm.hip: merged bucket set): with the window levels
 2^(offset_w) * P resident, all Pippenger windows share ONE bucket set.  Same group elements, so every proof must stay
-bit-identical to the oracle's.  By default only arrays of >= 2^24 points get levels; the tests lower the threshold
+bit-identical to the oracle's.  By default only arrays of >= 2^21 points get levels (round 4; 2^24 before); the tests lower the threshold
 (FK_MSM_PRE_MIN_LOG2) so that the merged path -- G1 and G2, oversized buckets included -- runs on small keys."""
 import numpy as np
 import pytest
@@ -102,3 +102,36 @@ def test_merged_sharded_setup_and_weighted_shards(ctx, oracle, low_threshold):
             sk.free()
         assert ctx.prove_assemble(dk, np.stack(parts), r, s).tobytes() == want
     dk.free()
+
+
+@pytest.mark.parametrize('levels', [True, False])
+def test_one_multiplication_over_a_resident_key_array(ctx, oracle, monkeypatch, levels):
+    """fk_prove_msm_array_dev (round 4: the micro entry point behind bench.py's standalone figures): ONE multiplication over each of
+    the key's resident arrays -- with its fixed-base levels and without -- against the oracle's multiexp over the downloaded array,
+    uniform and witness-like scalars; also for the shards of a key split by work (b_g1 and b_g2 sliced independently)."""
+    import c_oracle as co
+    import fawkes_crypto_amd as fk
+    monkeypatch.setenv('FK_MSM_PRE_MIN_LOG2', '8' if levels else '30')
+    csr, key, z, _ = _instance(oracle, 77, 5000, 3, 5200)
+    params = params_from_oracle_key(key, r1cs_product(csr))
+    for shard, count, split in ((0, 1, fk.api.Z_EQUAL_SPLIT), (1, 3, fk.api.Z_WORK_SPLIT), (2, 3, fk.api.Z_WORK_SPLIT)):
+        dk = ctx.load_key(params, shard_index=shard, shard_count=count, z_frac=split)
+        assert any(v > 1 for v in dk.precomputed().values()) == levels
+        info = dk.shard_info()
+        if count > 1:
+            assert info['b'] != info['b_g2']
+        for arr, cnt_key in (('h', 'h'), ('l', 'l'), ('a', 'a'), ('b_g1', 'b'), ('b_g2', 'b_g2')):
+            n = info[cnt_key][1] - info[cnt_key][0]
+            bases = dk.download(arr)
+            assert bases.shape == (n, 128 if arr == 'b_g2' else 64)
+            if n == 0:
+                continue
+            d_s = ctx.dev_alloc(n * 32)
+            for kind in (0, 1):
+                ctx.gen_scalars_dev(d_s, n, 900 + kind, kind)
+                sc = ctx.download(d_s, n * 32, np.uint64).reshape(-1, 4)
+                got = ctx.prove_msm_array_dev(dk, arr, d_s)
+                want = (co.msm_g2 if arr == 'b_g2' else co.msm_g1)(bases, sc)
+                assert got.tobytes() == np.asarray(want).tobytes(), (arr, kind, shard, count)
+            ctx.dev_free(d_s)
+        dk.free()
