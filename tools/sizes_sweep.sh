@@ -2,10 +2,10 @@
 set -u
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out/sweep
 for lg in 20 22 24 26 27; do
-  python3 bench.py --workload synthetic --log2n $lg --steps 8 --warmup 2 --no-cpu-baseline --no-standalone > gpurun_out/sweep/syn$lg.log 2>&1
+  python3 bench.py --workload synthetic --log2n $lg --steps 8 --warmup 2 --no-cpu-baseline --no-standalone --no-other-sizes > gpurun_out/sweep/syn$lg.log 2>&1
 done
 for c in 64 256; do
-  python3 bench.py --copies $c --steps 8 --warmup 2 --no-cpu-baseline --no-standalone --no-untiled > gpurun_out/sweep/roll$c.log 2>&1
+  python3 bench.py --copies $c --steps 8 --warmup 2 --no-cpu-baseline --no-standalone --no-untiled --no-other-sizes > gpurun_out/sweep/roll$c.log 2>&1
 done
 python3 - <<'PY'
 import json,glob
