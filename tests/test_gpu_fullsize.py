@@ -179,3 +179,44 @@ def test_config3_2p25_filled_domain_single_gpu_and_one_call_on_8_ranks(ctx):
         mkey.free(); mdr.free()
     finally:
         mc.close()
+
+
+def test_full_size_properties_transform_round_trips_and_two_routes_to_one_multiplication(ctx):
+    """Size-independent properties at BASELINE's full sizes, where no CPU oracle follows (SURVEY 8(c) substitute pins):
+    * iNTT(NTT(x)) = x and icoset(coset(x)) = x on 2^25 and 2^26 random elements, every byte compared;
+    * ONE 2^25-point G1 multiplication by two independent routes: over the key's resident h array with its fixed-base levels (one
+      merged bucket set, c = 22, 12 digits per scalar) and over the SAME points as plain device memory in two halves (the W-bucket-set
+      path, c = 20, 13 digits; bare-pointer entry point), the halves added by the oracle's group law -- same affine point."""
+    import bench
+    import c_oracle as co
+    for log_n in (25, 26):
+        n = 1 << log_n
+        d = ctx.dev_alloc(n * 32)
+        ctx.gen_scalars_dev(d, n, 4242 + log_n, 0)
+        want = ctx.download(d, n * 32, np.uint64)
+        for coset in (False, True):
+            ctx.ntt_dev(d, log_n, inverse=False, coset=coset)
+            mid = ctx.download(d, 1 << 20, np.uint64)
+            assert not np.array_equal(mid, want[:mid.size])
+            ctx.ntt_dev(d, log_n, inverse=True, coset=coset)
+            got = ctx.download(d, n * 32, np.uint64)
+            assert np.array_equal(got, want), (log_n, coset)
+        ctx.dev_free(d)
+    ctx.trim()
+    # a synthetic key of the benchmark's shape: 2^25 - 1 valid h bases with their levels
+    m = 1 << 25
+    key = ctx.synthetic_key(m, 2, 1 << 20, 1 << 20, 1 << 19, seed=5)
+    assert key.precomputed()['h'] > 0
+    n_h = m - 1
+    d_s = ctx.dev_alloc(n_h * 32)
+    ctx.gen_scalars_dev(d_s, n_h, 99, 0)
+    merged = ctx.prove_msm_array_dev(key, 'h', d_s)
+    bases = key.download('h')
+    key.free()
+    d_b = ctx.dev_alloc(bases.nbytes)
+    ctx.upload(d_b, bases)
+    half = n_h // 2
+    p0 = ctx.msm_g1_dev(d_b, d_s, half)
+    p1 = ctx.msm_g1_dev(d_b + half * 64, d_s + half * 32, n_h - half)
+    ctx.dev_free(d_b); ctx.dev_free(d_s)
+    assert merged.tobytes() != bytes(64) and merged.tobytes() == np.asarray(co.g1_add(p0, p1)).tobytes()
