@@ -35,7 +35,7 @@ EXPORTED_SYMBOLS = [
     'fk_fr_mul_batch', 'fk_ntt', 'fk_ntt_dev', 'fk_quotient_h', 'fk_quotient_h_dev',
     'fk_msm_g1', 'fk_msm_g2', 'fk_msm_g1_dev', 'fk_msm_g2_dev',
     'fk_gen_points_g1_dev', 'fk_gen_points_g2_dev', 'fk_gen_scalars_dev',
-    'fk_synthesize', 'fk_stats_reset', 'fk_stats_get', 'fk_calibrate', 'fk_verify', 'fk_verify_batch_dev', 'fk_shard_range', 'fk_h_shard_range',
+    'fk_synthesize', 'fk_stats_reset', 'fk_stats_get', 'fk_calibrate', 'fk_verify', 'fk_verify_batch_dev', 'fk_shard_range', 'fk_h_shard_range', 'fk_work_shard_ranges',
     'fk_dq_gather_dev', 'fk_dq_local_dev', 'fk_dq_cross_dev', 'fk_dq_cross_sub_dev',
     'fk_setup', 'fk_setup_tiled', 'fk_r1cs_load_tiled', 'fk_key_download', 'fk_key_load_bellman', 'fk_key_vk', 'fk_key_counts', 'fk_key_precomputed',
     'fk_gates_decode', 'fk_gates_free', 'fk_gates_info', 'fk_gates_export', 'fk_r1cs_load_gates',
@@ -1085,6 +1085,15 @@ def shard_range(n, index, count):
     lo, hi = C.c_uint64(), C.c_uint64()
     lib.fk_shard_range(C.c_uint64(n), C.c_uint32(index), C.c_uint32(count), C.byref(lo), C.byref(hi))
     return lo.value, hi.value
+
+
+def work_shard_ranges(n_l, n_a, n_b, index, count):
+    """fk_work_shard_ranges: dict of the [lo, hi) slices of l, a, b (= b_g1), b_g2 of shard `index` of `count` under Z_WORK_SPLIT"""
+    lib = load_library()
+    out = (C.c_uint64 * 8)()
+    lib.fk_work_shard_ranges(C.c_uint64(n_l), C.c_uint64(n_a), C.c_uint64(n_b), C.c_uint32(index), C.c_uint32(count), out)
+    v = list(out)
+    return dict(l=(v[0], v[1]), a=(v[2], v[3]), b=(v[4], v[5]), b_g2=(v[6], v[7]))
 
 
 def h_shard_range(n_h, index, count):

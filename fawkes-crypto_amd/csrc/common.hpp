@@ -229,6 +229,28 @@ static inline void h_slice(uint64_t n_h, uint32_t idx, uint32_t cnt, uint64_t *l
     *lo = a; *hi = b;
 }
 
+// FK_Z_WORK_SPLIT: the four witness arrays laid end to end on a line measured in WORK (a G2 point costs FK_G2_WORK G1 points: the
+// accumulation of a 128-byte point is ~2.8 G1 additions), the line cut into `count` equal pieces; out = [lo, hi) of l, a, b_g1, b_g2
+// for piece `index`.  A rank then holds one or two LARGE pieces (e.g. 19.4 M G1 points of l) instead of an eighth of each of the
+// four arrays: fewer, larger multiplications per rank (the fixed sort set-up and reduction latency of a multiplication does not
+// shrink with its size, and the accumulation of a 4 M-point shard runs at 75 - 85 % of its full-size efficiency, DESIGN.md section
+// 4.4).  h stays in blocks of the domain (what the distributed quotient leaves on the rank).  The cuts are monotone per array, so
+// the pieces tile every array exactly.
+static inline void work_slices(uint64_t n_l, uint64_t n_a, uint64_t n_b, uint32_t index, uint32_t count, uint64_t out[8]) {
+    const long double seg_w[4] = {1.0L, 1.0L, 1.0L, (long double)FK_G2_WORK};
+    const uint64_t seg_n[4] = {n_l, n_a, n_b, n_b};
+    long double total = 0; for (int i = 0; i < 4; i++) total += seg_w[i] * (long double)seg_n[i];
+    auto cut = [&](uint32_t g, int seg) -> uint64_t {           // index in array `seg` of the g-th cut of the line
+        if (g >= count) return seg_n[seg];
+        const long double x = total * (long double)g / (long double)count;
+        long double s0 = 0; for (int i = 0; i < seg; i++) s0 += seg_w[i] * (long double)seg_n[i];
+        if (x <= s0) return 0;
+        const long double q = (x - s0) / seg_w[seg];
+        return q >= (long double)seg_n[seg] ? seg_n[seg] : (uint64_t)q;
+    };
+    for (int seg = 0; seg < 4; seg++) { out[2 * seg] = cut(index, seg); out[2 * seg + 1] = cut(index + 1, seg); }
+}
+
 // Which part of l, a, b_g1, b_g2 a key holds (one rule for fk_key_load, fk_key_load_bellman, fk_setup*, fk_key_synthetic).
 // zlo < 0 (FK_Z_EQUAL_SPLIT): the equal split [index/count, (index+1)/count).  Otherwise the fractions [zlo, zhi) of
 // every array -- and (0, 0) then IS the empty slice (the rank that computes the quotient may hold no witness points at
@@ -246,28 +268,10 @@ static inline int key_plan_slices(fk_ctx *ctx, fk_key *k, double zlo, double zhi
         if (b < a) b = a;
         *olo = a; *ohi = b;
     };
-    if (zlo <= -1.5) {
-        // FK_Z_WORK_SPLIT: the four witness arrays laid end to end on a line measured in WORK (a G2 point costs FK_G2_WORK G1 points:
-        // the accumulation of a 128-byte point is ~2.8 G1 additions), the line cut into shard_count equal pieces.  A rank then holds one
-        // or two LARGE pieces (e.g. 19.7 M G1 points of l) instead of an eighth of each of the four arrays: fewer, larger
-        // multiplications per rank (the fixed sort set-up and reduction latency of a multiplication does not shrink with its size,
-        // and the accumulation of a 4 M-point shard runs at 75 - 85 % of its full-size efficiency).  h stays in
-        // blocks of the domain (what the distributed quotient leaves on the rank).  Cuts are monotone per array, so the shards tile it.
-        const long double seg_w[4] = {1.0L, 1.0L, 1.0L, (long double)FK_G2_WORK};
-        const uint64_t seg_n[4] = {k->n_l, k->n_a, k->n_b, k->n_b};
-        long double total = 0; for (int i = 0; i < 4; i++) total += seg_w[i] * (long double)seg_n[i];
-        auto cut = [&](uint32_t g, int seg) -> uint64_t {           // index in array `seg` of the g-th cut of the line
-            if (g >= k->shard_count) return seg_n[seg];
-            const long double x = total * (long double)g / (long double)k->shard_count;
-            long double s0 = 0; for (int i = 0; i < seg; i++) s0 += seg_w[i] * (long double)seg_n[i];
-            if (x <= s0) return 0;
-            const long double q = (x - s0) / seg_w[seg];
-            return q >= (long double)seg_n[seg] ? seg_n[seg] : (uint64_t)q;
-        };
-        k->l_lo = cut(k->shard_index, 0); k->l_hi = cut(k->shard_index + 1, 0);
-        k->a_lo = cut(k->shard_index, 1); k->a_hi = cut(k->shard_index + 1, 1);
-        k->b_lo = cut(k->shard_index, 2); k->b_hi = cut(k->shard_index + 1, 2);
-        k->b2_lo = cut(k->shard_index, 3); k->b2_hi = cut(k->shard_index + 1, 3);
+    if (zlo <= -1.5) {         // FK_Z_WORK_SPLIT
+        uint64_t r[8];
+        work_slices(k->n_l, k->n_a, k->n_b, k->shard_index, k->shard_count, r);
+        k->l_lo = r[0]; k->l_hi = r[1]; k->a_lo = r[2]; k->a_hi = r[3]; k->b_lo = r[4]; k->b_hi = r[5]; k->b2_lo = r[6]; k->b2_hi = r[7];
         return FK_OK;
     }
     if (zlo < 0.0) { eq(k->n_l, &k->l_lo, &k->l_hi); eq(k->n_a, &k->a_lo, &k->a_hi); eq(k->n_b, &k->b_lo, &k->b_hi); k->b2_lo = k->b_lo; k->b2_hi = k->b_hi; return FK_OK; }

@@ -1011,6 +1011,11 @@ void fk_shard_range(uint64_t n, uint32_t index, uint32_t count, uint64_t *lo, ui
     slice(n, index, count, lo, hi);
 }
 
+void fk_work_shard_ranges(uint64_t n_l, uint64_t n_a, uint64_t n_b, uint32_t index, uint32_t count, uint64_t out[8]) {
+    if (!count || index >= count || !out) return;
+    work_slices(n_l, n_a, n_b, index, count, out);
+}
+
 void fk_h_shard_range(uint64_t n_h, uint32_t index, uint32_t count, uint64_t *lo, uint64_t *hi) {
     if (!count || !lo || !hi) return;
     h_slice(n_h, index, count, lo, hi);

@@ -216,6 +216,9 @@ void fk_shard_range(uint64_t n, uint32_t index, uint32_t count, uint64_t *lo, ui
 /* the same for the h array (n_h = m - 1 bases): blocks of the evaluation domain, [index*m/count, (index+1)*m/count)
  * clipped to n_h -- the block of quotient coefficients the distributed quotient below leaves on that rank. */
 void fk_h_shard_range(uint64_t n_h, uint32_t index, uint32_t count, uint64_t *lo, uint64_t *hi);
+/* the slices of l, a, b_g1, b_g2 ([lo, hi) each: out[8]) that shard `index` of `count` holds under FK_Z_WORK_SPLIT (pure arithmetic:
+ * what every key loader applies; a host that shards keys itself calls this) */
+void fk_work_shard_ranges(uint64_t n_l, uint64_t n_a, uint64_t n_b, uint32_t index, uint32_t count, uint64_t out[8]);
 
 /* Distributed quotient: bellman's EvaluationDomain pipeline (domain.rs ifft / coset_fft / mul_assign / sub_assign /
  * divide_by_z_on_coset / icoset_fft) over W = 2^log_w GPUs, one process each ("NTT butterfly stages

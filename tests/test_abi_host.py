@@ -184,3 +184,27 @@ else:
     out = subprocess.run([sys.executable, '-c', child], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, (out.returncode, out.stderr[-800:])          # not killed by SIGABRT (std::terminate)
     assert out.stdout.strip().splitlines()[-1] == 'code 5', out.stdout + out.stderr[-400:]
+
+
+def test_work_split_planner_tiles_every_array_and_balances_the_work():
+    """FK_Z_WORK_SPLIT (round 4): l | a | b_g1 | b_g2 laid end to end on a line measured in work (a G2 point = 2.8 G1 points), cut
+    into `count` equal pieces.  Host arithmetic (fk_work_shard_ranges: what every key loader applies): for random array sizes and
+    shard counts the pieces tile every array exactly, in order, and carry equal work up to one point per cut."""
+    import random
+    from fawkes_crypto_amd import api
+    rnd = random.Random(2026)
+    cases = [(33597818, 32100559, 23632335, w) for w in (1, 2, 3, 4, 8)] + [(0, 5, 0, 3), (1, 1, 1, 8), (7, 0, 0, 2)]
+    cases += [(rnd.randrange(0, 1 << rnd.randrange(1, 28)), rnd.randrange(0, 1 << rnd.randrange(1, 28)), rnd.randrange(0, 1 << rnd.randrange(1, 27)),
+               rnd.choice([1, 2, 3, 4, 5, 7, 8, 16, 64])) for _ in range(200)]
+    for n_l, n_a, n_b, count in cases:
+        pieces = [api.work_shard_ranges(n_l, n_a, n_b, g, count) for g in range(count)]
+        for arr, n in (('l', n_l), ('a', n_a), ('b', n_b), ('b_g2', n_b)):
+            assert pieces[0][arr][0] == 0 and pieces[-1][arr][1] == n
+            assert all(lo <= hi for lo, hi in (p[arr] for p in pieces))
+            assert all(pieces[g][arr][1] == pieces[g + 1][arr][0] for g in range(count - 1))
+        work = [sum((p[a_][1] - p[a_][0]) * w for a_, w in (('l', 1.0), ('a', 1.0), ('b', 1.0), ('b_g2', 2.8))) for p in pieces]
+        assert max(work) - min(work) <= 2 * 2.8 + 1e-3, (n_l, n_a, n_b, count, work)
+    # the benchmark's key on 8 ranks: one or two LARGE pieces per rank
+    p8 = [api.work_shard_ranges(33597818, 32100559, 23632335, g, 8) for g in range(8)]
+    assert p8[0]['l'][1] - p8[0]['l'][0] > 19e6 and p8[0]['a'] == (0, 0) and p8[7]['b_g2'][1] == 23632335 and p8[7]['l'][0] == p8[7]['l'][1]
+    assert all(sum(1 for a_ in ('l', 'a', 'b', 'b_g2') if p[a_][1] > p[a_][0]) <= 2 for p in p8)
