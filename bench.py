@@ -698,9 +698,14 @@ def main():
     dq_ok = multi and (world & (world - 1)) == 0 and world <= 8
     dist_q = dq_ok and (dq_env == '1' or (dq_env != '0' and (world >= 4 or world == 1)))
     fracs = parallel.plan_z_fractions(world, m, num_aux, n_a, n_b)
+    # balanced schedule (2 ranks, rank counts that are not a power of two): since round 4 the key is split for "quotient on rank 0" --
+    # rank 0 holds ALL of h (it evaluates a, b, c, computes the whole quotient and H; that fixed work counts towards its piece of the
+    # work line), the other ranks hold witness pieces only: no h slices travel.  FK_MULTI_SPLIT=equal: the fraction split of rounds 1-3.
+    q0_split = world > 1 and not dist_q and os.environ.get('FK_MULTI_SPLIT') != 'equal'
     tox = {k: mont(v) for k, v in TOXIC.items()}
     key, vk = ctx.setup(r1cs, shard_index=rank, shard_count=world, copies=copies,
-                        z_frac=fracs[rank] if (world > 1 and not dist_q) else (fk.api.Z_WORK_SPLIT if (world > 1 and os.environ.get('FK_MULTI_SPLIT') != 'equal') else fk.api.Z_EQUAL_SPLIT), **tox)
+                        z_frac=fk.api.Z_WORK_SPLIT_Q0 if q0_split else fracs[rank] if (world > 1 and not dist_q) else
+                        (fk.api.Z_WORK_SPLIT if (world > 1 and os.environ.get('FK_MULTI_SPLIT') != 'equal') else fk.api.Z_EQUAL_SPLIT), **tox)
     pre_levels = key.precomputed()        # fixed-base window levels per key array (0 = none: FK_MSM_PRECOMP=0 or HBM short)
     r, s = mont(0xA11CE), mont(0xB0B)
     d_dens = dr.density_ptrs()
@@ -710,7 +715,7 @@ def main():
         recv = [torch.empty(m // world * 32, dtype=torch.uint8, device=dev) for _ in range(3)]
         a2a = parallel.torch_all_to_all(ctx)
     elif multi:
-        h_ranges = [fk.api.h_shard_range(m - 1, g, world) for g in range(world)]
+        h_ranges = ([(0, m - 1)] + [(m - 1, m - 1)] * (world - 1)) if q0_split else [fk.api.h_shard_range(m - 1, g, world) for g in range(world)]
         h_full_buf = torch.empty(m * 32, dtype=torch.uint8, device=dev) if rank == 0 else None
         recv_buf = torch.empty(max(h_ranges[rank][1] - h_ranges[rank][0], 1) * 32, dtype=torch.uint8, device=dev) if rank > 0 else None
         work = [torch.empty(m * 32, dtype=torch.uint8, device=dev) for _ in range(3)] if rank == 0 else [None] * 3
@@ -941,7 +946,8 @@ def main():
                        'msm_points': {'h': m - 1, 'l': num_aux, 'a': n_a, 'b_g1': n_b, 'b_g2': n_b},
                        'msm_fixed_base_levels': pre_levels,
                        'witness': '%.1f%% zeros, %.1f%% ones, rest dense 254-bit' % (100.0 * zeros / nv, 100.0 * ones / nv),
-                       'witness_array_split': None if world == 1 else ('fractions (balanced schedule)' if not dist_q else 'equal' if os.environ.get('FK_MULTI_SPLIT') == 'equal' else
+                       'witness_array_split': None if world == 1 else ('quotient on rank 0: all of h and a piece of the work line on rank 0, witness pieces elsewhere (FK_Z_WORK_SPLIT_Q0); nothing but 384-byte sums exchanged' if q0_split else
+                                                                        'fractions (balanced schedule)' if not dist_q else 'equal' if os.environ.get('FK_MULTI_SPLIT') == 'equal' else
                                                                         'by work: l | a | b_g1 | b_g2 cut into N equal pieces of work (FK_Z_WORK_SPLIT)'),
                        'parallelism': 'msm-shard%d%s' % (world, '' if not multi else
                                                          '+distributed-quotient (7 all-to-all per proof)' if dist_q else '+balanced-quotient')},

@@ -18,6 +18,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 FK_PROOF_BYTES = 256
 Z_EQUAL_SPLIT = (-1.0, -1.0)     # FK_Z_EQUAL_SPLIT: l / a / b sliced like h; any (lo, hi) with lo >= 0 is a fraction range, (0, 0) = empty
+Z_WORK_SPLIT_Q0 = (-3.0, -3.0)   # FK_Z_WORK_SPLIT_Q0: all of h on shard 0 (which computes the whole quotient), its fixed work counted into the work line
 Z_WORK_SPLIT = (-2.0, -2.0)      # FK_Z_WORK_SPLIT: l | a | b_g1 | b_g2 cut by work (G2 = 2.8 G1): one or two large pieces per rank
 FK_MSM_RESULT_BYTES = 4 * 64 + 128
 FR_MODULUS = 21888242871839275222246405745257275088548364400416034343698204186575808495617
@@ -35,7 +36,7 @@ EXPORTED_SYMBOLS = [
     'fk_fr_mul_batch', 'fk_ntt', 'fk_ntt_dev', 'fk_quotient_h', 'fk_quotient_h_dev',
     'fk_msm_g1', 'fk_msm_g2', 'fk_msm_g1_dev', 'fk_msm_g2_dev',
     'fk_gen_points_g1_dev', 'fk_gen_points_g2_dev', 'fk_gen_scalars_dev',
-    'fk_synthesize', 'fk_stats_reset', 'fk_stats_get', 'fk_calibrate', 'fk_verify', 'fk_verify_batch_dev', 'fk_shard_range', 'fk_h_shard_range', 'fk_work_shard_ranges',
+    'fk_synthesize', 'fk_stats_reset', 'fk_stats_get', 'fk_calibrate', 'fk_verify', 'fk_verify_batch_dev', 'fk_shard_range', 'fk_h_shard_range', 'fk_work_shard_ranges', 'fk_work_shard_ranges_q0',
     'fk_dq_gather_dev', 'fk_dq_local_dev', 'fk_dq_cross_dev', 'fk_dq_cross_sub_dev',
     'fk_setup', 'fk_setup_tiled', 'fk_r1cs_load_tiled', 'fk_key_download', 'fk_key_load_bellman', 'fk_key_vk', 'fk_key_counts', 'fk_key_precomputed',
     'fk_gates_decode', 'fk_gates_free', 'fk_gates_info', 'fk_gates_export', 'fk_r1cs_load_gates',
@@ -1087,11 +1088,15 @@ def shard_range(n, index, count):
     return lo.value, hi.value
 
 
-def work_shard_ranges(n_l, n_a, n_b, index, count):
-    """fk_work_shard_ranges: dict of the [lo, hi) slices of l, a, b (= b_g1), b_g2 of shard `index` of `count` under Z_WORK_SPLIT"""
+def work_shard_ranges(n_l, n_a, n_b, index, count, q0_domain=None):
+    """fk_work_shard_ranges: dict of the [lo, hi) slices of l, a, b (= b_g1), b_g2 of shard `index` of `count` under Z_WORK_SPLIT
+    (q0_domain = m: under Z_WORK_SPLIT_Q0, fk_work_shard_ranges_q0)"""
     lib = load_library()
     out = (C.c_uint64 * 8)()
-    lib.fk_work_shard_ranges(C.c_uint64(n_l), C.c_uint64(n_a), C.c_uint64(n_b), C.c_uint32(index), C.c_uint32(count), out)
+    if q0_domain is None:
+        lib.fk_work_shard_ranges(C.c_uint64(n_l), C.c_uint64(n_a), C.c_uint64(n_b), C.c_uint32(index), C.c_uint32(count), out)
+    else:
+        lib.fk_work_shard_ranges_q0(C.c_uint64(n_l), C.c_uint64(n_a), C.c_uint64(n_b), C.c_uint64(q0_domain), C.c_uint32(index), C.c_uint32(count), out)
     v = list(out)
     return dict(l=(v[0], v[1]), a=(v[2], v[3]), b=(v[4], v[5]), b_g2=(v[6], v[7]))
 

@@ -236,13 +236,20 @@ static inline void h_slice(uint64_t n_h, uint32_t idx, uint32_t cnt, uint64_t *l
 // shrink with its size, and the accumulation of a 4 M-point shard runs at 75 - 85 % of its full-size efficiency, DESIGN.md section
 // 4.4).  h stays in blocks of the domain (what the distributed quotient leaves on the rank).  The cuts are monotone per array, so
 // the pieces tile every array exactly.
-static inline void work_slices(uint64_t n_l, uint64_t n_a, uint64_t n_b, uint32_t index, uint32_t count, uint64_t out[8]) {
+// handicap: fixed work of piece 0 in the line's units (FK_Z_WORK_SPLIT_Q0: the evaluation, the whole quotient and H on shard 0); the line is
+// then total + handicap long, cut into equal pieces, and piece 0's part of the ARRAYS is what is left of its piece (possibly nothing).
+static inline void work_slices(uint64_t n_l, uint64_t n_a, uint64_t n_b, uint32_t index, uint32_t count, uint64_t out[8], long double handicap = 0.0L) {
     const long double seg_w[4] = {1.0L, 1.0L, 1.0L, (long double)FK_G2_WORK};
     const uint64_t seg_n[4] = {n_l, n_a, n_b, n_b};
     long double total = 0; for (int i = 0; i < 4; i++) total += seg_w[i] * (long double)seg_n[i];
     auto cut = [&](uint32_t g, int seg) -> uint64_t {           // index in array `seg` of the g-th cut of the line
         if (g >= count) return seg_n[seg];
-        const long double x = total * (long double)g / (long double)count;
+        if (g == 0) return 0;
+        long double x;
+        if (handicap > 0 && count > 1 && handicap * (long double)count >= total + handicap)
+            x = total * (long double)(g - 1) / (long double)(count - 1);      // piece 0's fixed work alone fills its share: the arrays go to the others, equally
+        else
+            x = (total + handicap) * (long double)g / (long double)count - handicap;
         long double s0 = 0; for (int i = 0; i < seg; i++) s0 += seg_w[i] * (long double)seg_n[i];
         if (x <= s0) return 0;
         const long double q = (x - s0) / seg_w[seg];
@@ -268,9 +275,11 @@ static inline int key_plan_slices(fk_ctx *ctx, fk_key *k, double zlo, double zhi
         if (b < a) b = a;
         *olo = a; *ohi = b;
     };
-    if (zlo <= -1.5) {         // FK_Z_WORK_SPLIT
+    if (zlo <= -1.5) {         // FK_Z_WORK_SPLIT, FK_Z_WORK_SPLIT_Q0
         uint64_t r[8];
-        work_slices(k->n_l, k->n_a, k->n_b, k->shard_index, k->shard_count, r);
+        const bool q0 = zlo <= -2.5 && k->shard_count > 1;
+        if (q0) { k->h_lo = k->shard_index == 0 ? 0 : k->n_h; k->h_hi = k->n_h; }           // all of h on shard 0, none elsewhere
+        work_slices(k->n_l, k->n_a, k->n_b, k->shard_index, k->shard_count, r, q0 ? (long double)FK_Q0_HANDICAP * (long double)k->m : 0.0L);
         k->l_lo = r[0]; k->l_hi = r[1]; k->a_lo = r[2]; k->a_hi = r[3]; k->b_lo = r[4]; k->b_hi = r[5]; k->b2_lo = r[6]; k->b2_hi = r[7];
         return FK_OK;
     }

@@ -294,7 +294,21 @@ static int prove_rank(fk_multi *M, int rank, const fk_multi_key *K, const fk_mul
     if (M->n == 1 && !M->force_exchange) return fk_prove_r1cs_dev(ctx, key, rs, d_z, r_, s_, out, tm);       // nothing to cut: the single-GPU prover
     const uint32_t log_m = ceil_log2_u64(key->m);
     uint8_t *part = me.part;
-    if (M->pow2 && log_m >= 2 * M->log_w) {
+    // the key's h slices say which schedule it was loaded for: all of h on rank 0 = "quotient on rank 0" (no exchange at all)
+    const bool q0 = M->n > 1 && K->shard[0]->h_hi - K->shard[0]->h_lo == K->shard[0]->n_h && K->shard[1]->h_hi == K->shard[1]->h_lo;
+    if (q0) {
+        if (rank == 0) {
+            const size_t mb = key->m * sizeof(Fr);
+            FK_HIP(ctx, ctx->stage_a.reserve(mb)); FK_HIP(ctx, ctx->stage_b.reserve(mb)); FK_HIP(ctx, ctx->stage_c.reserve(mb));
+            FK_TRY(fk_r1cs_eval_dev(ctx, rs, d_z, ctx->stage_a.p, ctx->stage_b.p, ctx->stage_c.p));
+            ctx->qidx = &rs->qidx;
+            const int rc = fk_prove_msms_dev(ctx, key, ctx->stage_a.p, ctx->stage_b.p, ctx->stage_c.p, rows, d_z, rs->d_a_aux, rs->d_b_in, rs->d_b_aux, part, nullptr);
+            ctx->qidx = nullptr;
+            FK_TRY(rc);
+        } else {
+            FK_TRY(fk_prove_msms_hz_r1cs_dev(ctx, key, rs, nullptr, d_z, part));          // witness multiplications only: this rank holds no h
+        }
+    } else if (M->pow2 && log_m >= 2 * M->log_w) {
         const uint64_t L = key->m >> M->log_w;
         if (me.buf_elems < L) {
             FK_HIP(ctx, hipStreamSynchronize(ctx->stream)); FK_HIP(ctx, hipStreamSynchronize(me.xs));
@@ -338,10 +352,18 @@ static int prove_rank(fk_multi *M, int rank, const fk_multi_key *K, const fk_mul
 
 // How the witness arrays are dealt to the ranks: by WORK from two ranks on (FK_Z_WORK_SPLIT: one or two large pieces of l | a | b_g1 | b_g2
 // per rank instead of 1 / N of each -- round 4); FK_MULTI_SPLIT=equal restores the equal split of rounds 1-3.
+// Which SCHEDULE follows from the split a key was loaded with (prove_rank looks at the key's h slices): with 4 or 8 ranks the transforms
+// are cut between the ranks (h in blocks of the domain, seven all-to-alls per proof); with 2 ranks -- where every all-to-all would move
+// m * 32 / 4 bytes over ONE link, seven times per proof: more than the transforms it saves -- and with rank counts
+// that are not a power of two, rank 0 evaluates a, b, c, computes the whole quotient and H, and the other ranks run witness multiplications
+// only: NOTHING is exchanged but the 384-byte partial sums (FK_Z_WORK_SPLIT_Q0; FK_MULTI_SPLIT=work forces the cut-transform schedule
+// with the work split on 2 ranks, =equal the equal split of rounds 1-3).
 static double multi_split(const fk_multi *M) {
     const char *e = getenv("FK_MULTI_SPLIT");
     if (e && !strcmp(e, "equal")) return FK_Z_EQUAL_SPLIT;
-    return M->n >= 2 ? FK_Z_WORK_SPLIT : FK_Z_EQUAL_SPLIT;
+    if (M->n < 2) return FK_Z_EQUAL_SPLIT;
+    if (e && !strcmp(e, "work")) return FK_Z_WORK_SPLIT;
+    return (M->pow2 && M->n >= 4) ? FK_Z_WORK_SPLIT : FK_Z_WORK_SPLIT_Q0;
 }
 
 static int multi_check(fk_multi *M, const fk_multi_key *K, const fk_multi_r1cs *R) {

@@ -1016,6 +1016,11 @@ void fk_work_shard_ranges(uint64_t n_l, uint64_t n_a, uint64_t n_b, uint32_t ind
     work_slices(n_l, n_a, n_b, index, count, out);
 }
 
+void fk_work_shard_ranges_q0(uint64_t n_l, uint64_t n_a, uint64_t n_b, uint64_t m, uint32_t index, uint32_t count, uint64_t out[8]) {
+    if (!count || index >= count || !out) return;
+    work_slices(n_l, n_a, n_b, index, count, out, count > 1 ? (long double)FK_Q0_HANDICAP * (long double)m : 0.0L);
+}
+
 void fk_h_shard_range(uint64_t n_h, uint32_t index, uint32_t count, uint64_t *lo, uint64_t *hi) {
     if (!count || !lo || !hi) return;
     h_slice(n_h, index, count, lo, hi);

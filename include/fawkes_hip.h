@@ -60,6 +60,12 @@ enum {
  * b_g2 are then sliced independently: fk_key_shard_info2).  h stays in blocks of the domain.  What fk_multi_* uses from 2 ranks on. */
 #define FK_Z_WORK_SPLIT (-2.0)
 #define FK_G2_WORK 2.8
+/* z_frac_lo = FK_Z_WORK_SPLIT_Q0: the split of the exchange-free schedule ("quotient on rank 0": fk_multi_* on 2, 3, 5, 6, 7 ranks).  Shard 0
+ * holds ALL of h -- it evaluates a, b, c, computes the whole quotient and H -- and the work line of l | a | b_g1 | b_g2 is cut so that this fixed
+ * work (FK_Q0_HANDICAP G1-point units per domain point) counts towards shard 0's piece; the other shards hold no h at all and never exchange
+ * anything but their 384-byte partial sums. */
+#define FK_Z_WORK_SPLIT_Q0 (-3.0)
+#define FK_Q0_HANDICAP 2.2
 #define FK_PROOF_BYTES 256
 #define FK_G1_BYTES 64
 #define FK_G2_BYTES 128
@@ -219,6 +225,8 @@ void fk_h_shard_range(uint64_t n_h, uint32_t index, uint32_t count, uint64_t *lo
 /* the slices of l, a, b_g1, b_g2 ([lo, hi) each: out[8]) that shard `index` of `count` holds under FK_Z_WORK_SPLIT (pure arithmetic:
  * what every key loader applies; a host that shards keys itself calls this) */
 void fk_work_shard_ranges(uint64_t n_l, uint64_t n_a, uint64_t n_b, uint32_t index, uint32_t count, uint64_t out[8]);
+/* ... under FK_Z_WORK_SPLIT_Q0 (m = the key's domain size: shard 0 carries FK_Q0_HANDICAP * m units of fixed work) */
+void fk_work_shard_ranges_q0(uint64_t n_l, uint64_t n_a, uint64_t n_b, uint64_t m, uint32_t index, uint32_t count, uint64_t out[8]);
 
 /* Distributed quotient: bellman's EvaluationDomain pipeline (domain.rs ifft / coset_fft / mul_assign / sub_assign /
  * divide_by_z_on_coset / icoset_fft) over W = 2^log_w GPUs, one process each ("NTT butterfly stages

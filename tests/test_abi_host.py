@@ -204,6 +204,24 @@ def test_work_split_planner_tiles_every_array_and_balances_the_work():
             assert all(pieces[g][arr][1] == pieces[g + 1][arr][0] for g in range(count - 1))
         work = [sum((p[a_][1] - p[a_][0]) * w for a_, w in (('l', 1.0), ('a', 1.0), ('b', 1.0), ('b_g2', 2.8))) for p in pieces]
         assert max(work) - min(work) <= 2 * 2.8 + 1e-3, (n_l, n_a, n_b, count, work)
+    # FK_Z_WORK_SPLIT_Q0 (the exchange-free schedule of 2, 3, 5, 6, 7 ranks): shard 0's fixed work -- 2.2 units per domain point -- counts
+    # towards its piece; still an exact tiling, the other shards equal among themselves, shard 0 never above them by more than a cut
+    for n_l, n_a, n_b, count in cases:
+        m = 1 << max(n_l + 3 - 1, 1).bit_length()
+        pieces = [api.work_shard_ranges(n_l, n_a, n_b, g, count, q0_domain=m) for g in range(count)]
+        for arr, n in (('l', n_l), ('a', n_a), ('b', n_b), ('b_g2', n_b)):
+            assert pieces[0][arr][0] == 0 and pieces[-1][arr][1] == n
+            assert all(pieces[g][arr][1] == pieces[g + 1][arr][0] for g in range(count - 1))
+        work = [sum((p[a_][1] - p[a_][0]) * w for a_, w in (('l', 1.0), ('a', 1.0), ('b', 1.0), ('b_g2', 2.8))) for p in pieces]
+        if count > 1:
+            total = sum(work)
+            share = (total + 2.2 * m) / count
+            if 2.2 * m >= share:       # shard 0's fixed work alone fills its share: it holds nothing of the arrays, the others share them equally
+                assert work[0] == 0 and max(work[1:]) - min(work[1:]) <= 2 * 2.8 + 1e-3, (n_l, n_a, n_b, count, work)
+            else:
+                assert abs(work[0] + 2.2 * m - share) <= 2.8 + 1e-3 and max(work[1:]) - min(work[1:]) <= 2 * 2.8 + 1e-3, (n_l, n_a, n_b, count, work)
+    two = [api.work_shard_ranges(33597818, 32100559, 23632335, g, 2, q0_domain=1 << 25) for g in range(2)]
+    assert two[0]['l'] == (0, 33597818) and 0 < two[0]['a'][1] < 32100559 and two[0]['b'] == (0, 0) and two[1]['b_g2'] == (0, 23632335)
     # the benchmark's key on 8 ranks: one or two LARGE pieces per rank
     p8 = [api.work_shard_ranges(33597818, 32100559, 23632335, g, 8) for g in range(8)]
     assert p8[0]['l'][1] - p8[0]['l'][0] > 19e6 and p8[0]['a'] == (0, 0) and p8[7]['b_g2'][1] == 23632335 and p8[7]['l'][0] == p8[7]['l'][1]

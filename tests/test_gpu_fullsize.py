@@ -164,16 +164,18 @@ def test_config3_2p25_filled_domain_single_gpu_and_one_call_on_8_ranks(ctx):
         mkey.free(); mdr.free()
     finally:
         mc.close()
-    # ... and on 2 ranks: the witness arrays dealt by work (round 4) -- rank 0 holds l, a and half of b_g1, rank 1 the other half and all
-    # of b_g2 (23.6 M G2 points count for 66 M G1 points) -- every piece with its fixed-base levels
+    # ... and on 2 ranks: the exchange-free schedule (round 4) -- rank 0 holds ALL of h (it evaluates a, b, c, computes the whole quotient
+    # and H) and, its fixed work counted, l and the head of a; rank 1 holds no h, the rest of a, b_g1 and all of b_g2 -- every piece
+    # with its fixed-base levels, nothing exchanged but the 384-byte partial sums
     mc = fk.MultiContext([0, 0])
     try:
         mkey, _ = mc.setup(inst, copies=copies, **tox)
         i0, i1 = mc.key_shard(mkey, 0).shard_info(), mc.key_shard(mkey, 1).shard_info()
-        assert i0['l'][1] - i0['l'][0] == copies * inst.num_aux and i1['l'] == (i0['l'][1], i0['l'][1])
-        assert i1['b_g2'][1] - i1['b_g2'][0] > 2e7 and i0['b_g2'][1] == i0['b_g2'][0] and i0['b'][1] == i1['b'][0]
+        assert i0['h'] == (0, (1 << log_m) - 1) and i1['h'][0] == i1['h'][1]
+        assert i0['l'][1] - i0['l'][0] == copies * inst.num_aux and i1['l'] == (i0['l'][1], i0['l'][1]) and 0 < i0['a'][1] == i1['a'][0]
+        assert i1['b_g2'][1] - i1['b_g2'][0] > 2e7 and i0['b_g2'][1] == i0['b_g2'][0] and i0['b'][1] == 0
         pre0, pre1 = mc.key_shard(mkey, 0).precomputed(), mc.key_shard(mkey, 1).precomputed()
-        assert pre0['h'] > 0 and pre0['l'] > 0 and pre0['a'] > 0 and pre1['h'] > 0 and pre1['b_g2'] > 0 and pre1['l'] == 0
+        assert pre0['h'] > 0 and pre0['l'] > 0 and pre0['a'] > 0 and pre1['h'] == 0 and pre1['b_g2'] > 0 and pre1['b_g1'] > 0 and pre1['l'] == 0
         mdr = mc.load_r1cs(inst, copies=copies)
         assert mc.prove_witness(mkey, mdr, z, r, s).tobytes() == want.tobytes()
         mkey.free(); mdr.free()

@@ -108,9 +108,13 @@ def test_multi_prove_one_call_matches_oracle(ctx, oracle, world):
         assert mc.size == world
         key, vk = mc.setup(r1cs, **tox)
         dr = mc.load_r1cs(r1cs)
+        # 4 and 8 ranks cut the transforms: h in blocks of the domain (what the distributed quotient leaves on a rank).  2 and 3 ranks run
+        # the exchange-free schedule (round 4): rank 0 holds ALL of h (it computes the whole quotient), the others none
+        n_h = (1 << 11) - 1
+        q0 = world in (2, 3)
         for g in range(world):
             info = mc.key_shard(key, g).shard_info()
-            assert info['h'] == fk.api.h_shard_range((1 << 11) - 1, g, world)
+            assert info['h'] == (((0, n_h) if g == 0 else (n_h, n_h)) if q0 else fk.api.h_shard_range(n_h, g, world))
         # round 4: from two ranks on the witness arrays are dealt BY WORK (FK_Z_WORK_SPLIT): l | a | b_g1 | b_g2 laid end to end, a G2
         # point counting 2.8 G1 points, cut into `world` equal pieces -- the shards must tile every array exactly and carry equal work
         cnt = mc.key_shard(key, 0).counts()
@@ -120,8 +124,14 @@ def test_multi_prove_one_call_matches_oracle(ctx, oracle, world):
             assert all(infos[g][arr][1] == infos[g + 1][arr][0] for g in range(world - 1)), (arr, infos)
         if world > 1:
             work = [sum((i[a_][1] - i[a_][0]) * w for a_, w in (('l', 1.0), ('a', 1.0), ('b', 1.0), ('b_g2', 2.8))) for i in infos]
-            assert max(work) - min(work) <= 2 * 2.8 + 1e-6, work
-            assert any(i['b'] != i['b_g2'] for i in infos)          # b_g1 and b_g2 are sliced independently
+            if q0:          # rank 0's fixed work (evaluation, quotient, H: 2.2 units per domain point) counts towards its piece
+                work[0] += 2.2 * (1 << 11)
+                assert max(work[1:]) - min(work[1:]) <= 2 * 2.8 + 1e-6 and (abs(work[0] - work[1]) <= 2 * 2.8 + 1e-6 or infos[0]['l'][1] == 0), work
+                assert [infos[g][a_] for g in range(world) for a_ in ('l', 'a', 'b', 'b_g2')] == \
+                       [fk.api.work_shard_ranges(cnt['n_l'], cnt['n_a'], cnt['n_b'], g, world, q0_domain=1 << 11)[a_] for g in range(world) for a_ in ('l', 'a', 'b', 'b_g2')]
+            else:
+                assert max(work) - min(work) <= 2 * 2.8 + 1e-6, work
+            assert q0 or any(i['b'] != i['b_g2'] for i in infos)          # b_g1 and b_g2 are sliced independently
         got = mc.prove_witness(key, dr, z, r, s)
         assert got.tobytes() == want.tobytes()
         assert ref.verify(fx.key_to_py(okey), z_in[1:], ref.proof_from_borsh(got.tobytes()))
@@ -134,9 +144,19 @@ def test_multi_prove_one_call_matches_oracle(ctx, oracle, world):
             finally:
                 del os.environ['FK_MULTI_SPLIT']
             ie = [mc.key_shard(key_e, g).shard_info() for g in range(world)]
-            assert all(i['b'] == i['b_g2'] and i['l'] == fk.api.shard_range(cnt['n_l'], g, world) for g, i in enumerate(ie))
-            assert mc.prove_witness(key_e, dr, z, r, s).tobytes() == want.tobytes()
+            assert all(i['b'] == i['b_g2'] and i['l'] == fk.api.shard_range(cnt['n_l'], g, world) and i['h'] == fk.api.h_shard_range(n_h, g, world)
+                       for g, i in enumerate(ie))
+            assert mc.prove_witness(key_e, dr, z, r, s).tobytes() == want.tobytes()        # (the cut-transform schedule: seven exchanges, also on 2 ranks)
             key_e.free()
+            # ... and the work split WITH the cut transforms on 2 ranks (FK_MULTI_SPLIT=work)
+            os.environ['FK_MULTI_SPLIT'] = 'work'
+            try:
+                key_w, _ = mc.setup(r1cs, **tox)
+            finally:
+                del os.environ['FK_MULTI_SPLIT']
+            assert mc.key_shard(key_w, 1).shard_info()['h'] == fk.api.h_shard_range(n_h, 1, world)
+            assert mc.prove_witness(key_w, dr, z, r, s).tobytes() == want.tobytes()
+            key_w.free()
         # the verifying key of the sharded derivation is the oracle's
         assert np.array_equal(vk['ic'], np.array(okey.ic)) and vk['alpha_g1'].tobytes() == np.array(okey.alpha_g1).tobytes()
         # pipelined: two witnesses in flight, a different one second

@@ -40,7 +40,7 @@ def main():
     ap.add_argument('--copies', type=int, default=1024)
     ap.add_argument('--ranks', default='1,2,4,8')
     ap.add_argument('--reps', type=int, default=3)
-    ap.add_argument('--split', choices=('work', 'equal'), default='work', help="how l, a, b_g1, b_g2 are dealt to the ranks (FK_Z_WORK_SPLIT / FK_Z_EQUAL_SPLIT)")
+    ap.add_argument('--split', choices=('work', 'equal', 'q0'), default='work', help="how l, a, b_g1, b_g2 are dealt to the ranks (FK_Z_WORK_SPLIT / FK_Z_EQUAL_SPLIT)")
     ap.add_argument('--all-ranks', action='store_true', help='measure every rank (default: rank 0 only; with the work split the ranks differ)')
     args = ap.parse_args()
     ctx = fk.Context(0)
@@ -56,9 +56,10 @@ def main():
     dr = ctx.load_r1cs(r1cs, copies=copies)
     tox = {k: bench.mont(v) for k, v in bench.TOXIC.items()}
     out = {'workload': '%d rollup-style transactions, domain 2^%d' % (copies, log_m), 'ranks': {}}
-    split = {'work': fk.api.Z_WORK_SPLIT, 'equal': fk.api.Z_EQUAL_SPLIT}[args.split]
+    split = {'work': fk.api.Z_WORK_SPLIT, 'equal': fk.api.Z_EQUAL_SPLIT, 'q0': fk.api.Z_WORK_SPLIT_Q0}[args.split]
+    q0 = args.split == 'q0'          # the exchange-free schedule: rank 0 evaluates, computes the WHOLE quotient and H; the others run witness multiplications only
     for W in [int(x) for x in args.ranks.split(',')]:
-        lw = parallel.log2_world(W)
+        lw = 0 if q0 else parallel.log2_world(W)
         L = m >> lw
         send = [Buf(ctx, L * 32) for _ in range(3)]
         recv = [Buf(ctx, L * 32) for _ in range(3)]
@@ -94,10 +95,24 @@ def main():
                 ev(); blk = quot()
                 return ctx.prove_msms_hz_r1cs_dev(key, dr, blk.data_ptr(), d_z)
 
+            if q0 and W > 1:
+                if g == 0:
+                    full = [Buf(ctx, m * 32) for _ in range(4)]
+                    ev = lambda: ctx.r1cs_eval_dev(dr, d_z, full[0].data_ptr(), full[1].data_ptr(), full[2].data_ptr())
+                    quot = lambda: ctx.quotient_h_dev(full[0].data_ptr(), full[1].data_ptr(), full[2].data_ptr(), n, full[3].data_ptr())
+                    msms = lambda: ctx.prove_msms_hz_r1cs_dev(key, dr, full[3].data_ptr(), d_z)
+                    whole = lambda: (ev(), quot(), msms())
+                else:
+                    full = []
+                    ev = quot = lambda: None
+                    msms = whole = lambda: ctx.prove_msms_hz_r1cs_dev(key, dr, 0, d_z)
             t_ev = timed(ev)
             ev(); t_q = timed(quot)
             t_m = timed(msms)
             t_all = timed(whole)
+            if q0 and W > 1:
+                for b_ in full:
+                    b_.free()
             info = key.shard_info()
             per_rank.append({'rank': g, 'eval_slice_ms': t_ev, 'quotient_compute_ms': t_q, 'msms_ms': t_m, 'whole_share_ms': t_all, 'levels': key.precomputed(),
                              'points': {k_: v_[1] - v_[0] for k_, v_ in info.items()}})
@@ -105,7 +120,7 @@ def main():
         worst = max(per_rank, key=lambda e: e['whole_share_ms'])
         # exchanges: 7 per proof, each rank sends (W - 1) / W of its L * 32 bytes, one chunk per peer, every peer on a link of its own
         chunk = L * 32 // W
-        t_x = 7 * (chunk / (XGMI_GBPS_PER_LINK_PER_DIRECTION * 1e9)) * 1e3 if W > 1 else 0.0
+        t_x = 7 * (chunk / (XGMI_GBPS_PER_LINK_PER_DIRECTION * 1e9)) * 1e3 if (W > 1 and not q0) else 0.0
         out['ranks'][str(W)] = dict(worst, split=args.split if W > 1 else None, per_rank=per_rank, witness_upload_bytes_per_rank=int(z.nbytes),
                                     exchange_bytes_per_rank_per_proof=7 * chunk * (W - 1), exchange_ms_by_link_arithmetic=t_x)
         print('W = %d (%s split): slowest rank %d: eval %.2f ms, quotient %.2f ms, MSMs %.2f ms, whole share %.2f ms; exchanges %.2f ms by link arithmetic'
