@@ -28,12 +28,13 @@ with the Groth16 pairing equation.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-N > 1: one process per GPU, strong scaling of a single proof: every rank holds 1/N of each key array (MSM sharded by points),
+N > 1: one process per GPU, strong scaling of a single proof: every rank holds its piece of the key (h in blocks of the domain; l, a, b_g1,
+b_g2 dealt by work: one or two large pieces per rank),
 evaluates only the rows t = rank (mod N) of a, b, c and computes 1/N of the quotient -- the transforms are cut across the
 ranks with one all-to-all (RCCL over xGMI) each -- then ONE all-gather of 384 bytes per rank exchanges the partial MSM sums and
 the proof is folded locally (fawkes-crypto_amd/parallel.py: prove_distributed_dev).  With 2 ranks, or a rank count that is not a
-power of two, rank 0 computes the quotient while the other ranks start on the witness MSMs, and h slices travel point to point
-(prove_balanced_dev); FK_DIST_QUOTIENT=1 / 0 forces either schedule.  The line of an N-rank run also carries the one-call form
+power of two, rank 0 computes the whole quotient and H while the other ranks run witness MSMs only (prove_balanced_dev with the key split
+for "quotient on rank 0", FK_Z_WORK_SPLIT_Q0: nothing but 384-byte partial sums is exchanged); FK_DIST_QUOTIENT=1 / 0 forces either schedule.  The line of an N-rank run also carries the one-call form
 of the same proof (`single_process_multi_gpu`: fk_init_devices + fk_multi_prove_r1cs, one process driving all GPUs, exchanges
 inside the library) and the throughput mode (`replica_proofs_per_sec`).
 
