@@ -38,7 +38,7 @@ EXPORTED_SYMBOLS = [
     'fk_gen_points_g1_dev', 'fk_gen_points_g2_dev', 'fk_gen_scalars_dev',
     'fk_synthesize', 'fk_stats_reset', 'fk_stats_get', 'fk_calibrate', 'fk_verify', 'fk_verify_batch_dev', 'fk_shard_range', 'fk_h_shard_range', 'fk_work_shard_ranges', 'fk_work_shard_ranges_q0',
     'fk_dq_gather_dev', 'fk_dq_local_dev', 'fk_dq_cross_dev', 'fk_dq_cross_sub_dev',
-    'fk_setup', 'fk_setup_tiled', 'fk_r1cs_load_tiled', 'fk_key_download', 'fk_key_load_bellman', 'fk_key_vk', 'fk_key_counts', 'fk_key_precomputed',
+    'fk_setup', 'fk_setup_tiled', 'fk_r1cs_load_tiled', 'fk_key_download', 'fk_key_load_bellman', 'fk_key_write_bellman', 'fk_key_vk', 'fk_key_counts', 'fk_key_precomputed',
     'fk_gates_decode', 'fk_gates_free', 'fk_gates_info', 'fk_gates_export', 'fk_r1cs_load_gates',
     'fk_r1cs_load', 'fk_r1cs_load_coded', 'fk_r1cs_free', 'fk_r1cs_info', 'fk_r1cs_density_ptrs', 'fk_r1cs_eval_dev', 'fk_r1cs_eval_slice_dev', 'fk_prove_r1cs', 'fk_prove_r1cs_dev',
     'fk_init_devices', 'fk_multi_free', 'fk_multi_last_error', 'fk_multi_size', 'fk_multi_transport', 'fk_multi_ctx', 'fk_multi_sync',
@@ -773,7 +773,7 @@ class Context:
     def load_key_bellman(self, data, shard_index=0, shard_count=1, z_frac=Z_EQUAL_SPLIT, flags=FK_KEY_CHECKED):
         """fk_key_load_bellman: `data` = bytes of bellman's Parameters::write; flags = FK_KEY_CHECKED | FK_KEY_NO_INFINITY (the
         `checked` / `disallow_points_at_infinity` arguments of Parameters::read, mod.rs:159).  Returns (DeviceKey, gamma_g2, ic)."""
-        buf = np.frombuffer(bytes(data), np.uint8)
+        buf = np.ascontiguousarray(data, np.uint8).reshape(-1) if isinstance(data, np.ndarray) else np.frombuffer(bytes(data), np.uint8)      # (no copy of a multi-GB array)
         h = C.c_void_p()
         gamma = np.zeros(128, np.uint8)
         n_ic = C.c_uint32()
@@ -783,6 +783,17 @@ class Context:
                                               C.c_double(z_frac[0]), C.c_double(z_frac[1]), C.byref(h), _vp(gamma), _vp(ic), C.c_uint32(cap),
                                               C.byref(n_ic)))
         return DeviceKey(self, h, shard_index, shard_count), gamma, ic[:min(n_ic.value, cap)].copy()
+
+    def write_key_bellman(self, key, vk):
+        """fk_key_write_bellman: bellman `Parameters::write` bytes of a whole resident key (GPU conversion); vk: the dict fk_setup* /
+        load_key_bellman returned (gamma_g2 and ic are not part of a proving key)"""
+        gamma = np.ascontiguousarray(vk['gamma_g2'], np.uint8).reshape(-1)
+        ic = np.ascontiguousarray(vk['ic'], np.uint8).reshape(-1, 64)
+        need = C.c_size_t()
+        self._ck(self.lib.fk_key_write_bellman(self.handle, key.handle, _vp(gamma), _vp(ic), C.c_uint32(ic.shape[0]), None, C.c_size_t(0), C.byref(need)))
+        out = np.empty(need.value, np.uint8)
+        self._ck(self.lib.fk_key_write_bellman(self.handle, key.handle, _vp(gamma), _vp(ic), C.c_uint32(ic.shape[0]), _vp(out), C.c_size_t(out.nbytes), C.byref(need)))
+        return out
 
     def setup(self, r1cs, tau, alpha, beta, gamma, delta, shard_index=0, shard_count=1, z_frac=Z_EQUAL_SPLIT, copies=None):
         """fk_setup: GPU key generation with explicit toxic waste (Montgomery limbs).  Returns (DeviceKey, vk dict)
@@ -970,7 +981,7 @@ class MultiContext:
         return _MultiHandle(self, h, self.lib.fk_multi_key_free)
 
     def load_key_bellman(self, data, flags=FK_KEY_CHECKED):
-        buf = np.frombuffer(bytes(data), np.uint8)
+        buf = np.ascontiguousarray(data, np.uint8).reshape(-1) if isinstance(data, np.ndarray) else np.frombuffer(bytes(data), np.uint8)      # (no copy of a multi-GB array)
         h = C.c_void_p()
         gamma = np.zeros(128, np.uint8)
         n_ic = C.c_uint32()

@@ -93,6 +93,33 @@ __global__ __launch_bounds__(128) void convert_g2_kernel(const uint8_t *in, size
     }
 }
 
+// ---- the other direction: bellman `Parameters::write` (mod.rs:156) from the device layout.  Montgomery LE limbs -> canonical 32-byte
+// BIG-endian integers (one Montgomery multiplication by 1, byte reversal); the identity (all zeros here, group.rs:55) -> 0x40 then zeros.
+static __device__ __forceinline__ void mont_to_be32(const FqC &m, uint8_t *p) {
+    const FqC v = FqC::from_mont(m);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint8_t *q = p + 28 - 4 * i;
+        q[0] = (uint8_t)(v.v[i] >> 24); q[1] = (uint8_t)(v.v[i] >> 16); q[2] = (uint8_t)(v.v[i] >> 8); q[3] = (uint8_t)v.v[i];
+    }
+}
+__global__ void write_g1_kernel(const Affine<FqC> *in, size_t n, uint8_t *out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint8_t *p = out + 64 * i;
+    const Affine<FqC> a = in[i];
+    if (a.x.is_zero() && a.y.is_zero()) { for (int k = 0; k < 64; k++) p[k] = 0; p[0] = 0x40; return; }
+    mont_to_be32(a.x, p); mont_to_be32(a.y, p + 32);
+}
+__global__ void write_g2_kernel(const Affine<Fq2C> *in, size_t n, uint8_t *out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint8_t *p = out + 128 * i;
+    const Affine<Fq2C> a = in[i];
+    if (a.x.is_zero() && a.y.is_zero()) { for (int k = 0; k < 128; k++) p[k] = 0; p[0] = 0x40; return; }
+    mont_to_be32(a.x.c1, p); mont_to_be32(a.x.c0, p + 32); mont_to_be32(a.y.c1, p + 64); mont_to_be32(a.y.c0, p + 96);      // c1 before c0
+}
+
 struct Cursor {
     const uint8_t *p; size_t left;
     bool take(size_t n, const uint8_t **out) { if (left < n) return false; *out = p; p += n; left -= n; return true; }
@@ -228,5 +255,56 @@ int fk_key_counts(const fk_key *key, uint64_t out[8]) {
     memcpy(out, v, sizeof v);
     return FK_OK;
 }
+
+// bellman `Parameters::write` of a WHOLE key resident in HBM (the counterpart of fk_key_load_bellman; fawkes' own header -- gate count,
+// gate blob, const-tracker bits, mod.rs:150-155 -- is the host's: params_io.write_parameters).  A proving key does not hold gamma_g2 and
+// the ic points: the caller passes what fk_setup* / fk_key_load_bellman returned.  out == NULL: only *needed is set.
+int fk_key_write_bellman(fk_ctx *ctx, const fk_key *key, const uint8_t *gamma_g2, const uint8_t *ic, uint32_t n_ic, uint8_t *out, size_t cap,
+                         size_t *needed) { return fk_guard(ctx, [&]() -> int {
+    if (!ctx) return FK_ERR_BAD_ARG;
+    if (!key || !gamma_g2 || (!ic && n_ic) || !needed) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "key write: null argument");
+    if (key->shard_count != 1) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "key write: a shard cannot be written as a Parameters file (load the whole key)");
+    if (n_ic != key->num_input) FK_SET_ERR(ctx, FK_ERR_KEY_MISMATCH, "key write: %u ic points for %u inputs", n_ic, key->num_input);
+    const uint64_t cnt[5] = {key->h_hi - key->h_lo, key->l_hi - key->l_lo, key->a_hi - key->a_lo, key->b_hi - key->b_lo, key->b2_hi - key->b2_lo};
+    const size_t total = 3 * 64 + 3 * 128 + 4 + (size_t)n_ic * 64 + 5 * 4 + (size_t)(cnt[0] + cnt[1] + cnt[2] + cnt[3]) * 64 + (size_t)cnt[4] * 128;
+    *needed = total;
+    if (!out) return FK_OK;
+    if (cap < total) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "key write: buffer of %zu bytes, %zu needed", cap, total);
+    FK_HIP(ctx, hipSetDevice(ctx->device));
+    uint8_t *w = out;
+    auto u32be = [&](uint32_t v) { w[0] = (uint8_t)(v >> 24); w[1] = (uint8_t)(v >> 16); w[2] = (uint8_t)(v >> 8); w[3] = (uint8_t)v; w += 4; };
+    // device conversion in chunks through ctx->misc: raw points in (device-resident arrays as they are; host points uploaded first)
+    const size_t CH = (size_t)1 << 22;          // points per chunk
+    FK_HIP(ctx, ctx->misc.reserve(CH * 128 * 2));
+    uint8_t *d_bytes = ctx->misc.as<uint8_t>(), *d_stage = d_bytes + CH * 128;
+    auto emit = [&](const void *src, bool src_on_device, size_t n, size_t width) -> int {
+        for (size_t off = 0; off < n; off += CH) {
+            const size_t cn = std::min(CH, n - off);
+            const uint8_t *d_src = (const uint8_t *)src + off * width;
+            if (!src_on_device) { FK_HIP(ctx, hipMemcpyAsync(d_stage, d_src, cn * width, hipMemcpyHostToDevice, ctx->stream)); d_src = d_stage; }
+            if (width == 64) hipLaunchKernelGGL(write_g1_kernel, dim3((unsigned)((cn + 255) / 256)), dim3(256), 0, ctx->stream, (const Affine<FqC> *)d_src, cn, d_bytes);
+            else hipLaunchKernelGGL(write_g2_kernel, dim3((unsigned)((cn + 255) / 256)), dim3(256), 0, ctx->stream, (const Affine<Fq2C> *)d_src, cn, d_bytes);
+            FK_HIP(ctx, hipGetLastError());
+            FK_HIP(ctx, hipMemcpyAsync(w, d_bytes, cn * width, hipMemcpyDeviceToHost, ctx->stream));
+            FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            w += cn * width;
+        }
+        return FK_OK;
+    };
+    // vk: alpha_g1, beta_g1 (G1), beta_g2, gamma_g2 (G2), delta_g1 (G1), delta_g2 (G2), u32 BE count, ic[]
+    FK_TRY(emit(&key->alpha_g1, false, 1, 64)); FK_TRY(emit(&key->beta_g1, false, 1, 64));
+    FK_TRY(emit(&key->beta_g2, false, 1, 128)); FK_TRY(emit(gamma_g2, false, 1, 128));
+    FK_TRY(emit(&key->delta_g1, false, 1, 64)); FK_TRY(emit(&key->delta_g2, false, 1, 128));
+    u32be(n_ic); FK_TRY(emit(ic, false, n_ic, 64));
+    // h, l, a, b_g1 (G1), b_g2 (G2): u32 BE count + points
+    if (cnt[0] > 0xffffffffull || cnt[1] > 0xffffffffull) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "key write: array too long for bellman's u32 count");
+    u32be((uint32_t)cnt[0]); FK_TRY(emit(key->d_h, true, cnt[0], 64));
+    u32be((uint32_t)cnt[1]); FK_TRY(emit(key->d_l, true, cnt[1], 64));
+    u32be((uint32_t)cnt[2]); FK_TRY(emit(key->d_a, true, cnt[2], 64));
+    u32be((uint32_t)cnt[3]); FK_TRY(emit(key->d_b1, true, cnt[3], 64));
+    u32be((uint32_t)cnt[4]); FK_TRY(emit(key->d_b2, true, cnt[4], 128));
+    if ((size_t)(w - out) != total) FK_SET_ERR(ctx, FK_ERR_HIP, "key write: wrote %zu of %zu bytes", (size_t)(w - out), total);
+    return FK_OK;
+}); }
 
 }  // extern "C"

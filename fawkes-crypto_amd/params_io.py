@@ -214,3 +214,16 @@ def store_parameters(key_arrays, r1cs, const_tracker_bits=(), compress=None):
     stream = encode_gate_stream(r1cs)
     blob = compress(stream) if compress is not None else RAW_MAGIC + stream
     return write_parameters(r1cs.num_gates, blob, list(const_tracker_bits), encode_bellman_parameters(key_arrays))
+
+
+def store_parameters_dev(ctx, key, vk, r1cs, const_tracker_bits=(), compress=None, gates_blob=None):
+    """`Parameters::write` (mod.rs:150-157) for a key RESIDENT in HBM, at any size: fawkes' header from the host, the bellman part
+    converted on the GPU (fk_key_write_bellman: Montgomery limbs -> big-endian canonical points, ~seconds for a 2^25 key, where
+    `store_parameters` walks every point in Python).  vk: the dict fk_setup* / load_key_bellman returned (gamma_g2, ic).  The gate
+    blob is `gates_blob` as given (e.g. the blob the key was loaded with) or the encoded `r1cs` (slow per-term encoder: small
+    systems)."""
+    if gates_blob is None:
+        stream = encode_gate_stream(r1cs)
+        gates_blob = compress(stream) if compress is not None else RAW_MAGIC + stream
+    bell = ctx.write_key_bellman(key, vk)
+    return write_parameters(r1cs.num_gates, gates_blob, list(const_tracker_bits), bell.tobytes())

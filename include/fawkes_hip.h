@@ -403,6 +403,12 @@ int fk_key_download(fk_ctx *ctx, const fk_key *key, int which, void *host, size_
 int fk_key_load_bellman(fk_ctx *ctx, const uint8_t *buf, size_t len, uint32_t flags, uint32_t shard_index, uint32_t shard_count,
                         double z_frac_lo, double z_frac_hi, fk_key **out, uint8_t *gamma_g2_out, uint8_t *ic_out,
                         uint32_t ic_cap, uint32_t *n_ic);
+/* bellman `Parameters::write` (mod.rs:156) of a WHOLE key resident in HBM -- the counterpart of fk_key_load_bellman: vk, then h, l, a, b_g1
+ * (G1) and b_g2 (G2), each a u32 BE count + uncompressed big-endian points, converted on the GPU.  gamma_g2 (128 B raw) and ic (n_ic x 64 B
+ * raw, n_ic = num_input) are the caller's (a proving key does not hold them: fk_setup* / fk_key_load_bellman return them).  out == NULL:
+ * only *needed is set.  fawkes' own header (gate count, gate blob, const-tracker bits, mod.rs:150-155) is written by the host. */
+int fk_key_write_bellman(fk_ctx *ctx, const fk_key *key, const uint8_t *gamma_g2, const uint8_t *ic, uint32_t n_ic, uint8_t *out, size_t cap,
+                         size_t *needed);
 /* alpha_g1, beta_g1, delta_g1 (64 B each) then beta_g2, delta_g2 (128 B each), raw Montgomery LE */
 int fk_key_vk(const fk_key *key, uint8_t out[3 * 64 + 2 * 128]);
 /* out[8] = m, num_input, num_aux, n_h, n_l, n_a, n_b, shard_count */

@@ -137,7 +137,24 @@ def test_config3_2p25_filled_domain_single_gpu_and_one_call_on_8_ranks(ctx):
     finally:
         for p_ in d_abc + [d_h]:
             ctx.dev_free(p_)
-    key.free()                                  # the key and its fixed-base levels (≈ 140 GB) make room for the eight shards' scratch
+    # `Parameters::write` / `Parameters::read(.., checked = true)` (mod.rs:150-175) at this size: the bellman part of the key -- 146.5 M points,
+    # 11 GB -- written from HBM by the GPU (fk_key_write_bellman) and read back with every point checked on the GPU (curve equation,
+    # G2 subgroup): the reloaded key proves the same bytes
+    import time
+    t0 = time.time()
+    blob = ctx.write_key_bellman(key, vk)
+    t_write = time.time() - t0
+    cnt = key.counts()
+    assert blob.nbytes == 3 * 64 + 3 * 128 + 4 + num_input * 64 + 5 * 4 + (cnt['n_h'] + cnt['n_l'] + cnt['n_a'] + cnt['n_b']) * 64 + cnt['n_b'] * 128
+    key.free()                                  # the key and its fixed-base levels (≈ 140 GB) make room
+    t0 = time.time()
+    key, gamma_g2, ic = ctx.load_key_bellman(blob, flags=fk.api.FK_KEY_CHECKED)
+    t_read = time.time() - t0
+    print('Parameters::write of the 2^25 key: %.1f s for %.1f GB; Parameters::read(checked) + fixed-base levels: %.1f s' % (t_write, blob.nbytes / 1e9, t_read))
+    assert gamma_g2.tobytes() == np.asarray(vk['gamma_g2'], np.uint8).tobytes() and ic.tobytes() == np.asarray(vk['ic'], np.uint8).tobytes()
+    assert ctx.prove_witness_dev(key, dr, d_z, r, s).tobytes() == want.tobytes()
+    del blob
+    key.free()
 
     ctx.dev_free(d_z); dr.free()
     ctx.trim()                                  # ... and so does the single-GPU prover's scratch (~70 GB)

@@ -288,3 +288,49 @@ def test_gate_decoder_refuses_a_forged_gate_count():
     with pytest.raises(fk.FkError) as e:
         api.Gates(stream, api.FK_GATES_RAW, 0xffffffff, 1, 0)
     assert e.value.code == 7
+
+
+@pytest.mark.gpu
+def test_native_bellman_writer_matches_the_restatement_and_round_trips(ctx, oracle):
+    """fk_key_write_bellman (round 4): `Parameters::write`'s bellman part (mod.rs:156) from the device layout, converted on the GPU --
+    byte-equal to the per-point Python restatement (params_io.encode_bellman_parameters) incl. an identity point inside an array
+    (0x40 flag byte), and fk_key_load_bellman(checked) of those bytes gives back identical device arrays, vk, gamma_g2 and ic;
+    a shard is refused; the whole `Parameters` file written through store_parameters_dev loads and proves like the original."""
+    from fawkes_crypto_amd import params_io as pio
+    import fawkes_crypto_amd as fk
+    cs, z_in, z_aux = ref.random_r1cs(43, 500, 3, 560)
+    csr = fx.r1cs_to_csr(cs)
+    key = oracle.setup(csr, **TOXIC)
+    r1cs = r1cs_product(csr)
+    arrays = _key_arrays(key)
+    arrays['a'] = arrays['a'].copy(); arrays['a'][7] = 0          # an identity point inside an array
+    shape = dict(m=key.m, num_input=key.num_input, num_aux=key.num_aux)
+    params = fk.Parameters(dict(arrays, **shape), r1cs)
+    dk = ctx.load_key(params)
+    vk = dict(gamma_g2=arrays['gamma_g2'], ic=arrays['ic'])
+    got = ctx.write_key_bellman(dk, vk)
+    want = pio.encode_bellman_parameters(arrays)
+    assert got.tobytes() == want
+    dk2, gamma, ic = ctx.load_key_bellman(got, flags=fk.api.FK_KEY_CHECKED)
+    for name in ('h', 'l', 'a', 'b_g1', 'b_g2'):
+        assert dk2.download(name).tobytes() == arrays[name].tobytes(), name
+    assert gamma.tobytes() == arrays['gamma_g2'].tobytes() and ic.tobytes() == np.asarray(arrays['ic'], np.uint8).tobytes()
+    assert all(dk2.vk()[n_].tobytes() == arrays[n_].tobytes() for n_ in ('alpha_g1', 'beta_g1', 'delta_g1', 'beta_g2', 'delta_g2'))
+    sk = ctx.load_key(params, shard_index=1, shard_count=2)
+    with pytest.raises(fk.FkError) as e:
+        ctx.write_key_bellman(sk, vk)
+    assert e.value.code == 1 and 'shard' in str(e.value)
+    sk.free()
+    # the whole file: fawkes header (host) + bellman part (GPU) -> load -> prove = the oracle's bytes
+    arrays_ok = _key_arrays(key)
+    dk3 = ctx.load_key(fk.Parameters(dict(arrays_ok, **shape), r1cs))
+    data = pio.store_parameters_dev(ctx, dk3, dict(gamma_g2=arrays_ok['gamma_g2'], ic=arrays_ok['ic']), r1cs, const_tracker_bits=[True, False])
+    assert data == pio.store_parameters(arrays_ok, r1cs, const_tracker_bits=[True, False])
+    dk4, dr4, hdr = pio.load_parameters(ctx, data)
+    z = fx.witness_mont(z_in, z_aux)
+    r, s = fx.mont_fr(3), fx.mont_fr(4)
+    a, b, c, aa, bi, ba = oracle.synthesize(csr, z)
+    assert ctx.prove_witness(dk4, dr4, z, r, s).tobytes() == oracle.prove(key, a, b, c, z, aa, bi, ba, r, s).tobytes()
+    for k_ in (dk, dk2, dk3, dk4):
+        k_.free()
+    dr4.free()
