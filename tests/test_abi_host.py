@@ -226,3 +226,18 @@ def test_work_split_planner_tiles_every_array_and_balances_the_work():
     p8 = [api.work_shard_ranges(33597818, 32100559, 23632335, g, 8) for g in range(8)]
     assert p8[0]['l'][1] - p8[0]['l'][0] > 19e6 and p8[0]['a'] == (0, 0) and p8[7]['b_g2'][1] == 23632335 and p8[7]['l'][0] == p8[7]['l'][1]
     assert all(sum(1 for a_ in ('l', 'a', 'b', 'b_g2') if p[a_][1] > p[a_][0]) <= 2 for p in p8)
+
+
+def test_header_is_plain_c():
+    """the drop-in boundary is a C ABI (plain pointers and sizes, no C++ or torch types in any signature): include/fawkes_hip.h must
+    compile as C99 on its own -- what a cgo / JNI / Rust-bindgen consumer does with it"""
+    import shutil
+    import subprocess
+    gcc = shutil.which('gcc')
+    if gcc is None:
+        pytest.skip('no gcc')
+    hdr = os.path.join(ROOT, 'include', 'fawkes_hip.h')
+    out = subprocess.run([gcc, '-std=c99', '-Wall', '-Werror', '-fsyntax-only', '-x', 'c', hdr], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    text = open(hdr).read()
+    assert 'torch' not in text.lower() and 'std::' not in text and 'template' not in text
