@@ -426,6 +426,20 @@ def single_process_leg(fk, n_ranks, same_device, r1cs, copies, z_pin, tox, r, s,
         mc.close()
 
 
+def host_rss():
+    """resident set of this process: now and its peak (VmRSS / VmHWM of /proc/self/status), bytes"""
+    out = {'now': None, 'peak': None}
+    try:
+        for ln in open('/proc/self/status'):
+            if ln.startswith('VmRSS:'):
+                out['now'] = int(ln.split()[1]) * 1024
+            elif ln.startswith('VmHWM:'):
+                out['peak'] = int(ln.split()[1]) * 1024
+    except OSError:
+        pass
+    return out
+
+
 def usable_cores():
     """host cores this process may actually use: the affinity mask, capped by the cgroup CPU quota (a container can show 256
     CPUs and be allowed the time of two)"""
@@ -612,7 +626,11 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-replicas', action='store_true', help='N > 1: skip the one-proof-per-GPU throughput leg')
     ap.add_argument('--no-single-process', action='store_true', help='N > 1: skip the fk_multi_prove_r1cs leg (one process driving all GPUs)')
-    ap.add_argument('--no-untiled', action='store_true', help='rollup1024, N = 1: skip the leg with the 9.6e8-term system materialised (no tiling shortcut)')
+    ap.add_argument('--tiled-headline', action='store_true',
+                    help='rollup1024, N = 1: measure `value` on the tiled resident system (fk_r1cs_load_tiled: one instance + a copy count, rounds 1-4) instead of '
+                         'the explicit system decoded from the gate blob of a `Parameters` image (the reference\'s own input form: the default)')
+    ap.add_argument('--blob-quality', type=int, default=1, help='brotli quality of the gate blob the benchmark writes (the reference\'s setup uses 9; any quality decodes alike)')
+    ap.add_argument('--no-untiled', action='store_true', help='rollup1024, N = 1: with --tiled-headline, skip the leg with the explicit system; otherwise skip the tiled leg')
     ap.add_argument('--no-standalone', action='store_true', help='N = 1: skip the standalone MSM / NTT figures')
     ap.add_argument('--no-other-sizes', action='store_true',
                     help='rollup1024, N = 1: skip the legs at other transaction counts (--secondary-copies, --reference-copies)')
@@ -707,8 +725,58 @@ def main():
     key, vk = ctx.setup(r1cs, shard_index=rank, shard_count=world, copies=copies,
                         z_frac=fk.api.Z_WORK_SPLIT_Q0 if q0_split else fracs[rank] if (world > 1 and not dist_q) else
                         (fk.api.Z_WORK_SPLIT if (world > 1 and os.environ.get('FK_MULTI_SPLIT') != 'equal') else fk.api.Z_EQUAL_SPLIT), **tox)
-    pre_levels = key.precomputed()        # fixed-base window levels per key array (0 = none: FK_MSM_PRECOMP=0 or HBM short)
     r, s = mont(0xA11CE), mont(0xB0B)
+    # ---------------------------------------------------------------- N = 1: through the reference's own input form
+    # fawkes hands its prover a `Parameters` object: (bellman key, num_gates, brotli(Borsh gates), const tracker), setup.rs:25-32 / mod.rs:139-175.
+    # The key generated above and the circuit are WRITTEN as such an image (Parameters::write: fk_gates_encode + fk_key_write_bellman), everything
+    # is dropped, and the prover is set up again from the image alone: gate blob -> fk_gates_decode -> fk_r1cs_load_gates (every one of the
+    # 1.64e9 terms explicit in HBM), bellman part -> fk_key_load_bellman(checked).  `value` is measured on THAT system.
+    load_block = None
+    params_form = not multi and copies is not None and not args.tiled_headline
+    if params_form:
+        from fawkes_crypto_amd import params_io as pio
+        tm_w, tm_r = {}, {}
+        image = pio.store_parameters_dev(ctx, key, vk, r1cs, copies=copies, quality=args.blob_quality, lgwin=22, timings=tm_w)
+        key.free(); dr.free()
+        key = dr = None
+        rss_before = host_rss()
+        t_l0 = time.perf_counter()
+        key, dr, p_hdr = pio.load_parameters(ctx, image, checked=True, disallow_points_at_infinity=False, timings=tm_r)
+        t_l1 = time.perf_counter()
+        first_proof = ctx.prove_witness(key, dr, z_pin[0], r, s).tobytes()
+        t_l2 = time.perf_counter()
+        if not np.array_equal(np.asarray(p_hdr['ic']), np.asarray(vk['ic'])) or bytes(p_hdr['gamma_g2']) != bytes(vk['gamma_g2']):
+            raise AssertionError('bench: the verifying key read back from the Parameters image differs from the generated one')
+        info = dr.info()
+        if (info['n_a'], info['n_b']) != (n_a, n_b):
+            raise AssertionError('bench: the system decoded from the gate blob has other A / B queries than the tiled one')
+        gp, ep = tm_r['gates_decode_profile'], tm_w.get('gates_encode_profile', {})
+        rss_after = host_rss()
+        load_block = {
+            'is': 'the prover set up from a `Parameters` image alone (mod.rs:150-175): gate blob -> fk_gates_decode (one decompressing thread = the serial '
+                  'floor of a brotli stream; parsing, range checks, coefficient dictionary and density flags on the other host threads) -> '
+                  'fk_r1cs_load_gates; bellman part -> fk_key_load_bellman(checked: every point on its curve, G2 in the subgroup) -> fixed-base levels',
+            'image_bytes': int(image.nbytes), 'blob_bytes': tm_w['blob_bytes'], 'bellman_bytes': tm_w['bellman_bytes'],
+            'blob': 'brotli quality %d, lgwin 22 (setup.rs:26 writes quality 9, lgwin 22; the decoder does not care)' % args.blob_quality,
+            'gate_stream_bytes': gp and int(p_hdr['gates_info']['decoded_bytes']), 'gates': int(p_hdr['gates_info']['num_gates']),
+            'matrix_terms': int(sum(p_hdr['gates_info']['nnz'])), 'distinct_coefficients': int(p_hdr['gates_info']['distinct_coefficients']),
+            'decode_seconds': tm_r['gates_decode_s'], 'decode_terms_per_sec': sum(p_hdr['gates_info']['nnz']) / tm_r['gates_decode_s'],
+            'decode_stream_GBps': p_hdr['gates_info']['decoded_bytes'] / tm_r['gates_decode_s'] / 1e9,
+            'decode_profile': gp,
+            'decode_bound': 'the decompressor: %.1f of %.1f s inside libbrotlidec on one thread (a brotli stream is one serial bit stream); the %d parsing threads '
+                            'used %.1f CPU-seconds beside it and made it wait %.1f s' % (gp['decompressor_s'], gp['wall_s'], gp['parse_threads'], gp['parse_cpu_s'], gp['waited_for_parsers_s']),
+            'r1cs_upload_seconds': tm_r['r1cs_load_s'],
+            'key_read_checked_seconds': tm_r['key_read_profile']['arrays_s'], 'key_levels_seconds': tm_r['key_read_profile']['levels_s'],
+            'load_parameters_seconds': t_l1 - t_l0, 'first_proof_seconds': t_l2 - t_l1, 'time_to_first_proof_seconds': t_l2 - t_l0,
+            'host_rss_peak_bytes': rss_after['peak'], 'host_rss_before_load_bytes': rss_before['now'], 'host_rss_after_load_bytes': rss_after['now'],
+            'host_rss_note': 'the image itself (%.1f GB, held by this process as one array) is part of every figure; the decoder adds 8 bytes per matrix term '
+                             'while it runs' % (image.nbytes / 1e9),
+            'write': {'gates_encode_seconds': tm_w['gates_encode_s'], 'gates_encode_profile': ep, 'key_write_seconds': tm_w['key_write_s'],
+                      'is': 'Parameters::write of the generated key and circuit (fk_gates_encode through libbrotlienc + fk_key_write_bellman); not part of any proving figure'},
+            'reference_does': 'the reference decompresses and replays the same blob for EVERY proof (WitnessCS::get_gate_iterator, cs.rs:243-245); here once per key',
+        }
+        del image
+    pre_levels = key.precomputed()        # fixed-base window levels per key array (0 = none: FK_MSM_PRECOMP=0 or HBM short)
     d_dens = dr.density_ptrs()
     if dist_q:
         work = [None] * 3         # a rank evaluates only its own rows, straight into send[] (fk_r1cs_eval_slice_dev): no m-element vectors
@@ -821,10 +889,45 @@ def main():
         if p_dev.tobytes() != want[0]:
             raise AssertionError('bench: device-resident proof differs from the host-witness proof')
 
-    # ---- not `value`: the SAME circuit with every one of its 9.6e8 terms explicit in HBM (no tiling shortcut: what a circuit that is
-    # not 1024 identical blocks costs in the evaluation of a, b, c); same key, same witness, same proof bytes
-    untiled = None
-    if not multi and copies is not None and not args.no_untiled:
+    # ---- not `value`: the other resident form of the SAME circuit, same key, same witnesses, same proof bytes.
+    #   default (`value` on the explicit system out of the Parameters image): `tiled` = fk_r1cs_load_tiled, ONE instance + a copy count
+    #     (4.4 MB of matrices instead of 13.9 GB; rounds 1-4 quoted this form) -- the host-witness pipeline timed exactly like `value`;
+    #   --tiled-headline: `untiled` = the explicit system built on the host (fk_r1cs_load_coded), witness resident.
+    untiled = tiled = None
+    if params_form and first_proof != want[0]:
+        raise AssertionError('bench: the first proof after load_parameters differs from the pipelined proofs')
+    if params_form and not args.no_untiled:
+        t1 = time.perf_counter()
+        dr_t = ctx.load_r1cs(r1cs, copies=copies)
+        t_load = time.perf_counter() - t1
+        p_t = ctx.prove_witness_dev(key, dr_t, d_z0, r, s)
+        ctx.sync()
+        t1 = time.perf_counter()
+        for _ in range(dev_steps):
+            p_t = ctx.prove_witness_dev(key, dr_t, d_z0, r, s)
+        t_dev_ms = (time.perf_counter() - t1) / dev_steps * 1e3
+        if p_t.tobytes() != want[0]:
+            raise AssertionError('bench: the proof from the tiled system differs from the one from the Parameters image')
+        tk = ctx.prove_witness_submit(key, dr_t, z_pin[0], r, s)
+        t_steps = max(4, min(args.steps, 10))
+        for i in range(2 + t_steps):
+            if i == 2:
+                ctx.sync()
+                t1 = time.perf_counter()
+            nxt = ctx.prove_witness_submit(key, dr_t, z_pin[(i + 1) & 1], r, s)
+            p_t = ctx.prove_witness_wait(tk).tobytes(); tk = nxt
+            if want[i & 1] is not None and p_t != want[i & 1]:
+                raise AssertionError('bench: pipelined proof from the tiled system differs from the one from the Parameters image')
+        ctx.sync()
+        t_ms = (time.perf_counter() - t1) / t_steps * 1e3
+        ctx.prove_witness_wait(tk)
+        tiled = {'ms_per_step': t_ms, 'proofs_per_sec': 1e3 / t_ms, 'steps': t_steps, 'device_resident_ms_per_step': t_dev_ms,
+                 'explicit_ms_per_step': elapsed / args.steps * 1e3, 'explicit_device_resident_ms_per_step': dev_ms,
+                 'matrix_bytes_resident': int(sum(dr_t.info()['nnz']) // copies) * 8, 'load_seconds': t_load,
+                 'is': 'fk_r1cs_load_tiled of ONE transaction + the copy count %d (the form rounds 1-4 quoted; no `Parameters` object can express it), same key, '
+                       'same two witnesses through the same two-slot pipeline; proof bytes equal to the explicit form\'s' % copies}
+        dr_t.free()
+    if not multi and copies is not None and not params_form and not args.no_untiled:
         t1 = time.perf_counter()
         u_in, u_aux, u_mats, u_table = materialise_rollup(copies)
         t_build = time.perf_counter() - t1
@@ -922,8 +1025,11 @@ def main():
         fill = n / float(m)
         if args.workload == 'rollup1024':
             wl = ('%d rollup-style transactions (two depth-32 poseidon merkle proofs + one eddsa-poseidon signature each; a composition of the '
-                  'reference\'s gadgets, tests/golden/rollup_tx_instance.npz) as ONE R1CS through fk_setup_tiled / fk_r1cs_load_tiled: %d rows '
-                  '= %.2f %% of the 2^%d domain (BASELINE configs[3] shape; BASELINE.md config 4: rows = 2^25)' % (copies, n, 100.0 * fill, log_m))
+                  'reference\'s gadgets, tests/golden/rollup_tx_instance.npz) as ONE R1CS of %d rows = %.2f %% of the 2^%d domain (BASELINE configs[3] shape; '
+                  'BASELINE.md config 4: rows = 2^25), %s' % (copies, n, 100.0 * fill, log_m,
+                  'handed to the prover as a `Parameters` image (brotli gate blob + bellman key, mod.rs:150-175): fk_gates_decode -> fk_r1cs_load_gates '
+                  '(all %.3g matrix terms explicit in HBM) + fk_key_load_bellman(checked)' % float(sum(info['nnz'])) if params_form else
+                  'through fk_setup_tiled / fk_r1cs_load_tiled (one instance + a copy count)'))
         else:
             wl = 'synthetic satisfiable R1CS, 2^%d rows, 1-2 term rows%s' % (log_m, ' / %d-term product gates' % args.lc_terms if args.lc_terms > 1 else '')
         out = {
@@ -939,6 +1045,7 @@ def main():
             'data': 'synthetic',
             'config': {'workload': wl + '; per step: witness from pinned HOST memory (two-slot pipeline, two distinct witnesses alternating) -> device '
                                       'SpMV + quotient (6 NTTs) + G1 MSMs H/L/A/B1 + G2 MSM B2 + assembly; constraint system and valid key resident in HBM',
+                       'matrix_form': ('explicit, from a Parameters gate blob' if params_form else 'tiled (one instance + copy count)' if copies is not None else 'explicit'),
                        'log2_domain': log_m, 'rows': n, 'domain_fill': fill, 'num_input': num_input, 'num_aux': num_aux,
                        'nnz': list(info['nnz']), 'witness_bytes_per_proof': nv * 32,
                        'distinct_transactions': (len(zs) if copies is not None else None),
@@ -1007,6 +1114,10 @@ def main():
         if not args.no_cpu_baseline:
             out['proof_verified_by_pairing_check'] = bool(pairing_check(vk, z_inputs[0], want[0]) and
                                                           (want[1] is None or pairing_check(vk, z_inputs[1], want[1])))
+        if load_block is not None:
+            out['load'] = load_block
+        if tiled is not None:
+            out['tiled'] = tiled
         if untiled is not None:
             out['untiled'] = untiled
         if standalone is not None:

@@ -38,8 +38,9 @@ EXPORTED_SYMBOLS = [
     'fk_gen_points_g1_dev', 'fk_gen_points_g2_dev', 'fk_gen_scalars_dev',
     'fk_synthesize', 'fk_stats_reset', 'fk_stats_get', 'fk_calibrate', 'fk_verify', 'fk_verify_batch_dev', 'fk_shard_range', 'fk_h_shard_range', 'fk_work_shard_ranges', 'fk_work_shard_ranges_q0',
     'fk_dq_gather_dev', 'fk_dq_local_dev', 'fk_dq_cross_dev', 'fk_dq_cross_sub_dev',
-    'fk_setup', 'fk_setup_tiled', 'fk_r1cs_load_tiled', 'fk_key_download', 'fk_key_load_bellman', 'fk_key_write_bellman', 'fk_key_vk', 'fk_key_counts', 'fk_key_precomputed',
-    'fk_gates_decode', 'fk_gates_free', 'fk_gates_info', 'fk_gates_export', 'fk_r1cs_load_gates',
+    'fk_setup', 'fk_setup_tiled', 'fk_r1cs_load_tiled', 'fk_key_download', 'fk_key_load_bellman', 'fk_key_write_bellman', 'fk_key_vk', 'fk_key_counts', 'fk_key_precomputed', 'fk_key_load_profile',
+    'fk_gates_decode', 'fk_gates_free', 'fk_gates_info', 'fk_gates_export', 'fk_r1cs_load_gates', 'fk_gates_profile',
+    'fk_gates_encode', 'fk_blob_data', 'fk_blob_profile', 'fk_blob_free',
     'fk_r1cs_load', 'fk_r1cs_load_coded', 'fk_r1cs_free', 'fk_r1cs_info', 'fk_r1cs_density_ptrs', 'fk_r1cs_eval_dev', 'fk_r1cs_eval_slice_dev', 'fk_prove_r1cs', 'fk_prove_r1cs_dev',
     'fk_init_devices', 'fk_multi_free', 'fk_multi_last_error', 'fk_multi_size', 'fk_multi_transport', 'fk_multi_ctx', 'fk_multi_sync',
     'fk_multi_key_load', 'fk_multi_key_load_bellman', 'fk_multi_setup', 'fk_multi_setup_tiled', 'fk_multi_key_free', 'fk_multi_key_shard',
@@ -114,6 +115,8 @@ def load_library():
         lib.fk_key_free.restype = None
         lib.fk_gates_free.argtypes = [C.c_void_p]
         lib.fk_gates_free.restype = None
+        lib.fk_blob_free.argtypes = [C.c_void_p]
+        lib.fk_blob_free.restype = None
         lib.fk_multi_last_error.restype = C.c_char_p
         lib.fk_multi_last_error.argtypes = [C.c_void_p]
         lib.fk_multi_free.argtypes = [C.c_void_p]
@@ -319,6 +322,12 @@ class DeviceKey:
             raise FkError(rc, 'fk_key_precomputed')
         return dict(zip(('h', 'l', 'a', 'b_g1', 'b_g2'), list(out)))
 
+    def load_profile(self):
+        """fk_key_load_profile: seconds the loader spent on the arrays (transfer, conversion, checks) and on the fixed-base levels"""
+        out = (C.c_double * 2)()
+        self.ctx._ck(self.ctx.lib.fk_key_load_profile(self.handle, out))
+        return dict(arrays_s=out[0], levels_s=out[1])
+
     def vk(self):
         """prover-side vk points as raw Montgomery LE uint8 arrays"""
         buf = np.zeros(3 * 64 + 2 * 128, np.uint8)
@@ -394,20 +403,74 @@ FK_GATES_RAW, FK_GATES_BROTLI = 0, 1
 FK_KEY_CHECKED, FK_KEY_NO_INFINITY = 1, 2
 
 
+def _bytes_view(data):
+    """uint8 numpy view of bytes / bytearray / memoryview / ndarray without copying"""
+    if isinstance(data, np.ndarray):
+        return np.ascontiguousarray(data).view(np.uint8).reshape(-1)
+    return np.frombuffer(data, np.uint8)
+
+
+class GateBlob:
+    """fk_blob: the gate blob of a `Parameters` object as fk_gates_encode wrote it (host memory owned by the library).
+    `.data` is a uint8 view valid until free()."""
+
+    def __init__(self, r1cs, copies=None, fmt=1, quality=9, lgwin=22, ctx=None):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.fk_gates_encode(ctx.handle if ctx else None, C.byref(r1cs.struct), C.c_uint32(int(copies or 1)), C.c_int(fmt), C.c_int(quality),
+                                      C.c_int(lgwin), C.byref(h))
+        if rc != 0:
+            msg = self.lib.fk_last_error(ctx.handle if ctx else None)
+            raise FkError(rc, msg.decode() if msg else 'fk_gates_encode')
+        self.handle = h
+        p, n = C.c_void_p(), C.c_size_t()
+        self.lib.fk_blob_data(h, C.byref(p), C.byref(n))
+        self.data = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n.value,)) if n.value else np.zeros(0, np.uint8)
+        self.num_gates = r1cs.num_gates * int(copies or 1)
+
+    def profile(self):
+        out = (C.c_double * 4)()
+        self.lib.fk_blob_profile(self.handle, out)
+        v = list(out)
+        return dict(wall_s=v[0], compressor_s=v[1], stream_bytes=int(v[2]), blob_bytes=int(v[3]))
+
+    def free(self):
+        if getattr(self, 'handle', None):
+            self.data = None
+            self.lib.fk_blob_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class Gates:
     """fk_gates: the constraint system decoded from the gate blob of a `Parameters` file (host memory, native decoder).
     fmt: FK_GATES_BROTLI (what the reference writes, setup.rs:25-32) or FK_GATES_RAW (the bare Borsh gate stream)."""
 
     def __init__(self, blob, fmt, num_gates, num_input, num_aux, ctx=None):
         self.lib = load_library()
-        buf = np.frombuffer(bytes(blob), np.uint8)
+        buf = _bytes_view(blob)              # no copy: a benchmark-size blob is GBs
         h = C.c_void_p()
         rc = self.lib.fk_gates_decode(ctx.handle if ctx else None, _vp(buf), C.c_size_t(buf.size), C.c_int(fmt), C.c_uint32(num_gates),
                                       C.c_uint32(num_input), C.c_uint32(num_aux), C.byref(h))
         if rc != 0:
-            msg = self.lib.fk_last_error(ctx.handle) if ctx else b''
+            msg = self.lib.fk_last_error(ctx.handle if ctx else None)
             raise FkError(rc, msg.decode() if msg else 'fk_gates_decode')
         self.handle = h
+
+    def profile(self):
+        """fk_gates_profile: how the decoding went (seconds; the decompressor is the serial floor, the parsing runs beside it)"""
+        out = (C.c_double * 8)()
+        rc = self.lib.fk_gates_profile(self.handle, out)
+        if rc != 0:
+            raise FkError(rc, 'fk_gates_profile')
+        v = list(out)
+        return dict(wall_s=v[0], decompressor_s=v[1], waited_for_parsers_s=v[2], parse_cpu_s=v[3], renumber_s=v[4], parse_threads=int(v[5]),
+                    blocks=int(v[6]), blob_bytes=int(v[7]))
 
     def info(self):
         out = (C.c_uint64 * 8)()
@@ -773,7 +836,7 @@ class Context:
     def load_key_bellman(self, data, shard_index=0, shard_count=1, z_frac=Z_EQUAL_SPLIT, flags=FK_KEY_CHECKED):
         """fk_key_load_bellman: `data` = bytes of bellman's Parameters::write; flags = FK_KEY_CHECKED | FK_KEY_NO_INFINITY (the
         `checked` / `disallow_points_at_infinity` arguments of Parameters::read, mod.rs:159).  Returns (DeviceKey, gamma_g2, ic)."""
-        buf = np.ascontiguousarray(data, np.uint8).reshape(-1) if isinstance(data, np.ndarray) else np.frombuffer(bytes(data), np.uint8)      # (no copy of a multi-GB array)
+        buf = _bytes_view(data)      # (no copy of a multi-GB array)
         h = C.c_void_p()
         gamma = np.zeros(128, np.uint8)
         n_ic = C.c_uint32()
@@ -784,16 +847,21 @@ class Context:
                                               C.byref(n_ic)))
         return DeviceKey(self, h, shard_index, shard_count), gamma, ic[:min(n_ic.value, cap)].copy()
 
-    def write_key_bellman(self, key, vk):
+    def write_key_bellman(self, key, vk, out=None, size_only=False):
         """fk_key_write_bellman: bellman `Parameters::write` bytes of a whole resident key (GPU conversion); vk: the dict fk_setup* /
-        load_key_bellman returned (gamma_g2 and ic are not part of a proving key)"""
+        load_key_bellman returned (gamma_g2 and ic are not part of a proving key).  out: a contiguous uint8 array of at least the
+        needed size to write into (e.g. the tail of a `Parameters` image); size_only: return the byte count."""
         gamma = np.ascontiguousarray(vk['gamma_g2'], np.uint8).reshape(-1)
         ic = np.ascontiguousarray(vk['ic'], np.uint8).reshape(-1, 64)
         need = C.c_size_t()
         self._ck(self.lib.fk_key_write_bellman(self.handle, key.handle, _vp(gamma), _vp(ic), C.c_uint32(ic.shape[0]), None, C.c_size_t(0), C.byref(need)))
-        out = np.empty(need.value, np.uint8)
+        if size_only:
+            return need.value
+        if out is None:
+            out = np.empty(need.value, np.uint8)
+        assert out.dtype == np.uint8 and out.flags['C_CONTIGUOUS'] and out.nbytes >= need.value
         self._ck(self.lib.fk_key_write_bellman(self.handle, key.handle, _vp(gamma), _vp(ic), C.c_uint32(ic.shape[0]), _vp(out), C.c_size_t(out.nbytes), C.byref(need)))
-        return out
+        return out[:need.value]
 
     def setup(self, r1cs, tau, alpha, beta, gamma, delta, shard_index=0, shard_count=1, z_frac=Z_EQUAL_SPLIT, copies=None):
         """fk_setup: GPU key generation with explicit toxic waste (Montgomery limbs).  Returns (DeviceKey, vk dict)
@@ -981,7 +1049,7 @@ class MultiContext:
         return _MultiHandle(self, h, self.lib.fk_multi_key_free)
 
     def load_key_bellman(self, data, flags=FK_KEY_CHECKED):
-        buf = np.ascontiguousarray(data, np.uint8).reshape(-1) if isinstance(data, np.ndarray) else np.frombuffer(bytes(data), np.uint8)      # (no copy of a multi-GB array)
+        buf = _bytes_view(data)      # (no copy of a multi-GB array)
         h = C.c_void_p()
         gamma = np.zeros(128, np.uint8)
         n_ic = C.c_uint32()

@@ -152,6 +152,7 @@ struct fk_key {
     fk::G1Affine alpha_g1, beta_g1, delta_g1;
     fk::G2Affine beta_g2, delta_g2;
     fk::KeyPre pre_h, pre_l, pre_a, pre_b1, pre_b2;       // optional (memory permitting), see key_precompute
+    double load_s[2] = {0, 0};                            // seconds the loader spent on the arrays (transfer, conversion, checks / derivation) and on the fixed-base levels
 };
 
 #define FK_SET_ERR(ctx, code, ...)                                   \
@@ -201,6 +202,9 @@ static inline int fk_guard(C *c, F &&body) noexcept {
 }
 
 namespace fk {
+
+std::string &tls_error();      // gatestream.hip: what fk_last_error(NULL) returns (context-free calls leave their message here)
+unsigned host_threads();       // gatestream.hip: FK_HOST_THREADS, else the cores this process may use
 
 // Tuning knobs.  A release build compiles the measured default in; `make EXP=1` (-DFK_EXPERIMENTS, libfawkes_hip_exp.so, loaded
 // with FK_LIB_VARIANT=exp) reads them from the environment for same-box A/B runs.  The run-time switches of a release build

@@ -12,6 +12,7 @@
 // The device kernel turns every 32-byte big-endian coordinate into the Montgomery little-endian limbs the
 // kernels use (byte reversal + one Montgomery multiplication by R^2) and reorders G2 to c0 || c1.
 #include "common.hpp"
+#include <chrono>
 #include <string.h>
 
 namespace fk {
@@ -141,6 +142,7 @@ int fk_key_load_bellman(fk_ctx *ctx, const uint8_t *buf, size_t len, uint32_t fl
     if (flags & ~(uint32_t)(FK_KEY_CHECKED | FK_KEY_NO_INFINITY)) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "key file: unknown flags 0x%x", flags);
     *out = nullptr;
     FK_HIP(ctx, hipSetDevice(ctx->device));
+    const auto t_start = std::chrono::steady_clock::now();
     Cursor c{buf, len};
     const uint8_t *vkp[6];
     const size_t vkw[6] = {64, 64, 128, 128, 64, 128};    // alpha_g1, beta_g1, beta_g2, gamma_g2, delta_g1, delta_g2
@@ -235,7 +237,10 @@ int fk_key_load_bellman(fk_ctx *ctx, const uint8_t *buf, size_t len, uint32_t fl
     if (gamma_g2_out) memcpy(gamma_g2_out, &vk2[1], 128);
     if (n_ic) *n_ic = cnt[0];
     if (ic_out) memcpy(ic_out, ic.data(), (size_t)(cnt[0] < ic_cap ? cnt[0] : ic_cap) * 64);
+    const auto t_arrays = std::chrono::steady_clock::now();
     if ((rc = key_precompute(ctx, k)) != FK_OK) { fk_key_free(ctx, k); return rc; }
+    k->load_s[0] = std::chrono::duration<double>(t_arrays - t_start).count();
+    k->load_s[1] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_arrays).count();
     *out = k;
     return FK_OK;
 }); }

@@ -113,7 +113,8 @@ void fk_free(fk_ctx *ctx) {
     delete ctx;
 }
 
-const char *fk_last_error(const fk_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+// ctx == NULL: the message of the calling thread's latest context-free call (fk_gates_decode / fk_gates_encode / fk_verify with a NULL context)
+const char *fk_last_error(const fk_ctx *ctx) { return ctx ? ctx->err.c_str() : fk::tls_error().c_str(); }
 
 // Releases everything the context has grown for the proofs it has run -- the MSM lanes' scratch, the transforms' tables and buffers, the
 // staging vectors, the two witness slots -- and keeps keys and resident constraint systems.  All of it is re-allocated on demand.
@@ -322,6 +323,12 @@ int fk_key_precomputed(const fk_key *k, uint32_t out[5]) {
     if (!k || !out) return FK_ERR_BAD_ARG;
     const KeyPre *p[5] = {&k->pre_h, &k->pre_l, &k->pre_a, &k->pre_b1, &k->pre_b2};
     for (int i = 0; i < 5; i++) out[i] = p[i]->lev ? p[i]->W : 0;
+    return FK_OK;
+}
+
+int fk_key_load_profile(const fk_key *k, double out[2]) {
+    if (!k || !out) return FK_ERR_BAD_ARG;
+    out[0] = k->load_s[0]; out[1] = k->load_s[1];
     return FK_OK;
 }
 

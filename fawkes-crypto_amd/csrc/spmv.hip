@@ -206,8 +206,10 @@ void fk_r1cs_free(fk_ctx *ctx, fk_r1cs_dev *r) {
 
 // cs: one instance; the resident system stands for `copies` of it (1 = the system itself).  pre_cidx / pre_table: the
 // coefficients already dictionary-coded (gatestream.hip: slot 0 = ONE), cs->*_val then unused.
+// pre_density: a_aux / b_in / b_aux flags the caller already derived (the gate decoder does, while it parses): the arrays then come
+// from this library's own decoder, which has range-checked every index -- the per-term passes over the host arrays are skipped.
 static int r1cs_load_impl(fk_ctx *ctx, const fk_r1cs *cs, uint32_t copies, fk_r1cs_dev **out, const uint32_t *const *pre_cidx = nullptr,
-                          const Fr *pre_table = nullptr, uint64_t n_pre_table = 0) {
+                          const Fr *pre_table = nullptr, uint64_t n_pre_table = 0, const uint8_t *const *pre_density = nullptr) {
     if (!ctx || !cs || !out) return FK_ERR_BAD_ARG;
     *out = nullptr;
     if (copies == 0) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "r1cs: copies must be at least 1");
@@ -220,6 +222,7 @@ static int r1cs_load_impl(fk_ctx *ctx, const fk_r1cs *cs, uint32_t copies, fk_r1
     for (int k = 0; k < 3; k++) {
         if (!ptrs[k]) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "r1cs: null row pointer");
         if (ptrs[k][0] != 0) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "r1cs: row_ptr[0] must be 0");
+        if (pre_density && pre_cidx) continue;
         for (uint64_t g = 0; g < cs->num_gates; g++) if (ptrs[k][g + 1] < ptrs[k][g]) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "r1cs: row_ptr not monotone");
         const uint64_t nnz = ptrs[k][cs->num_gates];
         if (nnz && !cols[k]) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "r1cs: null column array");   // vals[k] == NULL: all coefficients ONE
@@ -243,6 +246,11 @@ static int r1cs_load_impl(fk_ctx *ctx, const fk_r1cs *cs, uint32_t copies, fk_r1
         table.assign(pre_table, pre_table + n_pre_table);
     }
     std::vector<uint8_t> a_aux(cs->num_aux ? cs->num_aux : 1, 0), b_in(cs->num_input, 0), b_aux(cs->num_aux ? cs->num_aux : 1, 0);
+    const bool trusted = pre_density && pre_cidx;
+    if (trusted) {
+        if (cs->num_aux) { memcpy(a_aux.data(), pre_density[0], cs->num_aux); memcpy(b_aux.data(), pre_density[2], cs->num_aux); }
+        memcpy(b_in.data(), pre_density[1], cs->num_input);
+    }
     int rc = FK_OK;
     auto fail = [&](int code) { fk_r1cs_free(ctx, r); return code; };
     // rows of [wave_lo, wave_hi) terms of a batch of >= wave_copies copies go to spmv_tiled_wave_kernel (see there).  The length
@@ -260,9 +268,9 @@ static int r1cs_load_impl(fk_ctx *ctx, const fk_r1cs *cs, uint32_t copies, fk_r1
     for (int k = 0; k < 3 && rc == FK_OK; k++) {
         const uint64_t nnz = ptrs[k][cs->num_gates];
         r->nnz[k] = nnz * copies;
-        std::vector<uint32_t> cidx(nnz ? nnz : 1);
+        std::vector<uint32_t> cidx(trusted ? 1 : nnz ? nnz : 1);
         Fr last = one; uint32_t last_idx = 0;        // one-entry cache in front of the hash map
-        for (uint64_t i = 0; i < nnz; i++) {
+        for (uint64_t i = 0; i < nnz && !trusted; i++) {
             uint32_t ci = 0;
             if (pre_cidx) {
                 ci = pre_cidx[k][i];
@@ -290,7 +298,7 @@ static int r1cs_load_impl(fk_ctx *ctx, const fk_r1cs *cs, uint32_t copies, fk_r1
             hipMalloc((void **)&r->cidx[k], (nnz + 1) * 4) != hipSuccess) { ctx->err = "r1cs: device allocation failed"; return fail(FK_ERR_OOM); }
         if (hipMemcpy(r->ptr[k], ptrs[k], (cs->num_gates + 1) * 8, hipMemcpyHostToDevice) != hipSuccess) rc = FK_ERR_HIP;
         if (nnz && hipMemcpy(r->col[k], cols[k], nnz * 4, hipMemcpyHostToDevice) != hipSuccess) rc = FK_ERR_HIP;
-        if (nnz && hipMemcpy(r->cidx[k], cidx.data(), nnz * 4, hipMemcpyHostToDevice) != hipSuccess) rc = FK_ERR_HIP;
+        if (nnz && hipMemcpy(r->cidx[k], trusted ? pre_cidx[k] : cidx.data(), nnz * 4, hipMemcpyHostToDevice) != hipSuccess) rc = FK_ERR_HIP;
         // length classes (spmv_binned_kernel) when the matrix has long rows
         uint64_t maxlen = 0;
         for (uint64_t g = 0; g < cs->num_gates; g++) if (ptrs[k][g + 1] - ptrs[k][g] > maxlen) maxlen = ptrs[k][g + 1] - ptrs[k][g];
@@ -408,11 +416,11 @@ int fk_r1cs_load(fk_ctx *ctx, const fk_r1cs *cs, fk_r1cs_dev **out) { return fk_
 }  // extern "C"
 namespace fk {
 int r1cs_load_coded(fk_ctx *ctx, uint32_t num_input, uint32_t num_aux, uint64_t num_gates, const uint64_t *const ptr[3], const uint32_t *const col[3],
-                    const uint32_t *const cidx[3], const Fr *table, uint64_t n_table, fk_r1cs_dev **out) {
+                    const uint32_t *const cidx[3], const Fr *table, uint64_t n_table, fk_r1cs_dev **out, const uint8_t *const density[3]) {
     fk_r1cs cs{};
     cs.num_input = num_input; cs.num_aux = num_aux; cs.num_gates = num_gates;
     cs.a_ptr = ptr[0]; cs.a_col = col[0]; cs.b_ptr = ptr[1]; cs.b_col = col[1]; cs.c_ptr = ptr[2]; cs.c_col = col[2];
-    return r1cs_load_impl(ctx, &cs, 1, out, cidx, table, n_table);
+    return r1cs_load_impl(ctx, &cs, 1, out, cidx, table, n_table, density);
 }
 }  // namespace fk
 extern "C" {

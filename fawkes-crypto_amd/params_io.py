@@ -149,8 +149,9 @@ def write_parameters(num_gates, gates_blob, const_tracker_bits, bellman_bytes):
 
 
 def read_parameters(data):
-    """mod.rs:159-175.  Returns dict(num_gates, gates_blob, const_tracker (list of bool), bellman (bytes))."""
-    data = bytes(data)
+    """mod.rs:159-175.  Returns dict(num_gates, gates_blob, const_tracker (list of bool), bellman).  `gates_blob` and `bellman` are
+    memoryviews INTO `data` (bytes, bytearray, memoryview or a uint8 ndarray): a benchmark-size image is 14 GB and is not copied."""
+    data = memoryview(data).cast('B') if not isinstance(data, memoryview) else data.cast('B')
     pos = 0
 
     def u32():
@@ -173,38 +174,76 @@ def read_parameters(data):
     gates_blob = blob()
     nbits = u32()
     bv = blob()
-    return dict(num_gates=num_gates, gates_blob=gates_blob, const_tracker=bytes_to_bits(bv, nbits), bellman=data[pos:])
+    return dict(num_gates=num_gates, gates_blob=gates_blob, const_tracker=bytes_to_bits(bytes(bv), nbits), bellman=data[pos:])
+
+
+def bellman_counts(bellman):
+    """(num_input, num_aux, h, a, b) point counts of a bellman `Parameters::write` image without touching the points: the verifying key is
+    576 bytes, every array a u32 BE count followed by its uncompressed points (ic, h, l, a, b_g1: 64 B; b_g2: 128 B)."""
+    view = memoryview(bellman).cast('B') if not isinstance(bellman, memoryview) else bellman.cast('B')
+    pos, out = 64 + 64 + 128 + 128 + 64 + 128, []
+    for width in (64, 64, 64, 64, 64):
+        if pos + 4 > len(view):
+            raise ValueError('Parameters file truncated (bellman part)')
+        (n,) = struct.unpack_from('>I', view, pos)
+        out.append(n)
+        pos += 4 + n * width
+    ic, h, l, a, b = out
+    return dict(num_input=ic, num_aux=l, h=h, a=a, b=b)
 
 
 def load_parameters(ctx, data, shard_index=0, shard_count=1, z_frac=(-1.0, -1.0), checked=True, disallow_points_at_infinity=False,
-                    want_host_r1cs=False):
+                    want_host_r1cs=False, timings=None):
     """`Parameters::read(reader, disallow_points_at_infinity, checked)` (mod.rs:159-175) for the GPU prover: file bytes ->
     (DeviceKey resident in HBM, DeviceR1cs resident in HBM, header dict incl. gamma_g2 / ic / const_tracker for a verifier
     and for the witness generator).  The key part is converted and checked on the GPU (fk_key_load_bellman), the gate blob
-    is decoded natively (api.Gates).  want_host_r1cs: also return the decoded system as an api.R1cs in hdr['r1cs']."""
+    is decoded natively (api.Gates: one decompressing thread, the parsing on all host threads).  want_host_r1cs: also return the
+    decoded system as an api.R1cs in hdr['r1cs'].  timings: a dict that receives the seconds of every stage."""
+    import time
+    tm = timings if timings is not None else {}
+    t0 = time.perf_counter()
     hdr = read_parameters(data)
     flags = (api.FK_KEY_CHECKED if checked else 0) | (api.FK_KEY_NO_INFINITY if disallow_points_at_infinity else 0)
-    key, gamma_g2, ic = ctx.load_key_bellman(hdr['bellman'], shard_index, shard_count, z_frac, flags=flags)
-    c = key.counts()
-    blob = hdr['gates_blob']
-    raw = blob.startswith(RAW_MAGIC)
-    gates = dr = None
+    # The circuit first, then the key: the loader sizes the key's fixed-base levels against the HBM that is free at that moment, and a
+    # resident system of 1.6e9 terms is 14 GB the levels must not take.  num_input / num_aux are the lengths of ic and l.
     try:
+        c = bellman_counts(hdr['bellman'])
+    except ValueError:
+        ctx.load_key_bellman(hdr['bellman'], shard_index, shard_count, z_frac, flags=flags)[0].free()      # raises the loader's own FK_ERR_FORMAT
+        raise
+    blob = hdr['gates_blob']
+    raw = bytes(blob[:len(RAW_MAGIC)]) == RAW_MAGIC
+    gates = dr = key = None
+    try:
+        t1 = time.perf_counter()
         gates = api.Gates(blob[len(RAW_MAGIC):] if raw else blob, api.FK_GATES_RAW if raw else api.FK_GATES_BROTLI, hdr['num_gates'],
                           c['num_input'], c['num_aux'], ctx=ctx)
+        tm['gates_decode_s'] = time.perf_counter() - t1
+        tm['gates_decode_profile'] = gates.profile()
+        t1 = time.perf_counter()
         dr = gates.load(ctx)
-        hdr.update(gamma_g2=gamma_g2, ic=ic, gates_info=gates.info())
+        tm['r1cs_load_s'] = time.perf_counter() - t1
+        hdr['gates_info'] = gates.info()
         if want_host_r1cs:
             hdr['r1cs'] = gates.to_r1cs()
+        gates.free()
+        gates = None
+        t1 = time.perf_counter()
+        key, gamma_g2, ic = ctx.load_key_bellman(hdr['bellman'], shard_index, shard_count, z_frac, flags=flags)
+        tm['key_read_s'] = time.perf_counter() - t1               # bellman's Parameters::read incl. the fixed-base levels of the arrays
+        tm['key_read_profile'] = key.load_profile()
+        hdr.update(gamma_g2=gamma_g2, ic=ic)
     except Exception:
-        # nothing stays behind in HBM when the circuit half of the file is bad (a 2^25 key is several GB)
+        # nothing stays behind in HBM when either half of the file is bad (a 2^25 key is several GB)
         if dr is not None:
             dr.free()
-        key.free()
+        if key is not None:
+            key.free()
         raise
     finally:
         if gates is not None:
             gates.free()
+    tm['total_s'] = time.perf_counter() - t0
     return key, dr, hdr
 
 
@@ -216,14 +255,47 @@ def store_parameters(key_arrays, r1cs, const_tracker_bits=(), compress=None):
     return write_parameters(r1cs.num_gates, blob, list(const_tracker_bits), encode_bellman_parameters(key_arrays))
 
 
-def store_parameters_dev(ctx, key, vk, r1cs, const_tracker_bits=(), compress=None, gates_blob=None):
-    """`Parameters::write` (mod.rs:150-157) for a key RESIDENT in HBM, at any size: fawkes' header from the host, the bellman part
-    converted on the GPU (fk_key_write_bellman: Montgomery limbs -> big-endian canonical points, ~seconds for a 2^25 key, where
-    `store_parameters` walks every point in Python).  vk: the dict fk_setup* / load_key_bellman returned (gamma_g2, ic).  The gate
-    blob is `gates_blob` as given (e.g. the blob the key was loaded with) or the encoded `r1cs` (slow per-term encoder: small
-    systems)."""
+def store_parameters_dev(ctx, key, vk, r1cs, const_tracker_bits=(), compress=None, gates_blob=None, copies=None, quality=9, lgwin=22,
+                         timings=None):
+    """`Parameters::write` (mod.rs:150-157) for a key RESIDENT in HBM, at any size, as ONE uint8 array: fawkes' header from the host,
+    the gate blob written natively (fk_gates_encode: Gate::serialize of every gate through libbrotlienc; setup.rs:25-32 uses quality 9 /
+    lgwin 22 -- any setting decodes alike, and quality 1 is 25 x faster at 61 GB of stream), the bellman part converted on the GPU
+    straight into the image (fk_key_write_bellman: Montgomery limbs -> big-endian canonical points, ~seconds for a 2^25 key).
+    vk: the dict fk_setup* / load_key_bellman returned (gamma_g2, ic).  The gate blob is `gates_blob` as given (e.g. the blob the key
+    was loaded with), or `compress(encode_gate_stream(r1cs))` when a `compress` callable is given (the slow per-term restatement: small
+    systems, tests), or the native encoding of `copies` copies of `r1cs` (fk_r1cs_load_tiled's variable order; None = the system itself).
+    A blob of 4 GiB or more cannot be written: Borsh's Vec<u8> length is a u32 (the reference's writer fails the same way)."""
+    import time
+    tm = timings if timings is not None else {}
+    t0 = time.perf_counter()
+    owned = None
     if gates_blob is None:
-        stream = encode_gate_stream(r1cs)
-        gates_blob = compress(stream) if compress is not None else RAW_MAGIC + stream
-    bell = ctx.write_key_bellman(key, vk)
-    return write_parameters(r1cs.num_gates, gates_blob, list(const_tracker_bits), bell.tobytes())
+        if compress is not None:
+            gates_blob = compress(encode_gate_stream(r1cs))
+        else:
+            owned = api.GateBlob(r1cs, copies, fmt=api.FK_GATES_BROTLI, quality=quality, lgwin=lgwin, ctx=ctx)
+            gates_blob = owned.data
+            tm['gates_encode_profile'] = owned.profile()
+    tm['gates_encode_s'] = time.perf_counter() - t0
+    try:
+        blob = api._bytes_view(gates_blob)
+        if blob.size >= 1 << 32:
+            raise ValueError('gate blob of %d bytes: Borsh Vec<u8> holds less than 4 GiB (mod.rs:153)' % blob.size)
+        bits = list(const_tracker_bits)
+        bv = bits_to_bytes(bits)
+        head = struct.pack('<I', r1cs.num_gates * int(copies or 1)) + struct.pack('<I', blob.size)
+        mid = struct.pack('<I', len(bits)) + struct.pack('<I', len(bv)) + bv
+        t1 = time.perf_counter()
+        need = ctx.write_key_bellman(key, vk, size_only=True)
+        image = np.empty(len(head) + blob.size + len(mid) + need, np.uint8)
+        o = 0
+        image[o:o + len(head)] = np.frombuffer(head, np.uint8); o += len(head)
+        image[o:o + blob.size] = blob; o += blob.size
+        image[o:o + len(mid)] = np.frombuffer(mid, np.uint8); o += len(mid)
+        ctx.write_key_bellman(key, vk, out=image[o:])
+        tm['key_write_s'] = time.perf_counter() - t1
+        tm['blob_bytes'] = int(blob.size); tm['bellman_bytes'] = int(need); tm['total_s'] = time.perf_counter() - t0
+        return image
+    finally:
+        if owned is not None:
+            owned.free()

@@ -75,7 +75,7 @@ enum {
 /* ---------------------------------------------------------------- context */
 int fk_init(int device_id, fk_ctx **out);
 void fk_free(fk_ctx *ctx);
-const char *fk_last_error(const fk_ctx *ctx);
+const char *fk_last_error(const fk_ctx *ctx);     /* ctx == NULL: the calling thread's latest context-free call (fk_gates_decode, fk_gates_encode) */
 /* 0 = library default.  Pippenger window bits (2..22) used by subsequent MSMs; for tests/tuning. */
 /* Releases the scratch the context has grown for the proofs it has run (MSM lanes, transform tables, staging vectors, witness
  * slots); keys and resident constraint systems stay.  Everything is re-allocated on demand.  Not while a proof is submitted. */
@@ -145,6 +145,9 @@ int fk_key_shard_info2(const fk_key *key, uint64_t out[10]);
  * W, and wider windows.  Same group elements, so the proof bytes do not change.  FK_MSM_PRECOMP=0 turns it off; an
  * array whose levels do not fit simply keeps the ordinary path.  out[5] = levels held for h, l, a, b_g1, b_g2 (0 = none). */
 int fk_key_precomputed(const fk_key *key, uint32_t out[5]);
+/* what loading the key cost: out[0] = seconds for the arrays themselves (transfer + conversion + the checks of fk_key_load_bellman, or
+ * the derivation of fk_setup*), out[1] = seconds for the fixed-base levels */
+int fk_key_load_profile(const fk_key *key, double out[2]);
 /* Host-only key holding just the vk points fk_prove_assemble needs (no device memory, no GPU).
  * Free with fk_key_free(NULL, key). */
 int fk_key_host_vk(const uint8_t *alpha_g1, const uint8_t *beta_g1, const uint8_t *delta_g1,
@@ -366,8 +369,25 @@ void fk_gates_free(fk_gates *gates);
 int fk_gates_info(const fk_gates *gates, uint64_t out[8]);
 /* matrix mtx (0 = A, 1 = B, 2 = C) as the arrays of an fk_r1cs: ptr[num_gates + 1], col[nnz] and (if non-NULL) val[nnz x 4] */
 int fk_gates_export(const fk_gates *gates, int mtx, uint64_t *ptr, uint32_t *col, uint64_t *val);
-/* the resident constraint system of the decoded stream (as fk_r1cs_load; the dictionary is taken over as is) */
+/* the resident constraint system of the decoded stream (as fk_r1cs_load; the dictionary and the structural density flags the
+ * decoder derived while parsing are taken over as they are) */
 int fk_r1cs_load_gates(fk_ctx *ctx, const fk_gates *gates, fk_r1cs_dev **out);
+/* how the decoding went: out[8] = wall seconds, seconds inside the decompressor, seconds the decoding thread waited for a free
+ * parsing thread, parsing seconds summed over the threads, seconds renumbering the dictionary, parsing threads, blocks, blob bytes.
+ * (The decompressor is one serial bit stream -- the floor; the parsing runs beside it on FK_HOST_THREADS threads, default: the
+ * cores this process may use.) */
+int fk_gates_profile(const fk_gates *gates, double out[8]);
+/* The writer's side (setup.rs:25-32: `Parameters.2` = brotli(quality 9, lgwin 22) over Gate::serialize of every gate, cs.rs:184-191):
+ * the gate blob of `copies` copies of `cs` (fk_r1cs_load_tiled's variable order; 1 = the system itself), FK_GATES_BROTLI through the
+ * system's libbrotlienc.so.1 (FK_ERR_UNSUPPORTED if absent; quality 0 .. 11, lgwin 10 .. 24 -- any setting decodes alike) or
+ * FK_GATES_RAW (the bare stream; quality / lgwin ignored).  The stream is formatted by FK_HOST_THREADS threads and never exists as
+ * a whole: the benchmark's 61 GB stream becomes a 2.8 GB blob at quality 1.  ctx may be NULL. */
+typedef struct fk_blob fk_blob;
+int fk_gates_encode(fk_ctx *ctx, const fk_r1cs *cs, uint32_t copies, int format, int quality, int lgwin, fk_blob **out);
+int fk_blob_data(const fk_blob *blob, const uint8_t **data, size_t *len);
+/* out[4] = wall seconds, seconds inside the compressor, stream bytes, blob bytes */
+int fk_blob_profile(const fk_blob *blob, double out[4]);
+void fk_blob_free(fk_blob *blob);
 
 /* ---------------------------------------------------------------- key generation on the GPU
  * (SURVEY section 8f row 4): bellman's generate_parameters (reached from setup.rs:20) for EXPLICIT toxic

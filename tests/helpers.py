@@ -101,3 +101,19 @@ def brotli_compress(data, quality=9, lgwin=22):
     ok = enc.BrotliEncoderCompress(quality, lgwin, 0, len(data), bytes(data), C.byref(n), out)
     assert ok == 1, 'BrotliEncoderCompress failed'
     return out.raw[:n.value]
+
+
+def brotli_decompress(data, cap=1 << 28):
+    """the system's libbrotlidec.so.1, one-shot (test-side check of what fk_gates_encode wrote).  None when the library is absent."""
+    import ctypes as C
+    import ctypes.util
+    try:
+        dec = C.CDLL(ctypes.util.find_library('brotlidec') or 'libbrotlidec.so.1')
+    except OSError:
+        return None
+    dec.BrotliDecoderDecompress.argtypes = [C.c_size_t, C.c_char_p, C.POINTER(C.c_size_t), C.c_char_p]
+    out = C.create_string_buffer(cap)
+    n = C.c_size_t(cap)
+    ok = dec.BrotliDecoderDecompress(len(data), bytes(data), C.byref(n), out)
+    assert ok == 1, 'BrotliDecoderDecompress failed'
+    return out.raw[:n.value]

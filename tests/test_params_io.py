@@ -334,3 +334,114 @@ def test_native_bellman_writer_matches_the_restatement_and_round_trips(ctx, orac
     for k_ in (dk, dk2, dk3, dk4):
         k_.free()
     dr4.free()
+
+
+def _replicate(r1cs, copies):
+    """the explicit system fk_r1cs_load_tiled stands for: ONE shared, copy j's inputs at 1 + j*(ni-1), its aux at j*na (include/fawkes_hip.h)"""
+    from fawkes_crypto_amd import api
+    ni, na = r1cs.num_input, r1cs.num_aux
+    n_in = 1 + copies * (ni - 1)
+    mats = []
+    for ptr, col, val in r1cs.mats:
+        col = col.astype(np.int64)
+        cols, ptrs = [], [np.zeros(1, np.uint64)]
+        for j in range(copies):
+            c = col.copy()
+            is_in = (c > 0) & (c < ni)
+            is_aux = c >= ni
+            c[is_in] += j * (ni - 1)
+            c[is_aux] += n_in + j * na - ni
+            cols.append(c)
+            ptrs.append(ptr[1:] + np.uint64(j * len(col)))
+        mats.append((np.concatenate(ptrs), np.concatenate(cols).astype(np.uint32), None if val is None else np.tile(val, (copies, 1))))
+    return api.R1cs(n_in, copies * na, *mats)
+
+
+def test_native_gate_encoder_matches_the_restatement(oracle, monkeypatch):
+    """fk_gates_encode (csrc/gatestream.hip, host code): Gate::serialize of every gate (cs.rs:184-191) -- byte-equal to the per-term
+    Python restatement for a system and for `copies` copies of it (= the explicitly replicated system), as a raw stream and through
+    the system's brotli encoder at the reference's setting (quality 9, lgwin 22) and at the fast one the benchmark uses; the native
+    decoder returns the system that went in, with the SAME dictionary order whatever the thread count."""
+    import fawkes_crypto_amd as fk
+    from fawkes_crypto_amd import api, params_io as pio
+    from helpers import brotli_decompress
+    cs, _, _ = ref.random_r1cs(91, 120, 4, 150)
+    r1cs = r1cs_product(fx.r1cs_to_csr(cs))
+    want = pio.encode_gate_stream(r1cs)
+    raw = api.GateBlob(r1cs, None, fmt=api.FK_GATES_RAW)
+    assert raw.data.tobytes() == want and raw.num_gates == r1cs.num_gates
+    rep = _replicate(r1cs, 5)
+    want5 = pio.encode_gate_stream(rep)
+    raw5 = api.GateBlob(r1cs, 5, fmt=api.FK_GATES_RAW)
+    assert raw5.data.tobytes() == want5 and raw5.num_gates == 5 * r1cs.num_gates
+    if brotli_decompress(b'\x06') is None:            # (the empty stream) -- no libbrotli in this environment
+        pytest.skip('libbrotlidec.so.1 not present')
+    for q, lg in ((9, 22), (1, 22), (0, 18)):
+        b = api.GateBlob(r1cs, 5, fmt=api.FK_GATES_BROTLI, quality=q, lgwin=lg)
+        assert b.data.size < len(want5) and brotli_decompress(b.data.tobytes()) == want5
+        prof = b.profile()
+        assert prof['stream_bytes'] == len(want5) and prof['blob_bytes'] == b.data.size
+        g = api.Gates(b.data, api.FK_GATES_BROTLI, b.num_gates, rep.num_input, rep.num_aux)       # (a numpy view: no copy)
+        _same_system(g.to_r1cs(), rep)
+        b.free(); g.free()
+    with pytest.raises(fk.FkError) as e:
+        api.GateBlob(r1cs, 5, fmt=api.FK_GATES_BROTLI, quality=12)
+    assert e.value.code == 1
+    # a system of several blocks: the tables of a 1-thread and of a many-thread decode are the same arrays
+    cs2, _, _, _ = fx.fast_r1cs(78, 30000, 3, 31000)
+    big = r1cs_product(cs2)
+    blob = api.GateBlob(big, 9, fmt=api.FK_GATES_BROTLI, quality=1)
+    n_in, n_aux = 1 + 9 * (big.num_input - 1), 9 * big.num_aux
+    outs = []
+    for threads in ('1', '3', '8'):
+        monkeypatch.setenv('FK_HOST_THREADS', threads)
+        g = api.Gates(blob.data, api.FK_GATES_BROTLI, blob.num_gates, n_in, n_aux)
+        assert g.profile()['parse_threads'] == max(1, int(threads) - (int(threads) > 2)) and g.profile()['blocks'] >= 4
+        raw_tab = []
+        for k in range(3):
+            i = g.info()
+            ptr = np.zeros(i['num_gates'] + 1, np.uint64); col = np.zeros(i['nnz'][k], np.uint32); val = np.zeros((i['nnz'][k], 4), np.uint64)
+            assert g.lib.fk_gates_export(g.handle, k, ptr.ctypes.data_as(api.C.c_void_p), col.ctypes.data_as(api.C.c_void_p), val.ctypes.data_as(api.C.c_void_p)) == 0
+            raw_tab.append((ptr, col, val))
+        outs.append((g.info(), raw_tab))
+        g.free()
+    for info, tabs in outs[1:]:
+        assert info == outs[0][0]
+        for (p0, c0, v0), (p1, c1, v1) in zip(tabs, outs[0][1]):
+            assert np.array_equal(p0, p1) and np.array_equal(c0, c1) and np.array_equal(v0, v1)
+    _same_system(api.R1cs(n_in, n_aux, *outs[0][1]), _replicate(big, 9))
+
+
+def test_gate_decoder_blocks_giant_gate_and_earliest_error(monkeypatch):
+    """the threaded decoder's block cutting: a linear combination larger than a block (10 MiB of terms in ONE gate) passes through both
+    the in-memory and the decompressing path; with errors in two distant blocks the EARLIEST one is reported (what the reference's
+    serial reader would have hit)."""
+    import fawkes_crypto_amd as fk
+    from fawkes_crypto_amd import api
+    from helpers import brotli_compress
+    n_big = 300000                                   # x 37 B = 11.1 MB > the 8 MiB block target
+    one = (1).to_bytes(32, 'little')
+    item = lambda tag, idx, c=one: c + bytes([tag]) + idx.to_bytes(4, 'little')
+    small_gate = (1).to_bytes(4, 'little') + item(1, 3) + (1).to_bytes(4, 'little') + item(0, 0) + (0).to_bytes(4, 'little')
+    giant = (n_big).to_bytes(4, 'little') + b''.join(item(1, i % 7) for i in range(n_big)) + (0).to_bytes(4, 'little') + (1).to_bytes(4, 'little') + item(1, 6, (5).to_bytes(32, 'little'))
+    stream = small_gate * 3 + giant + small_gate * 2
+    monkeypatch.setenv('FK_HOST_THREADS', '4')
+    for data, fmt in ((stream, api.FK_GATES_RAW), (brotli_compress(stream), api.FK_GATES_BROTLI)):
+        if data is None:
+            continue
+        g = api.Gates(data, fmt, 6, 1, 7)
+        i = g.info()
+        assert i['nnz'] == (5 + n_big, 5, 1) and i['decoded_bytes'] == len(stream) and i['distinct_coefficients'] == 2
+        r = g.to_r1cs()
+        assert int(r.mats[0][0][4] - r.mats[0][0][3]) == n_big and np.array_equal(r.mats[0][1][3:3 + 14] - 1, np.arange(14) % 7)
+        g.free()
+    # two malformed items, ~40 MB apart: the first one's message wins whichever thread meets its block first
+    many = small_gate * 600000                       # 51 MB: several blocks
+    bad = bytearray(many)
+    first, second = 1000 * len(small_gate) + 4 + 32, 590000 * len(small_gate) + 4 + 33
+    bad[first] = 9                                   # tag 9: "enum elements overflow"
+    bad[second:second + 4] = (1 << 30).to_bytes(4, 'little')     # aux index out of range
+    for _ in range(3):
+        with pytest.raises(fk.FkError) as e:
+            api.Gates(bytes(bad), api.FK_GATES_RAW, 600000, 1, 7)
+        assert e.value.code == 7 and 'enum elements overflow' in str(e.value)
