@@ -808,7 +808,7 @@ def main():
         if not multi:
             state['ticket'] = ctx.prove_witness_submit(key, dr, z_pin[0], r, s)
         else:
-            ctx.witness_upload_async(0, z_pin[0])
+            state['wit'] = parallel.witness_all_gather(ctx, 0, z_pin[0], rank, world, device=comm_dev)
         state['i'] = 0
 
     def step():
@@ -818,7 +818,9 @@ def main():
             proof = ctx.prove_witness_wait(state['ticket'])                          # ... runs underneath this proof
             state['ticket'] = nxt
             return proof
-        ctx.witness_upload_async((i + 1) & 1, z_pin[(i + 1) & 1])                    # every rank evaluates the full constraint system
+        # every rank evaluates the full constraint system, so every rank needs all of z: each uploads 1 / N of it over its own PCIe link and
+        # the ranks all-gather the pieces over xGMI (RCCL) on the library's copy stream, underneath this proof
+        state['wit'] = parallel.witness_all_gather(ctx, (i + 1) & 1, z_pin[(i + 1) & 1], rank, world, device=comm_dev)
         return prove_multi(ctx.witness_ptr(i & 1))
 
     def drain():
@@ -1054,6 +1056,9 @@ def main():
                        'msm_points': {'h': m - 1, 'l': num_aux, 'a': n_a, 'b_g1': n_b, 'b_g2': n_b},
                        'msm_fixed_base_levels': pre_levels,
                        'witness': '%.1f%% zeros, %.1f%% ones, rest dense 254-bit' % (100.0 * zeros / nv, 100.0 * ones / nv),
+                       'witness_hand_over': None if not multi else dict(state.get('wit') or {}, what='per rank and proof: this rank\'s 1 / N piece over its own PCIe link '
+                                                                                      '(pcie_bytes), the rest collected from the peers by dist.all_gather_into_tensor (RCCL over xGMI) on '
+                                                                                      'the library\'s copy stream, underneath the proof before (gathered_bytes)'),
                        'witness_array_split': None if world == 1 else ('quotient on rank 0: all of h and a piece of the work line on rank 0, witness pieces elsewhere (FK_Z_WORK_SPLIT_Q0); nothing but 384-byte sums exchanged' if q0_split else
                                                                         'fractions (balanced schedule)' if not dist_q else 'equal' if os.environ.get('FK_MULTI_SPLIT') == 'equal' else
                                                                         'by work: l | a | b_g1 | b_g2 cut into N equal pieces of work (FK_Z_WORK_SPLIT)'),

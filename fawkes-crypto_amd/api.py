@@ -28,7 +28,7 @@ FQ_MODULUS = 2188824287183927522224640574525727508869631115729782366268903789464
 EXPORTED_SYMBOLS = [
     'fk_init', 'fk_free', 'fk_trim', 'fk_last_error', 'fk_set_window_bits',
     'fk_dev_alloc', 'fk_dev_free', 'fk_upload', 'fk_download', 'fk_dev_copy', 'fk_sync', 'fk_stream',
-    'fk_host_alloc', 'fk_host_free', 'fk_witness_upload_async', 'fk_witness_ptr', 'fk_prove_r1cs_submit', 'fk_prove_r1cs_wait',
+    'fk_host_alloc', 'fk_host_free', 'fk_witness_upload_async', 'fk_witness_ptr', 'fk_witness_slot', 'fk_witness_upload_part_async', 'fk_witness_mark_ready', 'fk_prove_r1cs_submit', 'fk_prove_r1cs_wait',
     'fk_key_load', 'fk_key_synthetic', 'fk_key_shard_info', 'fk_key_shard_info2', 'fk_key_host_vk', 'fk_key_free',
     'fk_prove', 'fk_prove_dev', 'fk_prove_msms', 'fk_prove_msms_dev', 'fk_prove_msms_z_dev', 'fk_prove_msm_h_dev', 'fk_prove_msm_array_dev', 'fk_prove_msms_hz_dev',
     'fk_prove_msms_z_begin_dev', 'fk_prove_msms_finish_dev', 'fk_prove_msms_hz_r1cs_dev', 'fk_prove_msms_z_begin_r1cs_dev',
@@ -42,7 +42,7 @@ EXPORTED_SYMBOLS = [
     'fk_gates_decode', 'fk_gates_free', 'fk_gates_info', 'fk_gates_export', 'fk_r1cs_load_gates', 'fk_gates_profile',
     'fk_gates_encode', 'fk_blob_data', 'fk_blob_profile', 'fk_blob_free',
     'fk_r1cs_load', 'fk_r1cs_load_coded', 'fk_r1cs_free', 'fk_r1cs_info', 'fk_r1cs_density_ptrs', 'fk_r1cs_eval_dev', 'fk_r1cs_eval_slice_dev', 'fk_prove_r1cs', 'fk_prove_r1cs_dev',
-    'fk_init_devices', 'fk_multi_free', 'fk_multi_last_error', 'fk_multi_size', 'fk_multi_transport', 'fk_multi_ctx', 'fk_multi_sync',
+    'fk_init_devices', 'fk_multi_free', 'fk_multi_last_error', 'fk_multi_size', 'fk_multi_transport', 'fk_multi_ctx', 'fk_multi_sync', 'fk_multi_witness_traffic',
     'fk_multi_key_load', 'fk_multi_key_load_bellman', 'fk_multi_setup', 'fk_multi_setup_tiled', 'fk_multi_key_free', 'fk_multi_key_shard',
     'fk_multi_r1cs_load', 'fk_multi_r1cs_load_tiled', 'fk_multi_r1cs_load_gates', 'fk_multi_r1cs_free', 'fk_multi_r1cs_replica',
     'fk_multi_prove_r1cs', 'fk_multi_prove_r1cs_submit', 'fk_multi_prove_r1cs_wait',
@@ -624,6 +624,21 @@ class Context:
         self._ck(self.lib.fk_witness_ptr(self.handle, C.c_int(slot), C.byref(p)))
         return p.value
 
+    # ---- the sharded hand-over: a rank uploads its own piece, the ranks all-gather the rest (parallel.witness_all_gather)
+    def witness_slot(self, slot, total_bytes):
+        """fk_witness_slot: (device pointer of the slot with room for total_bytes, hipStream_t of the copy stream as an integer)"""
+        p, st = C.c_void_p(), C.c_void_p()
+        self._ck(self.lib.fk_witness_slot(self.handle, C.c_int(slot), C.c_size_t(total_bytes), C.byref(p), C.byref(st)))
+        return p.value or 0, st.value or 0
+
+    def witness_upload_part_async(self, slot, part, offset):
+        """fk_witness_upload_part_async: `part` (contiguous array; pinned memory overlaps) -> slot bytes [offset, offset + part.nbytes)"""
+        assert part.flags['C_CONTIGUOUS']
+        self._ck(self.lib.fk_witness_upload_part_async(self.handle, C.c_int(slot), _vp(part) if part.nbytes else None, C.c_size_t(offset), C.c_size_t(part.nbytes)))
+
+    def witness_mark_ready(self, slot):
+        self._ck(self.lib.fk_witness_mark_ready(self.handle, C.c_int(slot)))
+
     def prove_witness_submit(self, key, dr, z, r, s):
         """fk_prove_r1cs_submit -> ticket.  z, r, s are kept referenced until prove_witness_wait(ticket)."""
         assert z.dtype == np.uint64 and z.flags['C_CONTIGUOUS']
@@ -1041,6 +1056,12 @@ class MultiContext:
 
     def sync(self):
         self._ck(self.lib.fk_multi_sync(self.handle))
+
+    def witness_traffic(self):
+        """fk_multi_witness_traffic: bytes the latest witness hand-over moved, summed over the ranks (host -> device, device -> device)"""
+        out = (C.c_uint64 * 2)()
+        self._ck(self.lib.fk_multi_witness_traffic(self.handle, out))
+        return dict(pcie_bytes=int(out[0]), gathered_bytes=int(out[1]))
 
     def load_key(self, params):
         d = params.desc(0, 1, Z_EQUAL_SPLIT)

@@ -122,6 +122,7 @@ struct fk_ctx {
     hipStream_t copy_st = nullptr;
     struct WitSlot {
         fk::DevBuf buf; hipEvent_t ready = nullptr; bool pending = false;        // pending: a submitted proof waits in this slot
+        hipEvent_t part = nullptr;               // sharded hand-over (fk_witness_upload_part_async): this rank's own piece has arrived; `ready` then follows the all-gather
         // deferred: the upload has not been queued yet -- the proof that runs first queues it behind its memory-bound front
         // (upload_deferred), so that the copy runs underneath transforms and accumulations instead of beside sorts
         bool deferred = false; const void *host_z = nullptr; size_t host_bytes = 0;
@@ -326,6 +327,7 @@ int msm_g2_end(fk_ctx *ctx, int tail, G2Xyzz *out);
 void msm_abandon(fk_ctx *ctx);
 int msm_run_deferred(fk_ctx *ctx, hipEvent_t after);
 int upload_deferred(fk_ctx *ctx, bool gate_on_main);      // queues the witness uploads fk_prove_r1cs_submit left for later
+int witness_slot_reserve(fk_ctx *ctx, int slot, size_t bytes, bool *moved = nullptr);      // prover.hip: room for `bytes` in a witness slot (+ its stream and events)
 int early_witness_begin(fk_ctx *ctx, const fk_key *key, const void *d_z, const void *d_a_aux, const void *d_b_in, const void *d_b_aux, int tails_out[4]);   // prover.hip
 bool early_front_applies(const fk_key *key);
 void msm_release(fk_ctx *ctx);

@@ -51,6 +51,7 @@ struct RcclApi {
     int (*GroupEnd)() = nullptr;
     int (*Send)(const void *, size_t, int, int, comm_t, hipStream_t) = nullptr;
     int (*Recv)(void *, size_t, int, int, comm_t, hipStream_t) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, comm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
     bool ok = false;
     RcclApi() {
@@ -63,8 +64,9 @@ struct RcclApi {
         GroupEnd = (decltype(GroupEnd))dlsym(h, "ncclGroupEnd");
         Send = (decltype(Send))dlsym(h, "ncclSend");
         Recv = (decltype(Recv))dlsym(h, "ncclRecv");
+        AllGather = (decltype(AllGather))dlsym(h, "ncclAllGather");
         GetErrorString = (decltype(GetErrorString))dlsym(h, "ncclGetErrorString");
-        ok = CommInitAll && CommDestroy && GroupStart && GroupEnd && Send && Recv;
+        ok = CommInitAll && CommDestroy && GroupStart && GroupEnd && Send && Recv && AllGather;
     }
 };
 static const RcclApi &rccl_api() { static RcclApi a; return a; }
@@ -105,6 +107,9 @@ struct fk_multi {
     bool host_event_wait = false;                       // FK_MULTI_HOST_EVENTS=1: wait for a peer's event on the host instead of in the stream
     bool force_exchange = false;                        // FK_MULTI_FORCE_EXCHANGE=1: run the distributed schedule (exchanges with itself) even with ONE rank -- test aid
     std::vector<void *> comms;                          // FK_MULTI_TRANSPORT=rccl: one RCCL communicator per rank (empty: peer copies)
+    std::vector<void *> comms_z;                        // ... and a second set for the witness all-gather, which is issued on the copy streams while a proof's exchanges may be in flight
+    bool whole_witness = false;                         // FK_MULTI_WITNESS=whole: every rank uploads the whole witness over its own PCIe link (rounds 3-4)
+    uint64_t z_bytes_uploaded = 0, z_bytes_gathered = 0;   // per hand-over, summed over the ranks: host -> device, device -> device
     // barrier of the rank threads
     std::mutex bmu;
     std::condition_variable bcv;
@@ -395,6 +400,7 @@ int fk_init_devices(int n_devices, const int *device_ids, fk_multi **out) {
     while ((1 << M->log_w) < n_devices) M->log_w++;
     { const char *e = getenv("FK_MULTI_HOST_EVENTS"); M->host_event_wait = e && e[0] && e[0] != '0'; }
     { const char *e = getenv("FK_MULTI_FORCE_EXCHANGE"); M->force_exchange = e && e[0] && e[0] != '0'; }
+    { const char *e = getenv("FK_MULTI_WITNESS"); M->whole_witness = e && !strcmp(e, "whole"); }
     int rc = FK_OK;
     for (int i = 0; i < n_devices && rc == FK_OK; i++) {
         fk_ctx *c = nullptr;
@@ -443,6 +449,10 @@ int fk_init_devices(int n_devices, const int *device_ids, fk_multi **out) {
                 M->comms.assign(n_devices, nullptr);
                 const int rcn = nc.CommInitAll(M->comms.data(), n_devices, device_ids);
                 if (rcn != 0) { M->comms.clear(); M->err = std::string("note: ncclCommInitAll failed (") + (nc.GetErrorString ? nc.GetErrorString(rcn) : "?") + ") -- peer copies are used"; }
+                else {
+                    M->comms_z.assign(n_devices, nullptr);
+                    if (nc.CommInitAll(M->comms_z.data(), n_devices, device_ids) != 0) { M->comms_z.clear(); M->err = "note: second RCCL communicator set failed -- the witness all-gather uses peer copies"; }
+                }
             }
         }
     }
@@ -468,6 +478,7 @@ void fk_multi_free(fk_multi *M) {
         for (int k = 0; k < 3; k++) { rk.send[k].release(); rk.recv[k].release(); }
     }
     for (void *c : M->comms) if (c) (void)rccl_api().CommDestroy(c);
+    for (void *c : M->comms_z) if (c) (void)rccl_api().CommDestroy(c);
     for (fk_ctx *c : M->ctx) fk_free(c);
     delete M;
 }
@@ -584,13 +595,60 @@ void fk_multi_r1cs_free(fk_multi *M, fk_multi_r1cs *R) {
 const fk_r1cs_dev *fk_multi_r1cs_replica(const fk_multi_r1cs *R, int rank) { return (R && rank >= 0 && rank < (int)R->rep.size()) ? R->rep[rank] : nullptr; }
 
 // ---------------------------------------------------------------- the prover: witness in (host memory) -> 256-byte proof out
-// Every rank uploads the witness over its own PCIe link into one of its two slots (the evaluation of a, b, c reads all of z
-// for a cyclic row slice, and the L / A / B slices are gathered from it).
+// The witness crosses PCIe ONCE: rank g uploads the piece z[g * C, (g + 1) * C) (C = ceil(variables / N) elements) over its own link into
+// its slot, then every rank collects the other N - 1 pieces from its peers over xGMI -- an all-gather of (N - 1) / N of the witness
+// into every GPU: peer DMA (hipMemcpyPeerAsync on the rank's copy stream, behind the owner's "piece has arrived" event), or ONE grouped
+// ncclAllGather with FK_MULTI_TRANSPORT=rccl.  (Rounds 3-4 had every rank upload all of z: N x 1.07 GB per proof out of one pinned
+// buffer -- 230 GB/s of host reads at N = 8 for a 38 ms share of the proof; FK_MULTI_WITNESS=whole keeps that form.)  Every rank needs
+// all of z: the evaluation of a, b, c reads it for a cyclic row slice, and the L / A / B slices are gathered from it.
 static int multi_upload(fk_multi *M, int slot, const uint64_t *z, size_t bytes) {
-    for (int r = 0; r < M->n; r++) {
-        const int rc = fk_witness_upload_async(M->ctx[r], slot, z, bytes);
-        if (rc != FK_OK) { char b[48]; snprintf(b, sizeof b, "rank %d: ", r); M->err = std::string(b) + M->ctx[r]->err; return rc; }
+    auto fail = [&](int r, int rc) { char b[48]; snprintf(b, sizeof b, "rank %d: ", r); M->err = std::string(b) + M->ctx[r]->err; return rc; };
+    if (M->n == 1 || M->whole_witness) {
+        for (int r = 0; r < M->n; r++) { const int rc = fk_witness_upload_async(M->ctx[r], slot, z, bytes); if (rc != FK_OK) return fail(r, rc); }
+        M->z_bytes_uploaded = bytes * (size_t)M->n; M->z_bytes_gathered = 0;
+        return FK_OK;
     }
+    const size_t n = (size_t)M->n, elems = bytes / sizeof(Fr), C = (elems + n - 1) / n * sizeof(Fr), padded = C * n;
+    // a slot that must grow moves: no peer may still be pulling from it (only ever the first hand-over of a larger system)
+    bool grow = false;
+    for (int r = 0; r < M->n; r++) grow = grow || M->ctx[r]->wslot[slot].buf.cap < padded;
+    if (grow) for (int r = 0; r < M->n; r++) if (M->ctx[r]->copy_st) { (void)hipSetDevice(M->dev[r]); if (hipStreamSynchronize(M->ctx[r]->copy_st) != hipSuccess) { M->ctx[r]->err = "witness upload: synchronize failed"; return fail(r, FK_ERR_HIP); } }
+    for (int r = 0; r < M->n; r++) { const int rc = witness_slot_reserve(M->ctx[r], slot, padded); if (rc != FK_OK) return fail(r, rc); }
+    auto piece = [&](int r, size_t *off, size_t *len) { *off = std::min(bytes, (size_t)r * C); *len = std::min(bytes - *off, C); };
+    for (int r = 0; r < M->n; r++) {
+        size_t off, len; piece(r, &off, &len);
+        const int rc = fk_witness_upload_part_async(M->ctx[r], slot, (const uint8_t *)z + off, off, len);
+        if (rc != FK_OK) return fail(r, rc);
+    }
+    if (!M->comms_z.empty()) {
+        const RcclApi &nc = rccl_api();
+        int rc = nc.GroupStart();
+        for (int r = 0; r < M->n && rc == 0; r++) {
+            uint8_t *buf = (uint8_t *)M->ctx[r]->wslot[slot].buf.p;
+            rc = nc.AllGather(buf + (size_t)r * C, buf, C, NCCL_UINT8, M->comms_z[r], M->ctx[r]->copy_st);        // in place: every rank's piece sits at its own offset
+        }
+        const int rce = nc.GroupEnd();
+        if (rc == 0) rc = rce;
+        if (rc != 0) { M->err = std::string("RCCL all-gather of the witness failed: ") + (nc.GetErrorString ? nc.GetErrorString(rc) : "?"); return FK_ERR_HIP; }
+    } else {
+        for (int r = 0; r < M->n; r++) {
+            fk_ctx *ctx = M->ctx[r];
+            if (hipSetDevice(M->dev[r]) != hipSuccess) { ctx->err = "witness gather: hipSetDevice failed"; return fail(r, FK_ERR_HIP); }
+            uint8_t *dst = (uint8_t *)ctx->wslot[slot].buf.p;
+            for (int i = 1; i < M->n; i++) {
+                const int p = (r + i) % M->n;          // rotated order: at any moment the ranks pull from different peers
+                size_t off, len; piece(p, &off, &len);
+                if (!len) continue;
+                hipError_t e = hipStreamWaitEvent(ctx->copy_st, M->ctx[p]->wslot[slot].part, 0);
+                const uint8_t *src = (const uint8_t *)M->ctx[p]->wslot[slot].buf.p + off;
+                if (e == hipSuccess) e = M->dev[p] == M->dev[r] ? hipMemcpyAsync(dst + off, src, len, hipMemcpyDeviceToDevice, ctx->copy_st)
+                                                              : hipMemcpyPeerAsync(dst + off, M->dev[r], src, M->dev[p], len, ctx->copy_st);
+                if (e != hipSuccess) { ctx->err = std::string("witness gather: ") + hipGetErrorString(e); (void)hipGetLastError(); return fail(r, FK_ERR_HIP); }
+            }
+        }
+    }
+    for (int r = 0; r < M->n; r++) { const int rc = fk_witness_mark_ready(M->ctx[r], slot); if (rc != FK_OK) return fail(r, rc); }
+    M->z_bytes_uploaded = bytes; M->z_bytes_gathered = bytes * (n - 1);
     return FK_OK;
 }
 
@@ -644,6 +702,13 @@ int fk_multi_prove_r1cs_wait(fk_multi *M, int ticket, uint8_t out[FK_PROOF_BYTES
     p.active = false;
     return multi_prove_slot(M, p.key, p.r1cs, ticket, p.r, p.s, out, tm);
 }); }
+
+// bytes the latest witness hand-over moved, summed over the ranks: out[0] host -> device (PCIe), out[1] device -> device (the all-gather)
+int fk_multi_witness_traffic(const fk_multi *M, uint64_t out[2]) {
+    if (!M || !out) return FK_ERR_BAD_ARG;
+    out[0] = M->z_bytes_uploaded; out[1] = M->z_bytes_gathered;
+    return FK_OK;
+}
 
 // waits for everything queued on every rank
 int fk_multi_sync(fk_multi *M) { return fk_guard(M, [&]() -> int {

@@ -108,7 +108,7 @@ void fk_free(fk_ctx *ctx) {
     for (auto &v : {&ctx->ev_acc, &ctx->ev_acc2, &ctx->ev_ntt}) for (auto &ep : *v) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     if (ctx->copy_st) { (void)hipStreamSynchronize(ctx->copy_st); (void)hipStreamDestroy(ctx->copy_st); }
-    for (auto &w : ctx->wslot) { w.buf.release(); if (w.ready) (void)hipEventDestroy(w.ready); }
+    for (auto &w : ctx->wslot) { w.buf.release(); if (w.ready) (void)hipEventDestroy(w.ready); if (w.part) (void)hipEventDestroy(w.part); }
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -133,7 +133,7 @@ int fk_trim(fk_ctx *ctx) { return fk_guard(ctx, [&]() -> int {
     for (DevBuf *b : {&ctx->misc, &ctx->ntt_s1, &ctx->ntt_s2, &ctx->ntt_io, &ctx->hbuf, &ctx->sc_a, &ctx->sc_b, &ctx->scan_tmp, &ctx->stage_a, &ctx->stage_b,
                       &ctx->stage_c, &ctx->stage_z, &ctx->stage_d})
         b->release();
-    for (auto &w : ctx->wslot) { w.buf.release(); w.deferred = false; if (w.ready) { (void)hipEventDestroy(w.ready); w.ready = nullptr; } }      // "holds nothing" again
+    for (auto &w : ctx->wslot) { w.buf.release(); w.deferred = false; if (w.ready) { (void)hipEventDestroy(w.ready); w.ready = nullptr; } if (w.part) { (void)hipEventDestroy(w.part); w.part = nullptr; } }      // "holds nothing" again
     ctx->lane_prev = 0; ctx->lane_next = 0;
     return FK_OK;
 }); }
@@ -204,18 +204,42 @@ int fk_host_free(fk_ctx *ctx, void *hptr) { return fk_guard(ctx, [&]() -> int {
 int fk_witness_upload_async(fk_ctx *ctx, int slot, const void *z_host, size_t bytes) { return fk_guard(ctx, [&]() -> int {
     if (!ctx) return FK_ERR_BAD_ARG;
     if (slot < 0 || slot > 1 || (bytes && !z_host)) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "witness upload: slot must be 0 or 1, buffer non-null");
-    FK_HIP(ctx, hipSetDevice(ctx->device));
-    if (!ctx->copy_st) FK_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_st, hipStreamNonBlocking));
+    FK_TRY(witness_slot_reserve(ctx, slot, bytes));
     fk_ctx::WitSlot &w = ctx->wslot[slot];
-    if (!w.ready) FK_HIP(ctx, hipEventCreateWithFlags(&w.ready, hipEventDisableTiming));
-    if (bytes > w.buf.cap) {                      // growing frees the old buffer: nothing may still be reading or filling it
-        FK_HIP(ctx, hipStreamSynchronize(ctx->copy_st));
-        FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        FK_TRY(msm_sync(ctx));
-        FK_HIP(ctx, w.buf.reserve(bytes));
-    }
     if (bytes) FK_HIP(ctx, hipMemcpyAsync(w.buf.p, z_host, bytes, hipMemcpyHostToDevice, ctx->copy_st));
     FK_HIP(ctx, hipEventRecord(w.ready, ctx->copy_st));
+    return FK_OK;
+}); }
+// The sharded hand-over (N ranks, one witness): a rank uploads only ITS piece over its PCIe link and the ranks exchange the pieces over
+// xGMI (an all-gather: the library's own between the ranks of an fk_multi, RCCL through torch.distributed between processes) -- the
+// witness crosses PCIe once instead of N times.
+//   fk_witness_slot           room for total_bytes in the slot; its device pointer (valid until a larger witness is handed over) and the
+//                             copy stream (hipStream_t) the hand-over is queued on, for a host that issues the collective itself
+//   fk_witness_upload_part_async   host bytes [offset, offset + len) of the witness -> the same offsets of the slot, on the copy stream
+//   fk_witness_mark_ready     everything queued on the copy stream so far completes the slot: fk_witness_ptr waits for this point
+int fk_witness_slot(fk_ctx *ctx, int slot, size_t total_bytes, void **dptr, void **copy_stream) { return fk_guard(ctx, [&]() -> int {
+    if (!ctx) return FK_ERR_BAD_ARG;
+    if (slot < 0 || slot > 1) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "witness slot must be 0 or 1");
+    FK_TRY(witness_slot_reserve(ctx, slot, total_bytes));
+    if (dptr) *dptr = ctx->wslot[slot].buf.p;
+    if (copy_stream) *copy_stream = (void *)ctx->copy_st;
+    return FK_OK;
+}); }
+int fk_witness_upload_part_async(fk_ctx *ctx, int slot, const void *z_host_part, size_t offset, size_t len) { return fk_guard(ctx, [&]() -> int {
+    if (!ctx) return FK_ERR_BAD_ARG;
+    if (slot < 0 || slot > 1 || (len && !z_host_part)) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "witness upload: slot must be 0 or 1, buffer non-null");
+    fk_ctx::WitSlot &w = ctx->wslot[slot];
+    if (!w.ready || offset + len > w.buf.cap) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "witness upload: piece [%zu, %zu) outside the slot (call fk_witness_slot first)", offset, offset + len);
+    FK_HIP(ctx, hipSetDevice(ctx->device));
+    if (len) FK_HIP(ctx, hipMemcpyAsync((uint8_t *)w.buf.p + offset, z_host_part, len, hipMemcpyHostToDevice, ctx->copy_st));
+    FK_HIP(ctx, hipEventRecord(w.part, ctx->copy_st));
+    return FK_OK;
+}); }
+int fk_witness_mark_ready(fk_ctx *ctx, int slot) { return fk_guard(ctx, [&]() -> int {
+    if (!ctx) return FK_ERR_BAD_ARG;
+    if (slot < 0 || slot > 1 || !ctx->wslot[slot].ready) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "witness slot %d holds nothing", slot);
+    FK_HIP(ctx, hipSetDevice(ctx->device));
+    FK_HIP(ctx, hipEventRecord(ctx->wslot[slot].ready, ctx->copy_st));
     return FK_OK;
 }); }
 int fk_witness_ptr(fk_ctx *ctx, int slot, void **dptr) { return fk_guard(ctx, [&]() -> int {
@@ -229,6 +253,22 @@ int fk_witness_ptr(fk_ctx *ctx, int slot, void **dptr) { return fk_guard(ctx, [&
 
 }  // extern "C"
 namespace fk {
+int witness_slot_reserve(fk_ctx *ctx, int slot, size_t bytes, bool *moved) {
+    FK_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->copy_st) FK_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_st, hipStreamNonBlocking));
+    fk_ctx::WitSlot &w = ctx->wslot[slot];
+    if (!w.ready) FK_HIP(ctx, hipEventCreateWithFlags(&w.ready, hipEventDisableTiming));
+    if (!w.part) FK_HIP(ctx, hipEventCreateWithFlags(&w.part, hipEventDisableTiming));
+    if (moved) *moved = false;
+    if (bytes > w.buf.cap) {                      // growing frees the old buffer: nothing may still be reading or filling it
+        FK_HIP(ctx, hipStreamSynchronize(ctx->copy_st));
+        FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        FK_TRY(msm_sync(ctx));
+        FK_HIP(ctx, w.buf.reserve(bytes));
+        if (moved) *moved = true;
+    }
+    return FK_OK;
+}
 // The uploads fk_prove_r1cs_submit deferred: queued on the copy stream, behind the current position of the main stream if
 // gate_on_main (the prover calls this when its memory-bound front -- sorts, evaluation of a, b, c -- is queued and the
 // VALU-bound part begins).

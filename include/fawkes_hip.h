@@ -103,6 +103,16 @@ int fk_host_free(fk_ctx *ctx, void *hptr);
  * witness underneath the current proof).  A slot may be refilled once the proof that read it has returned. */
 int fk_witness_upload_async(fk_ctx *ctx, int slot, const void *z_host, size_t bytes);
 int fk_witness_ptr(fk_ctx *ctx, int slot, void **dptr);
+/* The sharded hand-over (N ranks, one witness): a rank uploads only ITS piece over its PCIe link and the ranks exchange the pieces over
+ * xGMI with an all-gather, so that the witness crosses PCIe once instead of N times.  fk_multi_prove_r1cs* do this between the ranks of an
+ * fk_multi themselves; a rank-per-process host (torch.distributed over RCCL, fawkes-crypto_amd/parallel.py: witness_all_gather) uses:
+ *   fk_witness_slot               room for total_bytes in the slot; returns its device pointer (valid until a larger witness is handed
+ *                                 over) and the hipStream_t of the copy stream, on which the host issues its collective
+ *   fk_witness_upload_part_async  host bytes z_host_part[0, len) -> slot bytes [offset, offset + len), on the copy stream
+ *   fk_witness_mark_ready         everything queued on the copy stream so far completes the slot: fk_witness_ptr waits for this point */
+int fk_witness_slot(fk_ctx *ctx, int slot, size_t total_bytes, void **dptr, void **copy_stream);
+int fk_witness_upload_part_async(fk_ctx *ctx, int slot, const void *z_host_part, size_t offset, size_t len);
+int fk_witness_mark_ready(fk_ctx *ctx, int slot);
 
 /* ---------------------------------------------------------------- proving key
  * Replaces the `params.0` argument of prover.rs:80, i.e. bellman's `Parameters` { vk, h, l, a, b_g1,
@@ -442,7 +452,10 @@ int fk_key_counts(const fk_key *key, uint64_t out[8]);
  * cut once between the ranks; its all-to-all is device-to-device DMA over xGMI -- hipMemcpyPeerAsync pulls on an exchange
  * stream per rank, ordered with HIP events against the kernels on both sides, seven per proof) and 1/N of each of the five
  * multi-scalar multiplications; the N 384-byte partial results are folded on the host ("all-reduce of the partial sums":
- * no collective library has an elliptic-curve reduction operator).  N = 1, 2, 4, 8 use this schedule; any other N up to 64
+ * no collective library has an elliptic-curve reduction operator).  The WITNESS crosses PCIe once: rank g uploads the piece
+ * z[g * C, (g + 1) * C), C = ceil(variables / N), over its own link and every rank collects the other pieces from its peers over
+ * xGMI (an all-gather: peer DMA on the ranks' copy streams, or one grouped ncclAllGather with FK_MULTI_TRANSPORT=rccl) underneath the
+ * proof before; FK_MULTI_WITNESS=whole restores rounds 3-4 (every rank uploads all of z).  N = 1, 2, 4, 8 use this schedule; any other N up to 64
  * shards the multiplications only (every rank computes the whole quotient).  Device ids may repeat: several ranks then share
  * a GPU (how a one-GPU box tests the path).  The proof bytes do not depend on N.
  * An fk_multi is not thread-safe (one call at a time); keys and constraint systems loaded through it belong to it.
@@ -463,6 +476,8 @@ const char *fk_multi_transport(const fk_multi *multi);
 /* rank `rank`'s single-GPU context (statistics, calibration, building blocks); owned by the fk_multi */
 fk_ctx *fk_multi_ctx(fk_multi *multi, int rank);
 int fk_multi_sync(fk_multi *multi);
+/* bytes the latest witness hand-over moved, summed over the ranks: out[0] host -> device (PCIe), out[1] device -> device (all-gather) */
+int fk_multi_witness_traffic(const fk_multi *multi, uint64_t out[2]);
 /* the key loaders of the single-GPU interface, shard g of N on rank g (desc->shard_index / shard_count / z_frac_* are ignored) */
 int fk_multi_key_load(fk_multi *multi, const fk_key_desc *desc, fk_multi_key **out);
 int fk_multi_key_load_bellman(fk_multi *multi, const uint8_t *buf, size_t len, uint32_t flags, fk_multi_key **out, uint8_t *gamma_g2_out,

@@ -111,13 +111,27 @@ def fe_mul_batch(f, a, b):
     o = np.zeros_like(a); lib().orc_fe_mul_batch(f, _p(a), _p(b), _p(o), C.c_size_t(a.shape[0])); return o
 
 
-def fr_ntt(a, inverse=False, coset=False):
+class _threads:
+    """bellman's Worker size for the calls inside (1 = serial; more = its multicore split restated: same results)"""
+
+    def __init__(self, n):
+        self.n = int(n)
+
+    def __enter__(self):
+        lib().orc_set_threads(C.c_int(self.n))
+
+    def __exit__(self, *exc):
+        lib().orc_set_threads(C.c_int(1))
+
+
+def fr_ntt(a, inverse=False, coset=False, threads=1):
     """a: (2^k, 4) uint64 Montgomery Fr; returns transformed copy (natural order)."""
     a = np.ascontiguousarray(a, np.uint64).copy()
     logn = int(a.shape[0]).bit_length() - 1
     assert 1 << logn == a.shape[0]
     fn = lib().orc_fr_coset_ntt if coset else lib().orc_fr_ntt
-    rc = fn(_p(a), C.c_uint32(logn), C.c_int(1 if inverse else 0))
+    with _threads(threads):
+        rc = fn(_p(a), C.c_uint32(logn), C.c_int(1 if inverse else 0))
     assert rc == 0
     return a
 
@@ -134,20 +148,22 @@ def quotient_h(a, b, c):
     return h[:m - 1]
 
 
-def msm_g1(bases, scalars, density=None):
-    """bases: (nb, 64) uint8 raw LE; scalars (n, 4) uint64 Montgomery; density: optional uint8[n]."""
+def msm_g1(bases, scalars, density=None, threads=1):
+    """bases: (nb, 64) uint8 raw LE; scalars (n, 4) uint64 Montgomery; density: optional uint8[n]; threads: one task per multiexp region."""
     bases = np.ascontiguousarray(bases, np.uint8); scalars = np.ascontiguousarray(scalars, np.uint64)
     out = np.zeros(64, np.uint8)
     dp = _p(np.ascontiguousarray(density, np.uint8)) if density is not None else None
-    lib().orc_msm_g1(_p(bases), C.c_size_t(bases.shape[0]), _p(scalars), dp, C.c_size_t(scalars.shape[0]), _p(out))
+    with _threads(threads):
+        lib().orc_msm_g1(_p(bases), C.c_size_t(bases.shape[0]), _p(scalars), dp, C.c_size_t(scalars.shape[0]), _p(out))
     return out
 
 
-def msm_g2(bases, scalars, density=None):
+def msm_g2(bases, scalars, density=None, threads=1):
     bases = np.ascontiguousarray(bases, np.uint8); scalars = np.ascontiguousarray(scalars, np.uint64)
     out = np.zeros(128, np.uint8)
     dp = _p(np.ascontiguousarray(density, np.uint8)) if density is not None else None
-    lib().orc_msm_g2(_p(bases), C.c_size_t(bases.shape[0]), _p(scalars), dp, C.c_size_t(scalars.shape[0]), _p(out))
+    with _threads(threads):
+        lib().orc_msm_g2(_p(bases), C.c_size_t(bases.shape[0]), _p(scalars), dp, C.c_size_t(scalars.shape[0]), _p(out))
     return out
 
 

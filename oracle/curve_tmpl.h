@@ -166,6 +166,8 @@ static void CT_NAME(multiexp)(CT_NAME(jac) *out, const CT_NAME(aff) *bases, cons
                               const uint64_t *exps, size_t n_exps) {
     const unsigned c = CT_NAME(multiexp_window)(n_exps), nregions = CT_NAME(multiexp_regions)(c);
     CT_NAME(jac) *regions = (CT_NAME(jac) *)malloc(nregions * sizeof(CT_NAME(jac)));
+    /* one task per region, as bellman's multiexp_inner spawns them (ORC_THREADS = 1: the serial order; same result either way) */
+    #pragma omp parallel for schedule(dynamic, 1) num_threads(ORC_THREADS)
     for (unsigned reg = 0; reg < nregions; reg++) CT_NAME(multiexp_region)(&regions[reg], bases, density, exps, n_exps, c, reg);
     CT_NAME(multiexp_join)(out, regions, nregions, c);
     free(regions);

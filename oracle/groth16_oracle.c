@@ -190,6 +190,7 @@ static int q2_eq(const fe2 *a, const fe2 *b) { return memcmp(a, b, 64) == 0; }
 #define CT_ONE q_one
 #define CT_ISZERO fe_is_zero
 #define CT_EQ fe_eq
+static int ORC_THREADS;      /* worker threads (defined below with orc_set_threads); the multiexp template reads it */
 #include "curve_tmpl.h"
 #undef CT_NAME
 #undef CT_FE

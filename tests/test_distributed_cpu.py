@@ -243,3 +243,72 @@ def test_distributed_quotient_gloo(world):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok in results), results
+
+
+# ------------------------------------------------------------------------------------------ the witness: PCIe once, then an all-gather
+class _SlotRecorder:
+    """stand-in for the three witness-slot calls of api.Context (fk_witness_slot / _upload_part_async / _mark_ready): records what a rank
+    writes into its slot, so that parallel.witness_all_gather runs over real gloo ranks here"""
+
+    def __init__(self):
+        self.buf, self.ready, self.uploaded = None, False, 0
+
+    def witness_slot(self, slot, total_bytes):
+        self.buf = np.full(total_bytes, 0xEE, np.uint8)
+        return 0x1000, 0
+
+    def witness_upload_part_async(self, slot, part, offset):
+        b = np.ascontiguousarray(part).view(np.uint8).reshape(-1)
+        assert offset + b.size <= self.buf.size
+        self.buf[offset:offset + b.size] = b
+        self.uploaded += b.size
+
+    def witness_upload_async(self, slot, z):
+        self.buf = np.ascontiguousarray(z).view(np.uint8).reshape(-1).copy()
+        self.uploaded += self.buf.size
+
+    def witness_mark_ready(self, slot):
+        self.ready = True
+
+
+def _wit_worker(rank, world, port, q):
+    for p in (ROOT, os.path.join(ROOT, 'oracle'), os.path.join(ROOT, 'tests')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    from fawkes_crypto_amd import parallel
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        ok = True
+        for nv in (1001, 64, world - 1 if world > 1 else 1, 4096):       # ragged, tiny (an empty last piece) and even sizes
+            z = np.random.default_rng(7 + nv).integers(0, 1 << 63, size=(nv, 4), dtype=np.uint64)      # the same witness on every rank's host
+            rec = _SlotRecorder()
+            tr = parallel.witness_all_gather(rec, nv & 1, z, rank, world)
+            c, pieces = parallel.witness_pieces(nv, world)
+            lo, hi = pieces[rank]
+            ok = ok and rec.ready and rec.buf[:nv * 32].tobytes() == z.tobytes() and rec.buf.size == c * world * 32
+            ok = ok and tr['pcie_bytes'] == (hi - lo) * 32 and tr['gathered_bytes'] == (nv - (hi - lo)) * 32
+            ok = ok and sum(b - a for a, b in pieces) == nv and all(b - a <= c for a, b in pieces)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3, 4])
+def test_witness_all_gather_gloo(world):
+    """parallel.witness_all_gather over real torch.distributed ranks: every rank hands over only its piece of the witness (1 / world of the
+    bytes over its own PCIe link) and ends with the WHOLE witness in its slot, ragged sizes included"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_wit_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in results), results

@@ -135,6 +135,25 @@ def test_multi_prove_one_call_matches_oracle(ctx, oracle, world):
         got = mc.prove_witness(key, dr, z, r, s)
         assert got.tobytes() == want.tobytes()
         assert ref.verify(fx.key_to_py(okey), z_in[1:], ref.proof_from_borsh(got.tobytes()))
+        # round 5: the witness crosses PCIe ONCE -- every rank uploads its 1 / world piece, the ranks all-gather the rest among themselves
+        tr = mc.witness_traffic()
+        assert tr['pcie_bytes'] == z.nbytes and tr['gathered_bytes'] == (world - 1) * z.nbytes, tr
+        if world in (3, 8):
+            # ... FK_MULTI_WITNESS=whole (read by fk_init_devices): rounds 3-4, every rank uploads all of z -- same bytes
+            import os
+            os.environ['FK_MULTI_WITNESS'] = 'whole'
+            try:
+                mc_w = fk.MultiContext([0] * world)
+            finally:
+                del os.environ['FK_MULTI_WITNESS']
+            try:
+                key_w, _ = mc_w.setup(r1cs, **tox)
+                dr_w = mc_w.load_r1cs(r1cs)
+                assert mc_w.prove_witness(key_w, dr_w, z, r, s).tobytes() == want.tobytes()
+                assert mc_w.witness_traffic() == dict(pcie_bytes=world * z.nbytes, gathered_bytes=0)
+                key_w.free(); dr_w.free()
+            finally:
+                mc_w.close()
         if world in (2, 8):
             # the equal split of rounds 1-3 (FK_MULTI_SPLIT=equal, read at every key load): 1 / world of each array, same bytes
             import os

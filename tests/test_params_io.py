@@ -324,8 +324,15 @@ def test_native_bellman_writer_matches_the_restatement_and_round_trips(ctx, orac
     # the whole file: fawkes header (host) + bellman part (GPU) -> load -> prove = the oracle's bytes
     arrays_ok = _key_arrays(key)
     dk3 = ctx.load_key(fk.Parameters(dict(arrays_ok, **shape), r1cs))
-    data = pio.store_parameters_dev(ctx, dk3, dict(gamma_g2=arrays_ok['gamma_g2'], ic=arrays_ok['ic']), r1cs, const_tracker_bits=[True, False])
-    assert data == pio.store_parameters(arrays_ok, r1cs, const_tracker_bits=[True, False])
+    data = pio.store_parameters_dev(ctx, dk3, dict(gamma_g2=arrays_ok['gamma_g2'], ic=arrays_ok['ic']), r1cs, const_tracker_bits=[True, False],
+                                    gates_blob=pio.RAW_MAGIC + pio.encode_gate_stream(r1cs))
+    assert data.tobytes() == pio.store_parameters(arrays_ok, r1cs, const_tracker_bits=[True, False])
+    # ... and with the gate blob written natively (fk_gates_encode, the reference's brotli setting): another blob, the same system and key
+    data_n = pio.store_parameters_dev(ctx, dk3, dict(gamma_g2=arrays_ok['gamma_g2'], ic=arrays_ok['ic']), r1cs, const_tracker_bits=[True, False])
+    h_n, h_r = pio.read_parameters(data_n), pio.read_parameters(data)
+    assert bytes(h_n['bellman']) == bytes(h_r['bellman']) and h_n['num_gates'] == h_r['num_gates'] and len(h_n['gates_blob']) < len(h_r['gates_blob'])
+    from helpers import brotli_decompress
+    assert brotli_decompress(bytes(h_n['gates_blob'])) == pio.encode_gate_stream(r1cs)
     dk4, dr4, hdr = pio.load_parameters(ctx, data)
     z = fx.witness_mont(z_in, z_aux)
     r, s = fx.mont_fr(3), fx.mont_fr(4)
