@@ -383,7 +383,7 @@ def other_size_leg(ctx, inst, zs, copies, tox, r, s, steps, check=True):
             raise AssertionError('bench: device-resident proof of the %d-transaction system differs from the pipelined one' % copies)
         out = {'transactions': copies, 'rows': n, 'log2_domain': log_m, 'domain_fill': n / float(1 << log_m), 'num_aux': num_aux,
                'matrix_terms': int(sum(dr.info()['nnz'])), 'ms_per_step': ms, 'proofs_per_sec': 1e3 / ms, 'steps': steps,
-               'device_resident_ms_per_step': dev_ms, 'msm_fixed_base_levels': key.precomputed(), 'prep_seconds': prep,
+               'device_resident_ms_per_step': dev_ms, 'msm_fixed_base_levels': key.precomputed(), 'levels_plan': key.levels_plan(), 'prep_seconds': prep,
                'witness_bytes_per_proof': nv * 32}
         if check:
             out['proof_verified_by_pairing_check'] = bool(pairing_check(vk, z_pin[0][1:num_input].copy(), proofs[0]) and
@@ -640,6 +640,10 @@ def main():
                          'reference\'s one published figure, README.md:54-56; domain 2^26)')
     ap.add_argument('--cpu-full-budget', type=float, default=600.0,
                     help='seconds the FULL-SIZE all-cores CPU baseline run may take by projection from the sample (else the scaled sample is reported)')
+    ap.add_argument('--max-seconds', type=float, default=1500.0,
+                    help='wall-clock budget of the whole command: an optional leg (sensitivity, tiled / untiled, standalone, replicas, one-call form, CPU baseline, '
+                         'other sizes) is skipped -- and listed under `legs` with the reason -- when the time used so far plus its estimate would exceed it, so that '
+                         'the JSON line is always printed')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend ('nccl' = RCCL; 'gloo' only for single-GPU dry runs of the N>1 code path with FK_BENCH_SAME_DEVICE=1)")
     args = ap.parse_args()
 
@@ -673,6 +677,28 @@ def main():
             dist.init_process_group(args.backend, rank=rank, world_size=world)
     comm_dev = dev if args.backend == 'nccl' else None
     ctx = fk.Context(local_rank)
+
+    # ---------------------------------------------------------------- wall-clock plan of the optional legs (every rank decides alike)
+    t_start = time.time()
+    legs = {}
+
+    def leg_fits(name, estimate_s):
+        used = time.time() - t_start
+        if multi:
+            import torch.distributed as dist
+            tt = torch.tensor([used], dtype=torch.float64, device=dev if args.backend == 'nccl' else 'cpu')
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            used = float(tt.item())
+        if used + estimate_s > args.max_seconds:
+            legs[name] = 'skipped: %.0f s used + ~%.0f s estimated > --max-seconds %.0f' % (used, estimate_s, args.max_seconds)
+            return False
+        legs[name] = -time.time()
+        return True
+
+    def leg_done(name):
+        if isinstance(legs.get(name), float) and legs[name] < 0:
+            legs[name] = round(time.time() + legs[name], 2)
+    full_size = 2.0 ** min(0, (args.copies * 19271).bit_length() - 25) if args.workload == 'rollup1024' else 2.0 ** (args.log2n - 25)      # estimates scale with the system
 
     # ---------------------------------------------------------------- workload: constraint system, witness, valid key
     t_prep = time.time()
@@ -777,6 +803,7 @@ def main():
         }
         del image
     pre_levels = key.precomputed()        # fixed-base window levels per key array (0 = none: FK_MSM_PRECOMP=0 or HBM short)
+    levels_plan = key.levels_plan()
     d_dens = dr.density_ptrs()
     if dist_q:
         work = [None] * 3         # a rank evaluates only its own rows, straight into send[] (fk_r1cs_eval_slice_dev): no m-element vectors
@@ -891,6 +918,31 @@ def main():
         if p_dev.tobytes() != want[0]:
             raise AssertionError('bench: device-resident proof differs from the host-witness proof')
 
+    # ---- not `value`: does the tiled WITNESS flatter the number?  The benchmark's witness is `distinct_transactions` (32) real transaction
+    # witnesses dealt over the copies, so every scalar has ~54 twins that meet in the same buckets.  The same system is timed here with a
+    # device-generated witness of the same zero / one fractions in which every dense value is DISTINCT (fk_gen_scalars_dev kind 2).  It does
+    # not satisfy the constraints -- the proof is well defined and worthless: a TIMING leg, labelled so -- but the sorts, the bucket loads
+    # and the accumulations see what 1741 unrelated transactions would give them.
+    sensitivity = None
+    if not multi and copies is not None and not args.no_standalone and leg_fits('witness_sensitivity', 5 * full_size):
+        d_zs = ctx.dev_alloc(nv * 32)
+        ctx.gen_scalars_dev(d_zs, nv, 20261004, 2)
+        ctx.upload(d_zs, z_pin[0][:1])                     # z[0] = ONE
+        ctx.prove_witness_dev(key, dr, d_zs, r, s)
+        ctx.sync()
+        t1 = time.perf_counter()
+        for _ in range(dev_steps):
+            ctx.prove_witness_dev(key, dr, d_zs, r, s)
+        s_ms = (time.perf_counter() - t1) / dev_steps * 1e3
+        ctx.prove_witness_dev(key, dr, d_z0, r, s)         # (back to the real witness: warm lanes for the legs below)
+        ctx.dev_free(d_zs)
+        sensitivity = {'all_distinct_values_device_resident_ms_per_step': s_ms, 'tiled_witness_device_resident_ms_per_step': dev_ms,
+                       'ratio': s_ms / dev_ms, 'steps': dev_steps,
+                       'is': 'TIMING ONLY (the assignment is not satisfying, the proof is not valid): the same key and system proved from a device-generated '
+                             'witness with the same 5.3 %% zeros / 2.5 %% ones and every other value distinct, against the benchmark witness (%d distinct '
+                             'transactions dealt over %d copies), both resident in HBM, one proof at a time' % (len(zs), copies)}
+        leg_done('witness_sensitivity')
+
     # ---- not `value`: the other resident form of the SAME circuit, same key, same witnesses, same proof bytes.
     #   default (`value` on the explicit system out of the Parameters image): `tiled` = fk_r1cs_load_tiled, ONE instance + a copy count
     #     (4.4 MB of matrices instead of 13.9 GB; rounds 1-4 quoted this form) -- the host-witness pipeline timed exactly like `value`;
@@ -898,7 +950,7 @@ def main():
     untiled = tiled = None
     if params_form and first_proof != want[0]:
         raise AssertionError('bench: the first proof after load_parameters differs from the pipelined proofs')
-    if params_form and not args.no_untiled:
+    if params_form and not args.no_untiled and leg_fits('tiled', 10 * full_size):
         t1 = time.perf_counter()
         dr_t = ctx.load_r1cs(r1cs, copies=copies)
         t_load = time.perf_counter() - t1
@@ -929,7 +981,8 @@ def main():
                  'is': 'fk_r1cs_load_tiled of ONE transaction + the copy count %d (the form rounds 1-4 quoted; no `Parameters` object can express it), same key, '
                        'same two witnesses through the same two-slot pipeline; proof bytes equal to the explicit form\'s' % copies}
         dr_t.free()
-    if not multi and copies is not None and not params_form and not args.no_untiled:
+        leg_done('tiled')
+    if not multi and copies is not None and not params_form and not args.no_untiled and leg_fits('untiled', 20 * full_size):
         t1 = time.perf_counter()
         u_in, u_aux, u_mats, u_table = materialise_rollup(copies)
         t_build = time.perf_counter() - t1
@@ -951,9 +1004,11 @@ def main():
                    'is': 'fk_r1cs_load_coded of the explicitly replicated %d-transaction system (CSR with one 8-byte entry per term), same key, same '
                          'witness, witness resident; proof bytes equal to the tiled form' % copies}
         dr_u.free()
+        leg_done('untiled')
     standalone = None
-    if not multi and not args.no_standalone:
+    if not multi and not args.no_standalone and leg_fits('standalone', 10 + 30 * full_size):
         standalone = standalone_legs(ctx, key, m)
+        leg_done('standalone')
 
     # ---- N > 1: throughput mode, one whole proof per GPU (replicas of the single-GPU prover; no collective in the data path)
     replica = None
@@ -965,7 +1020,7 @@ def main():
         need = world * (384 * m * 13 + nv * 64 + m * 32 * 20 + (2 << 30))      # key + levels (worst case), witness slots, lane / quotient scratch
         if need > 0.9 * torch.cuda.get_device_properties(local_rank).total_memory:
             replica_skipped = 'FK_BENCH_SAME_DEVICE=1: %d whole keys with their levels do not fit one GPU at this size' % world
-    if world > 1 and not args.no_replicas and replica_skipped is None:
+    if world > 1 and not args.no_replicas and replica_skipped is None and leg_fits('replicas', 20 + 60 * full_size):
         import torch.distributed as dist
         key.free()
         key, _ = ctx.setup(r1cs, copies=copies, **tox)           # the whole key on every GPU
@@ -984,12 +1039,13 @@ def main():
         if p_rep.tobytes() != want[(dev_steps - 1) & 1] and want[(dev_steps - 1) & 1] is not None:
             raise AssertionError('bench: replica proof differs from the distributed proof')
         replica = world * (dev_steps + 1) / float(rep_t.item())
+        leg_done('replicas')
     ctx.dev_free(d_z0)
 
     # ---- N > 1: the one-call form (one process drives all GPUs through fk_multi_prove_r1cs).  Every rank releases its GPU memory
     # first; the other ranks wait on a host-side (gloo) barrier so that nothing of theirs runs on the GPUs meanwhile.
     single_proc = None
-    if world > 1 and not args.no_single_process:
+    if world > 1 and not args.no_single_process and leg_fits('single_process_multi_gpu', 30 + 90 * full_size):
         import torch.distributed as dist
         same_dev = os.environ.get('FK_BENCH_SAME_DEVICE') == '1'
         key.free(); key = None
@@ -1006,6 +1062,7 @@ def main():
             except Exception as e:     # noqa: BLE001 -- reported, the rank-per-GPU result above stands
                 single_proc = {'error': '%s: %s' % (type(e).__name__, e)}
         dist.barrier(group=hostgrp)
+        leg_done('single_process_multi_gpu')
 
     out = None
     if rank == 0:
@@ -1054,7 +1111,7 @@ def main():
                        'distinct_witnesses_in_the_pipeline': 2 if two_witnesses else 1,
                        'a_query_points': n_a, 'b_query_points': n_b,
                        'msm_points': {'h': m - 1, 'l': num_aux, 'a': n_a, 'b_g1': n_b, 'b_g2': n_b},
-                       'msm_fixed_base_levels': pre_levels,
+                       'msm_fixed_base_levels': pre_levels, 'levels_plan': levels_plan,
                        'witness': '%.1f%% zeros, %.1f%% ones, rest dense 254-bit' % (100.0 * zeros / nv, 100.0 * ones / nv),
                        'witness_hand_over': None if not multi else dict(state.get('wit') or {}, what='per rank and proof: this rank\'s 1 / N piece over its own PCIe link '
                                                                                       '(pcie_bytes), the rest collected from the peers by dist.all_gather_into_tensor (RCCL over xGMI) on '
@@ -1119,6 +1176,8 @@ def main():
         if not args.no_cpu_baseline:
             out['proof_verified_by_pairing_check'] = bool(pairing_check(vk, z_inputs[0], want[0]) and
                                                           (want[1] is None or pairing_check(vk, z_inputs[1], want[1])))
+        if sensitivity is not None:
+            out['witness_sensitivity'] = sensitivity
         if load_block is not None:
             out['load'] = load_block
         if tiled is not None:
@@ -1129,9 +1188,13 @@ def main():
             out['standalone'] = standalone
         if single_proc is not None:
             out['single_process_multi_gpu'] = single_proc
-        if not multi and not args.no_cpu_baseline:
+        if not multi and not args.no_cpu_baseline and leg_fits('cpu_baseline', 60):
             full = (key, vk, z_pin[0], r, s, want[0]) if copies is not None else None
+            # the full-size CPU proof gets what the plan leaves of the budget (minus the legs still to come), at most --cpu-full-budget
+            left = args.max_seconds - (time.time() - t_start) - 60 - (0 if args.no_other_sizes else 150 * full_size)
+            args.cpu_full_budget = max(0.0, min(args.cpu_full_budget, left))
             cb = cpu_baseline_leg(ctx, fk, args, full=full)
+            leg_done('cpu_baseline')
             best = cb['best_threads']
             scaled = lambda th: (cb['synth_s'] + cb['prove_s'][th]) * cb['scale']
             if cb['full'] is not None:
@@ -1165,7 +1228,7 @@ def main():
             ctx.host_free(zp)
         z_pin = []
         for tag, cp in (('secondary_1024_transactions', args.secondary_copies), ('reference_published', args.reference_copies)):
-            if cp <= 0 or cp == copies:
+            if cp <= 0 or cp == copies or not leg_fits(tag, 25 + 50 * full_size * (cp / float(copies))):
                 continue
             try:
                 leg = other_size_leg(ctx, r1cs, zs, cp, tox, r, s, max(3, min(args.steps, 6)), check=not args.no_cpu_baseline)
@@ -1177,6 +1240,10 @@ def main():
                                     'of at least that many rows (the reference\'s own rollup circuit is not in its repository), same domain 2^26')
                 leg['reference_seconds_per_proof'] = 628.0
             out[tag] = leg
+            leg_done(tag)
+    if out is not None:
+        out['legs'] = dict(legs, total_seconds=round(time.time() - t_start, 1), max_seconds=args.max_seconds,
+                           what='seconds each optional leg took, or why it was skipped (--max-seconds: the JSON line is printed whatever happens to the extras)')
     line = json.dumps(out) if out is not None else None
 
     for zp in z_pin:

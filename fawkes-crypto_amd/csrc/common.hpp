@@ -99,6 +99,8 @@ struct fk_ctx {
     fk::DevBuf misc;
     // witness multiplications (L, A, B1, B2) in flight: begun before / while the quotient runs on the main stream
     hipStream_t aux = nullptr;          // scalar compaction for the A / B queries
+    hipStream_t tail_st = nullptr;      // high-priority stream for the G2 multiplication's tail (msm.hip: back_tail); nullptr: the tail stays on its lane
+    hipEvent_t ev_tail_in = nullptr;
     hipEvent_t ev_aux = nullptr, ev_main = nullptr, ev_z = nullptr;
     // sorts-first schedule (prover.hip): with defer_back set, msm_begin queues only the front of a multiplication (digits, sort,
     // size ordering) and leaves the rest (accumulation, oversized buckets, reduction, download) here, to be queued by
@@ -331,6 +333,7 @@ int witness_slot_reserve(fk_ctx *ctx, int slot, size_t bytes, bool *moved = null
 int early_witness_begin(fk_ctx *ctx, const fk_key *key, const void *d_z, const void *d_a_aux, const void *d_b_in, const void *d_b_aux, int tails_out[4]);   // prover.hip
 bool early_front_applies(const fk_key *key);
 void msm_release(fk_ctx *ctx);
+int streams_init(fk_ctx *ctx);       // msm.hip: the context's copy / auxiliary / lane streams, created together in a fixed order (fk_init)
 int msm_sync(fk_ctx *ctx);
 // reuse_sort: the scalars are the ones of the immediately preceding MSM call on this context (same pointer
 // and n), so its digits / bucket sort are still valid and are not recomputed (B1 and B2 share scalars)

@@ -279,7 +279,10 @@ int fk_key_write_bellman(fk_ctx *ctx, const fk_key *key, const uint8_t *gamma_g2
     uint8_t *w = out;
     auto u32be = [&](uint32_t v) { w[0] = (uint8_t)(v >> 24); w[1] = (uint8_t)(v >> 16); w[2] = (uint8_t)(v >> 8); w[3] = (uint8_t)v; w += 4; };
     // device conversion in chunks through ctx->misc: raw points in (device-resident arrays as they are; host points uploaded first)
-    const size_t CH = (size_t)1 << 22;          // points per chunk
+    // (sized by the key: a key of a few thousand points must not grow the context's scratch by a GiB on a device that is full -- ADVICE r4)
+    for (int i = 0; i < 5; i++) if (cnt[i] > 0xffffffffull) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "key write: array too long for bellman's u32 count");
+    const size_t longest = (size_t)std::max<uint64_t>(std::max(std::max(cnt[0], cnt[1]), std::max(cnt[2], std::max(cnt[3], cnt[4]))), std::max<uint64_t>(n_ic, 1));
+    const size_t CH = std::min((size_t)1 << 22, longest);          // points per chunk
     FK_HIP(ctx, ctx->misc.reserve(CH * 128 * 2));
     uint8_t *d_bytes = ctx->misc.as<uint8_t>(), *d_stage = d_bytes + CH * 128;
     auto emit = [&](const void *src, bool src_on_device, size_t n, size_t width) -> int {
@@ -302,7 +305,6 @@ int fk_key_write_bellman(fk_ctx *ctx, const fk_key *key, const uint8_t *gamma_g2
     FK_TRY(emit(&key->delta_g1, false, 1, 64)); FK_TRY(emit(&key->delta_g2, false, 1, 128));
     u32be(n_ic); FK_TRY(emit(ic, false, n_ic, 64));
     // h, l, a, b_g1 (G1), b_g2 (G2): u32 BE count + points
-    if (cnt[0] > 0xffffffffull || cnt[1] > 0xffffffffull) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "key write: array too long for bellman's u32 count");
     u32be((uint32_t)cnt[0]); FK_TRY(emit(key->d_h, true, cnt[0], 64));
     u32be((uint32_t)cnt[1]); FK_TRY(emit(key->d_l, true, cnt[1], 64));
     u32be((uint32_t)cnt[2]); FK_TRY(emit(key->d_a, true, cnt[2], 64));

@@ -1004,6 +1004,38 @@ __global__ __launch_bounds__(256) void msm_fold_partials_kernel(const Xyzz<F> *w
         }                                                                                         \
     } while (0)
 
+// every stream of a context, created together and in one order (called by fk_init).  HIP maps streams onto a handful of hardware queues
+// in creation order, and streams that share a queue serialise: with lazily created streams the mapping depended on which call a
+// process happened to make first -- a process that proved once through fk_prove_r1cs before it pipelined got its copy stream onto the
+// hardware queue of the B pair's lane, the upload's completion then sat behind the G2 tail, and the early front of every pipelined
+// proof started ~12 ms late (251 against 228 ms per proof on one box; profiles/r05_stream_order_ab.log).  The order here is the one
+// the benchmark process of rounds 2-4 happened to create: main (fk_init), copy, auxiliary, the four lanes.
+int streams_init(fk_ctx *ctx) {
+    if (!ctx->copy_st) FK_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_st, hipStreamNonBlocking));
+    if (!ctx->aux) {
+        FK_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
+        FK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_aux, hipEventDisableTiming));
+    }
+    for (MsmLane &ln : ctx->lanes) {
+        if (ln.st) continue;
+        FK_HIP(ctx, hipStreamCreateWithFlags(&ln.st, hipStreamNonBlocking));
+        FK_HIP(ctx, hipEventCreateWithFlags(&ln.ev_in, hipEventDisableTiming));
+        FK_HIP(ctx, hipEventCreateWithFlags(&ln.ev_sorted, hipEventDisableTiming));
+    }
+    // The G2 multiplication's tail -- oversized buckets, fold, bucket reduction: 7 ms of work -- is queued behind its accumulation while H's
+    // accumulation (all registers of every compute unit) is running: on its lane's stream it took 29 + 1 + 5 ms and ended AFTER H, the
+    // last thing of the proof.  On a stream of HIGH priority its workgroups are placed first whenever H's leave a slot.
+    // FK_G2_TAIL_PRIORITY=0 keeps it on the lane.
+    { const char *e = getenv("FK_G2_TAIL_PRIORITY");
+      if (!(e && e[0] == '0') && !ctx->tail_st) {
+          int least = 0, greatest = 0;
+          FK_HIP(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
+          FK_HIP(ctx, hipStreamCreateWithPriority(&ctx->tail_st, hipStreamNonBlocking, greatest));
+          FK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_tail_in, hipEventDisableTiming));
+      } }
+    return FK_OK;
+}
+
 static int lane_init(fk_ctx *ctx, MsmLane &ln) {
     if (ln.st) return FK_OK;
     FK_HIP(ctx, hipStreamCreateWithFlags(&ln.st, hipStreamNonBlocking));
@@ -1212,6 +1244,11 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
     auto back_tail = [=]() -> int {
         MsmLane &ln = *lnp; MsmTail &tl = *tlp;
         Xyzz<F> *buckets = bucket_buf();
+        // G2: the tail moves to the high-priority stream (behind the lane's accumulation; the lane goes on behind the tail)
+        const bool prio = !IS_G1 && ctx->tail_st != nullptr;
+        hipStream_t lane_st = st;
+        hipStream_t st = prio ? ctx->tail_st : lane_st;
+        if (prio) { FK_HIP(ctx, hipEventRecord(ctx->ev_tail_in, lane_st)); FK_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_tail_in, 0)); }
         // oversized buckets: fixed grids looping over the device-built tables (they leave at once when there is nothing to do)
         if (lazy) hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_overflow_kernel<F, FC, 2>), dim3(2048), dim3(64), 0, st,
                                           d_bases, d_lev, sorted, n, starts, totals, p.B, dyn, d_tasks, ln.partials.as<Xyzz<FC>>());
@@ -1235,6 +1272,7 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
         FK_HIP(ctx, hipMemcpyAsync((char *)tl.h_wp + wp_bytes, d_adds, 8, hipMemcpyDeviceToHost, st));
         FK_HIP(ctx, hipMemcpyAsync((char *)tl.h_wp + wp_bytes + 8, &dyn->error, 4, hipMemcpyDeviceToHost, st));
         FK_HIP(ctx, hipEventRecord(tl.done, st));
+        if (prio) FK_HIP(ctx, hipStreamWaitEvent(lane_st, tl.done, 0));       // whatever is queued on the lane next may reuse the buffers the tail reads
         FK_DBG_ST(ctx, st, "msm_bucket_reduce");
         return FK_OK;
     };
@@ -1286,6 +1324,7 @@ static int msm_end(fk_ctx *ctx, int tail, Xyzz<F> *out) {
 
 int msm_sync(fk_ctx *ctx) {
     if (ctx->aux) FK_HIP(ctx, hipStreamSynchronize(ctx->aux));
+    if (ctx->tail_st) FK_HIP(ctx, hipStreamSynchronize(ctx->tail_st));
     for (MsmLane &ln : ctx->lanes) if (ln.st) FK_HIP(ctx, hipStreamSynchronize(ln.st));
     return FK_OK;
 }
@@ -1295,12 +1334,15 @@ void msm_abandon(fk_ctx *ctx) {
     ctx->early.done = false;
     ctx->defer_back = false; ctx->deferred.clear(); ctx->deferred_tails.clear();
     if (ctx->aux) (void)hipStreamSynchronize(ctx->aux);
+    if (ctx->tail_st) (void)hipStreamSynchronize(ctx->tail_st);
     for (int i = 0; i < MSM_TAILS; i++) ctx->tails[i].active = false;
     for (MsmLane &ln : ctx->lanes) { if (ln.st) (void)hipStreamSynchronize(ln.st); ln.last_sort_scalars = nullptr; }
 }
 
 void msm_release(fk_ctx *ctx) {
     if (ctx->aux) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamDestroy(ctx->aux); ctx->aux = nullptr; }
+    if (ctx->tail_st) { (void)hipStreamSynchronize(ctx->tail_st); (void)hipStreamDestroy(ctx->tail_st); ctx->tail_st = nullptr; }
+    if (ctx->ev_tail_in) { (void)hipEventDestroy(ctx->ev_tail_in); ctx->ev_tail_in = nullptr; }
     if (ctx->ev_aux) { (void)hipEventDestroy(ctx->ev_aux); ctx->ev_aux = nullptr; }
     if (ctx->ev_main) { (void)hipEventDestroy(ctx->ev_main); ctx->ev_main = nullptr; }
     if (ctx->ev_z) { (void)hipEventDestroy(ctx->ev_z); ctx->ev_z = nullptr; }
@@ -1424,9 +1466,12 @@ int key_precompute(fk_ctx *ctx, fk_key *k) {
     const size_t nmax = std::max<size_t>(std::max<size_t>(k->h_hi - k->h_lo, k->l_hi - k->l_lo), std::max<size_t>(k->a_hi - k->a_lo, std::max(k->b_hi - k->b_lo, k->b2_hi - k->b2_lo)));
     const MsmPlan pl = make_plan(nmax, ctx->window_bits, true);
     const size_t lane_fixed = (size_t)pl.W * pl.B * (MSM_LANES * (sizeof(Xyzz<Fq>) + 16) + sizeof(Xyzz<Fq2>)) + ((size_t)1 << 30);   // bucket sets (G1 per lane, G2 once), counters, tables
-    const bool cut = k->shard_count > 1 && !(k->shard_count & (k->shard_count - 1));       // the quotient is cut between 2^k ranks only
-    // (the twiddle and scale tables cover the whole domain on every rank; the vectors are cut)
-    const size_t need = pts * 14 * 13 + lane_fixed + (size_t)k->m * 32 * 6 + (size_t)k->m / (cut ? k->shard_count : 1) * 32 * 10 + 2 * nv * 32;
+    // The quotient's share of this shard follows from the h slice it holds: all of h = the whole quotient runs here (a lone
+    // shard, or rank 0 of the "quotient on rank 0" split: 10 vectors + 6 tables of m elements); no h at all = no quotient buffers (the
+    // other ranks of that split); a block of the domain = the cut transforms (vectors of m / ranks elements, tables of m on every rank).
+    const uint64_t h_held = k->h_hi - k->h_lo;
+    const size_t quot = h_held == 0 ? 0 : h_held >= k->n_h ? (size_t)k->m * 32 * (6 + 10) : (size_t)k->m * 32 * 6 + (size_t)k->m / k->shard_count * 32 * 10;
+    const size_t need = pts * 14 * 13 + lane_fixed + quot + 2 * nv * 32;
     // ... of which this context may hold a part already (grow-only buffers of earlier, possibly larger proofs: they are reused)
     size_t have = 0;
     for (const MsmLane &ln : ctx->lanes)
@@ -1436,14 +1481,70 @@ int key_precompute(fk_ctx *ctx, fk_key *k) {
                             &ctx->stage_d, &ctx->wslot[0].buf, &ctx->wslot[1].buf}) have += b->cap;
     // ranks of one fk_multi that share a GPU (fk_init_devices with a device named several times) each need this much again
     const size_t reserve = (need > have ? need - have : 0) * (size_t)std::max(1, ctx->co_tenants) + ((size_t)8 << 30);
-    // the long G1 accumulations first: if HBM runs short the later arrays stay on the ordinary path
-    if (k->d_h) FK_TRY(precompute_levels<Fq>(ctx, k->d_h, k->h_hi - k->h_lo, &k->pre_h, "h", require, reserve));
-    if (k->d_l) FK_TRY(precompute_levels<Fq>(ctx, k->d_l, k->l_hi - k->l_lo, &k->pre_l, "l", require, reserve));
-    const bool b_shared = k->b2_lo == k->b_lo && k->b2_hi == k->b_hi;          // B1 and B2 over the same scalars share one sort: same plan or none
-    if (k->d_b2) FK_TRY(precompute_levels<Fq2>(ctx, k->d_b2, k->b2_hi - k->b2_lo, &k->pre_b2, "b_g2", require, reserve));
-    if (k->d_b1 && (!b_shared || k->pre_b2.lev || !k->d_b2)) FK_TRY(precompute_levels<Fq>(ctx, k->d_b1, k->b_hi - k->b_lo, &k->pre_b1, "b_g1", require, reserve));
-    if (b_shared && k->pre_b2.lev && !k->pre_b1.lev && k->b_hi > k->b_lo) { (void)hipFree(k->pre_b2.lev); k->pre_b2 = KeyPre(); }       // b_g1's did not fit: neither keeps them
-    if (k->d_a) FK_TRY(precompute_levels<Fq>(ctx, k->d_a, k->a_hi - k->a_lo, &k->pre_a, "a", require, reserve));
+    // WHICH arrays get levels when they do not all fit (2^26: everything but one; 2^27: one or two): the set with the most accumulation
+    // work on the merged path that fits -- a knapsack over at most five items, solved by enumeration.  An array's worth is its points
+    // times the cost of one of its additions (a G2 addition = FK_G2_WORK G1 additions), its price (W - 1) levels of 64 / 128 bytes per
+    // point: G2 buys 1.4 x the work per byte of G1.  b_g1 and b_g2 over the same scalars share one sort, hence one plan: both or
+    // neither.  (Rounds 1-4 took the arrays in a fixed order h, l, b, a while they fitted: at 2^26 that dropped a, the cheapest, and at
+    // 2^27 kept only a -- VERDICT r4 #8.)
+    struct Cand { const char *name; int which; size_t n, bytes; double worth; };       // which: 0 h, 1 l, 2 a, 3 b_g1, 4 b_g2, 5 the b pair
+    std::vector<Cand> cand;
+    const bool b_shared = k->b2_lo == k->b_lo && k->b2_hi == k->b_hi && k->d_b1 && k->d_b2;          // B1 and B2 over the same scalars share one sort: same plan or none
+    auto level_bytes = [&](size_t n, size_t pt) -> size_t {
+        const char *e2 = getenv("FK_MSM_PRE_MIN_LOG2");
+        const int min_lg = e2 ? atoi(e2) : 21;
+        if (min_lg < 6 || min_lg > 40 || n + n / 2 < ((size_t)1 << min_lg)) return 0;
+        const MsmPlan p = make_plan(n, ctx->window_bits, true);
+        return p.W < 2 ? 0 : (size_t)(p.W - 1) * n * pt;
+    };
+    auto add_cand = [&](const char *name, int which, const void *d, size_t n, size_t pt, double w) {
+        const size_t b = d ? level_bytes(n, pt) : 0;
+        if (b) cand.push_back({name, which, n, b, w * (double)n});
+    };
+    add_cand("h", 0, k->d_h, k->h_hi - k->h_lo, 64, 1.0);
+    add_cand("l", 1, k->d_l, k->l_hi - k->l_lo, 64, 1.0);
+    add_cand("a", 2, k->d_a, k->a_hi - k->a_lo, 64, 1.0);
+    if (b_shared) {
+        const size_t nb = k->b_hi - k->b_lo, bb = level_bytes(nb, 64 + 128);
+        if (bb) cand.push_back({"b_g1 + b_g2", 5, nb, bb, (1.0 + (double)FK_G2_WORK) * (double)nb});
+    } else {
+        add_cand("b_g1", 3, k->d_b1, k->b_hi - k->b_lo, 64, 1.0);
+        add_cand("b_g2", 4, k->d_b2, k->b2_hi - k->b2_lo, 128, (double)FK_G2_WORK);
+    }
+    size_t fr = 0, tot = 0;
+    FK_HIP(ctx, hipMemGetInfo(&fr, &tot));
+    const size_t budget = fr > reserve ? fr - reserve : 0;
+    uint32_t best = 0; double best_w = -1; size_t best_b = 0;
+    for (uint32_t mask = 0; mask < (1u << cand.size()); mask++) {
+        size_t b = 0; double w = 0;
+        for (size_t i = 0; i < cand.size(); i++) if ((mask >> i) & 1) { b += cand[i].bytes; w += cand[i].worth; }
+        if (b <= budget && (w > best_w || (w == best_w && b < best_b))) { best = mask; best_w = w; best_b = b; }
+    }
+    for (size_t i = 0; i < cand.size(); i++) {
+        const Cand &c = cand[i];
+        if (!((best >> i) & 1)) {
+            // Not an error by default -- the array keeps the ordinary W-bucket-set path (same bytes, ~7-10 % slower at 2^25) -- but never
+            // silent: the text stays in fk_last_error (a second key or another process on the GPU is the usual cause).
+            char msg[320];
+            snprintf(msg, sizeof msg, "key: fixed-base levels of %s (%zu points, %.1f GiB) left out: %.1f GiB of HBM are free for levels and the arrays chosen instead carry more work",
+                     c.name, c.n, (double)c.bytes / (double)(1ull << 30), (double)budget / (double)(1ull << 30));
+            if (require) { ctx->err = std::string(msg) + " and FK_MSM_PRECOMP=require"; return FK_ERR_OOM; }
+            ctx->err += (ctx->err.empty() ? "warning: " : "; ") + std::string(msg) + " -- that array takes the slower W-bucket-set path";
+            continue;
+        }
+        switch (c.which) {
+            case 0: FK_TRY(precompute_levels<Fq>(ctx, k->d_h, c.n, &k->pre_h, "h", require, 0)); break;
+            case 1: FK_TRY(precompute_levels<Fq>(ctx, k->d_l, c.n, &k->pre_l, "l", require, 0)); break;
+            case 2: FK_TRY(precompute_levels<Fq>(ctx, k->d_a, c.n, &k->pre_a, "a", require, 0)); break;
+            case 3: FK_TRY(precompute_levels<Fq>(ctx, k->d_b1, c.n, &k->pre_b1, "b_g1", require, 0)); break;
+            case 4: FK_TRY(precompute_levels<Fq2>(ctx, k->d_b2, c.n, &k->pre_b2, "b_g2", require, 0)); break;
+            default:
+                FK_TRY(precompute_levels<Fq2>(ctx, k->d_b2, c.n, &k->pre_b2, "b_g2", require, 0));
+                FK_TRY(precompute_levels<Fq>(ctx, k->d_b1, c.n, &k->pre_b1, "b_g1", require, 0));
+                if (k->pre_b2.lev && !k->pre_b1.lev) { (void)hipFree(k->pre_b2.lev); k->pre_b2 = KeyPre(); }       // (an allocation failed after all: neither keeps them)
+                if (k->pre_b1.lev && !k->pre_b2.lev) { (void)hipFree(k->pre_b1.lev); k->pre_b1 = KeyPre(); }
+        }
+    }
     return FK_OK;
 }
 
@@ -1523,6 +1624,10 @@ __global__ void gen_scalars_kernel(Fr *out, size_t n, uint64_t seed, int kind) {
     if (kind == 1) {
         uint64_t sel = splitmix64(s);
         if (sel & 1) { for (int k = 0; k < 8; k++) v.v[k] = 0; v.v[0] = (uint32_t)((sel >> 1) & 1); }
+    } else if (kind == 2) {                // the benchmark witness's mix: 5.3 % zeros, 2.5 % ones, the rest dense and pairwise DISTINCT
+        const uint32_t sel = (uint32_t)(splitmix64(s) >> 32) >> 12;          // 20 bits
+        if (sel < 55575u) { for (int k = 0; k < 8; k++) v.v[k] = 0; }
+        else if (sel < 55575u + 26214u) { for (int k = 0; k < 8; k++) v.v[k] = 0; v.v[0] = 1; }
     }
     out[i] = Fr::to_mont(v);
 }

@@ -35,7 +35,10 @@
 
 using namespace fk;
 
-struct fk_multi_key { std::vector<fk_key *> shard; };
+struct fk_multi_key {
+    std::vector<fk_key *> shard;
+    double split = FK_Z_EQUAL_SPLIT;      // how the arrays were dealt (recorded by the loader, on the calling thread): decides the schedule of every proof with this key
+};
 struct fk_multi_r1cs { std::vector<fk_r1cs_dev *> rep; };
 
 namespace fk {
@@ -299,8 +302,9 @@ static int prove_rank(fk_multi *M, int rank, const fk_multi_key *K, const fk_mul
     if (M->n == 1 && !M->force_exchange) return fk_prove_r1cs_dev(ctx, key, rs, d_z, r_, s_, out, tm);       // nothing to cut: the single-GPU prover
     const uint32_t log_m = ceil_log2_u64(key->m);
     uint8_t *part = me.part;
-    // the key's h slices say which schedule it was loaded for: all of h on rank 0 = "quotient on rank 0" (no exchange at all)
-    const bool q0 = M->n > 1 && K->shard[0]->h_hi - K->shard[0]->h_lo == K->shard[0]->n_h && K->shard[1]->h_hi == K->shard[1]->h_lo;
+    // the split the key was loaded with says which schedule it is for (recorded in the key -- not inferred from the shape of its slices,
+    // ADVICE r4): FK_Z_WORK_SPLIT_Q0 = all of h on rank 0, "quotient on rank 0" (no exchange at all)
+    const bool q0 = M->n > 1 && K->split == FK_Z_WORK_SPLIT_Q0;
     if (q0) {
         if (rank == 0) {
             const size_t mb = key->m * sizeof(Fr);
@@ -502,9 +506,10 @@ int fk_multi_key_load(fk_multi *M, const fk_key_desc *desc, fk_multi_key **out) 
     if (!desc) { M->err = "key: null descriptor"; return FK_ERR_BAD_ARG; }
     fk_multi_key *K = new fk_multi_key();
     K->shard.assign(M->n, nullptr);
+    const double split = K->split = multi_split(M);          // (read here, on the calling thread: the workers do not touch the environment)
     const int rc = run_all(M, [&](int r) {
         fk_key_desc d = *desc;
-        d.shard_index = (uint32_t)r; d.shard_count = (uint32_t)M->n; d.z_frac_lo = multi_split(M); d.z_frac_hi = 0;
+        d.shard_index = (uint32_t)r; d.shard_count = (uint32_t)M->n; d.z_frac_lo = split; d.z_frac_hi = 0;
         return fk_key_load(M->ctx[r], &d, &K->shard[r]);
     }, shares_device(M));
     if (rc != FK_OK) { fk_multi_key_free(M, K); return rc; }
@@ -518,9 +523,10 @@ int fk_multi_key_load_bellman(fk_multi *M, const uint8_t *buf, size_t len, uint3
     *out = nullptr;
     fk_multi_key *K = new fk_multi_key();
     K->shard.assign(M->n, nullptr);
+    const double split = K->split = multi_split(M);
     const int rc = run_all(M, [&](int r) {
         uint32_t nic = 0;
-        const int x = fk_key_load_bellman(M->ctx[r], buf, len, flags, (uint32_t)r, (uint32_t)M->n, multi_split(M), 0, &K->shard[r],
+        const int x = fk_key_load_bellman(M->ctx[r], buf, len, flags, (uint32_t)r, (uint32_t)M->n, split, 0, &K->shard[r],
                                           r == 0 ? gamma_g2_out : nullptr, r == 0 ? ic_out : nullptr, r == 0 ? ic_cap : 0, &nic);
         if (r == 0 && n_ic) *n_ic = nic;
         return x;
@@ -538,13 +544,14 @@ static int multi_setup(fk_multi *M, const fk_r1cs *cs, uint32_t copies, const ui
     fk_multi_key *K = new fk_multi_key();
     K->shard.assign(M->n, nullptr);
     const size_t n_ic = copies ? 1 + (size_t)copies * (cs->num_input - 1) : cs->num_input;
+    const double split = K->split = multi_split(M);
     const int rc = run_all(M, [&](int r) {
         // every rank derives ONLY its shard of the five arrays (setup.hip); the verifying key comes out of each derivation, rank 0's is returned
         std::vector<uint8_t> vk_tmp, ic_tmp;
         uint8_t *vk = vk_out, *ic = ic_out;
         if (r != 0) { vk_tmp.resize(6 * 128); ic_tmp.resize(n_ic * 64 + 64); vk = vk_tmp.data(); ic = ic_tmp.data(); }
-        if (copies) return fk_setup_tiled(M->ctx[r], cs, copies, tau, alpha, beta, gamma, delta, (uint32_t)r, (uint32_t)M->n, multi_split(M), 0, &K->shard[r], vk, ic);
-        return fk_setup(M->ctx[r], cs, tau, alpha, beta, gamma, delta, (uint32_t)r, (uint32_t)M->n, multi_split(M), 0, &K->shard[r], vk, ic);
+        if (copies) return fk_setup_tiled(M->ctx[r], cs, copies, tau, alpha, beta, gamma, delta, (uint32_t)r, (uint32_t)M->n, split, 0, &K->shard[r], vk, ic);
+        return fk_setup(M->ctx[r], cs, tau, alpha, beta, gamma, delta, (uint32_t)r, (uint32_t)M->n, split, 0, &K->shard[r], vk, ic);
     }, shares_device(M));
     if (rc != FK_OK) { fk_multi_key_free(M, K); return rc; }
     *out = K;

@@ -12,6 +12,7 @@
 #include <unistd.h>
 #include "common.hpp"
 #include <chrono>
+#include <mutex>
 #include <string.h>
 #include <stdlib.h>
 
@@ -75,22 +76,38 @@ int fk_init(int device_id, fk_ctx **out) {
     if (ctx->debug || getenv("FK_BACKTRACE")) {
         // debugging aid (FK_DEBUG=1 or FK_BACKTRACE=1): a native backtrace on SIGSEGV / SIGABRT (the Python host's faulthandler only shows Python frames; the
         // offsets resolve against the same libfawkes_hip.so with addr2line / llvm-symbolizer)
-        static bool installed = false;
-        if (!installed) {
-            installed = true;
-            auto h = +[](int sig) {
+        // Installed once (std::call_once), with sigaction, CHAINING to whatever handler the host had (Python's faulthandler, Rust's
+        // stack-overflow guard): ours prints and hands the signal on.  backtrace() is called once here, at install time, so that its
+        // lazy initialisation (it may dlopen libgcc and allocate) does not happen inside a signal handler.
+        static std::once_flag once;
+        std::call_once(once, [] {
+            void *warm[4];
+            (void)backtrace(warm, 4);
+            static struct sigaction prev_segv, prev_abrt;
+            auto h = +[](int sig, siginfo_t *info, void *uctx) {
                 void *bt[64];
                 const int n = backtrace(bt, 64);
                 const char msg[] = "[fk] fatal signal, native backtrace:\n";
                 (void)!write(2, msg, sizeof msg - 1);
                 backtrace_symbols_fd(bt, n, 2);
+                const struct sigaction &prev = sig == SIGSEGV ? prev_segv : prev_abrt;
+                if ((prev.sa_flags & SA_SIGINFO) && prev.sa_sigaction) { prev.sa_sigaction(sig, info, uctx); return; }
+                if (!(prev.sa_flags & SA_SIGINFO) && prev.sa_handler != SIG_DFL && prev.sa_handler != SIG_IGN && prev.sa_handler) { prev.sa_handler(sig); return; }
                 signal(sig, SIG_DFL); raise(sig);
             };
-            signal(SIGSEGV, h); signal(SIGABRT, h);
-        }
+            struct sigaction sa;
+            memset(&sa, 0, sizeof sa);
+            sa.sa_sigaction = h;
+            sa.sa_flags = SA_SIGINFO | SA_ONSTACK;
+            sigemptyset(&sa.sa_mask);
+            sigaction(SIGSEGV, &sa, &prev_segv);
+            sigaction(SIGABRT, &sa, &prev_abrt);
+        });
     }
     { const int v = tune("FK_NTT_THREADS", 512); if (v == 64 || v == 128 || v == 256 || v == 512 || v == 1024) ctx->ntt_threads = (unsigned)v; }
     if (hipStreamCreate(&ctx->stream) != hipSuccess) { delete ctx; return FK_ERR_HIP; }
+    { const char *e = getenv("FK_LAZY_STREAMS");       // (=1: the streams are created on first use, as before round 5 -- for the A/B only)
+      if (!(e && e[0] == '1') && streams_init(ctx) != FK_OK) { fk_free(ctx); return FK_ERR_HIP; } }
     *out = ctx;
     return FK_OK;
 }
@@ -125,6 +142,7 @@ int fk_trim(fk_ctx *ctx) { return fk_guard(ctx, [&]() -> int {
     FK_HIP(ctx, hipSetDevice(ctx->device));
     for (const auto &w : ctx->wslot) if (w.pending) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "trim: a submitted proof is outstanding (call fk_prove_r1cs_wait first)");
     if (ctx->wit_active || ctx->early.done || !ctx->deferred.empty()) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "trim: multiplications are in flight");
+    for (const auto &t : ctx->tails) if (t.active) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "trim: a multiplication begun with a *_begin_* call has not been collected");
     FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     FK_TRY(msm_sync(ctx));
     if (ctx->copy_st) FK_HIP(ctx, hipStreamSynchronize(ctx->copy_st));
@@ -135,6 +153,7 @@ int fk_trim(fk_ctx *ctx) { return fk_guard(ctx, [&]() -> int {
         b->release();
     for (auto &w : ctx->wslot) { w.buf.release(); w.deferred = false; if (w.ready) { (void)hipEventDestroy(w.ready); w.ready = nullptr; } if (w.part) { (void)hipEventDestroy(w.part); w.part = nullptr; } }      // "holds nothing" again
     ctx->lane_prev = 0; ctx->lane_next = 0;
+    { const char *e = getenv("FK_LAZY_STREAMS"); if (!(e && e[0] == '1')) FK_TRY(streams_init(ctx)); }      // the streams come back together, in the same order
     return FK_OK;
 }); }
 
@@ -363,6 +382,21 @@ int fk_key_precomputed(const fk_key *k, uint32_t out[5]) {
     if (!k || !out) return FK_ERR_BAD_ARG;
     const KeyPre *p[5] = {&k->pre_h, &k->pre_l, &k->pre_a, &k->pre_b1, &k->pre_b2};
     for (int i = 0; i < 5; i++) out[i] = p[i]->lev ? p[i]->W : 0;
+    return FK_OK;
+}
+
+// per array (h, l, a, b_g1, b_g2): levels held, GiB they occupy (or would: negative when the array has none), and an ESTIMATE of the ms
+// per proof they save -- 4.6e-8 ms per point of G1 work (a G2 point = FK_G2_WORK), the all-levels-vs-none difference measured at 2^25
+// (DESIGN.md section 3.3); 0 for an array too small for levels
+int fk_key_levels_plan(const fk_key *k, double out[15]) {
+    if (!k || !out) return FK_ERR_BAD_ARG;
+    const KeyPre *p[5] = {&k->pre_h, &k->pre_l, &k->pre_a, &k->pre_b1, &k->pre_b2};
+    const uint64_t n[5] = {k->h_hi - k->h_lo, k->l_hi - k->l_lo, k->a_hi - k->a_lo, k->b_hi - k->b_lo, k->b2_hi - k->b2_lo};
+    for (int i = 0; i < 5; i++) {
+        const double pt = i == 4 ? 128.0 : 64.0, work = (i == 4 ? (double)FK_G2_WORK : 1.0) * (double)n[i];
+        if (p[i]->lev) { out[3 * i] = p[i]->W; out[3 * i + 1] = (double)(p[i]->W - 1) * (double)n[i] * pt / 1073741824.0; out[3 * i + 2] = work * 4.6e-8; }
+        else { out[3 * i] = 0; out[3 * i + 1] = n[i] + n[i] / 2 >= (1ull << 21) ? -11.0 * (double)n[i] * pt / 1073741824.0 : 0.0; out[3 * i + 2] = 0; }
+    }
     return FK_OK;
 }
 

@@ -155,6 +155,11 @@ int fk_key_shard_info2(const fk_key *key, uint64_t out[10]);
  * W, and wider windows.  Same group elements, so the proof bytes do not change.  FK_MSM_PRECOMP=0 turns it off; an
  * array whose levels do not fit simply keeps the ordinary path.  out[5] = levels held for h, l, a, b_g1, b_g2 (0 = none). */
 int fk_key_precomputed(const fk_key *key, uint32_t out[5]);
+/* The loader's choice when the levels do not all fit (2^26, 2^27 on one GPU): the set of arrays with the most accumulation work that fits
+ * the HBM left after what a proof will allocate (a knapsack over <= 5 items; b_g1 and b_g2 share a sort, hence both or neither; a G2 point
+ * is FK_G2_WORK G1 points of work at twice the bytes).  out[15] = per array h, l, a, b_g1, b_g2: levels held, GiB of levels (negative: the
+ * GiB the array WOULD need -- it was left out), estimated ms per proof saved. */
+int fk_key_levels_plan(const fk_key *key, double out[15]);
 /* what loading the key cost: out[0] = seconds for the arrays themselves (transfer + conversion + the checks of fk_key_load_bellman, or
  * the derivation of fk_setup*), out[1] = seconds for the fixed-base levels */
 int fk_key_load_profile(const fk_key *key, double out[2]);
@@ -286,7 +291,8 @@ int fk_msm_g2_dev(fk_ctx *ctx, const void *d_bases, const void *d_scalars, size_
 /* n valid pseudo-random curve points written to device memory (bench/test input generator) */
 int fk_gen_points_g1_dev(fk_ctx *ctx, void *d_out, size_t n, uint64_t seed);
 int fk_gen_points_g2_dev(fk_ctx *ctx, void *d_out, size_t n, uint64_t seed);
-/* n pseudo-random Montgomery Fr elements; kind 0 = uniform, 1 = witness-like (half in {0,1}) */
+/* n pseudo-random Montgomery Fr elements; kind 0 = uniform, 1 = witness-like (half in {0,1}), 2 = the benchmark witness's mix (5.3 % zeros,
+ * 2.5 % ones, the rest dense and pairwise distinct) */
 int fk_gen_scalars_dev(fk_ctx *ctx, void *d_out, size_t n, uint64_t seed, int kind);
 
 /* ---------------------------------------------------------------- synthesis (host side of the boundary)

@@ -86,7 +86,7 @@ impl HipProver {
             assert!(rc == ffi::FK_OK, "fk_multi_key_load: {}", last_error(multi));
             // the gate blob is decoded once on the host (ctx = NULL), then uploaded to every GPU
             let rc = ffi::fk_gates_decode(ptr::null_mut(), params.2.as_ptr(), params.2.len(), ffi::FK_GATES_BROTLI, params.1, num_input, num_aux, &mut gates);
-            assert!(rc == ffi::FK_OK, "fk_gates_decode failed ({}): malformed gate blob", rc);
+            assert!(rc == ffi::FK_OK, "fk_gates_decode failed ({}): {}", rc, CStr::from_ptr(ffi::fk_last_error(ptr::null())).to_string_lossy());
             let rc = ffi::fk_multi_r1cs_load_gates(multi, gates, &mut r1cs);
             ffi::fk_gates_free(gates);
             assert!(rc == ffi::FK_OK, "fk_multi_r1cs_load_gates: {}", last_error(multi));
@@ -114,6 +114,33 @@ impl Drop for HipProver {
     }
 }
 
+/// prover.rs:69-76 and 83-87 -- everything `prove` does on the host around `create_random_proof`: allocates the signals in a `WitnessCS`,
+/// runs the circuit closure (which fills in the assignment), and returns (z = values_input ++ values_aux in the variable order of
+/// cs.rs:255-268, the public inputs without the leading ONE, whether every cached constant was consumed: the assertion of prover.rs:83,
+/// which the callers make AFTER the proof like the reference).  Takes no lock and touches no GPU: a panic in the caller's closure
+/// (a witness that cannot be computed) leaves no shared state behind.
+fn host_witness<'a, E: Engine, Pub: Signal<WitnessCS<'a, E::Fr>>, Sec: Signal<WitnessCS<'a, E::Fr>>, C: Fn(Pub, Sec)>(
+    params: &'a Parameters<E>,
+    input_pub: &Pub::Value,
+    input_sec: &Sec::Value,
+    circuit: C,
+) -> (Vec<Num<E::Fr>>, Vec<Num<E::Fr>>, bool) {
+    let ref rcs = params.get_witness_rcs();                                  // prover.rs:69
+    let signal_pub = Pub::alloc(rcs, Some(input_pub));
+    signal_pub.inputize();
+    let signal_sec = Sec::alloc(rcs, Some(input_sec));
+    circuit(signal_pub, signal_sec);                                         // prover.rs:74: fills WitnessCS
+
+    let cs = rcs.borrow();
+    // `Num<Fr>` is #[repr(transparent)] over the limbs: the vector is the byte image the C ABI reads
+    let mut z: Vec<Num<E::Fr>> = Vec::with_capacity(cs.num_input() + cs.num_aux());
+    for i in 0..cs.num_input() as u32 { z.push(cs.get_value(Index::Input(i)).unwrap()); }
+    for j in 0..cs.num_aux() as u32 { z.push(cs.get_value(Index::Aux(j)).unwrap()); }
+    let mut inputs = Vec::with_capacity(cs.num_input());
+    for i in 1..cs.num_input() as u32 { inputs.push(cs.get_value(Index::Input(i)).unwrap()); }  // prover.rs:84-87
+    (z, inputs, cs.const_tracker_index == cs.const_tracker.len())
+}
+
 /// Deterministic twin of `prove_hip`: r, s given -- what `bellman::groth16::create_proof(circuit, params, r, s)` takes.
 /// Same signature as prover.rs:63-68 plus the resident prover and (r, s).
 pub fn prove_hip_with_rs<'a, E: Engine, Pub: Signal<WitnessCS<'a, E::Fr>>, Sec: Signal<WitnessCS<'a, E::Fr>>, C: Fn(Pub, Sec)>(
@@ -125,25 +152,11 @@ pub fn prove_hip_with_rs<'a, E: Engine, Pub: Signal<WitnessCS<'a, E::Fr>>, Sec: 
     r: Num<E::Fr>,
     s: Num<E::Fr>,
 ) -> (Vec<Num<E::Fr>>, Proof<E>) {
-    let ref rcs = params.get_witness_rcs();                                  // prover.rs:69
-    let signal_pub = Pub::alloc(rcs, Some(input_pub));
-    signal_pub.inputize();
-    let signal_sec = Sec::alloc(rcs, Some(input_sec));
-    circuit(signal_pub, signal_sec);                                         // prover.rs:74: fills WitnessCS
-
-    let cs = rcs.borrow();
-    // z = values_input ++ values_aux (variable order of cs.rs:255-268): `Num<Fr>` is #[repr(transparent)] over the limbs
-    let mut z: Vec<Num<E::Fr>> = Vec::with_capacity(cs.num_input() + cs.num_aux());
-    for i in 0..cs.num_input() as u32 { z.push(cs.get_value(Index::Input(i)).unwrap()); }
-    for j in 0..cs.num_aux() as u32 { z.push(cs.get_value(Index::Aux(j)).unwrap()); }
-
+    let (z, inputs, tracker_consumed) = host_witness::<E, Pub, Sec, C>(params, input_pub, input_sec, circuit);
     let bytes = hip.prove_bytes(&z, &r, &s);
     // the 256 bytes ARE fawkes' Borsh `Proof` (prover.rs:39-60: a, b, c; canonical little-endian coordinates)
     let proof = Proof::<E>::try_from_slice(&bytes).expect("proof bytes");
-
-    assert!(cs.const_tracker_index == cs.const_tracker.len(), "not all cached data used");    // prover.rs:83
-    let mut inputs = Vec::with_capacity(cs.num_input());
-    for i in 1..cs.num_input() as u32 { inputs.push(cs.get_value(Index::Input(i)).unwrap()); }  // prover.rs:84-87
+    assert!(tracker_consumed, "not all cached data used");                  // prover.rs:83
     (inputs, proof)
 }
 
@@ -195,19 +208,30 @@ fn cache_key<E: Engine>(params: &Parameters<E>, devices: &[i32]) -> CacheKey {
     (params as *const _ as usize, params.1, bp.h.len(), bp.l.len(), tag, devices.to_vec())
 }
 
+/// A panic while a lock was held (a failed key load, a failed proof) poisons a std Mutex; the state behind ours stays usable -- the map
+/// holds only finished provers, and the C library clears whatever a failed call had in flight -- so a poisoned lock is simply taken over.
+/// (The reference's `prove` has no shared state and survives a caught panic; so does this one.)
+fn lock_ignoring_poison<T>(m: &Mutex<T>) -> std::sync::MutexGuard<'_, T> {
+    m.lock().unwrap_or_else(|e| e.into_inner())
+}
+
 /// The cached prover of (`params`, FK_DEVICES), built on first use.  A `Parameters` value that is dropped should be `forget`-ed:
 /// the cache cannot see a drop, and HBM is released only when the entry goes.
+/// The prover is built OUTSIDE the map's lock (a key load takes seconds to minutes and may panic -- no usable GPU, out of HBM): other
+/// keys' proofs go on meanwhile, and a failed build leaves the map as it was.  Two threads that race for the same new key both build
+/// one; the loser's is dropped (its HBM freed) and everybody uses the winner's.
 pub fn resident_prover<E: Engine>(params: &Parameters<E>) -> Arc<Mutex<HipProver>> {
     let devices = devices_from_env();
     let key = cache_key(params, &devices);
-    let mut map = cache().lock().unwrap();
-    map.entry(key).or_insert_with(|| Arc::new(Mutex::new(HipProver::new(&devices, params)))).clone()
+    if let Some(p) = lock_ignoring_poison(cache()).get(&key) { return p.clone(); }
+    let built = Arc::new(Mutex::new(HipProver::new(&devices, params)));      // may panic: nothing is locked here
+    lock_ignoring_poison(cache()).entry(key).or_insert(built).clone()
 }
 
 /// Drops the cached prover(s) of `params` (all device lists): frees the key shards, levels and constraint system in HBM.
 pub fn forget<E: Engine>(params: &Parameters<E>) {
     let probe = cache_key(params, &[]);
-    cache().lock().unwrap().retain(|k, _| !(k.0 == probe.0 && k.1 == probe.1 && k.2 == probe.2 && k.3 == probe.3 && k.4 == probe.4));
+    lock_ignoring_poison(cache()).retain(|k, _| !(k.0 == probe.0 && k.1 == probe.1 && k.2 == probe.2 && k.3 == probe.3 && k.4 == probe.4));
 }
 
 /// `fawkes_crypto::backend::bellman_groth16::prover::prove` -- the SAME signature, argument meaning, return value and panics
@@ -219,12 +243,16 @@ pub fn prove<'a, E: Engine, Pub: Signal<WitnessCS<'a, E::Fr>>, Sec: Signal<Witne
     input_sec: &Sec::Value,
     circuit: C,
 ) -> (Vec<Num<E::Fr>>, Proof<E>) {
-    let hip = resident_prover(params);
-    let guard = hip.lock().unwrap();
-    prove_hip(params, &guard, input_pub, input_sec, circuit)
+    use bellman::pairing::ff::Field;
+    let ref mut rng = OsRng::new();
+    let r = <<E::BE as bellman::pairing::ff::ScalarEngine>::Fr as Field>::rand(rng);
+    let s = <<E::BE as bellman::pairing::ff::ScalarEngine>::Fr as Field>::rand(rng);
+    prove_with_rs(params, input_pub, input_sec, circuit, bellman_fp_to_num(r), bellman_fp_to_num(s))
 }
 
 /// Deterministic twin of `prove` (r, s given: bellman's `create_proof(circuit, params, r, s)`), for byte-exact comparisons.
+/// The caller's circuit closure runs BEFORE the prover's lock is taken: witness generation of one thread overlaps with the proof of
+/// another, and a closure that panics has locked nothing.
 pub fn prove_with_rs<'a, E: Engine, Pub: Signal<WitnessCS<'a, E::Fr>>, Sec: Signal<WitnessCS<'a, E::Fr>>, C: Fn(Pub, Sec)>(
     params: &'a Parameters<E>,
     input_pub: &Pub::Value,
@@ -233,7 +261,10 @@ pub fn prove_with_rs<'a, E: Engine, Pub: Signal<WitnessCS<'a, E::Fr>>, Sec: Sign
     r: Num<E::Fr>,
     s: Num<E::Fr>,
 ) -> (Vec<Num<E::Fr>>, Proof<E>) {
+    let (z, inputs, tracker_consumed) = host_witness::<E, Pub, Sec, C>(params, input_pub, input_sec, circuit);
     let hip = resident_prover(params);
-    let guard = hip.lock().unwrap();
-    prove_hip_with_rs(params, &guard, input_pub, input_sec, circuit, r, s)
+    let bytes = { let guard = lock_ignoring_poison(&hip); guard.prove_bytes(&z, &r, &s) };      // the only stretch that holds the prover
+    let proof = Proof::<E>::try_from_slice(&bytes).expect("proof bytes");
+    assert!(tracker_consumed, "not all cached data used");                  // prover.rs:83
+    (inputs, proof)
 }

@@ -1,0 +1,16 @@
+# same box: the default flow (explicit system out of the Parameters image) with the streams created eagerly in a fixed order (default) against
+# FK_LAZY_STREAMS=1 (created on first use, rounds 1-4), and the tiled headline both ways
+set -u
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"; O=gpurun_out/ab_streams; rm -rf $O; mkdir -p $O
+F="--steps 12 --warmup 4 --no-cpu-baseline --no-other-sizes --no-standalone"
+python3 bench.py $F > $O/explicit_eager.log 2>&1
+FK_LAZY_STREAMS=1 python3 bench.py $F > $O/explicit_lazy.log 2>&1
+python3 bench.py --tiled-headline --no-untiled $F > $O/tiled_eager.log 2>&1
+FK_LAZY_STREAMS=1 python3 bench.py --tiled-headline --no-untiled $F > $O/tiled_lazy.log 2>&1
+python3 bench.py $F > $O/explicit_eager_b.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o k -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-untiled --no-standalone --no-other-sizes > $O/kt.log 2>&1
+python3 tools/trace_gantt.py $O/kt 0.25 > $O/kt_gantt.txt 2>&1
+python3 tools/trace_window.py $O/kt ${WIN_K:-10} ${WIN_BEFORE:-50} 35 0.2 > $O/kt_boundary.txt 2>&1
+python3 tools/trace_union.py $O/kt auto > $O/kt_union.txt 2>&1
+find $O -name "*kernel_trace.csv" -delete
+find $O -name "*.csv" -size +20M -delete
