@@ -676,6 +676,12 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
     comm_dev = dev if args.backend == 'nccl' else None
+    # the witness all-gather gets a process group (= RCCL communicator and stream) of its own: issued on the default group it would sit in
+    # front of the running proof's all-to-alls in that communicator's queue and hold them back until the next witness has arrived
+    wit_group = None
+    if multi and world > 1:
+        import torch.distributed as dist
+        wit_group = dist.new_group(ranks=list(range(world)), backend=args.backend)
     ctx = fk.Context(local_rank)
 
     # ---------------------------------------------------------------- wall-clock plan of the optional legs (every rank decides alike)
@@ -835,7 +841,7 @@ def main():
         if not multi:
             state['ticket'] = ctx.prove_witness_submit(key, dr, z_pin[0], r, s)
         else:
-            state['wit'] = parallel.witness_all_gather(ctx, 0, z_pin[0], rank, world, device=comm_dev)
+            state['wit'] = parallel.witness_all_gather(ctx, 0, z_pin[0], rank, world, group=wit_group, device=comm_dev)
         state['i'] = 0
 
     def step():
@@ -847,7 +853,7 @@ def main():
             return proof
         # every rank evaluates the full constraint system, so every rank needs all of z: each uploads 1 / N of it over its own PCIe link and
         # the ranks all-gather the pieces over xGMI (RCCL) on the library's copy stream, underneath this proof
-        state['wit'] = parallel.witness_all_gather(ctx, (i + 1) & 1, z_pin[(i + 1) & 1], rank, world, device=comm_dev)
+        state['wit'] = parallel.witness_all_gather(ctx, (i + 1) & 1, z_pin[(i + 1) & 1], rank, world, group=wit_group, device=comm_dev)
         return prove_multi(ctx.witness_ptr(i & 1))
 
     def drain():

@@ -99,8 +99,6 @@ struct fk_ctx {
     fk::DevBuf misc;
     // witness multiplications (L, A, B1, B2) in flight: begun before / while the quotient runs on the main stream
     hipStream_t aux = nullptr;          // scalar compaction for the A / B queries
-    hipStream_t tail_st = nullptr;      // high-priority stream for the G2 multiplication's tail (msm.hip: back_tail); nullptr: the tail stays on its lane
-    hipEvent_t ev_tail_in = nullptr;
     hipEvent_t ev_aux = nullptr, ev_main = nullptr, ev_z = nullptr;
     // sorts-first schedule (prover.hip): with defer_back set, msm_begin queues only the front of a multiplication (digits, sort,
     // size ordering) and leaves the rest (accumulation, oversized buckets, reduction, download) here, to be queued by

@@ -415,10 +415,18 @@ static int gates_decode(fk_ctx *ctx, const uint8_t *blob, size_t len, int format
     g->num_input = num_input; g->num_aux = num_aux; g->num_gates = num_gates;
     auto fail = [&](int code, const std::string &msg) { ctx->err = "gates: " + msg; return code; };
     // num_gates comes straight from a file header: address space for what it promises (PROT_NONE: free), memory only for what arrives
-    const size_t TERM_SPACE = (size_t)1 << 38;          // 2^36 terms per matrix
+    // (2^36 terms per matrix; a process with a small address-space limit -- ulimit -v -- gets what it can reserve, down to 2^22 terms, and a
+    // stream that outgrows it is FK_ERR_OOM when it does; a raw stream says how many terms it can hold at most)
+    size_t term_space = (size_t)1 << 38;
+    if (format == FK_GATES_RAW) term_space = std::min(term_space, std::max<size_t>(len / 37 * 4 + 64, (size_t)1 << 20));
+    for (;;) {
+        bool ok = true;
+        for (int k = 0; k < 3 && ok; k++) ok = g->ptr[k].reserve(((size_t)num_gates + 1) * 8) && g->col[k].reserve(term_space) && g->cidx[k].reserve(term_space);
+        if (ok) break;
+        if (term_space <= ((size_t)1 << 24)) return fail(FK_ERR_OOM, "cannot reserve address space for the constraint system");
+        term_space >>= 2;
+    }
     for (int k = 0; k < 3; k++) {
-        if (!g->ptr[k].reserve(((size_t)num_gates + 1) * 8) || !g->col[k].reserve(TERM_SPACE) || !g->cidx[k].reserve(TERM_SPACE))
-            return fail(FK_ERR_OOM, "cannot reserve address space for the constraint system");
         if (!g->ptr[k].commit(8)) return fail(FK_ERR_OOM, "out of host memory");
         g->ptr[k].as<uint64_t>()[0] = 0;
     }
@@ -453,7 +461,7 @@ static int gates_decode(fk_ctx *ctx, const uint8_t *blob, size_t len, int format
         if (!sc.blk_gates) return true;
         for (int k = 0; k < 3; k++) {
             if (!g->ptr[k].commit((first_gate + sc.blk_gates + 1) * 8) || !g->col[k].commit((off[k] + sc.blk_nnz[k]) * 4 + 4) || !g->cidx[k].commit((off[k] + sc.blk_nnz[k]) * 4 + 4)) {
-                rc = FK_ERR_OOM; msg = "out of host memory while decoding the gate stream"; return false;
+                rc = FK_ERR_OOM; msg = "out of host memory (or of the address space this process may reserve) while decoding the gate stream"; return false;
             }
         }
         if (seq >= ((uint64_t)1 << 27)) { rc = FK_ERR_FORMAT; msg = "gate stream too long"; return false; }

@@ -1022,17 +1022,6 @@ int streams_init(fk_ctx *ctx) {
         FK_HIP(ctx, hipEventCreateWithFlags(&ln.ev_in, hipEventDisableTiming));
         FK_HIP(ctx, hipEventCreateWithFlags(&ln.ev_sorted, hipEventDisableTiming));
     }
-    // The G2 multiplication's tail -- oversized buckets, fold, bucket reduction: 7 ms of work -- is queued behind its accumulation while H's
-    // accumulation (all registers of every compute unit) is running: on its lane's stream it took 29 + 1 + 5 ms and ended AFTER H, the
-    // last thing of the proof.  On a stream of HIGH priority its workgroups are placed first whenever H's leave a slot.
-    // FK_G2_TAIL_PRIORITY=0 keeps it on the lane.
-    { const char *e = getenv("FK_G2_TAIL_PRIORITY");
-      if (!(e && e[0] == '0') && !ctx->tail_st) {
-          int least = 0, greatest = 0;
-          FK_HIP(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
-          FK_HIP(ctx, hipStreamCreateWithPriority(&ctx->tail_st, hipStreamNonBlocking, greatest));
-          FK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_tail_in, hipEventDisableTiming));
-      } }
     return FK_OK;
 }
 
@@ -1244,11 +1233,6 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
     auto back_tail = [=]() -> int {
         MsmLane &ln = *lnp; MsmTail &tl = *tlp;
         Xyzz<F> *buckets = bucket_buf();
-        // G2: the tail moves to the high-priority stream (behind the lane's accumulation; the lane goes on behind the tail)
-        const bool prio = !IS_G1 && ctx->tail_st != nullptr;
-        hipStream_t lane_st = st;
-        hipStream_t st = prio ? ctx->tail_st : lane_st;
-        if (prio) { FK_HIP(ctx, hipEventRecord(ctx->ev_tail_in, lane_st)); FK_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_tail_in, 0)); }
         // oversized buckets: fixed grids looping over the device-built tables (they leave at once when there is nothing to do)
         if (lazy) hipLaunchKernelGGL(HIP_KERNEL_NAME(msm_overflow_kernel<F, FC, 2>), dim3(2048), dim3(64), 0, st,
                                           d_bases, d_lev, sorted, n, starts, totals, p.B, dyn, d_tasks, ln.partials.as<Xyzz<FC>>());
@@ -1272,7 +1256,6 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
         FK_HIP(ctx, hipMemcpyAsync((char *)tl.h_wp + wp_bytes, d_adds, 8, hipMemcpyDeviceToHost, st));
         FK_HIP(ctx, hipMemcpyAsync((char *)tl.h_wp + wp_bytes + 8, &dyn->error, 4, hipMemcpyDeviceToHost, st));
         FK_HIP(ctx, hipEventRecord(tl.done, st));
-        if (prio) FK_HIP(ctx, hipStreamWaitEvent(lane_st, tl.done, 0));       // whatever is queued on the lane next may reuse the buffers the tail reads
         FK_DBG_ST(ctx, st, "msm_bucket_reduce");
         return FK_OK;
     };
@@ -1324,7 +1307,6 @@ static int msm_end(fk_ctx *ctx, int tail, Xyzz<F> *out) {
 
 int msm_sync(fk_ctx *ctx) {
     if (ctx->aux) FK_HIP(ctx, hipStreamSynchronize(ctx->aux));
-    if (ctx->tail_st) FK_HIP(ctx, hipStreamSynchronize(ctx->tail_st));
     for (MsmLane &ln : ctx->lanes) if (ln.st) FK_HIP(ctx, hipStreamSynchronize(ln.st));
     return FK_OK;
 }
@@ -1334,15 +1316,12 @@ void msm_abandon(fk_ctx *ctx) {
     ctx->early.done = false;
     ctx->defer_back = false; ctx->deferred.clear(); ctx->deferred_tails.clear();
     if (ctx->aux) (void)hipStreamSynchronize(ctx->aux);
-    if (ctx->tail_st) (void)hipStreamSynchronize(ctx->tail_st);
     for (int i = 0; i < MSM_TAILS; i++) ctx->tails[i].active = false;
     for (MsmLane &ln : ctx->lanes) { if (ln.st) (void)hipStreamSynchronize(ln.st); ln.last_sort_scalars = nullptr; }
 }
 
 void msm_release(fk_ctx *ctx) {
     if (ctx->aux) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamDestroy(ctx->aux); ctx->aux = nullptr; }
-    if (ctx->tail_st) { (void)hipStreamSynchronize(ctx->tail_st); (void)hipStreamDestroy(ctx->tail_st); ctx->tail_st = nullptr; }
-    if (ctx->ev_tail_in) { (void)hipEventDestroy(ctx->ev_tail_in); ctx->ev_tail_in = nullptr; }
     if (ctx->ev_aux) { (void)hipEventDestroy(ctx->ev_aux); ctx->ev_aux = nullptr; }
     if (ctx->ev_main) { (void)hipEventDestroy(ctx->ev_main); ctx->ev_main = nullptr; }
     if (ctx->ev_z) { (void)hipEventDestroy(ctx->ev_z); ctx->ev_z = nullptr; }

@@ -121,10 +121,23 @@ def main():
         # exchanges: 7 per proof, each rank sends (W - 1) / W of its L * 32 bytes, one chunk per peer, every peer on a link of its own
         chunk = L * 32 // W
         t_x = 7 * (chunk / (XGMI_GBPS_PER_LINK_PER_DIRECTION * 1e9)) * 1e3 if (W > 1 and not q0) else 0.0
-        out['ranks'][str(W)] = dict(worst, split=args.split if W > 1 else None, per_rank=per_rank, witness_upload_bytes_per_rank=int(z.nbytes),
+        # the witness (round 5): a rank uploads ceil(nv / W) elements over its own PCIe link (~50 GB/s pinned) and collects the other W - 1
+        # pieces from its peers, one piece per link, all links at once -- both underneath the PREVIOUS proof, so they bound the rate only
+        # where they exceed a rank's compute share.  (Rounds 3-4: every rank uploaded all of z out of the same pinned host buffer.)
+        piece = -(-z.shape[0] // W) * 32
+        t_up = piece / 50e9 * 1e3
+        t_ag = (piece / (XGMI_GBPS_PER_LINK_PER_DIRECTION * 1e9)) * 1e3 if W > 1 else 0.0
+        out['ranks'][str(W)] = dict(worst, split=args.split if W > 1 else None, per_rank=per_rank, witness_upload_bytes_per_rank=int(piece),
+                                    witness_upload_bytes_per_rank_rounds_3_4=int(z.nbytes), witness_all_gather_bytes_into_each_rank=int(piece * (W - 1)),
+                                    witness_upload_ms_at_50GBps=t_up, witness_all_gather_ms_by_link_arithmetic=t_ag,
+                                    host_read_GBps_for_uploads_at_this_rate=(z.nbytes / 1e9) / (worst['whole_share_ms'] / 1e3),
+                                    host_read_GBps_rounds_3_4=(W * z.nbytes / 1e9) / (worst['whole_share_ms'] / 1e3),
                                     exchange_bytes_per_rank_per_proof=7 * chunk * (W - 1), exchange_ms_by_link_arithmetic=t_x)
         print('W = %d (%s split): slowest rank %d: eval %.2f ms, quotient %.2f ms, MSMs %.2f ms, whole share %.2f ms; exchanges %.2f ms by link arithmetic'
               % (W, args.split if W > 1 else '-', worst['rank'], worst['eval_slice_ms'], worst['quotient_compute_ms'], worst['msms_ms'], worst['whole_share_ms'], t_x), flush=True)
+        print('        witness: %.0f MB per rank over PCIe (%.1f ms at 50 GB/s; rounds 3-4: %.0f MB), all-gather of %.0f MB into every rank (%.1f ms by link arithmetic), '
+              'both underneath the previous proof; host buffer read at %.0f GB/s in all (rounds 3-4: %.0f GB/s)'
+              % (piece / 1e6, t_up, z.nbytes / 1e6, piece * (W - 1) / 1e6, t_ag, (z.nbytes / 1e9) / (worst['whole_share_ms'] / 1e3), (W * z.nbytes / 1e9) / (worst['whole_share_ms'] / 1e3)), flush=True)
         if len(per_rank) > 1:
             print('        per rank (whole share ms / points l, a, b_g1, b_g2): ' + '; '.join(
                 '%d: %.1f / %s' % (e['rank'], e['whole_share_ms'], ','.join('%.1fM' % (e['points'][k_] / 1e6) for k_ in ('l', 'a', 'b', 'b_g2'))) for e in per_rank), flush=True)
