@@ -14,11 +14,16 @@ witness already resident in HBM is reported beside it (`device_resident_ms_per_s
 Default workload (`--workload rollup1024 --copies 1741`): BASELINE configs[3]'s "1024-tx shape" with real gadgets, sized so
 that it FILLS the 2^25 domain the metric names (rows = 2^25) -- 1741 rollup-style transactions (two
 depth-32 poseidon merkle proofs + one eddsa-poseidon signature each, 19 270 gates and 942 k matrix terms per transaction) as
-ONE R1CS of 33 552 553 rows (99.99 % of 2^25) / 1.64e9 matrix terms through fk_setup_tiled / fk_r1cs_load_tiled.  (Rounds 2-3
-benchmarked 1024 of them: 19.7 M rows, the same domain 59 % filled -- kept as the `secondary_1024_transactions` leg; the
-`reference_published` leg is 1853 transactions = 35.7 M rows on the 2^26 domain, the size of the reference's one published
-figure, README.md:54-56.)  The transaction comes from the committed data fixture tests/golden/rollup_tx_instance.npz (made by
-tests/golden/make_rollup_tx_fixture.py; the circuit builder itself is oracle-side and is NOT imported here).
+ONE R1CS of 33 552 553 rows (99.99 % of 2^25) / 1.64e9 matrix terms.  Since round 5 the prover receives it in the REFERENCE'S OWN INPUT
+FORM: the generated key and the circuit are written as a `Parameters` image (mod.rs:150-175: brotli gate blob + bellman key;
+fk_gates_encode + fk_key_write_bellman), everything is dropped, and the prover is set up from the image alone -- fk_gates_decode ->
+fk_r1cs_load_gates (every term explicit in HBM) beside fk_key_load_bellman(checked) -- and `value` is measured on THAT system (`load`:
+what the set-up cost; `--tiled-headline`: rounds 1-4's arrangement, `value` on fk_r1cs_load_tiled = one instance + a copy count, now
+the `tiled` leg).  (Rounds 2-3 benchmarked 1024 transactions: 19.7 M rows, the same domain 59 % filled -- kept as the
+`secondary_1024_transactions` leg; the `reference_published` leg is 1853 transactions = 35.7 M rows on the 2^26 domain, the size of
+the reference's one published figure, README.md:54-56.)  The transaction comes from the committed data fixture
+tests/golden/rollup_tx_instance.npz (made by tests/golden/make_rollup_tx_fixture.py; the circuit builder itself is oracle-side and
+is NOT imported here).
 `--workload synthetic` is the round-1 shape (1-2 term rows, m = 2^LOG2 exactly; `--lc-terms` for longer combinations).
 The key is a VALID key (fk_setup*, fixed toxic waste), so the proof produced in the timed region is checked afterwards
 with the Groth16 pairing equation.
@@ -28,7 +33,8 @@ with the Groth16 pairing equation.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-N > 1: one process per GPU, strong scaling of a single proof: every rank holds its piece of the key (h in blocks of the domain; l, a, b_g1,
+N > 1: one process per GPU, strong scaling of a single proof: every rank hands over 1 / N of the witness over its own PCIe link and the ranks
+all-gather the rest over xGMI (RCCL, parallel.witness_all_gather) underneath the proof before; every rank holds its piece of the key (h in blocks of the domain; l, a, b_g1,
 b_g2 dealt by work: one or two large pieces per rank),
 evaluates only the rows t = rank (mod N) of a, b, c and computes 1/N of the quotient -- the transforms are cut across the
 ranks with one all-to-all (RCCL over xGMI) each -- then ONE all-gather of 384 bytes per rank exchanges the partial MSM sums and
@@ -39,8 +45,10 @@ of the same proof (`single_process_multi_gpu`: fk_init_devices + fk_multi_prove_
 inside the library) and the throughput mode (`replica_proofs_per_sec`).
 
 Beside `value` (N = 1): `cpu_baseline` MEASURED at the benchmarked size when the projection from a sample fits --cpu-full-budget
-(the C oracle proves the same 2^25 system; its bytes must equal the GPU's), `standalone` (G1 / G2 MSM and Fr NTT timed alone,
-SURVEY 8(d) units), `untiled` (the same circuit with every matrix term explicit in HBM, fk_r1cs_load_coded).
+(the C oracle proves the same 2^25 system; its bytes must equal the GPU's), `load` (the Parameters image: blob bytes, decode seconds and
+what bounds them, host RSS peak, checked key read, levels, time to first proof), `tiled` (the same circuit as one instance + a copy count:
+same key, same bytes), `witness_sensitivity` (a witness with every dense value distinct: timing only), `standalone` (G1 / G2 MSM and Fr NTT
+timed alone, SURVEY 8(d) units), `legs` (seconds per optional leg; --max-seconds skips what would not fit and says so).
 
 The CPU oracle (oracle/) appears here only in the `cpu_baseline` leg: the timed CPU baseline (one thread = the
 reference's configured worker, and all host cores = bellman's multicore split), a live parity check of that same
@@ -666,7 +674,8 @@ def main():
     dev = torch.device('cuda', local_rank)
     # FK_BENCH_REHEARSE=1 with --gpus 1: run the multi-GPU code path (process group, all-to-all, all-gather, distributed
     # quotient with one rank) on a single GPU -- a rehearsal of the N > 1 plumbing over real RCCL, not a benchmark mode
-    multi = world > 1 or os.environ.get('FK_BENCH_REHEARSE') == '1'
+    rehearse = os.environ.get('FK_BENCH_REHEARSE') == '1'
+    multi = world > 1 or rehearse
     if multi:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -679,7 +688,7 @@ def main():
     # the witness all-gather gets a process group (= RCCL communicator and stream) of its own: issued on the default group it would sit in
     # front of the running proof's all-to-alls in that communicator's queue and hold them back until the next witness has arrived
     wit_group = None
-    if multi and world > 1:
+    if multi and (world > 1 or rehearse):
         import torch.distributed as dist
         wit_group = dist.new_group(ranks=list(range(world)), backend=args.backend)
     ctx = fk.Context(local_rank)
@@ -786,8 +795,9 @@ def main():
         rss_after = host_rss()
         load_block = {
             'is': 'the prover set up from a `Parameters` image alone (mod.rs:150-175): gate blob -> fk_gates_decode (one decompressing thread = the serial '
-                  'floor of a brotli stream; parsing, range checks, coefficient dictionary and density flags on the other host threads) -> '
-                  'fk_r1cs_load_gates; bellman part -> fk_key_load_bellman(checked: every point on its curve, G2 in the subgroup) -> fixed-base levels',
+                  'floor of a brotli stream; parsing, range checks, coefficient dictionary and density flags on the other host threads) WHILE the bellman part '
+                  'goes through fk_key_load_bellman(checked: every point on its curve, G2 in the subgroup) on the GPU; then fk_r1cs_load_gates, then the '
+                  'fixed-base levels (fk_key_derive_levels: sized against the HBM left beside the resident system)',
             'image_bytes': int(image.nbytes), 'blob_bytes': tm_w['blob_bytes'], 'bellman_bytes': tm_w['bellman_bytes'],
             'blob': 'brotli quality %d, lgwin 22 (setup.rs:26 writes quality 9, lgwin 22; the decoder does not care)' % args.blob_quality,
             'gate_stream_bytes': gp and int(p_hdr['gates_info']['decoded_bytes']), 'gates': int(p_hdr['gates_info']['num_gates']),
@@ -841,7 +851,7 @@ def main():
         if not multi:
             state['ticket'] = ctx.prove_witness_submit(key, dr, z_pin[0], r, s)
         else:
-            state['wit'] = parallel.witness_all_gather(ctx, 0, z_pin[0], rank, world, group=wit_group, device=comm_dev)
+            state['wit'] = parallel.witness_all_gather(ctx, 0, z_pin[0], rank, world, group=wit_group, device=comm_dev, force_collective=rehearse)
         state['i'] = 0
 
     def step():
@@ -853,7 +863,7 @@ def main():
             return proof
         # every rank evaluates the full constraint system, so every rank needs all of z: each uploads 1 / N of it over its own PCIe link and
         # the ranks all-gather the pieces over xGMI (RCCL) on the library's copy stream, underneath this proof
-        state['wit'] = parallel.witness_all_gather(ctx, (i + 1) & 1, z_pin[(i + 1) & 1], rank, world, group=wit_group, device=comm_dev)
+        state['wit'] = parallel.witness_all_gather(ctx, (i + 1) & 1, z_pin[(i + 1) & 1], rank, world, group=wit_group, device=comm_dev, force_collective=rehearse)
         return prove_multi(ctx.witness_ptr(i & 1))
 
     def drain():

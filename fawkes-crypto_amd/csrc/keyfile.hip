@@ -139,7 +139,7 @@ int fk_key_load_bellman(fk_ctx *ctx, const uint8_t *buf, size_t len, uint32_t fl
                         double z_frac_hi, fk_key **out, uint8_t *gamma_g2_out, uint8_t *ic_out, uint32_t ic_cap, uint32_t *n_ic) { return fk_guard(ctx, [&]() -> int {
     if (!ctx) return FK_ERR_BAD_ARG;
     if (!buf || !out) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "key file: null argument");
-    if (flags & ~(uint32_t)(FK_KEY_CHECKED | FK_KEY_NO_INFINITY)) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "key file: unknown flags 0x%x", flags);
+    if (flags & ~(uint32_t)(FK_KEY_CHECKED | FK_KEY_NO_INFINITY | FK_KEY_NO_LEVELS)) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "key file: unknown flags 0x%x", flags);
     *out = nullptr;
     FK_HIP(ctx, hipSetDevice(ctx->device));
     const auto t_start = std::chrono::steady_clock::now();
@@ -179,8 +179,8 @@ int fk_key_load_bellman(fk_ctx *ctx, const uint8_t *buf, size_t len, uint32_t fl
             const size_t cn = (size_t)((n - off) < CH ? (n - off) : CH);
             if (ctx->misc.reserve(cn * width) != hipSuccess) return FK_ERR_OOM;
             if (hipMemcpyAsync(ctx->misc.p, src + (lo + off) * width, cn * width, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return FK_ERR_HIP;
-            if (width == 64) hipLaunchKernelGGL(convert_g1_kernel, dim3((unsigned)((cn + 255) / 256)), dim3(256), 0, ctx->stream, ctx->misc.as<uint8_t>(), cn, (Affine<FqC> *)*dst + off, flags, d_bad);
-            else hipLaunchKernelGGL(convert_g2_kernel, dim3((unsigned)((cn + 127) / 128)), dim3(128), 0, ctx->stream, ctx->misc.as<uint8_t>(), cn, (Affine<Fq2C> *)*dst + off, flags, d_bad);
+            if (width == 64) hipLaunchKernelGGL(convert_g1_kernel, dim3((unsigned)((cn + 255) / 256)), dim3(256), 0, ctx->stream, ctx->misc.as<uint8_t>(), cn, (Affine<FqC> *)*dst + off, flags & (FK_KEY_CHECKED | FK_KEY_NO_INFINITY), d_bad);
+            else hipLaunchKernelGGL(convert_g2_kernel, dim3((unsigned)((cn + 127) / 128)), dim3(128), 0, ctx->stream, ctx->misc.as<uint8_t>(), cn, (Affine<Fq2C> *)*dst + off, flags & (FK_KEY_CHECKED | FK_KEY_NO_INFINITY), d_bad);
             if (hipStreamSynchronize(ctx->stream) != hipSuccess) return FK_ERR_HIP;   // misc is reused by the next chunk
         }
         return FK_OK;
@@ -238,7 +238,7 @@ int fk_key_load_bellman(fk_ctx *ctx, const uint8_t *buf, size_t len, uint32_t fl
     if (n_ic) *n_ic = cnt[0];
     if (ic_out) memcpy(ic_out, ic.data(), (size_t)(cnt[0] < ic_cap ? cnt[0] : ic_cap) * 64);
     const auto t_arrays = std::chrono::steady_clock::now();
-    if ((rc = key_precompute(ctx, k)) != FK_OK) { fk_key_free(ctx, k); return rc; }
+    if (!(flags & FK_KEY_NO_LEVELS) && (rc = key_precompute(ctx, k)) != FK_OK) { fk_key_free(ctx, k); return rc; }
     k->load_s[0] = std::chrono::duration<double>(t_arrays - t_start).count();
     k->load_s[1] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_arrays).count();
     *out = k;

@@ -400,6 +400,20 @@ int fk_key_levels_plan(const fk_key *k, double out[15]) {
     return FK_OK;
 }
 
+// (Re)derives the fixed-base levels of a loaded key against the HBM that is free NOW: for a key loaded with FK_KEY_NO_LEVELS while something else
+// was still to be placed in HBM (params_io.load_parameters reads the key while the gate blob is being decoded on the host, uploads the
+// constraint system, then calls this), or after memory has been freed.  Not while proofs with this key are in flight.
+int fk_key_derive_levels(fk_ctx *ctx, fk_key *k) { return fk_guard(ctx, [&]() -> int {
+    if (!ctx || !k) return FK_ERR_BAD_ARG;
+    FK_HIP(ctx, hipSetDevice(ctx->device));
+    FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    FK_TRY(msm_sync(ctx));
+    const auto t0 = std::chrono::steady_clock::now();
+    FK_TRY(key_precompute(ctx, k));
+    k->load_s[1] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return FK_OK;
+}); }
+
 int fk_key_load_profile(const fk_key *k, double out[2]) {
     if (!k || !out) return FK_ERR_BAD_ARG;
     out[0] = k->load_s[0]; out[1] = k->load_s[1];

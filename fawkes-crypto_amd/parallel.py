@@ -82,7 +82,7 @@ class _DevBytes:
         self.__cuda_array_interface__ = {'shape': (int(nbytes),), 'typestr': '|u1', 'data': (int(ptr), False), 'version': 2, 'strides': None}
 
 
-def witness_all_gather(ctx, slot, z_host, rank, world, group=None, device=None):
+def witness_all_gather(ctx, slot, z_host, rank, world, group=None, device=None, force_collective=False):
     """Hands the witness of the next proof to ALL ranks with ONE trip over PCIe: this rank uploads only its piece (1 / world of
     `z_host`, pinned memory, over its own link) into witness slot `slot` and the ranks exchange the pieces with an all-gather IN PLACE in
     the slot -- `dist.all_gather_into_tensor` over RCCL / xGMI, issued on the library's copy stream so that it runs underneath the proof
@@ -93,7 +93,7 @@ def witness_all_gather(ctx, slot, z_host, rank, world, group=None, device=None):
     import torch.distributed as dist
     z = z_host.reshape(-1, 4)
     nv = z.shape[0]
-    if world == 1:
+    if world == 1 and not force_collective:          # (force_collective: a one-rank rehearsal of the slot / copy-stream / in-place collective plumbing over real RCCL)
         ctx.witness_upload_async(slot, z)
         return dict(pcie_bytes=z.nbytes, gathered_bytes=0)
     c, pieces = witness_pieces(nv, world)

@@ -160,6 +160,8 @@ int fk_key_precomputed(const fk_key *key, uint32_t out[5]);
  * is FK_G2_WORK G1 points of work at twice the bytes).  out[15] = per array h, l, a, b_g1, b_g2: levels held, GiB of levels (negative: the
  * GiB the array WOULD need -- it was left out), estimated ms per proof saved. */
 int fk_key_levels_plan(const fk_key *key, double out[15]);
+/* (re)derives the fixed-base levels against the HBM that is free now (a key loaded with FK_KEY_NO_LEVELS; or after memory was freed) */
+int fk_key_derive_levels(fk_ctx *ctx, fk_key *key);
 /* what loading the key cost: out[0] = seconds for the arrays themselves (transfer + conversion + the checks of fk_key_load_bellman, or
  * the derivation of fk_setup*), out[1] = seconds for the fixed-base levels */
 int fk_key_load_profile(const fk_key *key, double out[2]);
@@ -436,6 +438,8 @@ int fk_key_download(fk_ctx *ctx, const fk_key *key, int which, void *host, size_
  * violation is FK_ERR_FORMAT (bellman: io::Error from GroupDecodingError) with the counts in fk_last_error. */
 #define FK_KEY_CHECKED 1u       /* `checked`: every point on its curve, G2 points in the order-r subgroup (checked on the GPU) */
 #define FK_KEY_NO_INFINITY 2u   /* `disallow_points_at_infinity`: no identity point in h, l, a, b_g1, b_g2 */
+#define FK_KEY_NO_LEVELS 4u     /* do not derive the fixed-base levels now: the caller calls fk_key_derive_levels once everything else it
+                                 * wants in HBM (a resident constraint system) has been placed */
 int fk_key_load_bellman(fk_ctx *ctx, const uint8_t *buf, size_t len, uint32_t flags, uint32_t shard_index, uint32_t shard_count,
                         double z_frac_lo, double z_frac_hi, fk_key **out, uint8_t *gamma_g2_out, uint8_t *ic_out,
                         uint32_t ic_cap, uint32_t *n_ic);

@@ -90,7 +90,7 @@ def traffic(fetch_dir, write_dir, log2n, points, out, proofs=None, workload='syn
     proofs = derived
     corr, corr_all = gather_correction(gcal_dir)
     j = dict(
-        workload=workload, fetch_size_calibration=corr_all,
+        workload=workload, workload_is=('bench.py --workload %s%s: the pass is matched to a bench line by this name, the domain AND the row count' % (workload, (' (%d rows)' % int(rows)) if rows else '')), fetch_size_calibration=corr_all,
         _doc='rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python3 bench.py --steps 1 --warmup 0 '
              '--no-cpu-baseline` (2^%d rows).  Counter units: KB (x1024 = bytes), summed over the launches of the whole pass (per_kernel); '
              'dominant_kernel is per proof.' % log2n,

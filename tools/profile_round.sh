@@ -3,7 +3,7 @@
 # Usage: bash tools/profile_round.sh [tag] [notest]      -> gpurun_out/<tag>/   (copy what is to be judged into profiles/)
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-TAG=${1:-r04}; O=gpurun_out/$TAG; mkdir -p $O
+TAG=${1:-r05}; O=gpurun_out/$TAG; mkdir -p $O
 # the profiled legs prove ONE system only (the default one): every proof in a pass has the same size, so the number of proofs in a
 # pass follows from its dispatch counts (tools/pmc_summary.py derives and cross-checks it)
 B="bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-untiled --no-standalone --no-other-sizes"
@@ -31,6 +31,8 @@ subprocess.check_call([sys.executable, 'tools/pmc_summary.py', 'valu', O + '/sq'
 PY
 # the kernel trace itself is tens of MB: keep the statistics, compute the busy fraction first
 python3 tools/trace_busy.py $O/kt > $O/kt_busy.txt 2>&1; cat $O/kt_busy.txt
+# (the last evaluations of the traced run belong to its one-proof-at-a-time legs: the 14th last one lies in the pipelined loop)
+python3 tools/trace_window.py $O/kt ${WIN_K:-14} ${WIN_BEFORE:-50} 40 0.2 > $O/kt_boundary.txt 2>&1
 python3 tools/trace_union.py $O/kt auto > $O/kt_union.txt 2>&1; python3 tools/trace_gantt.py $O/kt 0.25 > $O/kt_gantt.txt 2>&1
 find $O -name "*kernel_trace.csv" -delete
 find $O -name "*.csv" -size +20M -delete
