@@ -48,6 +48,28 @@ def test_parameters_image_2p20_rows_proof_equals_the_oracle(ctx, oracle):
     key, dr, vk, z, r, s, tiled_proof, _ = _image_roundtrip(ctx, inst, zs, 6, 9, bench)
     assert ctx.prove_witness(key, dr, z, r, s).tobytes() == tiled_proof
     key.free(); dr.free()
+    # FK_KEY_NO_LEVELS + fk_key_derive_levels (how load_parameters reads the key while the blob is being decoded): the key proves the same bytes
+    # without levels, and after the levels are derived it carries exactly the plan of a key loaded in one go
+    import os
+    from fawkes_crypto_amd import api, params_io as pio
+    os.environ['FK_MSM_PRE_MIN_LOG2'] = '8'                  # (read at every key load: levels on this small key too)
+    try:
+        tox = {k: bench.mont(v) for k, v in bench.TOXIC.items()}
+        key0, vk0 = ctx.setup(inst, copies=6, **tox)
+        dr0 = ctx.load_r1cs(inst, copies=6)
+        bell = ctx.write_key_bellman(key0, vk0)
+        want_plan = key0.levels_plan()
+        assert any(v['levels'] for v in want_plan.values())
+        key0.free()
+        k1, _, _ = ctx.load_key_bellman(bell, flags=api.FK_KEY_CHECKED | api.FK_KEY_NO_LEVELS)
+        assert not any(k1.precomputed().values())
+        assert ctx.prove_witness(k1, dr0, z, r, s).tobytes() == tiled_proof
+        k1.derive_levels()
+        assert k1.levels_plan() == want_plan and k1.load_profile()['levels_s'] > 0
+        assert ctx.prove_witness(k1, dr0, z, r, s).tobytes() == tiled_proof
+        k1.free(); dr0.free()
+    finally:
+        del os.environ['FK_MSM_PRE_MIN_LOG2']
     copies = 40
     key, dr, vk, z, r, s, tiled_proof, tm = _image_roundtrip(ctx, inst, zs, copies, 5, bench)
     try:
