@@ -265,8 +265,18 @@ def prove_variant(ctx, rnd, v, cs, key, params, toxm, z, r, s, abc, want):
             arrays = dict(alpha_g1=key.alpha_g1, beta_g1=key.beta_g1, beta_g2=key.beta_g2, gamma_g2=key.gamma_g2, delta_g1=key.delta_g1,
                           delta_g2=key.delta_g2, ic=np.array(key.ic), h=np.array(key.h), l=np.array(key.l), a=np.array(key.a),
                           b_g1=np.array(key.b_g1), b_g2=np.array(key.b_g2))
-            data = params_io.store_parameters(arrays, params.r1cs, const_tracker_bits=[rnd.random() < 0.5 for _ in range(rnd.randrange(0, 9))])
-            dk, dr, _ = params_io.load_parameters(ctx, data, shard_index=0, shard_count=1)
+            bits = [rnd.random() < 0.5 for _ in range(rnd.randrange(0, 9))]
+            how = rnd.randrange(3)
+            os.environ['FK_HOST_THREADS'] = str(rnd.choice([1, 2, 3, 5, 16]))          # (read per call: the gate codec's thread count)
+            if how == 0:                # the raw stream, written by the per-term Python restatement
+                data = params_io.store_parameters(arrays, params.r1cs, const_tracker_bits=bits)
+            else:                       # the native encoder (round 5): brotli at a random setting, or its raw stream
+                gb = fk.api.GateBlob(params.r1cs, None, fmt=fk.api.FK_GATES_BROTLI if how == 1 else fk.api.FK_GATES_RAW, quality=rnd.choice([0, 1, 5, 9, 11]), lgwin=rnd.choice([10, 16, 22, 24]))
+                blob = gb.data.tobytes() if how == 1 else params_io.RAW_MAGIC + gb.data.tobytes()
+                gb.free()
+                data = params_io.write_parameters(params.r1cs.num_gates, blob, bits, params_io.encode_bellman_parameters(arrays))
+            dk, dr, _ = params_io.load_parameters(ctx, data, shard_index=0, shard_count=1, overlap=rnd.random() < 0.7)
+            del os.environ['FK_HOST_THREADS']
             got = ctx.prove_witness(dk, dr, z, r, s).tobytes()
             dr.free(); dk.free()
     return got
