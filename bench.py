@@ -670,6 +670,7 @@ def main():
     from fawkes_crypto_amd import parallel
     if os.environ.get('FK_BENCH_SAME_DEVICE') == '1':
         local_rank = 0                      # dry run: all ranks share GPU 0 (needs --backend gloo)
+        os.environ.setdefault('FK_CO_TENANTS', str(world))
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     # FK_BENCH_REHEARSE=1 with --gpus 1: run the multi-GPU code path (process group, all-to-all, all-gather, distributed
@@ -763,9 +764,19 @@ def main():
     # work line), the other ranks hold witness pieces only: no h slices travel.  FK_MULTI_SPLIT=equal: the fraction split of rounds 1-3.
     q0_split = world > 1 and not dist_q and os.environ.get('FK_MULTI_SPLIT') != 'equal'
     tox = {k: mont(v) for k, v in TOXIC.items()}
-    key, vk = ctx.setup(r1cs, shard_index=rank, shard_count=world, copies=copies,
-                        z_frac=fk.api.Z_WORK_SPLIT_Q0 if q0_split else fracs[rank] if (world > 1 and not dist_q) else
-                        (fk.api.Z_WORK_SPLIT if (world > 1 and os.environ.get('FK_MULTI_SPLIT') != 'equal') else fk.api.Z_EQUAL_SPLIT), **tox)
+    # FK_BENCH_SAME_DEVICE=1 (rehearsal: every rank-process on ONE GPU): the processes cannot see each other's plans, so the keys are set up one
+    # rank after the other (each loader sizes its fixed-base levels against the HBM the earlier ranks left) and every context is told how many
+    # tenants share the device (FK_CO_TENANTS, read by fk_init: what a proof will allocate later is reserved that many times)
+    same_dev_turns = world if (world > 1 and os.environ.get('FK_BENCH_SAME_DEVICE') == '1') else 1
+    for turn in range(same_dev_turns):
+        if same_dev_turns == 1 or turn == rank:
+            key, vk = ctx.setup(r1cs, shard_index=rank, shard_count=world, copies=copies,
+                                z_frac=fk.api.Z_WORK_SPLIT_Q0 if q0_split else fracs[rank] if (world > 1 and not dist_q) else
+                                (fk.api.Z_WORK_SPLIT if (world > 1 and os.environ.get('FK_MULTI_SPLIT') != 'equal') else fk.api.Z_EQUAL_SPLIT), **tox)
+            ctx.sync()
+        if same_dev_turns > 1:
+            import torch.distributed as dist
+            dist.barrier()
     r, s = mont(0xA11CE), mont(0xB0B)
     # ---------------------------------------------------------------- N = 1: through the reference's own input form
     # fawkes hands its prover a `Parameters` object: (bellman key, num_gates, brotli(Borsh gates), const tracker), setup.rs:25-32 / mod.rs:139-175.

@@ -73,6 +73,8 @@ int fk_init(int device_id, fk_ctx **out) {
     fk_ctx *ctx = new fk_ctx();
     ctx->device = device_id;
     { const char *d = getenv("FK_DEBUG"); ctx->debug = d && d[0] && d[0] != '0'; }
+    // several PROCESSES proving on this GPU (each with a context of its own): the key loaders reserve what a proof allocates later that many times
+    { const char *t = getenv("FK_CO_TENANTS"); if (t) { const int v = atoi(t); if (v >= 1 && v <= 64) ctx->co_tenants = v; } }
     if (ctx->debug || getenv("FK_BACKTRACE")) {
         // debugging aid (FK_DEBUG=1 or FK_BACKTRACE=1): a native backtrace on SIGSEGV / SIGABRT (the Python host's faulthandler only shows Python frames; the
         // offsets resolve against the same libfawkes_hip.so with addr2line / llvm-symbolizer)
