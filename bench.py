@@ -1123,6 +1123,9 @@ def main():
             'value': args.steps / elapsed,
             'unit': 'proofs/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            # what carried the exchanges of THIS run: 'rccl' = torch.distributed backend nccl over xGMI (the N > 1 default), 'gloo' = host-staged (rehearsals on
+            # one GPU), None = a single rank without a process group
+            'transport': (None if not multi else 'rccl' if args.backend == 'nccl' else args.backend), 'rccl_world_size': (world if (multi and args.backend == 'nccl') else None),
             'ms_per_step': sec_per_step * 1e3,
             'higher_is_better': True,
             'scaling': 'strong',
