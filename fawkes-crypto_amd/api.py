@@ -41,7 +41,7 @@ EXPORTED_SYMBOLS = [
     'fk_setup', 'fk_setup_tiled', 'fk_r1cs_load_tiled', 'fk_key_download', 'fk_key_load_bellman', 'fk_key_write_bellman', 'fk_key_vk', 'fk_key_counts', 'fk_key_precomputed', 'fk_key_load_profile', 'fk_key_levels_plan', 'fk_key_derive_levels',
     'fk_gates_decode', 'fk_gates_free', 'fk_gates_info', 'fk_gates_export', 'fk_r1cs_load_gates', 'fk_gates_profile',
     'fk_gates_encode', 'fk_blob_data', 'fk_blob_profile', 'fk_blob_free',
-    'fk_r1cs_load', 'fk_r1cs_load_coded', 'fk_r1cs_free', 'fk_r1cs_info', 'fk_r1cs_density_ptrs', 'fk_r1cs_eval_dev', 'fk_r1cs_eval_slice_dev', 'fk_prove_r1cs', 'fk_prove_r1cs_dev',
+    'fk_r1cs_load', 'fk_r1cs_load_coded', 'fk_r1cs_free', 'fk_r1cs_info', 'fk_r1cs_windows', 'fk_r1cs_density_ptrs', 'fk_r1cs_eval_dev', 'fk_r1cs_eval_slice_dev', 'fk_prove_r1cs', 'fk_prove_r1cs_dev',
     'fk_init_devices', 'fk_multi_free', 'fk_multi_last_error', 'fk_multi_size', 'fk_multi_transport', 'fk_multi_ctx', 'fk_multi_sync', 'fk_multi_witness_traffic',
     'fk_multi_key_load', 'fk_multi_key_load_bellman', 'fk_multi_setup', 'fk_multi_setup_tiled', 'fk_multi_key_free', 'fk_multi_key_shard',
     'fk_multi_r1cs_load', 'fk_multi_r1cs_load_tiled', 'fk_multi_r1cs_load_gates', 'fk_multi_r1cs_free', 'fk_multi_r1cs_replica',
@@ -381,6 +381,17 @@ class DeviceR1cs:
             raise FkError(rc, 'fk_r1cs_info')
         v = list(out)
         return dict(rows=v[0], nnz=(v[1], v[2], v[3]), distinct_coefficients=v[4], n_a=v[5], n_b=v[6], num_vars=v[7])
+
+    def windows(self):
+        """row windows of the chunked witness hand-over (fk_r1cs_windows): dict(rows=[K + 1 gate bounds], need=[K witness prefixes]) or None"""
+        k = C.c_uint32(0)
+        rows, need = (C.c_uint64 * 17)(), (C.c_uint64 * 16)()
+        rc = self.ctx.lib.fk_r1cs_windows(self.handle, C.byref(k), rows, need)
+        if rc != 0:
+            raise FkError(rc, 'fk_r1cs_windows')
+        if not k.value:
+            return None
+        return dict(rows=list(rows)[:k.value + 1], need=list(need)[:k.value])
 
     def check_witness(self, z):
         """the prove calls read (num_input + num_aux) * 32 bytes from the caller's witness: refuse a vector of another length HERE

@@ -130,6 +130,7 @@ struct fk_ctx {
     } wslot[2];
     int wslot_next = 0;
     hipEvent_t ev_upload_gate = nullptr;
+    hipEvent_t ev_chunk[16] = {nullptr};      // fk_prove_r1cs, chunked hand-over: piece j of the witness has landed (spmv.hip)
     // NTT / prover scratch
     fk::DevBuf ntt_s1, ntt_s2, ntt_io, hbuf, sc_a, sc_b, scan_tmp, stage_a, stage_b, stage_c, stage_z, stage_d;
     // stats

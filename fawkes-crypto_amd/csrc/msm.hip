@@ -1326,6 +1326,7 @@ void msm_release(fk_ctx *ctx) {
     if (ctx->ev_main) { (void)hipEventDestroy(ctx->ev_main); ctx->ev_main = nullptr; }
     if (ctx->ev_z) { (void)hipEventDestroy(ctx->ev_z); ctx->ev_z = nullptr; }
     if (ctx->ev_upload_gate) { (void)hipEventDestroy(ctx->ev_upload_gate); ctx->ev_upload_gate = nullptr; }
+    for (hipEvent_t &e : ctx->ev_chunk) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     if (ctx->ev_acc_done) { (void)hipEventDestroy(ctx->ev_acc_done); ctx->ev_acc_done = nullptr; ctx->ev_acc_done_valid = false; }
     for (MsmLane &ln : ctx->lanes) {
         if (ln.st) (void)hipStreamSynchronize(ln.st);

@@ -49,6 +49,14 @@ struct fk_r1cs_dev {
     // batch circuits of >= 64 copies: the rows of middling length that spmv_tiled_wave_kernel takes (matrix << 30 | row, circuit
     // order) and where they sit in rowlist (sorted by length: [wave_from, wave_to) of each matrix)
     uint32_t *d_wavelist = nullptr, n_wavelist = 0, wave_from[3] = {0, 0, 0}, wave_to[3] = {0, 0, 0};
+    // Row windows (explicit systems whose class lists are block-sorted, all three matrices binned): the gate rows cut into win_k runs of
+    // consecutive rows.  win_cnt[j][s]: entries of launch segment s whose row lies below win_row[j] (a PREFIX of the segment's list: the
+    // lists are ordered by blocks of consecutive rows); win_need[j]: how many leading elements of z the rows below win_row[j + 1] read.
+    // fk_prove_r1cs uploads z in those pieces and evaluates window j as soon as piece j has landed (spmv.hip: prove_r1cs_chunked).
+    static constexpr uint32_t WIN_MAX = 16;
+    uint32_t win_k = 0;
+    uint64_t win_row[WIN_MAX + 1] = {0}, win_need[WIN_MAX] = {0};
+    uint32_t win_cnt[WIN_MAX + 1][fk::SPMV_SEGS] = {{0}};
     // host copies of the class lists and the per-log_w residue-grouped variants, built on first use (fk_r1cs_eval_slice_dev)
     std::vector<uint32_t> h_rowlist[3];
     mutable fk::SliceLists slices[4];

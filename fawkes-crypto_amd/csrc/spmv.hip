@@ -188,6 +188,20 @@ __global__ __launch_bounds__(256) void spmv_tiled_wave_kernel(SpmvArgs a, const 
     if (active) a.out[mtx][(uint64_t)copy * td.base_gates + row] = acc;
 }
 
+// the largest variable index each row window reads: terms [tb[j], tb[j + 1]) of a matrix belong to window j
+struct WinBounds { uint64_t tb[fk_r1cs_dev::WIN_MAX + 1]; uint32_t k; };
+__global__ __launch_bounds__(256) void col_window_max_kernel(const uint32_t *col, WinBounds wb, uint32_t *out) {
+    const uint64_t n = wb.tb[wb.k];
+    uint32_t w = 0, mx = 0; bool any = false;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+        while (i >= wb.tb[w + 1]) { if (any) atomicMax(&out[w], mx); mx = 0; any = false; w++; }
+        const uint32_t c = col[i];
+        if (c > mx) mx = c;
+        any = true;
+    }
+    if (any) atomicMax(&out[w], mx);
+}
+
 }  // namespace fk
 
 using namespace fk;
@@ -362,6 +376,38 @@ static int r1cs_load_impl(fk_ctx *ctx, const fk_r1cs *cs, uint32_t copies, fk_r1
         }
     }
     if (rc != FK_OK) { ctx->err = "r1cs: upload failed"; return fail(rc); }
+    // row windows for the chunked hand-over of fk_prove_r1cs (r1cs.hpp): explicit systems with block-sorted class lists, every matrix binned
+    {
+        static const uint32_t block_rows_w = (uint32_t)std::max(0, tune("FK_SPMV_BLOCK_ROWS", 4096));
+        static const int t_win = std::min<int>(fk_r1cs_dev::WIN_MAX, std::max(0, tune("FK_SPMV_WINDOWS", 8)));
+        const uint64_t ng = cs->num_gates;
+        if (copies == 1 && t_win >= 2 && block_rows_w && ng >= 16ull * block_rows_w && ng < 0xffffffffull && r->bins.mask == 7u) {
+            const uint32_t K = (uint32_t)t_win;
+            for (uint32_t j = 0; j <= K; j++) r->win_row[j] = j == K ? ng : (ng * j / K) / block_rows_w * block_rows_w;
+            for (uint32_t s = 0; s < r->bins.nseg; s++) {
+                const std::vector<uint32_t> &lst = r->h_rowlist[r->bins.mtx[s]];
+                const uint32_t *lo = lst.data() + r->bins.list_off[s], *hi = lo + r->bins.n_rows[s];
+                for (uint32_t j = 0; j <= K; j++) {
+                    const uint64_t bound = r->win_row[j];
+                    r->win_cnt[j][s] = (uint32_t)(std::partition_point(lo, hi, [&](uint32_t row) { return row < bound; }) - lo);       // a prefix: blocks of rows ascend inside a class
+                }
+            }
+            uint32_t *d_mx = nullptr;
+            if (hipMalloc((void **)&d_mx, K * 4) != hipSuccess || hipMemset(d_mx, 0, K * 4) != hipSuccess) { if (d_mx) (void)hipFree(d_mx); ctx->err = "r1cs: device allocation failed"; return fail(FK_ERR_OOM); }
+            for (int k = 0; k < 3; k++) {
+                WinBounds wb{}; wb.k = K;
+                for (uint32_t j = 0; j <= K; j++) wb.tb[j] = ptrs[k][r->win_row[j]];
+                if (wb.tb[K]) hipLaunchKernelGGL(col_window_max_kernel, dim3(2048), dim3(256), 0, ctx->stream, r->col[k], wb, d_mx);
+            }
+            uint32_t mx[fk_r1cs_dev::WIN_MAX] = {0};
+            const bool ok = hipStreamSynchronize(ctx->stream) == hipSuccess && hipMemcpy(mx, d_mx, K * 4, hipMemcpyDeviceToHost) == hipSuccess;
+            (void)hipFree(d_mx);
+            if (!ok) { ctx->err = "r1cs: window planning failed"; return fail(FK_ERR_HIP); }
+            uint64_t run = cs->num_input;                          // the rows behind the gates (input_i * 0 = 0) read the inputs: part of the first piece
+            for (uint32_t j = 0; j < K; j++) { run = std::max<uint64_t>(run, (uint64_t)mx[j] + 1); r->win_need[j] = j + 1 == K ? nv : run; }
+            r->win_k = K;
+        }
+    }
     if (copies > 1 && wave_copies && copies >= wave_copies && r->bins.mask && cs->num_gates < ((uint64_t)1 << 30)) {
         std::vector<uint32_t> wl;
         for (uint64_t g = 0; g < cs->num_gates; g++)
@@ -453,6 +499,14 @@ int fk_r1cs_info(const fk_r1cs_dev *r, uint64_t out[8]) {
     return FK_OK;
 }
 
+int fk_r1cs_windows(const fk_r1cs_dev *r, uint32_t *n_windows, uint64_t rows[17], uint64_t need[16]) {
+    if (!r || !n_windows) return FK_ERR_BAD_ARG;
+    *n_windows = r->win_k;
+    for (uint32_t j = 0; j <= r->win_k && rows; j++) rows[j] = r->win_row[j];
+    for (uint32_t j = 0; j < r->win_k && need; j++) need[j] = r->win_need[j];
+    return FK_OK;
+}
+
 }  // extern "C"
 namespace fk {
 // The per-log_w residue-grouped class lists of a constraint system with binned matrices (see SliceLists), built on first use.
@@ -485,7 +539,7 @@ static int slice_lists(fk_ctx *ctx, const fk_r1cs_dev *r, uint32_t log_w, const 
 
 // a, b, c <- the rows t = rank (mod 2^log_w) of A z, B z, C z, densely: out[j] = row rank + j * 2^log_w (sliced), or all rows
 // (not sliced: rank = log_w = 0).  n_out: elements the caller's arrays hold; those behind the last row are zeroed when sliced.
-int r1cs_eval_impl(fk_ctx *ctx, const fk_r1cs_dev *r, const void *d_z, void *d_a, void *d_b, void *d_c, bool sliced, uint32_t rank, uint32_t log_w, uint64_t n_out) {
+int r1cs_eval_impl(fk_ctx *ctx, const fk_r1cs_dev *r, const void *d_z, void *d_a, void *d_b, void *d_c, bool sliced, uint32_t rank, uint32_t log_w, uint64_t n_out, int window = -1) {
     FK_HIP(ctx, hipSetDevice(ctx->device));
     SpmvArgs a;
     for (int k = 0; k < 3; k++) { a.ptr[k] = r->ptr[k]; a.col[k] = r->col[k]; a.cidx[k] = r->cidx[k]; }
@@ -511,7 +565,9 @@ int r1cs_eval_impl(fk_ctx *ctx, const fk_r1cs_dev *r, const void *d_z, void *d_a
     const uint32_t binned = r->bins.mask;
     const dim3 grid((unsigned)((lanes + 255) / 256), 3), block(256);
     const bool tiled = r->copies > 1;
-    if (lanes) {
+    // window >= 0 (explicit system, every matrix binned): only the class-list entries of row window `window`; the rows behind the gates
+    // (this kernel's only work then) go with window 0
+    if (lanes && window <= 0) {
 #define FK_SPMV_LAUNCH(T_, S_) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_kernel<T_, S_>), grid, block, 0, ctx->stream, a, r->table, (const Fr *)d_z, r->num_gates, \
                                                   r->num_input, lg[0], lg[1], lg[2], td, binned, log_w, rank)
         if (tiled) { if (sliced) FK_SPMV_LAUNCH(true, true); else FK_SPMV_LAUNCH(true, false); }
@@ -560,6 +616,15 @@ int r1cs_eval_impl(fk_ctx *ctx, const fk_r1cs_dev *r, const void *d_z, void *d_a
             const uint64_t n_waves = (uint64_t)((r->copies + 63) / 64) * r->n_wavelist;
             hipLaunchKernelGGL(spmv_tiled_wave_kernel, dim3((unsigned)((n_waves + 3) / 4)), dim3(256), 0, ctx->stream, a, r->table, (const Fr *)d_z, r->num_input, td,
                                r->copies, r->d_wavelist, r->n_wavelist, (uint32_t)n_waves);
+        }
+        if (window >= 0) {
+            b.first_block[0] = 0;
+            for (uint32_t s = 0; s < b.nseg; s++) {
+                const uint32_t c0 = r->win_cnt[window][s], c1 = r->win_cnt[window + 1][s];
+                b.list_off[s] += c0; b.n_rows[s] = c1 - c0;
+                const uint64_t per = 256u >> b.lg[s];
+                b.first_block[s + 1] = b.first_block[s] + (uint32_t)((b.n_rows[s] + per - 1) / per);
+            }
         }
         const unsigned blocks = b.first_block[b.nseg];
         if (blocks) {
@@ -659,6 +724,54 @@ int fk_prove_msms_z_begin_r1cs_dev(fk_ctx *ctx, const fk_key *key, const fk_r1cs
     return rc;
 }); }
 
+}  // extern "C"
+namespace fk {
+// ONE proof at a time from a witness in host memory, with the hand-over CHUNKED (round 5): the 1.07 GB upload of the benchmark's witness is
+// 19 ms during which nothing else of this proof could run -- the proof's latency was upload + proof.  A circuit's rows read the variables
+// allocated before them, so the rows below win_row[j + 1] need only the first win_need[j] elements of z (planned at load, r1cs.hpp): the
+// witness goes up in win_k pieces on the copy stream and the evaluation of window j is queued behind piece j -- a, b, c are complete ~2 ms after
+// the last byte has landed instead of ~20 ms, and the witness sorts then run without the evaluation beside them.  A system whose first rows
+// read late variables degenerates to "upload everything, then evaluate" (win_need[0] = all of z).  Same kernels, same row order inside a
+// window, same bytes.
+static int prove_r1cs_chunked(fk_ctx *ctx, const fk_key *key, const fk_r1cs_dev *r, const uint64_t *z, const uint64_t rr[4], const uint64_t ss[4],
+                              uint8_t out_proof[FK_PROOF_BYTES], fk_timings *tm) {
+    const uint64_t rows = r->num_gates + r->num_input;
+    const size_t mb = key->m * sizeof(Fr);
+    FK_HIP(ctx, ctx->stage_a.reserve(mb)); FK_HIP(ctx, ctx->stage_b.reserve(mb)); FK_HIP(ctx, ctx->stage_c.reserve(mb));
+    if (!ctx->copy_st) FK_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_st, hipStreamNonBlocking));
+    if (!ctx->ev_upload_gate) FK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_upload_gate, hipEventDisableTiming));
+    if (!ctx->ev_z) FK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_z, hipEventDisableTiming));
+    // the pieces follow whatever the main stream still has queued (stage_z may be read by it)
+    FK_HIP(ctx, hipEventRecord(ctx->ev_upload_gate, ctx->stream));
+    FK_HIP(ctx, hipStreamWaitEvent(ctx->copy_st, ctx->ev_upload_gate, 0));
+    Fr *d_z = ctx->stage_z.as<Fr>();
+    uint64_t off = 0;
+    for (uint32_t j = 0; j < r->win_k; j++) {
+        const uint64_t end = r->win_need[j];
+        if (end > off) FK_HIP(ctx, hipMemcpyAsync(d_z + off, z + 4 * off, (end - off) * sizeof(Fr), hipMemcpyHostToDevice, ctx->copy_st));
+        if (!ctx->ev_chunk[j]) FK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_chunk[j], hipEventDisableTiming));
+        FK_HIP(ctx, hipEventRecord(ctx->ev_chunk[j], ctx->copy_st));
+        off = std::max(off, end);
+    }
+    ctx->qidx = &r->qidx;
+    int rc = FK_OK;
+    for (uint32_t j = 0; j < r->win_k && rc == FK_OK; j++) {
+        if (hipStreamWaitEvent(ctx->stream, ctx->ev_chunk[j], 0) != hipSuccess) { rc = FK_ERR_HIP; ctx->err = "prove: hipStreamWaitEvent failed"; break; }
+        if (j + 1 == r->win_k) {        // z is complete at this point of the main stream: the witness multiplications wait for THIS, not for the last window
+            if (hipEventRecord(ctx->ev_z, ctx->stream) != hipSuccess) { rc = FK_ERR_HIP; ctx->err = "prove: hipEventRecord failed"; break; }
+            ctx->ev_z_recorded = true;
+        }
+        rc = r1cs_eval_impl(ctx, r, d_z, ctx->stage_a.p, ctx->stage_b.p, ctx->stage_c.p, false, 0, 0, 0, (int)j);
+    }
+    if (rc == FK_OK) rc = fk_prove_dev(ctx, key, ctx->stage_a.p, ctx->stage_b.p, ctx->stage_c.p, rows, d_z, r->d_a_aux, r->d_b_in, r->d_b_aux, rr, ss, out_proof, tm);
+    else { (void)hipStreamSynchronize(ctx->copy_st); (void)hipStreamSynchronize(ctx->stream); }        // the caller's buffer is no longer read when an error returns
+    ctx->qidx = nullptr;
+    ctx->ev_z_recorded = false;
+    return rc;
+}
+}  // namespace fk
+extern "C" {
+
 int fk_prove_r1cs(fk_ctx *ctx, const fk_key *key, const fk_r1cs_dev *r, const uint64_t *z, const uint64_t rr[4], const uint64_t ss[4],
                   uint8_t out_proof[FK_PROOF_BYTES], fk_timings *tm) { return fk_guard(ctx, [&]() -> int {
     if (!ctx) return FK_ERR_BAD_ARG;
@@ -666,6 +779,14 @@ int fk_prove_r1cs(fk_ctx *ctx, const fk_key *key, const fk_r1cs_dev *r, const ui
     FK_HIP(ctx, hipSetDevice(ctx->device));
     const size_t zb = ((size_t)r->num_input + r->num_aux) * sizeof(Fr);
     FK_HIP(ctx, ctx->stage_z.reserve(zb));
+    static const bool t_chunked = !(getenv("FK_PROVE_CHUNKED_UPLOAD") && atoi(getenv("FK_PROVE_CHUNKED_UPLOAD")) == 0);      // documented switch (fawkes_hip.h)
+    if (t_chunked && r->win_k >= 2 && !ctx->early.done && !ctx->wslot[0].pending && !ctx->wslot[1].pending) {
+        if (r->num_input != key->num_input || r->num_aux != key->num_aux) FK_SET_ERR(ctx, FK_ERR_KEY_MISMATCH, "prove: constraint system and key disagree on the variable counts");
+        const uint64_t rows = r->num_gates + r->num_input;
+        if (rows > key->m || (key->m > 1 && rows <= key->m / 2)) FK_SET_ERR(ctx, FK_ERR_KEY_MISMATCH, "prove: %llu rows do not match key domain %llu",
+                                                                         (unsigned long long)rows, (unsigned long long)key->m);
+        return prove_r1cs_chunked(ctx, key, r, z, rr, ss, out_proof, tm);
+    }
     FK_HIP(ctx, hipMemcpyAsync(ctx->stage_z.p, z, zb, hipMemcpyHostToDevice, ctx->stream));
     return fk_prove_r1cs_dev(ctx, key, r, ctx->stage_z.p, rr, ss, out_proof, tm);
 }); }

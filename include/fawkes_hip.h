@@ -334,6 +334,13 @@ void fk_r1cs_free(fk_ctx *ctx, fk_r1cs_dev *r1cs);
 /* out[8] = rows, nnz(A), nnz(B), nnz(C), distinct coefficients, points the a query needs, points the b query needs,
  * variables (num_input + num_aux: the length of the witness vector the prove calls read) */
 int fk_r1cs_info(const fk_r1cs_dev *r1cs, uint64_t out[8]);
+/* The row windows of the chunked witness hand-over (fk_prove_r1cs, round 5).  An explicit system of >= 65536 gates whose three matrices
+ * all have the length-class lists is cut at load into *n_windows (8; FK_SPMV_WINDOWS) windows of consecutive gates: rows[j] .. rows[j + 1]
+ * are the gates of window j and need[j] the number of leading witness elements the windows 0 .. j read (need[last] = all).  fk_prove_r1cs
+ * then uploads the caller's witness in those pieces and evaluates window j as soon as piece j is on the device, so the 19 ms upload of the
+ * benchmark's witness hides the evaluation instead of preceding it.  *n_windows = 0: no windows (small, tiled or unbinned system) -- the
+ * witness is uploaded whole, as before.  FK_PROVE_CHUNKED_UPLOAD=0 disables the chunked path.  Either way the proof bytes are the same. */
+int fk_r1cs_windows(const fk_r1cs_dev *r1cs, uint32_t *n_windows, uint64_t rows[17], uint64_t need[16]);
 /* device pointers of the structural density maps: a_aux[num_aux], b_input[num_input], b_aux[num_aux] */
 int fk_r1cs_density_ptrs(const fk_r1cs_dev *r1cs, const void *out[3]);
 /* a, b, c <- A z, B z, C z on the device (arrays sized for next_pow2(rows) elements, `rows` written) */

@@ -200,3 +200,67 @@ def test_spmv_large_flat_system_block_ordering(ctx, oracle):
         dr.free()
         for p in d + [d_z]:
             ctx.dev_free(p)
+
+
+def _local_system(seed, lens_choices, gates, nin, naux):
+    """as _ragged_system, but a row reads variables allocated around its own position and before, the way a circuit's gates do"""
+    rng = np.random.default_rng(seed)
+    nv = nin + naux
+    coeffs = fx.co.limbs_arr([1, ref.R - 1, 2] + [int(x) for x in rng.integers(3, 2**62, 40)])
+    coeffs = np.stack([fx.mont_fr(int.from_bytes(c.tobytes(), 'little')) for c in coeffs])
+
+    def mat():
+        lens = rng.choice(lens_choices, size=gates)
+        ptr = np.zeros(gates + 1, np.uint64)
+        ptr[1:] = np.cumsum(lens)
+        nnz = int(ptr[-1])
+        row = np.repeat(np.arange(gates, dtype=np.int64), lens)
+        newest = nin + (row + 1) * naux // gates                      # the variables that exist when the row is written
+        col = (newest - 1 - rng.integers(0, 3000, nnz)).clip(0, nv - 1)
+        col[rng.integers(0, nnz, nnz // 50)] = 0                        # the constant ONE everywhere
+        return fx.co.Csr(ptr, col.astype(np.uint32), np.ascontiguousarray(coeffs[rng.integers(0, len(coeffs), nnz)]))
+
+    return fx.co.R1csC(nin, naux, mat(), mat(), mat())
+
+
+@pytest.mark.parametrize('local', [True, False])
+def test_prove_chunked_hand_over_same_bytes(ctx, local):
+    """fk_prove_r1cs hands a host witness over in pieces and evaluates a window of rows behind each piece (fk_r1cs_windows): the proof is
+    the one of the whole-witness path (fk_prove_r1cs_dev, checked against the oracle above and in test_gpu_params_image).  local = False:
+    rows that read variables from anywhere -- the first window needs all of z, the chunking degenerates and the bytes are still the same."""
+    lens = [0, 1, 1, 1, 2, 3, 4, 9, 31, 32, 33, 70, 200]
+    gates, nin, naux = 140001, 3, 120000
+    base = (_local_system if local else _ragged_system)(99, lens, gates, nin, naux)
+    nv = nin + naux
+    dr = ctx.load_r1cs(r1cs_product(base))
+    w = dr.windows()
+    assert w is not None and len(w['need']) == 8 and w['rows'][0] == 0 and w['rows'][-1] == gates and w['need'][-1] == nv
+    assert all(x % 4096 == 0 for x in w['rows'][:-1]) and sorted(w['rows']) == w['rows'] and sorted(w['need']) == w['need']
+    if local:
+        assert w['need'][0] < nv // 4 and w['need'][3] < 3 * nv // 4       # the pieces really are pieces
+        col = np.concatenate([m.col[:int(m.ptr[w['rows'][1]])] for m in (base.A, base.B, base.C)])
+        assert w['need'][0] == max(int(col.max()) + 1, nin)
+    else:
+        assert w['need'][0] >= nv - 5
+    key, _ = ctx.setup(r1cs_product(base), **{k: fx.mont_fr(v) for k, v in TOXIC.items()})
+    rnd = np.random.default_rng(5)
+    zs = []
+    for t in range(2):
+        z = fx.co.limbs_arr([1] + [int(x) % ref.R for x in rnd.integers(1, 2**63, nv - 1).astype(object) * (2**190 + 12345 + t)])
+        z[0] = fx.mont_fr(1)
+        zs.append(z)
+    r, s = fx.mont_fr(0x1111), fx.mont_fr(0x2222)
+    d_z = ctx.dev_alloc(zs[0].nbytes)
+    try:
+        ctx.upload(d_z, zs[1])
+        other = ctx.prove_witness_dev(key, dr, d_z, r, s)        # leaves ANOTHER witness's a, b, c in the staging buffers
+        got = ctx.prove_witness(key, dr, zs[0], r, s)             # chunked
+        ctx.upload(d_z, zs[0])
+        want = ctx.prove_witness_dev(key, dr, d_z, r, s)         # whole
+        assert got.tobytes() == want.tobytes() and got.tobytes() != other.tobytes()
+        got2 = ctx.prove_witness(key, dr, zs[1], r, s)
+        assert got2.tobytes() == other.tobytes()
+    finally:
+        ctx.dev_free(d_z)
+        dr.free()
+        key.free()
