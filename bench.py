@@ -1203,6 +1203,8 @@ def main():
         if replica is not None:
             out['replica_proofs_per_sec'] = replica
             out['replica_proofs_per_sec_is'] = 'throughput mode: every GPU holds the whole key and proves its own witnesses (host-witness pipeline), no collective'
+        import hashlib
+        out['proof_sha256'] = [hashlib.sha256(w).hexdigest()[:16] for w in want if w is not None]      # the bytes are a function of (Parameters, witness, r, s) alone: equal across runs, boxes and library builds
         if not args.no_cpu_baseline:
             out['proof_verified_by_pairing_check'] = bool(pairing_check(vk, z_inputs[0], want[0]) and
                                                           (want[1] is None or pairing_check(vk, z_inputs[1], want[1])))

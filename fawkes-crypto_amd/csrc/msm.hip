@@ -86,7 +86,8 @@ static MsmPlan make_plan(size_t n, unsigned forced_c, bool merged = false) {
     uint32_t c = forced_c ? forced_c : (lg >= 22 ? lg - t_delta : (lg >= 18 ? (uint32_t)t_small : (lg >= 6 ? lg - 2 : 4)));
     if (merged && !forced_c) c = (uint32_t)std::max(2, (int)c + t_pre_dc);
     if (c < 2) c = 2;
-    if (c > 22) c = 22;
+    static const uint32_t t_cmax = (uint32_t)std::min(tune("FK_MSM_C_MAX", 22), S2_MAX_HI >= 2048 ? 24 : 22);     // the sort's limit: 2^(c - 1) buckets = S2_MAX_HI high bins x <= 4096 low bins
+    if (c > t_cmax) c = t_cmax;
     p.c = c;
     p.W = (255 + c - 1) / c;
     p.cb = 255 / p.W;
