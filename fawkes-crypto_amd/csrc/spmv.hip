@@ -746,21 +746,23 @@ static int prove_r1cs_chunked(fk_ctx *ctx, const fk_key *key, const fk_r1cs_dev 
     FK_HIP(ctx, hipStreamWaitEvent(ctx->copy_st, ctx->ev_upload_gate, 0));
     Fr *d_z = ctx->stage_z.as<Fr>();
     uint64_t off = 0;
-    for (uint32_t j = 0; j < r->win_k; j++) {
-        const uint64_t end = r->win_need[j];
-        if (end > off) FK_HIP(ctx, hipMemcpyAsync(d_z + off, z + 4 * off, (end - off) * sizeof(Fr), hipMemcpyHostToDevice, ctx->copy_st));
-        if (!ctx->ev_chunk[j]) FK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_chunk[j], hipEventDisableTiming));
-        FK_HIP(ctx, hipEventRecord(ctx->ev_chunk[j], ctx->copy_st));
-        off = std::max(off, end);
-    }
     ctx->qidx = &r->qidx;
     int rc = FK_OK;
+    // piece j, then window j: from pageable memory hipMemcpyAsync returns only when the piece has been staged, so the windows must be
+    // queued BETWEEN the pieces for the evaluation to run beside the rest of the upload
     for (uint32_t j = 0; j < r->win_k && rc == FK_OK; j++) {
-        if (hipStreamWaitEvent(ctx->stream, ctx->ev_chunk[j], 0) != hipSuccess) { rc = FK_ERR_HIP; ctx->err = "prove: hipStreamWaitEvent failed"; break; }
-        if (j + 1 == r->win_k) {        // z is complete at this point of the main stream: the witness multiplications wait for THIS, not for the last window
-            if (hipEventRecord(ctx->ev_z, ctx->stream) != hipSuccess) { rc = FK_ERR_HIP; ctx->err = "prove: hipEventRecord failed"; break; }
-            ctx->ev_z_recorded = true;
+        const uint64_t end = r->win_need[j];
+        hipError_t e = hipSuccess;
+        if (end > off) e = hipMemcpyAsync(d_z + off, z + 4 * off, (end - off) * sizeof(Fr), hipMemcpyHostToDevice, ctx->copy_st);
+        if (e == hipSuccess && !ctx->ev_chunk[j]) e = hipEventCreateWithFlags(&ctx->ev_chunk[j], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventRecord(ctx->ev_chunk[j], ctx->copy_st);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->ev_chunk[j], 0);
+        off = std::max(off, end);
+        if (e == hipSuccess && j + 1 == r->win_k) {        // z is complete at this point of the main stream: the witness multiplications wait for THIS, not for the last window
+            e = hipEventRecord(ctx->ev_z, ctx->stream);
+            ctx->ev_z_recorded = e == hipSuccess;
         }
+        if (e != hipSuccess) { rc = FK_ERR_HIP; ctx->err = std::string("prove: chunked hand-over: ") + hipGetErrorString(e); break; }
         rc = r1cs_eval_impl(ctx, r, d_z, ctx->stage_a.p, ctx->stage_b.p, ctx->stage_c.p, false, 0, 0, 0, (int)j);
     }
     if (rc == FK_OK) rc = fk_prove_dev(ctx, key, ctx->stage_a.p, ctx->stage_b.p, ctx->stage_c.p, rows, d_z, r->d_a_aux, r->d_b_in, r->d_b_aux, rr, ss, out_proof, tm);
