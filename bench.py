@@ -807,8 +807,9 @@ def main():
         load_block = {
             'is': 'the prover set up from a `Parameters` image alone (mod.rs:150-175): gate blob -> fk_gates_decode (one decompressing thread = the serial '
                   'floor of a brotli stream; parsing, range checks, coefficient dictionary and density flags on the other host threads) WHILE the bellman part '
-                  'goes through fk_key_load_bellman(checked: every point on its curve, G2 in the subgroup) on the GPU; then fk_r1cs_load_gates, then the '
-                  'fixed-base levels (fk_key_derive_levels: sized against the HBM left beside the resident system)',
+                  'goes through fk_key_load_bellman(checked: every point on its curve, G2 in the subgroup) on the GPU and the fixed-base levels are '
+                  'derived (fk_key_derive_levels, still underneath the decoding); then fk_r1cs_load_gates, and fk_key_levels_headroom confirms the levels '
+                  'left the resident system its room (otherwise they are planned again)',
             'image_bytes': int(image.nbytes), 'blob_bytes': tm_w['blob_bytes'], 'bellman_bytes': tm_w['bellman_bytes'],
             'blob': 'brotli quality %d, lgwin 22 (setup.rs:26 writes quality 9, lgwin 22; the decoder does not care)' % args.blob_quality,
             'gate_stream_bytes': gp and int(p_hdr['gates_info']['decoded_bytes']), 'gates': int(p_hdr['gates_info']['num_gates']),
@@ -820,6 +821,7 @@ def main():
                             'used %.1f CPU-seconds beside it and made it wait %.1f s' % (gp['decompressor_s'], gp['wall_s'], gp['parse_threads'], gp['parse_cpu_s'], gp['waited_for_parsers_s']),
             'r1cs_upload_seconds': tm_r['r1cs_load_s'],
             'key_read_checked_seconds': tm_r['key_read_profile']['arrays_s'], 'key_levels_seconds': tm_r['key_read_profile']['levels_s'],
+            'key_levels_early': bool(tm_r.get('key_levels_early')), 'key_levels_headroom_GiB': tm_r.get('key_levels_headroom_GiB'), 'key_levels_replanned_seconds': tm_r.get('key_levels_replanned_s'),
             'load_parameters_seconds': t_l1 - t_l0, 'first_proof_seconds': t_l2 - t_l1, 'time_to_first_proof_seconds': t_l2 - t_l0,
             'host_rss_peak_bytes': rss_after['peak'], 'host_rss_before_load_bytes': rss_before['now'], 'host_rss_after_load_bytes': rss_after['now'],
             'host_rss_note': 'the image itself (%.1f GB, held by this process as one array) is part of every figure; the decoder adds 8 bytes per matrix term '

@@ -38,7 +38,7 @@ EXPORTED_SYMBOLS = [
     'fk_gen_points_g1_dev', 'fk_gen_points_g2_dev', 'fk_gen_scalars_dev',
     'fk_synthesize', 'fk_stats_reset', 'fk_stats_get', 'fk_calibrate', 'fk_verify', 'fk_verify_batch_dev', 'fk_shard_range', 'fk_h_shard_range', 'fk_work_shard_ranges', 'fk_work_shard_ranges_q0',
     'fk_dq_gather_dev', 'fk_dq_local_dev', 'fk_dq_cross_dev', 'fk_dq_cross_sub_dev',
-    'fk_setup', 'fk_setup_tiled', 'fk_r1cs_load_tiled', 'fk_key_download', 'fk_key_load_bellman', 'fk_key_write_bellman', 'fk_key_vk', 'fk_key_counts', 'fk_key_precomputed', 'fk_key_load_profile', 'fk_key_levels_plan', 'fk_key_derive_levels',
+    'fk_setup', 'fk_setup_tiled', 'fk_r1cs_load_tiled', 'fk_key_download', 'fk_key_load_bellman', 'fk_key_write_bellman', 'fk_key_vk', 'fk_key_counts', 'fk_key_precomputed', 'fk_key_load_profile', 'fk_key_levels_plan', 'fk_key_derive_levels', 'fk_key_levels_headroom', 'fk_key_drop_levels',
     'fk_gates_decode', 'fk_gates_free', 'fk_gates_info', 'fk_gates_export', 'fk_r1cs_load_gates', 'fk_gates_profile',
     'fk_gates_encode', 'fk_blob_data', 'fk_blob_profile', 'fk_blob_free',
     'fk_r1cs_load', 'fk_r1cs_load_coded', 'fk_r1cs_free', 'fk_r1cs_info', 'fk_r1cs_windows', 'fk_r1cs_density_ptrs', 'fk_r1cs_eval_dev', 'fk_r1cs_eval_slice_dev', 'fk_prove_r1cs', 'fk_prove_r1cs_dev',
@@ -321,6 +321,16 @@ class DeviceKey:
         if rc != 0:
             raise FkError(rc, 'fk_key_precomputed')
         return dict(zip(('h', 'l', 'a', 'b_g1', 'b_g2'), list(out)))
+
+    def levels_headroom(self):
+        """fk_key_levels_headroom: bytes of HBM free beyond what proofs with this key still allocate; negative -> derive_levels() again"""
+        out = C.c_int64(0)
+        self.ctx._ck(self.ctx.lib.fk_key_levels_headroom(self.ctx.handle, self.handle, C.byref(out)))
+        return out.value
+
+    def drop_levels(self):
+        """fk_key_drop_levels: release the fixed-base levels (derive_levels() brings them back)"""
+        self.ctx._ck(self.ctx.lib.fk_key_drop_levels(self.ctx.handle, self.handle))
 
     def derive_levels(self):
         """fk_key_derive_levels: the fixed-base levels against the HBM that is free now (a key loaded with FK_KEY_NO_LEVELS)"""

@@ -323,6 +323,7 @@ int msm_g1_end(fk_ctx *ctx, int tail, G1Xyzz *out);
 int msm_g2_begin(fk_ctx *ctx, const G2Affine *d_bases, const Fr *d_scalars, size_t n, bool reuse_sort, int *tail, hipEvent_t ready = nullptr, const KeyPre *pre = nullptr);
 // fills key->pre_* for the slices the key holds (FK_MSM_PRECOMP=0 disables; skipped silently when HBM is short); key_pre_free undoes
 int key_precompute(fk_ctx *ctx, fk_key *key);
+int key_levels_headroom(fk_ctx *ctx, const fk_key *key, int64_t *bytes);
 void key_pre_free(fk_key *key);
 int msm_g2_end(fk_ctx *ctx, int tail, G2Xyzz *out);
 void msm_abandon(fk_ctx *ctx);

@@ -1426,13 +1426,8 @@ void key_pre_free(fk_key *k) {
 
 // FK_MSM_PRECOMP: unset / 1 = derive the levels that fit (a skipped array leaves a warning in fk_last_error), 0 = none,
 // require = fail with FK_ERR_OOM instead of degrading.
-int key_precompute(fk_ctx *ctx, fk_key *k) {
-    const char *e = getenv("FK_MSM_PRECOMP");
-    const bool require = e && !strcmp(e, "require");
-    const int on = e && !require ? atoi(e) : 1;
-    key_pre_free(k);
-    ctx->err.clear();
-    if (!on) return FK_OK;
+// What proofs with key k will still allocate in this context (see key_precompute), times the ranks that share the device.
+static size_t proof_scratch_still_needed(fk_ctx *ctx, const fk_key *k) {
     // What proofs with this key allocate AFTER the key is loaded, and the levels must leave free (round 4: the rule used to be 640 B x
     // 4 lanes x the points of the array in hand -- 172 GB for the h array of a 2^26 domain, so the reference-size system of bench.py
     // lost h's levels although everything fits):
@@ -1461,7 +1456,26 @@ int key_precompute(fk_ctx *ctx, fk_key *k) {
     for (const DevBuf *b : {&ctx->ntt_s1, &ctx->ntt_s2, &ctx->ntt_io, &ctx->hbuf, &ctx->sc_a, &ctx->sc_b, &ctx->stage_a, &ctx->stage_b, &ctx->stage_c, &ctx->stage_z,
                             &ctx->stage_d, &ctx->wslot[0].buf, &ctx->wslot[1].buf}) have += b->cap;
     // ranks of one fk_multi that share a GPU (fk_init_devices with a device named several times) each need this much again
-    const size_t reserve = (need > have ? need - have : 0) * (size_t)std::max(1, ctx->co_tenants) + ((size_t)8 << 30);
+    return (need > have ? need - have : 0) * (size_t)std::max(1, ctx->co_tenants);
+}
+
+// HBM free now minus what proofs with this key still allocate (and 2 GB): negative = the levels were planned before something else was
+// placed in HBM and no longer leave room -- fk_key_derive_levels plans them again against what is free now.
+int key_levels_headroom(fk_ctx *ctx, const fk_key *k, int64_t *bytes) {
+    size_t fr = 0, tot = 0;
+    FK_HIP(ctx, hipMemGetInfo(&fr, &tot));
+    *bytes = (int64_t)fr - (int64_t)proof_scratch_still_needed(ctx, k) - ((int64_t)2 << 30);
+    return FK_OK;
+}
+
+int key_precompute(fk_ctx *ctx, fk_key *k) {
+    const char *e = getenv("FK_MSM_PRECOMP");
+    const bool require = e && !strcmp(e, "require");
+    const int on = e && !require ? atoi(e) : 1;
+    key_pre_free(k);
+    ctx->err.clear();
+    if (!on) return FK_OK;
+    const size_t reserve = proof_scratch_still_needed(ctx, k) + ((size_t)8 << 30);       // + 8 GB for the caller (a resident constraint system, the bench's own buffers)
     // WHICH arrays get levels when they do not all fit (2^26: everything but one; 2^27: one or two): the set with the most accumulation
     // work on the merged path that fits -- a knapsack over at most five items, solved by enumeration.  An array's worth is its points
     // times the cost of one of its additions (a G2 addition = FK_G2_WORK G1 additions), its price (W - 1) levels of 64 / 128 bytes per

@@ -416,6 +416,21 @@ int fk_key_derive_levels(fk_ctx *ctx, fk_key *k) { return fk_guard(ctx, [&]() ->
     return FK_OK;
 }); }
 
+int fk_key_drop_levels(fk_ctx *ctx, fk_key *k) { return fk_guard(ctx, [&]() -> int {
+    if (!ctx || !k) return FK_ERR_BAD_ARG;
+    FK_HIP(ctx, hipSetDevice(ctx->device));
+    FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    FK_TRY(msm_sync(ctx));
+    key_pre_free(k);
+    return FK_OK;
+}); }
+
+int fk_key_levels_headroom(fk_ctx *ctx, const fk_key *k, int64_t *bytes) { return fk_guard(ctx, [&]() -> int {
+    if (!ctx || !k || !bytes) return FK_ERR_BAD_ARG;
+    FK_HIP(ctx, hipSetDevice(ctx->device));
+    return key_levels_headroom(ctx, k, bytes);
+}); }
+
 int fk_key_load_profile(const fk_key *k, double out[2]) {
     if (!k || !out) return FK_ERR_BAD_ARG;
     out[0] = k->load_s[0]; out[1] = k->load_s[1];

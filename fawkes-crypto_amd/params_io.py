@@ -193,7 +193,7 @@ def bellman_counts(bellman):
 
 
 def load_parameters(ctx, data, shard_index=0, shard_count=1, z_frac=(-1.0, -1.0), checked=True, disallow_points_at_infinity=False,
-                    want_host_r1cs=False, timings=None, overlap=True):
+                    want_host_r1cs=False, timings=None, overlap=True, early_levels=True):
     """`Parameters::read(reader, disallow_points_at_infinity, checked)` (mod.rs:159-175) for the GPU prover: file bytes ->
     (DeviceKey resident in HBM, DeviceR1cs resident in HBM, header dict incl. gamma_g2 / ic / const_tracker for a verifier
     and for the witness generator).  The key part is converted and checked on the GPU (fk_key_load_bellman), the gate blob
@@ -227,8 +227,8 @@ def load_parameters(ctx, data, shard_index=0, shard_count=1, z_frac=(-1.0, -1.0)
         box['decode_s'] = time.perf_counter() - t1
     try:
         # The gate blob is decoded on host threads (ctypes releases the GIL) WHILE the key arrays are transferred, converted and checked on the
-        # GPU; the fixed-base levels wait until the constraint system is resident (overlap=False: one after the other, as in the first
-        # version of round 5: 37.9 s instead of 33 s to the first proof at the benchmark size).
+        # GPU, and (early_levels) the fixed-base levels are derived; early_levels=False: the levels wait until the constraint system is resident
+        # (33 s to the first proof at the benchmark size instead of 28); overlap=False: one after the other (37.9 s).
         th = threading.Thread(target=decode)
         th.start()
         if not overlap:
@@ -237,6 +237,13 @@ def load_parameters(ctx, data, shard_index=0, shard_count=1, z_frac=(-1.0, -1.0)
             t1 = time.perf_counter()
             key, gamma_g2, ic = ctx.load_key_bellman(hdr['bellman'], shard_index, shard_count, z_frac, flags=flags | api.FK_KEY_NO_LEVELS)
             tm['key_read_s'] = time.perf_counter() - t1
+            if overlap and early_levels:
+                # the decoder is still busy (at the benchmark size for another 20 s): derive the levels NOW, against the HBM free at this moment
+                # less the planner's allowance for the caller; whether they still leave room is checked once the system is resident
+                t1 = time.perf_counter()
+                key.derive_levels()
+                tm['key_levels_s'] = time.perf_counter() - t1
+                tm['key_levels_early'] = True
         finally:
             th.join()
         if 'error' in box:
@@ -245,16 +252,30 @@ def load_parameters(ctx, data, shard_index=0, shard_count=1, z_frac=(-1.0, -1.0)
         tm['gates_decode_s'] = box['decode_s']
         tm['gates_decode_profile'] = gates.profile()
         t1 = time.perf_counter()
-        dr = gates.load(ctx)
+        try:
+            dr = gates.load(ctx)
+        except api.FkError as e:
+            if e.code != 5 or not tm.get('key_levels_early'):     # FK_ERR_OOM with the levels already in place: they took the system's room
+                raise
+            key.drop_levels()
+            tm['key_levels_early'] = False
+            dr = gates.load(ctx)
         tm['r1cs_load_s'] = time.perf_counter() - t1
         hdr['gates_info'] = gates.info()
         if want_host_r1cs:
             hdr['r1cs'] = gates.to_r1cs()
         gates.free()
         gates = None
-        t1 = time.perf_counter()
-        key.derive_levels()                                        # sized against the HBM that is free NOW: the system is in place
-        tm['key_levels_s'] = time.perf_counter() - t1
+        if tm.get('key_levels_early'):
+            tm['key_levels_headroom_GiB'] = round(key.levels_headroom() / 2**30, 1)
+            if tm['key_levels_headroom_GiB'] < 0:                  # the system turned out larger than the planner's allowance: plan again, now that it is in place
+                t1 = time.perf_counter()
+                key.derive_levels()
+                tm['key_levels_replanned_s'] = time.perf_counter() - t1
+        else:
+            t1 = time.perf_counter()
+            key.derive_levels()                                    # sized against the HBM that is free NOW: the system is in place
+            tm['key_levels_s'] = time.perf_counter() - t1
         tm['key_read_profile'] = key.load_profile()
         hdr.update(gamma_g2=gamma_g2, ic=ic)
     except Exception:

@@ -162,6 +162,12 @@ int fk_key_precomputed(const fk_key *key, uint32_t out[5]);
 int fk_key_levels_plan(const fk_key *key, double out[15]);
 /* (re)derives the fixed-base levels against the HBM that is free now (a key loaded with FK_KEY_NO_LEVELS; or after memory was freed) */
 int fk_key_derive_levels(fk_ctx *ctx, fk_key *key);
+/* Levels planned EARLY (before a constraint system or anything else large was placed in HBM -- params_io.load_parameters derives them while
+ * the gate blob is still being decoded on the host): *bytes = HBM free now - what proofs with this key will still allocate in this context
+ * (lane scratch, quotient vectors, witness slots) - 2 GB.  Negative: call fk_key_derive_levels again, it plans against what is free now. */
+int fk_key_levels_headroom(fk_ctx *ctx, const fk_key *key, int64_t *bytes);
+/* releases the levels (the key itself stays; proofs take the ordinary W-bucket-set path until fk_key_derive_levels is called again) */
+int fk_key_drop_levels(fk_ctx *ctx, fk_key *key);
 /* what loading the key cost: out[0] = seconds for the arrays themselves (transfer + conversion + the checks of fk_key_load_bellman, or
  * the derivation of fk_setup*), out[1] = seconds for the fixed-base levels */
 int fk_key_load_profile(const fk_key *key, double out[2]);

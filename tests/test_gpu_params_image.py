@@ -103,8 +103,20 @@ def test_parameters_image_2p22_rows_explicit_system_equals_tiled(ctx):
     try:
         assert key.counts()['m'] == 1 << 23 and sum(dr.info()['nnz']) > 2.0e8
         assert all(v > 0 for v in key.precomputed().values()), key.precomputed()          # the checked reader's key carries its fixed-base levels
+        # ... derived WHILE the blob was still being decoded, and found to leave room once the system was resident
+        assert tm['read'].get('key_levels_early') is True and tm['read']['key_levels_headroom_GiB'] >= 0 and 'key_levels_replanned_s' not in tm['read']
+        assert key.levels_headroom() > 0
         got = ctx.prove_witness(key, dr, z, r, s).tobytes()
         assert got == tiled_proof
+        # the levels can be dropped and derived again (what load_parameters does when a system leaves too little room): same bytes each way
+        plan = key.levels_plan()
+        head0 = key.levels_headroom()
+        key.drop_levels()
+        assert not any(key.precomputed().values()) and key.levels_headroom() > head0
+        assert ctx.prove_witness(key, dr, z, r, s).tobytes() == tiled_proof
+        key.derive_levels()
+        assert key.levels_plan() == plan
+        assert ctx.prove_witness(key, dr, z, r, s).tobytes() == tiled_proof
         num_input = 1 + copies * (inst.num_input - 1)
         assert bench.pairing_check(vk, z[1:num_input].copy(), got)
         assert fk.api.verify(fk.api.vk_to_borsh(vk), z[1:num_input], got) is True
