@@ -452,3 +452,71 @@ def test_gate_decoder_blocks_giant_gate_and_earliest_error(monkeypatch):
         with pytest.raises(fk.FkError) as e:
             api.Gates(bytes(bad), api.FK_GATES_RAW, 600000, 1, 7)
         assert e.value.code == 7 and 'enum elements overflow' in str(e.value)
+
+
+def test_load_parameters_plans_levels_early_and_replans(oracle, monkeypatch):
+    """host logic of params_io.load_parameters (no GPU: a stand-in context records the calls; the gate blob is decoded by the real native
+    decoder): the key is read with FK_KEY_NO_LEVELS and its levels derived while the decoder runs; once the system is resident the
+    headroom is checked and the levels are planned again when it is negative; an out-of-memory system upload drops the levels, retries,
+    and derives them last; early_levels=False keeps the old order."""
+    from fawkes_crypto_amd import api, params_io as pio
+    cs, _, _ = ref.random_r1cs(43, 200, 3, 230)
+    csr = fx.r1cs_to_csr(cs)
+    key = oracle.setup(csr, **TOXIC)
+    r1cs = r1cs_product(csr)
+    data = pio.store_parameters(_key_arrays(key), r1cs, const_tracker_bits=[True])
+
+    class Key:
+        def __init__(self, log, headroom):
+            self.log, self.headroom = log, headroom
+        def derive_levels(self): self.log.append('derive')
+        def drop_levels(self): self.log.append('drop')
+        def levels_headroom(self): self.log.append('headroom'); return self.headroom.pop(0)
+        def load_profile(self): return dict(arrays_s=0.0, levels_s=0.0)
+        def free(self): self.log.append('key.free')
+
+    class Ctx:
+        def __init__(self, headroom):
+            self.log, self.headroom = [], headroom
+        def load_key_bellman(self, blob, si, sc, zf, flags=0):
+            self.log.append('key(flags=%d)' % flags)
+            return Key(self.log, self.headroom), b'g' * 128, np.zeros((4, 8), np.uint64)
+
+    class Dr:
+        def free(self): pass
+
+    fails = []
+
+    def fake_load(self, ctx):
+        ctx.log.append('system')
+        if fails:
+            raise api.FkError(fails.pop(0), 'r1cs: device allocation failed')
+        return Dr()
+    monkeypatch.setattr(api.Gates, 'load', fake_load)
+    nl = api.FK_KEY_CHECKED | api.FK_KEY_NO_LEVELS
+    # 1. the ordinary case: levels underneath the decoding, room confirmed afterwards
+    c = Ctx([5 << 30]); tm = {}
+    pio.load_parameters(c, data, timings=tm)
+    assert c.log == ['key(flags=%d)' % nl, 'derive', 'system', 'headroom'] and tm['key_levels_early'] and tm['key_levels_headroom_GiB'] == 5.0 and 'key_levels_replanned_s' not in tm
+    # 2. the system took the room the proofs need: planned again
+    c = Ctx([-(3 << 30)]); tm = {}
+    pio.load_parameters(c, data, timings=tm)
+    assert c.log == ['key(flags=%d)' % nl, 'derive', 'system', 'headroom', 'derive'] and tm['key_levels_headroom_GiB'] == -3.0 and 'key_levels_replanned_s' in tm
+    # 3. the upload itself ran out of memory: levels dropped, upload retried, levels last
+    c = Ctx([]); tm = {}; fails.append(5)
+    pio.load_parameters(c, data, timings=tm)
+    assert c.log == ['key(flags=%d)' % nl, 'derive', 'system', 'drop', 'system', 'derive'] and tm['key_levels_early'] is False
+    # ... any other failure, or a second out-of-memory, is the caller's: nothing stays behind
+    c = Ctx([]); fails.extend([5, 5])
+    with pytest.raises(api.FkError):
+        pio.load_parameters(c, data)
+    assert c.log[-1] == 'key.free'
+    c = Ctx([]); fails.append(3)
+    with pytest.raises(api.FkError):
+        pio.load_parameters(c, data)
+    assert 'drop' not in c.log and c.log[-1] == 'key.free'
+    # 4. early_levels=False / overlap=False: the order of the first version
+    for kw in (dict(early_levels=False), dict(overlap=False)):
+        c = Ctx([])
+        pio.load_parameters(c, data, **kw)
+        assert c.log == ['key(flags=%d)' % nl, 'system', 'derive'], (kw, c.log)
