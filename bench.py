@@ -637,7 +637,10 @@ def main():
     ap.add_argument('--tiled-headline', action='store_true',
                     help='rollup1024, N = 1: measure `value` on the tiled resident system (fk_r1cs_load_tiled: one instance + a copy count, rounds 1-4) instead of '
                          'the explicit system decoded from the gate blob of a `Parameters` image (the reference\'s own input form: the default)')
-    ap.add_argument('--blob-quality', type=int, default=1, help='brotli quality of the gate blob the benchmark writes (the reference\'s setup uses 9; any quality decodes alike)')
+    ap.add_argument('--blob-quality', type=int, default=2,
+                    help='brotli quality of the gate blob the benchmark writes.  The reference\'s setup uses 9 (20 minutes for this system on one thread); '
+                         'quality 2 writes a blob of nearly the same size that DECODES at the same speed as a quality-9 one (profiles/r05_blob_quality_decode.log), '
+                         'in 1.5 x the time of quality 1, whose blob is twice as large and decodes 30 %% slower')
     ap.add_argument('--no-untiled', action='store_true', help='rollup1024, N = 1: with --tiled-headline, skip the leg with the explicit system; otherwise skip the tiled leg')
     ap.add_argument('--no-standalone', action='store_true', help='N = 1: skip the standalone MSM / NTT figures')
     ap.add_argument('--no-other-sizes', action='store_true',
@@ -811,7 +814,7 @@ def main():
                   'derived (fk_key_derive_levels, still underneath the decoding); then fk_r1cs_load_gates, and fk_key_levels_headroom confirms the levels '
                   'left the resident system its room (otherwise they are planned again)',
             'image_bytes': int(image.nbytes), 'blob_bytes': tm_w['blob_bytes'], 'bellman_bytes': tm_w['bellman_bytes'],
-            'blob': 'brotli quality %d, lgwin 22 (setup.rs:26 writes quality 9, lgwin 22; the decoder does not care)' % args.blob_quality,
+            'blob': 'brotli quality %d, lgwin 22 (setup.rs:26 writes quality 9, lgwin 22: a quality-2 blob has its size within 6 %% and decodes at its speed, a quality-1 blob is 2.1 x larger and decodes 30 %% slower -- profiles/r05_blob_quality_decode.log)' % args.blob_quality,
             'gate_stream_bytes': gp and int(p_hdr['gates_info']['decoded_bytes']), 'gates': int(p_hdr['gates_info']['num_gates']),
             'matrix_terms': int(sum(p_hdr['gates_info']['nnz'])), 'distinct_coefficients': int(p_hdr['gates_info']['distinct_coefficients']),
             'decode_seconds': tm_r['gates_decode_s'], 'decode_terms_per_sec': sum(p_hdr['gates_info']['nnz']) / tm_r['gates_decode_s'],
