@@ -454,7 +454,7 @@ static int gates_decode(fk_ctx *ctx, const uint8_t *blob, size_t len, int format
 
     Scanner sc(num_gates);
     uint64_t seq = 0, first_gate = 0, off[3] = {0, 0, 0};
-    double t_brotli = 0, t_wait = 0;
+    double t_brotli = 0, t_wait = 0, t_scan = 0, t_buf = 0, t_disp = 0;
     int rc = FK_OK; std::string msg;
     // hands buf[0, sc.gate_end) to the workers as one block (commits the arrays it will write first)
     auto dispatch = [&](const uint8_t *data, std::vector<uint8_t> *own) -> bool {
@@ -505,13 +505,20 @@ static int gates_decode(fk_ctx *ctx, const uint8_t *blob, size_t len, int format
             if (res == 0) { rc = FK_ERR_FORMAT; msg = "corrupt brotli stream"; break; }
             fill += before - avail_out;
             g->decoded_bytes += before - avail_out;
-            if (!sc.scan(cur.data(), fill)) { rc = FK_ERR_FORMAT; msg = "trailing bytes after the last gate"; break; }
+            const double ts0 = now_s();
+            const bool sok = sc.scan(cur.data(), fill);
+            t_scan += now_s() - ts0;
+            if (!sok) { rc = FK_ERR_FORMAT; msg = "trailing bytes after the last gate"; break; }
             if (res == 2 && avail_in == 0) { rc = FK_ERR_FORMAT; msg = "brotli stream truncated"; break; }
             if (sc.gate_end >= TARGET || (res == 1 && sc.blk_gates)) {
+                const double td0 = now_s();
                 const size_t end = sc.gate_end, tail = fill - end;
                 std::vector<uint8_t> nxt = dec.buffer(std::max(TARGET + 2 * CHUNK, tail + CHUNK));
                 if (tail) memcpy(nxt.data(), cur.data() + end, tail);
-                if (!dispatch(nullptr, &cur)) break;
+                const double td1 = now_s();
+                const bool dok = dispatch(nullptr, &cur);
+                t_buf += td1 - td0; t_disp += now_s() - td1;
+                if (!dok) break;
                 cur = std::move(nxt); fill = tail; sc.pos -= end; sc.gate_end = 0;
             }
             if (res == 1) {
@@ -520,6 +527,7 @@ static int gates_decode(fk_ctx *ctx, const uint8_t *blob, size_t len, int format
             }
         }
     }
+    const double t_join = now_s();
     dec.close();
     for (auto &x : threads) if (x.joinable()) x.join();
     if (dec.failed.load()) return fail(dec.err_code, dec.err);          // the earliest block's error: what a serial reader would have met
@@ -548,6 +556,7 @@ static int gates_decode(fk_ctx *ctx, const uint8_t *blob, size_t len, int format
         for (auto &x : rt) x.join();
     }
     const double t_end = now_s();
+    if (getenv("FK_GATES_TRACE")) fprintf(stderr, "[fk] gates: wall %.2f brotli %.2f scan %.2f buffers %.2f dispatch %.2f (of it waiting %.2f) join+renumber %.2f\n", t_end - t_start, t_brotli, t_scan, t_buf, t_disp, t_wait, t_end - t_join);
     const double prof[8] = {t_end - t_start, t_brotli, t_wait, dec.parse_s, t_end - t_ren, (double)n_start, (double)seq, (double)len};
     memcpy(g->prof, prof, sizeof prof);
     *out = gp.release();
