@@ -487,7 +487,12 @@ static int gates_decode(fk_ctx *ctx, const uint8_t *blob, size_t len, int format
         }
         if (rc == FK_OK && !dec.failed.load() && (base != len || sc.gates != num_gates)) { rc = FK_ERR_FORMAT; msg = "gate stream truncated (fewer than num_gates gates)"; }
     } else {
-        const size_t TARGET = (size_t)8 << 20, CHUNK = (size_t)1 << 20;
+        // The decompressor is asked for 256 KiB of output at a time: the scanner that follows every call is a POINTER CHASE through the bytes just
+        // written (a count says where the next count is), 10^8 dependent loads for the benchmark's stream -- with 1 MiB pieces they had left the
+        // near caches by the time the scanner came (3.9 s of a 16.2 s decode), with 256 KiB they have not (0.3 s; 64 KiB the same, 16 KiB costs the
+        // decompressor more calls than it saves: profiles/r05_decode_chunk_probe.log).  FK_GATES_CHUNK_KB overrides.
+        static const size_t chunk_kb = getenv("FK_GATES_CHUNK_KB") ? (size_t)std::min(8192, std::max(4, atoi(getenv("FK_GATES_CHUNK_KB")))) : 256;
+        const size_t TARGET = (size_t)8 << 20, CHUNK = chunk_kb << 10;
         std::vector<uint8_t> cur = dec.buffer(TARGET + 2 * CHUNK);
         size_t fill = 0;
         size_t avail_in = len; const uint8_t *next_in = blob;

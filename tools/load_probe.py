@@ -21,7 +21,7 @@ z = bench.tile_witness(zs, inst.num_input, copies)
 zp = ctx.host_alloc(z.shape)
 zp[:] = z
 key, vk = ctx.setup(inst, copies=copies, **tox)
-image = pio.store_parameters_dev(ctx, key, vk, inst, copies=copies, quality=1, lgwin=22)
+image = pio.store_parameters_dev(ctx, key, vk, inst, copies=copies, quality=int(os.environ.get("BLOB_QUALITY", "2")), lgwin=22)
 key.free()
 want = None
 for early in (False, True, False, True):
