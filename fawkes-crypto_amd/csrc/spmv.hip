@@ -830,7 +830,10 @@ static int early_front(fk_ctx *ctx, int slot) {
     if (w.deferred) { w.deferred = false; FK_TRY(fk_witness_upload_async(ctx, slot, w.host_z, w.host_bytes)); }
     void *d_z = nullptr;
     FK_TRY(fk_witness_ptr(ctx, slot, &d_z));               // the main stream waits for the slot's upload
-    if (ctx->ev_acc_done_valid) FK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_acc_done, 0));      // ... and for the current proof's last accumulation (H's)
+    // FK_PROVE_EARLY_SORTS (experiment build): the witness sorts are queued BEFORE the wait for H's accumulation -- each lane's stream orders them
+    // behind that lane's own work of the current proof -- and only the evaluation waits
+    static const int t_early_sorts = tune("FK_PROVE_EARLY_SORTS", 0);
+    if (!t_early_sorts && ctx->ev_acc_done_valid) FK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_acc_done, 0));      // ... and for the current proof's last accumulation (H's)
     const size_t mb = key->m * sizeof(Fr);
     if (mb > ctx->stage_a.cap || mb > ctx->stage_b.cap || mb > ctx->stage_c.cap) return FK_OK;       // never grow buffers the current proof may still read: no early front
     if (!ctx->ev_z) FK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_z, hipEventDisableTiming));
@@ -840,6 +843,7 @@ static int early_front(fk_ctx *ctx, int slot) {
     const int wb = early_witness_begin(ctx, key, d_z, r->d_a_aux, r->d_b_in, r->d_b_aux, tails);
     if (wb < 0) { ctx->qidx = nullptr; return -wb; }
     if (wb == 0) { ctx->qidx = nullptr; return FK_OK; }     // (the schedule does not apply: nothing was queued but the waits)
+    if (t_early_sorts && ctx->ev_acc_done_valid) FK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_acc_done, 0));
     const int rce = fk_r1cs_eval_dev(ctx, r, d_z, ctx->stage_a.p, ctx->stage_b.p, ctx->stage_c.p);
     ctx->qidx = nullptr;
     if (rce != FK_OK) return rce;
