@@ -57,6 +57,9 @@ def test_bench_default_workload_small():
     assert ld['image_bytes'] == 4 + 4 + ld['blob_bytes'] + 4 + 4 + ld['bellman_bytes'] and ld['decode_seconds'] > 0 and ld['decode_profile']['parse_threads'] >= 1
     assert ld['time_to_first_proof_seconds'] >= ld['load_parameters_seconds'] > ld['decode_seconds'] and ld['host_rss_peak_bytes'] >= ld['host_rss_after_load_bytes'] > 0
     assert ld['key_read_checked_seconds'] > 0 and ld['write']['gates_encode_seconds'] > 0
+    # the levels are planned underneath the decoding and re-checked once the system is resident; the proof bytes are named in the line
+    assert ld['key_levels_early'] is True and ld['key_levels_headroom_GiB'] > 0 and ld['key_levels_replanned_seconds'] is None
+    assert len(j['proof_sha256']) == 2 and j['proof_sha256'][0] != j['proof_sha256'][1] and j['latency_pageable_ms_per_proof'] > 0
     # ... and the tiled form of the same circuit (what rounds 1-4 quoted) is the secondary leg: same proof bytes (asserted by bench.py itself)
     assert j['tiled']['ms_per_step'] > 0 and j['tiled']['device_resident_ms_per_step'] > 0 and j['tiled']['explicit_ms_per_step'] == j['ms_per_step']
     # the witness shortcut is quantified (a timing-only leg with every dense value distinct), every optional leg is timed, the level planner reports
