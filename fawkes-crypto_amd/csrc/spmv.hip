@@ -17,6 +17,7 @@
 #include "common.hpp"
 #include <string.h>
 #include <algorithm>
+#include <chrono>
 #include <unordered_map>
 #include <string>
 
@@ -246,6 +247,8 @@ static int r1cs_load_impl(fk_ctx *ctx, const fk_r1cs *cs, uint32_t copies, fk_r1
     const uint64_t t_in = 1 + (uint64_t)copies * (cs->num_input - 1), t_aux = (uint64_t)copies * cs->num_aux, t_gates = (uint64_t)copies * cs->num_gates;
     if (t_in + t_aux > 0xffffffffull || t_gates + t_in > 0xffffffffull || (copies > 1 && cs->num_gates == 0))
         FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "r1cs: %u copies of this system do not fit 32-bit variable / row indices", copies);
+    const auto t_load0 = std::chrono::steady_clock::now();
+    double t_copy = 0;
     fk_r1cs_dev *r = new fk_r1cs_dev();
     r->num_input = (uint32_t)t_in; r->num_aux = (uint32_t)t_aux; r->num_gates = t_gates;
     r->copies = copies; r->base_input = cs->num_input; r->base_aux = cs->num_aux; r->base_gates = (uint32_t)cs->num_gates;
@@ -308,11 +311,13 @@ static int r1cs_load_impl(fk_ctx *ctx, const fk_r1cs *cs, uint32_t copies, fk_r1
             if (k == 0) { if (v >= cs->num_input) a_aux[v - cs->num_input] = 1; }
             else if (k == 1) { if (v < cs->num_input) b_in[v] = 1; else b_aux[v - cs->num_input] = 1; }
         }
+        const auto tc0 = std::chrono::steady_clock::now();
         if (hipMalloc((void **)&r->ptr[k], (cs->num_gates + 1) * 8) != hipSuccess || hipMalloc((void **)&r->col[k], (nnz + 1) * 4) != hipSuccess ||
             hipMalloc((void **)&r->cidx[k], (nnz + 1) * 4) != hipSuccess) { ctx->err = "r1cs: device allocation failed"; return fail(FK_ERR_OOM); }
         if (hipMemcpy(r->ptr[k], ptrs[k], (cs->num_gates + 1) * 8, hipMemcpyHostToDevice) != hipSuccess) rc = FK_ERR_HIP;
         if (nnz && hipMemcpy(r->col[k], cols[k], nnz * 4, hipMemcpyHostToDevice) != hipSuccess) rc = FK_ERR_HIP;
         if (nnz && hipMemcpy(r->cidx[k], trusted ? pre_cidx[k] : cidx.data(), nnz * 4, hipMemcpyHostToDevice) != hipSuccess) rc = FK_ERR_HIP;
+        t_copy += std::chrono::duration<double>(std::chrono::steady_clock::now() - tc0).count();
         // length classes (spmv_binned_kernel) when the matrix has long rows
         uint64_t maxlen = 0;
         for (uint64_t g = 0; g < cs->num_gates; g++) if (ptrs[k][g + 1] - ptrs[k][g] > maxlen) maxlen = ptrs[k][g + 1] - ptrs[k][g];
@@ -375,6 +380,7 @@ static int r1cs_load_impl(fk_ctx *ctx, const fk_r1cs *cs, uint32_t copies, fk_r1
             }
         }
     }
+    if (getenv("FK_GATES_TRACE")) fprintf(stderr, "[fk] r1cs load: %.2f s so far, %.2f of them allocating and copying the matrices\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_load0).count(), t_copy);
     if (rc != FK_OK) { ctx->err = "r1cs: upload failed"; return fail(rc); }
     // row windows for the chunked hand-over of fk_prove_r1cs (r1cs.hpp): explicit systems with block-sorted class lists, every matrix binned
     {

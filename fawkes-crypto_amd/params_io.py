@@ -203,6 +203,7 @@ def load_parameters(ctx, data, shard_index=0, shard_count=1, z_frac=(-1.0, -1.0)
     tm = timings if timings is not None else {}
     t0 = time.perf_counter()
     hdr = read_parameters(data)
+    tm['header_s'] = time.perf_counter() - t0
     flags = (api.FK_KEY_CHECKED if checked else 0) | (api.FK_KEY_NO_INFINITY if disallow_points_at_infinity else 0)
     # The circuit first, then the key: the loader sizes the key's fixed-base levels against the HBM that is free at that moment, and a
     # resident system of 1.6e9 terms is 14 GB the levels must not take.  num_input / num_aux are the lengths of ic and l.
@@ -264,8 +265,10 @@ def load_parameters(ctx, data, shard_index=0, shard_count=1, z_frac=(-1.0, -1.0)
         hdr['gates_info'] = gates.info()
         if want_host_r1cs:
             hdr['r1cs'] = gates.to_r1cs()
+        t1 = time.perf_counter()
         gates.free()
         gates = None
+        tm['gates_free_s'] = time.perf_counter() - t1
         if tm.get('key_levels_early'):
             tm['key_levels_headroom_GiB'] = round(key.levels_headroom() / 2**30, 1)
             if tm['key_levels_headroom_GiB'] < 0:                  # the system turned out larger than the planner's allowance: plan again, now that it is in place
