@@ -532,9 +532,9 @@ class Gates:
         return DeviceR1cs(ctx, h)
 
     def free(self):
-        if getattr(self, 'handle', None):
-            self.lib.fk_gates_free(self.handle)
-            self.handle = None
+        h, self.handle = getattr(self, 'handle', None), None          # (taken first: load_parameters frees on a background thread)
+        if h:
+            self.lib.fk_gates_free(h)
 
     def __del__(self):
         try:

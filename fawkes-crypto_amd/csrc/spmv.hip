@@ -17,7 +17,9 @@
 #include "common.hpp"
 #include <string.h>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <thread>
 #include <unordered_map>
 #include <string>
 
@@ -282,6 +284,71 @@ static int r1cs_load_impl(fk_ctx *ctx, const fk_r1cs *cs, uint32_t copies, fk_r1
     }();
     uint64_t bin_min = 8;          // rows this long make a matrix binned; FK_SPMV_BIN_MIN=0 turns the binned product off (a run-time switch: the tests run both kernels)
     if (const char *e = getenv("FK_SPMV_BIN_MIN")) { bin_min = strtoull(e, nullptr, 10); if (!bin_min) bin_min = ~0ull; }
+    // The class lists of a matrix depend on its row lengths alone: the three are built side by side (a third of a second each for the
+    // benchmark's 33.5 M rows) before the matrices are uploaded.
+    struct ListPlan { bool binned = false; std::vector<uint32_t> list; uint32_t cls_n[SPMV_CLASSES] = {0}, wave_from = 0, wave_to = 0; };
+    ListPlan plans[3];
+    static const uint32_t cls_lo[SPMV_CLASSES] = {64, 32, 16, 8, 0}, cls_lg[SPMV_CLASSES] = {4, 3, 2, 1, 0};
+    auto build_lists = [&](int k) {
+        ListPlan &lp = plans[k];
+        uint64_t maxlen = 0;
+        for (uint64_t g = 0; g < cs->num_gates; g++) if (ptrs[k][g + 1] - ptrs[k][g] > maxlen) maxlen = ptrs[k][g + 1] - ptrs[k][g];
+        if (!(maxlen >= bin_min && cs->num_gates && cs->num_gates < 0xffffffffull)) return;
+        lp.binned = true;
+        const uint32_t ng = (uint32_t)cs->num_gates, CAP = 1024;            // counting sort by min(length, CAP), descending, stable
+        std::vector<uint32_t> cnt(CAP + 2, 0);
+        std::vector<uint32_t> &list = lp.list;
+        list.resize(ng);
+        auto key = [&](uint32_t g) { const uint64_t l = ptrs[k][g + 1] - ptrs[k][g]; return (uint32_t)(l < CAP ? l : CAP); };
+        for (uint32_t g = 0; g < ng; g++) cnt[CAP - key(g) + 1]++;
+        for (uint32_t i = 0; i <= CAP; i++) cnt[i + 1] += cnt[i];
+        for (uint32_t g = 0; g < ng; g++) list[cnt[CAP - key(g)]++] = g;
+        // classes: 16 lanes per row from 64 terms, 8 from 32, 4 from 16, 2 from 8, one lane below -- a lane then has 4 .. 7 terms
+        // (one or two four-term steps with a shared reduction) in every class but the last; cnt[i] is now the END of key CAP - i
+        uint32_t cls_start[SPMV_CLASSES];
+        for (int c = 0; c < SPMV_CLASSES; c++) {
+            cls_start[c] = c ? cnt[CAP - cls_lo[c - 1]] : 0;
+            lp.cls_n[c] = (cls_lo[c] ? cnt[CAP - cls_lo[c]] : ng) - cls_start[c];
+        }
+        // A large flat system (a circuit as it comes out of a Parameters file): sorting a class by length over the WHOLE system
+        // puts rows from everywhere in the circuit side by side -- every wave then gathers z from all over the witness and
+        // streams its matrix entries from all over the CSR.  Sort by length inside blocks of consecutive rows instead: the rows
+        // that share a wave still have (nearly) the same length, and what runs at one time reads one window of the circuit
+        // (the benchmark's system with every term explicit: evaluation 15.2 -> see profiles/r03_spmv_rollup_probe.log).
+        static const uint32_t block_rows = (uint32_t)std::max(0, tune("FK_SPMV_BLOCK_ROWS", 4096));
+        if (copies == 1 && block_rows && ng >= 16 * block_rows) {
+            uint32_t pos[SPMV_CLASSES];                            // class c holds the rows of cls_lo[c] <= length < cls_lo[c - 1]
+            for (int c = 0; c < SPMV_CLASSES; c++) pos[c] = cls_start[c];
+            std::vector<uint32_t> bc(CAP + 2);
+            std::vector<uint32_t> tmp(block_rows);
+            for (uint32_t g0 = 0; g0 < ng; g0 += block_rows) {
+                const uint32_t g1 = std::min(ng, g0 + block_rows);
+                std::fill(bc.begin(), bc.end(), 0u);
+                for (uint32_t g = g0; g < g1; g++) bc[CAP - key(g) + 1]++;
+                for (uint32_t i = 0; i <= CAP; i++) bc[i + 1] += bc[i];
+                for (uint32_t g = g0; g < g1; g++) tmp[bc[CAP - key(g)]++] = g;           // the block's rows, longest first (stable)
+                for (uint32_t i = 0; i < g1 - g0; i++) {
+                    const uint32_t l = key(tmp[i]);
+                    int c = 0;
+                    while (l < cls_lo[c]) c++;
+                    list[pos[c]++] = tmp[i];
+                }
+            }
+        }
+        lp.wave_from = cnt[CAP - wave_hi]; lp.wave_to = cnt[CAP - wave_lo];
+    };
+    if (cs->num_gates >= ((uint64_t)1 << 20)) {
+        std::atomic<bool> threw{false};
+        auto guarded = [&](int k) { try { build_lists(k); } catch (...) { threw = true; } };       // (an exception must not leave a thread)
+        {
+            std::thread t1([&] { guarded(1); });
+            std::thread t2;
+            try { t2 = std::thread([&] { guarded(2); }); } catch (...) { guarded(2); }
+            guarded(0);
+            t1.join(); if (t2.joinable()) t2.join();
+        }
+        if (threw) { ctx->err = "r1cs: out of host memory while ordering the rows"; return fail(FK_ERR_OOM); }
+    } else for (int k = 0; k < 3; k++) build_lists(k);
     for (int k = 0; k < 3 && rc == FK_OK; k++) {
         const uint64_t nnz = ptrs[k][cs->num_gates];
         r->nnz[k] = nnz * copies;
@@ -318,53 +385,16 @@ static int r1cs_load_impl(fk_ctx *ctx, const fk_r1cs *cs, uint32_t copies, fk_r1
         if (nnz && hipMemcpy(r->col[k], cols[k], nnz * 4, hipMemcpyHostToDevice) != hipSuccess) rc = FK_ERR_HIP;
         if (nnz && hipMemcpy(r->cidx[k], trusted ? pre_cidx[k] : cidx.data(), nnz * 4, hipMemcpyHostToDevice) != hipSuccess) rc = FK_ERR_HIP;
         t_copy += std::chrono::duration<double>(std::chrono::steady_clock::now() - tc0).count();
-        // length classes (spmv_binned_kernel) when the matrix has long rows
-        uint64_t maxlen = 0;
-        for (uint64_t g = 0; g < cs->num_gates; g++) if (ptrs[k][g + 1] - ptrs[k][g] > maxlen) maxlen = ptrs[k][g + 1] - ptrs[k][g];
-        if (maxlen >= bin_min && cs->num_gates && cs->num_gates < 0xffffffffull && rc == FK_OK) {
-            const uint32_t ng = (uint32_t)cs->num_gates, CAP = 1024;            // counting sort by min(length, CAP), descending, stable
-            std::vector<uint32_t> cnt(CAP + 2, 0), list(ng);
-            auto key = [&](uint32_t g) { const uint64_t l = ptrs[k][g + 1] - ptrs[k][g]; return (uint32_t)(l < CAP ? l : CAP); };
-            for (uint32_t g = 0; g < ng; g++) cnt[CAP - key(g) + 1]++;
-            for (uint32_t i = 0; i <= CAP; i++) cnt[i + 1] += cnt[i];
-            for (uint32_t g = 0; g < ng; g++) list[cnt[CAP - key(g)]++] = g;
-            // classes: 16 lanes per row from 64 terms, 8 from 32, 4 from 16, 2 from 8, one lane below -- a lane then has 4 .. 7 terms
-            // (one or two four-term steps with a shared reduction) in every class but the last; cnt[i] is now the END of key CAP - i
-            const uint32_t cls_lo[SPMV_CLASSES] = {64, 32, 16, 8, 0}, cls_lg[SPMV_CLASSES] = {4, 3, 2, 1, 0};
-            uint32_t cls_n[SPMV_CLASSES], cls_start[SPMV_CLASSES];
-            for (int c = 0; c < SPMV_CLASSES; c++) {
-                cls_start[c] = c ? cnt[CAP - cls_lo[c - 1]] : 0;
-                cls_n[c] = (cls_lo[c] ? cnt[CAP - cls_lo[c]] : ng) - cls_start[c];
-            }
-            // A large flat system (a circuit as it comes out of a Parameters file): sorting a class by length over the WHOLE system
-            // puts rows from everywhere in the circuit side by side -- every wave then gathers z from all over the witness and
-            // streams its matrix entries from all over the CSR.  Sort by length inside blocks of consecutive rows instead: the rows
-            // that share a wave still have (nearly) the same length, and what runs at one time reads one window of the circuit
-            // (the benchmark's system with every term explicit: evaluation 15.2 -> see profiles/r03_spmv_rollup_probe.log).
-            static const uint32_t block_rows = (uint32_t)std::max(0, tune("FK_SPMV_BLOCK_ROWS", 4096));
-            if (copies == 1 && block_rows && ng >= 16 * block_rows) {
-                uint32_t pos[SPMV_CLASSES];                            // class c holds the rows of cls_lo[c] <= length < cls_lo[c - 1]
-                for (int c = 0; c < SPMV_CLASSES; c++) pos[c] = cls_start[c];
-                std::vector<uint32_t> bc(CAP + 2);
-                std::vector<uint32_t> tmp(block_rows);
-                for (uint32_t g0 = 0; g0 < ng; g0 += block_rows) {
-                    const uint32_t g1 = std::min(ng, g0 + block_rows);
-                    std::fill(bc.begin(), bc.end(), 0u);
-                    for (uint32_t g = g0; g < g1; g++) bc[CAP - key(g) + 1]++;
-                    for (uint32_t i = 0; i <= CAP; i++) bc[i + 1] += bc[i];
-                    for (uint32_t g = g0; g < g1; g++) tmp[bc[CAP - key(g)]++] = g;           // the block's rows, longest first (stable)
-                    for (uint32_t i = 0; i < g1 - g0; i++) {
-                        const uint32_t l = key(tmp[i]);
-                        int c = 0;
-                        while (l < cls_lo[c]) c++;
-                        list[pos[c]++] = tmp[i];
-                    }
-                }
-            }
-            r->wave_from[k] = cnt[CAP - wave_hi]; r->wave_to[k] = cnt[CAP - wave_lo];             // rows of wave_lo <= length < wave_hi
+        // length classes (spmv_binned_kernel) when the matrix has long rows: planned above (build_lists)
+        ListPlan &lp = plans[k];
+        if (lp.binned && rc == FK_OK) {
+            const uint32_t ng = (uint32_t)cs->num_gates;
+            std::vector<uint32_t> &list = lp.list;
+            const uint32_t *cls_n = lp.cls_n;
+            r->wave_from[k] = lp.wave_from; r->wave_to[k] = lp.wave_to;             // rows of wave_lo <= length < wave_hi
             if (hipMalloc((void **)&r->rowlist[k], (size_t)ng * 4) != hipSuccess) { ctx->err = "r1cs: device allocation failed"; return fail(FK_ERR_OOM); }
             if (hipMemcpy(r->rowlist[k], list.data(), (size_t)ng * 4, hipMemcpyHostToDevice) != hipSuccess) rc = FK_ERR_HIP;
-            r->h_rowlist[k] = list;
+            r->h_rowlist[k] = std::move(list);
             BinArgs &b = r->bins;
             b.rowlist[k] = r->rowlist[k]; b.mask |= 1u << k;
             uint32_t off = 0;

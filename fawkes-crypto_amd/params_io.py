@@ -193,7 +193,7 @@ def bellman_counts(bellman):
 
 
 def load_parameters(ctx, data, shard_index=0, shard_count=1, z_frac=(-1.0, -1.0), checked=True, disallow_points_at_infinity=False,
-                    want_host_r1cs=False, timings=None, overlap=True, early_levels=True):
+                    want_host_r1cs=False, timings=None, overlap=True, early_levels=True, background_free=False):
     """`Parameters::read(reader, disallow_points_at_infinity, checked)` (mod.rs:159-175) for the GPU prover: file bytes ->
     (DeviceKey resident in HBM, DeviceR1cs resident in HBM, header dict incl. gamma_g2 / ic / const_tracker for a verifier
     and for the witness generator).  The key part is converted and checked on the GPU (fk_key_load_bellman), the gate blob
@@ -265,8 +265,14 @@ def load_parameters(ctx, data, shard_index=0, shard_count=1, z_frac=(-1.0, -1.0)
         hdr['gates_info'] = gates.info()
         if want_host_r1cs:
             hdr['r1cs'] = gates.to_r1cs()
+        # the decoder's arrays (8 bytes per term: 14 GB at the benchmark size) go back to the system: 0.7 - 0.9 s of unmapping.  background_free
+        # does it on a thread of its own -- measured: the first proof then takes exactly that much longer (the unmapping holds the address
+        # space's lock against the runtime's own mappings), so it is off by default
         t1 = time.perf_counter()
-        gates.free()
+        if background_free:
+            threading.Thread(target=gates.free, name='fk-gates-free').start()
+        else:
+            gates.free()
         gates = None
         tm['gates_free_s'] = time.perf_counter() - t1
         if tm.get('key_levels_early'):

@@ -24,7 +24,7 @@ key, vk = ctx.setup(inst, copies=copies, **tox)
 image = pio.store_parameters_dev(ctx, key, vk, inst, copies=copies, quality=int(os.environ.get("BLOB_QUALITY", "2")), lgwin=22)
 key.free()
 want = None
-for early in (False, True, False, True):
+for early in ((False, True, False, True) if os.environ.get("PROBE_AB", "1") == "1" else (True, True)):
     ctx.trim()
     tm = {}
     t0 = time.perf_counter()
