@@ -315,7 +315,7 @@ def store_parameters_dev(ctx, key, vk, r1cs, const_tracker_bits=(), compress=Non
                          timings=None):
     """`Parameters::write` (mod.rs:150-157) for a key RESIDENT in HBM, at any size, as ONE uint8 array: fawkes' header from the host,
     the gate blob written natively (fk_gates_encode: Gate::serialize of every gate through libbrotlienc; setup.rs:25-32 uses quality 9 /
-    lgwin 22 -- any setting decodes alike, and quality 1 is 25 x faster at 61 GB of stream), the bellman part converted on the GPU
+    lgwin 22 -- any setting decodes to the same stream; quality 2 is 16 x faster to write at 61 GB of stream and its blob decodes like a quality-9 one), the bellman part converted on the GPU
     straight into the image (fk_key_write_bellman: Montgomery limbs -> big-endian canonical points, ~seconds for a 2^25 key).
     vk: the dict fk_setup* / load_key_bellman returned (gamma_g2, ic).  The gate blob is `gates_blob` as given (e.g. the blob the key
     was loaded with), or `compress(encode_gate_stream(r1cs))` when a `compress` callable is given (the slow per-term restatement: small

@@ -410,7 +410,7 @@ int fk_r1cs_load_gates(fk_ctx *ctx, const fk_gates *gates, fk_r1cs_dev **out);
 int fk_gates_profile(const fk_gates *gates, double out[8]);
 /* The writer's side (setup.rs:25-32: `Parameters.2` = brotli(quality 9, lgwin 22) over Gate::serialize of every gate, cs.rs:184-191):
  * the gate blob of `copies` copies of `cs` (fk_r1cs_load_tiled's variable order; 1 = the system itself), FK_GATES_BROTLI through the
- * system's libbrotlienc.so.1 (FK_ERR_UNSUPPORTED if absent; quality 0 .. 11, lgwin 10 .. 24 -- any setting decodes alike) or
+ * system's libbrotlienc.so.1 (FK_ERR_UNSUPPORTED if absent; quality 0 .. 11, lgwin 10 .. 24 -- any setting decodes to the same stream; 2 .. 9 at the same speed, 0 and 1 slower) or
  * FK_GATES_RAW (the bare stream; quality / lgwin ignored).  The stream is formatted by FK_HOST_THREADS threads and never exists as
  * a whole: the benchmark's 61 GB stream becomes a 2.8 GB blob at quality 1, 1.35 GB at quality 2 (which decodes 1.5 x faster, like a quality-9 blob).  ctx may be NULL. */
 typedef struct fk_blob fk_blob;
