@@ -30,7 +30,8 @@ for early in ((False, True, False, True) if os.environ.get("PROBE_AB", "1") == "
     t0 = time.perf_counter()
     key, dr, hdr = pio.load_parameters(ctx, image, checked=True, timings=tm, early_levels=early)
     t1 = time.perf_counter()
-    p1 = ctx.prove_witness(key, dr, zp, r, s).tobytes()
+    p1, tm1 = ctx.prove_witness(key, dr, zp, r, s, want_timings=True)
+    p1 = p1.tobytes()
     t2 = time.perf_counter()
     p2 = ctx.prove_witness(key, dr, zp, r, s).tobytes()
     t3 = time.perf_counter()
@@ -38,5 +39,5 @@ for early in ((False, True, False, True) if os.environ.get("PROBE_AB", "1") == "
     want = p1
     print(json.dumps(dict(early_levels=early, load_s=round(t1 - t0, 2), first_proof_s=round(t2 - t1, 2), second_proof_s=round(t3 - t2, 3), to_first_proof_s=round(t2 - t0, 2),
                           decode_s=round(tm['gates_decode_s'], 2), key_read_s=round(tm['key_read_s'], 2), levels_s=round(tm['key_levels_s'], 2),
-                          r1cs_load_s=round(tm['r1cs_load_s'], 2), header_s=round(tm.get('header_s', 0), 3), gates_free_s=round(tm.get('gates_free_s', 0), 3), headroom_GiB=tm.get('key_levels_headroom_GiB'), levels=key.precomputed())), flush=True)
+                          r1cs_load_s=round(tm['r1cs_load_s'], 2), header_s=round(tm.get('header_s', 0), 3), gates_free_s=round(tm.get('gates_free_s', 0), 3), headroom_GiB=tm.get('key_levels_headroom_GiB'), first_proof_stages_ms={k: round(v, 1) for k, v in tm1.items()}, levels=key.precomputed())), flush=True)
     key.free(); dr.free()
