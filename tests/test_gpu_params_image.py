@@ -106,6 +106,7 @@ def test_parameters_image_2p22_rows_explicit_system_equals_tiled(ctx):
         # ... derived WHILE the blob was still being decoded, and found to leave room once the system was resident
         assert tm['read'].get('key_levels_early') is True and tm['read']['key_levels_headroom_GiB'] >= 0 and 'key_levels_replanned_s' not in tm['read']
         assert key.levels_headroom() > 0
+        assert tm['read'].get('warm_up_error') is None           # (the throw-away proof of the warm-up, when the decoder left time for it, ran)
         got = ctx.prove_witness(key, dr, z, r, s).tobytes()
         assert got == tiled_proof
         # the levels can be dropped and derived again (what load_parameters does when a system leaves too little room): same bytes each way

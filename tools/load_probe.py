@@ -39,5 +39,5 @@ for early in ((False, True, False, True) if os.environ.get("PROBE_AB", "1") == "
     want = p1
     print(json.dumps(dict(early_levels=early, load_s=round(t1 - t0, 2), first_proof_s=round(t2 - t1, 2), second_proof_s=round(t3 - t2, 3), to_first_proof_s=round(t2 - t0, 2),
                           decode_s=round(tm['gates_decode_s'], 2), key_read_s=round(tm['key_read_s'], 2), levels_s=round(tm['key_levels_s'], 2),
-                          r1cs_load_s=round(tm['r1cs_load_s'], 2), header_s=round(tm.get('header_s', 0), 3), gates_free_s=round(tm.get('gates_free_s', 0), 3), headroom_GiB=tm.get('key_levels_headroom_GiB'), first_proof_stages_ms={k: round(v, 1) for k, v in tm1.items()}, levels=key.precomputed())), flush=True)
+                          r1cs_load_s=round(tm['r1cs_load_s'], 2), header_s=round(tm.get('header_s', 0), 3), gates_free_s=round(tm.get('gates_free_s', 0), 3), headroom_GiB=tm.get('key_levels_headroom_GiB'), warm_up_s=tm.get('warm_up_s'), warm_up_error=tm.get('warm_up_error'), first_proof_stages_ms={k: round(v, 1) for k, v in tm1.items()}, levels=key.precomputed())), flush=True)
     key.free(); dr.free()
