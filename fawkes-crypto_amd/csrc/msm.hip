@@ -578,6 +578,11 @@ static __device__ __forceinline__ void s2_scatter1n_body(const uint32_t *digits,
 #define S2N_ARGS1 const uint32_t *digits, size_t n, size_t chunk, uint32_t nchunks, uint32_t LB, uint32_t nhi, const uint32_t *cnt1, const uint32_t *seg_start, uint32_t *tmp_idx, uint16_t *tmp_lo
 #define S2N_PASS1 digits, n, chunk, nchunks, LB, nhi, cnt1, seg_start, tmp_idx, tmp_lo
 __global__ __launch_bounds__(1024) void s2_scatter1_n1024_kernel(S2N_ARGS1) { s2_scatter1n_body<1024>(S2N_PASS1); }
+// experiment builds only (-DFK_S1_NT=256 -DFK_S1_TILE=4096 [-DFK_S1_NO_PREFETCH]): the same pass in thin workgroups -- one wave per SIMD and few registers,
+// which could sit BESIDE the G2 accumulation's two 226-register waves per SIMD (rounds 1-2 measured thin shapes underneath G1 accumulations only)
+#ifdef FK_S1_NT
+__global__ __launch_bounds__(FK_S1_NT) void s2_scatter1_thin_kernel(S2N_ARGS1) { s2_scatter1n_body<FK_S1_NT>(S2N_PASS1); }
+#endif
 
 // ------------------------------------------------------------------------------------------ bucket -> lane assignment
 // A wave runs as long as its longest bucket, so lanes are handed buckets of (nearly) equal length: buckets are
@@ -1140,6 +1145,10 @@ static int msm_begin(fk_ctx *ctx, const Affine<F> *d_bases, const Fr *d_scalars,
         hipLaunchKernelGGL(s2_hist1_kernel, dim3(p.nchunks, p.W), dim3(SORT_THREADS), p.nhi * 4, ss, digits, n, p.chunk, p.nchunks, p.LB, p.nhi, cnt1);
         hipLaunchKernelGGL(s2_prefix1_kernel, dim3(p.W), dim3(1024), p.nhi * 4, ss, cnt1, p.nchunks, p.nhi, seg_size, seg_start, seg_tiles);
         hipLaunchKernelGGL(s2_tile_prefix_kernel, dim3(1), dim3(1024), 0, ss, seg_tiles, nseg, tile_start);
+#ifdef FK_S1_NT
+        if (tune("FK_S1_THIN", 1)) hipLaunchKernelGGL(s2_scatter1_thin_kernel, dim3(p.nchunks, p.W), dim3(FK_S1_NT), 0, ss, digits, n, p.chunk, p.nchunks, p.LB, p.nhi, cnt1, seg_start, tmp_idx, tmp_lo);
+        else
+#endif
         hipLaunchKernelGGL(s2_scatter1_n1024_kernel, dim3(p.nchunks, p.W), dim3(1024), 0, ss, digits, n, p.chunk, p.nchunks, p.LB, p.nhi, cnt1, seg_start, tmp_idx, tmp_lo);
         FK_HIP(ctx, hipGetLastError());
         FK_DBG_ST(ctx, ss, "msm_sort_pass1");
