@@ -214,6 +214,36 @@ def load_rollup_instance(path=None):
     return fk.R1cs(int(d['num_input']), int(d['num_aux']), *mats), zs
 
 
+def workload_dims(args):
+    """(variables, domain size) of the workload `args` names, from the data fixture alone (no GPU, no library): what the first-contact
+    preflight sizes its collectives with"""
+    if args.workload == 'rollup1024':
+        d = np.load(os.path.join(ROOT, 'tests', 'golden', 'rollup_tx_instance.npz'))
+        b_in, b_aux, gates = int(d['num_input']), int(d['num_aux']), len(d['a_ptr']) - 1
+        n_in = 1 + args.copies * (b_in - 1)
+        n = args.copies * gates + n_in
+        return n_in + args.copies * b_aux, 1 << max(n - 1, 1).bit_length()
+    return 1 << args.log2n, 1 << args.log2n
+
+
+def shared_image_path(estimate_bytes):
+    """where rank 0 writes the `Parameters` image every rank of an N > 1 run maps: FK_BENCH_IMAGE_DIR, else shared memory when it has the room
+    (the file is page cache: one copy for all ranks), else the temporary directory"""
+    import tempfile
+    token = '%s_%d' % (os.environ.get('MASTER_PORT', '0'), os.getpid())
+    for d in (os.environ.get('FK_BENCH_IMAGE_DIR'), '/dev/shm', tempfile.gettempdir()):
+        if not d or not os.path.isdir(d) or not os.access(d, os.W_OK):
+            continue
+        try:
+            st = os.statvfs(d)
+            if st.f_bavail * st.f_frsize < 1.2 * estimate_bytes + (1 << 30):
+                continue
+        except OSError:
+            continue
+        return os.path.join(d, 'fk_bench_params_%s.bin' % token)
+    raise SystemExit('bench: no directory with room for the %.1f GB Parameters image (set FK_BENCH_IMAGE_DIR)' % (estimate_bytes / 1e9))
+
+
 def tile_witness(zs, num_input, copies, out=None):
     """witness of `copies` instances as one system, fk_r1cs_load_tiled's variable order: ONE, every copy's inputs, every
     copy's aux; copy j carries witness j mod len(zs)."""
@@ -403,14 +433,27 @@ def other_size_leg(ctx, inst, zs, copies, tox, r, s, steps, check=True):
             ctx.host_free(zp)
 
 
-def single_process_leg(fk, n_ranks, same_device, r1cs, copies, z_pin, tox, r, s, want, steps):
+def single_process_leg(fk, n_ranks, same_device, r1cs, copies, z_pin, tox, r, s, want, steps, image=None):
     """The one-call form of the multi-GPU prover (fk_init_devices + fk_multi_prove_r1cs: one process, a worker thread per GPU,
-    peer-DMA exchanges inside the library) on the same workload, host-witness pipeline."""
+    peer-DMA exchanges inside the library) on the same workload, host-witness pipeline.  image: the `Parameters` image the ranks were set up
+    from -- the one-call prover is then set up from it as well (fk_multi_key_load_bellman(checked) + fk_gates_decode -> fk_multi_r1cs_load_gates:
+    the explicit system on every GPU); None: fk_multi_setup_tiled / fk_multi_r1cs_load_tiled."""
     mc = fk.MultiContext([0] * n_ranks if same_device else list(range(n_ranks)))
     try:
         t0 = time.perf_counter()
-        key, _ = mc.setup(r1cs, copies=copies, **tox)
-        dr = mc.load_r1cs(r1cs, copies=copies)
+        if image is not None:
+            from fawkes_crypto_amd import params_io as pio
+            hdr = pio.read_parameters(image)
+            cnt = pio.bellman_counts(hdr['bellman'])
+            gates = fk.api.Gates(hdr['gates_blob'], fk.api.FK_GATES_BROTLI, hdr['num_gates'], cnt['num_input'], cnt['num_aux'], ctx=None)
+            try:
+                key, _, _ = mc.load_key_bellman(hdr['bellman'], flags=fk.api.FK_KEY_CHECKED)
+                dr = mc.load_gates(gates)
+            finally:
+                gates.free()
+        else:
+            key, _ = mc.setup(r1cs, copies=copies, **tox)
+            dr = mc.load_r1cs(r1cs, copies=copies)
         prep = time.perf_counter() - t0
         tk, slot = mc.prove_witness_submit(key, dr, z_pin[0], r, s), 0
         mc.sync()
@@ -429,6 +472,8 @@ def single_process_leg(fk, n_ranks, same_device, r1cs, copies, z_pin, tox, r, s,
         mc.prove_witness_wait(tk)
         key.free(); dr.free()
         return {'ms_per_step': ms, 'proofs_per_sec': 1e3 / ms, 'ranks': n_ranks, 'steps': steps, 'prep_seconds': prep,
+                'matrix_form': 'explicit, from a Parameters gate blob' if image is not None else 'tiled (one instance + copy count)',
+                'transport': mc.transport, 'topology': mc.topology(), 'note': mc.note(),
                 'is': 'fk_multi_prove_r1cs (ONE call on %d GPUs, in-library peer-DMA all-to-all), same proof bytes' % n_ranks}
     finally:
         mc.close()
@@ -589,6 +634,106 @@ def pmc_traffic(args, log_m, rows, world, acc, acc_s, achieved):
     return None, None, 'no committed PMC traffic pass for this workload / domain / row count under profiles/'
 
 
+def hbm_block(kernel, units, bytes_per_unit, union_ms, sum_ms, launches, unit_name, note=None):
+    """roofline block of one kernel against HBM.  Two readings of "the kernel's duration" (VERDICT r5 item 5):
+      achieved / frac                      algorithmic bytes / the UNION of the launches' HIP-event intervals (launches that run side by side on
+                                           different lanes each span the whole phase: the union is the time the kernel took);
+      achieved_per_launch / frac_per_launch  the bytes of an average launch / the average of the launches' own durations -- what
+                                           `rocprofv3 --kernel-trace --stats` calls AverageNs (side-by-side launches each count the shared time)."""
+    union_s, sum_s = union_ms * 1e-3, sum_ms * 1e-3
+    ach = units * bytes_per_unit / union_s / 1e9 if union_s > 0 else 0.0
+    per = units * bytes_per_unit / sum_s / 1e9 if sum_s > 0 else 0.0
+    n_l = max(int(launches), 1)
+    b = {'bound': 'hbm', 'kernel': kernel, 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
+         'achieved_per_launch': per, 'frac_per_launch': per / HBM_PEAK_GBS, 'traffic': None, 'traffic_ratio': None,
+         'launches': int(launches), 'union_ms_per_launch': union_ms / n_l, 'avg_launch_ms': sum_ms / n_l,
+         'avg_launch_ms_is': 'mean of the launches\' own HIP-event durations (rocprofv3\'s AverageNs); union_ms_per_launch = union of their intervals / launches',
+         'algorithmic_bytes_per_%s' % unit_name: bytes_per_unit, '%ss' % unit_name: int(units)}
+    if note:
+        b['note'] = note
+    return b
+
+
+def measure_traffic_leg(args, log_m, g1_points, g2_points, rows, limit_s):
+    """HBM bytes of the accumulations and the transforms from the PMC counters, measured by THIS run: two child processes
+    `rocprofv3 --pmc FETCH_SIZE -- python3 bench.py <one step, no optional legs>` and the same with WRITE_SIZE (separate passes, never combined with a
+    trace domain, the program directly after `--`; /opt/skills/guides/MI355X_MICROARCH.md), summarised by tools/pmc_summary.py -- the proof count of
+    a pass is derived from its own dispatches.  The parent has released its key and system before (two 2^25 provers do not fit one GPU).
+    Returns (summary dict or None, error or None)."""
+    import importlib.util
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    exe = shutil.which('rocprofv3') or ('/opt/rocm/bin/rocprofv3' if os.path.exists('/opt/rocm/bin/rocprofv3') else None)
+    if exe is None:
+        return None, 'rocprofv3 not found on this machine'
+    tmp = tempfile.mkdtemp(prefix='fk_pmc_', dir='/tmp' if os.path.isdir('/tmp') else None)
+    base = [sys.executable, os.path.abspath(__file__), '--gpus', '1', '--steps', '1', '--warmup', '0', '--no-cpu-baseline', '--no-untiled', '--no-standalone',
+            '--no-other-sizes', '--no-preflight', '--measure-traffic', 'off', '--tiled-headline', '--workload', args.workload, '--copies', str(args.copies),
+            '--log2n', str(args.log2n), '--lc-terms', str(args.lc_terms)]
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'FK_BENCH_REHEARSE')}
+    env['TMPDIR'] = '/tmp'
+    t0 = time.time()
+    try:
+        for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
+            left = limit_s - (time.time() - t0)
+            if left < 20:
+                return None, 'time limit reached before the %s pass' % ctr
+            cmd = [exe, '--pmc', ctr, '--output-format', 'csv', '-d', os.path.join(tmp, ctr), '-o', 'p', '--'] + base
+            proc = subprocess.Popen(cmd, env=env, cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, start_new_session=True)
+            try:
+                log, _ = proc.communicate(timeout=left)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)        # the process group WE started (start_new_session): rocprofv3 and its python3
+                except OSError:
+                    pass
+                proc.communicate()
+                return None, 'the %s pass did not finish within %.0f s' % (ctr, left)
+            if proc.returncode != 0:
+                return None, 'the %s pass ended with rc %s: %s' % (ctr, proc.returncode, (log or '')[-300:].replace('\n', ' | '))
+        spec = importlib.util.spec_from_file_location('fk_pmc_summary', os.path.join(ROOT, 'tools', 'pmc_summary.py'))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        out_json = os.path.join(tmp, 'traffic.json')
+        try:
+            mod.traffic(os.path.join(tmp, 'FETCH_SIZE'), os.path.join(tmp, 'WRITE_SIZE'), log_m, g1_points, out_json, None, args.workload, None, rows)
+        except SystemExit as e:
+            return None, 'tools/pmc_summary.py: %s' % e
+        j = json.load(open(out_json))
+        j['seconds'] = round(time.time() - t0, 1)
+        j['g2_points_per_proof'] = g2_points
+        return j, None
+    except Exception as e:       # noqa: BLE001 -- the line is printed whatever happens here
+        return None, '%s: %s' % (type(e).__name__, e)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def check_digest(copies, two_witnesses, zs, want):
+    """the benchmarked proofs against the ORACLE's bytes at this size, when tests/golden/fullsize_digests.json holds them (made by
+    tests/golden/make_fullsize_digests.py: oracle/groth16_oracle.c on the host cores; DATA, nothing of the oracle runs here) -- so the parity of the
+    timed proofs is checked in every run, also with --no-cpu-baseline.  Returns a dict for the JSON line, or None when no entry applies."""
+    import hashlib
+    path = os.path.join(ROOT, 'tests', 'golden', 'fullsize_digests.json')
+    if copies is None or not os.path.exists(path):
+        return None
+    e = json.load(open(path))['entries'].get('rollup%d' % copies)
+    if e is None:
+        return None
+    if e.get('witness_set_sha256') != hashlib.sha256(np.ascontiguousarray(zs).tobytes()).hexdigest():
+        return {'file': 'tests/golden/fullsize_digests.json', 'entry': 'rollup%d' % copies, 'applies': False,
+                'why': 'the digests were made for another set of transaction witnesses (tests/golden/_generated/rollup_tx_witnesses.npy absent or different)'}
+    got = [w.hex() for w in want if w is not None]
+    ok = all(g == x for g, x in zip(got, e['proofs']))
+    if not ok:
+        raise AssertionError('bench: the benchmarked proof bytes differ from the oracle\'s bytes in tests/golden/fullsize_digests.json (entry rollup%d)' % copies)
+    return {'file': 'tests/golden/fullsize_digests.json', 'entry': 'rollup%d' % copies, 'applies': True, 'proofs_compared': len(got), 'equal': True,
+            'is': 'the 256 proof bytes of oracle/groth16_oracle.c at this size (%s threads, %s s per proof on the box that made the file): committed data, '
+                  'compared in every run' % (e.get('threads'), e.get('oracle_seconds'))}
+
+
 def self_launch(n_gpus):
     """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nproc-per-node N bench.py <same
     arguments>` as a child process (one rank per GPU, rendezvous on 127.0.0.1 at a free port), pass its output through and
@@ -655,6 +800,15 @@ def main():
                     help='wall-clock budget of the whole command: an optional leg (sensitivity, tiled / untiled, standalone, replicas, one-call form, CPU baseline, '
                          'other sizes) is skipped -- and listed under `legs` with the reason -- when the time used so far plus its estimate would exceed it, so that '
                          'the JSON line is always printed')
+    ap.add_argument('--no-preflight', action='store_true',
+                    help='skip the first-contact checks (fawkes-crypto_amd/preflight.py: the proof\'s collectives at their real sizes with contents verified, the '
+                         'library\'s peer-access table and one verified 64 MiB pull per ordered device pair -- run in a child process per rank before any key is built; '
+                         'on a failure the run continues over the documented fallback and says so in the `preflight` block)')
+    ap.add_argument('--measure-traffic', choices=('auto', 'on', 'off'), default='auto',
+                    help='N = 1: at the end of the run (everything freed), run this command again under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (two child '
+                         'processes, python3 directly after `--`, one step without the optional legs) and quote `roofline.traffic` from THOSE counters instead of the '
+                         'committed pass under profiles/.  auto: on for systems of 2^23 rows and more (the benchmark), off for small ones; skipped with the reason when '
+                         'rocprofv3 is absent or --max-seconds would be exceeded')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend ('nccl' = RCCL; 'gloo' only for single-GPU dry runs of the N>1 code path with FK_BENCH_SAME_DEVICE=1)")
     args = ap.parse_args()
 
@@ -668,32 +822,50 @@ def main():
     if world != args.gpus:
         raise SystemExit('--gpus %d != WORLD_SIZE %d' % (args.gpus, world))
 
-    import torch
-    import fawkes_crypto_amd as fk
-    from fawkes_crypto_amd import parallel
-    if os.environ.get('FK_BENCH_SAME_DEVICE') == '1':
-        local_rank = 0                      # dry run: all ranks share GPU 0 (needs --backend gloo)
-        os.environ.setdefault('FK_CO_TENANTS', str(world))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    same_device = os.environ.get('FK_BENCH_SAME_DEVICE') == '1'
     # FK_BENCH_REHEARSE=1 with --gpus 1: run the multi-GPU code path (process group, all-to-all, all-gather, distributed
     # quotient with one rank) on a single GPU -- a rehearsal of the N > 1 plumbing over real RCCL, not a benchmark mode
     rehearse = os.environ.get('FK_BENCH_REHEARSE') == '1'
     multi = world > 1 or rehearse
+    # ---------------------------------------------------------------- first contact (before this process touches the GPU): the proof's collectives at
+    # their real sizes, the peer-access table and a verified pull per device pair, in a child process with a time limit.  A failure selects the
+    # documented fallback for THIS run (gloo-staged exchanges / host-side event waits) and is reported, instead of ending the run.
+    preflight = None
+    if not args.no_preflight and os.environ.get('FK_BENCH_PREFLIGHT', '1') != '0':
+        from fawkes_crypto_amd import preflight as pf_mod
+        dims_nv, dims_m = workload_dims(args)
+        preflight = pf_mod.run(rank, local_rank, world, args.backend, same_device, dims_nv, dims_m,
+                               limit_s=float(os.environ.get('FK_BENCH_PREFLIGHT_LIMIT', '150')))
+        if args.backend == 'nccl' and multi and preflight['decision']['backend'] != 'nccl':
+            args.backend = preflight['decision']['backend']
+        if preflight['decision']['host_events']:
+            os.environ['FK_MULTI_HOST_EVENTS'] = '1'
+
+    import torch
+    import fawkes_crypto_amd as fk
+    from fawkes_crypto_amd import parallel
+    if same_device:
+        local_rank = 0                      # dry run: all ranks share GPU 0 (needs --backend gloo)
+        os.environ.setdefault('FK_CO_TENANTS', str(world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    data_group = None
     if multi:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
+        # control plane: a gloo group (barriers, the agreement on timings and plans -- host tensors); data plane: a group of the chosen backend
+        # ('nccl' = RCCL over xGMI on device tensors; 'gloo' = host-staged, rehearsals and the preflight's fallback).  Keeping the control plane off
+        # RCCL means that a node whose RCCL does not work can still finish the run and say so.
+        dist.init_process_group('gloo', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=1800))
         if args.backend == 'nccl':
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
+            data_group = dist.new_group(ranks=list(range(world)), backend='nccl')
     comm_dev = dev if args.backend == 'nccl' else None
-    # the witness all-gather gets a process group (= RCCL communicator and stream) of its own: issued on the default group it would sit in
+    # the witness all-gather gets a process group (= RCCL communicator and stream) of its own: issued on the data group it would sit in
     # front of the running proof's all-to-alls in that communicator's queue and hold them back until the next witness has arrived
     wit_group = None
-    if multi and (world > 1 or rehearse):
-        import torch.distributed as dist
+    if multi:
         wit_group = dist.new_group(ranks=list(range(world)), backend=args.backend)
     ctx = fk.Context(local_rank)
 
@@ -705,7 +877,7 @@ def main():
         used = time.time() - t_start
         if multi:
             import torch.distributed as dist
-            tt = torch.tensor([used], dtype=torch.float64, device=dev if args.backend == 'nccl' else 'cpu')
+            tt = torch.tensor([used], dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             used = float(tt.item())
         if used + estimate_s > args.max_seconds:
@@ -770,25 +942,87 @@ def main():
     # FK_BENCH_SAME_DEVICE=1 (rehearsal: every rank-process on ONE GPU): the processes cannot see each other's plans, so the keys are set up one
     # rank after the other (each loader sizes its fixed-base levels against the HBM the earlier ranks left) and every context is told how many
     # tenants share the device (FK_CO_TENANTS, read by fk_init: what a proof will allocate later is reserved that many times)
-    same_dev_turns = world if (world > 1 and os.environ.get('FK_BENCH_SAME_DEVICE') == '1') else 1
-    for turn in range(same_dev_turns):
-        if same_dev_turns == 1 or turn == rank:
-            key, vk = ctx.setup(r1cs, shard_index=rank, shard_count=world, copies=copies,
-                                z_frac=fk.api.Z_WORK_SPLIT_Q0 if q0_split else fracs[rank] if (world > 1 and not dist_q) else
-                                (fk.api.Z_WORK_SPLIT if (world > 1 and os.environ.get('FK_MULTI_SPLIT') != 'equal') else fk.api.Z_EQUAL_SPLIT), **tox)
-            ctx.sync()
-        if same_dev_turns > 1:
-            import torch.distributed as dist
-            dist.barrier()
+    same_dev_turns = world if (world > 1 and same_device) else 1
+    params_form = copies is not None and not args.tiled_headline
+    z_frac_of = lambda g: (fk.api.Z_WORK_SPLIT_Q0 if q0_split else fracs[g] if (world > 1 and not dist_q) else
+                           (fk.api.Z_WORK_SPLIT if (world > 1 and os.environ.get('FK_MULTI_SPLIT') != 'equal') else fk.api.Z_EQUAL_SPLIT))
     r, s = mont(0xA11CE), mont(0xB0B)
+    shared_image = None
+    multi_load = None
+    if multi and params_form:
+        # ------------------------------------------------------------ N > 1: the SAME input form as N = 1.  Rank 0 generates the whole key
+        # once and writes key + circuit as ONE `Parameters` image (Parameters::write, mod.rs:150-157) into a file every rank maps; then EVERY rank sets its
+        # prover up from that image alone -- load_parameters(image, shard = rank / world): fk_gates_decode once per process -> fk_r1cs_load_gates (the
+        # explicit system, resident on every GPU) beside fk_key_load_bellman(checked) of the rank's slices of the key arrays.
+        import torch.distributed as dist
+        from fawkes_crypto_amd import params_io as pio
+        path_box = [None]
+        tm_w = {}
+        if rank == 0:
+            est = 64 * (m + num_aux + n_a + n_b) + 128 * n_b + int(sum(info['nnz'])) + (1 << 20)
+            path_box[0] = shared_image_path(est)
+            import atexit
+            atexit.register(lambda p_=path_box[0]: os.path.exists(p_) and os.remove(p_))      # (the ranks that map it keep their pages until they exit)
+            prev = os.environ.get('FK_MSM_PRECOMP')
+            os.environ['FK_MSM_PRECOMP'] = '0'            # the writer's key needs no fixed-base levels (read at every key load)
+            try:
+                key_w, vk = ctx.setup(r1cs, copies=copies, **tox)
+            finally:
+                if prev is None:
+                    del os.environ['FK_MSM_PRECOMP']
+                else:
+                    os.environ['FK_MSM_PRECOMP'] = prev
+            img_w = pio.store_parameters_dev(ctx, key_w, vk, r1cs, copies=copies, quality=args.blob_quality, lgwin=22, timings=tm_w,
+                                             alloc=lambda nb: np.memmap(path_box[0], dtype=np.uint8, mode='w+', shape=(nb,)))
+            img_w.flush()
+            key_w.free()
+            del img_w, key_w
+            ctx.trim()
+        else:
+            vk = None
+        dr.free(); dr = None
+        dist.broadcast_object_list(path_box, src=0)
+        shared_image = path_box[0]
+        image = np.memmap(shared_image, dtype=np.uint8, mode='r')
+        tm_r = {}
+        t_l0 = time.perf_counter()
+        for turn in range(same_dev_turns):
+            if same_dev_turns == 1 or turn == rank:
+                key, dr, p_hdr = pio.load_parameters(ctx, image, shard_index=rank, shard_count=world, z_frac=z_frac_of(rank), checked=True,
+                                                     disallow_points_at_infinity=False, timings=tm_r, warm=False)
+                ctx.sync()
+            if same_dev_turns > 1:
+                dist.barrier()
+        t_l1 = time.perf_counter()
+        info = dr.info()
+        if (info['n_a'], info['n_b']) != (n_a, n_b):
+            raise AssertionError('bench: the system decoded from the gate blob has other A / B queries than the tiled one')
+        if rank == 0 and (not np.array_equal(np.asarray(p_hdr['ic']), np.asarray(vk['ic'])) or bytes(p_hdr['gamma_g2']) != bytes(vk['gamma_g2'])):
+            raise AssertionError('bench: the verifying key read back from the Parameters image differs from the generated one')
+        multi_load = {
+            'is': 'rank 0 wrote ONE `Parameters` image (mod.rs:150-157: fk_gates_encode + fk_key_write_bellman of the whole key) into a file every rank maps; '
+                  'every rank then set its prover up from the image alone: fk_gates_decode (once per process) -> fk_r1cs_load_gates, and '
+                  'fk_key_load_bellman(checked) of its slices (shard_index = rank, shard_count = world)',
+            'image_bytes': int(image.size), 'image_file': os.path.dirname(shared_image), 'blob_bytes': tm_w.get('blob_bytes'),
+            'matrix_terms': int(sum(p_hdr['gates_info']['nnz'])), 'decode_seconds': tm_r.get('gates_decode_s'), 'key_read_checked_seconds': tm_r.get('key_read_s'),
+            'load_parameters_seconds_rank0': t_l1 - t_l0, 'one_rank_at_a_time': same_dev_turns > 1,
+            'write': {'gates_encode_seconds': tm_w.get('gates_encode_s'), 'key_write_seconds': tm_w.get('key_write_s')},
+        }
+    else:
+        for turn in range(same_dev_turns):
+            if same_dev_turns == 1 or turn == rank:
+                key, vk = ctx.setup(r1cs, shard_index=rank, shard_count=world, copies=copies, z_frac=z_frac_of(rank), **tox)
+                ctx.sync()
+            if same_dev_turns > 1:
+                import torch.distributed as dist
+                dist.barrier()
     # ---------------------------------------------------------------- N = 1: through the reference's own input form
     # fawkes hands its prover a `Parameters` object: (bellman key, num_gates, brotli(Borsh gates), const tracker), setup.rs:25-32 / mod.rs:139-175.
     # The key generated above and the circuit are WRITTEN as such an image (Parameters::write: fk_gates_encode + fk_key_write_bellman), everything
     # is dropped, and the prover is set up again from the image alone: gate blob -> fk_gates_decode -> fk_r1cs_load_gates (every one of the
     # 1.64e9 terms explicit in HBM), bellman part -> fk_key_load_bellman(checked).  `value` is measured on THAT system.
     load_block = None
-    params_form = not multi and copies is not None and not args.tiled_headline
-    if params_form:
+    if params_form and not multi:
         from fawkes_crypto_amd import params_io as pio
         tm_w, tm_r = {}, {}
         image = pio.store_parameters_dev(ctx, key, vk, r1cs, copies=copies, quality=args.blob_quality, lgwin=22, timings=tm_w)
@@ -841,7 +1075,7 @@ def main():
         work = [None] * 3         # a rank evaluates only its own rows, straight into send[] (fk_r1cs_eval_slice_dev): no m-element vectors
         send = [torch.empty(m // world * 32, dtype=torch.uint8, device=dev) for _ in range(3)]
         recv = [torch.empty(m // world * 32, dtype=torch.uint8, device=dev) for _ in range(3)]
-        a2a = parallel.torch_all_to_all(ctx)
+        a2a = parallel.torch_all_to_all(ctx, group=data_group)
     elif multi:
         h_ranges = ([(0, m - 1)] + [(m - 1, m - 1)] * (world - 1)) if q0_split else [fk.api.h_shard_range(m - 1, g, world) for g in range(world)]
         h_full_buf = torch.empty(m * 32, dtype=torch.uint8, device=dev) if rank == 0 else None
@@ -858,9 +1092,9 @@ def main():
         ev = (lambda: ctx.r1cs_eval_dev(dr, d_z, wp[0], wp[1], wp[2])) if wp[0] else None
         if dist_q:
             return parallel.prove_distributed_dev(ctx, key, rank, world, wp, n, log_m, d_z, d_dens[0], d_dens[1], d_dens[2], r, s, send, recv,
-                                                  device=comm_dev, a2a=a2a, device_r1cs=dr, eval_fn=ev)
+                                                  group=data_group, device=comm_dev, a2a=a2a, device_r1cs=dr, eval_fn=ev)
         return parallel.prove_balanced_dev(ctx, key, rank, world, wp[0], wp[1], wp[2], n, d_z, d_dens[0], d_dens[1], d_dens[2], r, s,
-                                           h_ranges, h_full_buf, recv_buf, device=comm_dev, eval_fn=ev if rank == 0 else None)
+                                           h_ranges, h_full_buf, recv_buf, group=data_group, device=comm_dev, eval_fn=ev if rank == 0 else None)
 
     def prime():
         """hand over the first witness (before the timed region: the pipeline is one upload ahead)"""
@@ -914,7 +1148,7 @@ def main():
         raise AssertionError('bench: two different witnesses gave the same proof bytes')
     if multi:
         import torch.distributed as dist
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == 'nccl' else 'cpu')
+        tmax = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
@@ -991,9 +1225,9 @@ def main():
     #     (4.4 MB of matrices instead of 13.9 GB; rounds 1-4 quoted this form) -- the host-witness pipeline timed exactly like `value`;
     #   --tiled-headline: `untiled` = the explicit system built on the host (fk_r1cs_load_coded), witness resident.
     untiled = tiled = None
-    if params_form and first_proof != want[0]:
+    if params_form and not multi and first_proof != want[0]:
         raise AssertionError('bench: the first proof after load_parameters differs from the pipelined proofs')
-    if params_form and not args.no_untiled and leg_fits('tiled', 10 * full_size):
+    if params_form and not multi and not args.no_untiled and leg_fits('tiled', 10 * full_size):
         t1 = time.perf_counter()
         dr_t = ctx.load_r1cs(r1cs, copies=copies)
         t_load = time.perf_counter() - t1
@@ -1066,7 +1300,10 @@ def main():
     if world > 1 and not args.no_replicas and replica_skipped is None and leg_fits('replicas', 20 + 60 * full_size):
         import torch.distributed as dist
         key.free()
-        key, _ = ctx.setup(r1cs, copies=copies, **tox)           # the whole key on every GPU
+        if shared_image is not None:                              # the whole key on every GPU, out of the same image
+            key = ctx.load_key_bellman(pio.read_parameters(image)['bellman'], flags=fk.api.FK_KEY_CHECKED)[0]
+        else:
+            key, _ = ctx.setup(r1cs, copies=copies, **tox)
         ctx.prove_witness_dev(key, dr, d_z0, r, s)
         barrier()
         t1 = time.perf_counter()
@@ -1077,7 +1314,7 @@ def main():
             state['ticket'] = nxt
         ctx.prove_witness_wait(state['ticket']); state['ticket'] = None
         barrier()
-        rep_t = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev if args.backend == 'nccl' else 'cpu')
+        rep_t = torch.tensor([time.perf_counter() - t1], dtype=torch.float64)
         dist.all_reduce(rep_t, op=dist.ReduceOp.MAX)
         if p_rep.tobytes() != want[(dev_steps - 1) & 1] and want[(dev_steps - 1) & 1] is not None:
             raise AssertionError('bench: replica proof differs from the distributed proof')
@@ -1097,11 +1334,12 @@ def main():
         import gc
         gc.collect()
         torch.cuda.empty_cache()
-        hostgrp = dist.new_group(backend='gloo') if args.backend == 'nccl' else None
+        hostgrp = None                      # (the default group IS the host-side gloo group)
         barrier()
         if rank == 0:
             try:
-                single_proc = single_process_leg(fk, world, same_dev, r1cs, copies, z_pin, tox, r, s, want, dev_steps)
+                single_proc = single_process_leg(fk, world, same_dev, r1cs, copies, z_pin, tox, r, s, want, dev_steps,
+                                                 image=image if shared_image is not None else None)
             except Exception as e:     # noqa: BLE001 -- reported, the rank-per-GPU result above stands
                 single_proc = {'error': '%s: %s' % (type(e).__name__, e)}
         dist.barrier(group=hostgrp)
@@ -1125,6 +1363,23 @@ def main():
         merged = bool(pre_levels.get('h'))
         kname = '%s<Fq> (G1 bucket accumulation)' % ('msm_accumulate_merged_kernel' if merged else 'msm_accumulate_kernel')
         fill = n / float(m)
+        rl_g1 = hbm_block(kname, acc['units'], G1_BYTES_PER_SCALAR_MUL, acc.get('union_ms', acc['ms']), acc['ms'], acc['launches'], 'scalar_mul',
+                          note='quoted against HBM as north_star asks.  96 B feed ~12 mixed additions = ~120 modular products = ~4e4 integer instructions, so the '
+                               'algorithmic-byte fraction is necessarily ~2 %; the traffic above it is structural (every base is gathered once per window from its '
+                               'fixed-base level: W x 64 B + scalar)')
+        rl_g1.update(traffic=traffic, traffic_ratio=(traffic / achieved if (traffic and achieved > 0) else None), traffic_source=traffic_src,
+                     kernel_time_is='`achieved` / `frac`: union of the launches\' HIP-event intervals (launches of B1, L and A run side by side: %.1f ms per step as a '
+                                    'union, %.1f ms as the sum of the launches\' own durations); `achieved_per_launch` / `frac_per_launch`: the average launch\'s bytes / '
+                                    'the average launch\'s own duration' % (acc_s * 1e3 / args.steps, acc['ms'] / args.steps),
+                     binding_resource='VALU integer multiplier, not HBM: see roofline_valu')
+        a2 = stats['acc_g2']
+        rl_g2 = hbm_block('%s<Fq2> (G2 bucket accumulation)' % ('msm_accumulate_merged_kernel' if bool(pre_levels.get('b_g2')) else 'msm_accumulate_kernel'),
+                          a2['units'], 160, a2.get('union_ms', a2['ms']), a2['ms'], a2['launches'], 'scalar_mul',
+                          note='SURVEY 8(d): 160 B per G2 scalar-mul (128 B affine base + 32 B scalar); VALU-bound like the G1 kernel (28 base-field products per mixed addition)')
+        nt = stats['ntt']
+        rl_ntt = hbm_block('ntt_pass_kernel<Fr> (all passes of the quotient\'s 6 transforms)', 6 * m * args.steps, 64, nt['ms'], nt['ms'], nt['launches'], 'element_transform',
+                           note='SURVEY 8(d): 64 B per element per transform (one ideal pass) x the 6 transforms of a quotient / the time of all their passes; a 2^%d '
+                                'transform is %d passes, so the data MOVED is %d x that (kernel_ms_per_step.ntt_algorithmic_GBps)' % (log_m, (log_m + 8) // 9, (log_m + 8) // 9))
         if args.workload == 'rollup1024':
             wl = ('%d rollup-style transactions (two depth-32 poseidon merkle proofs + one eddsa-poseidon signature each; a composition of the '
                   'reference\'s gadgets, tests/golden/rollup_tx_instance.npz) as ONE R1CS of %d rows = %.2f %% of the 2^%d domain (BASELINE configs[3] shape; '
@@ -1176,19 +1431,9 @@ def main():
             'latency_ms_per_proof_is': 'ONE proof at a time from the witness in pinned host memory (fk_prove_r1cs: the witness goes up in the pieces of fk_r1cs_windows, '
                                        'row window j is evaluated behind piece j, then the proof); `latency_pageable_ms_per_proof` the same call on a pageable buffer; '
                                        '`ms_per_step` is the pipelined rate, `device_resident_ms_per_step` the same without the upload',
-            'roofline': {
-                'bound': 'hbm', 'kernel': kname,
-                'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                'traffic': traffic, 'traffic_source': traffic_src,
-                'launches': acc['launches'], 'avg_launch_ms': acc_s * 1e3 / max(acc['launches'], 1),
-                'kernel_time_is': 'union of the launches\' HIP-event intervals (launches of B1, L and A run side by side: %.1f ms per step as a '
-                                  'union, %.1f ms as the sum of the launches\' own durations)' % (acc_s * 1e3 / args.steps, acc['ms'] / args.steps),
-                'algorithmic_bytes_per_scalar_mul': G1_BYTES_PER_SCALAR_MUL,
-                'binding_resource': 'VALU integer multiplier, not HBM: see roofline_valu',
-                'note': 'quoted against HBM as north_star asks.  96 B feed ~12 mixed additions = ~120 modular products = ~4e4 integer '
-                        'instructions, so the algorithmic-byte fraction is necessarily ~2 %; the traffic above it is structural (every base '
-                        'is gathered once per window from its fixed-base level: W x 64 B + scalar)',
-            },
+            'roofline': rl_g1,
+            'roofline_g2': rl_g2,
+            'roofline_ntt': rl_ntt,
             'roofline_valu': {
                 'bound': 'valu-int-mul', 'kernel': kname,
                 'achieved': modmul / acc_s / 1e9 if acc_s > 0 else 0.0, 'peak': valu_peak / 1e9, 'unit': 'G modmul/s',
@@ -1221,6 +1466,13 @@ def main():
         if replica is not None:
             out['replica_proofs_per_sec'] = replica
             out['replica_proofs_per_sec_is'] = 'throughput mode: every GPU holds the whole key and proves its own witnesses (host-witness pipeline), no collective'
+        if preflight is not None:
+            out['preflight'] = preflight
+        if multi_load is not None:
+            out['load'] = multi_load
+        dg = check_digest(copies, two_witnesses, zs if copies is not None else None, want)
+        if dg is not None:
+            out['oracle_digest_check'] = dg
         import hashlib
         out['proof_sha256'] = [hashlib.sha256(w).hexdigest()[:16] for w in want if w is not None]      # the bytes are a function of (Parameters, witness, r, s) alone: equal across runs, boxes and library builds
         if not args.no_cpu_baseline:
@@ -1291,6 +1543,50 @@ def main():
                 leg['reference_seconds_per_proof'] = 628.0
             out[tag] = leg
             leg_done(tag)
+    # ---- not `value`: HBM traffic of the accumulations and the transforms from the PMC counters, measured by THIS run (child processes under
+    # rocprofv3; everything of this process is released first: two provers of this size do not fit one GPU)
+    mt_on = args.measure_traffic == 'on' or (args.measure_traffic == 'auto' and n >= (1 << 23))
+    if out is not None and not multi and mt_on and leg_fits('measure_traffic', 60 + 200 * full_size):
+        if key is not None:
+            key.free(); key = None
+        if dr is not None:
+            dr.free(); dr = None
+        for zp in z_pin:
+            ctx.host_free(zp)
+        z_pin = []
+        ctx.trim()
+        torch.cuda.empty_cache()
+        pmc, err = measure_traffic_leg(args, log_m, (m - 1) + num_aux + n_a + n_b, n_b, n, max(30.0, args.max_seconds - (time.time() - t_start) - 20))
+        leg_done('measure_traffic')
+        if pmc is None:
+            out['roofline']['traffic_measured_error'] = err
+        else:
+            # FETCH_SIZE corrections (gfx950): x1.00 for the G1 kernel's 64-byte gathers, x1.98 for 128-byte ones, x2.00 for wide coalesced streams --
+            # calibrated with tools/mulbench/gathercal (profiles/r05f_pmc_traffic_bench_rollup1741.json: fetch_size_calibration) in line with
+            # /opt/skills/guides/MI355X_MICROARCH.md; WRITE_SIZE is exact
+            pp = max(int(pmc['proofs_in_the_pass']), 1)
+            dk = pmc['dominant_kernel']
+            per_pt = (dk['fetch_bytes_per_proof_raw'] * 1.0 + dk['write_bytes_per_proof']) / dk['points_per_proof']
+            rl = out['roofline']
+            rl['traffic_imported'] = {'GBps': rl['traffic'], 'source': rl.get('traffic_source')}
+            rl['traffic'] = per_pt * acc['units'] / acc_s / 1e9
+            rl['traffic_ratio'] = rl['traffic'] / rl['achieved'] if rl['achieved'] > 0 else None
+            rl['traffic_bytes_per_scalar_mul'] = per_pt
+            rl['traffic_source'] = ('MEASURED BY THIS RUN: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE over one-step child runs of this command (%d proofs in each pass, '
+                                    'derived from its dispatches; %.0f s); bytes per (scalar, base) pair of the pass x this run\'s pairs / this run\'s kernel time; FETCH_SIZE x 1.00 '
+                                    '(64-byte gathers)' % (pp, pmc['seconds']))
+            rl.pop('traffic_error', None)
+            for blk, prefix, corr, per_proof_units in ((out['roofline_g2'], 'msm_accumulate', 1.98, n_b), (out['roofline_ntt'], 'ntt_pass_kernel', 2.0, 6 * m)):
+                ks = [k for k in pmc['per_kernel'] if k['kernel'].startswith(prefix) and ('Fq2T' in k['kernel']) == (blk is out['roofline_g2'])]
+                if not ks or per_proof_units <= 0:
+                    continue
+                byts = sum(k['FETCH_SIZE_KB'] * 1024 * corr + k['WRITE_SIZE_KB'] * 1024 for k in ks) / pp
+                if blk is out['roofline_ntt'] and pmc['per_kernel']:
+                    byts = byts * (6 * ((log_m + 8) // 9)) / max(sum(k['launches'] for k in ks) / pp, 1)      # the quotient's passes only (the key set-up adds one or two transforms)
+                blk['traffic_bytes_per_unit'] = byts / per_proof_units
+                blk['traffic_ratio'] = blk['traffic_bytes_per_unit'] / (160 if blk is out['roofline_g2'] else 64)
+                blk['traffic'] = blk['achieved'] * blk['traffic_ratio']
+                blk['traffic_source'] = 'the same two passes; FETCH_SIZE x %.2f (%s)' % (corr, '128-byte gathers' if corr < 2 else 'wide coalesced streams')
     if out is not None:
         out['legs'] = dict(legs, total_seconds=round(time.time() - t_start, 1), max_seconds=args.max_seconds,
                            what='seconds each optional leg took, or why it was skipped (--max-seconds: the JSON line is printed whatever happens to the extras)')

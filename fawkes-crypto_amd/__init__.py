@@ -11,7 +11,7 @@ The directory name carries a hyphen (the reference's crate name); import it as `
 There is NO CPU fallback: if libfawkes_hip.so is missing or no GPU is visible, `Context()` raises.
 """
 from .api import (  # noqa: F401
-    FkError, Context, MultiContext, Parameters, Proof, G1Point, G2Point, R1cs, prove, prove_with_rs, lib_path, load_library,
+    FkError, Context, MultiContext, Parameters, Proof, VK, G1Point, G2Point, R1cs, prove, prove_with_rs, lib_path, load_library,
     FK_MSM_RESULT_BYTES, FK_PROOF_BYTES, EXPORTED_SYMBOLS, build_library,
     verify, verify_batch, vk_to_borsh, synthesize, sample_fr,
 )

@@ -42,7 +42,7 @@ EXPORTED_SYMBOLS = [
     'fk_gates_decode', 'fk_gates_free', 'fk_gates_info', 'fk_gates_export', 'fk_r1cs_load_gates', 'fk_gates_profile',
     'fk_gates_encode', 'fk_blob_data', 'fk_blob_profile', 'fk_blob_free',
     'fk_r1cs_load', 'fk_r1cs_load_coded', 'fk_r1cs_free', 'fk_r1cs_info', 'fk_r1cs_windows', 'fk_r1cs_density_ptrs', 'fk_r1cs_eval_dev', 'fk_r1cs_eval_slice_dev', 'fk_prove_r1cs', 'fk_prove_r1cs_dev',
-    'fk_init_devices', 'fk_multi_free', 'fk_multi_last_error', 'fk_multi_size', 'fk_multi_transport', 'fk_multi_ctx', 'fk_multi_sync', 'fk_multi_witness_traffic',
+    'fk_init_devices', 'fk_multi_free', 'fk_multi_last_error', 'fk_multi_size', 'fk_multi_transport', 'fk_multi_topology', 'fk_multi_preflight', 'fk_multi_ctx', 'fk_multi_sync', 'fk_multi_witness_traffic',
     'fk_multi_key_load', 'fk_multi_key_load_bellman', 'fk_multi_setup', 'fk_multi_setup_tiled', 'fk_multi_key_free', 'fk_multi_key_shard',
     'fk_multi_r1cs_load', 'fk_multi_r1cs_load_tiled', 'fk_multi_r1cs_load_gates', 'fk_multi_r1cs_free', 'fk_multi_r1cs_replica',
     'fk_multi_prove_r1cs', 'fk_multi_prove_r1cs_submit', 'fk_multi_prove_r1cs_wait',
@@ -192,11 +192,44 @@ class R1cs:
         return self.num_gates + self.num_input
 
 
+def num_to_json(v):
+    """serde form of `Num<Fp>` (ff-uint/src/num/mod.rs:445-451): the canonical value as a DECIMAL string"""
+    return str(int(v))
+
+
+def num_from_json(sv, modulus=None):
+    """`Num<Fp>`'s Deserialize (ff-uint/src/num/mod.rs:454-459 -> NumRepr::from_str, ff-uint/src/uint/mod.rs:367-388): a string of ASCII digits
+    only ("Invalid character" otherwise; the empty string is 0, as upstream's loop gives), at most 256 bits ("Invalid length"), below the
+    modulus ("Field overflow").  The messages are upstream's."""
+    if not isinstance(sv, str):
+        raise ValueError('Wrong number format')          # NumRepr's Deserialize maps every parse error to this (mod.rs:95-97)
+    if not all(48 <= ord(ch) <= 57 for ch in sv):
+        raise ValueError('Wrong number format: Invalid character')
+    v = 0
+    for ch in sv:
+        v = v * 10 + (ord(ch) - 48)
+        if v >> 256:
+            raise ValueError('Wrong number format: Invalid length')
+    if modulus is not None and v >= modulus:
+        raise ValueError('Field overflow')
+    return v
+
+
 class G1Point:
     """group.rs:13 -- affine (x, y) as canonical ints; (0, 0) is the point at infinity (group.rs:55)."""
 
     def __init__(self, x, y):
         self.x, self.y = int(x), int(y)
+
+    def to_json(self):
+        """serde form (group.rs:12-13: a derived tuple struct of two `Num<Fq>`): ["x", "y"], decimal strings"""
+        return [num_to_json(self.x), num_to_json(self.y)]
+
+    @classmethod
+    def from_json(cls, j):
+        if not isinstance(j, (list, tuple)) or len(j) != 2:
+            raise ValueError('G1Point: expected a sequence of 2 elements')
+        return cls(num_from_json(j[0], FQ_MODULUS), num_from_json(j[1], FQ_MODULUS))
 
     def is_zero(self):
         return self.x == 0 and self.y == 0
@@ -217,6 +250,16 @@ class G2Point:
 
     def __init__(self, x, y):
         self.x, self.y = (int(x[0]), int(x[1])), (int(y[0]), int(y[1]))
+
+    def to_json(self):
+        """serde form (group.rs:83-85: a tuple struct of two pairs, "X+IY" little-endian): [["x_re", "x_im"], ["y_re", "y_im"]]"""
+        return [[num_to_json(self.x[0]), num_to_json(self.x[1])], [num_to_json(self.y[0]), num_to_json(self.y[1])]]
+
+    @classmethod
+    def from_json(cls, j):
+        if not isinstance(j, (list, tuple)) or len(j) != 2 or any(not isinstance(c, (list, tuple)) or len(c) != 2 for c in j):
+            raise ValueError('G2Point: expected a sequence of 2 pairs')
+        return cls(tuple(num_from_json(v, FQ_MODULUS) for v in j[0]), tuple(num_from_json(v, FQ_MODULUS) for v in j[1]))
 
     def is_zero(self):
         return self.x == (0, 0) and self.y == (0, 0)
@@ -247,6 +290,74 @@ class Proof:
         b = bytes(b)
         assert len(b) == FK_PROOF_BYTES
         return cls(G1Point.from_bytes(b[:64]), G2Point.from_bytes(b[64:192]), G1Point.from_bytes(b[192:]))
+
+    def __eq__(self, o):
+        return self.to_bytes() == o.to_bytes()
+
+    def to_json(self):
+        """serde form (prover.rs:11-17: derived, named fields): {"a": G1, "b": G2, "c": G1} -- what serde_json::to_value gives"""
+        return {'a': self.a.to_json(), 'b': self.b.to_json(), 'c': self.c.to_json()}
+
+    @classmethod
+    def from_json(cls, j):
+        if isinstance(j, (str, bytes)):
+            import json as _json
+            j = _json.loads(j)
+        missing = [k for k in 'abc' if k not in j]
+        if missing:
+            raise ValueError('missing field `%s`' % missing[0])          # serde's message
+        return cls(G1Point.from_json(j['a']), G2Point.from_json(j['b']), G1Point.from_json(j['c']))
+
+    def to_json_str(self):
+        import json as _json
+        return _json.dumps(self.to_json(), separators=(',', ':'))           # serde_json::to_string's compact form, field order a, b, c
+
+
+class VK:
+    """verifier.rs:10-18 -- alpha (G1), beta, gamma, delta (G2), ic (Vec<G1>) as canonical coordinates.  Borsh = the five fields in order,
+    `ic` as a u32 LE count + points (verifier.rs:46-54); serde = {"alpha", "beta", "gamma", "delta", "ic"} (derived, verifier.rs:10-11)."""
+
+    def __init__(self, alpha, beta, gamma, delta, ic):
+        self.alpha, self.beta, self.gamma, self.delta, self.ic = alpha, beta, gamma, delta, list(ic)
+
+    def to_bytes(self):
+        return (self.alpha.to_bytes() + self.beta.to_bytes() + self.gamma.to_bytes() + self.delta.to_bytes() +
+                len(self.ic).to_bytes(4, 'little') + b''.join(p.to_bytes() for p in self.ic))
+
+    @classmethod
+    def from_bytes(cls, b):
+        b = bytes(b)
+        if len(b) < 64 + 3 * 128 + 4:
+            raise ValueError('Unexpected length of input')            # Borsh's message
+        n = int.from_bytes(b[448:452], 'little')
+        if len(b) != 452 + 64 * n:
+            raise ValueError('Unexpected length of input')
+        return cls(G1Point.from_bytes(b[:64]), G2Point.from_bytes(b[64:192]), G2Point.from_bytes(b[192:320]), G2Point.from_bytes(b[320:448]),
+                   [G1Point.from_bytes(b[452 + 64 * i:516 + 64 * i]) for i in range(n)])
+
+    @classmethod
+    def from_raw(cls, vk):
+        """from the dict fk_setup* / load_key_bellman return (raw Montgomery LE arrays: alpha_g1, beta_g2, gamma_g2, delta_g2, ic)"""
+        return cls.from_bytes(vk_to_borsh(vk))
+
+    def to_json(self):
+        return {'alpha': self.alpha.to_json(), 'beta': self.beta.to_json(), 'gamma': self.gamma.to_json(), 'delta': self.delta.to_json(),
+                'ic': [p.to_json() for p in self.ic]}
+
+    @classmethod
+    def from_json(cls, j):
+        if isinstance(j, (str, bytes)):
+            import json as _json
+            j = _json.loads(j)
+        missing = [k for k in ('alpha', 'beta', 'gamma', 'delta', 'ic') if k not in j]
+        if missing:
+            raise ValueError('missing field `%s`' % missing[0])
+        return cls(G1Point.from_json(j['alpha']), G2Point.from_json(j['beta']), G2Point.from_json(j['gamma']), G2Point.from_json(j['delta']),
+                   [G1Point.from_json(p) for p in j['ic']])
+
+    def to_json_str(self):
+        import json as _json
+        return _json.dumps(self.to_json(), separators=(',', ':'))
 
     def __eq__(self, o):
         return self.to_bytes() == o.to_bytes()
@@ -1061,6 +1172,28 @@ class MultiContext:
         """text left by fk_init_devices / the last call (e.g. why RCCL was not used)"""
         msg = self.lib.fk_multi_last_error(self.handle)
         return msg.decode() if msg else ''
+
+    PEER_STATES = {0: 'self', 1: 'direct', 2: 'staged (not reachable)', 3: 'staged (enable refused)'}
+
+    def topology(self):
+        """fk_multi_topology: N x N list of strings -- entry [i][j] says how copies INTO rank i's device FROM rank j's travel:
+        'self' (same device), 'direct' (peer access granted: DMA over xGMI), 'staged (...)' (the runtime stages them)"""
+        n = self.size
+        out = (C.c_int32 * (n * n))()
+        self._ck(self.lib.fk_multi_topology(self.handle, out))
+        return [[self.PEER_STATES.get(int(out[i * n + j]), '?') for j in range(n)] for i in range(n)]
+
+    def preflight(self, nbytes=64 << 20):
+        """fk_multi_preflight: one verified, timed `nbytes` pull per ordered pair of ranks behind a cross-device event wait.  Returns
+        dict(ok, gbps (N x N), status (N x N), host_events (the library switched itself to host-side event waits), note).  Never raises for
+        a failing pair: the caller decides what to do with a node whose links do not work."""
+        n = self.size
+        gb = (C.c_double * (n * n))()
+        st = (C.c_int32 * (n * n))()
+        he = C.c_int(0)
+        rc = self.lib.fk_multi_preflight(self.handle, C.c_size_t(int(nbytes)), gb, st, C.byref(he))
+        return dict(ok=rc == 0, rc=int(rc), bytes=int(nbytes), gbps=[[round(float(gb[i * n + j]), 2) for j in range(n)] for i in range(n)],
+                    status=[[int(st[i * n + j]) for j in range(n)] for i in range(n)], host_events=bool(he.value), note=self.note())
 
     def close(self):
         if getattr(self, 'handle', None):

@@ -50,6 +50,20 @@ namespace fk {
 
 std::string &tls_error() { static thread_local std::string e; return e; }      // what fk_last_error(NULL) returns
 
+// Threads of a host-side fan-out.  Joined on EVERY path out of the scope -- an exception between two thread starts must not destroy a joinable
+// std::thread (std::terminate inside an extern "C" entry point, which fk_guard cannot turn into a status code: ADVICE r5) -- and a share whose
+// thread cannot be started (std::system_error: EAGAIN, the thread limit; or no memory for the vector) runs on the calling thread instead.
+// Only for shares that terminate on their own (a fixed range, or a loop over a shared atomic counter).
+struct ThreadSet {
+    std::vector<std::thread> t;
+    template <class F> void run(F f) {
+        try { t.emplace_back(f); }
+        catch (const std::exception &) { f(); }
+    }
+    void join() { for (auto &x : t) if (x.joinable()) x.join(); t.clear(); }
+    ~ThreadSet() { join(); }
+};
+
 // host threads this process may use: FK_HOST_THREADS, else the affinity mask capped by the cgroup CPU quota (a container can
 // show 256 CPUs and be allowed the time of 16), at most 64
 unsigned host_threads() {
@@ -251,7 +265,10 @@ struct Decoder {
     size_t in_flight = 0, max_in_flight = 4;
     bool closed = false;
     std::atomic<bool> failed{false};
-    uint64_t err_seq = ~0ull; int err_code = FK_ERR_FORMAT; std::string err;    // the error of the EARLIEST block (what a serial parser would have hit first)
+    // the error of the EARLIEST block (what a serial parser would have hit first).  err_seq is read by the workers without the lock: a block is
+    // skipped only when it lies BEHIND the earliest failure known so far -- a block in front of it is still parsed and may replace the recorded
+    // error, so that the message and the FORMAT / OOM code do not depend on which worker got to which block first
+    std::atomic<uint64_t> err_seq{~0ull}; int err_code = FK_ERR_FORMAT; std::string err;
     double parse_s = 0;
 
     explicit Decoder(fk_gates *g_) : g(g_) {
@@ -264,7 +281,7 @@ struct Decoder {
 
     void fail(uint64_t seq, int code, const char *msg) {
         std::lock_guard<std::mutex> lock(mu);
-        if (seq < err_seq) { err_seq = seq; err_code = code; try { err = msg; } catch (...) {} }
+        if (seq < err_seq.load(std::memory_order_relaxed)) { err_seq.store(seq, std::memory_order_relaxed); err_code = code; try { err = msg; } catch (...) {} }
         failed.store(true);
         cv_room.notify_all();
     }
@@ -289,7 +306,7 @@ struct Decoder {
                 b = std::move(queue.front()); queue.pop_front();
             }
             const double t0 = now_s();
-            if (!failed.load(std::memory_order_relaxed)) try {
+            if (b->seq < err_seq.load(std::memory_order_relaxed)) try {
                 const uint8_t *p = b->data;
                 uint64_t run[3] = {b->off[0], b->off[1], b->off[2]};
                 uint64_t ordinal = 0;
@@ -551,14 +568,14 @@ static int gates_decode(fk_ctx *ctx, const uint8_t *blob, size_t len, int format
     for (size_t i = 0; i < nt; i++) { perm[order[i]] = (uint32_t)i; g->table[i] = dec.dict.table[order[i]]; if (order[i] != i) identity = false; }
     if (!identity) {
         const unsigned nth = small ? 1 : n_workers;
-        std::vector<std::thread> rt;
+        ThreadSet rt;
         for (int k = 0; k < 3; k++) {
             uint32_t *c = g->cidx[k].as<uint32_t>();
             const uint64_t n = g->nnz[k];
             for (unsigned t = 0; t < nth; t++)
-                rt.emplace_back([=, &perm] { for (uint64_t i = n * t / nth, e = n * (t + 1) / nth; i < e; i++) c[i] = perm[c[i]]; });
+                rt.run([=, &perm] { for (uint64_t i = n * t / nth, e = n * (t + 1) / nth; i < e; i++) c[i] = perm[c[i]]; });
         }
-        for (auto &x : rt) x.join();
+        rt.join();
     }
     const double t_end = now_s();
     if (getenv("FK_GATES_TRACE")) fprintf(stderr, "[fk] gates: wall %.2f brotli %.2f scan %.2f buffers %.2f dispatch %.2f (of it waiting %.2f) join+renumber %.2f\n", t_end - t_start, t_brotli, t_scan, t_buf, t_disp, t_wait, t_end - t_join);
@@ -648,10 +665,10 @@ static int gates_encode(fk_ctx *ctx, const fk_r1cs *cs, uint32_t copies, int for
         tpl.resize(copy_bytes ? copy_bytes : 1);
         {
             const unsigned nth = (unsigned)std::min<uint64_t>(host_threads(), R ? R : 1);
-            std::vector<std::thread> th;
             std::atomic<uint64_t> next{0};
-            for (unsigned t = 0; t < nth; t++) th.emplace_back([&] { for (uint64_t u; (u = next.fetch_add(1)) < R;) format_range(0, unit_g[u], unit_g[u + 1], tpl.data() + gate_off[unit_g[u]]); });
-            for (auto &x : th) x.join();
+            ThreadSet th;
+            for (unsigned t = 0; t < nth; t++) th.run([&] { for (uint64_t u; (u = next.fetch_add(1)) < R;) format_range(0, unit_g[u], unit_g[u + 1], tpl.data() + gate_off[unit_g[u]]); });
+            th.join();
         }
         unit_patch.assign(R + 1, 0);
         uint64_t at = 0;
@@ -687,12 +704,12 @@ static int gates_encode(fk_ctx *ctx, const fk_r1cs *cs, uint32_t copies, int for
     if (format == FK_GATES_RAW) {
         if (!bl->mem.commit((size_t)total + 1)) FK_SET_ERR(ctx, FK_ERR_OOM, "gates: out of host memory for the raw gate stream");
         const unsigned nth = (unsigned)std::min<uint64_t>(host_threads(), n_units ? n_units : 1);
-        std::vector<std::thread> th;
         std::atomic<uint64_t> next{0};
-        for (unsigned t = 0; t < nth; t++) th.emplace_back([&] {
+        ThreadSet th;
+        for (unsigned t = 0; t < nth; t++) th.run([&] {
             for (uint64_t unit; (unit = next.fetch_add(1)) < n_units;) fill_unit(unit, bl->mem.base + (size_t)(unit / R) * copy_bytes + gate_off[unit_g[unit % R]]);
         });
-        for (auto &x : th) x.join();
+        th.join();
         bl->len = (size_t)total;
     } else {
         const BrotliEnc &be = brotli_enc();
@@ -713,7 +730,11 @@ static int gates_encode(fk_ctx *ctx, const fk_r1cs *cs, uint32_t copies, int for
         uint64_t consumed = 0, claimed = 0;            // units compressed so far; units handed to a formatting thread
         bool stop = false;
         std::vector<std::thread> th;
-        for (unsigned t = 0; t < nth; t++) th.emplace_back([&] {
+        th.reserve(nth);
+        // (declared BEFORE the first thread starts: whatever leaves this scope -- a status code, an exception between two thread starts -- first
+        // tells the formatters to stop and joins them; a joinable std::thread must never be destroyed: std::terminate inside an extern "C" entry)
+        struct J_ { std::mutex &mu; std::condition_variable &cv; bool &stop; std::vector<std::thread> &th; ~J_() { { std::lock_guard<std::mutex> l(mu); stop = true; } cv.notify_all(); for (auto &x : th) if (x.joinable()) x.join(); } } joiner{mu, cv, stop, th};
+        for (unsigned t = 0; t < nth; t++) try { th.emplace_back([&] {
             for (;;) {
                 uint64_t unit;
                 {
@@ -726,8 +747,8 @@ static int gates_encode(fk_ctx *ctx, const fk_r1cs *cs, uint32_t copies, int for
                 { std::lock_guard<std::mutex> lock(mu); holds[unit % ring] = (int64_t)unit; }
                 cv.notify_all();
             }
-        });
-        struct J_ { std::mutex &mu; std::condition_variable &cv; bool &stop; std::vector<std::thread> &th; ~J_() { { std::lock_guard<std::mutex> l(mu); stop = true; } cv.notify_all(); for (auto &x : th) if (x.joinable()) x.join(); } } joiner{mu, cv, stop, th};
+        }); } catch (const std::system_error &) { break; }        // the thread limit: go on with the formatters that did start
+        if (th.empty()) FK_SET_ERR(ctx, FK_ERR_OOM, "gates: no formatting thread could be started");
         size_t out_len = 0;
         double t_enc = 0;
         auto pump = [&](int op, const uint8_t *src, size_t n) -> int {

@@ -111,6 +111,8 @@ struct fk_multi {
     bool force_exchange = false;                        // FK_MULTI_FORCE_EXCHANGE=1: run the distributed schedule (exchanges with itself) even with ONE rank -- test aid
     std::vector<void *> comms;                          // FK_MULTI_TRANSPORT=rccl: one RCCL communicator per rank (empty: peer copies)
     std::vector<void *> comms_z;                        // ... and a second set for the witness all-gather, which is issued on the copy streams while a proof's exchanges may be in flight
+    std::vector<int32_t> peer;                          // n x n: what fk_init_devices found for every ordered pair of ranks (FK_PEER_*: fk_multi_topology)
+    std::vector<int32_t> peer_hip;                      // ... and the HIP error code of a refused hipDeviceEnablePeerAccess (0 otherwise)
     bool whole_witness = false;                         // FK_MULTI_WITNESS=whole: every rank uploads the whole witness over its own PCIe link (rounds 3-4)
     uint64_t z_bytes_uploaded = 0, z_bytes_gathered = 0;   // per hand-over, summed over the ranks: host -> device, device -> device
     // barrier of the rank threads
@@ -418,17 +420,33 @@ int fk_init_devices(int n_devices, const int *device_ids, fk_multi **out) {
         for (int j = 0; j < n_devices; j++) same += device_ids[j] == device_ids[i];
         M->ctx[i]->co_tenants = same;
     }
-    // direct access between every pair of distinct devices (xGMI); "already enabled" is fine, a refusal leaves the copies staged by the runtime
-    for (int i = 0; i < n_devices && rc == FK_OK; i++)
-        for (int j = 0; j < n_devices; j++) {
-            if (device_ids[i] == device_ids[j]) continue;
-            int can = 0;
-            if (hipDeviceCanAccessPeer(&can, device_ids[i], device_ids[j]) == hipSuccess && can) {
+    // direct access between every pair of distinct devices (xGMI).  "already enabled" is fine; a refusal leaves the copies staged by the runtime --
+    // and is RECORDED per ordered pair (fk_multi_topology), with a note in fk_multi_last_error: a first run on a real node must be able to say
+    // whether its exchanges went direct or staged (the result used to be dropped)
+    M->peer.assign((size_t)n_devices * n_devices, FK_PEER_SELF);
+    M->peer_hip.assign((size_t)n_devices * n_devices, 0);
+    {
+        int staged = 0, refused = 0;
+        for (int i = 0; i < n_devices && rc == FK_OK; i++)
+            for (int j = 0; j < n_devices; j++) {
+                if (device_ids[i] == device_ids[j]) continue;
+                int32_t &st = M->peer[(size_t)i * n_devices + j];
+                int can = 0;
+                const hipError_t ec = hipDeviceCanAccessPeer(&can, device_ids[i], device_ids[j]);
+                if (ec != hipSuccess || !can) { st = FK_PEER_STAGED; M->peer_hip[(size_t)i * n_devices + j] = (int32_t)ec; staged++; (void)hipGetLastError(); continue; }
                 (void)hipSetDevice(device_ids[i]);
-                (void)hipDeviceEnablePeerAccess(device_ids[j], 0);
+                const hipError_t ee = hipDeviceEnablePeerAccess(device_ids[j], 0);
                 (void)hipGetLastError();
+                if (ee == hipSuccess || ee == hipErrorPeerAccessAlreadyEnabled) st = FK_PEER_DIRECT;
+                else { st = FK_PEER_REFUSED; M->peer_hip[(size_t)i * n_devices + j] = (int32_t)ee; refused++; }
             }
+        if (staged || refused) {
+            char b[200];
+            snprintf(b, sizeof b, "note: peer access missing for %d ordered device pairs (%d not reachable, %d refused) -- their copies are staged by the runtime (fk_multi_topology)",
+                     staged + refused, staged, refused);
+            M->err = b;
         }
+    }
     for (int i = 0; i < n_devices && rc == FK_OK; i++) {
         M->ranks.emplace_back();
         MultiRank &rk = M->ranks.back();
@@ -489,6 +507,97 @@ void fk_multi_free(fk_multi *M) {
 
 // which transport the exchanges use: "rccl" or "peer-dma"
 const char *fk_multi_transport(const fk_multi *M) { return (M && !M->comms.empty()) ? "rccl" : "peer-dma"; }
+
+// what fk_init_devices found per ordered pair of ranks: out[i * n + j] = FK_PEER_* for copies INTO rank i's device FROM rank j's
+int fk_multi_topology(const fk_multi *M, int32_t *out) {
+    if (!M || !out) return FK_ERR_BAD_ARG;
+    for (size_t k = 0; k < M->peer.size(); k++) out[k] = M->peer[k];
+    return FK_OK;
+}
+
+// First contact with a node's links, before any key is built: for every ordered pair of ranks (i, j), i != j, rank j fills `bytes` bytes of its
+// device with a pattern of the pair ON ITS MAIN STREAM and records an event; rank i's exchange stream waits for that event (in the stream, or on
+// the host with FK_MULTI_HOST_EVENTS) and pulls the bytes -- hipMemcpyPeerAsync between distinct devices, exactly what every exchange of a proof
+// does -- timed by an event pair on that stream; the bytes are then compared on the host.  One pair at a time (a link's own rate, not the
+// node's).  gbps[i * n + j] = GB/s of the pull, status[i * n + j] = FK_OK / FK_ERR_* (0 on the diagonal).  If the in-stream cross-device wait of
+// the first distinct-device pair FAILS and the host-side wait works, the context switches itself to host-side waits (what FK_MULTI_HOST_EVENTS=1
+// selects) and says so: *host_events_out = 1 and a note in fk_multi_last_error.  Returns FK_OK when every pair passed.
+int fk_multi_preflight(fk_multi *M, size_t bytes, double *gbps, int32_t *status, int *host_events_out) { return fk_guard(M, [&]() -> int {
+    if (!M || !gbps || !status || bytes < 64 || bytes > ((size_t)1 << 32) || (bytes & 7)) return FK_ERR_BAD_ARG;
+    const int n = M->n;
+    for (int k = 0; k < n * n; k++) { gbps[k] = 0.0; status[k] = FK_OK; }
+    if (host_events_out) *host_events_out = M->host_event_wait ? 1 : 0;
+    std::vector<uint64_t> want(bytes / 8), got(bytes / 8);
+    std::vector<void *> buf(n, nullptr), dst(n, nullptr);
+    int rc = FK_OK;
+    auto fail = [&](int i, int j, int code, const char *what, hipError_t e) {
+        status[i * n + j] = code;
+        char b[256]; snprintf(b, sizeof b, "preflight: pair (into rank %d / device %d, from rank %d / device %d): %s%s%s", i, M->dev[i], j, M->dev[j], what,
+                              e != hipSuccess ? ": " : "", e != hipSuccess ? hipGetErrorString(e) : "");
+        M->err = b;
+        (void)hipGetLastError();
+        rc = code;
+    };
+    for (int r = 0; r < n; r++) {
+        if (hipSetDevice(M->dev[r]) != hipSuccess || hipMalloc(&buf[r], bytes) != hipSuccess || hipMalloc(&dst[r], bytes) != hipSuccess) { M->err = "preflight: hipMalloc failed"; rc = FK_ERR_OOM; break; }
+    }
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    for (int i = 0; i < n && rc != FK_ERR_OOM; i++) {
+        for (int j = 0; j < n; j++) {
+            if (i == j) continue;
+            fk_ctx *ci = M->ctx[i], *cj = M->ctx[j];
+            MultiRank &me = M->ranks[i], &peer = M->ranks[j];
+            uint64_t x = 0x9e3779b97f4a7c15ull * (uint64_t)(i * 64 + j + 1);
+            for (auto &w : want) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; w = x; }
+            // producer side: rank j's main stream
+            hipError_t e = hipSetDevice(M->dev[j]);
+            if (e == hipSuccess) e = hipMemcpyAsync(buf[j], want.data(), bytes, hipMemcpyHostToDevice, cj->stream);
+            if (e == hipSuccess) e = hipEventRecord(peer.ev_ready[0], cj->stream);
+            if (e != hipSuccess) { fail(i, j, FK_ERR_HIP, "producer side", e); continue; }
+            // consumer side: rank i's exchange stream
+            e = hipSetDevice(M->dev[i]);
+            if (e == hipSuccess && !t0) { e = hipEventCreate(&t0); if (e == hipSuccess) e = hipEventCreate(&t1); }
+            if (e == hipSuccess) e = hipMemsetAsync(dst[i], 0, bytes, me.xs);
+            if (e == hipSuccess) {
+                if (M->host_event_wait) e = hipEventSynchronize(peer.ev_ready[0]);
+                else {
+                    e = hipStreamWaitEvent(me.xs, peer.ev_ready[0], 0);
+                    if (e != hipSuccess && M->dev[i] != M->dev[j]) {
+                        // the cross-device wait is refused: fall back to the host-side wait for this and every later exchange
+                        (void)hipGetLastError();
+                        const hipError_t e2 = hipEventSynchronize(peer.ev_ready[0]);
+                        if (e2 == hipSuccess) {
+                            M->host_event_wait = true;
+                            if (host_events_out) *host_events_out = 1;
+                            M->err = std::string("note: preflight: hipStreamWaitEvent on another device's event failed (") + hipGetErrorString(e) + ") -- switched to host-side event waits (FK_MULTI_HOST_EVENTS)";
+                            e = hipSuccess;
+                        }
+                    }
+                }
+            }
+            if (e == hipSuccess) e = hipEventRecord(t0, me.xs);
+            if (e == hipSuccess) e = M->dev[i] == M->dev[j] ? hipMemcpyAsync(dst[i], buf[j], bytes, hipMemcpyDeviceToDevice, me.xs)
+                                                            : hipMemcpyPeerAsync(dst[i], M->dev[i], buf[j], M->dev[j], bytes, me.xs);
+            if (e == hipSuccess) e = hipEventRecord(t1, me.xs);
+            if (e == hipSuccess) e = hipStreamSynchronize(me.xs);
+            if (e != hipSuccess) { fail(i, j, FK_ERR_HIP, "pull", e); continue; }
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, t0, t1);
+            e = hipMemcpy(got.data(), dst[i], bytes, hipMemcpyDeviceToHost);
+            if (e != hipSuccess) { fail(i, j, FK_ERR_HIP, "read-back", e); continue; }
+            if (memcmp(got.data(), want.data(), bytes) != 0) { fail(i, j, FK_ERR_HIP, "the pulled bytes differ from the bytes written", hipSuccess); continue; }
+            gbps[i * n + j] = ms > 0.f ? (double)bytes / (ms * 1e-3) / 1e9 : 0.0;
+            (void)ci;
+        }
+    }
+    for (int r = 0; r < n; r++) {
+        (void)hipSetDevice(M->dev[r]);
+        if (buf[r]) (void)hipFree(buf[r]);
+        if (dst[r]) (void)hipFree(dst[r]);
+    }
+    if (t0) { (void)hipSetDevice(M->dev[0]); (void)hipEventDestroy(t0); (void)hipEventDestroy(t1); }
+    return rc;
+}); }
 
 const char *fk_multi_last_error(const fk_multi *M) { return M ? M->err.c_str() : "null multi-GPU context"; }
 int fk_multi_size(const fk_multi *M) { return M ? M->n : 0; }

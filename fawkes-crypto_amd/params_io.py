@@ -363,7 +363,7 @@ def store_parameters(key_arrays, r1cs, const_tracker_bits=(), compress=None):
 
 
 def store_parameters_dev(ctx, key, vk, r1cs, const_tracker_bits=(), compress=None, gates_blob=None, copies=None, quality=9, lgwin=22,
-                         timings=None):
+                         timings=None, alloc=None):
     """`Parameters::write` (mod.rs:150-157) for a key RESIDENT in HBM, at any size, as ONE uint8 array: fawkes' header from the host,
     the gate blob written natively (fk_gates_encode: Gate::serialize of every gate through libbrotlienc; setup.rs:25-32 uses quality 9 /
     lgwin 22 -- any setting decodes to the same stream; quality 2 is 16 x faster to write at 61 GB of stream and its blob decodes like a quality-9 one), the bellman part converted on the GPU
@@ -371,7 +371,9 @@ def store_parameters_dev(ctx, key, vk, r1cs, const_tracker_bits=(), compress=Non
     vk: the dict fk_setup* / load_key_bellman returned (gamma_g2, ic).  The gate blob is `gates_blob` as given (e.g. the blob the key
     was loaded with), or `compress(encode_gate_stream(r1cs))` when a `compress` callable is given (the slow per-term restatement: small
     systems, tests), or the native encoding of `copies` copies of `r1cs` (fk_r1cs_load_tiled's variable order; None = the system itself).
-    A blob of 4 GiB or more cannot be written: Borsh's Vec<u8> length is a u32 (the reference's writer fails the same way)."""
+    A blob of 4 GiB or more cannot be written: Borsh's Vec<u8> length is a u32 (the reference's writer fails the same way).
+    alloc(nbytes) -> writable uint8 array of that length, e.g. a numpy.memmap over a file several processes will read (bench.py --gpus N: every
+    rank sets its prover up from the same image); default: process memory."""
     import time
     tm = timings if timings is not None else {}
     t0 = time.perf_counter()
@@ -394,7 +396,10 @@ def store_parameters_dev(ctx, key, vk, r1cs, const_tracker_bits=(), compress=Non
         mid = struct.pack('<I', len(bits)) + struct.pack('<I', len(bv)) + bv
         t1 = time.perf_counter()
         need = ctx.write_key_bellman(key, vk, size_only=True)
-        image = np.empty(len(head) + blob.size + len(mid) + need, np.uint8)
+        total = len(head) + blob.size + len(mid) + need
+        image = np.empty(total, np.uint8) if alloc is None else alloc(total)
+        if image.dtype != np.uint8 or image.ndim != 1 or image.size != total:
+            raise ValueError('alloc(%d) must return a one-dimensional uint8 array of that length' % total)
         o = 0
         image[o:o + len(head)] = np.frombuffer(head, np.uint8); o += len(head)
         image[o:o + blob.size] = blob; o += blob.size

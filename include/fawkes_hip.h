@@ -496,6 +496,22 @@ const char *fk_multi_last_error(const fk_multi *multi);
 int fk_multi_size(const fk_multi *multi);
 /* "peer-dma" (hipMemcpyPeerAsync pulls, the default) or "rccl" */
 const char *fk_multi_transport(const fk_multi *multi);
+/* What fk_init_devices found when it asked for direct access between the ranks' devices (hipDeviceCanAccessPeer /
+ * hipDeviceEnablePeerAccess), per ORDERED pair: out[i * N + j] describes copies INTO rank i's device FROM rank j's.  A pair that is not
+ * FK_PEER_DIRECT still works -- the runtime stages its copies -- and fk_multi_last_error carries a note counting such pairs. */
+#define FK_PEER_SELF 0     /* both ranks name the same device */
+#define FK_PEER_DIRECT 1   /* peer access granted (or already on): hipMemcpyPeerAsync is device-to-device DMA over xGMI */
+#define FK_PEER_STAGED 2   /* hipDeviceCanAccessPeer says no: copies are staged by the runtime */
+#define FK_PEER_REFUSED 3  /* hipDeviceEnablePeerAccess refused: copies are staged by the runtime */
+int fk_multi_topology(const fk_multi *multi, int32_t *out);
+/* First contact with a node, before any key is built: for every ordered pair of ranks (i != j) a `bytes`-byte pull into rank i's device
+ * from rank j's on rank i's exchange stream, ordered behind an event recorded on rank j's main stream (the cross-device wait every
+ * exchange of a proof uses), timed with HIP events on that stream and compared byte for byte on the host; one pair at a time.
+ * gbps[i * N + j]: GB/s of the pull; status[i * N + j]: FK_OK or the failing code (the message of the last failure: fk_multi_last_error).
+ * If the in-stream wait on another device's event fails and the host-side wait works, the context switches ITSELF to host-side waits
+ * (what FK_MULTI_HOST_EVENTS=1 selects), sets *host_events_out = 1 (may be NULL) and leaves a note.  `bytes`: a multiple of 8, 64 .. 2^32.
+ * Returns FK_OK when every pair passed. */
+int fk_multi_preflight(fk_multi *multi, size_t bytes, double *gbps, int32_t *status, int *host_events_out);
 /* rank `rank`'s single-GPU context (statistics, calibration, building blocks); owned by the fk_multi */
 fk_ctx *fk_multi_ctx(fk_multi *multi, int rank);
 int fk_multi_sync(fk_multi *multi);

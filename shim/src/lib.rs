@@ -77,20 +77,40 @@ impl HipProver {
             b_g1: b1.as_ptr(), b_g2: b2.as_ptr(), n_b: bp.b_g1.len() as u64,
             shard_index: 0, shard_count: 1, z_frac_lo: ffi::FK_Z_EQUAL_SPLIT, z_frac_hi: ffi::FK_Z_EQUAL_SPLIT,
         };
+        // Everything acquired so far is owned by a guard whose Drop releases it: an `assert!` below that fails (no usable GPU, out of HBM, a
+        // malformed gate blob) unwinds through it, so a failed build leaves NOTHING behind in HBM or host memory (each failed build
+        // used to leak the key shards and the decoded gate arrays for the life of the process).
+        struct Building { multi: *mut ffi::fk_multi, key: *mut ffi::fk_multi_key, gates: *mut ffi::fk_gates, r1cs: *mut ffi::fk_multi_r1cs }
+        impl Drop for Building {
+            fn drop(&mut self) {
+                unsafe {
+                    if !self.gates.is_null() { ffi::fk_gates_free(self.gates); }
+                    if !self.multi.is_null() {
+                        if !self.r1cs.is_null() { ffi::fk_multi_r1cs_free(self.multi, self.r1cs); }
+                        if !self.key.is_null() { ffi::fk_multi_key_free(self.multi, self.key); }
+                        ffi::fk_multi_free(self.multi);
+                    }
+                }
+            }
+        }
+        let mut b = Building { multi: ptr::null_mut(), key: ptr::null_mut(), gates: ptr::null_mut(), r1cs: ptr::null_mut() };
         unsafe {
-            let (mut multi, mut key, mut gates, mut r1cs) = (ptr::null_mut(), ptr::null_mut(), ptr::null_mut(), ptr::null_mut());
-            let rc = ffi::fk_init_devices(device_ids.len() as i32, device_ids.as_ptr(), &mut multi);
+            let rc = ffi::fk_init_devices(device_ids.len() as i32, device_ids.as_ptr(), &mut b.multi);
             assert!(rc == ffi::FK_OK, "fk_init_devices: no usable MI355X (there is no CPU fallback)");
             // shard g of every key array goes to device_ids[g] (desc.shard_* are ignored by the multi-GPU loader)
-            let rc = ffi::fk_multi_key_load(multi, &desc, &mut key);
-            assert!(rc == ffi::FK_OK, "fk_multi_key_load: {}", last_error(multi));
+            let rc = ffi::fk_multi_key_load(b.multi, &desc, &mut b.key);
+            assert!(rc == ffi::FK_OK, "fk_multi_key_load: {}", last_error(b.multi));
             // the gate blob is decoded once on the host (ctx = NULL), then uploaded to every GPU
-            let rc = ffi::fk_gates_decode(ptr::null_mut(), params.2.as_ptr(), params.2.len(), ffi::FK_GATES_BROTLI, params.1, num_input, num_aux, &mut gates);
+            let rc = ffi::fk_gates_decode(ptr::null_mut(), params.2.as_ptr(), params.2.len(), ffi::FK_GATES_BROTLI, params.1, num_input, num_aux, &mut b.gates);
             assert!(rc == ffi::FK_OK, "fk_gates_decode failed ({}): {}", rc, CStr::from_ptr(ffi::fk_last_error(ptr::null())).to_string_lossy());
-            let rc = ffi::fk_multi_r1cs_load_gates(multi, gates, &mut r1cs);
-            ffi::fk_gates_free(gates);
-            assert!(rc == ffi::FK_OK, "fk_multi_r1cs_load_gates: {}", last_error(multi));
-            HipProver { multi, key, r1cs }
+            let rc = ffi::fk_multi_r1cs_load_gates(b.multi, b.gates, &mut b.r1cs);
+            ffi::fk_gates_free(b.gates);
+            b.gates = ptr::null_mut();
+            assert!(rc == ffi::FK_OK, "fk_multi_r1cs_load_gates: {}", last_error(b.multi));
+            // finished: ownership moves to the prover (whose own Drop frees the same three handles)
+            let out = HipProver { multi: b.multi, key: b.key, r1cs: b.r1cs };
+            b.multi = ptr::null_mut(); b.key = ptr::null_mut(); b.r1cs = ptr::null_mut();
+            out
         }
     }
 
@@ -187,8 +207,14 @@ pub fn prove_hip<'a, E: Engine, Pub: Signal<WitnessCS<'a, E::Fr>>, Sec: Signal<W
 
 type CacheKey = (usize, u32, usize, usize, [u8; 64], Vec<i32>);
 
-fn cache() -> &'static Mutex<HashMap<CacheKey, Arc<Mutex<HipProver>>>> {
-    static CACHE: OnceLock<Mutex<HashMap<CacheKey, Arc<Mutex<HipProver>>>>> = OnceLock::new();
+/// One entry of the cache: the prover of a key, or the marker that some thread is building it.  The map's own lock is held only to find or
+/// insert a slot; the BUILD happens under the slot's lock, so (a) exactly one thread builds a given key while the others wait on that slot and
+/// then share the result -- N first calls for the same `Parameters` do not run N key loads, level derivations and 61 GB gate decodes side by side
+/// on the same GPU, each planning against HBM the others are about to take -- and (b) proofs of OTHER keys go on meanwhile.
+pub struct Slot { prover: Mutex<Option<HipProver>> }
+
+fn cache() -> &'static Mutex<HashMap<CacheKey, Arc<Slot>>> {
+    static CACHE: OnceLock<Mutex<HashMap<CacheKey, Arc<Slot>>>> = OnceLock::new();
     CACHE.get_or_init(|| Mutex::new(HashMap::new()))
 }
 
@@ -208,24 +234,28 @@ fn cache_key<E: Engine>(params: &Parameters<E>, devices: &[i32]) -> CacheKey {
     (params as *const _ as usize, params.1, bp.h.len(), bp.l.len(), tag, devices.to_vec())
 }
 
-/// A panic while a lock was held (a failed key load, a failed proof) poisons a std Mutex; the state behind ours stays usable -- the map
-/// holds only finished provers, and the C library clears whatever a failed call had in flight -- so a poisoned lock is simply taken over.
+/// A panic while a lock was held (a failed key load, a failed proof) poisons a std Mutex; the state behind ours stays usable -- a slot
+/// holds a finished prover or None, and the C library clears whatever a failed call had in flight -- so a poisoned lock is simply taken over.
 /// (The reference's `prove` has no shared state and survives a caught panic; so does this one.)
 fn lock_ignoring_poison<T>(m: &Mutex<T>) -> std::sync::MutexGuard<'_, T> {
     m.lock().unwrap_or_else(|e| e.into_inner())
 }
 
-/// The cached prover of (`params`, FK_DEVICES), built on first use.  A `Parameters` value that is dropped should be `forget`-ed:
-/// the cache cannot see a drop, and HBM is released only when the entry goes.
-/// The prover is built OUTSIDE the map's lock (a key load takes seconds to minutes and may panic -- no usable GPU, out of HBM): other
-/// keys' proofs go on meanwhile, and a failed build leaves the map as it was.  Two threads that race for the same new key both build
-/// one; the loser's is dropped (its HBM freed) and everybody uses the winner's.
-pub fn resident_prover<E: Engine>(params: &Parameters<E>) -> Arc<Mutex<HipProver>> {
+/// The cached prover of (`params`, FK_DEVICES), built on first use, handed out LOCKED (the C ABI allows one proof at a time per prover).
+/// A `Parameters` value that is dropped should be `forget`-ed: the cache cannot see a drop, and HBM is released only when the entry goes.
+/// The map's lock is held only while the slot is looked up or inserted.  The first thread to lock an empty slot builds the prover inside it
+/// (seconds to minutes; may panic -- no usable GPU, out of HBM); threads that want the same key meanwhile wait on the slot and find it
+/// filled.  A build that panics unwinds with the slot still empty (`HipProver::new` releases what it had acquired), the poisoned slot lock
+/// is taken over by the next caller, and that caller builds again -- a failed build never leaves a half-made or a leaked prover behind.
+pub fn with_resident_prover<E: Engine, R>(params: &Parameters<E>, f: impl FnOnce(&HipProver) -> R) -> R {
     let devices = devices_from_env();
     let key = cache_key(params, &devices);
-    if let Some(p) = lock_ignoring_poison(cache()).get(&key) { return p.clone(); }
-    let built = Arc::new(Mutex::new(HipProver::new(&devices, params)));      // may panic: nothing is locked here
-    lock_ignoring_poison(cache()).entry(key).or_insert(built).clone()
+    let slot = lock_ignoring_poison(cache()).entry(key).or_insert_with(|| Arc::new(Slot { prover: Mutex::new(None) })).clone();
+    let mut guard = lock_ignoring_poison(&slot.prover);
+    if guard.is_none() {
+        *guard = Some(HipProver::new(&devices, params));      // may panic: the slot stays None, nothing else is locked
+    }
+    f(guard.as_ref().unwrap())
 }
 
 /// Drops the cached prover(s) of `params` (all device lists): frees the key shards, levels and constraint system in HBM.
@@ -262,8 +292,7 @@ pub fn prove_with_rs<'a, E: Engine, Pub: Signal<WitnessCS<'a, E::Fr>>, Sec: Sign
     s: Num<E::Fr>,
 ) -> (Vec<Num<E::Fr>>, Proof<E>) {
     let (z, inputs, tracker_consumed) = host_witness::<E, Pub, Sec, C>(params, input_pub, input_sec, circuit);
-    let hip = resident_prover(params);
-    let bytes = { let guard = lock_ignoring_poison(&hip); guard.prove_bytes(&z, &r, &s) };      // the only stretch that holds the prover
+    let bytes = with_resident_prover(params, |hip| hip.prove_bytes(&z, &r, &s));      // the only stretch that holds the prover
     let proof = Proof::<E>::try_from_slice(&bytes).expect("proof bytes");
     assert!(tracker_consumed, "not all cached data used");                  // prover.rs:83
     (inputs, proof)

@@ -117,3 +117,34 @@ def brotli_decompress(data, cap=1 << 28):
     ok = dec.BrotliDecoderDecompress(len(data), bytes(data), C.byref(n), out)
     assert ok == 1, 'BrotliDecoderDecompress failed'
     return out.raw[:n.value]
+
+
+FULLSIZE_DIGESTS = os.path.join(GOLDEN, 'fullsize_digests.json')
+
+
+def fullsize_digest(name):
+    """entry `name` of tests/golden/fullsize_digests.json (made by tests/golden/make_fullsize_digests.py: the C oracle's 256 proof
+    bytes of a BASELINE configuration at its FULL size), or None when the file holds none"""
+    if not os.path.exists(FULLSIZE_DIGESTS):
+        return None
+    return golden('fullsize_digests.json')['entries'].get(name)
+
+
+def eddsa_batch_inputs(copies=4096):
+    """BASELINE configs[2] at full size, as tests/test_gpu_tiled.py::test_config2_full_batch_4096_signatures and
+    tests/golden/make_fullsize_digests.py both build it: three eddsa-poseidon signature circuits (oracle/fawkes_circuit.py), dealt
+    to `copies` instances by a seeded choice; r and s drawn from the same generator.
+    Returns (signatures, one (R1csC of ONE verifier), picks, z (tiled Montgomery witness), r, s)."""
+    import random
+    import fawkes_circuit as fc
+    rnd = random.Random(4096)
+    pp, jj = fc.PoseidonParams(4, 8, 54), fc.JubJubBN256()
+    sigs = [fc.eddsa_circuit(rnd.randrange(fc.FS), rnd.randrange(ref.R), rnd.randrange(fc.FS), pp, jj)[0] for _ in range(3)]
+    one = fx.r1cs_to_csr(sigs[0].r1cs())
+    rnd = random.Random(7)
+    picks = [rnd.randrange(3) for _ in range(copies)]
+    zs = [fx.witness_mont(c.z_in, c.z_aux) for c in sigs]
+    ni = one.num_input
+    z = np.ascontiguousarray(np.concatenate([zs[0][:1]] + [zs[p][1:ni] for p in picks] + [zs[p][ni:] for p in picks]))
+    r, s = fx.mont_fr(rnd.randrange(ref.R)), fx.mont_fr(rnd.randrange(ref.R))
+    return sigs, one, picks, z, r, s

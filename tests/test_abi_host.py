@@ -49,6 +49,49 @@ def test_proof_borsh_roundtrip_and_points():
     assert fk.G2Point.from_bytes(bytes(128)).is_zero()
 
 
+def test_serde_json_forms_of_proof_vk_and_points():
+    """serde-equivalent JSON of `Proof` / `VK` / `G1Point` / `G2Point` (prover.rs:11-17, verifier.rs:10-18, group.rs:12-13, 83-85 with
+    `Num`'s Serialize = its decimal string, ff-uint/src/num/mod.rs:445-459): shapes, field names and order as serde_json gives them, round
+    trips through both encodings, and `Num`'s deserialisation errors (digits only, at most 256 bits, below the modulus)."""
+    import json
+    import fawkes_crypto_amd as fk
+    from fawkes_crypto_amd import api
+    g = golden('proof_golden.json')
+    pf = fk.Proof.from_bytes(bytes.fromhex(g['proof']))
+    j = pf.to_json()
+    assert list(j) == ['a', 'b', 'c'] and len(j['a']) == 2 and len(j['b']) == 2 and len(j['b'][0]) == 2 and len(j['c']) == 2
+    assert all(isinstance(v, str) and v.isdigit() for v in j['a'] + j['b'][0] + j['b'][1] + j['c'])
+    assert j['a'][0] == str(int.from_bytes(pf.to_bytes()[:32], 'little'))           # canonical value, decimal
+    assert j['b'][0][1] == str(int.from_bytes(pf.to_bytes()[96:128], 'little'))      # b.x imaginary part: second of the first pair ("X+IY")
+    s = pf.to_json_str()
+    assert s.startswith('{"a":["') and ' ' not in s and json.loads(s) == j
+    assert fk.Proof.from_json(s) == pf and fk.Proof.from_json(j).to_bytes() == pf.to_bytes()
+    # the point at infinity is (0, 0) in both forms (group.rs:55)
+    assert fk.G1Point(0, 0).to_json() == ['0', '0'] and fk.G1Point.from_json(['0', '0']).is_zero()
+    assert fk.G2Point.from_json([['0', '0'], ['0', '0']]).is_zero()
+    # Num's Deserialize: upstream's three failures
+    for bad, msg in (('12a', 'Invalid character'), ('-1', 'Invalid character'), ('0x10', 'Invalid character'), ('1' * 80, 'Invalid length'),
+                     (str(api.FQ_MODULUS), 'Field overflow')):
+        with pytest.raises(ValueError, match=msg):
+            fk.G1Point.from_json([bad, '1'])
+    with pytest.raises(ValueError):
+        fk.G1Point.from_json([5, '1'])                  # a JSON number is not a Num
+    with pytest.raises(ValueError, match='missing field `c`'):
+        fk.Proof.from_json({'a': j['a'], 'b': j['b']})
+    assert api.num_from_json('', api.FQ_MODULUS) == 0 and api.num_from_json(str(api.FQ_MODULUS - 1), api.FQ_MODULUS) == api.FQ_MODULUS - 1
+    # VK: Borsh (verifier.rs:46-54) <-> JSON
+    pts = [fk.G1Point(1, 2), fk.G1Point(0, 0), fk.G1Point(api.FQ_MODULUS - 1, 7)]
+    g2 = fk.G2Point((3, 4), (5, 6))
+    vk = fk.VK(pts[0], g2, fk.G2Point((7, 8), (9, 10)), g2, pts)
+    b = vk.to_bytes()
+    assert len(b) == 64 + 3 * 128 + 4 + 3 * 64 and b[448:452] == (3).to_bytes(4, 'little')
+    vj = vk.to_json()
+    assert list(vj) == ['alpha', 'beta', 'gamma', 'delta', 'ic'] and vj['ic'][2] == [str(api.FQ_MODULUS - 1), '7'] and vj['gamma'] == [['7', '8'], ['9', '10']]
+    assert fk.VK.from_json(vk.to_json_str()) == vk and fk.VK.from_bytes(b) == vk and fk.VK.from_bytes(b).to_json() == vj
+    with pytest.raises(ValueError):
+        fk.VK.from_bytes(b[:-1])
+
+
 def test_sample_fr_rule():
     """bellman Fr::rand as driven by fawkes' OsRng (osrng.rs:13-17; SURVEY App. A.6)."""
     from fawkes_crypto_amd import api

@@ -312,3 +312,51 @@ def test_witness_all_gather_gloo(world):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok in results), results
+
+
+# ------------------------------------------------------------------------------------------ first-contact preflight (fawkes-crypto_amd/preflight.py)
+def _preflight_worker(rank, world, port, q):
+    for p in (ROOT,):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ['MASTER_PORT'] = str(port)
+    from fawkes_crypto_amd import preflight
+    try:
+        q.put((rank, preflight.run(rank, rank, world, 'gloo', True, 1000, 1 << 10, limit_s=60.0, token='test_%d' % port)))
+    except BaseException as e:      # noqa: BLE001
+        q.put((rank, repr(e)))
+
+
+def test_preflight_two_ranks_gloo_no_gpu():
+    """The preflight's host side with two ranks and NO GPU: each rank starts its child process, the children rendezvous over their own file store,
+    agree on a verdict (gloo all-reduce) and every rank reads the same decision.  Backend gloo: RCCL is not exercised (and says so); rank 0's library
+    part fails for want of a device and is REPORTED, not raised -- the block must come back whatever happens in the child."""
+    import multiprocessing as mp
+    mpc = mp.get_context('spawn')
+    q = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_preflight_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(60)
+    for r in (0, 1):
+        b = res[r]
+        assert isinstance(b, dict), b
+        assert b['ran'] is True and b['world'] == 2 and b['control_plane'] == 'gloo ok' and b['all_ranks_ok'] is True, b
+        assert b['rccl'] is None and b['rccl_world_size'] is None
+        assert b['decision']['backend'] == 'gloo' and b['decision']['host_events'] is False and 'RCCL not exercised' in b['decision']['why']
+        assert b['seconds'] > 0
+    lib = res[0]['library']
+    assert lib is not None and lib['ok'] is False and 'error' in lib          # no GPU here: reported
+    assert res[1]['library'] is None
+
+
+def test_preflight_child_that_dies_is_a_verdict_not_an_exception(tmp_path, monkeypatch):
+    """a child that cannot even start its control plane (world 2 announced, only one rank present: the store never fills) ends in a 'failed' verdict
+    within the time limit, and a requested nccl backend falls back to gloo"""
+    from fawkes_crypto_amd import preflight
+    monkeypatch.setenv('MASTER_PORT', str(_free_port()))
+    b = preflight.run(0, 0, 2, 'nccl', True, 100, 1 << 8, limit_s=3.0, token='lonely_%d' % os.getpid())
+    assert b['all_ranks_ok'] is False and b['decision']['backend'] == 'gloo' and 'gloo' in b['decision']['why']
