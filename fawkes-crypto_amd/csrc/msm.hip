@@ -575,13 +575,102 @@ static __device__ __forceinline__ void s2_scatter1n_body(const uint32_t *digits,
     }
 }
 
+// The same pass on a register diet (experiment builds, -DFK_S1_LEAN with -DFK_S1_NT=256): 32 VGPRs, so that one wave of it fits
+// into the 32 registers per SIMD lane that the G2 accumulation's two 240-register waves leave (profiles/r05_sort_kernel_resources.txt) and the pass
+// can run BESIDE that accumulation instead of waiting for drained compute units.  What the diet costs: no unrolling of the global loops (one load in
+// flight per lane, FK_S1_LEAN_VEC=4: one 16-byte load), 32-bit offsets inside the chunk, scheduling barriers that keep the compiler from software-
+// pipelining the write-out loop (which alone took the allocation from 32 to 46).  Same arguments, same result as s2_scatter1n_body.
+#ifdef FK_S1_LEAN
+#ifndef FK_S1_LEAN_TILE
+#define FK_S1_LEAN_TILE 4096
+#endif
+static constexpr uint32_t LEAN_TILE = FK_S1_LEAN_TILE;      // its own sub-tile: the production kernel of the same build keeps S1_TILE
+template <uint32_t NT>
+static __device__ __forceinline__ void s2_scatter1_lean_body(const uint32_t *digits, size_t n, size_t chunk, uint32_t nchunks, uint32_t LB,
+                                                              uint32_t nhi, const uint32_t *cnt1, const uint32_t *seg_start, uint32_t *tmp_idx,
+                                                              uint16_t *tmp_lo) {
+    constexpr uint32_t BPL = S2_MAX_HI / NT;
+    __shared__ uint32_t cursor[S2_MAX_HI];
+    __shared__ uint32_t lcnt[S2_MAX_HI];
+    __shared__ uint32_t lexc[S2_MAX_HI];
+    __shared__ uint32_t part[16];
+    __shared__ uint32_t stage_idx[LEAN_TILE];
+    __shared__ uint16_t stage_lo[LEAN_TILE];
+    __shared__ uint16_t stage_bin[LEAN_TILE];
+    __shared__ uint32_t stage_dig[LEAN_TILE];       // the sub-tile's digits: global memory is read once per entry
+    const uint32_t ch = blockIdx.x, w = blockIdx.y, tid = threadIdx.x;
+    const uint32_t *cnt = cnt1 + ((size_t)w * nchunks + ch) * nhi;
+    for (uint32_t b = tid; b < S2_MAX_HI; b += NT) cursor[b] = b < nhi ? seg_start[(size_t)w * nhi + b] + cnt[b] : 0;
+    const size_t c_lo = (size_t)ch * chunk, c_hi = c_lo + chunk < n ? c_lo + chunk : n;
+    const uint32_t lomask = (1u << LB) - 1;
+    uint32_t *oidx = tmp_idx + (size_t)w * n;
+    uint16_t *olo = tmp_lo + (size_t)w * n;
+    const uint32_t clen = (uint32_t)(c_hi > c_lo ? c_hi - c_lo : 0);
+    const uint32_t *dgc = digits + (size_t)w * n + c_lo;
+    const uint32_t base_idx = (uint32_t)c_lo;
+    for (uint32_t so = 0; so < clen; so += LEAN_TILE) {
+        const uint32_t cntt = clen - so < LEAN_TILE ? clen - so : LEAN_TILE;
+        const uint32_t *src = dgc + so;
+        const uint32_t sub = base_idx + so;
+        for (uint32_t b = tid; b < S2_MAX_HI; b += NT) lcnt[b] = 0;
+        __syncthreads();
+        // counting: the digits are parked in LDS (stage_idx) on the way, so global memory is read ONCE per entry
+#pragma clang loop unroll(disable)
+        for (uint32_t k = tid; k < cntt; k += NT) {
+            const uint32_t dd = src[k];
+            stage_dig[k] = dd;
+            const uint32_t bkt = dd & 0x7fffffffu;
+            if (bkt) atomicAdd(&lcnt[(bkt - 1) >> LB], 1u);
+        }
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        uint32_t c[BPL], mine = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < BPL; i++) { c[i] = lcnt[tid * BPL + i]; mine += c[i]; }
+        uint32_t total;
+        uint32_t ex = block_excl_scan_nt<NT>(mine, part, &total);
+#pragma unroll
+        for (uint32_t i = 0; i < BPL; i++) { lexc[tid * BPL + i] = ex; ex += c[i]; }
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        // placing: the digits come back out of LDS (stage_dig), each entry draws its slot from its bin's cursor
+#pragma clang loop unroll(disable)
+        for (uint32_t k = tid; k < cntt; k += NT) {
+            const uint32_t dd = stage_dig[k], bkt = dd & 0x7fffffffu;
+            if (bkt) {
+                const uint32_t bin = (bkt - 1) >> LB, q = atomicAdd(&lexc[bin], 1u);
+                stage_idx[q] = (sub + k) | (dd & 0x80000000u); stage_lo[q] = (uint16_t)((bkt - 1) & lomask); stage_bin[q] = (uint16_t)bin;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma clang loop unroll(disable)
+        for (uint32_t q = tid; q < total; q += NT) {
+            const uint32_t bn = stage_bin[q];
+            const uint32_t dst = cursor[bn] + (q - (lexc[bn] - lcnt[bn]));
+            oidx[dst] = stage_idx[q];
+            olo[dst] = stage_lo[q];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        for (uint32_t b = tid; b < S2_MAX_HI; b += NT) cursor[b] += lcnt[b];
+        __syncthreads();
+    }
+}
+#endif
+
 #define S2N_ARGS1 const uint32_t *digits, size_t n, size_t chunk, uint32_t nchunks, uint32_t LB, uint32_t nhi, const uint32_t *cnt1, const uint32_t *seg_start, uint32_t *tmp_idx, uint16_t *tmp_lo
 #define S2N_PASS1 digits, n, chunk, nchunks, LB, nhi, cnt1, seg_start, tmp_idx, tmp_lo
 __global__ __launch_bounds__(1024) void s2_scatter1_n1024_kernel(S2N_ARGS1) { s2_scatter1n_body<1024>(S2N_PASS1); }
 // experiment builds only (-DFK_S1_NT=256 -DFK_S1_TILE=4096 [-DFK_S1_NO_PREFETCH]): the same pass in thin workgroups -- one wave per SIMD and few registers,
 // which could sit BESIDE the G2 accumulation's two 226-register waves per SIMD (rounds 1-2 measured thin shapes underneath G1 accumulations only)
 #ifdef FK_S1_NT
+#ifdef FK_S1_LEAN
+__global__ __launch_bounds__(FK_S1_NT) void s2_scatter1_thin_kernel(S2N_ARGS1) { s2_scatter1_lean_body<FK_S1_NT>(S2N_PASS1); }
+#else
 __global__ __launch_bounds__(FK_S1_NT) void s2_scatter1_thin_kernel(S2N_ARGS1) { s2_scatter1n_body<FK_S1_NT>(S2N_PASS1); }
+#endif
 #endif
 
 // ------------------------------------------------------------------------------------------ bucket -> lane assignment

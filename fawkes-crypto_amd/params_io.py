@@ -242,7 +242,10 @@ def load_parameters(ctx, data, shard_index=0, shard_count=1, z_frac=(-1.0, -1.0)
     (DeviceKey resident in HBM, DeviceR1cs resident in HBM, header dict incl. gamma_g2 / ic / const_tracker for a verifier
     and for the witness generator).  The key part is converted and checked on the GPU (fk_key_load_bellman), the gate blob
     is decoded natively (api.Gates: one decompressing thread, the parsing on all host threads).  want_host_r1cs: also return the
-    decoded system as an api.R1cs in hdr['r1cs'].  timings: a dict that receives the seconds of every stage."""
+    decoded system as an api.R1cs in hdr['r1cs'].  timings: a dict that receives the seconds of every stage.
+    warm (default on, single-GPU loads only): while the decoder is still busy, one throw-away proof of the key's size over generated vectors
+    (timings['warm_up_s']; skipped -- timings['warm_up_skipped'] -- when the HBM left beside the levels would not cover the system still to
+    come).  Side effects: the context's grow-only proof scratch exists afterwards; fk_stats counters are reset if they were empty before."""
     import time
     tm = timings if timings is not None else {}
     t0 = time.perf_counter()
@@ -292,10 +295,22 @@ def load_parameters(ctx, data, shard_index=0, shard_count=1, z_frac=(-1.0, -1.0)
                 if warm and shard_count == 1 and th.is_alive():
                     # ... and if the decoder is STILL busy: one throw-away proof of the key's size over generated vectors, so that what a
                     # context sets up on its first proof (the transform tables of the domain: 1.2 s at 2^25; the multiplications' lane
-                    # scratch: 0.3 s) is in place when the caller's first proof comes (tools/load_probe.py: 1.6 -> 0.3 s in a fresh process)
-                    t1 = time.perf_counter()
-                    tm['warm_up_error'] = _warm_up(ctx, key, c)
-                    tm['warm_up_s'] = time.perf_counter() - t1
+                    # scratch: 0.3 s) is in place when the caller's first proof comes (tools/load_probe.py: 1.6 -> 0.3 s in a fresh process).
+                    # Only when the HBM left after the levels covers the resident system still to come (estimated from the key: 8 bytes per
+                    # matrix term, ~4 terms per row and matrix at fawkes' densities, + the warm-up's own a, b, c, z) -- on a smaller GPU the
+                    # warm-up's scratch must not be what pushes the system's upload into the drop-levels-and-retry path.
+                    est_system = 8 * 3 * 4 * int(hdr['num_gates']) + 32 * (3 * key.counts()['m'] + c['num_input'] + c['num_aux'])
+                    headroom = key.levels_headroom()
+                    if headroom < est_system:
+                        tm['warm_up_skipped'] = 'HBM headroom %.1f GiB < %.1f GiB the system and a throw-away proof would need' % (headroom / 2**30, est_system / 2**30)
+                    else:
+                        t1 = time.perf_counter()
+                        before = ctx.stats()
+                        tm['warm_up_error'] = _warm_up(ctx, key, c)
+                        # the throw-away proof is not the caller's: the kernel statistics (fk_stats_get) do not show it when they were empty before
+                        if all(v.get('launches', 0) == 0 for v in before.values()):
+                            ctx.stats_reset()
+                        tm['warm_up_s'] = time.perf_counter() - t1
         finally:
             th.join()
         if 'error' in box:

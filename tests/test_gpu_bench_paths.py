@@ -87,6 +87,75 @@ def test_bench_default_workload_small():
     assert j['kernel_ms_per_step']['ntt_sec8d_GBps'] > 0
 
 
+def _rank_run(n_ranks, copies, *extra):
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'FK_DIST_QUOTIENT')}
+    env['FK_BENCH_SAME_DEVICE'] = '1'
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(n_ranks), '--backend', 'gloo', '--steps', '2', '--warmup', '1',
+                          '--copies', str(copies), *extra], env=env, cwd=ROOT, capture_output=True, text=True, timeout=1800)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
+    return json.loads(out.stdout.strip().splitlines()[-1])
+
+
+@pytest.fixture(scope='module')
+def single_gpu_2p22():
+    """the single-GPU line at 217 transactions (4 181 809 rows on the 2^22 domain), through the Parameters image: the bytes every rank count must reproduce"""
+    j = _run({}, '--copies', '217', '--no-cpu-baseline', '--no-other-sizes', '--no-standalone', '--no-untiled')
+    assert j['config']['log2_domain'] == 22 and j['config']['matrix_form'] == 'explicit, from a Parameters gate blob'
+    return j
+
+
+@pytest.mark.parametrize('n_ranks', [2, 4, 8])
+def test_ranks_set_up_from_the_same_parameters_image_reproduce_the_single_gpu_bytes(single_gpu_2p22, n_ranks):
+    """`bench.py --gpus N` proves the SAME input form as N = 1 -- rank 0 writes one `Parameters` image, every rank sets its prover
+    up from it (load_parameters(image, shard = rank / world): fk_gates_decode once per process, fk_key_load_bellman(checked) of its slices), the
+    one-call leg through fk_multi_key_load_bellman + fk_multi_r1cs_load_gates -- and the proof bytes (both witnesses) equal the single-GPU run's.
+    2^22 rows, every rank-process on this box's one GPU (gloo)."""
+    j = _rank_run(n_ranks, 217, '--no-replicas')
+    assert j['n_gpus'] == n_ranks and j['config']['matrix_form'] == 'explicit, from a Parameters gate blob', j['config']['matrix_form']
+    assert j['proof_sha256'] == single_gpu_2p22['proof_sha256'] and len(j['proof_sha256']) == 2
+    assert j['proof_verified_by_pairing_check'] is True
+    ld = j['load']
+    assert ld['matrix_terms'] == sum(j['config']['nnz']) and ld['image_bytes'] > ld['blob_bytes'] > 0 and ld['one_rank_at_a_time'] is True
+    sp = j['single_process_multi_gpu']
+    assert sp['ranks'] == n_ranks and sp['ms_per_step'] > 0 and sp['matrix_form'] == 'explicit, from a Parameters gate blob', sp
+    assert len(sp['topology']) == n_ranks and all(c == 'self' for row in sp['topology'] for c in row)
+    pf = j['preflight']
+    assert pf['ran'] is True and pf['world'] == n_ranks and pf['all_ranks_ok'] is True and pf['decision']['backend'] == 'gloo', pf
+    lib = pf['library']
+    assert lib['ok'] is True and len(lib['pull_GBps']) == n_ranks and all(lib['pull_GBps'][i][k] > 0 for i in range(n_ranks) for k in range(n_ranks) if i != k), lib
+    assert all(v == 0 for row in lib['pull_status'] for v in row) and lib['host_events'] is False
+
+
+def test_launcher_with_one_rank_is_the_single_gpu_line(single_gpu_2p22):
+    """`--gpus 1` under the launcher's environment (RANK / WORLD_SIZE / LOCAL_RANK set, world 1) takes the single-GPU path: same form, same bytes, and
+    the `preflight` block is there with rccl_world_size 1"""
+    env = {'RANK': '0', 'WORLD_SIZE': '1', 'LOCAL_RANK': '0', 'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': '29547'}
+    j = _run(env, '--copies', '217', '--no-cpu-baseline', '--no-other-sizes', '--no-standalone', '--no-untiled')
+    assert j['proof_sha256'] == single_gpu_2p22['proof_sha256'] and j['config']['matrix_form'] == 'explicit, from a Parameters gate blob'
+    for line in (j, single_gpu_2p22):
+        pf = line['preflight']
+        assert pf['ran'] is True and pf['rccl_world_size'] == 1 and pf['rccl']['ok'] is True and pf['all_ranks_ok'] is True, pf
+        assert pf['rccl']['all_gather']['verified'] and pf['rccl']['all_to_all']['verified'] and pf['rccl']['all_gather_384']['verified']
+        assert pf['decision']['backend'] == 'nccl' and pf['library']['ok'] is True and pf['library']['pull_GBps'][0][1] > 0
+
+
+def test_roofline_blocks_say_what_they_are_and_traffic_is_measured_in_the_run():
+    """`frac` (union of the launches) beside `frac_per_launch` (rocprof's average launch), the G2 and NTT blocks, and -- with
+    --measure-traffic on -- `traffic` from PMC passes taken BY THIS RUN (rocprofv3 child processes) instead of an imported figure"""
+    j = _run({}, '--copies', '40', '--no-cpu-baseline', '--no-other-sizes', '--no-standalone', '--no-untiled', '--measure-traffic', 'on')
+    rl = j['roofline']
+    assert 0 < rl['frac_per_launch'] <= rl['frac'] * 1.0001 < 1 and rl['union_ms_per_launch'] <= rl['avg_launch_ms'] * 1.0001
+    assert 'avg_launch_ms_is' in rl and rl['algorithmic_bytes_per_scalar_mul'] == 96
+    for name, per in (('roofline_g2', 160), ('roofline_ntt', 64)):
+        b = j[name]
+        assert b['bound'] == 'hbm' and 0 < b['frac'] < 1 and 0 < b['frac_per_launch'] <= b['frac'] * 1.0001 and b['launches'] > 0, b
+        assert per in (b.get('algorithmic_bytes_per_scalar_mul'), b.get('algorithmic_bytes_per_element_transform'))
+    assert isinstance(j['legs'].get('measure_traffic'), float), j['legs']
+    assert rl.get('traffic_measured_error') is None, rl.get('traffic_measured_error')
+    assert rl['traffic'] > rl['achieved'] and rl['traffic_ratio'] > 1 and 'MEASURED BY THIS RUN' in rl['traffic_source'], rl
+    assert j['roofline_ntt']['traffic_ratio'] > 0.5 and j['roofline_g2']['traffic_ratio'] > 1
+
+
 def test_bench_plain_command_starts_its_own_ranks():
     """`python bench.py --gpus 2` with NO launcher and no WORLD_SIZE in the environment: bench.py starts the two ranks itself
     (fresh child processes, before it has touched the GPU) and relays rank 0's line.  Both ranks share this box's one GPU
@@ -121,6 +190,7 @@ def test_bench_plain_command_with_4_and_8_ranks(n_ranks):
     assert j['config']['distinct_witnesses_in_the_pipeline'] == 2
     assert j['single_process_multi_gpu']['ranks'] == n_ranks and j['single_process_multi_gpu']['ms_per_step'] > 0, j['single_process_multi_gpu']
     assert j['replica_proofs_per_sec'] > 0
+    assert j['config']['matrix_form'] == 'explicit, from a Parameters gate blob' and j['preflight']['all_ranks_ok'] is True
 
 
 def test_bench_synthetic_workload_small():

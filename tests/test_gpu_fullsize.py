@@ -19,6 +19,19 @@ import bn254_ref as ref
 pytestmark = pytest.mark.gpu
 
 
+def _digest(name, zs=None):
+    """the oracle's proof bytes of a full-size configuration (helpers.fullsize_digest), None when the entry was made for another witness set"""
+    import hashlib
+    from helpers import fullsize_digest
+    e = fullsize_digest(name)
+    if e is None:
+        return None
+    if zs is not None and e.get('witness_set_sha256') != hashlib.sha256(np.ascontiguousarray(zs).tobytes()).hexdigest():
+        return None
+    assert all(e['gpu_equal']) and all(e['pairing'])         # what the generator itself saw on the box that made the file
+    return e
+
+
 def _verifies(bench, vk, z_inputs, proof):
     try:
         return bench.pairing_check(vk, z_inputs, proof.tobytes())
@@ -97,6 +110,12 @@ def test_config3_2p25_filled_domain_single_gpu_and_one_call_on_8_ranks(ctx):
     assert all(v > 0 for v in key.precomputed().values()), key.precomputed()   # every array of the single-GPU key carries its fixed-base levels (merged bucket sets)
     want = ctx.prove_witness_dev(key, dr, d_z, r, s)
     assert _verifies(bench, vk, z[1:num_input], want)
+    # full-size parity against the ORACLE: tests/golden/fullsize_digests.json holds the 256 bytes oracle/groth16_oracle.c produced
+    # for this very system, key, witness pair, r and s (tests/golden/make_fullsize_digests.py).  Every route below is compared with `want`, hence with
+    # the oracle: pipelined, separate multiplications, the reloaded bellman key, ONE call on 8 ranks and on 2 ranks.
+    dg = _digest('rollup%d' % copies, zs)
+    assert dg is not None, 'tests/golden/fullsize_digests.json has no applicable entry for the %d-transaction system' % copies
+    assert want.tobytes().hex() == dg['proofs'][0], 'the single-GPU proof differs from the oracle\'s bytes at full size'
     # the product's own verifier (fk_verify, host) agrees with the oracle's, also on a proof for other public inputs
     vkb = fk.api.vk_to_borsh(vk)
     assert fk.api.verify(vkb, z[1:num_input], want.tobytes()) is True
@@ -111,6 +130,7 @@ def test_config3_2p25_filled_domain_single_gpu_and_one_call_on_8_ranks(ctx):
     want2 = ctx.prove_witness_dev(key, dr, d_z2, r, s)
     ctx.dev_free(d_z2)
     assert want2.tobytes() != want.tobytes() and _verifies(bench, vk, z2[1:num_input], want2)
+    assert want2.tobytes().hex() == dg['proofs'][1], 'the second witness\' proof differs from the oracle\'s bytes at full size'
     zp = [ctx.host_alloc(z.shape), ctx.host_alloc(z.shape)]
     zp[0][:] = z; zp[1][:] = z2
     tk = ctx.prove_witness_submit(key, dr, zp[0], r, s)
@@ -239,3 +259,45 @@ def test_full_size_properties_transform_round_trips_and_two_routes_to_one_multip
     p1 = ctx.msm_g1_dev(d_b + half * 64, d_s + half * 32, n_h - half)
     ctx.dev_free(d_b); ctx.dev_free(d_s)
     assert merged.tobytes() != bytes(64) and merged.tobytes() == np.asarray(co.g1_add(p0, p1)).tobytes()
+
+
+def test_config3_parameters_image_at_full_size_equals_the_oracle_bytes(ctx):
+    """The benchmark's own path at its full size inside the test suite: the 1741-transaction key and circuit WRITTEN as a `Parameters` image
+    (Parameters::write, mod.rs:150-157), everything dropped, the prover set up from the image alone (load_parameters: fk_gates_decode ->
+    fk_r1cs_load_gates, 1.64e9 explicit terms; fk_key_load_bellman(checked)) -- and both benchmark witnesses proved through the two-slot
+    host-witness pipeline: the 256 bytes equal the ORACLE's (tests/golden/fullsize_digests.json), which is what bench.py's `proof_sha256` names."""
+    import hashlib
+    import bench
+    from fawkes_crypto_amd import params_io as pio
+    copies = 1741
+    inst, zs = bench.load_rollup_instance()
+    dg = _digest('rollup%d' % copies, zs)
+    assert dg is not None
+    tox = {k: bench.mont(v) for k, v in bench.TOXIC.items()}
+    r, s = bench.mont(0xA11CE), bench.mont(0xB0B)
+    ctx.trim()
+    key, vk = ctx.setup(inst, copies=copies, **tox)
+    image = pio.store_parameters_dev(ctx, key, vk, inst, copies=copies, quality=2, lgwin=22)
+    key.free()
+    key, dr, hdr = pio.load_parameters(ctx, image, checked=True)
+    del image
+    assert sum(dr.info()['nnz']) > 1.6e9 and dr.info()['rows'] == dg['rows']
+    assert hashlib.sha256(np.asarray(hdr['ic'], np.uint8).tobytes()).hexdigest() == dg['vk_ic_sha256']
+    nv = dg['num_input'] + dg['num_aux']
+    zp = [ctx.host_alloc((nv, 4)), ctx.host_alloc((nv, 4))]
+    bench.tile_witness(zs, inst.num_input, copies, out=zp[0])
+    bench.tile_witness(zs[::-1], inst.num_input, copies, out=zp[1])
+    try:
+        tk = ctx.prove_witness_submit(key, dr, zp[0], r, s)
+        for i in range(3):
+            nxt = ctx.prove_witness_submit(key, dr, zp[(i + 1) & 1], r, s)
+            assert ctx.prove_witness_wait(tk).tobytes().hex() == dg['proofs'][i & 1], 'pipelined proof %d from the Parameters image differs from the oracle\'s bytes' % i
+            tk = nxt
+        ctx.prove_witness_wait(tk)
+        # one proof at a time (the chunked hand-over: fk_prove_r1cs)
+        assert ctx.prove_witness(key, dr, zp[1], r, s).tobytes().hex() == dg['proofs'][1]
+    finally:
+        for p_ in zp:
+            ctx.host_free(p_)
+        dr.free(); key.free()
+        ctx.trim()

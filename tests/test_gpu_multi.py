@@ -247,6 +247,30 @@ def test_multi_init_argument_checks():
         fk.MultiContext([0, 99])
 
 
+@pytest.mark.parametrize('host_events', [False, True])
+def test_topology_and_preflight_on_one_device_named_three_times(monkeypatch, host_events):
+    """fk_multi_topology / fk_multi_preflight where a one-GPU box can run them: three ranks on device 0 -- every pair is 'self',
+    every ordered pair's 16 MiB pull behind the other rank's event is verified and timed, with in-stream and with host-side event waits; the
+    argument checks of the preflight"""
+    import fawkes_crypto_amd as fk
+    if host_events:
+        monkeypatch.setenv('FK_MULTI_HOST_EVENTS', '1')
+    mc = fk.MultiContext([0, 0, 0])
+    try:
+        topo = mc.topology()
+        assert topo == [['self'] * 3] * 3
+        pf = mc.preflight(16 << 20)
+        assert pf['ok'] is True and pf['host_events'] is host_events and pf['bytes'] == 16 << 20, pf
+        for i in range(3):
+            for j in range(3):
+                assert pf['status'][i][j] == 0
+                assert (pf['gbps'][i][j] > 1.0) == (i != j), pf['gbps']          # a device-to-device copy inside one MI355X: far above 1 GB/s
+        bad = mc.preflight(12)                                                    # not a multiple of 8 / below 64 bytes
+        assert bad['ok'] is False and bad['rc'] == 1
+    finally:
+        mc.close()
+
+
 @pytest.mark.parametrize('transport', ['peer-dma', 'rccl'])
 def test_one_rank_runs_the_exchanges_over_both_transports(ctx, oracle, monkeypatch, transport):
     """FK_MULTI_FORCE_EXCHANGE=1: a single rank runs the distributed schedule -- seven exchanges with itself -- once with the

@@ -114,21 +114,23 @@ def test_eddsa_batch_tiled_equals_oracle(ctx, oracle, signatures):
 
 def test_config2_full_batch_4096_signatures(ctx, signatures):
     """BASELINE configs[2] at its full size: 4096 eddsa-poseidon verifiers as one R1CS (16.9 M gates, domain 2^25).
-    No CPU prover follows at this size, so: the proof satisfies the pairing equation for the 4096 public keys, fails it
-    when one of them is altered, and is the same proof on a second run."""
-    one = fx.r1cs_to_csr(signatures[0].r1cs())
+    The proof equals, byte for byte, the ORACLE's proof of the same batch (tests/golden/fullsize_digests.json, made by
+    tests/golden/make_fullsize_digests.py: oracle/groth16_oracle.c on the host cores), satisfies the pairing
+    equation for the 4096 public keys, fails it when one of them is altered, and is the same proof on a second run."""
+    import hashlib
+    from helpers import eddsa_batch_inputs, fullsize_digest
     copies = 4096
-    rnd = random.Random(7)
-    picks = [rnd.randrange(3) for _ in range(copies)]
-    zs = [fx.witness_mont(c.z_in, c.z_aux) for c in signatures]
-    z = _tile_z(zs, one.num_input, picks)
+    sigs, one, picks, z, r, s = eddsa_batch_inputs(copies)
+    assert [c.z_in for c in sigs] == [c.z_in for c in signatures]          # the shared builder is the module fixture's
     base_p = r1cs_product(one)
     dk, vk = ctx.setup(base_p, copies=copies, **TOX)
     dr = ctx.load_r1cs(base_p, copies=copies)
     assert dk.counts()['m'] == 1 << 25 and dr.info()['rows'] == copies * 4123 + 1 + copies
-    r, s = fx.mont_fr(rnd.randrange(ref.R)), fx.mont_fr(rnd.randrange(ref.R))
     proof = ctx.prove_witness(dk, dr, z, r, s)
     assert ctx.prove_witness(dk, dr, z, r, s).tobytes() == proof.tobytes()
+    dg = fullsize_digest('eddsa%d' % copies)
+    assert dg is not None and dg['witness_sha256'] == hashlib.sha256(z.tobytes()).hexdigest(), 'tests/golden/fullsize_digests.json: no entry for this batch'
+    assert proof.tobytes().hex() == dg['proofs'][0], 'the 4096-signature proof differs from the oracle\'s bytes'
     g1 = lambda b: ref.g1_from_raw_le(bytes(b)); g2 = lambda b: ref.g2_from_raw_le(bytes(b))
     pk = dict(alpha_g1=g1(vk['alpha_g1']), beta_g2=g2(vk['beta_g2']), gamma_g2=g2(vk['gamma_g2']), delta_g2=g2(vk['delta_g2']),
               ic=[g1(x.tobytes()) for x in vk['ic']])
