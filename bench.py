@@ -423,6 +423,9 @@ def other_size_leg(ctx, inst, zs, copies, tox, r, s, steps, check=True):
                'matrix_terms': int(sum(dr.info()['nnz'])), 'ms_per_step': ms, 'proofs_per_sec': 1e3 / ms, 'steps': steps,
                'device_resident_ms_per_step': dev_ms, 'msm_fixed_base_levels': key.precomputed(), 'levels_plan': key.levels_plan(), 'prep_seconds': prep,
                'witness_bytes_per_proof': nv * 32}
+        dg = check_digest(copies, True, zs, proofs)          # the oracle's bytes at this size, when committed (raises on a difference)
+        if dg is not None:
+            out['oracle_digest_check'] = dg
         if check:
             out['proof_verified_by_pairing_check'] = bool(pairing_check(vk, z_pin[0][1:num_input].copy(), proofs[0]) and
                                                           pairing_check(vk, z_pin[1][1:num_input].copy(), proofs[1]))
@@ -831,6 +834,12 @@ def main():
     # their real sizes, the peer-access table and a verified pull per device pair, in a child process with a time limit.  A failure selects the
     # documented fallback for THIS run (gloo-staged exchanges / host-side event waits) and is reported, instead of ending the run.
     preflight = None
+    # under a profiler (rocprofv3 preloads its library into every process it starts) neither the preflight's child nor the traffic leg's
+    # rocprofv3 children are started: never a profiler inside a profiler, never an extra GPU process inside a counter pass
+    under_profiler = 'rocprof' in os.environ.get('LD_PRELOAD', '').lower() or any(k.startswith(('ROCPROFILER_', 'ROCPROF_')) for k in os.environ)
+    if under_profiler:
+        args.no_preflight = True
+        args.measure_traffic = 'off'
     if not args.no_preflight and os.environ.get('FK_BENCH_PREFLIGHT', '1') != '0':
         from fawkes_crypto_amd import preflight as pf_mod
         dims_nv, dims_m = workload_dims(args)
@@ -1556,7 +1565,7 @@ def main():
         z_pin = []
         ctx.trim()
         torch.cuda.empty_cache()
-        pmc, err = measure_traffic_leg(args, log_m, (m - 1) + num_aux + n_a + n_b, n_b, n, max(30.0, args.max_seconds - (time.time() - t_start) - 20))
+        pmc, err = measure_traffic_leg(args, log_m, (m - 1) + num_aux + n_a + n_b, n_b, n, min(420.0, max(30.0, args.max_seconds - (time.time() - t_start) - 20)))
         leg_done('measure_traffic')
         if pmc is None:
             out['roofline']['traffic_measured_error'] = err

@@ -58,6 +58,9 @@ extern "C" {
     pub fn fk_init_devices(n_devices: c_int, device_ids: *const c_int, out: *mut *mut fk_multi) -> c_int;
     pub fn fk_multi_free(multi: *mut fk_multi);
     pub fn fk_multi_last_error(multi: *const fk_multi) -> *const c_char;
+    // first contact with a node: out[i * N + j] = FK_PEER_* for copies into rank i's device from rank j's; one verified, timed pull per ordered pair
+    pub fn fk_multi_topology(multi: *const fk_multi, out: *mut i32) -> c_int;
+    pub fn fk_multi_preflight(multi: *mut fk_multi, bytes: usize, gbps: *mut f64, status: *mut i32, host_events_out: *mut c_int) -> c_int;
     pub fn fk_multi_key_load(multi: *mut fk_multi, desc: *const fk_key_desc, out: *mut *mut fk_multi_key) -> c_int;
     pub fn fk_multi_key_free(multi: *mut fk_multi, key: *mut fk_multi_key);
     pub fn fk_multi_r1cs_load_gates(multi: *mut fk_multi, gates: *const fk_gates, out: *mut *mut fk_multi_r1cs) -> c_int;

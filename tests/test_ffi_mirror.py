@@ -17,7 +17,7 @@ HEADER = os.path.join(ROOT, 'include', 'fawkes_hip.h')
 
 OPAQUE = {'fk_ctx', 'fk_key', 'fk_r1cs_dev', 'fk_gates', 'fk_multi', 'fk_multi_key', 'fk_multi_r1cs', 'fk_blob'}
 STRUCTS = {'fk_key_desc', 'fk_timings', 'fk_r1cs'}
-C_SCALARS = {'int': 'i32', 'uint32_t': 'u32', 'uint64_t': 'u64', 'size_t': 'usize', 'double': 'f64', 'uint8_t': 'u8', 'char': 'char', 'void': 'void', 'unsigned': 'u32'}
+C_SCALARS = {'int': 'i32', 'int32_t': 'i32', 'uint32_t': 'u32', 'uint64_t': 'u64', 'size_t': 'usize', 'double': 'f64', 'uint8_t': 'u8', 'char': 'char', 'void': 'void', 'unsigned': 'u32'}
 RS_SCALARS = {'c_int': 'i32', 'i32': 'i32', 'u32': 'u32', 'u64': 'u64', 'usize': 'usize', 'f64': 'f64', 'u8': 'u8', 'c_char': 'char', 'c_void': 'void',
               'std::os::raw::c_char': 'char', 'std::ffi::c_void': 'void', 'std::os::raw::c_void': 'void'}
 # INTEGRATION.md spells the opaque types in CamelCase

@@ -3,15 +3,15 @@
 # Usage: bash tools/profile_round.sh [tag] [notest]      -> gpurun_out/<tag>/   (copy what is to be judged into profiles/)
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-TAG=${1:-r05}; O=gpurun_out/$TAG; mkdir -p $O
+TAG=${1:-r06}; O=gpurun_out/$TAG; mkdir -p $O
 # the profiled legs prove ONE system only (the default one): every proof in a pass has the same size, so the number of proofs in a
 # pass follows from its dispatch counts (tools/pmc_summary.py derives and cross-checks it)
-B="bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-untiled --no-standalone --no-other-sizes"
+B="bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-untiled --no-standalone --no-other-sizes --no-preflight --measure-traffic off"   # (never a profiler inside a profiler)
 if [ "${2:-}" != "notest" ]; then
   python3 -m pytest tests -m gpu -q --durations=10 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log; tail -4 $O/pytest_gpu.log
 fi
 python3 bench.py --steps 20 --warmup 5 > $O/bench.log 2>&1; tail -c 1500 $O/bench.log; echo
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o k -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-untiled --no-standalone --no-other-sizes > $O/kt.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o k -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-untiled --no-standalone --no-other-sizes --no-preflight --measure-traffic off > $O/kt.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -o f -- python3 $B > $O/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -o w -- python3 $B > $O/write.log 2>&1
 rocprofv3 --pmc VALUBusy VALUUtilization MemUnitBusy --output-format csv -d $O/derived -o d -- python3 $B > $O/derived.log 2>&1
