@@ -89,7 +89,10 @@ __global__ __launch_bounds__(256) void spmv_kernel(SpmvArgs a, const Fr *table, 
 // launch is one (matrix, class); a tiled system walks its copies in the outer order, so a copy's z stays in cache.
 // SLICED (b.rowlist = the residue-grouped lists, b.first_block = this rank's plan): group index -> (copy, position in the
 // residue group that copy needs); the row's result goes to out[(copy * base_gates + row) >> log_w].
-template <bool TILED, bool SLICED>
+// FAKE4 (experiment builds, FK_SPMV_FAKE4=1, TIMING ONLY -- the results are wrong): the kernel streams 4 bytes per term instead of 8 -- the coefficient
+// index is derived from the column (no cidx load) -- which is what a packed form (u16 coefficient index + u16 column offset inside a row block's
+// window) would stream at best: an upper bound on what that form can save (tools/spmv_untiled_probe.py).
+template <bool TILED, bool SLICED, bool FAKE4 = false>
 __global__ __launch_bounds__(256) void spmv_binned_kernel(SpmvArgs a, BinArgs b, const Fr *table, const Fr *z, uint32_t num_input, TileDims td, uint32_t copies, SliceArgs sl) {
     uint32_t s = 0;
     while (s + 1 < b.nseg && blockIdx.x >= b.first_block[s + 1]) s++;
@@ -121,13 +124,13 @@ __global__ __launch_bounds__(256) void spmv_binned_kernel(SpmvArgs a, BinArgs b,
     // four terms per step with ONE Montgomery reduction (Fp::dot4: 328 multiply-accumulates instead of 544) ...
     for (; k + 3 * (uint64_t)G < e; k += 4 * G) {
         const uint32_t c0 = var(col[k]), c1 = var(col[k + G]), c2 = var(col[k + 2 * G]), c3 = var(col[k + 3 * G]);
-        const uint32_t i0 = cidx[k], i1 = cidx[k + G], i2 = cidx[k + 2 * G], i3 = cidx[k + 3 * G];
+        const uint32_t i0 = FAKE4 ? (c0 & 4095u) : cidx[k], i1 = FAKE4 ? (c1 & 4095u) : cidx[k + G], i2 = FAKE4 ? (c2 & 4095u) : cidx[k + 2 * G], i3 = FAKE4 ? (c3 & 4095u) : cidx[k + 3 * G];
         acc = Fr::add(acc, Fr::dot4(z[c0], table[i0], z[c1], table[i1], z[c2], table[i2], z[c3], table[i3]));
     }           // (loading the NEXT step's indices ahead of this step's products was measured: 169.8 against 168.8 ms per proof)
     if (lg) {   // ... then two (one lane per row: the last terms one by one, ONE coefficients skipped)
         Fr acc1 = Fr::zero();
         for (; k + G < e; k += 2 * G) {        // table[0] is ONE: multiplying by it returns the (reduced) value itself
-            const uint32_t c0 = var(col[k]), c1 = var(col[k + G]), i0 = cidx[k], i1 = cidx[k + G];
+            const uint32_t c0 = var(col[k]), c1 = var(col[k + G]), i0 = FAKE4 ? (c0 & 4095u) : cidx[k], i1 = FAKE4 ? (c1 & 4095u) : cidx[k + G];
             Fr p0, p1;
             Fr::mul2(z[c0], table[i0], z[c1], table[i1], p0, p1);
             Fr::add2(acc, p0, acc1, p1, acc, acc1);
@@ -135,8 +138,9 @@ __global__ __launch_bounds__(256) void spmv_binned_kernel(SpmvArgs a, BinArgs b,
         acc = Fr::add(acc, acc1);
     }
     for (; k < e; k += G) {
-        Fr v = z[var(col[k])];
-        const uint32_t ci = cidx[k];
+        const uint32_t cv = var(col[k]);
+        Fr v = z[cv];
+        const uint32_t ci = FAKE4 ? (cv & 4095u) : cidx[k];
         if (ci) v = Fr::mul(v, table[ci]);
         acc = Fr::add(acc, v);
     }
@@ -666,6 +670,12 @@ int r1cs_eval_impl(fk_ctx *ctx, const fk_r1cs_dev *r, const void *d_z, void *d_a
         if (blocks) {
 #define FK_SPMVB_LAUNCH(T_, S_) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_binned_kernel<T_, S_>), dim3(blocks), dim3(256), 0, ctx->stream, a, b, r->table, (const Fr *)d_z, \
                                                    r->num_input, td, r->copies, sa)
+#ifdef FK_EXPERIMENTS
+            if (!tiled && !sliced && tune("FK_SPMV_FAKE4", 0) && r->n_table > 4096)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_binned_kernel<false, false, true>), dim3(blocks), dim3(256), 0, ctx->stream, a, b, r->table, (const Fr *)d_z,
+                                   r->num_input, td, r->copies, sa);
+            else
+#endif
             if (tiled) { if (sliced) FK_SPMVB_LAUNCH(true, true); else FK_SPMVB_LAUNCH(true, false); }
             else { if (sliced) FK_SPMVB_LAUNCH(false, true); else FK_SPMVB_LAUNCH(false, false); }
 #undef FK_SPMVB_LAUNCH

@@ -236,6 +236,32 @@ def _warm_up(ctx, key, counts):
                 pass
 
 
+def _maybe_warm_up(ctx, key, hdr, counts, tm):
+    """the loader's throw-away proof (see load_parameters), guarded: one proof of the key's size over generated vectors while the decoder is still
+    busy, so that what a context sets up on its first proof (the transform tables of the domain: 1.2 s at 2^25; the multiplications' lane scratch:
+    0.3 s) is in place when the caller's first proof comes (tools/load_probe.py: 1.6 -> 0.3 s in a fresh process).  Only when the HBM left after the
+    levels covers the resident system still to come (estimated from the header: 8 bytes per matrix term, ~4 terms per row and matrix at fawkes'
+    densities) and the warm-up's own a, b, c, z -- on a smaller GPU its scratch must not be what pushes the system's upload into the
+    drop-levels-and-retry path.  Never an error: anything that goes wrong here only means the first real proof does the work itself."""
+    import time
+    try:
+        m = 1 << max(int(counts['h']), 1).bit_length()          # h holds m - 1 points
+        est = 8 * 3 * 4 * int(hdr['num_gates']) + 32 * (3 * m + counts['num_input'] + counts['num_aux'])
+        headroom = key.levels_headroom()
+        if headroom < est:
+            tm['warm_up_skipped'] = 'HBM headroom %.1f GiB < the %.1f GiB the system and a throw-away proof would need' % (headroom / 2**30, est / 2**30)
+            return
+        t1 = time.perf_counter()
+        before = ctx.stats()
+        tm['warm_up_error'] = _warm_up(ctx, key, counts)
+        # the throw-away proof is not the caller's: the kernel statistics (fk_stats_get) do not show it when they were empty before
+        if all(v.get('launches', 0) == 0 for v in before.values()):
+            ctx.stats_reset()
+        tm['warm_up_s'] = time.perf_counter() - t1
+    except Exception as e:       # noqa: BLE001
+        tm['warm_up_error'] = repr(e)
+
+
 def load_parameters(ctx, data, shard_index=0, shard_count=1, z_frac=(-1.0, -1.0), checked=True, disallow_points_at_infinity=False,
                     want_host_r1cs=False, timings=None, overlap=True, early_levels=True, background_free=False, warm=True):
     """`Parameters::read(reader, disallow_points_at_infinity, checked)` (mod.rs:159-175) for the GPU prover: file bytes ->
@@ -293,24 +319,7 @@ def load_parameters(ctx, data, shard_index=0, shard_count=1, z_frac=(-1.0, -1.0)
                 tm['key_levels_s'] = time.perf_counter() - t1
                 tm['key_levels_early'] = True
                 if warm and shard_count == 1 and th.is_alive():
-                    # ... and if the decoder is STILL busy: one throw-away proof of the key's size over generated vectors, so that what a
-                    # context sets up on its first proof (the transform tables of the domain: 1.2 s at 2^25; the multiplications' lane
-                    # scratch: 0.3 s) is in place when the caller's first proof comes (tools/load_probe.py: 1.6 -> 0.3 s in a fresh process).
-                    # Only when the HBM left after the levels covers the resident system still to come (estimated from the key: 8 bytes per
-                    # matrix term, ~4 terms per row and matrix at fawkes' densities, + the warm-up's own a, b, c, z) -- on a smaller GPU the
-                    # warm-up's scratch must not be what pushes the system's upload into the drop-levels-and-retry path.
-                    est_system = 8 * 3 * 4 * int(hdr['num_gates']) + 32 * (3 * key.counts()['m'] + c['num_input'] + c['num_aux'])
-                    headroom = key.levels_headroom()
-                    if headroom < est_system:
-                        tm['warm_up_skipped'] = 'HBM headroom %.1f GiB < %.1f GiB the system and a throw-away proof would need' % (headroom / 2**30, est_system / 2**30)
-                    else:
-                        t1 = time.perf_counter()
-                        before = ctx.stats()
-                        tm['warm_up_error'] = _warm_up(ctx, key, c)
-                        # the throw-away proof is not the caller's: the kernel statistics (fk_stats_get) do not show it when they were empty before
-                        if all(v.get('launches', 0) == 0 for v in before.values()):
-                            ctx.stats_reset()
-                        tm['warm_up_s'] = time.perf_counter() - t1
+                    _maybe_warm_up(ctx, key, hdr, c, tm)
         finally:
             th.join()
         if 'error' in box:

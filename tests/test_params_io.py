@@ -458,7 +458,8 @@ def test_load_parameters_plans_levels_early_and_replans(oracle, monkeypatch):
     """host logic of params_io.load_parameters (no GPU: a stand-in context records the calls; the gate blob is decoded by the real native
     decoder): the key is read with FK_KEY_NO_LEVELS and its levels derived while the decoder runs; once the system is resident the
     headroom is checked and the levels are planned again when it is negative; an out-of-memory system upload drops the levels, retries,
-    and derives them last; early_levels=False keeps the old order."""
+    and derives them last; early_levels=False keeps the old order.  (warm=False: the throw-away proof depends on whether the decoder is still busy --
+    its guard is tested below.)"""
     from fawkes_crypto_amd import api, params_io as pio
     cs, _, _ = ref.random_r1cs(43, 200, 3, 230)
     csr = fx.r1cs_to_csr(cs)
@@ -496,27 +497,54 @@ def test_load_parameters_plans_levels_early_and_replans(oracle, monkeypatch):
     nl = api.FK_KEY_CHECKED | api.FK_KEY_NO_LEVELS
     # 1. the ordinary case: levels underneath the decoding, room confirmed afterwards
     c = Ctx([5 << 30]); tm = {}
-    pio.load_parameters(c, data, timings=tm)
+    pio.load_parameters(c, data, timings=tm, warm=False)
     assert c.log == ['key(flags=%d)' % nl, 'derive', 'system', 'headroom'] and tm['key_levels_early'] and tm['key_levels_headroom_GiB'] == 5.0 and 'key_levels_replanned_s' not in tm
     # 2. the system took the room the proofs need: planned again
     c = Ctx([-(3 << 30)]); tm = {}
-    pio.load_parameters(c, data, timings=tm)
+    pio.load_parameters(c, data, timings=tm, warm=False)
     assert c.log == ['key(flags=%d)' % nl, 'derive', 'system', 'headroom', 'derive'] and tm['key_levels_headroom_GiB'] == -3.0 and 'key_levels_replanned_s' in tm
     # 3. the upload itself ran out of memory: levels dropped, upload retried, levels last
     c = Ctx([]); tm = {}; fails.append(5)
-    pio.load_parameters(c, data, timings=tm)
+    pio.load_parameters(c, data, timings=tm, warm=False)
     assert c.log == ['key(flags=%d)' % nl, 'derive', 'system', 'drop', 'system', 'derive'] and tm['key_levels_early'] is False
     # ... any other failure, or a second out-of-memory, is the caller's: nothing stays behind
     c = Ctx([]); fails.extend([5, 5])
     with pytest.raises(api.FkError):
-        pio.load_parameters(c, data)
+        pio.load_parameters(c, data, warm=False)
     assert c.log[-1] == 'key.free'
     c = Ctx([]); fails.append(3)
     with pytest.raises(api.FkError):
-        pio.load_parameters(c, data)
+        pio.load_parameters(c, data, warm=False)
     assert 'drop' not in c.log and c.log[-1] == 'key.free'
     # 4. early_levels=False / overlap=False: the order of the first version
     for kw in (dict(early_levels=False), dict(overlap=False)):
         c = Ctx([])
-        pio.load_parameters(c, data, **kw)
+        pio.load_parameters(c, data, warm=False, **kw)
         assert c.log == ['key(flags=%d)' % nl, 'system', 'derive'], (kw, c.log)
+    # 5. the warm-up's guard: skipped when the HBM left beside the levels would not cover the system still to come; otherwise run, and the
+    # statistics it touched are reset when they were empty before; nothing it does can raise
+    hdr = pio.read_parameters(data)
+    cnt = pio.bellman_counts(hdr['bellman'])
+
+    class WKey(Key):
+        def counts(self): return dict(m=256, n_a=10, n_b=10)
+
+    class WCtx(Ctx):
+        def __init__(self, headroom, launches):
+            super().__init__(headroom); self.launches = launches
+        def stats(self): self.log.append('stats'); return dict(acc_g1=dict(launches=self.launches), ntt=dict(launches=0))
+        def stats_reset(self): self.log.append('stats_reset')
+        def dev_alloc(self, n): raise api.FkError(5, 'no device here')
+        def dev_free(self, p_): pass
+    w = WCtx([1 << 10], 0); tm = {}
+    pio._maybe_warm_up(w, WKey(w.log, w.headroom), hdr, cnt, tm)
+    assert 'warm_up_skipped' in tm and 'stats' not in w.log and 'warm_up_s' not in tm
+    w = WCtx([1 << 40], 0); tm = {}
+    pio._maybe_warm_up(w, WKey(w.log, w.headroom), hdr, cnt, tm)
+    assert w.log == ['headroom', 'stats', 'stats_reset'] and 'FkError' in tm['warm_up_error'] and tm['warm_up_s'] >= 0
+    w = WCtx([1 << 40], 7); tm = {}            # the caller's own counters are running: left alone
+    pio._maybe_warm_up(w, WKey(w.log, w.headroom), hdr, cnt, tm)
+    assert w.log == ['headroom', 'stats']
+    w = WCtx([], 0); tm = {}                    # a key that cannot answer: an error string, never an exception
+    pio._maybe_warm_up(w, WKey(w.log, w.headroom), hdr, cnt, tm)
+    assert 'IndexError' in tm['warm_up_error']

@@ -44,3 +44,9 @@ t_u = timed(du, e)
 print('untiled  %.3f ms  %.1f G terms/s' % (t_u * 1e3, nnz / t_u / 1e9), flush=True)
 same = all(np.array_equal(ctx.download(d[k], rows * 32, np.uint64), ctx.download(e[k], rows * 32, np.uint64)) for k in range(3))
 print('same a, b, c:', same)
+if os.environ.get('FK_LIB_VARIANT') == 'exp':
+    # upper bound of a 4-bytes-per-term form (TIMING ONLY: the kernel derives the coefficient index from the column instead of loading it)
+    os.environ['FK_SPMV_FAKE4'] = '1'
+    print('NOTE: tune() reads FK_SPMV_FAKE4 at every launch in the experiment build')
+    t_f = timed(du, e)
+    print('untiled, 4 bytes per term streamed (timing only)  %.3f ms  %.1f G terms/s  -> at most %.3f ms to gain' % (t_f * 1e3, nnz / t_f / 1e9, (t_u - t_f) * 1e3))
