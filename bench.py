@@ -442,6 +442,16 @@ def single_process_leg(fk, n_ranks, same_device, r1cs, copies, z_pin, tox, r, s,
     from -- the one-call prover is then set up from it as well (fk_multi_key_load_bellman(checked) + fk_gates_decode -> fk_multi_r1cs_load_gates:
     the explicit system on every GPU); None: fk_multi_setup_tiled / fk_multi_r1cs_load_tiled."""
     mc = fk.MultiContext([0] * n_ranks if same_device else list(range(n_ranks)))
+    form_note = None
+    if image is not None and same_device:
+        # one-GPU rehearsal: N explicit replicas of the system (8 bytes per term each) beside the key and its levels may not fit ONE device -- on a node
+        # every rank has its own HBM.  Then the rehearsal's one-call leg keeps the tiled replicas (4 MB each) and says so.
+        import torch
+        from fawkes_crypto_amd import params_io as pio
+        terms = sum(int(x) for x in (len(c_) for _, c_, _ in r1cs.mats)) * int(copies)
+        if n_ranks * 8 * terms > 0.3 * torch.cuda.get_device_properties(0).total_memory:
+            image = None
+            form_note = 'tiled (one-GPU rehearsal: %d explicit replicas of %.1f GB do not fit one device beside the key and its levels)' % (n_ranks, 8 * terms / 1e9)
     try:
         t0 = time.perf_counter()
         if image is not None:
@@ -475,7 +485,7 @@ def single_process_leg(fk, n_ranks, same_device, r1cs, copies, z_pin, tox, r, s,
         mc.prove_witness_wait(tk)
         key.free(); dr.free()
         return {'ms_per_step': ms, 'proofs_per_sec': 1e3 / ms, 'ranks': n_ranks, 'steps': steps, 'prep_seconds': prep,
-                'matrix_form': 'explicit, from a Parameters gate blob' if image is not None else 'tiled (one instance + copy count)',
+                'matrix_form': 'explicit, from a Parameters gate blob' if image is not None else (form_note or 'tiled (one instance + copy count)'),
                 'transport': mc.transport, 'topology': mc.topology(), 'note': mc.note(),
                 'is': 'fk_multi_prove_r1cs (ONE call on %d GPUs, in-library peer-DMA all-to-all), same proof bytes' % n_ranks}
     finally:
