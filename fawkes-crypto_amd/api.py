@@ -36,7 +36,7 @@ EXPORTED_SYMBOLS = [
     'fk_fr_mul_batch', 'fk_ntt', 'fk_ntt_dev', 'fk_quotient_h', 'fk_quotient_h_dev',
     'fk_msm_g1', 'fk_msm_g2', 'fk_msm_g1_dev', 'fk_msm_g2_dev',
     'fk_gen_points_g1_dev', 'fk_gen_points_g2_dev', 'fk_gen_scalars_dev',
-    'fk_synthesize', 'fk_stats_reset', 'fk_stats_get', 'fk_calibrate', 'fk_verify', 'fk_verify_batch_dev', 'fk_shard_range', 'fk_h_shard_range', 'fk_work_shard_ranges', 'fk_work_shard_ranges_q0',
+    'fk_synthesize', 'fk_roctx_active', 'fk_stats_reset', 'fk_stats_get', 'fk_calibrate', 'fk_verify', 'fk_verify_batch_dev', 'fk_shard_range', 'fk_h_shard_range', 'fk_work_shard_ranges', 'fk_work_shard_ranges_q0',
     'fk_dq_gather_dev', 'fk_dq_local_dev', 'fk_dq_cross_dev', 'fk_dq_cross_sub_dev',
     'fk_setup', 'fk_setup_tiled', 'fk_r1cs_load_tiled', 'fk_key_download', 'fk_key_load_bellman', 'fk_key_write_bellman', 'fk_key_vk', 'fk_key_counts', 'fk_key_precomputed', 'fk_key_load_profile', 'fk_key_levels_plan', 'fk_key_derive_levels', 'fk_key_levels_headroom', 'fk_key_drop_levels',
     'fk_gates_decode', 'fk_gates_free', 'fk_gates_info', 'fk_gates_export', 'fk_r1cs_load_gates', 'fk_gates_profile',

@@ -187,6 +187,9 @@ struct fk_key {
     } while (0)
 
 #define FK_TRY(expr) do { int _rc = (expr); if (_rc != FK_OK) return _rc; } while (0)
+#define FK_CAT2_(a, b) a##b
+#define FK_CAT_(a, b) FK_CAT2_(a, b)
+#define FK_RANGE(name) fk::RoctxRange FK_CAT_(fk_range_, __LINE__)(name)
 
 // Every extern "C" entry that can allocate on the host (std::vector / std::string / std::function behind almost all of them) runs
 // its body through this guard: a C++ exception must never leave an extern "C" function -- std::terminate would take the Rust or
@@ -207,6 +210,19 @@ namespace fk {
 
 std::string &tls_error();      // gatestream.hip: what fk_last_error(NULL) returns (context-free calls leave their message here)
 unsigned host_threads();       // gatestream.hip: FK_HOST_THREADS, else the cores this process may use
+
+// roctx ranges around the library's phases (tracing).  FK_ROCTX=1 binds libroctx64.so.4 with dlopen on first use; a trace taken with
+// `rocprofv3 --marker-trace --kernel-trace -- python3 bench.py ...` then shows which host call queued which kernels (the proof's kernels run
+// asynchronously: a range brackets the QUEUEING of a phase and, where the call blocks, the wait).  Unset: one predictable branch per range.
+struct RoctxApi { int (*push)(const char *) = nullptr; int (*pop)() = nullptr; };
+const RoctxApi &roctx_api();   // gatestream.hip
+struct RoctxRange {
+    bool on;
+    explicit RoctxRange(const char *name) { const RoctxApi &r = roctx_api(); on = r.push != nullptr; if (on) (void)r.push(name); }
+    ~RoctxRange() { if (on) (void)roctx_api().pop(); }
+    RoctxRange(const RoctxRange &) = delete;
+    RoctxRange &operator=(const RoctxRange &) = delete;
+};
 
 // Tuning knobs.  A release build compiles the measured default in; `make EXP=1` (-DFK_EXPERIMENTS, libfawkes_hip_exp.so, loaded
 // with FK_LIB_VARIANT=exp) reads them from the environment for same-box A/B runs.  The run-time switches of a release build

@@ -64,6 +64,22 @@ struct ThreadSet {
     ~ThreadSet() { join(); }
 };
 
+const RoctxApi &roctx_api() {
+    static const RoctxApi api = [] {
+        RoctxApi a;
+        const char *e = getenv("FK_ROCTX");
+        if (!e || !e[0] || e[0] == '0') return a;
+        void *h = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return a;
+        a.push = (int (*)(const char *))dlsym(h, "roctxRangePushA");
+        a.pop = (int (*)())dlsym(h, "roctxRangePop");
+        if (!a.push || !a.pop) a = RoctxApi{};
+        return a;
+    }();
+    return api;
+}
+
 // host threads this process may use: FK_HOST_THREADS, else the affinity mask capped by the cgroup CPU quota (a container can
 // show 256 CPUs and be allowed the time of 16), at most 64
 unsigned host_threads() {
@@ -786,7 +802,11 @@ using namespace fk;
 
 extern "C" {
 
+// 1 when roctx ranges are being emitted (FK_ROCTX=1 and libroctx64 bound), else 0
+int fk_roctx_active(void) { return fk::roctx_api().push != nullptr ? 1 : 0; }
+
 int fk_gates_decode(fk_ctx *ctx, const uint8_t *blob, size_t len, int format, uint32_t num_gates, uint32_t num_input, uint32_t num_aux, fk_gates **out) {
+    FK_RANGE("fk_gates_decode");
     fk_ctx local;                  // host-only routine: usable without a GPU context
     if (!ctx) ctx = &local;
     // a tiny brotli blob can inflate to anything: running out of host memory is a status code, never an exception that leaves

@@ -137,6 +137,7 @@ extern "C" {
 // *n_ic gets the count; gamma_g2_out (may be NULL): 128 bytes raw.  shard arguments as in fk_key_desc.
 int fk_key_load_bellman(fk_ctx *ctx, const uint8_t *buf, size_t len, uint32_t flags, uint32_t shard_index, uint32_t shard_count, double z_frac_lo,
                         double z_frac_hi, fk_key **out, uint8_t *gamma_g2_out, uint8_t *ic_out, uint32_t ic_cap, uint32_t *n_ic) { return fk_guard(ctx, [&]() -> int {
+    FK_RANGE("fk_key_load_bellman");
     if (!ctx) return FK_ERR_BAD_ARG;
     if (!buf || !out) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "key file: null argument");
     if (flags & ~(uint32_t)(FK_KEY_CHECKED | FK_KEY_NO_INFINITY | FK_KEY_NO_LEVELS)) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "key file: unknown flags 0x%x", flags);

@@ -787,6 +787,7 @@ static int multi_prove_slot(fk_multi *M, const fk_multi_key *K, const fk_multi_r
 
 int fk_multi_prove_r1cs(fk_multi *M, const fk_multi_key *K, const fk_multi_r1cs *R, const uint64_t *z, const uint64_t r_[4], const uint64_t s_[4],
                         uint8_t out[FK_PROOF_BYTES], fk_timings *tm) { return fk_guard(M, [&]() -> int {
+    FK_RANGE("fk_multi_prove_r1cs");
     if (!M) return FK_ERR_BAD_ARG;
     if (!z || !r_ || !s_ || !out) { M->err = "prove: null argument"; return FK_ERR_BAD_ARG; }
     if (M->pending[0].active || M->pending[1].active) { M->err = "prove: submitted proofs are outstanding (call fk_multi_prove_r1cs_wait first)"; return FK_ERR_BAD_ARG; }

@@ -341,6 +341,7 @@ static int key_check_shape(fk_ctx *ctx, uint64_t m, uint32_t num_input, uint64_t
     return FK_OK;
 }
 int fk_key_load(fk_ctx *ctx, const fk_key_desc *d, fk_key **out) { return fk_guard(ctx, [&]() -> int {
+    FK_RANGE("fk_key_load");
     if (!ctx || !d || !out) return FK_ERR_BAD_ARG;
     *out = nullptr;
     FK_HIP(ctx, hipSetDevice(ctx->device));
@@ -647,6 +648,7 @@ static int prove_msms_dev(fk_ctx *ctx, const fk_key *key, Fr *d_a, Fr *d_b, Fr *
     if (n == 0 || n > key->m || (key->m > 1 && n <= key->m / 2)) FK_SET_ERR(ctx, FK_ERR_KEY_MISMATCH, "prove: %llu rows do not match key domain %llu",
                                                       (unsigned long long)n, (unsigned long long)key->m);
     FK_HIP(ctx, hipSetDevice(ctx->device));
+    FK_RANGE("prove: queue front, quotient, accumulations; wait for the results");
     const double t0 = now_ms();
     FK_HIP(ctx, ctx->hbuf.reserve(key->m * sizeof(Fr)));
     Fr *d_h = ctx->hbuf.as<Fr>();
@@ -696,7 +698,8 @@ static int prove_msms_dev(fk_ctx *ctx, const fk_key *key, Fr *d_a, Fr *d_b, Fr *
             if (ln.ev_sorted_valid) { FK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ln.ev_sorted, 0)); ln.ev_sorted_valid = false; }
     }
     { const int rcu = upload_deferred(ctx, true); if (rcu != FK_OK) { if (gate) msm_abandon(ctx); return rcu; } }      // the next proof's witness: underneath what follows
-    const int rcq = quotient_dev(ctx, d_a, d_b, d_c, n, d_h, &m);          // queued on the main stream, not waited for
+    int rcq;
+    { FK_RANGE("prove: queue quotient (6 transforms)"); rcq = quotient_dev(ctx, d_a, d_b, d_c, n, d_h, &m); }          // queued on the main stream, not waited for
     if (rcq != FK_OK) { if (gate) msm_abandon(ctx); return rcq; }
     const double t1 = now_ms();
     if (wfirst) {
@@ -726,10 +729,11 @@ static int prove_msms_dev(fk_ctx *ctx, const fk_key *key, Fr *d_a, Fr *d_b, Fr *
             ctx->wit_active = false;
             std::function<int()> hook;
             hook.swap(ctx->before_block);
-            const int rce = hook();
+            int rce;
+            { FK_RANGE("prove: queue the NEXT proof's early front"); rce = hook(); }
             if (rce != FK_OK) { msm_abandon(ctx); return rce; }
-            FK_TRY(witness_end(ctx, out, t_h0, mine));
-        } else FK_TRY(witness_end(ctx, out, t_h0));
+            { FK_RANGE("prove: wait for the five multiplications"); FK_TRY(witness_end(ctx, out, t_h0, mine)); }
+        } else { FK_RANGE("prove: wait for the five multiplications"); FK_TRY(witness_end(ctx, out, t_h0)); }
         if (tm) { tm->ntt_ms = t1 - t0; tm->msm_l_ms = t2w - t1; tm->msm_h_ms = now_ms() - t2w; tm->total_ms = now_ms() - t0; }
         return FK_OK;
     }

@@ -446,12 +446,14 @@ static int setup_impl(fk_ctx *ctx, const fk_r1cs *cs, uint32_t copies, const uin
 int fk_setup(fk_ctx *ctx, const fk_r1cs *cs, const uint64_t tau[4], const uint64_t alpha[4], const uint64_t beta[4], const uint64_t gamma[4],
              const uint64_t delta[4], uint32_t shard_index, uint32_t shard_count, double z_frac_lo, double z_frac_hi, fk_key **out_key,
              uint8_t vk_out[6 * 128], uint8_t *ic_out) { return fk_guard(ctx, [&]() -> int {
+    FK_RANGE("fk_setup");
     return setup_impl(ctx, cs, 1, tau, alpha, beta, gamma, delta, shard_index, shard_count, z_frac_lo, z_frac_hi, out_key, vk_out, ic_out);
 }); }
 
 int fk_setup_tiled(fk_ctx *ctx, const fk_r1cs *instance, uint32_t copies, const uint64_t tau[4], const uint64_t alpha[4], const uint64_t beta[4],
                    const uint64_t gamma[4], const uint64_t delta[4], uint32_t shard_index, uint32_t shard_count, double z_frac_lo, double z_frac_hi,
                    fk_key **out_key, uint8_t vk_out[6 * 128], uint8_t *ic_out) { return fk_guard(ctx, [&]() -> int {
+    FK_RANGE("fk_setup_tiled");
     return setup_impl(ctx, instance, copies, tau, alpha, beta, gamma, delta, shard_index, shard_count, z_frac_lo, z_frac_hi, out_key, vk_out, ic_out);
 }); }
 

@@ -709,6 +709,7 @@ int fk_r1cs_eval_slice_dev(fk_ctx *ctx, const fk_r1cs_dev *r, const void *d_z, u
 // witness in -> proof out: SpMV, quotient, MSMs, assembly.  z: device pointer (num_input + num_aux elements).
 int fk_prove_r1cs_dev(fk_ctx *ctx, const fk_key *key, const fk_r1cs_dev *r, const void *d_z, const uint64_t rr[4], const uint64_t ss[4],
                       uint8_t out_proof[FK_PROOF_BYTES], fk_timings *tm) { return fk_guard(ctx, [&]() -> int {
+    FK_RANGE("fk_prove_r1cs_dev");
     if (!ctx) return FK_ERR_BAD_ARG;
     if (!key || !r || !d_z) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "prove: null argument");
     if (r->num_input != key->num_input || r->num_aux != key->num_aux) FK_SET_ERR(ctx, FK_ERR_KEY_MISMATCH, "prove: constraint system and key disagree on the variable counts");
@@ -822,6 +823,7 @@ extern "C" {
 
 int fk_prove_r1cs(fk_ctx *ctx, const fk_key *key, const fk_r1cs_dev *r, const uint64_t *z, const uint64_t rr[4], const uint64_t ss[4],
                   uint8_t out_proof[FK_PROOF_BYTES], fk_timings *tm) { return fk_guard(ctx, [&]() -> int {
+    FK_RANGE("fk_prove_r1cs");
     if (!ctx) return FK_ERR_BAD_ARG;
     if (!key || !r || !z) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "prove: null argument");
     FK_HIP(ctx, hipSetDevice(ctx->device));
@@ -900,6 +902,7 @@ static int early_front(fk_ctx *ctx, int slot) {
 }  // namespace fk
 extern "C" {
 int fk_prove_r1cs_wait(fk_ctx *ctx, int ticket, uint8_t out_proof[FK_PROOF_BYTES], fk_timings *tm) { return fk_guard(ctx, [&]() -> int {
+    FK_RANGE("fk_prove_r1cs_wait");
     if (!ctx) return FK_ERR_BAD_ARG;
     if (ticket < 0 || ticket > 1 || !ctx->wslot[ticket].pending) FK_SET_ERR(ctx, FK_ERR_BAD_ARG, "prove: no submitted proof with ticket %d", ticket);
     fk_ctx::WitSlot &w = ctx->wslot[ticket];

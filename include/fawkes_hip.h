@@ -564,6 +564,11 @@ int fk_verify_batch_dev(fk_ctx *ctx, const uint8_t *vk, size_t vk_len, const uin
  * in G1), counted on the device from the sorted bucket sizes; 5 / 6 = the same kernels as 0 / 1 with ms = the UNION of the
  * launches' intervals (launches of one kernel that run side by side on different lanes each span the whole phase: the union
  * is the time the kernel took, the sum counts it once per launch). */
+/* Tracing: with FK_ROCTX=1 in the environment the library brackets its phases with roctx ranges (libroctx64.so.4, bound with
+ * dlopen on first use) -- key loads, the gate decoder, set-up, and inside a proof the queueing of the front, of the quotient, of the next proof's
+ * early front and the wait for the five multiplications -- so that `rocprofv3 --marker-trace --kernel-trace` shows which call queued which
+ * kernels.  Returns 1 when ranges are being emitted, 0 otherwise (unset, or the library is absent: never an error). */
+int fk_roctx_active(void);
 int fk_stats_reset(fk_ctx *ctx);
 /* Live calibration of the VALU ceilings the measurement quotes (a few milliseconds): out[0] = v_mad_u64_u32 lane-operations
  * per second (the 32 x 32 -> 64-bit multiply-accumulate every Montgomery product is made of), out[1] = Montgomery products

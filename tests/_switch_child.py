@@ -22,4 +22,4 @@ out = []
 for _ in range(2):          # twice: the second proof runs on warm lane buffers (no growth, different queueing)
     out.append(bytes(ctx.prove_witness(key, dr, z, r, s)).hex())
 assert out[0] == out[1], 'two proofs of the same witness differ'
-print('PROOF', out[0], key.precomputed())
+print('PROOF', out[0], key.precomputed(), 'roctx=%d' % fk.load_library().fk_roctx_active())

@@ -49,6 +49,22 @@ def test_proof_borsh_roundtrip_and_points():
     assert fk.G2Point.from_bytes(bytes(128)).is_zero()
 
 
+def test_roctx_ranges_are_off_by_default_and_bind_on_request():
+    """fk_roctx_active (tracing): 0 in a process without FK_ROCTX; with FK_ROCTX=1 the library binds libroctx64 on first use --
+    the ROCm image has it, so 1 (a machine without the library answers 0: never an error).  Read once per process, hence the child."""
+    import subprocess
+    import sys
+    import fawkes_crypto_amd as fk
+    if 'FK_ROCTX' not in os.environ:
+        assert fk.load_library().fk_roctx_active() == 0
+    code = 'import fawkes_crypto_amd as fk; print(fk.load_library().fk_roctx_active())'
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, FK_ROCTX='1'), cwd=root, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-500:]
+    have = os.path.exists('/opt/rocm/lib/libroctx64.so.4')
+    assert out.stdout.strip() == ('1' if have else '0')
+
+
 def test_serde_json_forms_of_proof_vk_and_points():
     """serde-equivalent JSON of `Proof` / `VK` / `G1Point` / `G2Point` (prover.rs:11-17, verifier.rs:10-18, group.rs:12-13, 83-85 with
     `Num`'s Serialize = its decimal string, ff-uint/src/num/mod.rs:445-459): shapes, field names and order as serde_json gives them, round

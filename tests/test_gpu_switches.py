@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SWITCHES = [
     {'FK_PROVE_SORTS_FIRST': '1'}, {'FK_PROVE_SORTS_FIRST': '0'},
     {'FK_MSM_PRE_MIN_LOG2': '8'}, {'FK_MSM_PRE_MIN_LOG2': '8', 'FK_PROVE_SORTS_FIRST': '1'}, {'FK_MSM_PRE_MIN_LOG2': '8', 'FK_MSM_PRECOMP': 'require'},
-    {'FK_MSM_PRECOMP': '0'}, {'FK_SPMV_BIN_MIN': '0'}, {'FK_DEBUG': '1'},
+    {'FK_MSM_PRECOMP': '0'}, {'FK_SPMV_BIN_MIN': '0'}, {'FK_DEBUG': '1'}, {'FK_ROCTX': '1'},
 ]
 
 
@@ -39,5 +39,7 @@ def reference():
 def test_switch_leaves_the_proof_unchanged(env, reference):
     _, proof, levels = _child(env)
     assert proof == reference
+    if 'FK_ROCTX' in env:         # the ranges are really being emitted (libroctx64.so.4 is part of the ROCm image), and change nothing
+        assert 'roctx=1' in levels
     if 'FK_MSM_PRE_MIN_LOG2' in env:
-        assert any(v for v in eval(levels).values()), 'the fixed-base levels were expected to be in use: ' + levels
+        assert any(v for v in eval(levels.split(' roctx=')[0]).values()), 'the fixed-base levels were expected to be in use: ' + levels
