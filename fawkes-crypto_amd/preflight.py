@@ -35,8 +35,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _pattern(torch, n, sender, device):
     """n bytes that name their sender and their position (period 251 x 256 is irrelevant: a misrouted or shifted piece differs)"""
-    i = torch.arange(n, dtype=torch.int64, device=device)
-    return ((i * 131 + (i >> 8) * 7 + sender * 37 + 11) & 255).to(torch.uint8)
+    i = torch.arange(n, dtype=torch.int32, device=device)          # (n < 2^31: a witness piece is at most ~1 GB; int32 products wrap alike on both sides)
+    return ((i * 131 + (i >> 8) * 7 + (sender * 37 + 11)) & 255).to(torch.uint8)
 
 
 def _rccl_checks(torch, dist, group, rank, world, device, piece_bytes, chunk_bytes, out):
