@@ -106,14 +106,20 @@ def single_gpu_2p22():
 
 @pytest.mark.parametrize('n_ranks', [2, 4, 8])
 def test_ranks_set_up_from_the_same_parameters_image_reproduce_the_single_gpu_bytes(single_gpu_2p22, n_ranks):
-    """`bench.py --gpus N` proves the SAME input form as N = 1 -- rank 0 writes one `Parameters` image, every rank sets its prover
+    """The schedules a first multi-GPU hardware run will take -- `python bench.py --gpus N` as a plain command (no launcher: the ranks are fresh children started
+    before the parent touches the GPU, no re-exec), balanced quotient at 2 ranks, distributed quotient from 4 on, the one-call leg, at 4 ranks the replica
+    leg -- and VERDICT r5 item 2: `bench.py --gpus N` proves the SAME input form as N = 1 -- rank 0 writes one `Parameters` image, every rank sets its prover
     up from it (load_parameters(image, shard = rank / world): fk_gates_decode once per process, fk_key_load_bellman(checked) of its slices), the
     one-call leg through fk_multi_key_load_bellman + fk_multi_r1cs_load_gates -- and the proof bytes (both witnesses) equal the single-GPU run's.
     2^22 rows, every rank-process on this box's one GPU (gloo)."""
-    j = _rank_run(n_ranks, 217, '--no-replicas')
+    j = _rank_run(n_ranks, 217, *(() if n_ranks == 4 else ('--no-replicas',)))        # (4 ranks: with the throughput leg, one whole key per rank out of the image)
     assert j['n_gpus'] == n_ranks and j['config']['matrix_form'] == 'explicit, from a Parameters gate blob', j['config']['matrix_form']
     assert j['proof_sha256'] == single_gpu_2p22['proof_sha256'] and len(j['proof_sha256']) == 2
     assert j['proof_verified_by_pairing_check'] is True
+    assert 'distributed-quotient' in j['config']['parallelism'] if n_ranks >= 4 else 'balanced-quotient' in j['config']['parallelism']
+    assert j['config']['parallelism'].startswith('msm-shard%d' % n_ranks) and j['config']['distinct_witnesses_in_the_pipeline'] == 2
+    if n_ranks == 4:
+        assert j['replica_proofs_per_sec'] > 0
     ld = j['load']
     assert ld['matrix_terms'] == sum(j['config']['nnz']) and ld['image_bytes'] > ld['blob_bytes'] > 0 and ld['one_rank_at_a_time'] is True
     sp = j['single_process_multi_gpu']
@@ -170,27 +176,6 @@ def test_bench_plain_command_starts_its_own_ranks():
     assert j['n_gpus'] == 2 and j['value'] > 0 and j['proof_verified_by_pairing_check'] is True
     assert j['single_process_multi_gpu']['ranks'] == 2 and j['single_process_multi_gpu']['ms_per_step'] > 0
     assert j['replica_proofs_per_sec'] > 0
-
-
-@pytest.mark.parametrize('n_ranks', [4, 8])
-def test_bench_plain_command_with_4_and_8_ranks(n_ranks):
-    """The schedules the first multi-GPU hardware run will take: `python bench.py --gpus 4` and `--gpus 8` as plain
-    commands -- the rank-per-process DISTRIBUTED QUOTIENT (the default from 4 ranks on) with 4 and 8 real processes, the replica leg and
-    the one-call leg (fk_multi_prove_r1cs on N ranks), end to end, every rank on this box's one GPU (FK_BENCH_SAME_DEVICE=1, gloo: RCCL
-    needs one device per rank).  No re-exec anywhere: the ranks are fresh children started before the parent touches the GPU."""
-    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'FK_DIST_QUOTIENT')}
-    env['FK_BENCH_SAME_DEVICE'] = '1'
-    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(n_ranks), '--backend', 'gloo', '--steps', '2', '--warmup', '1',
-                          '--copies', '11'], env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
-    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
-    last = out.stdout.strip().splitlines()[-1]
-    j = json.loads(last)
-    assert j['n_gpus'] == n_ranks and j['value'] > 0 and j['proof_verified_by_pairing_check'] is True
-    assert 'distributed-quotient' in j['config']['parallelism'] and j['config']['parallelism'].startswith('msm-shard%d' % n_ranks)
-    assert j['config']['distinct_witnesses_in_the_pipeline'] == 2
-    assert j['single_process_multi_gpu']['ranks'] == n_ranks and j['single_process_multi_gpu']['ms_per_step'] > 0, j['single_process_multi_gpu']
-    assert j['replica_proofs_per_sec'] > 0
-    assert j['config']['matrix_form'] == 'explicit, from a Parameters gate blob' and j['preflight']['all_ranks_ok'] is True
 
 
 def test_bench_synthetic_workload_small():

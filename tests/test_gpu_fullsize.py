@@ -277,7 +277,7 @@ def test_config3_parameters_image_at_full_size_equals_the_oracle_bytes(ctx):
     r, s = bench.mont(0xA11CE), bench.mont(0xB0B)
     ctx.trim()
     key, vk = ctx.setup(inst, copies=copies, **tox)
-    image = pio.store_parameters_dev(ctx, key, vk, inst, copies=copies, quality=2, lgwin=22)
+    image = pio.store_parameters_dev(ctx, key, vk, inst, copies=copies, quality=1, lgwin=22)      # (quality 1: the fastest writer; any setting decodes to the same stream)
     key.free()
     key, dr, hdr = pio.load_parameters(ctx, image, checked=True)
     del image
