@@ -92,8 +92,11 @@ __global__ __launch_bounds__(256) void spmv_kernel(SpmvArgs a, const Fr *table, 
 // FAKE4 (experiment builds, FK_SPMV_FAKE4=1, TIMING ONLY -- the results are wrong): the kernel streams 4 bytes per term instead of 8 -- the coefficient
 // index is derived from the column (no cidx load) -- which is what a packed form (u16 coefficient index + u16 column offset inside a row block's
 // window) would stream at best: an upper bound on what that form can save (tools/spmv_untiled_probe.py).
+#ifndef FK_SPMV_MINB
+#define FK_SPMV_MINB 1      // workgroups per compute unit the register allocation is held to (256 lanes = one wave per SIMD each): see the kernel's comment
+#endif
 template <bool TILED, bool SLICED, bool FAKE4 = false>
-__global__ __launch_bounds__(256) void spmv_binned_kernel(SpmvArgs a, BinArgs b, const Fr *table, const Fr *z, uint32_t num_input, TileDims td, uint32_t copies, SliceArgs sl) {
+__global__ __launch_bounds__(256, FK_SPMV_MINB) void spmv_binned_kernel(SpmvArgs a, BinArgs b, const Fr *table, const Fr *z, uint32_t num_input, TileDims td, uint32_t copies, SliceArgs sl) {
     uint32_t s = 0;
     while (s + 1 < b.nseg && blockIdx.x >= b.first_block[s + 1]) s++;
     const uint32_t lg = b.lg[s], mtx = b.mtx[s], nr = b.n_rows[s];
