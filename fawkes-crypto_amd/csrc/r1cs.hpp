@@ -10,6 +10,7 @@ struct BinArgs {
     uint32_t nseg = 0, mask = 0;            // mask: bit k = matrix k is binned
     uint32_t first_block[SPMV_SEGS + 1] = {0}, lg[SPMV_SEGS] = {0}, mtx[SPMV_SEGS] = {0}, n_rows[SPMV_SEGS] = {0}, list_off[SPMV_SEGS] = {0};
     const uint32_t *rowlist[3] = {nullptr, nullptr, nullptr};
+    const uint64_t *pptr[3] = {nullptr, nullptr, nullptr};      // experiment builds, FK_SPMV_SEQ: row pointers of a layout permuted into class-list order
 };
 // Cyclic row slices (multi-GPU: rank g of W = 2^log_w evaluates only the rows t = g (mod W), the slice the distributed
 // quotient starts from).  The length-class lists are kept a second time per log_w with every class grouped by row mod W
@@ -45,6 +46,7 @@ struct fk_r1cs_dev {
     uint32_t copies = 1, base_input = 0, base_aux = 0, base_gates = 0;
     // matrices with long rows: the (instance's) rows in classes by length, sorted by length inside a class (see spmv_binned_kernel)
     uint32_t *rowlist[3] = {nullptr, nullptr, nullptr};
+    uint64_t *pptr[3] = {nullptr, nullptr, nullptr};             // (experiment builds only; freed with the system)
     fk::BinArgs bins;
     // batch circuits of >= 64 copies: the rows of middling length that spmv_tiled_wave_kernel takes (matrix << 30 | row, circuit
     // order) and where they sit in rowlist (sorted by length: [wave_from, wave_to) of each matrix)

@@ -89,13 +89,13 @@ __global__ __launch_bounds__(256) void spmv_kernel(SpmvArgs a, const Fr *table, 
 // launch is one (matrix, class); a tiled system walks its copies in the outer order, so a copy's z stays in cache.
 // SLICED (b.rowlist = the residue-grouped lists, b.first_block = this rank's plan): group index -> (copy, position in the
 // residue group that copy needs); the row's result goes to out[(copy * base_gates + row) >> log_w].
-// FAKE4 (experiment builds, FK_SPMV_FAKE4=1, TIMING ONLY -- the results are wrong): the kernel streams 4 bytes per term instead of 8 -- the coefficient
+// MODE 1 (experiment builds, FK_SPMV_FAKE4=1, TIMING ONLY -- the results are wrong): the kernel streams 4 bytes per term instead of 8 -- the coefficient
 // index is derived from the column (no cidx load) -- which is what a packed form (u16 coefficient index + u16 column offset inside a row block's
 // window) would stream at best: an upper bound on what that form can save (tools/spmv_untiled_probe.py).
 #ifndef FK_SPMV_MINB
 #define FK_SPMV_MINB 1      // workgroups per compute unit the register allocation is held to (256 lanes = one wave per SIMD each): see the kernel's comment
 #endif
-template <bool TILED, bool SLICED, bool FAKE4 = false>
+template <bool TILED, bool SLICED, int MODE = 0>
 __global__ __launch_bounds__(256, FK_SPMV_MINB) void spmv_binned_kernel(SpmvArgs a, BinArgs b, const Fr *table, const Fr *z, uint32_t num_input, TileDims td, uint32_t copies, SliceArgs sl) {
     uint32_t s = 0;
     while (s + 1 < b.nseg && blockIdx.x >= b.first_block[s + 1]) s++;
@@ -119,21 +119,25 @@ __global__ __launch_bounds__(256, FK_SPMV_MINB) void spmv_binned_kernel(SpmvArgs
     const uint32_t row = b.rowlist[mtx][b.list_off[s] + li];
     const uint32_t in_off = copy * (td.base_input - 1), aux_off = num_input + copy * td.base_aux - td.base_input;
     const uint64_t *ptr = a.ptr[mtx]; const uint32_t *col = a.col[mtx]; const uint32_t *cidx = a.cidx[mtx];
-    const uint64_t e = ptr[row + 1];
-    uint64_t k = ptr[row] + sub;
+    // MODE 2 (experiment builds, FK_SPMV_SEQ=1, TIMING ONLY): the row's terms are read from where a layout PERMUTED into class-list order would
+    // hold them -- [pptr[i], pptr[i + 1]) at list position i: neighbouring lane groups read neighbouring pointers and neighbouring runs of col / cidx,
+    // no rowlist -> ptr -> col chain (the row id is only needed for the store) -- same row lengths, the terms themselves are another row's
+    const uint64_t pi = (uint64_t)b.list_off[s] + li;
+    const uint64_t e = MODE == 2 ? b.pptr[mtx][pi + 1] : ptr[row + 1];
+    uint64_t k = (MODE == 2 ? b.pptr[mtx][pi] : ptr[row]) + sub;
     const uint32_t G = 1u << lg;
     auto var = [&](uint32_t cv) -> uint32_t { if (TILED && cv) cv += cv < td.base_input ? in_off : aux_off; return cv; };
     Fr acc = Fr::zero();
     // four terms per step with ONE Montgomery reduction (Fp::dot4: 328 multiply-accumulates instead of 544) ...
     for (; k + 3 * (uint64_t)G < e; k += 4 * G) {
         const uint32_t c0 = var(col[k]), c1 = var(col[k + G]), c2 = var(col[k + 2 * G]), c3 = var(col[k + 3 * G]);
-        const uint32_t i0 = FAKE4 ? (c0 & 4095u) : cidx[k], i1 = FAKE4 ? (c1 & 4095u) : cidx[k + G], i2 = FAKE4 ? (c2 & 4095u) : cidx[k + 2 * G], i3 = FAKE4 ? (c3 & 4095u) : cidx[k + 3 * G];
+        const uint32_t i0 = (MODE == 1) ? (c0 & 4095u) : cidx[k], i1 = (MODE == 1) ? (c1 & 4095u) : cidx[k + G], i2 = (MODE == 1) ? (c2 & 4095u) : cidx[k + 2 * G], i3 = (MODE == 1) ? (c3 & 4095u) : cidx[k + 3 * G];
         acc = Fr::add(acc, Fr::dot4(z[c0], table[i0], z[c1], table[i1], z[c2], table[i2], z[c3], table[i3]));
     }           // (loading the NEXT step's indices ahead of this step's products was measured: 169.8 against 168.8 ms per proof)
     if (lg) {   // ... then two (one lane per row: the last terms one by one, ONE coefficients skipped)
         Fr acc1 = Fr::zero();
         for (; k + G < e; k += 2 * G) {        // table[0] is ONE: multiplying by it returns the (reduced) value itself
-            const uint32_t c0 = var(col[k]), c1 = var(col[k + G]), i0 = FAKE4 ? (c0 & 4095u) : cidx[k], i1 = FAKE4 ? (c1 & 4095u) : cidx[k + G];
+            const uint32_t c0 = var(col[k]), c1 = var(col[k + G]), i0 = (MODE == 1) ? (c0 & 4095u) : cidx[k], i1 = (MODE == 1) ? (c1 & 4095u) : cidx[k + G];
             Fr p0, p1;
             Fr::mul2(z[c0], table[i0], z[c1], table[i1], p0, p1);
             Fr::add2(acc, p0, acc1, p1, acc, acc1);
@@ -143,7 +147,7 @@ __global__ __launch_bounds__(256, FK_SPMV_MINB) void spmv_binned_kernel(SpmvArgs
     for (; k < e; k += G) {
         const uint32_t cv = var(col[k]);
         Fr v = z[cv];
-        const uint32_t ci = FAKE4 ? (cv & 4095u) : cidx[k];
+        const uint32_t ci = (MODE == 1) ? (cv & 4095u) : cidx[k];
         if (ci) v = Fr::mul(v, table[ci]);
         acc = Fr::add(acc, v);
     }
@@ -221,7 +225,7 @@ extern "C" {
 void fk_r1cs_free(fk_ctx *ctx, fk_r1cs_dev *r) {
     if (!r) return;
     if (ctx) (void)hipSetDevice(ctx->device);
-    for (int k = 0; k < 3; k++) { if (r->ptr[k]) (void)hipFree(r->ptr[k]); if (r->col[k]) (void)hipFree(r->col[k]); if (r->cidx[k]) (void)hipFree(r->cidx[k]); if (r->rowlist[k]) (void)hipFree(r->rowlist[k]); }
+    for (int k = 0; k < 3; k++) { if (r->ptr[k]) (void)hipFree(r->ptr[k]); if (r->col[k]) (void)hipFree(r->col[k]); if (r->cidx[k]) (void)hipFree(r->cidx[k]); if (r->rowlist[k]) (void)hipFree(r->rowlist[k]); if (r->pptr[k]) (void)hipFree(r->pptr[k]); }
     for (void *p : {(void *)r->table, (void *)r->d_a_aux, (void *)r->d_b_in, (void *)r->d_b_aux, (void *)r->d_idx_a, (void *)r->d_idx_b}) if (p) (void)hipFree(p);
     for (auto &sl : r->slices) for (uint32_t *p : sl.d_list) if (p) (void)hipFree(p);
     if (r->d_wavelist) (void)hipFree(r->d_wavelist);
@@ -401,6 +405,16 @@ static int r1cs_load_impl(fk_ctx *ctx, const fk_r1cs *cs, uint32_t copies, fk_r1
             r->wave_from[k] = lp.wave_from; r->wave_to[k] = lp.wave_to;             // rows of wave_lo <= length < wave_hi
             if (hipMalloc((void **)&r->rowlist[k], (size_t)ng * 4) != hipSuccess) { ctx->err = "r1cs: device allocation failed"; return fail(FK_ERR_OOM); }
             if (hipMemcpy(r->rowlist[k], list.data(), (size_t)ng * 4, hipMemcpyHostToDevice) != hipSuccess) rc = FK_ERR_HIP;
+#ifdef FK_EXPERIMENTS
+            if (tune("FK_SPMV_SEQ", 0) && copies == 1 && rc == FK_OK) {      // pointers of the layout permuted into class-list order (timing experiment)
+                std::vector<uint64_t> pp((size_t)ng + 1);
+                pp[0] = 0;
+                for (uint32_t i = 0; i < ng; i++) pp[i + 1] = pp[i] + (ptrs[k][list[i] + 1] - ptrs[k][list[i]]);
+                if (hipMalloc((void **)&r->pptr[k], ((size_t)ng + 1) * 8) != hipSuccess) { ctx->err = "r1cs: device allocation failed"; return fail(FK_ERR_OOM); }
+                if (hipMemcpy(r->pptr[k], pp.data(), ((size_t)ng + 1) * 8, hipMemcpyHostToDevice) != hipSuccess) rc = FK_ERR_HIP;
+                r->bins.pptr[k] = r->pptr[k];
+            }
+#endif
             r->h_rowlist[k] = std::move(list);
             BinArgs &b = r->bins;
             b.rowlist[k] = r->rowlist[k]; b.mask |= 1u << k;
@@ -675,7 +689,10 @@ int r1cs_eval_impl(fk_ctx *ctx, const fk_r1cs_dev *r, const void *d_z, void *d_a
                                                    r->num_input, td, r->copies, sa)
 #ifdef FK_EXPERIMENTS
             if (!tiled && !sliced && tune("FK_SPMV_FAKE4", 0) && r->n_table > 4096)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_binned_kernel<false, false, true>), dim3(blocks), dim3(256), 0, ctx->stream, a, b, r->table, (const Fr *)d_z,
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_binned_kernel<false, false, 1>), dim3(blocks), dim3(256), 0, ctx->stream, a, b, r->table, (const Fr *)d_z,
+                                   r->num_input, td, r->copies, sa);
+            else if (!tiled && !sliced && window < 0 && tune("FK_SPMV_SEQ", 0) && b.pptr[0] && b.pptr[1] && b.pptr[2])
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_binned_kernel<false, false, 2>), dim3(blocks), dim3(256), 0, ctx->stream, a, b, r->table, (const Fr *)d_z,
                                    r->num_input, td, r->copies, sa);
             else
 #endif

@@ -13,6 +13,9 @@ import bench  # noqa: E402
 import fawkes_crypto_amd as fk  # noqa: E402
 
 COPIES = int(os.environ.get('COPIES', 1024))
+SEQ = os.environ.get('FK_LIB_VARIANT') == 'exp'
+if SEQ:
+    os.environ['FK_SPMV_SEQ'] = '0'
 ctx = fk.Context(0)
 r1cs, zs = bench.load_rollup_instance()
 z = bench.tile_witness(zs, r1cs.num_input, COPIES)
@@ -38,7 +41,11 @@ nnz = sum(dt.info()['nnz'])
 print('tiled    %.3f ms  %.1f G terms/s' % (t_t * 1e3, nnz / t_t / 1e9), flush=True)
 t0 = time.perf_counter()
 u_in, u_aux, u_mats, u_table = bench.materialise_rollup(COPIES)
+if SEQ:
+    os.environ['FK_SPMV_SEQ'] = '1'         # (read at load: the permuted layout's pointers are built beside the class lists)
 du = ctx.load_r1cs_coded(u_in, u_aux, u_mats, u_table)
+if SEQ:
+    os.environ['FK_SPMV_SEQ'] = '0'
 print('untiled system built and loaded in %.1f s' % (time.perf_counter() - t0), flush=True)
 t_u = timed(du, e)
 print('untiled  %.3f ms  %.1f G terms/s' % (t_u * 1e3, nnz / t_u / 1e9), flush=True)
@@ -49,4 +56,9 @@ if os.environ.get('FK_LIB_VARIANT') == 'exp':
     os.environ['FK_SPMV_FAKE4'] = '1'
     print('NOTE: tune() reads FK_SPMV_FAKE4 at every launch in the experiment build')
     t_f = timed(du, e)
+    os.environ['FK_SPMV_FAKE4'] = '0'
+    os.environ['FK_SPMV_SEQ'] = '1'
+    t_s = timed(du, e)
+    os.environ['FK_SPMV_SEQ'] = '0'
+    print('untiled, terms read where a layout permuted into class-list order would hold them (timing only)  %.3f ms  -> at most %.3f ms to gain' % (t_s * 1e3, (t_u - t_s) * 1e3))
     print('untiled, 4 bytes per term streamed (timing only)  %.3f ms  %.1f G terms/s  -> at most %.3f ms to gain' % (t_f * 1e3, nnz / t_f / 1e9, (t_u - t_f) * 1e3))
