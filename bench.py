@@ -33,6 +33,15 @@ with the Groth16 pairing equation.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
+Round 6: (a) before anything touches the GPU a FIRST-CONTACT PREFLIGHT runs in a child process per rank (fawkes-crypto_amd/preflight.py: the proof's three
+collectives at their real sizes with contents verified, the library's peer-access table and one verified 64 MiB pull per ordered device pair); a failure
+selects the documented fallback (gloo-staged exchanges, host-side event waits) and is reported in the `preflight` block -- the run goes on; (b) N > 1 proves
+the SAME input form as N = 1: rank 0 writes ONE `Parameters` image into a file every rank maps, every rank sets its prover up from it
+(load_parameters(image, shard = rank / world)); the control plane (barriers, agreement on plans and timings) is a gloo group, the data plane an RCCL group;
+(c) the timed proofs are compared with the ORACLE's committed bytes at this size (tests/golden/fullsize_digests.json, `oracle_digest_check`) in every run;
+(d) `roofline` carries `frac` (union of the launches) and `frac_per_launch` (rocprof's average launch), blocks for the G2 kernel and the NTT, and `traffic`
+measured BY THIS RUN (two rocprofv3 --pmc child processes at the end, everything of this process released first; --measure-traffic auto / on / off).
+
 N > 1: one process per GPU, strong scaling of a single proof: every rank hands over 1 / N of the witness over its own PCIe link and the ranks
 all-gather the rest over xGMI (RCCL, parallel.witness_all_gather) underneath the proof before; every rank holds its piece of the key (h in blocks of the domain; l, a, b_g1,
 b_g2 dealt by work: one or two large pieces per rank),
