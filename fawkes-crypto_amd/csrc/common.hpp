@@ -210,6 +210,7 @@ namespace fk {
 
 std::string &tls_error();      // gatestream.hip: what fk_last_error(NULL) returns (context-free calls leave their message here)
 unsigned host_threads();       // gatestream.hip: FK_HOST_THREADS, else the cores this process may use
+bool cu_masks(::fk_ctx *ctx, std::vector<uint32_t> &compute, std::vector<uint32_t> &mem);      // msm.hip: FK_CU_SPLIT (experiment builds)
 
 // roctx ranges around the library's phases (tracing).  FK_ROCTX=1 binds libroctx64.so.4 with dlopen on first use; a trace taken with
 // `rocprofv3 --marker-trace --kernel-trace -- python3 bench.py ...` then shows which host call queued which kernels (the proof's kernels run

@@ -1105,7 +1105,30 @@ __global__ __launch_bounds__(256) void msm_fold_partials_kernel(const Xyzz<F> *w
 // hardware queue of the B pair's lane, the upload's completion then sat behind the G2 tail, and the early front of every pipelined
 // proof started ~12 ms late (251 against 228 ms per proof on one box; profiles/r05_stream_order_ab.log).  The order here is the one
 // the benchmark process of rounds 2-4 happened to create: main (fk_init), copy, auxiliary, the four lanes.
+// FK_CU_SPLIT=k (experiment builds; 1 <= k <= 4): k of every 8 compute units are set aside -- the lane streams (sorts, accumulations, tails) are created
+// with a CU mask that leaves them out.  Step 1 of "memory-bound work on compute units of its own": what does an accumulation lose when it may
+// use only (8 - k) / 8 of the chip?  FK_CU_SPLIT_MODE picks which units of the mask are set aside: 0 = bits with i mod 8 < k, 1 = bits with (i div 8) mod 8 < k
+// (how mask bits map to XCDs is not documented for gfx950: with a round-robin mapping mode 0 sets whole XCDs aside and mode 1 units of every XCD, with a
+// linear mapping the other way round).
+bool cu_masks(fk_ctx *ctx, std::vector<uint32_t> &compute, std::vector<uint32_t> &mem) {
+    const int k = tune("FK_CU_SPLIT", 0), mode = tune("FK_CU_SPLIT_MODE", 0);
+    if (k < 1 || k > 4) return false;
+    hipDeviceProp_t pr;
+    if (hipGetDeviceProperties(&pr, ctx->device) != hipSuccess) return false;
+    const int ncu = pr.multiProcessorCount, words = (ncu + 31) / 32;
+    compute.assign(words, 0); mem.assign(words, 0);
+    for (int i = 0; i < ncu; i++) {
+        // measured (tools/mulbench/cumask.hip, profiles/r06_cu_mask_semantics.log): mask bit i = XCD i mod 8, unit i div 8 of that XCD; an XCD whose bits are
+        // ALL clear is not switched off, it runs unrestricted -- so mode 0 is a no-op; mode 2 sets aside the units j < k of EVERY XCD (j = i div 8)
+        const bool m = mode == 0 ? (i % 8) < k : mode == 1 ? ((i / 8) % 8) < k : (i / 8) < k;
+        (m ? mem : compute)[i / 32] |= 1u << (i % 32);
+    }
+    return true;
+}
+
 int streams_init(fk_ctx *ctx) {
+    std::vector<uint32_t> m_compute, m_mem;
+    const bool split = cu_masks(ctx, m_compute, m_mem);
     if (!ctx->copy_st) FK_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_st, hipStreamNonBlocking));
     if (!ctx->aux) {
         FK_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
@@ -1113,10 +1136,12 @@ int streams_init(fk_ctx *ctx) {
     }
     for (MsmLane &ln : ctx->lanes) {
         if (ln.st) continue;
-        FK_HIP(ctx, hipStreamCreateWithFlags(&ln.st, hipStreamNonBlocking));
+        if (split) FK_HIP(ctx, hipExtStreamCreateWithCUMask(&ln.st, (uint32_t)m_compute.size(), ((tune("FK_CU_SPLIT_INVERT", 0) || tune("FK_CU_SPLIT_ALL", 0)) ? m_mem : m_compute).data()));      // (INVERT: sanity check of the mask; ALL: a guest context, everything on the set-aside units)
+        else FK_HIP(ctx, hipStreamCreateWithFlags(&ln.st, hipStreamNonBlocking));
         FK_HIP(ctx, hipEventCreateWithFlags(&ln.ev_in, hipEventDisableTiming));
         FK_HIP(ctx, hipEventCreateWithFlags(&ln.ev_sorted, hipEventDisableTiming));
     }
+    if (split && getenv("FK_DEBUG")) fprintf(stderr, "[fk] FK_CU_SPLIT: lane streams masked to %zu words (compute %08x.., set aside %08x..)\n", m_compute.size(), m_compute[0], m_mem[0]);
     return FK_OK;
 }
 

@@ -107,7 +107,12 @@ int fk_init(int device_id, fk_ctx **out) {
         });
     }
     { const int v = tune("FK_NTT_THREADS", 512); if (v == 64 || v == 128 || v == 256 || v == 512 || v == 1024) ctx->ntt_threads = (unsigned)v; }
-    if (hipStreamCreate(&ctx->stream) != hipSuccess) { delete ctx; return FK_ERR_HIP; }
+    {   // FK_CU_SPLIT_ALL=1 (experiment builds): a GUEST context -- every stream, the main one included, on the set-aside units of FK_CU_SPLIT
+        std::vector<uint32_t> mc, mm;
+        if (tune("FK_CU_SPLIT_ALL", 0) && cu_masks(ctx, mc, mm)) {
+            if (hipExtStreamCreateWithCUMask(&ctx->stream, (uint32_t)mm.size(), mm.data()) != hipSuccess) { delete ctx; return FK_ERR_HIP; }
+        } else if (hipStreamCreate(&ctx->stream) != hipSuccess) { delete ctx; return FK_ERR_HIP; }
+    }
     { const char *e = getenv("FK_LAZY_STREAMS");       // (=1: the streams are created on first use, as before round 5 -- for the A/B only)
       if (!(e && e[0] == '1') && streams_init(ctx) != FK_OK) { fk_free(ctx); return FK_ERR_HIP; } }
     *out = ctx;
