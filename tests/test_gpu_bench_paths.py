@@ -178,6 +178,19 @@ def test_bench_plain_command_starts_its_own_ranks():
     assert j['replica_proofs_per_sec'] > 0
 
 
+def test_ranks_fall_back_to_their_own_key_shards_when_no_directory_can_hold_the_image():
+    """a container with a tiny /dev/shm and /tmp (FK_BENCH_IMAGE_DIR=none simulates it): rank 0 finds no room for the `Parameters` image, says so to every
+    rank, and the ranks prove the tiled form from their own key shards as before round 6 -- the line says which form it measured and why"""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'FK_DIST_QUOTIENT')}
+    env.update(FK_BENCH_SAME_DEVICE='1', FK_BENCH_IMAGE_DIR='none')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--steps', '2', '--warmup', '1', '--copies', '9',
+                          '--no-replicas', '--no-single-process'], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
+    j = json.loads(out.stdout.strip().splitlines()[-1])
+    assert j['n_gpus'] == 2 and j['config']['matrix_form'].startswith('tiled') and 'no directory with room' in j['load']['error']
+    assert j['proof_verified_by_pairing_check'] is True
+
+
 def test_bench_synthetic_workload_small():
     j = _run({}, '--workload', 'synthetic', '--log2n', '14', '--cpu-log2n', '12')
     _check_line(j)
