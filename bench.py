@@ -889,6 +889,13 @@ def main():
         # ('nccl' = RCCL over xGMI on device tensors; 'gloo' = host-staged, rehearsals and the preflight's fallback).  Keeping the control plane off
         # RCCL means that a node whose RCCL does not work can still finish the run and say so.
         dist.init_process_group('gloo', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=1800))
+        # every rank read its OWN child's verdict: agree on the data plane here (a rank whose child died without a verdict decided 'gloo' alone)
+        agree = torch.tensor([1 if args.backend == 'nccl' else 0], dtype=torch.int32)
+        dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+        if args.backend == 'nccl' and int(agree.item()) == 0:
+            args.backend = 'gloo'
+            if preflight is not None:
+                preflight['decision'] = dict(preflight['decision'], backend='gloo', why=preflight['decision']['why'] + '; another rank\'s checks did not pass: the data plane is gloo on every rank')
         if args.backend == 'nccl':
             data_group = dist.new_group(ranks=list(range(world)), backend='nccl')
     comm_dev = dev if args.backend == 'nccl' else None
