@@ -45,7 +45,8 @@ def test_timed_proofs_are_compared_with_the_committed_oracle_bytes():
     e = doc['entries']['rollup1741']
     assert e['rows'] == 33552553 and e['log2_domain'] == 25 and all(e['gpu_equal']) and all(e['pairing']) and len(e['proofs']) == 2
     assert all(len(bytes.fromhex(p)) == 256 for v in doc['entries'].values() for p in v['proofs'])
-    assert set(doc['entries']) >= {'rollup1741', 'eddsa4096', 'rollup1024', 'rollup1853'} and doc['entries']['rollup1853']['log2_domain'] == 26
+    assert set(doc['entries']) >= {'rollup1741', 'eddsa4096', 'rollup1024', 'rollup1853', 'synthetic2p27'} and doc['entries']['rollup1853']['log2_domain'] == 26
+    assert doc['entries']['synthetic2p27']['rows'] == 1 << 27 and all(doc['entries']['synthetic2p27']['gpu_equal'])
     inst_zs = bench.load_rollup_instance()[1]
     import hashlib
     same_set = hashlib.sha256(np.ascontiguousarray(inst_zs).tobytes()).hexdigest() == e['witness_set_sha256']

@@ -1,4 +1,6 @@
-"""BASELINE.json's two large configurations at their FULL sizes on one GPU, where no CPU oracle can follow: the checks are
+"""BASELINE.json's two large configurations at their FULL sizes on one GPU.  Since round 6 the ORACLE's proof bytes at these sizes are committed
+data (tests/golden/fullsize_digests.json: minutes of 16 host threads per proof on the GPU box, tests/golden/make_fullsize_digests.py) and every
+route below is compared with them; beside that the checks of rounds 1-5 remain:
 the Groth16 pairing equation (oracle/bn254_ref.py verifier -- an independent big-int implementation), a negative control
 (one witness element changed: the proof must be rejected), and byte equality between independent routes to the same
 proof (single GPU vs ONE fk_multi_prove_r1cs call on 8 ranks with sharded keys and the distributed quotient).
@@ -67,6 +69,13 @@ def test_config4_2p27_rows_with_g2_pairing_checked(ctx):
         proof = ctx.prove_witness_dev(key, dr, d_z, r, s)
         assert _verifies(bench, vk, z[1:r1cs.num_input], proof)
         assert ctx.prove_witness_dev(key, dr, d_z, r, s).tobytes() == proof.tobytes()       # deterministic
+        # ... and equal, byte for byte, to the ORACLE's proof of this very system (tests/golden/fullsize_digests.json, entry synthetic2p27:
+        # oracle/groth16_oracle.c, 16 host threads, 326 s; made by tests/golden/make_fullsize_digests.py --only synthetic2p27)
+        dg = _digest('synthetic2p%d' % log2n)
+        assert dg is not None and dg['rows'] == 1 << log2n and dg['num_aux'] == r1cs.num_aux
+        import hashlib
+        assert hashlib.sha256(np.asarray(vk['ic'], np.uint8).tobytes()).hexdigest() == dg['vk_ic_sha256']
+        assert proof.tobytes().hex() == dg['proofs'][0], 'the 2^27 proof differs from the oracle\'s bytes'
         # negative control: one dense witness element changed -> the constraint system is violated -> must be rejected
         j = r1cs.num_input + r1cs.num_aux - 12345       # an output of a product gate
         bad = z[j].copy(); bad[0] ^= np.uint64(2)
